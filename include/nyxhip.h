@@ -1,0 +1,212 @@
+/*
+ * nyxhip.h -- C ABI of the MI355X-native per-ROI feature reducer.
+ *
+ * This is the drop-in boundary for the reference's ROI-batch reduce step:
+ *
+ *   reduce_trivial_rois_manual(std::vector<int>& Pending, Environment& env)
+ *       /root/reference/src/nyx/reduce_trivial_rois.cpp:772-795
+ *   reduce_trivial_2d(...)                       reduce_trivial_rois.cpp:62-413
+ *   runParallel(F::reduce, nThr, ...)            src/nyx/parallel.h:23-42
+ *
+ * i.e. "given a batch of in-RAM ROIs (pixel cloud + bounding box + min/max),
+ * fill every ROI's feature values for the enabled feature families".
+ * The reference keeps ROIs as `LR` records (src/nyx/roi_cache.h:31-84) holding
+ * an AoS `Pixel2{long x; long y; uint inten}` cloud (features/pixel.h:52-61) and a
+ * dense bounding-box matrix (features/image_matrix.h:284-304); here the same
+ * information crosses the boundary as flat SoA arrays (plain pointers + sizes).
+ *
+ * Everything below is plain C: no C++ types, no torch types.  All calls return
+ * an int status (NYXHIP_OK == 0); nyxhip_last_error() gives the message.
+ * Degenerate ROIs are not errors: they produce the reference's soft-NaN
+ * sentinel values (reference: glcm.cpp:27-95, intensity.cpp:121-122).
+ */
+#ifndef NYXHIP_H
+#define NYXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NYXHIP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    NYXHIP_OK = 0,
+    NYXHIP_ERR_INVALID_ARG = 1,   /* null pointer, bad size, bad mask          */
+    NYXHIP_ERR_NO_DEVICE = 2,     /* HIP runtime / GPU not available           */
+    NYXHIP_ERR_HIP = 3,           /* a HIP call failed (message has detail)    */
+    NYXHIP_ERR_UNSUPPORTED = 4,   /* setting outside what the kernels cover    */
+    NYXHIP_ERR_ROI_TOO_LARGE = 5  /* ROI exceeds the LDS-resident capacity     */
+};
+
+/* ---- feature families (bitmask) -----------------------------------------
+ * One bit per reference FeatureMethod class on the hot path; replaces the
+ * `if (F::required(fs)) runParallel(F::reduce ...)` ladder of
+ * reduce_trivial_rois.cpp:65-70 (intensity), :199-204 (GLCM), :207-212 (GLRLM),
+ * :223-228 (GLSZM), :247-252 (NGTDM), :364-369 (Gabor), :373-378 (Zernike). */
+enum {
+    NYXHIP_FAM_INTENSITY = 1u << 0, /* PixelIntensityFeatures, 36 columns      */
+    NYXHIP_FAM_GLCM      = 1u << 1, /* GLCMFeature, 30*n_angles + 29 columns   */
+    NYXHIP_FAM_GLRLM     = 1u << 2, /* GLRLMFeature, 16*4 + 16 columns         */
+    NYXHIP_FAM_GLSZM     = 1u << 3, /* GLSZMFeature, 16 columns                */
+    NYXHIP_FAM_NGTDM     = 1u << 4, /* NGTDMFeature, 5 columns                 */
+    NYXHIP_FAM_GABOR     = 1u << 5, /* GaborFeature, n_gabor_filters columns   */
+    NYXHIP_FAM_ZERNIKE   = 1u << 6, /* ZernikeFeature, 30 columns              */
+    NYXHIP_FAM_ALL       = 0x7Fu
+};
+
+#define NYXHIP_MAX_GLCM_ANGLES 4
+#define NYXHIP_MAX_GABOR_FILTERS 16
+
+/* ---- settings ------------------------------------------------------------
+ * Mirrors the slots of `Fsettings` indexed by `NyxSetting`
+ * (src/nyx/feature_settings.h:17-54) as filled by
+ * Environment::compile_feature_settings (src/nyx/env_features.cpp:713-736),
+ * plus the class-static knobs the reference keeps process-global:
+ * GLCMFeature::angles / symmetric_glcm (features/glcm.cpp:8-9) and the Gabor
+ * bank (features/gabor.cpp:14-25). */
+typedef struct nyxhip_settings {
+    double soft_nan;          /* NyxSetting::SOFTNAN  (default 0.0)            */
+    double tiny;              /* NyxSetting::TINY     (default 1e-10)          */
+    int32_t grey_depth;       /* NyxSetting::GREYDEPTH: >0 matlab binning with
+                                 that many levels, <0 radiomics binning with
+                                 |n| bins (texture_feature.h:100-102); also
+                                 the intensity-histogram bin count
+                                 (intensity.cpp:125)                           */
+    int32_t ibsi;             /* NyxSetting::IBSI: no binning when non-zero    */
+    int32_t glcm_grey_depth;  /* NyxSetting::GLCM_GREYDEPTH (degeneracy guard
+                                 only, glcm.cpp:23-29)                         */
+    int32_t glcm_offset;      /* NyxSetting::GLCM_OFFSET (default 1)           */
+    int32_t glcm_n_angles;    /* GLCMFeature::angles.size()                    */
+    int32_t glcm_angles[NYXHIP_MAX_GLCM_ANGLES]; /* subset of {0,45,90,135}    */
+    int32_t glcm_symmetric;   /* GLCMFeature::symmetric_glcm                   */
+    /* Gabor bank (features/gabor.cpp:14-25) */
+    double gabor_gamma, gabor_sig2lam, gabor_f0lp, gabor_graythr;
+    int32_t gabor_kersize;
+    int32_t gabor_n_filters;
+    double gabor_f0[NYXHIP_MAX_GABOR_FILTERS];
+    double gabor_theta[NYXHIP_MAX_GABOR_FILTERS];   /* radians */
+} nyxhip_settings;
+
+/* Fills `s` with the reference defaults (environment.cpp / env_features.cpp:
+ * SOFTNAN 0.0, TINY 1e-10, grey depth 64, IBSI off, GLCM offset 1, angles
+ * {0,45,90,135}, asymmetric; Gabor gamma .1, sig2lam .8, n 16, f0LP .1,
+ * thr .025, bank {(4,0),(16,pi/4),(32,pi/2),(64,3pi/4)}). */
+void nyxhip_default_settings(nyxhip_settings* s);
+
+/* ---- a batch of ROIs -------------------------------------------------------
+ * SoA restatement of `std::vector<int> labels` + `unordered_map<int,LR>`
+ * (the two containers `functype` receives, parallel.h:13).  ROI r owns pixels
+ * [px_offset[r], px_offset[r+1]).  Coordinates are relative to the ROI's
+ * bounding-box origin (LR::aabb), so they fit uint16 for every in-RAM
+ * ("trivial") ROI.  Pixel order inside an ROI is the scan order of the caller
+ * (column-major for the in-memory API, phase2_2d.cpp:655-656); no kernel
+ * result depends on it beyond floating-point summation order.
+ *
+ * `memory` says where ALL pointers of the struct live. */
+enum { NYXHIP_MEM_HOST = 0, NYXHIP_MEM_DEVICE = 1 };
+
+typedef struct nyxhip_batch {
+    uint64_t n_roi;
+    const uint32_t* roi_label;   /* [n_roi]   LR::label (informational)        */
+    const uint64_t* px_offset;   /* [n_roi+1] CSR offsets into x/y/inten       */
+    const uint16_t* x;           /* [n_px]    Pixel2::x - aabb.xmin            */
+    const uint16_t* y;           /* [n_px]    Pixel2::y - aabb.ymin            */
+    const uint32_t* inten;       /* [n_px]    Pixel2::inten                    */
+    const uint32_t* bbox_w;      /* [n_roi]   aabb width                       */
+    const uint32_t* bbox_h;      /* [n_roi]   aabb height                      */
+    const uint32_t* min_inten;   /* [n_roi]   LR::aux_min                      */
+    const uint32_t* max_inten;   /* [n_roi]   LR::aux_max                      */
+    const double* slide_min;     /* [n_roi] or NULL: SlideProps::min_preroi_inten
+                                    of the ROI's slide (intensity.cpp:72-77);
+                                    NULL = slide_idx < 0 (feature left at 0)   */
+    const double* slide_max;     /* [n_roi] or NULL                            */
+    int32_t memory;              /* NYXHIP_MEM_HOST | NYXHIP_MEM_DEVICE        */
+} nyxhip_batch;
+
+typedef struct nyxhip_ctx nyxhip_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int nyxhip_abi_version(void);
+
+/* Binds a context to one GPU (one context per GPU / per process rank).  Fails
+ * with NYXHIP_ERR_NO_DEVICE when no HIP device exists: there is no CPU
+ * fallback behind this ABI. */
+int nyxhip_init(int device, nyxhip_ctx** out_ctx);
+void nyxhip_destroy(nyxhip_ctx* ctx);
+const char* nyxhip_last_error(const nyxhip_ctx* ctx);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own stream.  NULL restores the context stream. */
+int nyxhip_set_stream(nyxhip_ctx* ctx, void* hip_stream);
+
+/* ---- output-table layout ----------------------------------------------------
+ * Columns follow `Feature2D` enum order with the angle / index expansion of
+ * save_features_2_buffer (src/nyx/output_2_buffer.cpp:303-584): angled GLCM and
+ * GLRLM features expand to `_0,_45,_90,_135`, GABOR to `_i`, ZERNIKE2D to `_Z i`.
+ * Column names are the reference's user-facing feature names. */
+int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s);
+/* Writes the NUL-terminated name of column `col` into buf; returns NYXHIP_OK or
+ * NYXHIP_ERR_INVALID_ARG. */
+int nyxhip_column_name(uint32_t family_mask, const nyxhip_settings* s, int col,
+                       char* buf, size_t buf_len);
+
+/* ---- the hot path -----------------------------------------------------------
+ * Replaces reduce_trivial_rois_manual() for the families in `family_mask`.
+ * out_table is row-major [n_roi x out_ld] doubles (out_ld >= n_columns), in host
+ * memory when batch->memory == NYXHIP_MEM_HOST, in device memory otherwise.
+ * Synchronous: results are complete on return.  NaN/inf are NOT replaced here;
+ * that is the table writer's job in the reference too (force_finite_number,
+ * helpers/helpers.h:376-382) -- see nyxhip_finalize_table(). */
+int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* batch,
+                           uint32_t family_mask, const nyxhip_settings* s,
+                           double* out_table, size_t out_ld);
+
+/* Asynchronous form for device-resident batches: enqueues the kernels on the
+ * context's stream and returns; call nyxhip_sync() (or synchronise the stream
+ * given to nyxhip_set_stream) before reading out_table. */
+int nyxhip_featurize_batch_async(nyxhip_ctx* ctx, const nyxhip_batch* batch,
+                                 uint32_t family_mask, const nyxhip_settings* s,
+                                 double* out_table, size_t out_ld);
+int nyxhip_sync(nyxhip_ctx* ctx);
+
+/* Host-side NaN/inf -> soft_nan replacement over a host table, as
+ * save_features_2_buffer does per value (output_2_buffer.cpp:296,...). */
+void nyxhip_finalize_table(double* table, size_t n_rows, size_t n_cols, size_t ld,
+                           double soft_nan);
+
+/* ---- fused tile path ("next" row: phases 1-2 + reduce on the device) ---------
+ * Replaces gatherRoisMetricsInMemory (src/nyx/phase1.cpp:373-409) +
+ * scanTrivialRoisInMemory (src/nyx/phase2_2d.cpp:637-684) +
+ * allocateTrivialRoisBuffers (:427-465) + reduce_trivial_rois_manual for one
+ * intensity/label tile pair already in device or host memory.
+ *
+ * Pass 1 (nyxhip_tile_scan): per-label area / min / max / bounding box.
+ *   Returns the number of distinct non-zero labels in *n_roi_out; labels come
+ *   back sorted ascending (row order of save_features_2_buffer).
+ * Pass 2 (nyxhip_featurize_tile): one workgroup per ROI reads its bounding-box
+ *   window of the tile; rows of out_table follow ascending label.
+ * `max_label` bounds the label values present (labels are dense small ints in
+ * segmentation masks); the scan uses a [max_label+1] device table. */
+int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label,
+                          uint32_t width, uint32_t height, int32_t memory,
+                          uint32_t max_label, uint32_t family_mask,
+                          const nyxhip_settings* s,
+                          uint32_t* out_labels, uint64_t max_rows,
+                          double* out_table, size_t out_ld, uint64_t* n_roi_out);
+
+/* ---- measurement hooks -------------------------------------------------------
+ * Average device time (ms) of the dominant kernel over the launches issued since
+ * the last nyxhip_timing_reset(), measured with hipEvents recorded on the launch
+ * stream around each kernel.  Used by bench.py for `roofline.achieved`. */
+int nyxhip_timing_enable(nyxhip_ctx* ctx, int on);
+int nyxhip_timing_reset(nyxhip_ctx* ctx);
+int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NYXHIP_H */

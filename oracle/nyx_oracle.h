@@ -1,0 +1,39 @@
+/*
+ * nyx_oracle.h -- TEST INFRASTRUCTURE (see nyx_oracle.c header).
+ * Entry points of the plain-C CPU restatement of the reference hot path.
+ */
+#ifndef NYX_ORACLE_H
+#define NYX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#include "../include/nyxhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* features/intensity.cpp:57-192 -> out[36] in Feature2D order */
+void nyxo_intensity(const uint32_t* inten, uint64_t n_px, uint32_t aux_min, uint32_t aux_max,
+                    int has_slide, double slide_min, double slide_max, int n_grey_bins,
+                    double* out);
+
+/* features/texture_feature.h:77-98 bin_pixel */
+uint32_t nyxo_bin_pixel(uint32_t x, uint32_t mn, uint32_t mx, int greybin_info);
+
+/* features/image_matrix.h:284-304; caller frees */
+uint32_t* nyxo_dense_from_cloud(const uint16_t* x, const uint16_t* y, const uint32_t* inten,
+                                uint64_t n_px, uint32_t w, uint32_t h);
+
+/* features/glcm.cpp:16-100,143-208 -> out[30*n_angles + 29] */
+void nyxo_glcm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+               const nyxhip_settings* s, double* out);
+
+int nyxo_n_columns(uint32_t mask, const nyxhip_settings* s);
+
+/* Host-memory batch, same argument meaning as nyxhip_featurize_batch. */
+int nyxo_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
+                         double* out, size_t ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
