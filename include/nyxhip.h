@@ -125,6 +125,12 @@ typedef struct nyxhip_batch {
                                     NULL = slide_idx < 0 (feature left at 0)   */
     const double* slide_max;     /* [n_roi] or NULL                            */
     int32_t memory;              /* NYXHIP_MEM_HOST | NYXHIP_MEM_DEVICE        */
+    /* Batch extrema, used to size the per-workgroup LDS carve-out.  The reference
+     * tracks the same quantities per dataset (Dataset::dataset_max_roi_area / _w /
+     * _h, src/nyx/dataset.h:12-18).  0 = unknown: the library derives them (for a
+     * device batch that costs one small device->host copy and a stream sync). */
+    uint32_t max_px;             /* max over ROIs of px_offset[r+1]-px_offset[r] */
+    uint32_t max_bbox_area;      /* max over ROIs of bbox_w[r]*bbox_h[r]        */
 } nyxhip_batch;
 
 typedef struct nyxhip_ctx nyxhip_ctx;

@@ -73,6 +73,8 @@ class Batch(C.Structure):
         ("slide_min", C.c_void_p),
         ("slide_max", C.c_void_p),
         ("memory", C.c_int32),
+        ("max_px", C.c_uint32),
+        ("max_bbox_area", C.c_uint32),
     ]
 
 
@@ -155,6 +157,8 @@ class HostBatch:
         b.slide_min = self.slide_min.ctypes.data if self.slide_min is not None else None
         b.slide_max = self.slide_max.ctypes.data if self.slide_max is not None else None
         b.memory = MEM_HOST
+        b.max_px = int(np.diff(self.px_offset.astype(np.int64)).max()) if self.n_roi else 0
+        b.max_bbox_area = int((self.bbox_w.astype(np.int64) * self.bbox_h.astype(np.int64)).max()) if self.n_roi else 0
         return b
 
 

@@ -1,0 +1,157 @@
+"""Loader and thin Python face of the C ABI (``include/nyxhip.h``).
+
+The HIP library is the product: if ``libnyxhip.so`` is missing or no GPU is
+present this module raises -- there is no CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnyxhip.so")
+
+# every symbol include/nyxhip.h declares
+ABI_SYMBOLS = [
+    "nyxhip_abi_version", "nyxhip_default_settings", "nyxhip_init", "nyxhip_destroy", "nyxhip_last_error",
+    "nyxhip_set_stream", "nyxhip_n_columns", "nyxhip_column_name", "nyxhip_featurize_batch",
+    "nyxhip_featurize_batch_async", "nyxhip_sync", "nyxhip_finalize_table", "nyxhip_featurize_tile",
+    "nyxhip_timing_enable", "nyxhip_timing_reset", "nyxhip_timing_get",
+]
+
+
+class NyxHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nyxhip error {code} ({_abi.ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen()s libnyxhip.so and declares the prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C nyxus_amd/csrc).  The MI355X path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.nyxhip_abi_version.restype = C.c_int
+    lib.nyxhip_default_settings.argtypes = [P(_abi.Settings)]
+    lib.nyxhip_default_settings.restype = None
+    lib.nyxhip_init.argtypes = [C.c_int, P(C.c_void_p)]
+    lib.nyxhip_init.restype = C.c_int
+    lib.nyxhip_destroy.argtypes = [C.c_void_p]
+    lib.nyxhip_destroy.restype = None
+    lib.nyxhip_last_error.argtypes = [C.c_void_p]
+    lib.nyxhip_last_error.restype = C.c_char_p
+    lib.nyxhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.nyxhip_set_stream.restype = C.c_int
+    lib.nyxhip_n_columns.argtypes = [C.c_uint32, P(_abi.Settings)]
+    lib.nyxhip_n_columns.restype = C.c_int
+    lib.nyxhip_column_name.argtypes = [C.c_uint32, P(_abi.Settings), C.c_int, C.c_char_p, C.c_size_t]
+    lib.nyxhip_column_name.restype = C.c_int
+    for name in ("nyxhip_featurize_batch", "nyxhip_featurize_batch_async"):
+        f = getattr(lib, name)
+        f.argtypes = [C.c_void_p, P(_abi.Batch), C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_size_t]
+        f.restype = C.c_int
+    lib.nyxhip_sync.argtypes = [C.c_void_p]
+    lib.nyxhip_sync.restype = C.c_int
+    lib.nyxhip_finalize_table.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double]
+    lib.nyxhip_finalize_table.restype = None
+    lib.nyxhip_featurize_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,
+                                          C.c_uint32, C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_uint64,
+                                          C.c_void_p, C.c_size_t, P(C.c_uint64)]
+    lib.nyxhip_featurize_tile.restype = C.c_int
+    lib.nyxhip_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.nyxhip_timing_enable.restype = C.c_int
+    lib.nyxhip_timing_reset.argtypes = [C.c_void_p]
+    lib.nyxhip_timing_reset.restype = C.c_int
+    lib.nyxhip_timing_get.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
+    lib.nyxhip_timing_get.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def column_names(mask: int, s: _abi.Settings) -> List[str]:
+    lib = load()
+    n = lib.nyxhip_n_columns(mask, C.byref(s))
+    buf = C.create_string_buffer(128)
+    out = []
+    for i in range(n):
+        rc = lib.nyxhip_column_name(mask, C.byref(s), i, buf, 128)
+        if rc != 0:
+            raise NyxHipError(rc, f"column {i}")
+        out.append(buf.value.decode())
+    return out
+
+
+class Context:
+    """One ``nyxhip_ctx`` bound to one GPU (one per process rank)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.nyxhip_init(device, C.byref(h))
+        if rc != 0:
+            raise NyxHipError(rc, (self._lib.nyxhip_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nyxhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise NyxHipError(rc, (self._lib.nyxhip_last_error(self._h) or b"").decode())
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._check(self._lib.nyxhip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def n_columns(self, mask: int, s: _abi.Settings) -> int:
+        return self._lib.nyxhip_n_columns(mask, C.byref(s))
+
+    def featurize_host(self, batch: _abi.HostBatch, mask: int, s: _abi.Settings) -> np.ndarray:
+        """Host arrays in, host table out (synchronous)."""
+        ncol = self.n_columns(mask, s)
+        out = np.empty((batch.n_roi, ncol), np.float64)
+        cb = batch.c_struct()
+        self._check(self._lib.nyxhip_featurize_batch(self._h, C.byref(cb), mask, C.byref(s), out.ctypes.data, ncol))
+        return out
+
+    def featurize_device_async(self, cb: _abi.Batch, mask: int, s: _abi.Settings, out_ptr: int, ld: int):
+        """Device pointers in ``cb``; enqueues the kernel on the context's stream."""
+        self._check(self._lib.nyxhip_featurize_batch_async(self._h, C.byref(cb), mask, C.byref(s), C.c_void_p(out_ptr), ld))
+
+    def sync(self):
+        self._check(self._lib.nyxhip_sync(self._h))
+
+    def timing(self, on: bool):
+        self._check(self._lib.nyxhip_timing_enable(self._h, 1 if on else 0))
+        self._check(self._lib.nyxhip_timing_reset(self._h))
+
+    def timing_reset(self):
+        self._check(self._lib.nyxhip_timing_reset(self._h))
+
+    def timing_get(self):
+        ms = C.c_double()
+        n = C.c_uint64()
+        self._check(self._lib.nyxhip_timing_get(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

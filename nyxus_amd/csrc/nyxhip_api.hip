@@ -1,0 +1,521 @@
+// nyxhip_api.hip -- the C ABI of include/nyxhip.h: context, staging, launch, errors.
+//
+// Host-side counterpart of reduce_trivial_rois_manual()
+// (/root/reference/src/nyx/reduce_trivial_rois.cpp:772-795): instead of fanning a
+// label vector out over std::async threads per feature family (parallel.h:23-42),
+// one fused kernel launch covers every requested family for the whole ROI batch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nyxhip.h"
+#include "roi_kernel.h"
+
+using namespace nyxhip;
+
+struct nyxhip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t user_stream = nullptr;
+    bool use_user_stream = false;
+    int* d_status = nullptr;
+    uint32_t* d_extrema = nullptr; // [2]
+    std::string err;
+    // grow-only device staging for host-memory batches
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    hipStream_t stream() const { return use_user_stream ? user_stream : own_stream; }
+};
+
+namespace {
+
+thread_local std::string g_init_error;
+
+int fail(nyxhip_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_init_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(ctx, NYXHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- column catalogue (Feature2D enum order; names = user-facing feature names,
+// src/nyx/featureset.cpp UserFacingFeatureNames) -------------------------------------
+const char* kIntensityNames[kIntensityCols] = {
+    "COV", "COVERED_IMAGE_INTENSITY_RANGE", "ENERGY", "ENTROPY", "EXCESS_KURTOSIS", "HYPERFLATNESS",
+    "HYPERSKEWNESS", "INTEGRATED_INTENSITY", "INTERQUARTILE_RANGE", "KURTOSIS", "MAX", "MEAN",
+    "MEAN_ABSOLUTE_DEVIATION", "MEDIAN", "MEDIAN_ABSOLUTE_DEVIATION", "MIN", "MODE", "P01", "P10", "P25",
+    "P75", "P90", "P99", "QCOD", "RANGE", "ROBUST_MEAN", "ROBUST_MEAN_ABSOLUTE_DEVIATION",
+    "ROOT_MEAN_SQUARED", "SKEWNESS", "STANDARD_DEVIATION", "STANDARD_DEVIATION_BIASED", "STANDARD_ERROR",
+    "VARIANCE", "VARIANCE_BIASED", "UNIFORMITY", "UNIFORMITY_PIU"};
+const char* kGlcmNames[kGlcmAngled] = {
+    "GLCM_ASM", "GLCM_ACOR", "GLCM_CLUPROM", "GLCM_CLUSHADE", "GLCM_CLUTEND", "GLCM_CONTRAST",
+    "GLCM_CORRELATION", "GLCM_DIFAVE", "GLCM_DIFENTRO", "GLCM_DIFVAR", "GLCM_DIS", "GLCM_ENERGY",
+    "GLCM_ENTROPY", "GLCM_HOM1", "GLCM_HOM2", "GLCM_ID", "GLCM_IDN", "GLCM_IDM", "GLCM_IDMN",
+    "GLCM_INFOMEAS1", "GLCM_INFOMEAS2", "GLCM_IV", "GLCM_JAVE", "GLCM_JE", "GLCM_JMAX", "GLCM_JVAR",
+    "GLCM_SUMAVERAGE", "GLCM_SUMENTROPY", "GLCM_SUMVARIANCE", "GLCM_VARIANCE"};
+const char* kGlcmAveNames[kGlcmAve] = {
+    "GLCM_ASM_AVE", "GLCM_ACOR_AVE", "GLCM_CLUPROM_AVE", "GLCM_CLUSHADE_AVE", "GLCM_CLUTEND_AVE",
+    "GLCM_CONTRAST_AVE", "GLCM_CORRELATION_AVE", "GLCM_DIFAVE_AVE", "GLCM_DIFENTRO_AVE", "GLCM_DIFVAR_AVE",
+    "GLCM_DIS_AVE", "GLCM_ENERGY_AVE", "GLCM_ENTROPY_AVE", "GLCM_HOM1_AVE", "GLCM_ID_AVE", "GLCM_IDN_AVE",
+    "GLCM_IDM_AVE", "GLCM_IDMN_AVE", "GLCM_IV_AVE", "GLCM_JAVE_AVE", "GLCM_JE_AVE", "GLCM_INFOMEAS1_AVE",
+    "GLCM_INFOMEAS2_AVE", "GLCM_VARIANCE_AVE", "GLCM_JMAX_AVE", "GLCM_JVAR_AVE", "GLCM_SUMAVERAGE_AVE",
+    "GLCM_SUMENTROPY_AVE", "GLCM_SUMVARIANCE_AVE"};
+
+// families the kernels cover so far
+constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM;
+
+bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
+{
+    if (!s) { why = "settings is NULL"; return false; }
+    if (mask & NYXHIP_FAM_INTENSITY) {
+        if (s->grey_depth == 0) { why = "grey_depth must be non-zero (histogram bin count)"; return false; }
+    }
+    if (mask & NYXHIP_FAM_GLCM) {
+        if (s->glcm_n_angles < 0 || s->glcm_n_angles > NYXHIP_MAX_GLCM_ANGLES) { why = "glcm_n_angles out of range"; return false; }
+        for (int i = 0; i < s->glcm_n_angles; i++) {
+            int a = s->glcm_angles[i];
+            if (a != 0 && a != 45 && a != 90 && a != 135) { why = "unsupported GLCM angle (glcm.cpp:252-254)"; return false; }
+        }
+        if (s->glcm_offset < 0) { why = "glcm_offset must be >= 0"; return false; }
+    }
+    return true;
+}
+
+std::vector<std::string> column_names(uint32_t mask, const nyxhip_settings* s)
+{
+    std::vector<std::string> v;
+    if (mask & NYXHIP_FAM_INTENSITY)
+        for (auto n : kIntensityNames) v.push_back(n);
+    if (mask & NYXHIP_FAM_GLCM) {
+        for (auto n : kGlcmNames)
+            for (int a = 0; a < s->glcm_n_angles; a++)
+                v.push_back(std::string(n) + "_" + std::to_string(s->glcm_angles[a])); // output_2_buffer.cpp:336-343
+        for (auto n : kGlcmAveNames) v.push_back(n);
+    }
+    return v;
+}
+
+uint32_t pow2ceil(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// Carves the workgroup's LDS for one launch.  Returns false when the batch extrema
+// do not fit the 160 KiB of a CU.
+bool make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
+                 LdsLayout& L, std::string& why)
+{
+    memset(&L, 0, sizeof(L));
+    const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
+    uint32_t off = 0;
+    L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
+    L.red = off; off = align16(off + 8u * kWaves * 8);
+    L.stat = off; off = align16(off + 8u * 16);
+    L.lb100 = off; off = align16(off + 4u * 104);
+    uint32_t n_hist = (uint32_t)abs(s->grey_depth);
+    L.lbc = off; off = align16(off + 4u * (do_int ? n_hist + 8 : 8));
+    L.sort_cap = do_int ? pow2ceil(max_px ? max_px : 1) : 0;
+    L.val = off; off = align16(off + 4u * L.sort_cap);
+    L.dense_cap = do_glcm ? max_area : 0;
+    L.dense = off; off = align16(off + 2u * L.dense_cap);
+    if (do_glcm) {
+        const int greyInfo = s->ibsi ? 0 : s->grey_depth;
+        L.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0;
+        L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 8));
+        const size_t cap = roi_features_max_lds();
+        auto need = [&](uint32_t ng, uint32_t app) -> size_t {
+            return (size_t)off + align16(4u * app * ng * ng) + 8ull * (25ull * ng + 128);
+        };
+        uint32_t ng;
+        if (greyInfo != 0) {
+            ng = (uint32_t)abs(greyInfo);
+            if (need(ng, 1) > cap) { why = "GLCM grey depth too large for the LDS-resident co-occurrence matrix"; return false; }
+        } else {
+            // IBSI: matrix order = max intensity (glcm.cpp:412-419), unknown before the scan;
+            // reserve the largest order that fits, up to 128.
+            ng = 128;
+            while (ng > 8 && need(ng, 1) > cap) ng >>= 1;
+        }
+        uint32_t app = 4;
+        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || need(ng, app) > cap)) app >>= 1;
+        L.ng_cap = ng;
+        L.app = app;
+        L.P = off; off = align16(off + 4u * app * ng * ng);
+        L.gscr = off; off = align16(off + 8u * (25u * ng + 128));
+    }
+    L.total = off;
+    if (L.total > roi_features_max_lds()) {
+        why = "ROI too large for the LDS-resident path (" + std::to_string(L.total) + " B of LDS needed; max_px=" +
+              std::to_string(max_px) + ", max_bbox_area=" + std::to_string(max_area) + ")";
+        return false;
+    }
+    return true;
+}
+
+__global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
+                                     uint32_t* out2)
+{
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint32_t n = 0, a = 0;
+    if (i < n_roi) {
+        n = (uint32_t)(px_offset[i + 1] - px_offset[i]);
+        a = bw[i] * bh[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64);
+        n = on > n ? on : n;
+        a = oa > a ? oa : a;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out2[0], n);
+        atomicMax(&out2[1], a);
+    }
+}
+
+int ensure_stage(nyxhip_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes)
+        return NYXHIP_OK;
+    if (ctx->d_stage)
+        HIP_TRY(ctx, hipFree(ctx->d_stage));
+    ctx->d_stage = nullptr;
+    ctx->stage_bytes = 0;
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    HIP_TRY(ctx, hipMalloc(&ctx->d_stage, want));
+    ctx->stage_bytes = want;
+    return NYXHIP_OK;
+}
+
+int check_status(nyxhip_ctx* ctx)
+{
+    int st = 0;
+    HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        int zero = 0;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_status, &zero, sizeof(int), hipMemcpyHostToDevice));
+        if (st == NYXHIP_ERR_ROI_TOO_LARGE)
+            return fail(ctx, st, "an ROI exceeds the LDS-resident capacity declared by the batch extrema");
+        if (st == NYXHIP_ERR_UNSUPPORTED)
+            return fail(ctx, st, "GLCM matrix order exceeds the LDS-resident capacity (IBSI mode with large intensities?)");
+        return fail(ctx, st, "device-side error " + std::to_string(st));
+    }
+    return NYXHIP_OK;
+}
+
+// Launch on device-resident arrays.
+int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
+                  size_t ld, uint32_t max_px, uint32_t max_area)
+{
+    std::string why;
+    const int n_cols = nyxhip_n_columns(mask, s);
+    RoiArgs a;
+    memset(&a, 0, sizeof(a));
+    if (!make_layout(mask, s, n_cols, max_px, max_area, a.L, why))
+        return fail(ctx, why.find("grey depth") != std::string::npos ? NYXHIP_ERR_UNSUPPORTED : NYXHIP_ERR_ROI_TOO_LARGE, why);
+    a.n_roi = b->n_roi;
+    a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
+    a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
+    a.slide_min = b->slide_min; a.slide_max = b->slide_max;
+    a.out = d_out; a.ld = ld; a.status = ctx->d_status;
+    a.mask = mask; a.n_cols = n_cols;
+    int c = 0;
+    a.col_intensity = a.col_glcm = -1;
+    if (mask & NYXHIP_FAM_INTENSITY) { a.col_intensity = c; c += kIntensityCols; }
+    if (mask & NYXHIP_FAM_GLCM) { a.col_glcm = c; c += kGlcmAngled * s->glcm_n_angles + kGlcmAve; }
+    a.soft_nan = s->soft_nan;
+    a.grey_depth = s->grey_depth; a.ibsi = s->ibsi; a.glcm_grey_depth = s->glcm_grey_depth;
+    a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
+    for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
+    a.n_hist = abs(s->grey_depth);
+
+    hipStream_t st = ctx->stream();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        if (ctx->ev_used == ctx->ev.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(ctx, hipEventCreate(&x));
+            HIP_TRY(ctx, hipEventCreate(&y));
+            ctx->ev.push_back({x, y});
+        }
+        e0 = ctx->ev[ctx->ev_used].first;
+        e1 = ctx->ev[ctx->ev_used].second;
+        ctx->ev_used++;
+        HIP_TRY(ctx, hipEventRecord(e0, st));
+    }
+    int rc = launch_roi_features(a, st);
+    if (rc != 0)
+        return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    if (ctx->timing)
+        HIP_TRY(ctx, hipEventRecord(e1, st));
+    return NYXHIP_OK;
+}
+
+int validate(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* out, size_t ld)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    if (!b || !s || !out) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null batch / settings / out_table");
+    if (mask == 0 || (mask & ~NYXHIP_FAM_ALL)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
+    if (mask & ~kImplemented)
+        return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "requested feature family is not implemented by the HIP path yet "
+                    "(implemented: INTENSITY, GLCM)");
+    std::string why;
+    if (!settings_ok(s, mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
+    if (b->n_roi && (!b->px_offset || !b->x || !b->y || !b->inten || !b->bbox_w || !b->bbox_h || !b->min_inten || !b->max_inten))
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "batch has null array pointers");
+    if ((b->slide_min == nullptr) != (b->slide_max == nullptr))
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "slide_min and slide_max must both be given or both NULL");
+    if ((int)ld < nyxhip_n_columns(mask, s)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "out_ld smaller than the column count");
+    if (b->n_roi > 0x7FFFFFFFull) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "too many ROIs in one batch");
+    return NYXHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int nyxhip_abi_version(void) { return NYXHIP_ABI_VERSION; }
+
+void nyxhip_default_settings(nyxhip_settings* s)
+{
+    if (!s) return;
+    memset(s, 0, sizeof(*s));
+    s->soft_nan = 0.0;                 // cli_result_options.h:75
+    s->tiny = 1e-10;
+    s->grey_depth = 64;                // environment: coarse gray depth default
+    s->ibsi = 0;
+    s->glcm_grey_depth = 64;
+    s->glcm_offset = 1;                // env_features.cpp:727
+    s->glcm_n_angles = 4;              // glcm.cpp:9
+    s->glcm_angles[0] = 0; s->glcm_angles[1] = 45; s->glcm_angles[2] = 90; s->glcm_angles[3] = 135;
+    s->glcm_symmetric = 0;             // glcm.cpp:8
+    s->gabor_gamma = 0.1; s->gabor_sig2lam = 0.8; s->gabor_kersize = 16; s->gabor_f0lp = 0.1; s->gabor_graythr = 0.025;
+    s->gabor_n_filters = 4;            // gabor.cpp:19-25, consumed as (first = f0, second = theta) at :107-110
+    const double pi4 = 0.78539816339744830962;
+    const double f0[4] = {0.0, pi4, 2 * pi4, pi4 * 3.0}, th[4] = {4.0, 16.0, 32.0, 64.0};
+    for (int i = 0; i < 4; i++) { s->gabor_f0[i] = f0[i]; s->gabor_theta[i] = th[i]; }
+}
+
+int nyxhip_init(int device, nyxhip_ctx** out_ctx)
+{
+    if (!out_ctx) return NYXHIP_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, NYXHIP_ERR_NO_DEVICE, "no HIP device available: the MI355X path has no CPU fallback");
+    if (device < 0 || device >= n)
+        return fail(nullptr, NYXHIP_ERR_INVALID_ARG, "device index out of range");
+    nyxhip_ctx* ctx = new nyxhip_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_extrema, 2 * sizeof(uint32_t)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, NYXHIP_ERR_HIP, "failed to create the device context");
+    }
+    *out_ctx = ctx;
+    return NYXHIP_OK;
+}
+
+void nyxhip_destroy(nyxhip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
+    for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
+    delete ctx;
+}
+
+const char* nyxhip_last_error(const nyxhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int nyxhip_set_stream(nyxhip_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    ctx->user_stream = (hipStream_t)hip_stream;
+    ctx->use_user_stream = true; // NULL is the legacy default stream, a valid choice
+    return NYXHIP_OK;
+}
+
+int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s)
+{
+    if (!s) return 0;
+    int n = 0;
+    if (family_mask & NYXHIP_FAM_INTENSITY) n += kIntensityCols;
+    if (family_mask & NYXHIP_FAM_GLCM) n += kGlcmAngled * s->glcm_n_angles + kGlcmAve;
+    return n;
+}
+
+int nyxhip_column_name(uint32_t family_mask, const nyxhip_settings* s, int col, char* buf, size_t buf_len)
+{
+    if (!s || !buf || buf_len == 0) return NYXHIP_ERR_INVALID_ARG;
+    auto v = column_names(family_mask & kImplemented, s);
+    if (col < 0 || col >= (int)v.size()) return NYXHIP_ERR_INVALID_ARG;
+    snprintf(buf, buf_len, "%s", v[col].c_str());
+    return NYXHIP_OK;
+}
+
+int nyxhip_sync(nyxhip_ctx* ctx)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream()));
+    return check_status(ctx);
+}
+
+int nyxhip_featurize_batch_async(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
+                                 double* out, size_t ld)
+{
+    int rc = validate(ctx, b, mask, s, out, ld);
+    if (rc) return rc;
+    if (b->memory != NYXHIP_MEM_DEVICE)
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the async form takes device-resident batches only");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (b->n_roi == 0) return NYXHIP_OK;
+    uint32_t max_px = b->max_px, max_area = b->max_bbox_area;
+    if (max_px == 0 || max_area == 0) {
+        hipStream_t st = ctx->stream();
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 2 * sizeof(uint32_t), st));
+        unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
+        hipLaunchKernelGGL(batch_extrema_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, ctx->d_extrema);
+        uint32_t h[2];
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_extrema, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        max_px = h[0];
+        max_area = h[1];
+    }
+    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area);
+}
+
+int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
+                           double* out, size_t ld)
+{
+    int rc = validate(ctx, b, mask, s, out, ld);
+    if (rc) return rc;
+    if (b->memory == NYXHIP_MEM_DEVICE) {
+        rc = nyxhip_featurize_batch_async(ctx, b, mask, s, out, ld);
+        if (rc) return rc;
+        return nyxhip_sync(ctx);
+    }
+    if (b->memory != NYXHIP_MEM_HOST) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad batch->memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (b->n_roi == 0) return NYXHIP_OK;
+
+    // host batch: derive extrema, stage SoA arrays into one device slab, run, copy the table back
+    const uint64_t nr = b->n_roi, npx = b->px_offset[nr];
+    uint32_t max_px = 0, max_area = 0;
+    for (uint64_t r = 0; r < nr; r++) {
+        if (b->px_offset[r + 1] < b->px_offset[r]) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "px_offset is not monotone");
+        uint64_t n = b->px_offset[r + 1] - b->px_offset[r];
+        uint64_t a = (uint64_t)b->bbox_w[r] * b->bbox_h[r];
+        if (n > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "ROI exceeds 2^32 pixels");
+        if (n > max_px) max_px = (uint32_t)n;
+        if (a > max_area) max_area = (uint32_t)a;
+    }
+    const int n_cols = nyxhip_n_columns(mask, s);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o_off = 0, o_x = al(o_off + 8 * (nr + 1)), o_y = al(o_x + 2 * npx), o_i = al(o_y + 2 * npx),
+           o_bw = al(o_i + 4 * npx), o_bh = al(o_bw + 4 * nr), o_mn = al(o_bh + 4 * nr), o_mx = al(o_mn + 4 * nr),
+           o_smin = al(o_mx + 4 * nr), o_smax = al(o_smin + 8 * nr), o_out = al(o_smax + 8 * nr),
+           total = al(o_out + 8ull * nr * n_cols);
+    rc = ensure_stage(ctx, total);
+    if (rc) return rc;
+    char* base = (char*)ctx->d_stage;
+    hipStream_t st = ctx->stream();
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_off, b->px_offset, 8 * (nr + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x, b->x, 2 * npx, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_y, b->y, 2 * npx, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_i, b->inten, 4 * npx, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_bw, b->bbox_w, 4 * nr, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_bh, b->bbox_h, 4 * nr, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_mn, b->min_inten, 4 * nr, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_mx, b->max_inten, 4 * nr, hipMemcpyHostToDevice, st));
+    if (b->slide_min) {
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_smin, b->slide_min, 8 * nr, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_smax, b->slide_max, 8 * nr, hipMemcpyHostToDevice, st));
+    }
+    nyxhip_batch d = *b;
+    d.memory = NYXHIP_MEM_DEVICE;
+    d.px_offset = (const uint64_t*)(base + o_off);
+    d.x = (const uint16_t*)(base + o_x); d.y = (const uint16_t*)(base + o_y); d.inten = (const uint32_t*)(base + o_i);
+    d.bbox_w = (const uint32_t*)(base + o_bw); d.bbox_h = (const uint32_t*)(base + o_bh);
+    d.min_inten = (const uint32_t*)(base + o_mn); d.max_inten = (const uint32_t*)(base + o_mx);
+    d.slide_min = b->slide_min ? (const double*)(base + o_smin) : nullptr;
+    d.slide_max = b->slide_max ? (const double*)(base + o_smax) : nullptr;
+    double* d_out = (double*)(base + o_out);
+    rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy2DAsync(out, ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
+                                  (size_t)n_cols * sizeof(double), nr, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return check_status(ctx);
+}
+
+void nyxhip_finalize_table(double* table, size_t n_rows, size_t n_cols, size_t ld, double soft_nan)
+{
+    if (!table) return;
+    for (size_t r = 0; r < n_rows; r++)
+        for (size_t c = 0; c < n_cols; c++) {
+            double& v = table[r * ld + c];
+            if (isnan(v) || isinf(v)) v = soft_nan; // force_finite_number, helpers/helpers.h:376-382
+        }
+}
+
+int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t*, const uint32_t*, uint32_t, uint32_t, int32_t, uint32_t, uint32_t,
+                          const nyxhip_settings*, uint32_t*, uint64_t, double*, size_t, uint64_t*)
+{
+    return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "nyxhip_featurize_tile: the fused tile path is not built yet");
+}
+
+int nyxhip_timing_enable(nyxhip_ctx* ctx, int on)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    ctx->timing = on != 0;
+    return NYXHIP_OK;
+}
+
+int nyxhip_timing_reset(nyxhip_ctx* ctx)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    ctx->ev_used = 0;
+    return NYXHIP_OK;
+}
+
+int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launches)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double tot = 0;
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i].second));
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i].first, ctx->ev[i].second));
+        tot += ms;
+    }
+    if (avg_kernel_ms) *avg_kernel_ms = ctx->ev_used ? tot / (double)ctx->ev_used : 0.0;
+    if (n_launches) *n_launches = ctx->ev_used;
+    return NYXHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,752 @@
+// roi_features.hip -- the fused per-ROI feature kernel for gfx950 (MI355X).
+//
+// One 256-thread workgroup (4 wave64) per ROI.  The ROI's pixel cloud is read from
+// HBM exactly once (coalesced SoA streams x:u16, y:u16, inten:u32) and everything
+// else happens in LDS:
+//
+//   * intensities are staged into an LDS array and bitonic-sorted in place; all
+//     first-order statistics (moments, percentile/n-bin histograms by binary search
+//     on the sorted array, exact median, exact mode, robust/median absolute
+//     deviations) are computed from that one resident copy
+//       -> replaces PixelIntensityFeatures::calculate
+//          (/root/reference/src/nyx/features/intensity.cpp:57-192), TrivialHistogram
+//          (features/histogram.h:27-309) and Moments4 (features/moments.h:48-109);
+//   * the binned bounding-box plane is scattered into LDS while loading, the
+//     co-occurrence matrices of all angles are accumulated with LDS atomics and each
+//     wave then derives the 30 Haralick features of one angle
+//       -> replaces GLCMFeature::calculate / calculateCoocMatAtAngle / f_*
+//          (features/glcm.cpp:16-100, 343-485, 487-1202).
+//
+// HBM bound by construction: algorithmic traffic is 8 B per ROI pixel in and
+// 8 B x n_cols out; there are no re-reads.  No MFMA: nothing here is a contraction.
+//
+// Built with -ffp-contract=off (see device_math.h).
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+// ---- column slots (Feature2D enum order, featureset.h) ---------------------------
+enum {
+    I_COV = 0, I_COVERED_IMAGE_INTENSITY_RANGE, I_ENERGY, I_ENTROPY, I_EXCESS_KURTOSIS,
+    I_HYPERFLATNESS, I_HYPERSKEWNESS, I_INTEGRATED_INTENSITY, I_INTERQUARTILE_RANGE,
+    I_KURTOSIS, I_MAX, I_MEAN, I_MEAN_ABSOLUTE_DEVIATION, I_MEDIAN,
+    I_MEDIAN_ABSOLUTE_DEVIATION, I_MIN, I_MODE, I_P01, I_P10, I_P25, I_P75, I_P90, I_P99,
+    I_QCOD, I_RANGE, I_ROBUST_MEAN, I_ROBUST_MEAN_ABSOLUTE_DEVIATION, I_ROOT_MEAN_SQUARED,
+    I_SKEWNESS, I_STANDARD_DEVIATION, I_STANDARD_DEVIATION_BIASED, I_STANDARD_ERROR,
+    I_VARIANCE, I_VARIANCE_BIASED, I_UNIFORMITY, I_UNIFORMITY_PIU
+};
+enum {
+    G_ASM = 0, G_ACOR, G_CLUPROM, G_CLUSHADE, G_CLUTEND, G_CONTRAST, G_CORRELATION, G_DIFAVE,
+    G_DIFENTRO, G_DIFVAR, G_DIS, G_ENERGY, G_ENTROPY, G_HOM1, G_HOM2, G_ID, G_IDN, G_IDM, G_IDMN,
+    G_INFOMEAS1, G_INFOMEAS2, G_IV, G_JAVE, G_JE, G_JMAX, G_JVAR, G_SUMAVERAGE, G_SUMENTROPY,
+    G_SUMVARIANCE, G_VARIANCE
+};
+// the 29 _AVE columns (featureset.h:205-233) as indices into the angled block
+__constant__ int c_glcm_ave_order[kGlcmAve] = {
+    G_ASM, G_ACOR, G_CLUPROM, G_CLUSHADE, G_CLUTEND, G_CONTRAST, G_CORRELATION, G_DIFAVE,
+    G_DIFENTRO, G_DIFVAR, G_DIS, G_ENERGY, G_ENTROPY, G_HOM1, G_ID, G_IDN, G_IDM, G_IDMN, G_IV,
+    G_JAVE, G_JE, G_INFOMEAS1, G_INFOMEAS2, G_VARIANCE, G_JMAX, G_JVAR, G_SUMAVERAGE,
+    G_SUMENTROPY, G_SUMVARIANCE};
+
+// slots of the block-wide scalar array s_stat
+enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MEAN1090, S_POP1090, S_NG, S_SKIP_GLCM, S_MODEKEY_LO, S_MODEKEY_HI };
+
+// Lanes of one wave exchange data through LDS without a workgroup barrier: LDS
+// instructions of a wave execute in issue order, so only the compiler has to be
+// kept from reordering / caching across the exchange.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sum N doubles across the workgroup in a fixed order (deterministic): wave shuffle
+// tree, then the four wave partials in wave order.  All threads get the totals.
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            s_red[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double t = s_red[k];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++)
+            t += s_red[w * 8 + k];
+        v[k] = t;
+    }
+    __syncthreads();
+}
+
+// In-place ascending bitonic sort of s[0..P), P a power of two.
+__device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
+{
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += kBlock) {
+                uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                uint32_t l = i | j;
+                uint32_t a = s[i], b = s[l];
+                bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- GLCM features of one angle, computed by one wave -----------------------------
+// P: Ng*Ng counts, P[center*Ng + neighbour]  (== SimpleMatrix::xy(a,b)++ with a =
+//    neighbour level, b = centre level, glcm.cpp:437-472; xy(x,y) = [y*W+x]).
+// Iv: level values I[] (glcm.cpp:388-420).  scr: 6*Ng doubles.  f: 30 outputs.
+__device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, double* scr,
+                                   double soft_nan, double* f, int lane)
+{
+    const int NN = Ng * Ng;
+    // sum_p (glcm.cpp:481-484): integer counts, exact in any order
+    unsigned long long cnt_sum = 0;
+    for (int e = lane; e < NN; e += 64)
+        cnt_sum += P[e];
+    cnt_sum = wave_sum_u64(cnt_sum);
+    cnt_sum = __shfl(cnt_sum, 0, 64);
+    if (cnt_sum == 0) { // glcm.cpp:260-295
+        if (lane < kGlcmAngled)
+            f[lane] = soft_nan;
+        wave_sync();
+        return;
+    }
+    const double sum_p = (double)cnt_sum;
+
+    double* pcol = scr;           // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
+    double* prow = scr + Ng;      // py[j] = sum_i xy(i,j)/sum_p
+    double* Pxpy = scr + 2 * Ng;  // [2Ng]  glcm.cpp:503-508
+    double* Pxmy = scr + 4 * Ng;  // [Ng]
+    double* dvar = scr + 5 * Ng;  // [Ng]   f_dvar's var[k]
+
+    // marginals and the x+y / |x-y| distributions; each lane owns whole entries and
+    // accumulates in the reference's loop order, so these are bit-identical to it.
+    for (int i = lane; i < Ng; i += 64) {
+        double a = 0;
+        for (int j = 0; j < Ng; j++)
+            a += (double)P[j * Ng + i] / sum_p;
+        pcol[i] = a;
+        double b = 0;
+        for (int j = 0; j < Ng; j++)
+            b += (double)P[i * Ng + j] / sum_p;
+        prow[i] = b;
+        // |x-y| = i : visiting order of calculatePxpmy is x outer, y inner
+        double d = 0;
+        for (int x = 0; x < Ng; x++) {
+            if (x - i >= 0)
+                d += (double)P[x * Ng + (x - i)] / sum_p;
+            if (i > 0 && x + i < Ng)
+                d += (double)P[x * Ng + (x + i)] / sum_p;
+        }
+        Pxmy[i] = d;
+    }
+    for (int k = lane; k < 2 * Ng; k += 64) {
+        double a = 0;
+        int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
+        for (int x = x0; x <= x1; x++)
+            a += (double)P[x * Ng + (k - x)] / sum_p;
+        Pxpy[k] = a;
+    }
+    wave_sync();
+
+    // by_row_mean (glcm.cpp:531-536), sequential; every lane computes the same value
+    double brm = 0;
+    for (int i = 0; i < Ng; ++i)
+        brm += pcol[i] * Iv[i];
+
+    // ---- pass 1 over matrix elements -------------------------------------------------
+    double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis = 0, hom2 = 0, jmax = -1;
+    for (int e = lane; e < NN; e += 64) {
+        int r = e / Ng, c = e - r * Ng;
+        double cnt = (double)P[e];
+        double p = cnt / sum_p;
+        double ir = Iv[r], ic = Iv[c];
+        asm_ += p * p;                               // f_asm :555 / f_energy :927-928
+        double d = ir - ic;
+        contrast_n += cnt * d * d;                   // f_contrast :579 (integer-exact)
+        S_r += cnt * ir;                             // f_corr mr :601, f_var mean :662, JAVE :1144
+        S_c += cnt * ic;                             // f_corr mc :608
+        acor_n += cnt * ir * ic;                     // f_GLCM_ACOR :961
+        int adiff = r > c ? r - c : c - r;
+        hom1 += p / (1.0 + (double)adiff);           // f_homogeneity :942
+        ent += plogp(p, p);                          // f_entropy :734-735, JE :1160-1161, HXY :868
+        dis += (double)adiff * cnt / sum_p;          // f_GLCM_DIS :1052
+        hom2 += p / (1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
+        jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
+    }
+    asm_ = wave_sum(asm_); contrast_n = wave_sum(contrast_n); S_r = wave_sum(S_r); S_c = wave_sum(S_c);
+    acor_n = wave_sum(acor_n); hom1 = wave_sum(hom1); ent = wave_sum(ent); dis = wave_sum(dis);
+    hom2 = wave_sum(hom2); jmax = wave_max(jmax);
+    S_r = __shfl(S_r, 0, 64);
+    S_c = __shfl(S_c, 0, 64);
+    const double mr = S_r / sum_p, mc = S_c / sum_p; // mr == f_var's mean == JAVE (exact numerators)
+
+    // ---- pass 2: central quantities ---------------------------------------------------
+    double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
+    for (int e = lane; e < NN; e += 64) {
+        int r = e / Ng, c = e - r * Ng;
+        double cnt = (double)P[e];
+        double p = cnt / sum_p;
+        double ir = Iv[r], ic = Iv[c];
+        double dr = ir - mr, dc = ic - mc;
+        s2r += p * dr * dr;                           // f_corr :617
+        s2c += p * dc * dc;                           // :626
+        tmp1 += dr * dc * cnt / sum_p;                // :633
+        var_n += dr * dr * cnt;                       // f_var :672
+        double m = ir + ic - brm - brm;               // CLUPROM :985, CLUSHADE :1007
+        cprom += m * m * m * m * cnt / sum_p;
+        cshade += m * m * m * cnt / sum_p;
+        double m2 = ic + ir - brm * 2.0;              // CLUTEND :1034 (xy(x,y): x = column)
+        ctend += m2 * m2 * cnt / sum_p;
+        double dj = (double)(c + 1) - mr;             // f_GLCM_JVAR :1196-1199 (x = column, +1 index)
+        jvar += dj * dj * cnt / sum_p;
+        double pp = pcol[c] * prow[r];                // px[i]*py[j], i = column, j = row (:869, :909)
+        double lg = fast_log10(pp + 0.000000001);
+        hxy1 += p * lg / 0.30102999566;
+        hxy2 += pp * lg / 0.30102999566;
+    }
+    s2r = wave_sum(s2r); s2c = wave_sum(s2c); tmp1 = wave_sum(tmp1); var_n = wave_sum(var_n);
+    cprom = wave_sum(cprom); cshade = wave_sum(cshade); ctend = wave_sum(ctend); jvar = wave_sum(jvar);
+    hxy1 = wave_sum(hxy1); hxy2 = wave_sum(hxy2);
+
+    // difference average (glcm.cpp:786-795); kValuesDiff[k] = |I[Ng-1] - I[Ng-1-k]| is the
+    // last pair written by calculatePxpmy (:512); every lane computes it (needed by dvar).
+    double diffAvg = 0;
+    for (int k = 0; k < Ng; k++)
+        diffAvg += (k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k])) * Pxmy[k];
+    // f_dvar (glcm.cpp:742-766): var[k] receives the same term Ng times
+    for (int k = lane; k < Ng; k += 64) {
+        double dk = (double)k - diffAvg;
+        double t = dk * dk * Pxmy[k], a = 0;
+        for (int x = 0; x < Ng; x++)
+            a += t;
+        dvar[k] = a;
+    }
+    wave_sync();
+
+    if (lane == 0) {
+        f[G_ASM] = asm_;
+        f[G_ENERGY] = asm_;
+        f[G_CONTRAST] = contrast_n / sum_p;
+        f[G_ACOR] = acor_n / sum_p;
+        f[G_HOM1] = hom1;
+        f[G_HOM2] = hom2;
+        f[G_ENTROPY] = -ent;
+        f[G_JE] = -ent;
+        f[G_DIS] = dis;
+        f[G_JMAX] = jmax;
+        f[G_JAVE] = mr;
+        f[G_VARIANCE] = var_n / sum_p;
+        f[G_CLUPROM] = cprom;
+        f[G_CLUSHADE] = cshade;
+        f[G_CLUTEND] = ctend;
+        f[G_SUMVARIANCE] = ctend;                     // glcm.cpp:323-326
+        f[G_JVAR] = jvar;
+        {   // f_corr tail, glcm.cpp:619-643
+            double denom = sqrt(s2r) * sqrt(s2c);
+            f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : tmp1 / denom;
+        }
+        // 1-D features, sequential in the reference's order
+        double idm = 0, savg = 0, sent = 0, dent = 0, idmn = 0, id = 0, idn = 0, iv = 0, hx = 0, dv = 0;
+        const double Ng2 = (double)Ng * (double)Ng;
+        for (int k = 0; k < Ng; ++k) {
+            double q = Pxmy[k];
+            idm += q / (double)(1 + (k * k));                        // f_idm :685-687
+            if (q != 0)
+                dent += plogp(q, q);                                 // f_dentropy :778-781
+            idmn += q / (1.0 + ((double)k * (double)k) / Ng2);       // :1083-1084
+            id += q / (1.0 + (double)k);                             // :1096-1097
+            idn += q / (1.0 + (double)k / (double)Ng);               // :1110-1111
+            if (k >= 1) {
+                double kval = fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
+                iv += q / (kval * kval);                             // :1123-1128
+            }
+            hx += plogp(pcol[k], pcol[k]);                           // :873-874
+            dv += dvar[k];
+        }
+        for (int k = 0; k < 2 * Ng; k++) {
+            double q = Pxpy[k];
+            // kValuesSum[k] = I[x]+I[y] of the last (x,y) with x+y = k (:511): x = min(k, Ng-1)
+            double ks = 0;
+            if (k <= 2 * Ng - 2) {
+                int x = k < Ng - 1 ? k : Ng - 1;
+                ks = Iv[x] + Iv[k - x];
+            }
+            savg += ks * q;                                          // f_savg :700-701
+            sent += plogp(q, q);                                     // f_sentropy :712-716
+        }
+        f[G_IDM] = idm;
+        f[G_SUMAVERAGE] = savg;
+        f[G_SUMENTROPY] = -sent;
+        f[G_DIFENTRO] = -dent;
+        f[G_DIFAVE] = diffAvg;
+        f[G_DIFVAR] = dv / (double)Ng;
+        f[G_IDMN] = idmn;
+        f[G_ID] = id;
+        f[G_IDN] = idn;
+        f[G_IV] = iv;
+        {   // f_info_meas_corr1/2, glcm.cpp:880-883, :913 (HXY = ent here)
+            double r1 = (ent - hxy1) / hx;
+            f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+            f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2 + ent))));
+        }
+    }
+    wave_sync();
+}
+
+// ---- the fused kernel --------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+
+    double* s_out = (double*)(lds + A.L.out);
+    double* s_red = (double*)(lds + A.L.red);
+    double* s_stat = (double*)(lds + A.L.stat);
+    uint32_t* s_lb100 = (uint32_t*)(lds + A.L.lb100);
+    uint32_t* s_lbc = (uint32_t*)(lds + A.L.lbc);
+    uint32_t* s_val = (uint32_t*)(lds + A.L.val);
+    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
+    uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);
+    uint32_t* s_P = (uint32_t*)(lds + A.L.P);
+    double* s_g = (double*)(lds + A.L.gscr);
+
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t area = w * h;
+    const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
+    const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0;
+    const bool do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
+    double* const out_row = A.out + roi * A.ld;
+
+    // smallest power of two >= n (sort length)
+    uint32_t P2 = 1;
+    while (P2 < n)
+        P2 <<= 1;
+    if (n == 0 || (do_int && P2 > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
+        if (tid == 0 && n != 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        for (int c = tid; c < A.n_cols; c += kBlock)
+            out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+
+    // grey binning used by the co-occurrence scan (glcm.cpp:354,379-385)
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
+
+    // ---- phase 0: clear LDS state ---------------------------------------------------
+    for (int c = tid; c < A.n_cols; c += kBlock)
+        s_out[c] = 0.0;
+    if (do_glcm) {
+        for (uint32_t i = tid; i < area; i += kBlock)
+            s_dense[i] = 0;
+        if (greyInfo < 0)
+            for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
+                s_lvlmap[i] = 0;
+    }
+    if (do_int)
+        for (uint32_t i = n + tid; i < P2; i += kBlock)
+            s_val[i] = 0xFFFFFFFFu;
+    if (tid < 16)
+        s_stat[tid] = 0.0;
+    __syncthreads();
+
+    // ---- phase 1: the only pass over HBM ------------------------------------------------
+    unsigned long long sum = 0, sumsq = 0;
+    uint32_t lvl_max = 0;
+    for (uint32_t i = tid; i < n; i += kBlock) {
+        uint32_t v = A.inten[off + i];
+        if (do_int) {
+            s_val[i] = v;
+            sum += v;
+            sumsq += (uint32_t)(v * v); // unsigned-int product, wraps (intensity.cpp:90)
+        }
+        if (do_glcm) {
+            uint32_t px = A.x[off + i], py = A.y[off + i];
+            uint32_t lvl = 0;
+            if (v != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
+                lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo)
+                    : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+                if (greyInfo < 0)
+                    s_lvlmap[lvl] = 1;
+                lvl_max = lvl > lvl_max ? lvl : lvl_max;
+            }
+            if (px < w && py < h)
+                s_dense[py * w + px] = (uint16_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+        }
+    }
+
+    // =====================================================================================
+    // first-order intensity
+    // =====================================================================================
+    if (do_int) {
+        double* o = s_out + A.col_intensity;
+        const double dn = (double)n;
+        // integer sums are exact in any order (the reference's double accumulation is
+        // exact too while partial sums stay below 2^53)
+        sum = wave_sum_u64(sum);
+        sumsq = wave_sum_u64(sumsq);
+        if (lane == 0) {
+            s_red[wave * 8 + 0] = (double)sum;
+            s_red[wave * 8 + 1] = (double)sumsq;
+        }
+        __syncthreads();
+        double tot = 0, totsq = 0;
+        for (int wv = 0; wv < kWaves; wv++) {
+            tot += s_red[wv * 8 + 0];
+            totsq += s_red[wv * 8 + 1];
+        }
+        const double mean = tot / dn;
+        __syncthreads();
+
+        bitonic_sort(s_val, P2, tid);
+
+        // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183;
+        // M2..M4 of moments.h:53-74 equal the plain central sums)
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t i = tid; i < n; i += kBlock) {
+            double d = (double)s_val[i] - mean;
+            double d2 = d * d;
+            acc[0] += fabs(d);
+            acc[1] += d2;
+            acc[2] += d2 * d;
+            acc[3] += d2 * d2;
+            acc[4] += d2 * d2 * d;
+            acc[5] += d2 * d2 * d2;
+        }
+        block_sum<6>(acc, s_red, tid);
+
+        const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
+        const uint32_t range = vmax - vmin;
+        const double binW100 = (double)range / 100.;
+        const uint32_t nb = (uint32_t)A.n_hist;
+
+        if (!blank) {
+            // histogram bin boundaries by binary search over the sorted values:
+            // idx(v) is monotone in v, so count(idx < b) is a lower bound
+            // (histogram.h:55-66 percentile bins, :69-78 n-bin histogram)
+            for (uint32_t t = tid; t < 100 + nb; t += kBlock) {
+                uint32_t lo = 0, hi = n;
+                if (t < 100) {
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        double realIdx = (double)(s_val[mid] - vmin) / binW100;
+                        int idx = (realIdx != realIdx) ? 0 : (int)realIdx;
+                        if (idx < (int)t) lo = mid + 1; else hi = mid;
+                    }
+                    s_lb100[t] = lo;
+                } else {
+                    uint32_t b = t - 100;
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        uint32_t idx = to_grayscale(s_val[mid], vmin, range, nb);
+                        if (idx < b) lo = mid + 1; else hi = mid;
+                    }
+                    s_lbc[b] = lo;
+                }
+            }
+            // mode (histogram.h:289-309): longest run, smallest value on ties
+            if (tid == 0) {
+                s_stat[S_MODEKEY_LO] = 0;
+            }
+            unsigned long long* s_modekey = (unsigned long long*)&s_stat[S_MODEKEY_LO];
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kBlock) {
+                uint32_t v = s_val[i];
+                if (i == n - 1 || s_val[i + 1] != v) {
+                    uint32_t lo = 0, hi = i;
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (s_val[mid] < v) lo = mid + 1; else hi = mid;
+                    }
+                    unsigned long long key = ((unsigned long long)(i - lo + 1) << 32) | (unsigned long long)(0xFFFFFFFFu - v);
+                    atomicMax(s_modekey, key);
+                }
+            }
+            __syncthreads();
+
+            // percentiles: lanes 0..5 of wave 0 each run the 100-bin scan for one of
+            // P01,P10,P25,P75,P90,P99 (histogram.h:214-243; every matching bin overwrites)
+            if (wave == 0) {
+                double pv = 0;
+                if (lane < 6) {
+                    const double frac = lane == 0 ? 0.01 : lane == 1 ? 0.1 : lane == 2 ? 0.25 : lane == 3 ? 0.75 : lane == 4 ? 0.9 : 0.99;
+                    const double cnt_p = dn * frac;
+                    uint32_t runSum = 0;
+                    for (int i = 0; i < 100; i++) {
+                        uint32_t bi = (i < 99 ? s_lb100[i + 1] : n) - s_lb100[i];
+                        if ((double)runSum <= cnt_p && cnt_p <= (double)(runSum + bi))
+                            pv = (cnt_p - (double)runSum) * binW100 / (double)bi + (double)vmin + binW100 * (double)i;
+                        runSum += bi;
+                    }
+                }
+                double p01 = __shfl(pv, 0, 64), p10 = __shfl(pv, 1, 64), p25 = __shfl(pv, 2, 64),
+                       p75 = __shfl(pv, 3, 64), p90 = __shfl(pv, 4, 64), p99 = __shfl(pv, 5, 64);
+                // entropy / uniformity over the n+1 slots (histogram.h:145-151): slot n is 0
+                double e = 0, u = 0;
+                for (uint32_t k = lane; k < nb; k += 64) {
+                    uint32_t ck = (k < nb - 1 ? s_lbc[k + 1] : n) - s_lbc[k];
+                    double p = (double)ck / dn;
+                    e += p * log2(p + 2.2e-16);
+                    u += p * p;
+                }
+                e = wave_sum(e);
+                u = wave_sum(u);
+                if (lane == 0) {
+                    e += 0.0 * log2(0.0 + 2.2e-16); // the folded, emptied slot n
+                    double median; // histogram.h:268-287
+                    if (n & 1)
+                        median = (double)s_val[n / 2];
+                    else
+                        median = (double)(uint32_t)(s_val[n / 2] + s_val[n / 2 - 1]) / 2.0;
+                    unsigned long long key = *s_modekey;
+                    o[I_MEDIAN] = median;
+                    o[I_MODE] = (double)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu));
+                    o[I_P01] = p01; o[I_P10] = p10; o[I_P25] = p25; o[I_P75] = p75; o[I_P90] = p90; o[I_P99] = p99;
+                    o[I_QCOD] = (p75 - p25) / (p75 + p25);
+                    o[I_INTERQUARTILE_RANGE] = p75 - p25;
+                    o[I_ENTROPY] = -e;
+                    o[I_UNIFORMITY] = u;
+                    s_stat[S_P10] = p10;
+                    s_stat[S_P90] = p90;
+                    s_stat[S_MEDIAN] = median;
+                }
+            }
+            __syncthreads();
+
+            // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
+            const double p10 = s_stat[S_P10], p90 = s_stat[S_P90], median = s_stat[S_MEDIAN];
+            double rb[2] = {0, 0};
+            for (uint32_t i = tid; i < n; i += kBlock) {
+                double a = (double)s_val[i];
+                if (a >= p10 && a <= p90) {
+                    rb[0] += a;
+                    rb[1] += 1.0;
+                }
+            }
+            block_sum<2>(rb, s_red, tid);
+            const double mean1090 = rb[1] > 0 ? rb[0] / rb[1] : 0.0;
+            // robust MAD (histogram.h:102-112) and median absolute deviation (intensity.cpp:156-159)
+            double ad[2] = {0, 0};
+            for (uint32_t i = tid; i < n; i += kBlock) {
+                double a = (double)s_val[i];
+                if (a >= p10 && a <= p90)
+                    ad[0] += fabs(a - mean1090);
+                ad[1] += fabs(a - median);
+            }
+            block_sum<2>(ad, s_red, tid);
+            if (tid == 0) {
+                o[I_ROBUST_MEAN] = mean1090;
+                o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
+                o[I_MEDIAN_ABSOLUTE_DEVIATION] = ad[1] / dn;
+            }
+        }
+
+        if (tid == 0) {
+            o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
+            o[I_MAX] = (double)vmax;
+            o[I_RANGE] = (double)vmax - (double)vmin;
+            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
+                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
+            o[I_MEAN] = mean;                          // intensity.cpp:95-99
+            o[I_ENERGY] = totsq;
+            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
+            o[I_INTEGRATED_INTENSITY] = tot;
+            const double var = acc[1];                 // intensity.cpp:110-118
+            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
+            const double variance = dn > 1 ? var / (dn - 1) : 0.0;
+            const double variance_b = dn > 1 ? var / dn : 0.0;
+            const double sd = sqrt(variance);
+            o[I_VARIANCE] = variance;
+            o[I_VARIANCE_BIASED] = variance_b;
+            o[I_STANDARD_DEVIATION] = sd;
+            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
+            o[I_COV] = sd / mean;
+            o[I_STANDARD_ERROR] = sd / sqrt(dn);
+            if (!blank) {
+                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
+                const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
+                if (M2 != 0.0) {
+                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / pow(M2, 1.5) : 0.0;
+                    o[I_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
+                    o[I_EXCESS_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) - 3 : 0.0;
+                }
+                double denom = dn * pow(sd, 5.);       // intensity.cpp:186-191
+                o[I_HYPERSKEWNESS] = denom == 0. ? 0. : acc[4] / denom;
+                denom = dn * pow(sd, 6.);
+                o[I_HYPERFLATNESS] = denom == 0. ? 0. : acc[5] / denom;
+            }
+        }
+    }
+
+    // =====================================================================================
+    // GLCM
+    // =====================================================================================
+    if (do_glcm) {
+        double* o = s_out + A.col_glcm;
+        const int na = A.glcm_na;
+        const int ncol_g = kGlcmAngled * na + kGlcmAve;
+        // degenerate guard (glcm.cpp:27-95) uses GLCM_GREYDEPTH
+        const bool degenerate = bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth);
+
+        // matrix order and level values (glcm.cpp:388-420)
+        lvl_max = wave_max_u32(lvl_max);
+        if (lane == 0)
+            s_red[wave * 8] = (double)lvl_max;
+        __syncthreads(); // also orders s_dense / s_lvlmap writes of phase 1
+        double* s_I = s_g;                       // [ng_cap] level values
+        double* s_f = s_g + A.L.ng_cap;          // [kMaxAngles][32] per-angle features
+        double* s_scr = s_f + kMaxAngles * 32;   // [kMaxAngles][6*ng_cap]
+        if (tid == 0) {
+            int Ng;
+            if (greyInfo > 0)
+                Ng = greyInfo;
+            else if (greyInfo == 0) {
+                double m = 0;
+                for (int wv = 0; wv < kWaves; wv++)
+                    m = s_red[wv * 8] > m ? s_red[wv * 8] : m;
+                Ng = (int)m;
+            } else {
+                // unique sorted non-zero levels -> compact indices (glcm.cpp:391-397)
+                int k = 0;
+                for (uint32_t l = 1; l <= A.L.lvl_cap; l++)
+                    if (s_lvlmap[l]) {
+                        s_lvlmap[l] = (uint16_t)(k + 1);
+                        if ((uint32_t)k < A.L.ng_cap)
+                            s_I[k] = (double)l;
+                        k++;
+                    }
+                Ng = k;
+            }
+            s_stat[S_NG] = (double)Ng;
+        }
+        __syncthreads();
+        const int Ng = (int)s_stat[S_NG];
+        const bool too_big = (uint32_t)Ng > A.L.ng_cap;
+        if (too_big && tid == 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
+        if (greyInfo >= 0 && !too_big)
+            for (int i = tid; i < Ng; i += kBlock)
+                s_I[i] = (double)(i + 1);
+
+        if (degenerate) {
+            for (int c = tid; c < ncol_g; c += kBlock)
+                o[c] = A.soft_nan;
+        } else if (too_big) {
+            for (int c = tid; c < ncol_g; c += kBlock)
+                o[c] = __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            const int NN = Ng * Ng;
+            const bool symmetric = A.glcm_symmetric || greyInfo <= 0; // glcm.cpp:475
+            const int app = (int)A.L.app;
+            for (int a0 = 0; a0 < na; a0 += app) {
+                const int na_pass = (na - a0) < app ? (na - a0) : app;
+                __syncthreads();
+                for (int i = tid; i < na_pass * NN; i += kBlock)
+                    s_P[i] = 0;
+                __syncthreads();
+                // co-occurrence scan (glcm.cpp:431-478): LDS atomics, all angles of the pass
+                for (uint32_t p = tid; p < area; p += kBlock) {
+                    uint32_t lb = s_dense[p];
+                    if (lb == 0)
+                        continue;
+                    int row = (int)(p / w), col = (int)(p - (uint32_t)row * w);
+                    int ib = greyInfo < 0 ? (int)s_lvlmap[lb] - 1 : (int)lb - 1;
+                    for (int q = 0; q < na_pass; q++) {
+                        int ang = A.glcm_angles[a0 + q];
+                        int dx, dy;                     // glcm.cpp:234-255
+                        if (ang == 0) { dx = A.glcm_offset; dy = 0; }
+                        else if (ang == 45) { dx = A.glcm_offset; dy = A.glcm_offset; }
+                        else if (ang == 90) { dx = 0; dy = A.glcm_offset; }
+                        else { dx = -A.glcm_offset; dy = A.glcm_offset; }
+                        int r2 = row + dy, c2 = col + dx;
+                        if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
+                            continue;
+                        uint32_t la = s_dense[(uint32_t)r2 * w + (uint32_t)c2];
+                        if (la == 0)
+                            continue;
+                        int ia = greyInfo < 0 ? (int)s_lvlmap[la] - 1 : (int)la - 1;
+                        atomicAdd(&s_P[q * NN + ib * Ng + ia], 1u);
+                        if (symmetric)
+                            atomicAdd(&s_P[q * NN + ia * Ng + ib], 1u);
+                    }
+                }
+                __syncthreads();
+                if (wave < na_pass)
+                    glcm_features_wave(s_P + wave * NN, Ng, s_I, s_scr + wave * 6 * A.L.ng_cap, A.soft_nan,
+                                       s_f + (a0 + wave) * 32, lane);
+            }
+            __syncthreads();
+            // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
+            for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
+                int k = c / na, a = c - k * na;
+                o[c] = s_f[a * 32 + k];
+            }
+            for (int j = tid; j < kGlcmAve; j += kBlock) {
+                // calc_ave (glcm.cpp:1205-1214): libstdc++ std::reduce folds four at a time
+                int k = c_glcm_ave_order[j];
+                double init = 0.0;
+                int a = 0;
+                for (; na - a >= 4; a += 4) {
+                    double v1 = s_f[a * 32 + k] + s_f[(a + 1) * 32 + k];
+                    double v2 = s_f[(a + 2) * 32 + k] + s_f[(a + 3) * 32 + k];
+                    init = init + (v1 + v2);
+                }
+                for (; a < na; a++)
+                    init = init + s_f[a * 32 + k];
+                o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int c = tid; c < A.n_cols; c += kBlock)
+        out_row[c] = s_out[c];
+}
+
+size_t roi_features_max_lds()
+{
+    return 160 * 1024; // gfx950: 160 KiB per CU, all of it usable by one workgroup
+}
+
+int launch_roi_features(const RoiArgs& a, void* stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        if (e != hipSuccess)
+            return (int)e;
+        attr_set = true;
+    }
+    if (a.n_roi == 0)
+        return 0;
+    hipLaunchKernelGGL(roi_features_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

@@ -1,0 +1,67 @@
+// roi_kernel.h -- host/device shared declarations of the fused per-ROI kernel.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace nyxhip {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup, one workgroup per ROI
+constexpr int kWaves = kBlock / 64;
+constexpr int kIntensityCols = 36;   // Feature2D COV..UNIFORMITY_PIU (featureset.h:12-46)
+constexpr int kGlcmAngled = 30;      // Feature2D GLCM_ASM..GLCM_VARIANCE (featureset.h:174-203)
+constexpr int kGlcmAve = 29;         // Feature2D GLCM_ASM_AVE..GLCM_SUMVARIANCE_AVE (:205-233)
+constexpr int kMaxAngles = 4;
+
+// Byte offsets of the regions carved out of the workgroup's dynamic LDS; computed
+// on the host per launch (size classes differ per batch).
+struct LdsLayout {
+    uint32_t out;      // double[n_cols]       staged output row
+    uint32_t red;      // double[kWaves*8]     cross-wave reduction scratch
+    uint32_t stat;     // double[16]           block-wide scalars
+    uint32_t lb100;    // uint32[104]          lower bounds of the 100 percentile bins
+    uint32_t lbc;      // uint32[n_hist+8]     lower bounds of the n-bin histogram
+    uint32_t val;      // uint32[sort_cap]     intensities, sorted in place
+    uint32_t dense;    // uint16[dense_cap]    binned bounding-box plane (0 = skip)
+    uint32_t lvlmap;   // uint16[lvl_cap+8]    radiomics level -> compact index
+    uint32_t P;        // uint32[app*ng_cap^2] co-occurrence counts
+    uint32_t gscr;     // double[kMaxAngles*(6*ng_cap+40)] per-angle marginals + features
+    uint32_t total;
+    uint32_t sort_cap;   // power of two >= max_px
+    uint32_t dense_cap;  // >= max bbox area
+    uint32_t ng_cap;     // max GLCM matrix order held in LDS
+    uint32_t lvl_cap;    // number of radiomics bins
+    uint32_t app;        // angles per co-occurrence pass (4, 2 or 1)
+};
+
+struct RoiArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    const double* slide_min;
+    const double* slide_max;
+    double* out;
+    uint64_t ld;
+    int* status;         // device word: first error code raised by any workgroup
+    uint32_t mask;
+    int32_t n_cols;
+    int32_t col_intensity;   // first column of each family's block (-1 = absent)
+    int32_t col_glcm;
+    // settings (nyxhip_settings)
+    double soft_nan;
+    int32_t grey_depth, ibsi, glcm_grey_depth, glcm_offset, glcm_na, glcm_symmetric;
+    int32_t glcm_angles[kMaxAngles];
+    int32_t n_hist;          // |grey_depth| = intensity histogram bins
+    LdsLayout L;
+};
+
+// implemented in roi_features.hip
+int launch_roi_features(const RoiArgs& a, void* stream);
+size_t roi_features_max_lds();
+
+} // namespace nyxhip
