@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- ROIs/sec of the per-ROI feature reduce (*ALL_GLCM* + *ALL_INTENSITY*)
+on synthetic 1024x1024 tiles, the metric of BASELINE.json.
+
+A "step" is one pass of the hot path (nyxhip_featurize_batch_async: the replacement
+of reduce_trivial_rois_manual, /root/reference/src/nyx/reduce_trivial_rois.cpp:772-795)
+over one batch of ROIs that is already resident in HBM: `--tiles` tiles (default 1000,
+the tile count of BASELINE.json configs[1]/[2]) x 196 ROIs per tile (14x14 disks of
+radius 30 -> 2821 px, bbox 61x61), intensities uniform in [1, 4095],
+coarse_gray_depth=8, GLCM angles {0,45,90,135}, offset 1, matlab binning.
+
+Per rank (one process per GPU): the same number of tiles (weak scaling); after every
+step the rank's feature-table block is gathered on rank 0 with one RCCL gather that
+overlaps the next step's kernel (nyxus_amd/sharding.py).  Output: ONE JSON line on
+rank 0 (contract in the task statement) plus `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tiles", type=int, default=1000, help="tiles per GPU per step")
+    ap.add_argument("--gray-depth", type=int, default=8)
+    ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def disk_cloud(radius=30):
+    """Column-major cloud of one benchmark ROI (phase2_2d.cpp:655-656 scan order)."""
+    r = radius
+    yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+    m = (xx * xx + yy * yy) <= r * r
+    y, x = np.nonzero(m)
+    o = np.lexsort((y, x))
+    return x[o].astype(np.uint16), y[o].astype(np.uint16), 2 * r + 1
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from nyxus_amd import _abi, _lib
+    from nyxus_amd.sharding import TableGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    s = _abi.default_settings(a.gray_depth)
+    ctx = _lib.Context(local_rank)
+    ncol = ctx.n_columns(mask, s)
+
+    # ---- synthetic batch, generated on the device (seeded) ---------------------------------
+    px, py, side = disk_cloud(30)
+    n_px_roi = len(px)                       # 2821
+    rois_per_tile = 196
+    n_roi = a.tiles * rois_per_tile
+    n_px = n_roi * n_px_roi
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    inten = torch.randint(1, 4096, (n_px,), generator=g, device=dev, dtype=torch.int32)
+    x = torch.from_numpy(px.view(np.int16)).to(dev).repeat(n_roi)
+    y = torch.from_numpy(py.view(np.int16)).to(dev).repeat(n_roi)
+    off = torch.arange(0, n_roi + 1, device=dev, dtype=torch.int64) * n_px_roi
+    bw = torch.full((n_roi,), side, device=dev, dtype=torch.int32)
+    bh = torch.full((n_roi,), side, device=dev, dtype=torch.int32)
+    iv = inten.view(n_roi, n_px_roi)
+    mn = iv.min(dim=1).values.contiguous()
+    mx = iv.max(dim=1).values.contiguous()
+    labels = (torch.arange(n_roi, device=dev, dtype=torch.int32) % rois_per_tile) + 1
+    outs = [torch.empty((n_roi, ncol), dtype=torch.float64, device=dev) for _ in range(2)]
+
+    cb = _abi.Batch()
+    cb.n_roi = n_roi
+    cb.roi_label = labels.data_ptr(); cb.px_offset = off.data_ptr()
+    cb.x = x.data_ptr(); cb.y = y.data_ptr(); cb.inten = inten.data_ptr()
+    cb.bbox_w = bw.data_ptr(); cb.bbox_h = bh.data_ptr()
+    cb.min_inten = mn.data_ptr(); cb.max_inten = mx.data_ptr()
+    cb.slide_min = None; cb.slide_max = None
+    cb.memory = _abi.MEM_DEVICE
+    cb.max_px = n_px_roi; cb.max_bbox_area = side * side
+
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)       # kernels + events on torch's current stream
+    gather = TableGather(ncol, dst=0) if world > 1 else None
+
+    def step(i):
+        out = outs[i & 1]
+        ctx.featurize_device_async(cb, mask, s, out.data_ptr(), ncol)
+        if gather is not None:
+            if i > 0:
+                gather.finish()              # previous step's gather overlapped this launch
+            # ProcessGroupNCCL orders the collective after the work already queued on the
+            # current stream (this step's kernel); async_op leaves the next launch free to overlap
+            gather.start(out, rows_per_rank=[n_roi] * world)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    if gather is not None and a.warmup:
+        gather.finish()
+    fence()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    last = None
+    for i in range(a.steps):
+        last = step(i)
+    if gather is not None:
+        gather.finish()
+    fence()
+    t1 = time.perf_counter()
+    ctx.sync()                               # raises on a device-side error flag
+    kern_ms, n_launch = ctx.timing_get()
+    ctx.timing(False)
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    if rank == 0:
+        total_rois = n_roi * world * a.steps
+        value = total_rois / elapsed
+        # algorithmic bytes per launch (pre-assembled clouds):
+        # 8 B per ROI pixel in (x:u16, y:u16, inten:u32) + 8 B x n_cols out per ROI
+        alg_bytes = n_px * 8 + n_roi * ncol * 8
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):            # PMC-derived HBM bytes per launch, see profiles/README.md
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("tiles") == a.tiles and tj.get("gray_depth") == a.gray_depth:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "ROIs/sec (*ALL_GLCM*+*ALL_INTENSITY*, 1024^2 tiles)",
+            "value": value, "unit": "ROIs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"*ALL_GLCM*+*ALL_INTENSITY*, coarse_gray_depth={a.gray_depth}, 4 angles, d=1, "
+                                   f"{a.tiles} synthetic 1024x1024 tiles/GPU x {rois_per_tile} ROIs/tile "
+                                   f"(disk r=30, {n_px_roi} px, bbox {side}x{side}), intensities U[1,4095]; "
+                                   "reduce stage on pre-assembled ROI clouds resident in HBM",
+                       "rois_per_step_per_gpu": n_roi, "n_columns": ncol,
+                       "sharding": f"{world} rank(s), tiles block-partitioned, RCCL gather of the table to rank 0"
+                                   if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "roi_features_kernel", "kernel_ms": kern_ms, "launches": int(n_launch),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+
+        # ---- parity spot check of what was timed (first tile of the last step) -----------------
+        if not a.no_check:
+            from oracle import pyoracle as po
+            from tests import parity
+            k = rois_per_tile
+            hb = _abi.HostBatch(labels[:k].cpu().numpy().astype(np.uint32), off[:k + 1].cpu().numpy().astype(np.uint64),
+                                x[:k * n_px_roi].cpu().numpy().view(np.uint16), y[:k * n_px_roi].cpu().numpy().view(np.uint16),
+                                inten[:k * n_px_roi].cpu().numpy().view(np.uint32), bw[:k].cpu().numpy().view(np.uint32),
+                                bh[:k].cpu().numpy().view(np.uint32), mn[:k].cpu().numpy().view(np.uint32),
+                                mx[:k].cpu().numpy().view(np.uint32))
+            want = po.oracle_featurize(hb, mask, s)
+            bad = parity.compare_tables(last[:k].cpu().numpy(), want, _lib.column_names(mask, s))
+            rec["config"]["parity_check"] = "first tile of the last timed step vs oracle: " + ("ok" if not bad else f"{len(bad)} MISMATCHES")
+            if bad:
+                print("\n".join(bad[:10]), file=sys.stderr)
+
+        # ---- CPU baseline: the reference's own multithreaded reduce on host cores ---------------
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import pyoracle as po
+            cores = os.cpu_count() or 1
+            kind = "reference" if po.have_ref() else "port"
+            thr = cores if kind == "reference" else 1
+            ct = a.cpu_tiles or max(2, min(a.tiles, 4 * thr if kind == "reference" else 8))
+            k = ct * rois_per_tile
+            hb = _abi.HostBatch(labels[:k].cpu().numpy().astype(np.uint32), off[:k + 1].cpu().numpy().astype(np.uint64),
+                                x[:k * n_px_roi].cpu().numpy().view(np.uint16), y[:k * n_px_roi].cpu().numpy().view(np.uint16),
+                                inten[:k * n_px_roi].cpu().numpy().view(np.uint32), bw[:k].cpu().numpy().view(np.uint32),
+                                bh[:k].cpu().numpy().view(np.uint32), mn[:k].cpu().numpy().view(np.uint32),
+                                mx[:k].cpu().numpy().view(np.uint32))
+            if kind == "reference":
+                tm = []
+                po.ref_featurize(hb, mask, s, n_threads=thr, timing=tm)   # reduce stage only (runParallel ladder)
+                sec = tm[0]
+            else:
+                c0 = time.perf_counter()
+                po.oracle_featurize(hb, mask, s)
+                sec = time.perf_counter() - c0
+            rec["cpu_baseline"] = {
+                "value": k / sec, "unit": "ROIs/s", "cores": thr, "kind": kind,
+                "sample": f"{ct} tiles ({k} ROIs) of the same workload; "
+                          + ("reference PixelIntensityFeatures::reduce + GLCMFeature::parallel_process_1_batch via runParallel "
+                             f"with {thr} threads, reduce stage only ({sec:.2f} s)" if kind == "reference"
+                             else f"single-threaded C restatement ({sec:.2f} s)"),
+                "host_cpus": cores}
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

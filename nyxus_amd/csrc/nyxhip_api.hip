@@ -119,13 +119,15 @@ uint32_t pow2ceil(uint32_t v)
 }
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
-// Carves the workgroup's LDS for one launch.  Returns false when the batch extrema
-// do not fit the 160 KiB of a CU.
-bool make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
-                 LdsLayout& L, std::string& why)
+// Carves the workgroup's LDS for one launch.  Returns NYXHIP_OK, or
+// NYXHIP_ERR_UNSUPPORTED when the grey depth alone cannot be held in LDS, or
+// NYXHIP_ERR_ROI_TOO_LARGE when the batch extrema do not fit the 160 KiB of a CU.
+int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
+                LdsLayout& L, std::string& why)
 {
     memset(&L, 0, sizeof(L));
     const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
+    const size_t cap = roi_features_max_lds();
     uint32_t off = 0;
     L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
     L.red = off; off = align16(off + 8u * kWaves * 8);
@@ -133,42 +135,49 @@ bool make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t m
     L.lb100 = off; off = align16(off + 4u * 104);
     uint32_t n_hist = (uint32_t)abs(s->grey_depth);
     L.lbc = off; off = align16(off + 4u * (do_int ? n_hist + 8 : 8));
+    const uint32_t fixed = off;               // everything that does not scale with the ROI
     L.sort_cap = do_int ? pow2ceil(max_px ? max_px : 1) : 0;
-    L.val = off; off = align16(off + 4u * L.sort_cap);
+    L.val = off;
+    if (4ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident sort buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    off = align16(off + 4u * L.sort_cap);
     L.dense_cap = do_glcm ? max_area : 0;
-    L.dense = off; off = align16(off + 2u * L.dense_cap);
+    L.dense = off;
+    if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    off = align16(off + 2u * L.dense_cap);
     if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         L.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0;
         L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 8));
-        const size_t cap = roi_features_max_lds();
-        auto need = [&](uint32_t ng, uint32_t app) -> size_t {
-            return (size_t)off + align16(4u * app * ng * ng) + 8ull * (25ull * ng + 128);
+        auto glcm_bytes = [&](uint32_t ng, uint32_t app) -> size_t {
+            return (size_t)align16(4u * app * ng * ng) + 8ull * (25ull * ng + 128);
         };
         uint32_t ng;
         if (greyInfo != 0) {
             ng = (uint32_t)abs(greyInfo);
-            if (need(ng, 1) > cap) { why = "GLCM grey depth too large for the LDS-resident co-occurrence matrix"; return false; }
+            if (fixed + 2ull * (L.lvl_cap + 8) + glcm_bytes(ng, 1) > cap) {
+                why = "GLCM grey depth " + std::to_string(ng) + " too large for the LDS-resident co-occurrence matrix";
+                return NYXHIP_ERR_UNSUPPORTED;
+            }
         } else {
             // IBSI: matrix order = max intensity (glcm.cpp:412-419), unknown before the scan;
-            // reserve the largest order that fits, up to 128.
+            // reserve the largest order that fits next to this batch's ROIs, up to 128.
             ng = 128;
-            while (ng > 8 && need(ng, 1) > cap) ng >>= 1;
+            while (ng > 8 && off + glcm_bytes(ng, 1) > cap) ng >>= 1;
         }
         uint32_t app = 4;
-        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || need(ng, app) > cap)) app >>= 1;
+        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || off + glcm_bytes(ng, app) > cap)) app >>= 1;
         L.ng_cap = ng;
         L.app = app;
         L.P = off; off = align16(off + 4u * app * ng * ng);
         L.gscr = off; off = align16(off + 8u * (25u * ng + 128));
     }
     L.total = off;
-    if (L.total > roi_features_max_lds()) {
+    if (L.total > cap) {
         why = "ROI too large for the LDS-resident path (" + std::to_string(L.total) + " B of LDS needed; max_px=" +
               std::to_string(max_px) + ", max_bbox_area=" + std::to_string(max_area) + ")";
-        return false;
+        return NYXHIP_ERR_ROI_TOO_LARGE;
     }
-    return true;
+    return NYXHIP_OK;
 }
 
 __global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
@@ -229,8 +238,8 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     const int n_cols = nyxhip_n_columns(mask, s);
     RoiArgs a;
     memset(&a, 0, sizeof(a));
-    if (!make_layout(mask, s, n_cols, max_px, max_area, a.L, why))
-        return fail(ctx, why.find("grey depth") != std::string::npos ? NYXHIP_ERR_UNSUPPORTED : NYXHIP_ERR_ROI_TOO_LARGE, why);
+    if (int lrc = make_layout(mask, s, n_cols, max_px, max_area, a.L, why))
+        return fail(ctx, lrc, why);
     a.n_roi = b->n_roi;
     a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
     a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;

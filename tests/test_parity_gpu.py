@@ -1,0 +1,138 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle
+(and, when the prebuilt checker travelled, the reference's own classes).
+
+Bar (north_star / BASELINE.md 3.6): bit-exact for label/count/order-statistic features,
+<= 1e-5 relative elsewhere (tests/parity.py)."""
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi, _lib
+from oracle import pyoracle as po
+from tests import fixtures, parity, synth
+
+pytestmark = pytest.mark.gpu
+
+MASK = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+CONFIGS = [(8, False, 4), (64, False, 4), (-16, False, 4), (100, False, 2), (20, True, 4), (24, False, 1)]
+
+
+def _check(ctx, b, mask, s, against_ref=True):
+    names = _lib.column_names(mask, s)
+    G = ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    bad = parity.compare_tables(G, O, names)
+    assert not bad, "\n".join(bad[:20])
+    if against_ref and po.have_ref():
+        R = po.ref_featurize(b, mask, s, n_threads=2)
+        bad = parity.compare_tables(G, R, names)
+        assert not bad, "vs reference classes:\n" + "\n".join(bad[:20])
+    return G
+
+
+@pytest.mark.parametrize("gd,ibsi,na", CONFIGS)
+def test_random_rois_match_oracle(hip_ctx, gd, ibsi, na):
+    rois = synth.random_rois(120, seed=11, slide=True)
+    if ibsi:
+        rois = [dict(r, inten=(np.asarray(r["inten"]) % 9).astype(np.uint32)) for r in rois]
+    s = _abi.default_settings(gd, ibsi)
+    s.glcm_n_angles = na
+    _check(hip_ctx, _abi.batch_from_rois(rois), MASK, s)
+
+
+@pytest.mark.parametrize("mask", [_abi.FAM_INTENSITY, _abi.FAM_GLCM])
+def test_single_family_masks(hip_ctx, mask):
+    s = _abi.default_settings(8)
+    _check(hip_ctx, _abi.batch_from_rois(synth.random_rois(40, seed=5)), mask, s)
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+def test_benchmark_tile(hip_ctx, irregular):
+    """One tile of the metric configuration (config 2+3): 196 ROIs of a 1024^2 tile."""
+    b = synth.tile_batch(1, irregular=irregular)
+    s = _abi.default_settings(8)
+    G = _check(hip_ctx, b, MASK, s)
+    assert G.shape == (196, 185)
+
+
+def test_edge_cases(hip_ctx):
+    """Single pixel, two pixels, constant, all-zero, zero pixels inside, 0xFFFFFFFF."""
+    rois = [
+        dict(x=[5], y=[7], inten=[9]),
+        dict(x=[0, 1], y=[0, 0], inten=[3, 3]),
+        dict(x=[0, 1, 2, 3], y=[0, 0, 0, 0], inten=[0, 0, 0, 0]),
+        dict(x=[0, 1, 2, 0, 1, 2], y=[0, 0, 0, 1, 1, 1], inten=[0, 5, 0, 7, 0, 9]),
+        dict(x=[0, 1, 0, 1], y=[0, 0, 1, 1], inten=[2 ** 32 - 1, 2 ** 32 - 2, 1, 2 ** 31]),
+        dict(x=list(range(64)), y=[0] * 64, inten=[42] * 64),
+        dict(x=[0, 3], y=[0, 3], inten=[1, 200]),          # bbox mostly background
+    ]
+    for gd in (8, -8):
+        s = _abi.default_settings(gd)
+        _check(hip_ctx, _abi.batch_from_rois(rois), MASK, s)
+
+
+def test_reference_golden_fixtures_through_hip(hip_ctx):
+    """The reference's own fixtures (tests/golden/reference_tests.json) through the HIP
+    path at the reference's own tolerances (rel 1e-3 / 1e-2)."""
+    ref = fixtures.reference_tests()
+    r = fixtures.roi_from_triplets(ref["pixels"]["pixelIntensityFeaturesTestData"])
+    r["slide_min"], r["slide_max"] = 0.0, 65535.0
+    b = _abi.batch_from_rois([r])
+    s = _abi.default_settings(24)
+    names = _lib.column_names(_abi.FAM_INTENSITY, s)
+    row = dict(zip(names, hip_ctx.featurize_host(b, _abi.FAM_INTENSITY, s)[0]))
+    for k, v in ref["goldens"]["firstorder_2d_matlab_ref_vals"].items():
+        if k != "UNIFORMITY":
+            assert abs(row[k] - v) <= abs(v) / 1000.0, (k, row[k], v)
+    # GLCM regression (matlab binning, 100 levels) and IBSI consensus values
+    for gold, s in (("glcm_2d_regression_ref_vals", _abi.default_settings(100)),
+                    ("glcm_2d_ibsi_ref_vals", _abi.default_settings(0, ibsi=True))):
+        s.glcm_grey_depth = s.grey_depth
+        s.grey_depth = s.grey_depth or 1  # histogram bins unused for GLCM-only
+        T = hip_ctx.featurize_host(fixtures.ibsi_phantom_batch(ref), _abi.FAM_GLCM, s)
+        gn = _lib.column_names(_abi.FAM_GLCM, s)
+        for k, v in ref["goldens"][gold].items():
+            cols = [i for i, n in enumerate(gn) if n in (f"{k}_0", f"{k}_45", f"{k}_90", f"{k}_135")]
+            got = T[:, cols].sum() / 16.0
+            assert abs(got - v) <= abs(v) / 100.0, (gold, k, got, v)
+
+
+def test_device_resident_async_path(hip_ctx):
+    """Device pointers + async launch on torch's current stream (the bench path)."""
+    import torch
+    b = synth.tile_batch(2)
+    s = _abi.default_settings(8)
+    ncol = hip_ctx.n_columns(MASK, s)
+    dev = {k: torch.from_numpy(getattr(b, k).view(np.int16 if getattr(b, k).dtype == np.uint16 else
+                                                  np.int32 if getattr(b, k).dtype == np.uint32 else np.int64)).cuda()
+           for k in ("px_offset", "x", "y", "inten", "bbox_w", "bbox_h", "min_inten", "max_inten")}
+    out = torch.empty((b.n_roi, ncol), dtype=torch.float64, device="cuda")
+    cb = _abi.Batch()
+    cb.n_roi = b.n_roi
+    for k, t in dev.items():
+        setattr(cb, k, t.data_ptr())
+    cb.memory = _abi.MEM_DEVICE
+    hip_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)  # extrema derived on device
+        hip_ctx.sync()
+    finally:
+        hip_ctx._lib.nyxhip_set_stream(hip_ctx._h, None)
+        hip_ctx._lib.nyxhip_set_stream  # keep user-stream mode: NULL = default stream
+    G = out.cpu().numpy()
+    O = po.oracle_featurize(b, MASK, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(MASK, s))
+
+
+def test_roi_too_large_is_reported(hip_ctx):
+    n = 70000  # > LDS capacity for the sort buffer (2^17 * 4 B)
+    rois = [dict(x=np.arange(n) % 300, y=np.arange(n) // 300, inten=np.arange(n) % 1000 + 1)]
+    with pytest.raises(_lib.NyxHipError) as ei:
+        hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK, _abi.default_settings(8))
+    assert ei.value.code == 5
+
+
+def test_unimplemented_family_is_an_error_not_a_fallback(hip_ctx):
+    b = _abi.batch_from_rois(synth.random_rois(3))
+    with pytest.raises(_lib.NyxHipError) as ei:
+        hip_ctx.featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(8))
+    assert ei.value.code == 4
