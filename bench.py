@@ -103,6 +103,7 @@ def main():
     cb.slide_min = None; cb.slide_max = None
     cb.memory = _abi.MEM_DEVICE
     cb.max_px = n_px_roi; cb.max_bbox_area = side * side
+    cb.max_inten_range = int((mx - mn).max().item())
 
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)       # kernels + events on torch's current stream

@@ -14,7 +14,8 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnyxhip.so")
+# NYXHIP_LIB selects another build of the same ABI (e.g. the stamped diagnostic build)
+LIB_PATH = os.environ.get("NYXHIP_LIB") or os.path.join(_HERE, "libnyxhip.so")
 
 # every symbol include/nyxhip.h declares
 ABI_SYMBOLS = [

@@ -11,8 +11,9 @@
 namespace nyxhip {
 
 // helpers/helpers.h:283-330 fast_log10(): float32 quadratic fit of log2 on the
-// significand + integer exponent, scaled to log10 in double.  Bit-for-bit.
-__device__ __forceinline__ double fast_log10(double _x)
+// significand + integer exponent.  fast_log2f() is that function up to (and bit-for-bit
+// including) its float `lg2`; the reference then returns lg2 * 0.30102999566.
+__device__ __forceinline__ float fast_log2f(double _x)
 {
     float x = (float)_x;
     const float a = -.6296735f;
@@ -31,15 +32,21 @@ __device__ __forceinline__ double fast_log10(double _x)
     // fexp + a*signif*signif + b*signif, left to right, no FMA
     float t1 = __fmul_rn(__fmul_rn(a, signif), signif);
     float t2 = __fmul_rn(b, signif);
-    float lg2 = __fadd_rn(__fadd_rn(fexp, t1), t2);
-    return (double)lg2 * 0.30102999566;
+    return __fadd_rn(__fadd_rn(fexp, t1), t2);
+}
+__device__ __forceinline__ double fast_log10(double _x)
+{
+    return (double)fast_log2f(_x) * 0.30102999566;
 }
 
-// x * fast_log10(x + eps) / LOG10_2 as written throughout features/glcm.cpp
-// (EPSILON glcm.h:250, LOG10_2 glcm.h:242).
+// The GLCM code always uses the form  p * fast_log10(arg + EPSILON) / LOG10_2
+// (EPSILON glcm.h:250, LOG10_2 = 0.30102999566 glcm.h:242), i.e. it scales lg2 by the
+// constant and divides it out again.  (lg2*c)/c equals lg2 to within 1 ulp of double, so
+// the product p * lg2 is used directly: one multiply instead of mul + mul + fp64 divide,
+// at a relative deviation <= 2.3e-16 from the reference expression.
 __device__ __forceinline__ double plogp(double p, double arg)
 {
-    return p * fast_log10(arg + 0.000000001) / 0.30102999566;
+    return p * (double)fast_log2f(arg + 0.000000001);
 }
 
 // features/texture_feature.h:106-118 to_grayscale_radiomix

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -22,7 +23,8 @@ struct nyxhip_ctx {
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
     int* d_status = nullptr;
-    uint32_t* d_extrema = nullptr; // [2]
+    uint32_t* d_extrema = nullptr; // [3]
+    unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
     // grow-only device staging for host-memory batches
     void* d_stage = nullptr;
@@ -123,7 +125,7 @@ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 // NYXHIP_ERR_UNSUPPORTED when the grey depth alone cannot be held in LDS, or
 // NYXHIP_ERR_ROI_TOO_LARGE when the batch extrema do not fit the 160 KiB of a CU.
 int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
-                LdsLayout& L, std::string& why)
+                uint32_t max_range, LdsLayout& L, std::string& why)
 {
     memset(&L, 0, sizeof(L));
     const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
@@ -136,10 +138,23 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     uint32_t n_hist = (uint32_t)abs(s->grey_depth);
     L.lbc = off; off = align16(off + 4u * (do_int ? n_hist + 8 : 8));
     const uint32_t fixed = off;               // everything that does not scale with the ROI
-    L.sort_cap = do_int ? pow2ceil(max_px ? max_px : 1) : 0;
-    L.val = off;
-    if (4ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident sort buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    off = align16(off + 4u * L.sort_cap);
+    // order-statistics engine (roi_features.hip): a counting table over [min, max] when the
+    // batch's largest intensity range fits kCountCapMax entries -- then no ROI sorts and the
+    // value buffer needs no power-of-two padding; otherwise ROIs with a small range still
+    // count (table of kCountCapMixed) and the rest bitonic-sort a padded buffer.
+    constexpr uint32_t kCountCapMax = 16384, kCountCapMixed = 4096;
+    if (do_int) {
+        if ((uint64_t)max_range + 1 <= kCountCapMax) {
+            L.count_cap = (max_range + 1 + 63u) & ~63u;
+            L.sort_cap = max_px ? max_px : 1;
+        } else {
+            L.count_cap = kCountCapMixed;
+            L.sort_cap = pow2ceil(max_px ? max_px : 1);
+        }
+    }
+    // [val | cnt] is dead once the intensity block has finished, so the GLCM matrices and
+    // their scratch alias the same bytes (the kernel separates the two uses by barriers);
+    // the dense plane is written during the load phase and stays separate.
     L.dense_cap = do_glcm ? max_area : 0;
     L.dense = off;
     if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
@@ -148,6 +163,14 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         L.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0;
         L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 8));
+    }
+    const uint32_t shared0 = off;
+    L.val = off;
+    if (4ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    off = align16(off + 4u * L.sort_cap);
+    L.cnt = off; off = align16(off + 4u * L.count_cap);
+    if (do_glcm) {
+        const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         auto glcm_bytes = [&](uint32_t ng, uint32_t app) -> size_t {
             return (size_t)align16(4u * app * ng * ng) + 8ull * (25ull * ng + 128);
         };
@@ -162,14 +185,16 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
             // IBSI: matrix order = max intensity (glcm.cpp:412-419), unknown before the scan;
             // reserve the largest order that fits next to this batch's ROIs, up to 128.
             ng = 128;
-            while (ng > 8 && off + glcm_bytes(ng, 1) > cap) ng >>= 1;
+            while (ng > 8 && shared0 + glcm_bytes(ng, 1) > cap) ng >>= 1;
         }
         uint32_t app = 4;
-        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || off + glcm_bytes(ng, app) > cap)) app >>= 1;
+        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || shared0 + glcm_bytes(ng, app) > cap)) app >>= 1;
         L.ng_cap = ng;
         L.app = app;
-        L.P = off; off = align16(off + 4u * app * ng * ng);
-        L.gscr = off; off = align16(off + 8u * (25u * ng + 128));
+        uint32_t goff = shared0;
+        L.P = goff; goff = align16(goff + 4u * app * ng * ng);
+        L.gscr = goff; goff = align16(goff + 8u * (25u * ng + 128));
+        if (goff > off) off = goff;
     }
     L.total = off;
     if (L.total > cap) {
@@ -181,22 +206,25 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
 }
 
 __global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
-                                     uint32_t* out2)
+                                     const uint32_t* mn, const uint32_t* mx, uint32_t* out3)
 {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint32_t n = 0, a = 0;
+    uint32_t n = 0, a = 0, r = 0;
     if (i < n_roi) {
         n = (uint32_t)(px_offset[i + 1] - px_offset[i]);
         a = bw[i] * bh[i];
+        r = mx[i] - mn[i];
     }
     for (int off = 32; off > 0; off >>= 1) {
-        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64);
+        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64), orr = __shfl_down(r, off, 64);
         n = on > n ? on : n;
         a = oa > a ? oa : a;
+        r = orr > r ? orr : r;
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&out2[0], n);
-        atomicMax(&out2[1], a);
+        atomicMax(&out3[0], n);
+        atomicMax(&out3[1], a);
+        atomicMax(&out3[2], r);
     }
 }
 
@@ -232,19 +260,20 @@ int check_status(nyxhip_ctx* ctx)
 
 // Launch on device-resident arrays.
 int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                  size_t ld, uint32_t max_px, uint32_t max_area)
+                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range)
 {
     std::string why;
     const int n_cols = nyxhip_n_columns(mask, s);
     RoiArgs a;
     memset(&a, 0, sizeof(a));
-    if (int lrc = make_layout(mask, s, n_cols, max_px, max_area, a.L, why))
+    if (int lrc = make_layout(mask, s, n_cols, max_px, max_area, max_range, a.L, why))
         return fail(ctx, lrc, why);
     a.n_roi = b->n_roi;
     a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
     a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
     a.slide_min = b->slide_min; a.slide_max = b->slide_max;
     a.out = d_out; a.ld = ld; a.status = ctx->d_status;
+    a.stamps = ctx->d_stamps;
     a.mask = mask; a.n_cols = n_cols;
     int c = 0;
     a.col_intensity = a.col_glcm = -1;
@@ -337,9 +366,13 @@ int nyxhip_init(int device, nyxhip_ctx** out_ctx)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_extrema, 2 * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_extrema, 4 * sizeof(uint32_t)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, NYXHIP_ERR_HIP, "failed to create the device context");
+    }
+    if (getenv("NYXHIP_STAMPS")) { // diagnostic builds only; never set in production
+        if (hipMalloc((void**)&ctx->d_stamps, 32 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(ctx->d_stamps, 0, 32 * sizeof(unsigned long long));
     }
     *out_ctx = ctx;
     return NYXHIP_OK;
@@ -354,6 +387,16 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
+    if (ctx->d_stamps) {
+        unsigned long long h[32];
+        if (hipMemcpy(h, ctx->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 32; i++) tot += h[i];
+            for (int i = 0; i < 32; i++)
+                if (h[i]) fprintf(stderr, "[nyxhip stamp] phase %2d: %14llu cycles  %5.1f %%\n", i, h[i], 100.0 * (double)h[i] / (double)tot);
+        }
+        (void)hipFree(ctx->d_stamps);
+    }
     delete ctx;
 }
 
@@ -402,19 +445,21 @@ int nyxhip_featurize_batch_async(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_
         return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the async form takes device-resident batches only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->n_roi == 0) return NYXHIP_OK;
-    uint32_t max_px = b->max_px, max_area = b->max_bbox_area;
+    uint32_t max_px = b->max_px, max_area = b->max_bbox_area, max_range = b->max_inten_range;
     if (max_px == 0 || max_area == 0) {
         hipStream_t st = ctx->stream();
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 3 * sizeof(uint32_t), st));
         unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
-        hipLaunchKernelGGL(batch_extrema_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, ctx->d_extrema);
-        uint32_t h[2];
+        hipLaunchKernelGGL(batch_extrema_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h,
+                           b->min_inten, b->max_inten, ctx->d_extrema);
+        uint32_t h[3];
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_extrema, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         max_px = h[0];
         max_area = h[1];
+        max_range = h[2];
     }
-    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area);
+    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area, max_range);
 }
 
 int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
@@ -433,7 +478,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
 
     // host batch: derive extrema, stage SoA arrays into one device slab, run, copy the table back
     const uint64_t nr = b->n_roi, npx = b->px_offset[nr];
-    uint32_t max_px = 0, max_area = 0;
+    uint32_t max_px = 0, max_area = 0, max_range = 0;
     for (uint64_t r = 0; r < nr; r++) {
         if (b->px_offset[r + 1] < b->px_offset[r]) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "px_offset is not monotone");
         uint64_t n = b->px_offset[r + 1] - b->px_offset[r];
@@ -441,6 +486,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
         if (n > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "ROI exceeds 2^32 pixels");
         if (n > max_px) max_px = (uint32_t)n;
         if (a > max_area) max_area = (uint32_t)a;
+        if (b->max_inten[r] - b->min_inten[r] > max_range) max_range = b->max_inten[r] - b->min_inten[r];
     }
     const int n_cols = nyxhip_n_columns(mask, s);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -473,7 +519,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
     d.slide_min = b->slide_min ? (const double*)(base + o_smin) : nullptr;
     d.slide_max = b->slide_max ? (const double*)(base + o_smax) : nullptr;
     double* d_out = (double*)(base + o_out);
-    rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area);
+    rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area, max_range);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy2DAsync(out, ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
                                   (size_t)n_cols * sizeof(double), nr, hipMemcpyDeviceToHost, st));

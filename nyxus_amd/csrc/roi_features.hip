@@ -4,10 +4,12 @@
 // HBM exactly once (coalesced SoA streams x:u16, y:u16, inten:u32) and everything
 // else happens in LDS:
 //
-//   * intensities are staged into an LDS array and bitonic-sorted in place; all
-//     first-order statistics (moments, percentile/n-bin histograms by binary search
-//     on the sorted array, exact median, exact mode, robust/median absolute
-//     deviations) are computed from that one resident copy
+//   * intensities are staged into an LDS array; order statistics come from one of two
+//     LDS-resident engines chosen per ROI: a counting table over [min, max] (LDS
+//     atomics + wave-scan prefix sums) when the intensity range fits, else an in-place
+//     bitonic sort.  Exact median, exact mode, the 100-bin percentile histogram and the
+//     n-bin histogram are all read off that engine by binary search; moments and the
+//     robust / median absolute deviations are further passes over the resident copy
 //       -> replaces PixelIntensityFeatures::calculate
 //          (/root/reference/src/nyx/features/intensity.cpp:57-192), TrivialHistogram
 //          (features/histogram.h:27-309) and Moments4 (features/moments.h:48-109);
@@ -52,7 +54,7 @@ __constant__ int c_glcm_ave_order[kGlcmAve] = {
     G_SUMENTROPY, G_SUMVARIANCE};
 
 // slots of the block-wide scalar array s_stat
-enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MEAN1090, S_POP1090, S_NG, S_SKIP_GLCM, S_MODEKEY_LO, S_MODEKEY_HI };
+enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MODE, S_NG };
 
 // Lanes of one wave exchange data through LDS without a workgroup barrier: LDS
 // instructions of a wave execute in issue order, so only the compiler has to be
@@ -114,6 +116,11 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 // P: Ng*Ng counts, P[center*Ng + neighbour]  (== SimpleMatrix::xy(a,b)++ with a =
 //    neighbour level, b = centre level, glcm.cpp:437-472; xy(x,y) = [y*W+x]).
 // Iv: level values I[] (glcm.cpp:388-420).  scr: 6*Ng doubles.  f: 30 outputs.
+//
+// Numerics: marginals and the x+y / |x-y| distributions are formed from exact integer
+// count sums and divided by sum_p once (the reference sums the already divided
+// elements, glcm.cpp:503-508, :523-525: same value to ~1e-16 relative); matrix-wide sums
+// are lane-strided partial sums combined by a shuffle tree (deterministic order).
 __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, double* scr,
                                    double soft_nan, double* f, int lane)
 {
@@ -136,45 +143,40 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     double* prow = scr + Ng;      // py[j] = sum_i xy(i,j)/sum_p
     double* Pxpy = scr + 2 * Ng;  // [2Ng]  glcm.cpp:503-508
     double* Pxmy = scr + 4 * Ng;  // [Ng]
-    double* dvar = scr + 5 * Ng;  // [Ng]   f_dvar's var[k]
 
-    // marginals and the x+y / |x-y| distributions; each lane owns whole entries and
-    // accumulates in the reference's loop order, so these are bit-identical to it.
     for (int i = lane; i < Ng; i += 64) {
-        double a = 0;
-        for (int j = 0; j < Ng; j++)
-            a += (double)P[j * Ng + i] / sum_p;
-        pcol[i] = a;
-        double b = 0;
-        for (int j = 0; j < Ng; j++)
-            b += (double)P[i * Ng + j] / sum_p;
-        prow[i] = b;
-        // |x-y| = i : visiting order of calculatePxpmy is x outer, y inner
-        double d = 0;
-        for (int x = 0; x < Ng; x++) {
-            if (x - i >= 0)
-                d += (double)P[x * Ng + (x - i)] / sum_p;
-            if (i > 0 && x + i < Ng)
-                d += (double)P[x * Ng + (x + i)] / sum_p;
+        uint32_t cc = 0, rc = 0, dc = 0;
+        for (int j = 0; j < Ng; j++) {
+            cc += P[j * Ng + i];
+            rc += P[i * Ng + j];
         }
-        Pxmy[i] = d;
+        for (int x = i; x < Ng; x++) { // |x-y| = i
+            dc += P[x * Ng + (x - i)];
+            if (i > 0)
+                dc += P[(x - i) * Ng + x];
+        }
+        pcol[i] = (double)cc / sum_p;
+        prow[i] = (double)rc / sum_p;
+        Pxmy[i] = (double)dc / sum_p;
     }
     for (int k = lane; k < 2 * Ng; k += 64) {
-        double a = 0;
+        uint32_t c = 0;
         int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
         for (int x = x0; x <= x1; x++)
-            a += (double)P[x * Ng + (k - x)] / sum_p;
-        Pxpy[k] = a;
+            c += P[x * Ng + (k - x)];
+        Pxpy[k] = (double)c / sum_p;
     }
     wave_sync();
 
-    // by_row_mean (glcm.cpp:531-536), sequential; every lane computes the same value
+    // by_row_mean (glcm.cpp:531-536)
     double brm = 0;
-    for (int i = 0; i < Ng; ++i)
+    for (int i = lane; i < Ng; i += 64)
         brm += pcol[i] * Iv[i];
+    brm = wave_sum(brm);
+    brm = __shfl(brm, 0, 64);
 
     // ---- pass 1 over matrix elements -------------------------------------------------
-    double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis = 0, hom2 = 0, jmax = -1;
+    double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis_n = 0, hom2 = 0, jmax = -1;
     for (int e = lane; e < NN; e += 64) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
@@ -189,16 +191,30 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         int adiff = r > c ? r - c : c - r;
         hom1 += p / (1.0 + (double)adiff);           // f_homogeneity :942
         ent += plogp(p, p);                          // f_entropy :734-735, JE :1160-1161, HXY :868
-        dis += (double)adiff * cnt / sum_p;          // f_GLCM_DIS :1052
+        dis_n += (double)adiff * cnt;                // f_GLCM_DIS :1052 (integer-exact numerator)
         hom2 += p / (1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
         jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
     }
     asm_ = wave_sum(asm_); contrast_n = wave_sum(contrast_n); S_r = wave_sum(S_r); S_c = wave_sum(S_c);
-    acor_n = wave_sum(acor_n); hom1 = wave_sum(hom1); ent = wave_sum(ent); dis = wave_sum(dis);
+    acor_n = wave_sum(acor_n); hom1 = wave_sum(hom1); ent = wave_sum(ent); dis_n = wave_sum(dis_n);
     hom2 = wave_sum(hom2); jmax = wave_max(jmax);
     S_r = __shfl(S_r, 0, 64);
     S_c = __shfl(S_c, 0, 64);
     const double mr = S_r / sum_p, mc = S_c / sum_p; // mr == f_var's mean == JAVE (exact numerators)
+    if (lane == 0) { // results leave the registers as soon as they exist
+        f[G_ASM] = asm_;
+        f[G_ENERGY] = asm_;
+        f[G_CONTRAST] = contrast_n / sum_p;
+        f[G_ACOR] = acor_n / sum_p;
+        f[G_HOM1] = hom1;
+        f[G_HOM2] = hom2;
+        f[G_ENTROPY] = -ent;
+        f[G_JE] = -ent;
+        f[G_DIS] = dis_n / sum_p;
+        f[G_JMAX] = jmax;
+        f[G_JAVE] = mr;
+    }
+    ent = __shfl(ent, 0, 64);
 
     // ---- pass 2: central quantities ---------------------------------------------------
     double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
@@ -210,90 +226,75 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         double dr = ir - mr, dc = ic - mc;
         s2r += p * dr * dr;                           // f_corr :617
         s2c += p * dc * dc;                           // :626
-        tmp1 += dr * dc * cnt / sum_p;                // :633
+        tmp1 += dr * dc * p;                          // :633
         var_n += dr * dr * cnt;                       // f_var :672
-        double m = ir + ic - brm - brm;               // CLUPROM :985, CLUSHADE :1007
-        cprom += m * m * m * m * cnt / sum_p;
-        cshade += m * m * m * cnt / sum_p;
-        double m2 = ic + ir - brm * 2.0;              // CLUTEND :1034 (xy(x,y): x = column)
-        ctend += m2 * m2 * cnt / sum_p;
+        double m = ir + ic - brm - brm;               // CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+        double m2 = m * m;
+        cprom += m2 * m2 * p;
+        cshade += m2 * m * p;
+        ctend += m2 * p;
         double dj = (double)(c + 1) - mr;             // f_GLCM_JVAR :1196-1199 (x = column, +1 index)
-        jvar += dj * dj * cnt / sum_p;
+        jvar += dj * dj * p;
         double pp = pcol[c] * prow[r];                // px[i]*py[j], i = column, j = row (:869, :909)
-        double lg = fast_log10(pp + 0.000000001);
-        hxy1 += p * lg / 0.30102999566;
-        hxy2 += pp * lg / 0.30102999566;
+        double lg = (double)fast_log2f(pp + 0.000000001);
+        hxy1 += p * lg;
+        hxy2 += pp * lg;
     }
     s2r = wave_sum(s2r); s2c = wave_sum(s2c); tmp1 = wave_sum(tmp1); var_n = wave_sum(var_n);
     cprom = wave_sum(cprom); cshade = wave_sum(cshade); ctend = wave_sum(ctend); jvar = wave_sum(jvar);
     hxy1 = wave_sum(hxy1); hxy2 = wave_sum(hxy2);
-
-    // difference average (glcm.cpp:786-795); kValuesDiff[k] = |I[Ng-1] - I[Ng-1-k]| is the
-    // last pair written by calculatePxpmy (:512); every lane computes it (needed by dvar).
-    double diffAvg = 0;
-    for (int k = 0; k < Ng; k++)
-        diffAvg += (k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k])) * Pxmy[k];
-    // f_dvar (glcm.cpp:742-766): var[k] receives the same term Ng times
-    for (int k = lane; k < Ng; k += 64) {
-        double dk = (double)k - diffAvg;
-        double t = dk * dk * Pxmy[k], a = 0;
-        for (int x = 0; x < Ng; x++)
-            a += t;
-        dvar[k] = a;
-    }
-    wave_sync();
-
     if (lane == 0) {
-        f[G_ASM] = asm_;
-        f[G_ENERGY] = asm_;
-        f[G_CONTRAST] = contrast_n / sum_p;
-        f[G_ACOR] = acor_n / sum_p;
-        f[G_HOM1] = hom1;
-        f[G_HOM2] = hom2;
-        f[G_ENTROPY] = -ent;
-        f[G_JE] = -ent;
-        f[G_DIS] = dis;
-        f[G_JMAX] = jmax;
-        f[G_JAVE] = mr;
         f[G_VARIANCE] = var_n / sum_p;
         f[G_CLUPROM] = cprom;
         f[G_CLUSHADE] = cshade;
         f[G_CLUTEND] = ctend;
         f[G_SUMVARIANCE] = ctend;                     // glcm.cpp:323-326
         f[G_JVAR] = jvar;
-        {   // f_corr tail, glcm.cpp:619-643
-            double denom = sqrt(s2r) * sqrt(s2c);
-            f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : tmp1 / denom;
-        }
-        // 1-D features, sequential in the reference's order
-        double idm = 0, savg = 0, sent = 0, dent = 0, idmn = 0, id = 0, idn = 0, iv = 0, hx = 0, dv = 0;
-        const double Ng2 = (double)Ng * (double)Ng;
-        for (int k = 0; k < Ng; ++k) {
-            double q = Pxmy[k];
-            idm += q / (double)(1 + (k * k));                        // f_idm :685-687
-            if (q != 0)
-                dent += plogp(q, q);                                 // f_dentropy :778-781
-            idmn += q / (1.0 + ((double)k * (double)k) / Ng2);       // :1083-1084
-            id += q / (1.0 + (double)k);                             // :1096-1097
-            idn += q / (1.0 + (double)k / (double)Ng);               // :1110-1111
-            if (k >= 1) {
-                double kval = fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
-                iv += q / (kval * kval);                             // :1123-1128
-            }
-            hx += plogp(pcol[k], pcol[k]);                           // :873-874
-            dv += dvar[k];
-        }
-        for (int k = 0; k < 2 * Ng; k++) {
-            double q = Pxpy[k];
-            // kValuesSum[k] = I[x]+I[y] of the last (x,y) with x+y = k (:511): x = min(k, Ng-1)
-            double ks = 0;
-            if (k <= 2 * Ng - 2) {
-                int x = k < Ng - 1 ? k : Ng - 1;
-                ks = Iv[x] + Iv[k - x];
-            }
-            savg += ks * q;                                          // f_savg :700-701
-            sent += plogp(q, q);                                     // f_sentropy :712-716
-        }
+        double denom = sqrt(s2r) * sqrt(s2c);         // f_corr tail, glcm.cpp:619-643
+        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : tmp1 / denom;
+        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2 + ent)))); // glcm.cpp:913 (HXY = ent)
+    }
+
+    // ---- 1-D features over p_{x-y} (k < Ng) and p_{x+y} (k < 2Ng), lanes over k ----------
+    // kValuesDiff[k] = |I[Ng-1] - I[Ng-1-k]| and kValuesSum[k] = I[min(k,Ng-1)] + I[k - min(k,Ng-1)]
+    // are the last pairs calculatePxpmy writes (glcm.cpp:511-512).
+    double idm = 0, dent = 0, idmn = 0, id = 0, idn = 0, iv = 0, hx = 0, davg = 0;
+    const double Ng2 = (double)Ng * (double)Ng;
+    for (int k = lane; k < Ng; k += 64) {
+        double q = Pxmy[k];
+        double kval = k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
+        idm += q / (double)(1 + (k * k));                        // f_idm :685-687
+        if (q != 0)
+            dent += plogp(q, q);                                 // f_dentropy :778-781
+        idmn += q / (1.0 + ((double)k * (double)k) / Ng2);       // :1083-1084
+        id += q / (1.0 + (double)k);                             // :1096-1097
+        idn += q / (1.0 + (double)k / (double)Ng);               // :1110-1111
+        if (k >= 1)
+            iv += q / (kval * kval);                             // :1123-1128
+        hx += plogp(pcol[k], pcol[k]);                           // :873-874
+        davg += kval * q;                                        // f_difference_avg :791-792
+    }
+    idm = wave_sum(idm); dent = wave_sum(dent); idmn = wave_sum(idmn); id = wave_sum(id);
+    idn = wave_sum(idn); iv = wave_sum(iv); hx = wave_sum(hx); davg = wave_sum(davg);
+    const double diffAvg = __shfl(davg, 0, 64);
+    double savg = 0, sent = 0, dv = 0;
+    for (int k = lane; k < 2 * Ng - 1; k += 64) {
+        double q = Pxpy[k];
+        int x = k < Ng - 1 ? k : Ng - 1;
+        savg += (Iv[x] + Iv[k - x]) * q;                         // f_savg :700-701
+        sent += plogp(q, q);                                     // f_sentropy :712-716
+    }
+    for (int k = lane; k < Ng; k += 64) {
+        // f_dvar (glcm.cpp:742-766): var[k] receives the same term Ng times, total / Ng
+        double dk = (double)k - diffAvg;
+        double t = dk * dk * Pxmy[k], a = 0;
+        for (int x = 0; x < Ng; x++)
+            a += t;
+        dv += a;
+    }
+    savg = wave_sum(savg); sent = wave_sum(sent); dv = wave_sum(dv);
+
+    if (lane == 0) {
         f[G_IDM] = idm;
         f[G_SUMAVERAGE] = savg;
         f[G_SUMENTROPY] = -sent;
@@ -304,14 +305,25 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         f[G_ID] = id;
         f[G_IDN] = idn;
         f[G_IV] = iv;
-        {   // f_info_meas_corr1/2, glcm.cpp:880-883, :913 (HXY = ent here)
-            double r1 = (ent - hxy1) / hx;
-            f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
-            f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2 + ent))));
-        }
+        double r1 = (ent - hxy1) / hx;                // f_info_meas_corr1, glcm.cpp:880-883
+        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
     }
     wave_sync();
 }
+
+// Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
+// workgroup adds the cycles spent between consecutive stamps to A.stamps[phase].  The
+// product build compiles the macro away.
+#ifdef NYX_STAMP
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        unsigned long long t__ = __builtin_readcyclecounter();                            \
+        if (tid == 0 && A.stamps) atomicAdd(&A.stamps[i], t__ - t_prev__);                \
+        t_prev__ = __builtin_readcyclecounter();                                          \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // ---- the fused kernel --------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
@@ -341,12 +353,19 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
     const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0;
     const bool do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
     double* const out_row = A.out + roi * A.ld;
+#ifdef NYX_STAMP
+    unsigned long long t_prev__ = __builtin_readcyclecounter();
+#endif
 
-    // smallest power of two >= n (sort length)
+    // order-statistics engine for this ROI: counting table when [vmin, vmax] fits
+    const uint32_t range = vmax - vmin;
+    const bool use_count = do_int && A.L.count_cap != 0 && range < A.L.count_cap;
+    uint32_t* s_cnt = (uint32_t*)(lds + A.L.cnt);
+    // smallest power of two >= n (sort length of the fallback engine)
     uint32_t P2 = 1;
     while (P2 < n)
         P2 <<= 1;
-    if (n == 0 || (do_int && P2 > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
+    if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
         if (tid == 0 && n != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         for (int c = tid; c < A.n_cols; c += kBlock)
@@ -368,38 +387,64 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
             for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
                 s_lvlmap[i] = 0;
     }
-    if (do_int)
-        for (uint32_t i = n + tid; i < P2; i += kBlock)
-            s_val[i] = 0xFFFFFFFFu;
+    if (do_int) {
+        if (use_count) {
+            for (uint32_t i = tid; i <= range; i += kBlock)
+                s_cnt[i] = 0;
+        } else {
+            for (uint32_t i = n + tid; i < P2; i += kBlock)
+                s_val[i] = 0xFFFFFFFFu;
+        }
+    }
     if (tid < 16)
         s_stat[tid] = 0.0;
     __syncthreads();
 
+    STAMP(0);
     // ---- phase 1: the only pass over HBM ------------------------------------------------
     unsigned long long sum = 0, sumsq = 0;
     uint32_t lvl_max = 0;
-    for (uint32_t i = tid; i < n; i += kBlock) {
-        uint32_t v = A.inten[off + i];
-        if (do_int) {
-            s_val[i] = v;
-            sum += v;
-            sumsq += (uint32_t)(v * v); // unsigned-int product, wraps (intensity.cpp:90)
+    // four pixels per thread per trip: all global loads of a trip are issued before the first
+    // use, so one HBM round trip covers 1024 pixels of the workgroup
+    constexpr int kU = 4;
+    for (uint32_t base = 0; base < n; base += kU * kBlock) {
+        uint32_t v[kU], px[kU], py[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            uint32_t i = base + u * kBlock + tid;
+            bool ok = i < n;
+            v[u] = ok ? A.inten[off + i] : 0u;
+            px[u] = (ok && do_glcm) ? (uint32_t)A.x[off + i] : 0u;
+            py[u] = (ok && do_glcm) ? (uint32_t)A.y[off + i] : 0u;
         }
-        if (do_glcm) {
-            uint32_t px = A.x[off + i], py = A.y[off + i];
-            uint32_t lvl = 0;
-            if (v != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
-                lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo)
-                    : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
-                if (greyInfo < 0)
-                    s_lvlmap[lvl] = 1;
-                lvl_max = lvl > lvl_max ? lvl : lvl_max;
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            uint32_t i = base + u * kBlock + tid;
+            if (i >= n)
+                continue;
+            if (do_int) {
+                s_val[i] = v[u];
+                sum += v[u];
+                sumsq += (uint32_t)(v[u] * v[u]); // unsigned-int product, wraps (intensity.cpp:90)
+                if (use_count)
+                    atomicAdd(&s_cnt[v[u] - vmin], 1u);
             }
-            if (px < w && py < h)
-                s_dense[py * w + px] = (uint16_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+            if (do_glcm) {
+                uint32_t lvl = 0;
+                if (v[u] != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
+                    lvl = greyInfo > 0 ? bin_matlab(v[u], mslope, greyInfo)
+                        : greyInfo < 0 ? bin_radiomix(v[u], vmin, vmax, -greyInfo) : v[u];
+                    if (greyInfo < 0)
+                        s_lvlmap[lvl] = 1;
+                    lvl_max = lvl > lvl_max ? lvl : lvl_max;
+                }
+                if (px[u] < w && py[u] < h)
+                    s_dense[py[u] * w + px[u]] = (uint16_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+            }
         }
     }
 
+    STAMP(1);
     // =====================================================================================
     // first-order intensity
     // =====================================================================================
@@ -414,16 +459,100 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
             s_red[wave * 8 + 0] = (double)sum;
             s_red[wave * 8 + 1] = (double)sumsq;
         }
-        __syncthreads();
+        __syncthreads(); // also: every s_val / s_cnt write of phase 1 is visible
         double tot = 0, totsq = 0;
         for (int wv = 0; wv < kWaves; wv++) {
             tot += s_red[wv * 8 + 0];
             totsq += s_red[wv * 8 + 1];
         }
         const double mean = tot / dn;
+        const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
         __syncthreads();
+        STAMP(2);
 
-        bitonic_sort(s_val, P2, tid);
+        const double binW100 = (double)range / 100.;
+        const uint32_t nb = (uint32_t)A.n_hist;
+        // count of values strictly below the first value whose bin index reaches b; `pred`
+        // is the bin index of a value, monotone in the value (histogram.h:55-66, :69-78)
+        auto idx100 = [=](uint32_t v) -> int {
+            double realIdx = (double)(v - vmin) / binW100;
+            return (realIdx != realIdx) ? 0 : (int)realIdx;
+        };
+
+        // Q = entries of the counting table scanned per wave (multiple of 256)
+        const uint32_t Q = ((range + 1 + kWaves * 256 - 1) / (kWaves * 256)) * 256;
+        uint32_t woff1 = 0, woff2 = 0, woff3 = 0; // prefix offsets of waves 1..3 (wave 0 starts at 0)
+        if (use_count) {
+            // ---- counting engine: per-wave inclusive prefix sums over s_cnt, in place (each
+            // lane owns 4 consecutive entries of a 256-entry tile: one 16-byte LDS access each
+            // way and one 6-step shuffle scan per tile); the mode (largest count, smallest value
+            // on ties: histogram.h:289-309) falls out of the same sweep
+            uint32_t carry = 0, best_c = 0, best_i = 0;
+            const uint32_t base = wave * Q;
+            for (uint32_t t = 0; t < Q; t += 256) {
+                uint32_t i = base + t + 4 * lane;
+                uint4 c4 = make_uint4(0, 0, 0, 0);
+                if (i + 3 <= range)
+                    c4 = *(const uint4*)&s_cnt[i];
+                else {
+                    if (i <= range) c4.x = s_cnt[i];
+                    if (i + 1 <= range) c4.y = s_cnt[i + 1];
+                    if (i + 2 <= range) c4.z = s_cnt[i + 2];
+                }
+                if (c4.x > best_c) { best_c = c4.x; best_i = i; }
+                if (c4.y > best_c) { best_c = c4.y; best_i = i + 1; }
+                if (c4.z > best_c) { best_c = c4.z; best_i = i + 2; }
+                if (c4.w > best_c) { best_c = c4.w; best_i = i + 3; }
+                c4.y += c4.x; c4.z += c4.y; c4.w += c4.z;
+                uint32_t sc = c4.w;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t up = __shfl_up(sc, d, 64);
+                    if (lane >= d) sc += up;
+                }
+                uint32_t excl = carry + sc - c4.w;
+                c4.x += excl; c4.y += excl; c4.z += excl; c4.w += excl;
+                if (i + 3 <= range)
+                    *(uint4*)&s_cnt[i] = c4;
+                else {
+                    if (i <= range) s_cnt[i] = c4.x;
+                    if (i + 1 <= range) s_cnt[i + 1] = c4.y;
+                    if (i + 2 <= range) s_cnt[i + 2] = c4.z;
+                }
+                carry += __shfl(sc, 63, 64);
+            }
+            // wave-level best (count desc, index asc)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                uint32_t oc = __shfl_down(best_c, d, 64), oi = __shfl_down(best_i, d, 64);
+                if (oc > best_c || (oc == best_c && oi < best_i)) { best_c = oc; best_i = oi; }
+            }
+            if (lane == 0) {
+                s_red[wave * 8 + 0] = (double)carry;
+                s_red[wave * 8 + 1] = (double)best_c;
+                s_red[wave * 8 + 2] = (double)best_i;
+            }
+            __syncthreads();
+            uint32_t mc = 0, mi = 0;
+            for (int wv = 0; wv < kWaves; wv++) {
+                uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
+                if (c > mc) { mc = c; mi = i; } // waves cover ascending value ranges
+            }
+            woff1 = (uint32_t)s_red[0];
+            woff2 = woff1 + (uint32_t)s_red[8];
+            woff3 = woff2 + (uint32_t)s_red[16];
+            if (tid == 0)
+                s_stat[S_MODE] = (double)(vmin + mi);
+            __syncthreads();
+        } else {
+            bitonic_sort(s_val, P2, tid);
+        }
+        STAMP(3);
+        // C(i) = number of values <= vmin + i (counting engine)
+        auto cum = [=](uint32_t i) -> uint32_t {
+            uint32_t wq = i / Q;
+            return s_cnt[i] + (wq == 0 ? 0u : wq == 1 ? woff1 : wq == 2 ? woff2 : woff3);
+        };
 
         // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183;
         // M2..M4 of moments.h:53-74 equal the plain central sums)
@@ -439,74 +568,132 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
             acc[5] += d2 * d2 * d2;
         }
         block_sum<6>(acc, s_red, tid);
-
-        const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
-        const uint32_t range = vmax - vmin;
-        const double binW100 = (double)range / 100.;
-        const uint32_t nb = (uint32_t)A.n_hist;
+        if (tid == 0) { // everything that depends only on the sums leaves the registers now
+            o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
+            o[I_MAX] = (double)vmax;
+            o[I_RANGE] = (double)vmax - (double)vmin;
+            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
+                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
+            o[I_MEAN] = mean;                          // intensity.cpp:95-99
+            o[I_ENERGY] = totsq;
+            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
+            o[I_INTEGRATED_INTENSITY] = tot;
+            const double var = acc[1];                 // intensity.cpp:110-118
+            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
+            const double variance = dn > 1 ? var / (dn - 1) : 0.0;
+            const double variance_b = dn > 1 ? var / dn : 0.0;
+            const double sd = sqrt(variance);
+            o[I_VARIANCE] = variance;
+            o[I_VARIANCE_BIASED] = variance_b;
+            o[I_STANDARD_DEVIATION] = sd;
+            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
+            o[I_COV] = sd / mean;
+            o[I_STANDARD_ERROR] = sd / sqrt(dn);
+            if (!blank) {
+                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
+                const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
+                if (M2 != 0.0) {
+                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / (M2 * sqrt(M2)) : 0.0;   // pow(M2, 1.5)
+                    o[I_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
+                    o[I_EXCESS_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) - 3 : 0.0;
+                }
+                const double sd2 = sd * sd;
+                double denom = dn * (sd2 * sd2 * sd);  // n * pow(sd, 5), intensity.cpp:186-191
+                o[I_HYPERSKEWNESS] = denom == 0. ? 0. : acc[4] / denom;
+                denom = dn * (sd2 * sd2 * sd2);
+                o[I_HYPERFLATNESS] = denom == 0. ? 0. : acc[5] / denom;
+            }
+        }
+        STAMP(4);
 
         if (!blank) {
-            // histogram bin boundaries by binary search over the sorted values:
-            // idx(v) is monotone in v, so count(idx < b) is a lower bound
-            // (histogram.h:55-66 percentile bins, :69-78 n-bin histogram)
+            // histogram bin boundaries: lower bounds found by binary search, over the value
+            // domain (counting engine) or over the sorted array (sort engine)
             for (uint32_t t = tid; t < 100 + nb; t += kBlock) {
-                uint32_t lo = 0, hi = n;
-                if (t < 100) {
-                    while (lo < hi) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        double realIdx = (double)(s_val[mid] - vmin) / binW100;
-                        int idx = (realIdx != realIdx) ? 0 : (int)realIdx;
-                        if (idx < (int)t) lo = mid + 1; else hi = mid;
+                const bool is100 = t < 100;
+                const uint32_t b = is100 ? t : t - 100;
+                uint32_t lo = 0, hi = use_count ? range + 1 : n;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    uint32_t v = use_count ? vmin + mid : s_val[mid];
+                    uint32_t idx = is100 ? (uint32_t)idx100(v) : to_grayscale(v, vmin, range, nb);
+                    if (idx < b) lo = mid + 1; else hi = mid;
+                }
+                uint32_t lb = use_count ? (lo > 0 ? cum(lo - 1) : 0u) : lo;
+                if (is100) s_lb100[b] = lb; else s_lbc[b] = lb;
+            }
+            STAMP(5);
+            if (!use_count) {
+                // mode on the sorted array: longest run, smallest value on ties; every thread
+                // keeps its best run, then a wave / block reduction
+                uint32_t best_c = 0, best_v = 0;
+                for (uint32_t i = tid; i < n; i += kBlock) {
+                    uint32_t v = s_val[i];
+                    if (i == n - 1 || s_val[i + 1] != v) {
+                        uint32_t lo = 0, hi = i;
+                        while (lo < hi) {
+                            uint32_t mid = (lo + hi) >> 1;
+                            if (s_val[mid] < v) lo = mid + 1; else hi = mid;
+                        }
+                        uint32_t c = i - lo + 1;
+                        if (c > best_c || (c == best_c && v < best_v)) { best_c = c; best_v = v; }
                     }
-                    s_lb100[t] = lo;
-                } else {
-                    uint32_t b = t - 100;
-                    while (lo < hi) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        uint32_t idx = to_grayscale(s_val[mid], vmin, range, nb);
-                        if (idx < b) lo = mid + 1; else hi = mid;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    uint32_t oc = __shfl_down(best_c, d, 64), ov = __shfl_down(best_v, d, 64);
+                    if (oc > best_c || (oc == best_c && ov < best_v)) { best_c = oc; best_v = ov; }
+                }
+                if (lane == 0) {
+                    s_red[wave * 8 + 0] = (double)best_c;
+                    s_red[wave * 8 + 1] = (double)best_v;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t mc = 0, mv = 0;
+                    for (int wv = 0; wv < kWaves; wv++) {
+                        uint32_t c = (uint32_t)s_red[wv * 8 + 0], v = (uint32_t)s_red[wv * 8 + 1];
+                        if (c > mc || (c == mc && v < mv)) { mc = c; mv = v; }
                     }
-                    s_lbc[b] = lo;
+                    s_stat[S_MODE] = (double)mv;
                 }
             }
-            // mode (histogram.h:289-309): longest run, smallest value on ties
-            if (tid == 0) {
-                s_stat[S_MODEKEY_LO] = 0;
-            }
-            unsigned long long* s_modekey = (unsigned long long*)&s_stat[S_MODEKEY_LO];
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += kBlock) {
-                uint32_t v = s_val[i];
-                if (i == n - 1 || s_val[i + 1] != v) {
-                    uint32_t lo = 0, hi = i;
-                    while (lo < hi) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if (s_val[mid] < v) lo = mid + 1; else hi = mid;
-                    }
-                    unsigned long long key = ((unsigned long long)(i - lo + 1) << 32) | (unsigned long long)(0xFFFFFFFFu - v);
-                    atomicMax(s_modekey, key);
-                }
-            }
-            __syncthreads();
+            STAMP(6);
 
-            // percentiles: lanes 0..5 of wave 0 each run the 100-bin scan for one of
-            // P01,P10,P25,P75,P90,P99 (histogram.h:214-243; every matching bin overwrites)
+            // three independent reductions run on three different waves
             if (wave == 0) {
-                double pv = 0;
-                if (lane < 6) {
-                    const double frac = lane == 0 ? 0.01 : lane == 1 ? 0.1 : lane == 2 ? 0.25 : lane == 3 ? 0.75 : lane == 4 ? 0.9 : 0.99;
+                // percentiles P01,P10,P25,P75,P90,P99 (histogram.h:214-243): the LAST bin i with
+                // runSum_i <= cnt <= runSum_i + bins_i wins (every matching bin overwrites);
+                // runSum_i is exactly the lower bound of bin i.  Lanes test bins i and i+64.
+                const int i0 = lane, i1 = lane + 64;
+                const uint32_t r0 = s_lb100[i0], e0 = (i0 < 99 ? s_lb100[i0 + 1] : n);
+                const uint32_t r1 = i1 < 100 ? s_lb100[i1] : 0u, e1 = i1 < 100 ? (i1 < 99 ? s_lb100[i1 + 1] : n) : 0u;
+                double pq[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double frac = q == 0 ? 0.01 : q == 1 ? 0.1 : q == 2 ? 0.25 : q == 3 ? 0.75 : q == 4 ? 0.9 : 0.99;
                     const double cnt_p = dn * frac;
-                    uint32_t runSum = 0;
-                    for (int i = 0; i < 100; i++) {
-                        uint32_t bi = (i < 99 ? s_lb100[i + 1] : n) - s_lb100[i];
-                        if ((double)runSum <= cnt_p && cnt_p <= (double)(runSum + bi))
-                            pv = (cnt_p - (double)runSum) * binW100 / (double)bi + (double)vmin + binW100 * (double)i;
-                        runSum += bi;
+                    bool m0 = (double)r0 <= cnt_p && cnt_p <= (double)e0;
+                    bool m1 = i1 < 100 && (double)r1 <= cnt_p && cnt_p <= (double)e1;
+                    unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+                    int win = b1 ? 64 + (63 - __clzll((long long)b1)) : (b0 ? 63 - __clzll((long long)b0) : -1);
+                    double pv = 0;
+                    if (win >= 0) {
+                        uint32_t rs = s_lb100[win], bi = (win < 99 ? s_lb100[win + 1] : n) - rs;
+                        pv = (cnt_p - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)win;
                     }
+                    pq[q] = pv;
                 }
-                double p01 = __shfl(pv, 0, 64), p10 = __shfl(pv, 1, 64), p25 = __shfl(pv, 2, 64),
-                       p75 = __shfl(pv, 3, 64), p90 = __shfl(pv, 4, 64), p99 = __shfl(pv, 5, 64);
-                // entropy / uniformity over the n+1 slots (histogram.h:145-151): slot n is 0
+                if (lane == 0) {
+                    o[I_P01] = pq[0]; o[I_P10] = pq[1]; o[I_P25] = pq[2]; o[I_P75] = pq[3]; o[I_P90] = pq[4]; o[I_P99] = pq[5];
+                    o[I_QCOD] = (pq[3] - pq[2]) / (pq[3] + pq[2]);
+                    o[I_INTERQUARTILE_RANGE] = pq[3] - pq[2];
+                    s_stat[S_P10] = pq[1];
+                    s_stat[S_P90] = pq[4];
+                }
+            } else if (wave == 1) {
+                // entropy / uniformity over the n+1 slots (histogram.h:145-151): slot n is empty
                 double e = 0, u = 0;
                 for (uint32_t k = lane; k < nb; k += 64) {
                     uint32_t ck = (k < nb - 1 ? s_lbc[k + 1] : n) - s_lbc[k];
@@ -517,26 +704,35 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                 e = wave_sum(e);
                 u = wave_sum(u);
                 if (lane == 0) {
-                    e += 0.0 * log2(0.0 + 2.2e-16); // the folded, emptied slot n
-                    double median; // histogram.h:268-287
-                    if (n & 1)
-                        median = (double)s_val[n / 2];
-                    else
-                        median = (double)(uint32_t)(s_val[n / 2] + s_val[n / 2 - 1]) / 2.0;
-                    unsigned long long key = *s_modekey;
-                    o[I_MEDIAN] = median;
-                    o[I_MODE] = (double)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu));
-                    o[I_P01] = p01; o[I_P10] = p10; o[I_P25] = p25; o[I_P75] = p75; o[I_P90] = p90; o[I_P99] = p99;
-                    o[I_QCOD] = (p75 - p25) / (p75 + p25);
-                    o[I_INTERQUARTILE_RANGE] = p75 - p25;
                     o[I_ENTROPY] = -e;
                     o[I_UNIFORMITY] = u;
-                    s_stat[S_P10] = p10;
-                    s_stat[S_P90] = p90;
+                }
+            } else if (wave == 2) {
+                // median (histogram.h:268-287): order statistics n/2 and n/2-1
+                uint32_t hi_v, lo_v;
+                if (use_count) {
+                    uint32_t k = lane == 0 ? n / 2 : (n / 2 ? n / 2 - 1 : 0);
+                    uint32_t lo = 0, hi = range; // smallest i with C(i) > k
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (cum(mid) > k) hi = mid; else lo = mid + 1;
+                    }
+                    uint32_t val = vmin + lo;
+                    hi_v = __shfl(val, 0, 64);
+                    lo_v = __shfl(val, 1, 64);
+                } else {
+                    hi_v = s_val[n / 2];
+                    lo_v = s_val[n / 2 ? n / 2 - 1 : 0];
+                }
+                if (lane == 0) {
+                    double median = (n & 1) ? (double)hi_v : (double)(uint32_t)(hi_v + lo_v) / 2.0;
+                    o[I_MEDIAN] = median;
+                    o[I_MODE] = s_stat[S_MODE];
                     s_stat[S_MEDIAN] = median;
                 }
             }
             __syncthreads();
+            STAMP(7);
 
             // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
             const double p10 = s_stat[S_P10], p90 = s_stat[S_P90], median = s_stat[S_MEDIAN];
@@ -566,43 +762,10 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
             }
         }
 
-        if (tid == 0) {
-            o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
-            o[I_MAX] = (double)vmax;
-            o[I_RANGE] = (double)vmax - (double)vmin;
-            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
-                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
-            o[I_MEAN] = mean;                          // intensity.cpp:95-99
-            o[I_ENERGY] = totsq;
-            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
-            o[I_INTEGRATED_INTENSITY] = tot;
-            const double var = acc[1];                 // intensity.cpp:110-118
-            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
-            const double variance = dn > 1 ? var / (dn - 1) : 0.0;
-            const double variance_b = dn > 1 ? var / dn : 0.0;
-            const double sd = sqrt(variance);
-            o[I_VARIANCE] = variance;
-            o[I_VARIANCE_BIASED] = variance_b;
-            o[I_STANDARD_DEVIATION] = sd;
-            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
-            o[I_COV] = sd / mean;
-            o[I_STANDARD_ERROR] = sd / sqrt(dn);
-            if (!blank) {
-                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
-                const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
-                if (M2 != 0.0) {
-                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / pow(M2, 1.5) : 0.0;
-                    o[I_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
-                    o[I_EXCESS_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) - 3 : 0.0;
-                }
-                double denom = dn * pow(sd, 5.);       // intensity.cpp:186-191
-                o[I_HYPERSKEWNESS] = denom == 0. ? 0. : acc[4] / denom;
-                denom = dn * pow(sd, 6.);
-                o[I_HYPERFLATNESS] = denom == 0. ? 0. : acc[5] / denom;
-            }
-        }
+        STAMP(8);
     }
 
+    STAMP(9);
     // =====================================================================================
     // GLCM
     // =====================================================================================
@@ -669,38 +832,47 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                 for (int i = tid; i < na_pass * NN; i += kBlock)
                     s_P[i] = 0;
                 __syncthreads();
-                // co-occurrence scan (glcm.cpp:431-478): LDS atomics, all angles of the pass
-                for (uint32_t p = tid; p < area; p += kBlock) {
-                    uint32_t lb = s_dense[p];
-                    if (lb == 0)
-                        continue;
-                    int row = (int)(p / w), col = (int)(p - (uint32_t)row * w);
-                    int ib = greyInfo < 0 ? (int)s_lvlmap[lb] - 1 : (int)lb - 1;
-                    for (int q = 0; q < na_pass; q++) {
-                        int ang = A.glcm_angles[a0 + q];
-                        int dx, dy;                     // glcm.cpp:234-255
-                        if (ang == 0) { dx = A.glcm_offset; dy = 0; }
-                        else if (ang == 45) { dx = A.glcm_offset; dy = A.glcm_offset; }
-                        else if (ang == 90) { dx = 0; dy = A.glcm_offset; }
-                        else { dx = -A.glcm_offset; dy = A.glcm_offset; }
-                        int r2 = row + dy, c2 = col + dx;
-                        if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
+                STAMP(10);
+                // co-occurrence scan (glcm.cpp:431-478): LDS atomics, all angles of the pass.
+                // Rows are dealt to waves, columns to lanes (no integer division per pixel).
+                int ddx[kMaxAngles], ddy[kMaxAngles];
+#pragma unroll
+                for (int q = 0; q < kMaxAngles; q++) {
+                    int ang = A.glcm_angles[(a0 + q) < na ? (a0 + q) : 0]; // glcm.cpp:234-255
+                    ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
+                    ddy[q] = ang == 0 ? 0 : A.glcm_offset;
+                }
+                for (int row = wave; row < (int)h; row += kWaves) {
+                    for (int col = lane; col < (int)w; col += 64) {
+                        uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
+                        if (lb == 0)
                             continue;
-                        uint32_t la = s_dense[(uint32_t)r2 * w + (uint32_t)c2];
-                        if (la == 0)
-                            continue;
-                        int ia = greyInfo < 0 ? (int)s_lvlmap[la] - 1 : (int)la - 1;
-                        atomicAdd(&s_P[q * NN + ib * Ng + ia], 1u);
-                        if (symmetric)
-                            atomicAdd(&s_P[q * NN + ia * Ng + ib], 1u);
+                        int ib = greyInfo < 0 ? (int)s_lvlmap[lb] - 1 : (int)lb - 1;
+#pragma unroll
+                        for (int q = 0; q < kMaxAngles; q++) {
+                            if (q >= na_pass)
+                                break;
+                            int r2 = row + ddy[q], c2 = col + ddx[q];
+                            if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
+                                continue;
+                            uint32_t la = s_dense[(uint32_t)r2 * w + (uint32_t)c2];
+                            if (la == 0)
+                                continue;
+                            int ia = greyInfo < 0 ? (int)s_lvlmap[la] - 1 : (int)la - 1;
+                            atomicAdd(&s_P[q * NN + ib * Ng + ia], 1u);
+                            if (symmetric)
+                                atomicAdd(&s_P[q * NN + ia * Ng + ib], 1u);
+                        }
                     }
                 }
                 __syncthreads();
+                STAMP(11);
                 if (wave < na_pass)
                     glcm_features_wave(s_P + wave * NN, Ng, s_I, s_scr + wave * 6 * A.L.ng_cap, A.soft_nan,
                                        s_f + (a0 + wave) * 32, lane);
             }
             __syncthreads();
+            STAMP(12);
             // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
             for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
                 int k = c / na, a = c - k * na;
@@ -724,8 +896,10 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
     }
 
     __syncthreads();
+    STAMP(13);
     for (int c = tid; c < A.n_cols; c += kBlock)
         out_row[c] = s_out[c];
+    STAMP(14);
 }
 
 size_t roi_features_max_lds()

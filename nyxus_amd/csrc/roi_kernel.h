@@ -20,13 +20,15 @@ struct LdsLayout {
     uint32_t stat;     // double[16]           block-wide scalars
     uint32_t lb100;    // uint32[104]          lower bounds of the 100 percentile bins
     uint32_t lbc;      // uint32[n_hist+8]     lower bounds of the n-bin histogram
-    uint32_t val;      // uint32[sort_cap]     intensities, sorted in place
+    uint32_t val;      // uint32[sort_cap]     intensities (sorted in place by the sort engine)
+    uint32_t cnt;      // uint32[count_cap]    counting table over [min, max] -> prefix sums
     uint32_t dense;    // uint16[dense_cap]    binned bounding-box plane (0 = skip)
     uint32_t lvlmap;   // uint16[lvl_cap+8]    radiomics level -> compact index
     uint32_t P;        // uint32[app*ng_cap^2] co-occurrence counts
     uint32_t gscr;     // double[kMaxAngles*(6*ng_cap+40)] per-angle marginals + features
     uint32_t total;
-    uint32_t sort_cap;   // power of two >= max_px
+    uint32_t sort_cap;   // >= max_px (a power of two when the sort engine may run)
+    uint32_t count_cap;  // intensity ranges below this use the counting engine (0 = never)
     uint32_t dense_cap;  // >= max bbox area
     uint32_t ng_cap;     // max GLCM matrix order held in LDS
     uint32_t lvl_cap;    // number of radiomics bins
@@ -48,6 +50,7 @@ struct RoiArgs {
     double* out;
     uint64_t ld;
     int* status;         // device word: first error code raised by any workgroup
+    unsigned long long* stamps; // diagnostic build only (-DNYX_STAMP): per-phase cycle sums; NULL otherwise
     uint32_t mask;
     int32_t n_cols;
     int32_t col_intensity;   // first column of each family's block (-1 = absent)
