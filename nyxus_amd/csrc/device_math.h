@@ -96,38 +96,91 @@ __device__ __forceinline__ uint32_t to_grayscale(uint32_t i, uint32_t min_i, uin
     return (uint32_t)pi;
 }
 
-// ---- wave64 / block reductions ------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off, 64);
-    return v; // valid in lane 0
+// ---- wave64 reductions on the DPP path -------------------------------------------------
+// Cross-lane traffic goes through DPP (VALU data-parallel primitives: row_shr within a row
+// of 16 lanes, row_bcast:15 / row_bcast:31 across rows on GFX9-family CDNA) instead of
+// ds_bpermute, which would occupy the LDS pipe that the histograms need.
+// After the six steps lane 63 holds the wave total; v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
+{   // lanes without a source (or masked rows) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ double wave_max(double v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov0(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_down(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    uint32_t lo = dpp_mov0<CTRL, ROW_MASK>((uint32_t)u), hi = dpp_mov0<CTRL, ROW_MASK>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_mov0(unsigned long long u)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off, 64);
-    return v;
+    uint32_t lo = dpp_mov0<CTRL, ROW_MASK>((uint32_t)u), hi = dpp_mov0<CTRL, ROW_MASK>((uint32_t)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane63(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ unsigned long long readlane63(unsigned long long u)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t readlane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
+// DPP control words (GFX9 ISA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+// Sum over the 64 lanes; the total is returned in EVERY lane (fixed, deterministic order).
+template <typename T>
+__device__ __forceinline__ T wave_sum_t(T v)
+{
+    v += dpp_mov0<0x111, 0xF>(v);
+    v += dpp_mov0<0x112, 0xF>(v);
+    v += dpp_mov0<0x114, 0xF>(v);
+    v += dpp_mov0<0x118, 0xF>(v);   // lane 15 of each row = row total
+    v += dpp_mov0<0x142, 0xA>(v);   // rows 1,3 += previous row's lane 15
+    v += dpp_mov0<0x143, 0xC>(v);   // rows 2,3 += lane 31
+    return readlane63(v);
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_t<double>(v); }
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) { return wave_sum_t<unsigned long long>(v); }
+
+// max over the 64 lanes (values >= 0 or compared against the 0 fill: callers pass
+// non-negative data or accept 0 as the floor), result in every lane
+__device__ __forceinline__ double wave_max_nonneg(double v)
+{
+    double o;
+    o = dpp_mov0<0x111, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x112, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x114, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x118, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x142, 0xA>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x143, 0xC>(v); v = o > v ? o : v;
+    return readlane63(v);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = __shfl_down(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    uint32_t o;
+    o = dpp_mov0<0x111, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x112, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x114, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x118, 0xF>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x142, 0xA>(v); v = o > v ? o : v;
+    o = dpp_mov0<0x143, 0xC>(v); v = o > v ? o : v;
+    return readlane63(v);
+}
+// neighbour lanes through DPP wave shifts (GFX9: wave_shl:1 = 0x130, wave_shr:1 = 0x138);
+// the lane without a source reads `fill`
+__device__ __forceinline__ uint32_t lane_plus1(uint32_t v, uint32_t fill)   // value of lane+1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_minus1(uint32_t v, uint32_t fill)  // value of lane-1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
 
 } // namespace nyxhip

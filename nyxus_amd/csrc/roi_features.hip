@@ -129,8 +129,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     unsigned long long cnt_sum = 0;
     for (int e = lane; e < NN; e += 64)
         cnt_sum += P[e];
-    cnt_sum = wave_sum_u64(cnt_sum);
-    cnt_sum = __shfl(cnt_sum, 0, 64);
+    cnt_sum = wave_sum_u64(cnt_sum); // total in every lane
     if (cnt_sum == 0) { // glcm.cpp:260-295
         if (lane < kGlcmAngled)
             f[lane] = soft_nan;
@@ -138,6 +137,9 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         return;
     }
     const double sum_p = (double)cnt_sum;
+    // per-element probabilities use one reciprocal (<= 1 ulp from cnt / sum_p); marginals and
+    // the exact-numerator features below keep true divisions
+    const double inv_sum_p = 1.0 / sum_p;
 
     double* pcol = scr;           // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
     double* prow = scr + Ng;      // py[j] = sum_i xy(i,j)/sum_p
@@ -173,14 +175,13 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     for (int i = lane; i < Ng; i += 64)
         brm += pcol[i] * Iv[i];
     brm = wave_sum(brm);
-    brm = __shfl(brm, 0, 64);
 
     // ---- pass 1 over matrix elements -------------------------------------------------
     double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis_n = 0, hom2 = 0, jmax = -1;
     for (int e = lane; e < NN; e += 64) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
-        double p = cnt / sum_p;
+        double p = cnt * inv_sum_p;
         double ir = Iv[r], ic = Iv[c];
         asm_ += p * p;                               // f_asm :555 / f_energy :927-928
         double d = ir - ic;
@@ -197,9 +198,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     }
     asm_ = wave_sum(asm_); contrast_n = wave_sum(contrast_n); S_r = wave_sum(S_r); S_c = wave_sum(S_c);
     acor_n = wave_sum(acor_n); hom1 = wave_sum(hom1); ent = wave_sum(ent); dis_n = wave_sum(dis_n);
-    hom2 = wave_sum(hom2); jmax = wave_max(jmax);
-    S_r = __shfl(S_r, 0, 64);
-    S_c = __shfl(S_c, 0, 64);
+    hom2 = wave_sum(hom2); jmax = wave_max_nonneg(jmax);
     const double mr = S_r / sum_p, mc = S_c / sum_p; // mr == f_var's mean == JAVE (exact numerators)
     if (lane == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
@@ -214,14 +213,13 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         f[G_JMAX] = jmax;
         f[G_JAVE] = mr;
     }
-    ent = __shfl(ent, 0, 64);
 
     // ---- pass 2: central quantities ---------------------------------------------------
     double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
     for (int e = lane; e < NN; e += 64) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
-        double p = cnt / sum_p;
+        double p = cnt * inv_sum_p;
         double ir = Iv[r], ic = Iv[c];
         double dr = ir - mr, dc = ic - mc;
         s2r += p * dr * dr;                           // f_corr :617
@@ -276,7 +274,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     }
     idm = wave_sum(idm); dent = wave_sum(dent); idmn = wave_sum(idmn); id = wave_sum(id);
     idn = wave_sum(idn); iv = wave_sum(iv); hx = wave_sum(hx); davg = wave_sum(davg);
-    const double diffAvg = __shfl(davg, 0, 64);
+    const double diffAvg = davg;
     double savg = 0, sent = 0, dv = 0;
     for (int k = lane; k < 2 * Ng - 1; k += 64) {
         double q = Pxpy[k];
@@ -381,16 +379,18 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
     for (int c = tid; c < A.n_cols; c += kBlock)
         s_out[c] = 0.0;
     if (do_glcm) {
-        for (uint32_t i = tid; i < area; i += kBlock)
-            s_dense[i] = 0;
+        uint32_t* d32 = (uint32_t*)s_dense;       // region is 16-byte aligned and padded
+        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlock)
+            d32[i] = 0;
         if (greyInfo < 0)
             for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
                 s_lvlmap[i] = 0;
     }
     if (do_int) {
         if (use_count) {
-            for (uint32_t i = tid; i <= range; i += kBlock)
-                s_cnt[i] = 0;
+            uint4* c4 = (uint4*)s_cnt;             // count_cap is a multiple of 64 entries
+            for (uint32_t i = tid; i < (range + 4) / 4; i += kBlock)
+                c4[i] = make_uint4(0, 0, 0, 0);
         } else {
             for (uint32_t i = n + tid; i < P2; i += kBlock)
                 s_val[i] = 0xFFFFFFFFu;
@@ -612,15 +612,29 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
             for (uint32_t t = tid; t < 100 + nb; t += kBlock) {
                 const bool is100 = t < 100;
                 const uint32_t b = is100 ? t : t - 100;
-                uint32_t lo = 0, hi = use_count ? range + 1 : n;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    uint32_t v = use_count ? vmin + mid : s_val[mid];
-                    uint32_t idx = is100 ? (uint32_t)idx100(v) : to_grayscale(v, vmin, range, nb);
-                    if (idx < b) lo = mid + 1; else hi = mid;
+                uint32_t lo;
+                if (use_count) {
+                    // smallest offset d in [0, range+1] whose bin index reaches b: start from the
+                    // real-valued boundary and settle with the exact (reference) bin function
+                    double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
+                    uint32_t d = edge >= (double)range + 1.0 ? range + 1 : (uint32_t)edge;
+                    auto bin_of = [=](uint32_t dd) -> uint32_t {
+                        return is100 ? (uint32_t)idx100(vmin + dd) : to_grayscale(vmin + dd, vmin, range, nb);
+                    };
+                    while (d > 0 && bin_of(d - 1) >= b) d--;
+                    while (d <= range && bin_of(d) < b) d++;
+                    lo = d > 0 ? cum(d - 1) : 0u;
+                } else {
+                    uint32_t hi = n;
+                    lo = 0;
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        uint32_t v = s_val[mid];
+                        uint32_t idx = is100 ? (uint32_t)idx100(v) : to_grayscale(v, vmin, range, nb);
+                        if (idx < b) lo = mid + 1; else hi = mid;
+                    }
                 }
-                uint32_t lb = use_count ? (lo > 0 ? cum(lo - 1) : 0u) : lo;
-                if (is100) s_lb100[b] = lb; else s_lbc[b] = lb;
+                if (is100) s_lb100[b] = lo; else s_lbc[b] = lo;
             }
             STAMP(5);
             if (!use_count) {
@@ -842,6 +856,40 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                     ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
                     ddy[q] = ang == 0 ? 0 : A.glcm_offset;
                 }
+                if (A.glcm_offset == 1 && w <= 64) {
+                    // one lane per column: horizontal neighbours come from DPP lane shifts, the
+                    // row below is read once and becomes the next iteration's centre row; each
+                    // wave owns a contiguous block of rows
+                    const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                    const int r_begin = wave * rows_per_wave;
+                    const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                    const bool in_col = lane < (int)w;
+                    uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
+                    for (int row = r_begin; row < r_end; row++) {
+                        uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                        uint32_t nb_e = lane_plus1(cur, 0);      // (row,   col+1)  angle 0
+                        uint32_t nb_se = lane_plus1(nxt, 0);     // (row+1, col+1)  angle 45
+                        uint32_t nb_sw = lane_minus1(nxt, 0);    // (row+1, col-1)  angle 135
+                        if (lane + 1 >= (int)w) { nb_e = 0; nb_se = 0; }
+                        if (cur != 0) {
+                            const int ib = greyInfo < 0 ? (int)s_lvlmap[cur] - 1 : (int)cur - 1;
+#pragma unroll
+                            for (int q = 0; q < kMaxAngles; q++) {
+                                if (q >= na_pass)
+                                    break;
+                                const int ang = ddy[q] == 0 ? 0 : ddx[q] > 0 ? 45 : ddx[q] == 0 ? 90 : 135;
+                                uint32_t la = ang == 0 ? nb_e : ang == 45 ? nb_se : ang == 90 ? nxt : nb_sw;
+                                if (la == 0)
+                                    continue;
+                                const int ia = greyInfo < 0 ? (int)s_lvlmap[la] - 1 : (int)la - 1;
+                                atomicAdd(&s_P[q * NN + ib * Ng + ia], 1u);
+                                if (symmetric)
+                                    atomicAdd(&s_P[q * NN + ia * Ng + ib], 1u);
+                            }
+                        }
+                        cur = nxt;
+                    }
+                } else
                 for (int row = wave; row < (int)h; row += kWaves) {
                     for (int col = lane; col < (int)w; col += 64) {
                         uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
