@@ -791,35 +791,38 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
         const bool degenerate = bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth);
 
         // matrix order and level values (glcm.cpp:388-420)
-        lvl_max = wave_max_u32(lvl_max);
-        if (lane == 0)
-            s_red[wave * 8] = (double)lvl_max;
-        __syncthreads(); // also orders s_dense / s_lvlmap writes of phase 1
         double* s_I = s_g;                       // [ng_cap] level values
         double* s_f = s_g + A.L.ng_cap;          // [kMaxAngles][32] per-angle features
         double* s_scr = s_f + kMaxAngles * 32;   // [kMaxAngles][6*ng_cap]
-        if (tid == 0) {
-            int Ng;
-            if (greyInfo > 0)
-                Ng = greyInfo;
-            else if (greyInfo == 0) {
-                double m = 0;
-                for (int wv = 0; wv < kWaves; wv++)
-                    m = s_red[wv * 8] > m ? s_red[wv * 8] : m;
-                Ng = (int)m;
-            } else {
-                // unique sorted non-zero levels -> compact indices (glcm.cpp:391-397)
-                int k = 0;
-                for (uint32_t l = 1; l <= A.L.lvl_cap; l++)
-                    if (s_lvlmap[l]) {
-                        s_lvlmap[l] = (uint16_t)(k + 1);
-                        if ((uint32_t)k < A.L.ng_cap)
-                            s_I[k] = (double)l;
-                        k++;
-                    }
-                Ng = k;
+        if (greyInfo > 0) {
+            if (tid == 0)
+                s_stat[S_NG] = (double)greyInfo;
+        } else {
+            lvl_max = wave_max_u32(lvl_max);
+            if (lane == 0)
+                s_red[wave * 8] = (double)lvl_max;
+            __syncthreads(); // also orders the s_lvlmap writes of phase 1
+            if (tid == 0) {
+                int Ng;
+                if (greyInfo == 0) {
+                    double m = 0;
+                    for (int wv = 0; wv < kWaves; wv++)
+                        m = s_red[wv * 8] > m ? s_red[wv * 8] : m;
+                    Ng = (int)m;
+                } else {
+                    // unique sorted non-zero levels -> compact indices (glcm.cpp:391-397)
+                    int k = 0;
+                    for (uint32_t l = 1; l <= A.L.lvl_cap; l++)
+                        if (s_lvlmap[l]) {
+                            s_lvlmap[l] = (uint16_t)(k + 1);
+                            if ((uint32_t)k < A.L.ng_cap)
+                                s_I[k] = (double)l;
+                            k++;
+                        }
+                    Ng = k;
+                }
+                s_stat[S_NG] = (double)Ng;
             }
-            s_stat[S_NG] = (double)Ng;
         }
         __syncthreads();
         const int Ng = (int)s_stat[S_NG];
@@ -859,32 +862,43 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                 if (A.glcm_offset == 1 && w <= 64) {
                     // one lane per column: horizontal neighbours come from DPP lane shifts, the
                     // row below is read once and becomes the next iteration's centre row; each
-                    // wave owns a contiguous block of rows
+                    // wave owns a contiguous block of rows.  slot[d] = matrix of this pass that
+                    // direction d (E, SE, S, SW = 0, 45, 90, 135 degrees) accumulates into, or -1.
+                    int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+                    for (int q = 0; q < kMaxAngles; q++)
+                        if (q < na_pass) {
+                            int ang = A.glcm_angles[a0 + q];
+                            if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                        }
+                    const int slot[4] = {slot0, slot1, slot2, slot3};
                     const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
                     const int r_begin = wave * rows_per_wave;
                     const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                     const bool in_col = lane < (int)w;
+                    const bool has_right = lane + 1 < (int)w;
+                    const bool remap = greyInfo < 0;
                     uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
+                    if (remap && cur) cur = s_lvlmap[cur];
                     for (int row = r_begin; row < r_end; row++) {
                         uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
-                        uint32_t nb_e = lane_plus1(cur, 0);      // (row,   col+1)  angle 0
-                        uint32_t nb_se = lane_plus1(nxt, 0);     // (row+1, col+1)  angle 45
-                        uint32_t nb_sw = lane_minus1(nxt, 0);    // (row+1, col-1)  angle 135
-                        if (lane + 1 >= (int)w) { nb_e = 0; nb_se = 0; }
-                        if (cur != 0) {
-                            const int ib = greyInfo < 0 ? (int)s_lvlmap[cur] - 1 : (int)cur - 1;
+                        if (remap && nxt) nxt = s_lvlmap[nxt];      // compact index + 1 (0 stays "skip")
+                        uint32_t nb[4];
+                        nb[0] = lane_plus1(cur, 0);                  // (row,   col+1)  angle 0
+                        nb[1] = lane_plus1(nxt, 0);                  // (row+1, col+1)  angle 45
+                        nb[2] = nxt;                                 // (row+1, col  )  angle 90
+                        nb[3] = lane_minus1(nxt, 0);                 // (row+1, col-1)  angle 135
+                        if (!has_right) { nb[0] = 0; nb[1] = 0; }
+                        const uint32_t rowbase = (cur - 1) * (uint32_t)Ng;
 #pragma unroll
-                            for (int q = 0; q < kMaxAngles; q++) {
-                                if (q >= na_pass)
-                                    break;
-                                const int ang = ddy[q] == 0 ? 0 : ddx[q] > 0 ? 45 : ddx[q] == 0 ? 90 : 135;
-                                uint32_t la = ang == 0 ? nb_e : ang == 45 ? nb_se : ang == 90 ? nxt : nb_sw;
-                                if (la == 0)
-                                    continue;
-                                const int ia = greyInfo < 0 ? (int)s_lvlmap[la] - 1 : (int)la - 1;
-                                atomicAdd(&s_P[q * NN + ib * Ng + ia], 1u);
+                        for (int d = 0; d < 4; d++) {
+                            if (slot[d] < 0)
+                                continue;
+                            if (cur != 0 && nb[d] != 0) {
+                                uint32_t* Pq = s_P + slot[d] * NN;
+                                atomicAdd(&Pq[rowbase + (nb[d] - 1)], 1u);
                                 if (symmetric)
-                                    atomicAdd(&s_P[q * NN + ia * Ng + ib], 1u);
+                                    atomicAdd(&Pq[(nb[d] - 1) * (uint32_t)Ng + (cur - 1)], 1u);
                             }
                         }
                         cur = nxt;
