@@ -27,6 +27,14 @@ uint32_t* nyxo_dense_from_cloud(const uint16_t* x, const uint16_t* y, const uint
 void nyxo_glcm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
                const nyxhip_settings* s, double* out);
 
+/* features/glrlm.cpp:20-276 -> out[16*4 + 16]; glszm.cpp:56-340 -> out[16]; ngtdm.cpp:33-345 -> out[5] */
+void nyxo_glrlm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                const nyxhip_settings* s, double* out);
+void nyxo_glszm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                const nyxhip_settings* s, double* out);
+void nyxo_ngtdm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                const nyxhip_settings* s, double* out);
+
 int nyxo_n_columns(uint32_t mask, const nyxhip_settings* s);
 
 /* Host-memory batch, same argument meaning as nyxhip_featurize_batch. */

@@ -117,3 +117,60 @@ def test_oracle_matches_reference_on_bench_tile():
     A = po.oracle_featurize(b, mask, s)
     R = po.ref_featurize(b, mask, s, n_threads=4)
     assert ((A == R) | (np.isnan(A) & np.isnan(R))).all()
+
+
+GLRLM = ["GLRLM_SRE", "GLRLM_LRE", "GLRLM_GLN", "GLRLM_GLNN", "GLRLM_RLN", "GLRLM_RLNN", "GLRLM_RP", "GLRLM_GLV",
+         "GLRLM_RV", "GLRLM_RE", "GLRLM_LGLRE", "GLRLM_HGLRE", "GLRLM_SRLGLE", "GLRLM_SRHGLE", "GLRLM_LRLGLE",
+         "GLRLM_LRHGLE"]
+GLSZM = ["GLSZM_SAE", "GLSZM_LAE", "GLSZM_GLN", "GLSZM_GLNN", "GLSZM_SZN", "GLSZM_SZNN", "GLSZM_ZP", "GLSZM_GLV",
+         "GLSZM_ZV", "GLSZM_ZE", "GLSZM_LGLZE", "GLSZM_HGLZE", "GLSZM_SALGLE", "GLSZM_SAHGLE", "GLSZM_LALGLE",
+         "GLSZM_LAHGLE"]
+NGTDM = ["NGTDM_COARSENESS", "NGTDM_CONTRAST", "NGTDM_BUSYNESS", "NGTDM_COMPLEXITY", "NGTDM_STRENGTH"]
+
+
+def _phantom_mean(fam, s, names, angled):
+    T = po.oracle_featurize(fixtures.ibsi_phantom_batch(REF), fam, s)
+    if angled:  # mean over 4 slices x 4 angles
+        return {n: T[:, k * 4:(k + 1) * 4].sum() / 16.0 for k, n in enumerate(names)}
+    return {n: T[:, k].sum() / 4.0 for k, n in enumerate(names)}
+
+
+@pytest.mark.parametrize("gold,gd,ibsi", [("glrlm_2d_regression_ref_vals", 100, False), ("glrlm_2d_ibsi_ref_vals", 128, True)])
+def test_glrlm_goldens(gold, gd, ibsi):
+    """tests/test_2d_glrlm_regression.h:17-34 (matlab binning; the test sets GLRLMFeature::n_levels = 100, :61) and
+    tests/test_2d_glrlm_ibsi.h (IBSI path): 4 phantom slices x 4 angles averaged, 1 % tier."""
+    got = _phantom_mean(_abi.FAM_GLRLM, _abi.default_settings(gd, ibsi), GLRLM, True)
+    for k, v in REF["goldens"][gold].items():
+        assert agrees_gt(got[k], v, 100.0), (gold, k, got[k], v)
+
+
+@pytest.mark.parametrize("gold,gd,ibsi", [("glszm_2d_regression_ref_vals", 64, False), ("glszm_2d_ibsi_ref_vals", 128, True)])
+def test_glszm_goldens(gold, gd, ibsi):
+    """tests/test_2d_glszm_regression.h:16-33 (GREYDEPTH 64, matlab) and test_2d_glszm_ibsi.h."""
+    got = _phantom_mean(_abi.FAM_GLSZM, _abi.default_settings(gd, ibsi), GLSZM, False)
+    for k, v in REF["goldens"][gold].items():
+        assert agrees_gt(got[k], v, 100.0), (gold, k, got[k], v)
+
+
+@pytest.mark.parametrize("gold,gd,ibsi", [("ngtdm_2d_regression_ref_vals", 100, False), ("ngtdm_2d_ibsi_ref_vals", 128, True)])
+def test_ngtdm_goldens(gold, gd, ibsi):
+    """tests/test_2d_ngtdm_regression.h:16-22 (NGTDMFeature::n_levels = 100, :40) and test_2d_ngtdm_ibsi.h."""
+    got = _phantom_mean(_abi.FAM_NGTDM, _abi.default_settings(gd, ibsi), NGTDM, False)
+    for k, v in REF["goldens"][gold].items():
+        assert agrees_gt(got[k], v, 100.0), (gold, k, got[k], v)
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libnyxref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("gd,ibsi", [(8, False), (64, False), (-16, False), (20, True)])
+def test_texture_families_match_reference_classes_bit_exact(gd, ibsi):
+    rois = synth.random_rois(50, seed=9)
+    if ibsi:  # the reference dereferences an empty set for an all-zero ROI in IBSI NGTDM (ngtdm.cpp:58)
+        rois = [dict(r, inten=(np.asarray(r["inten"]) % 7).astype(np.uint32)) for r in rois]
+        rois = [r for r in rois if np.asarray(r["inten"]).max() > 0]
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd, ibsi)
+    mask = _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+    A = po.oracle_featurize(b, mask, s)
+    R = po.ref_featurize(b, mask, s, n_threads=2)
+    same = (A == R) | (np.isnan(A) & np.isnan(R))
+    assert same.all(), np.argwhere(~same)[:10]
