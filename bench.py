@@ -104,6 +104,7 @@ def main():
     cb.memory = _abi.MEM_DEVICE
     cb.max_px = n_px_roi; cb.max_bbox_area = side * side
     cb.max_inten_range = int((mx - mn).max().item())
+    cb.max_bbox_side = side
 
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)       # kernels + events on torch's current stream

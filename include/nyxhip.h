@@ -131,8 +131,9 @@ typedef struct nyxhip_batch {
      * device batch that costs one small device->host copy and a stream sync). */
     uint32_t max_px;             /* max over ROIs of px_offset[r+1]-px_offset[r] */
     uint32_t max_bbox_area;      /* max over ROIs of bbox_w[r]*bbox_h[r]        */
-    uint32_t max_inten_range;    /* max over ROIs of max_inten[r]-min_inten[r]; with
-                                    max_px == 0 it is derived too                */
+    uint32_t max_inten_range;    /* max over ROIs of max_inten[r]-min_inten[r]     */
+    uint32_t max_bbox_side;      /* max over ROIs of max(bbox_w[r], bbox_h[r])     */
+                                 /* (all four are derived when max_px == 0)        */
 } nyxhip_batch;
 
 typedef struct nyxhip_ctx nyxhip_ctx;

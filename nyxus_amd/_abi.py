@@ -76,6 +76,7 @@ class Batch(C.Structure):
         ("max_px", C.c_uint32),
         ("max_bbox_area", C.c_uint32),
         ("max_inten_range", C.c_uint32),
+        ("max_bbox_side", C.c_uint32),
     ]
 
 
@@ -161,6 +162,7 @@ class HostBatch:
         b.max_px = int(np.diff(self.px_offset.astype(np.int64)).max()) if self.n_roi else 0
         b.max_bbox_area = int((self.bbox_w.astype(np.int64) * self.bbox_h.astype(np.int64)).max()) if self.n_roi else 0
         b.max_inten_range = int((self.max_inten.astype(np.int64) - self.min_inten.astype(np.int64)).max()) if self.n_roi else 0
+        b.max_bbox_side = int(max(self.bbox_w.max(), self.bbox_h.max())) if self.n_roi else 0
         return b
 
 

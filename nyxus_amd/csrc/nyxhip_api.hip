@@ -11,6 +11,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/nyxhip.h"
 #include "roi_kernel.h"
@@ -23,7 +24,7 @@ struct nyxhip_ctx {
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
     int* d_status = nullptr;
-    uint32_t* d_extrema = nullptr; // [3]
+    uint32_t* d_extrema = nullptr; // [4]
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
     // grow-only device staging for host-memory batches
@@ -79,8 +80,18 @@ const char* kGlcmAveNames[kGlcmAve] = {
     "GLCM_INFOMEAS2_AVE", "GLCM_VARIANCE_AVE", "GLCM_JMAX_AVE", "GLCM_JVAR_AVE", "GLCM_SUMAVERAGE_AVE",
     "GLCM_SUMENTROPY_AVE", "GLCM_SUMVARIANCE_AVE"};
 
+const char* kGlrlmNames[16] = {"GLRLM_SRE", "GLRLM_LRE", "GLRLM_GLN", "GLRLM_GLNN", "GLRLM_RLN", "GLRLM_RLNN", "GLRLM_RP",
+                               "GLRLM_GLV", "GLRLM_RV", "GLRLM_RE", "GLRLM_LGLRE", "GLRLM_HGLRE", "GLRLM_SRLGLE",
+                               "GLRLM_SRHGLE", "GLRLM_LRLGLE", "GLRLM_LRHGLE"};
+const char* kGlszmNames[16] = {"GLSZM_SAE", "GLSZM_LAE", "GLSZM_GLN", "GLSZM_GLNN", "GLSZM_SZN", "GLSZM_SZNN", "GLSZM_ZP",
+                               "GLSZM_GLV", "GLSZM_ZV", "GLSZM_ZE", "GLSZM_LGLZE", "GLSZM_HGLZE", "GLSZM_SALGLE",
+                               "GLSZM_SAHGLE", "GLSZM_LALGLE", "GLSZM_LAHGLE"};
+const char* kNgtdmNames[5] = {"NGTDM_COARSENESS", "NGTDM_CONTRAST", "NGTDM_BUSYNESS", "NGTDM_COMPLEXITY", "NGTDM_STRENGTH"};
+const int kGlrlmAngles[4] = {0, 45, 90, 135}; // GLRLMFeature::rotAngles, glrlm.h:134
+
 // families the kernels cover so far
-constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM;
+constexpr uint32_t kTexture = NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM | NYXHIP_FAM_NGTDM;
+constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture;
 
 bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
 {
@@ -110,6 +121,15 @@ std::vector<std::string> column_names(uint32_t mask, const nyxhip_settings* s)
                 v.push_back(std::string(n) + "_" + std::to_string(s->glcm_angles[a])); // output_2_buffer.cpp:336-343
         for (auto n : kGlcmAveNames) v.push_back(n);
     }
+    if (mask & NYXHIP_FAM_GLRLM) {
+        for (auto n : kGlrlmNames)
+            for (int a : kGlrlmAngles) v.push_back(std::string(n) + "_" + std::to_string(a)); // output_2_buffer.cpp:351-361
+        for (auto n : kGlrlmNames) v.push_back(std::string(n) + "_AVE");
+    }
+    if (mask & NYXHIP_FAM_GLSZM)
+        for (auto n : kGlszmNames) v.push_back(n);
+    if (mask & NYXHIP_FAM_NGTDM)
+        for (auto n : kNgtdmNames) v.push_back(n);
     return v;
 }
 
@@ -205,26 +225,80 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     return NYXHIP_OK;
 }
 
+// LDS carve-out of the texture kernel (roi_texture.hip)
+int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_area, uint32_t max_side,
+                    TexLayout& L, std::string& why)
+{
+    memset(&L, 0, sizeof(L));
+    const size_t cap = roi_features_max_lds();
+    const int greyInfo = s->ibsi ? 0 : s->grey_depth;
+    uint32_t off = 0;
+    L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
+    L.red = off; off = align16(off + 8u * kWaves * 8);
+    L.stat = off; off = align16(off + 8u * 16);
+    L.dense_cap = max_area ? max_area : 1;
+    L.side_cap = max_side ? max_side : 1;
+    if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    L.dense = off; off = align16(off + 2u * L.dense_cap + 4);
+    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
+    if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the texture kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    L.ng_cap = L.lvl_cap + 1;
+    L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
+    L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));
+    L.work = off;
+    size_t need = 0;
+    if (mask & NYXHIP_FAM_NGTDM)
+        need = std::max(need, (size_t)(L.ng_cap + 2) * (8 + 4 + 8 + 8) + 64);
+    if (mask & NYXHIP_FAM_GLSZM) {
+        // distinct (level, size) pairs <= sqrt(2 * Ng * area) (sizes of one level sum to <= its area)
+        double bound = sqrt(2.0 * (double)L.ng_cap * (double)L.dense_cap) + (double)L.ng_cap;
+        uint32_t distinct = (uint32_t)std::min((double)L.dense_cap, bound) + 1;
+        L.hash_cap = pow2ceil(2 * distinct);
+        size_t szm = 4ull * L.dense_cap + 4ull * (L.dense_cap + 8) + 8ull * L.hash_cap + 4ull * (L.ng_cap + 4);
+        L.szm_ok = (off + szm <= cap) ? 1 : 0;
+        if (!L.szm_ok) { why = "ROI too large for the LDS-resident GLSZM zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+        need = std::max(need, szm);
+    }
+    if (mask & NYXHIP_FAM_GLRLM) {
+        size_t slot = 4ull * ((size_t)L.ng_cap * L.side_cap + L.ng_cap + L.side_cap + 4);
+        if (off + 512 + slot > cap) { why = "ROI too large for the LDS-resident run-length matrix"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+        size_t k = 4;
+        while (k > 1 && off + 512 + k * slot > cap) k--;
+        // keep the carve-out modest when four matrices would crowd out co-resident workgroups
+        while (k > 1 && 512 + k * slot > 48 * 1024) k--;
+        need = std::max(need, 512 + k * slot);
+    }
+    L.work_bytes = (uint32_t)need;
+    off = align16(off + (uint32_t)need);
+    L.total = off;
+    if (L.total > cap) { why = "ROI too large for the LDS-resident texture path"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    return NYXHIP_OK;
+}
+
 __global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
-                                     const uint32_t* mn, const uint32_t* mx, uint32_t* out3)
+                                     const uint32_t* mn, const uint32_t* mx, uint32_t* out4)
 {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint32_t n = 0, a = 0, r = 0;
+    uint32_t n = 0, a = 0, r = 0, sd = 0;
     if (i < n_roi) {
         n = (uint32_t)(px_offset[i + 1] - px_offset[i]);
         a = bw[i] * bh[i];
         r = mx[i] - mn[i];
+        sd = bw[i] > bh[i] ? bw[i] : bh[i];
     }
     for (int off = 32; off > 0; off >>= 1) {
-        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64), orr = __shfl_down(r, off, 64);
+        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64), orr = __shfl_down(r, off, 64),
+                 os = __shfl_down(sd, off, 64);
         n = on > n ? on : n;
         a = oa > a ? oa : a;
         r = orr > r ? orr : r;
+        sd = os > sd ? os : sd;
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&out3[0], n);
-        atomicMax(&out3[1], a);
-        atomicMax(&out3[2], r);
+        atomicMax(&out4[0], n);
+        atomicMax(&out4[1], a);
+        atomicMax(&out4[2], r);
+        atomicMax(&out4[3], sd);
     }
 }
 
@@ -260,30 +334,47 @@ int check_status(nyxhip_ctx* ctx)
 
 // Launch on device-resident arrays.
 int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range)
+                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
 {
     std::string why;
     const int n_cols = nyxhip_n_columns(mask, s);
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture;
+    const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s);
     RoiArgs a;
     memset(&a, 0, sizeof(a));
-    if (int lrc = make_layout(mask, s, n_cols, max_px, max_area, max_range, a.L, why))
-        return fail(ctx, lrc, why);
-    a.n_roi = b->n_roi;
-    a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
-    a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
-    a.slide_min = b->slide_min; a.slide_max = b->slide_max;
-    a.out = d_out; a.ld = ld; a.status = ctx->d_status;
-    a.stamps = ctx->d_stamps;
-    a.mask = mask; a.n_cols = n_cols;
-    int c = 0;
-    a.col_intensity = a.col_glcm = -1;
-    if (mask & NYXHIP_FAM_INTENSITY) { a.col_intensity = c; c += kIntensityCols; }
-    if (mask & NYXHIP_FAM_GLCM) { a.col_glcm = c; c += kGlcmAngled * s->glcm_n_angles + kGlcmAve; }
-    a.soft_nan = s->soft_nan;
-    a.grey_depth = s->grey_depth; a.ibsi = s->ibsi; a.glcm_grey_depth = s->glcm_grey_depth;
-    a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
-    for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
-    a.n_hist = abs(s->grey_depth);
+    if (mask1) {
+        if (int lrc = make_layout(mask1, s, n_cols1, max_px, max_area, max_range, a.L, why))
+            return fail(ctx, lrc, why);
+        a.n_roi = b->n_roi;
+        a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
+        a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
+        a.slide_min = b->slide_min; a.slide_max = b->slide_max;
+        a.out = d_out; a.ld = ld; a.status = ctx->d_status;
+        a.stamps = ctx->d_stamps;
+        a.mask = mask1; a.n_cols = n_cols1;
+        int c = 0;
+        a.col_intensity = a.col_glcm = -1;
+        if (mask1 & NYXHIP_FAM_INTENSITY) { a.col_intensity = c; c += kIntensityCols; }
+        if (mask1 & NYXHIP_FAM_GLCM) { a.col_glcm = c; c += kGlcmAngled * s->glcm_n_angles + kGlcmAve; }
+        a.soft_nan = s->soft_nan;
+        a.grey_depth = s->grey_depth; a.ibsi = s->ibsi; a.glcm_grey_depth = s->glcm_grey_depth;
+        a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
+        for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
+        a.n_hist = abs(s->grey_depth);
+    }
+    TexArgs t;
+    memset(&t, 0, sizeof(t));
+    if (mask2) {
+        if (int lrc = make_tex_layout(mask2, s, n_cols2, max_area, max_side, t.L, why))
+            return fail(ctx, lrc, why);
+        t.n_roi = b->n_roi;
+        t.px_offset = b->px_offset; t.x = b->x; t.y = b->y; t.inten = b->inten;
+        t.bbox_w = b->bbox_w; t.bbox_h = b->bbox_h; t.min_inten = b->min_inten; t.max_inten = b->max_inten;
+        t.out = d_out; t.ld = ld; t.status = ctx->d_status;
+        t.mask = mask2; t.n_cols = n_cols2; t.col0 = n_cols1;
+        t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
+    }
+    (void)n_cols;
 
     hipStream_t st = ctx->stream();
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -299,7 +390,9 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         ctx->ev_used++;
         HIP_TRY(ctx, hipEventRecord(e0, st));
     }
-    int rc = launch_roi_features(a, st);
+    int rc = mask1 ? launch_roi_features(a, st) : 0;
+    if (rc == 0 && mask2)
+        rc = launch_roi_texture(t, st);
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     if (ctx->timing)
@@ -314,7 +407,7 @@ int validate(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip
     if (mask == 0 || (mask & ~NYXHIP_FAM_ALL)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
     if (mask & ~kImplemented)
         return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "requested feature family is not implemented by the HIP path yet "
-                    "(implemented: INTENSITY, GLCM)");
+                    "(implemented: INTENSITY, GLCM, GLRLM, GLSZM, NGTDM)");
     std::string why;
     if (!settings_ok(s, mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
     if (b->n_roi && (!b->px_offset || !b->x || !b->y || !b->inten || !b->bbox_w || !b->bbox_h || !b->min_inten || !b->max_inten))
@@ -416,6 +509,9 @@ int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s)
     int n = 0;
     if (family_mask & NYXHIP_FAM_INTENSITY) n += kIntensityCols;
     if (family_mask & NYXHIP_FAM_GLCM) n += kGlcmAngled * s->glcm_n_angles + kGlcmAve;
+    if (family_mask & NYXHIP_FAM_GLRLM) n += kGlrlmCols;
+    if (family_mask & NYXHIP_FAM_GLSZM) n += kGlszmCols;
+    if (family_mask & NYXHIP_FAM_NGTDM) n += kNgtdmCols;
     return n;
 }
 
@@ -445,21 +541,22 @@ int nyxhip_featurize_batch_async(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_
         return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the async form takes device-resident batches only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->n_roi == 0) return NYXHIP_OK;
-    uint32_t max_px = b->max_px, max_area = b->max_bbox_area, max_range = b->max_inten_range;
-    if (max_px == 0 || max_area == 0) {
+    uint32_t max_px = b->max_px, max_area = b->max_bbox_area, max_range = b->max_inten_range, max_side = b->max_bbox_side;
+    if (max_px == 0 || max_area == 0 || max_side == 0) {
         hipStream_t st = ctx->stream();
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 3 * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 4 * sizeof(uint32_t), st));
         unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
         hipLaunchKernelGGL(batch_extrema_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h,
                            b->min_inten, b->max_inten, ctx->d_extrema);
-        uint32_t h[3];
+        uint32_t h[4];
         HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_extrema, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         max_px = h[0];
         max_area = h[1];
         max_range = h[2];
+        max_side = h[3];
     }
-    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area, max_range);
+    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area, max_range, max_side);
 }
 
 int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
@@ -478,7 +575,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
 
     // host batch: derive extrema, stage SoA arrays into one device slab, run, copy the table back
     const uint64_t nr = b->n_roi, npx = b->px_offset[nr];
-    uint32_t max_px = 0, max_area = 0, max_range = 0;
+    uint32_t max_px = 0, max_area = 0, max_range = 0, max_side = 0;
     for (uint64_t r = 0; r < nr; r++) {
         if (b->px_offset[r + 1] < b->px_offset[r]) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "px_offset is not monotone");
         uint64_t n = b->px_offset[r + 1] - b->px_offset[r];
@@ -487,6 +584,8 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
         if (n > max_px) max_px = (uint32_t)n;
         if (a > max_area) max_area = (uint32_t)a;
         if (b->max_inten[r] - b->min_inten[r] > max_range) max_range = b->max_inten[r] - b->min_inten[r];
+        if (b->bbox_w[r] > max_side) max_side = b->bbox_w[r];
+        if (b->bbox_h[r] > max_side) max_side = b->bbox_h[r];
     }
     const int n_cols = nyxhip_n_columns(mask, s);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -519,7 +618,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
     d.slide_min = b->slide_min ? (const double*)(base + o_smin) : nullptr;
     d.slide_max = b->slide_max ? (const double*)(base + o_smax) : nullptr;
     double* d_out = (double*)(base + o_out);
-    rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area, max_range);
+    rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area, max_range, max_side);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy2DAsync(out, ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
                                   (size_t)n_cols * sizeof(double), nr, hipMemcpyDeviceToHost, st));

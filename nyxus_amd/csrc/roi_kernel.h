@@ -63,8 +63,47 @@ struct RoiArgs {
     LdsLayout L;
 };
 
-// implemented in roi_features.hip
+// ---- second kernel: GLRLM + GLSZM + NGTDM (roi_texture.hip) -------------------------------
+constexpr int kGlrlmCols = 16 * 4 + 16;   // Feature2D GLRLM_SRE..GLRLM_LRHGLE x4, then 16 _AVE (featureset.h:236-268)
+constexpr int kGlszmCols = 16;            // Feature2D GLSZM_SAE..GLSZM_LAHGLE (featureset.h:291-306)
+constexpr int kNgtdmCols = 5;             // Feature2D NGTDM_COARSENESS..NGTDM_STRENGTH (featureset.h:346-350)
+
+struct TexLayout {
+    uint32_t out;       // double[n_cols]
+    uint32_t red;       // double[kWaves*8]
+    uint32_t stat;      // double[16]
+    uint32_t dense;     // uint16[dense_cap]   binned bounding-box plane (background = level 1 under matlab binning)
+    uint32_t lvlmap;    // uint16[lvl_cap+2]   level -> row index + 1
+    uint32_t lv;        // uint32[ng_cap+2]    row index -> level value
+    uint32_t work;      // per-family scratch, families run one after the other
+    uint32_t total;
+    uint32_t dense_cap, side_cap, lvl_cap, ng_cap, hash_cap, work_bytes, szm_ok;
+};
+
+struct TexArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;        // subset of GLRLM | GLSZM | NGTDM
+    int32_t n_cols;       // columns this kernel writes
+    int32_t col0;         // first of them inside the output row
+    double soft_nan;
+    int32_t grey_depth, ibsi;
+    TexLayout L;
+};
+
+// implemented in roi_features.hip / roi_texture.hip
 int launch_roi_features(const RoiArgs& a, void* stream);
+int launch_roi_texture(const TexArgs& a, void* stream);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

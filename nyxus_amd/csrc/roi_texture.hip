@@ -1,0 +1,585 @@
+// roi_texture.hip -- GLRLM + GLSZM + NGTDM for gfx950: the second per-ROI kernel.
+//
+// One 256-thread workgroup per ROI; the binned bounding-box plane lives in LDS and all
+// three matrices are built there with integer LDS atomics (exact, order-independent):
+//
+//   GLRLM  (/root/reference/src/nyx/features/glrlm.cpp:20-276, 357-885): one wave per
+//          angle; a pixel starts a run when its predecessor along the angle differs, the
+//          run is walked forward and counted into an LDS Ng x Nr matrix.
+//   GLSZM  (features/glszm.cpp:56-395): the reference's zones are directed-reachability
+//          sets (depth-first search through E/SE/S/SW neighbours from the raster-first
+//          unvisited pixel).  zone(p) = min raster index s with p reachable from s, which
+//          obeys  owner(p) = min(p, owner(W), owner(NW), owner(N), owner(NE))  over
+//          equal-valued predecessors -- one raster sweep: rows in sequence, a segmented
+//          prefix-min along each row.  Zone sizes by LDS atomics keyed by owner; the
+//          (level, size) multiplicities P(i,j) through an LDS hash table (the reference's
+//          dense Ng x (w*h) matrix is mostly zeros).
+//   NGTDM  (features/ngtdm.cpp:33-345): 3x3 stencil; the per-level sums of |i - mean|
+//          are accumulated exactly in units of 1/840 (lcm of the neighbour counts 1..8)
+//          with 64-bit integer LDS atomics, hence deterministic.
+//
+// HBM traffic: the ROI cloud in (8 B/px), 101 doubles out; everything else is LDS.
+// Built with -ffp-contract=off (device_math.h).
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+enum { R_SRE = 0, R_LRE, R_GLN, R_GLNN, R_RLN, R_RLNN, R_RP, R_GLV, R_RV, R_RE, R_LGLRE, R_HGLRE,
+       R_SRLGLE, R_SRHGLE, R_LRLGLE, R_LRHGLE };
+enum { Z_SAE = 0, Z_LAE, Z_GLN, Z_GLNN, Z_SZN, Z_SZNN, Z_ZP, Z_GLV, Z_ZV, Z_ZE, Z_LGLZE, Z_HGLZE,
+       Z_SALGLE, Z_SAHGLE, Z_LALGLE, Z_LAHGLE };
+
+__device__ __forceinline__ void wave_sync_t()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// p * fast_log10(p + EPS) / LOG10_2 with EPS = 2.2e-16 (glrlm.h:169-171, glszm.h:138-140);
+// (lg2 * c) / c == lg2 to 1 ulp, see device_math.h plogp.
+__device__ __forceinline__ double plog_tex(double p)
+{
+    return p * (double)fast_log2f(p + 2.2e-16);
+}
+
+// ---- GLRLM features of one angle from its LDS matrix, by one wave -------------------------
+// P[row * Nr + (len-1)], rows = level indices; lv[row] = level value (PixIntens).
+// ri / rj: scratch for row / column sums.
+__device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
+                                    uint32_t Np, double* f, int lane)
+{
+    unsigned long long tot = 0;
+    for (int i = lane; i < Ng; i += 64) {
+        uint32_t sm = 0;
+        for (int j = 0; j < Nr; j++) sm += P[i * Nr + j];
+        ri[i] = sm;
+        tot += sm;
+    }
+    for (int j = lane; j < Nr; j += 64) {
+        uint32_t sm = 0;
+        for (int i = 0; i < Ng; i++) sm += P[i * Nr + j];
+        rj[j] = sm;
+    }
+    tot = wave_sum_u64(tot);
+    wave_sync_t();
+    if (tot == 0) { // sum_p == 0 -> every feature 0.0 (glrlm.cpp:364-367 etc.)
+        if (lane < 16) f[lane] = 0.0;
+        wave_sync_t();
+        return;
+    }
+    const double sum_p = (double)tot;
+    // level-only and length-only sums from the marginals
+    double gln = 0, mu_g = 0, lgl = 0, hgl = 0;
+    for (int i = lane; i < Ng; i += 64) {
+        double r = (double)ri[i];
+        uint32_t in2 = lv[i] * lv[i];                 // unsigned-int product as in the reference
+        gln += r * r;                                  // calc_GLN :431-461
+        mu_g += r / sum_p * (double)lv[i];             // calc_GLV mu :602-609
+        lgl += r / (double)in2;                        // calc_LGLRE :712-741
+        hgl += r * (double)in2;                        // calc_HGLRE :744-773
+    }
+    double sre = 0, lre = 0, rln = 0, mu_r = 0;
+    for (int j = lane; j < Nr; j += 64) {
+        double c = (double)rj[j];
+        int jj = j + 1;
+        sre += c / (double)(jj * jj);                  // calc_SRE :378-385
+        lre += c * (double)jj * (double)jj;            // calc_LRE :411-418 (integer-exact)
+        rln += c * c;                                  // calc_RLN :499-529
+        mu_r += c / sum_p * (double)jj;                // calc_RV mu :649-655
+    }
+    gln = wave_sum(gln); mu_g = wave_sum(mu_g); lgl = wave_sum(lgl); hgl = wave_sum(hgl);
+    sre = wave_sum(sre); lre = wave_sum(lre); rln = wave_sum(rln); mu_r = wave_sum(mu_r);
+    double glv = 0, rv = 0;
+    for (int i = lane; i < Ng; i += 64) {
+        double d = (double)lv[i] - mu_g;
+        glv += (double)ri[i] / sum_p * (d * d);        // calc_GLV :611-620
+    }
+    for (int j = lane; j < Nr; j += 64) {
+        double d = (double)(j + 1) - mu_r;
+        rv += (double)rj[j] / sum_p * (d * d);         // calc_RV :657-665
+    }
+    glv = wave_sum(glv); rv = wave_sum(rv);
+    // cell-level sums
+    double re = 0, srl = 0, srh = 0, lrl = 0, lrh = 0;
+    const int NN = Ng * Nr;
+    for (int e = lane; e < NN; e += 64) {
+        uint32_t c = P[e];
+        if (c == 0)
+            continue;                                  // zero cells add +-0 in the reference
+        int i = e / Nr, jj = e - i * Nr + 1;
+        double cnt = (double)c;
+        uint32_t in2 = lv[i] * lv[i];
+        uint32_t j2 = (uint32_t)jj * (uint32_t)jj;
+        re += plog_tex(cnt / sum_p);                   // calc_RE :693-699
+        srl += cnt / (double)(uint32_t)(in2 * j2);     // calc_SRLGLE :790-797
+        srh += cnt * (double)in2 / (double)(jj * jj);  // calc_SRHGLE :822-829
+        lrl += cnt * (double)(jj * jj) / (double)in2;  // calc_LRLGLE :855-862
+        lrh += cnt * (double)(uint32_t)(in2 * j2);     // calc_LRHGLE :887-894
+    }
+    re = wave_sum(re); srl = wave_sum(srl); srh = wave_sum(srh); lrl = wave_sum(lrl); lrh = wave_sum(lrh);
+    if (lane == 0) {
+        f[R_SRE] = sre / sum_p;
+        f[R_LRE] = lre / sum_p;
+        f[R_GLN] = gln / sum_p;
+        f[R_GLNN] = gln / (sum_p * sum_p);
+        f[R_RLN] = rln / sum_p;
+        f[R_RLNN] = rln / (sum_p * sum_p);
+        f[R_RP] = sum_p / (double)(int)Np;             // calc_RP :569-585
+        f[R_GLV] = glv;
+        f[R_RV] = rv;
+        f[R_RE] = -re;
+        f[R_LGLRE] = lgl / sum_p;
+        f[R_HGLRE] = hgl / sum_p;
+        f[R_SRLGLE] = srl / sum_p;
+        f[R_SRHGLE] = srh / sum_p;
+        f[R_LRLGLE] = lrl / sum_p;
+        f[R_LRHGLE] = lrh / sum_p;
+    }
+    wave_sync_t();
+}
+
+__global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    double* s_out = (double*)(lds + A.L.out);
+    double* s_red = (double*)(lds + A.L.red);
+    double* s_stat = (double*)(lds + A.L.stat);
+    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
+    uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);   // level -> row index + 1
+    uint32_t* s_lv = (uint32_t*)(lds + A.L.lv);           // row index -> level value
+    unsigned char* s_work = lds + A.L.work;                // per-family scratch (aliased)
+
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t area = w * h;
+    const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
+    double* const out_row = A.out + roi * A.ld + A.col0;
+    const bool do_rlm = (A.mask & NYXHIP_FAM_GLRLM) != 0, do_szm = (A.mask & NYXHIP_FAM_GLSZM) != 0,
+               do_ngt = (A.mask & NYXHIP_FAM_NGTDM) != 0;
+    const uint32_t side = w > h ? w : h;
+    if (n == 0 || area > A.L.dense_cap || side > A.L.side_cap) {
+        if (tid == 0 && n != 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        for (int c = tid; c < A.n_cols; c += kBlock)
+            out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
+    const uint32_t Lcap = A.L.lvl_cap;
+
+    // ---- phase 0: plane = background level (matlab binning sends 0 -> 1, texture_feature.h:150-154)
+    for (int c = tid; c < A.n_cols; c += kBlock)
+        s_out[c] = 0.0;
+    {
+        const uint32_t bg = greyInfo > 0 ? 0x00010001u : 0u;
+        uint32_t* d32 = (uint32_t*)s_dense;
+        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlock)
+            d32[i] = bg;
+        for (uint32_t i = tid; i <= Lcap + 1; i += kBlock)
+            s_lvlmap[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: cloud -> binned plane -----------------------------------------------------------
+    uint32_t nz_orig = 0, lvl_over = 0;
+    for (uint32_t i = tid; i < n; i += kBlock) {
+        uint32_t v = A.inten[off + i];
+        uint32_t px = A.x[off + i], py = A.y[off + i];
+        uint32_t lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+        nz_orig += v != 0;
+        if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
+        if (px < w && py < h)
+            s_dense[py * w + px] = (uint16_t)lvl;
+    }
+    nz_orig = (uint32_t)wave_sum_u64(nz_orig);
+    lvl_over = wave_max_u32(lvl_over);
+    if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
+    __syncthreads();
+    uint32_t Np_orig = 0;   // non-zero ORIGINAL pixels (glrlm.cpp:197-204)
+    bool over = false;
+    for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; }
+    if (over) { // IBSI level beyond the LDS-resident capacity
+        if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
+        for (int c = tid; c < A.n_cols; c += kBlock)
+            out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    // levels present in the plane (background included)
+    uint32_t nz_bin = 0;
+    for (uint32_t p = tid; p < area; p += kBlock) {
+        uint32_t l = s_dense[p];
+        if (l) { s_lvlmap[l] = 1; nz_bin++; }
+    }
+    nz_bin = (uint32_t)wave_sum_u64(nz_bin);
+    __syncthreads();
+    if (lane == 0) s_red[wave * 8] = (double)nz_bin;
+    __syncthreads();
+    uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
+    for (int wv = 0; wv < kWaves; wv++) Np_bin += (uint32_t)s_red[wv * 8];
+    // sorted unique non-zero levels (glrlm.cpp:101-105, glszm.cpp:97-101, ngtdm.cpp:53-67);
+    // IBSI: I = 1..max (GLRLM/GLSZM) and 0..max (NGTDM)
+    if (tid == 0) {
+        int k = 0;
+        uint32_t mx = 0;
+        for (uint32_t l = 1; l <= Lcap; l++)
+            if (s_lvlmap[l]) {
+                mx = l;
+                if (greyInfo != 0) { s_lvlmap[l] = (uint16_t)(k + 1); s_lv[k] = l; }
+                k++;
+            }
+        if (greyInfo == 0)
+            for (uint32_t l = 1; l <= mx; l++) { s_lvlmap[l] = (uint16_t)l; s_lv[l - 1] = l; }
+        s_stat[0] = (double)(greyInfo == 0 ? (int)mx : k);   // Ng for GLRLM / GLSZM
+        s_stat[1] = (double)k;                               // Ngp = unique non-zero levels (ngtdm.cpp:150)
+    }
+    __syncthreads();
+    const int Ng = (int)s_stat[0];
+    const int Nuniq = (int)s_stat[1];
+    const bool blank = vmin == vmax;
+    int col = 0;
+
+    // =====================================================================================
+    // GLRLM
+    // =====================================================================================
+    if (do_rlm) {
+        double* o = s_out + col;
+        col += 80;
+        double* s_f = (double*)s_work;                       // [4][16]
+        uint32_t* s_mat = (uint32_t*)(s_work + 4 * 16 * 8);  // slots of Ng*Nr + Ng + Nr words
+        const int Nr = (int)side;
+        const uint32_t slot_words = (uint32_t)(Ng * Nr + Ng + Nr + 4);
+        const int nslot = (int)(A.L.work_bytes > 512 ? (A.L.work_bytes - 512) / (4ull * slot_words) : 0);
+        if (blank) {                                         // glrlm.cpp:29-52
+            for (int c = tid; c < 80; c += kBlock) o[c] = A.soft_nan;
+        } else if (nslot < 1 || Ng < 1) {
+            if (tid == 0 && Ng >= 1) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+            for (int c = tid; c < 80; c += kBlock) o[c] = Ng < 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
+            for (int a0 = 0; a0 < 4; a0 += per) {
+                __syncthreads();
+                for (uint32_t i = tid; i < (uint32_t)per * slot_words; i += kBlock) s_mat[i] = 0;
+                __syncthreads();
+                if (wave < per && a0 + wave < 4) {
+                    const int ai = a0 + wave;
+                    uint32_t* P = s_mat + wave * slot_words;
+                    const int dx = ai == 2 ? 0 : ai == 3 ? -1 : 1, dy = ai == 0 ? 0 : 1; // glrlm.cpp:128-176
+                    for (uint32_t p = lane; p < area; p += 64) {
+                        uint32_t v = s_dense[p];
+                        if (v == 0) continue;
+                        int row = (int)(p / w), cl = (int)(p - (uint32_t)row * w);
+                        int pr = row - dy, pc = cl - dx;
+                        if (pr >= 0 && pc >= 0 && pc < (int)w && s_dense[(uint32_t)pr * w + pc] == v)
+                            continue;                        // not the first pixel of its run
+                        int len = 1, r2 = row + dy, c2 = cl + dx;
+                        while (r2 < (int)h && c2 >= 0 && c2 < (int)w && s_dense[(uint32_t)r2 * w + c2] == v) {
+                            len++; r2 += dy; c2 += dx;
+                        }
+                        atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
+                    }
+                    wave_sync_t();
+                    glrlm_features_wave(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < 64; c += kBlock) {         // feature-major, angle-minor
+                int k = c >> 2, a = c & 3;
+                o[c] = s_f[a * 16 + k];
+            }
+            for (int k = tid; k < 16; k += kBlock) {         // calc_ave :903-910 (std::reduce of 4)
+                double v = 0.0 + ((s_f[0 * 16 + k] + s_f[1 * 16 + k]) + (s_f[2 * 16 + k] + s_f[3 * 16 + k]));
+                o[64 + k] = v / 4.0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // =====================================================================================
+    // GLSZM
+    // =====================================================================================
+    if (do_szm) {
+        double* o = s_out + col;
+        col += 16;
+        uint32_t* s_label = (uint32_t*)s_work;               // [area] owner index of each pixel
+        uint32_t* s_count = s_label + A.L.dense_cap;         // [area] zone size at the owner / later zones per size
+        uint32_t* s_hkey = s_count + A.L.dense_cap + 4;      // [hcap] (row << 20 | size), 0xFFFFFFFF = empty
+        uint32_t* s_hval = s_hkey + A.L.hash_cap;            // [hcap] multiplicity P(i,j)
+        uint32_t* s_si = s_hval + A.L.hash_cap;              // [Ng] zones per level
+        const uint32_t hcap = A.L.hash_cap;
+        if (blank) {                                         // glszm.cpp:61-65
+            for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
+        } else if (A.L.szm_ok == 0 || area > (1u << 20) - 1) {
+            if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+            for (int c = tid; c < 16; c += kBlock) o[c] = __longlong_as_double(0x7ff8000000000000LL);
+        } else {
+            for (uint32_t i = tid; i < area; i += kBlock) s_count[i] = 0;
+            for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0xFFFFFFFFu; s_hval[i] = 0; }
+            for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
+            // owner labels: wave 0 sweeps the rows; lanes own columns (chunks of 64)
+            if (wave == 0) {
+                for (uint32_t row = 0; row < h; row++) {
+                    uint32_t carry_v = 0, carry_l = 0;       // right-most pixel of the previous chunk
+                    for (uint32_t c0 = 0; c0 < w; c0 += 64) {
+                        const uint32_t cl = c0 + lane;
+                        const bool in = cl < w;
+                        const uint32_t p = row * w + cl;
+                        const uint32_t v = in ? s_dense[p] : 0u;
+                        uint32_t lab = p;
+                        if (v != 0 && row > 0) {             // N, NW, NE predecessors (final labels)
+                            const uint32_t q = p - w;
+                            if (s_dense[q] == v) lab = min(lab, s_label[q]);
+                            if (cl > 0 && s_dense[q - 1] == v) lab = min(lab, s_label[q - 1]);
+                            if (cl + 1 < w && s_dense[q + 1] == v) lab = min(lab, s_label[q + 1]);
+                        }
+                        // W chain: segmented inclusive prefix-min over runs of equal value
+                        uint32_t vl = __shfl_up(v, 1, 64);
+                        if (lane == 0) vl = carry_v;
+                        const bool start = v == 0 || vl != v;   // run starts here (or not a zone pixel)
+                        if (lane == 0 && !start) lab = min(lab, carry_l);
+                        const unsigned long long smask = __ballot(start);
+                        const int run0 = 63 - __clzll((long long)(smask & ((2ull << lane) - 1ull)) | 1ll);
+                        // (bit 0 is forced so that a chunk continuing the previous chunk's run starts at lane 0)
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            uint32_t o2 = __shfl_up(lab, d, 64);
+                            if (lane - d >= run0) lab = min(lab, o2);
+                        }
+                        if (in && v != 0) s_label[p] = lab;
+                        carry_v = __shfl(v, 63, 64);
+                        carry_l = __shfl(lab, 63, 64);
+                    }
+                    wave_sync_t();
+                }
+            }
+            __syncthreads();
+            // zone sizes at the owners
+            for (uint32_t p = tid; p < area; p += kBlock)
+                if (s_dense[p] != 0)
+                    atomicAdd(&s_count[s_label[p]], 1u);
+            __syncthreads();
+            // zones -> P(i,j) multiplicities (hash), zones per level; Nz
+            uint32_t nzone = 0;
+            for (uint32_t p = tid; p < area; p += kBlock) {
+                uint32_t sz = s_count[p];
+                if (sz == 0) continue;
+                nzone++;
+                uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
+                atomicAdd(&s_si[rowi], 1u);
+                uint32_t key = (rowi << 20) | sz;
+                uint32_t hsl = (key * 2654435761u) & (hcap - 1);
+                for (;;) {
+                    uint32_t prev = atomicCAS(&s_hkey[hsl], 0xFFFFFFFFu, key);
+                    if (prev == 0xFFFFFFFFu || prev == key) { atomicAdd(&s_hval[hsl], 1u); break; }
+                    hsl = (hsl + 1) & (hcap - 1);
+                }
+            }
+            nzone = (uint32_t)wave_sum_u64(nzone);
+            __syncthreads();
+            if (lane == 0) s_red[wave * 8] = (double)nzone;
+            // zones per size (sj): reuse s_count, keyed by size
+            for (uint32_t i = tid; i <= area; i += kBlock) s_count[i] = 0;
+            __syncthreads();
+            double sum_p = 0;
+            for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
+            for (uint32_t i = tid; i < hcap; i += kBlock)
+                if (s_hkey[i] != 0xFFFFFFFFu)
+                    atomicAdd(&s_count[s_hkey[i] & 0xFFFFFu], s_hval[i]);
+            __syncthreads();
+            if (sum_p == 0) {                                // glszm.cpp:229-233
+                for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
+            } else {
+                // calc_sums_of_P :342-395 over the non-zero cells
+                double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t i = tid; i < hcap; i += kBlock) {
+                    uint32_t key = s_hkey[i];
+                    if (key == 0xFFFFFFFFu) continue;
+                    double p = (double)s_hval[i];
+                    double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
+                    double i2 = inten * inten, j2 = jd * jd;
+                    acc[0] += p * i2 * j2;                   // f_LAHGLE
+                    acc[1] += p * j2 / i2;                   // f_LALGLE
+                    acc[2] += p * i2 / j2;                   // f_SAHGLE
+                    acc[3] += p / (i2 * j2);                 // f_SALGLE
+                    acc[4] += plog_tex(p / sum_p);           // f_ZE
+                    acc[5] += p / sum_p * jd;                // mu_ZV
+                    acc[6] += p / sum_p * inten;             // mu_GLV
+                }
+                // block reduction (fixed order)
+#pragma unroll
+                for (int k = 0; k < 7; k++) acc[k] = wave_sum(acc[k]);
+                if (lane == 0)
+                    for (int k = 0; k < 7; k++) s_red[wave * 8 + k] = acc[k];
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 7; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                __syncthreads();
+                const double mu_ZV = acc[5], mu_GLV = acc[6];
+                double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t i = tid; i < hcap; i += kBlock) {
+                    uint32_t key = s_hkey[i];
+                    if (key == 0xFFFFFFFFu) continue;
+                    double p = (double)s_hval[i] / sum_p;
+                    double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
+                    b[0] += p * (dg * dg);                   // calc_GLV :497-510
+                    b[1] += p * (dz * dz);                   // calc_ZV :512-524
+                }
+                for (uint32_t j = 1 + tid; j <= area; j += kBlock) {
+                    double sj = (double)s_count[j];
+                    if (sj == 0) continue;
+                    int jj = (int)j * (int)j;
+                    b[2] += sj / (double)jj;                 // calc_SAE :419-428
+                    b[3] += sj * (double)jj;                 // calc_LAE :430-439
+                    b[4] += sj * sj;                         // calc_SZN :464-474
+                }
+                for (int i = tid; i < Ng; i += kBlock) {
+                    double si = (double)s_si[i], inten = (double)s_lv[i];
+                    b[5] += si * si;                         // calc_GLN :441-451
+                    b[6] += si / (inten * inten);            // calc_LGLZE :531-541
+                    b[7] += si * (inten * inten);            // calc_HGLZE :543-553
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) b[k] = wave_sum(b[k]);
+                if (lane == 0)
+                    for (int k = 0; k < 8; k++) s_red[wave * 8 + k] = b[k];
+                __syncthreads();
+                if (tid == 0) {
+                    for (int k = 0; k < 8; k++) b[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                    o[Z_SAE] = b[2] / sum_p;
+                    o[Z_LAE] = b[3] / sum_p;
+                    o[Z_GLN] = b[5] / sum_p;
+                    o[Z_GLNN] = b[5] / (sum_p * sum_p);
+                    o[Z_SZN] = b[4] / sum_p;
+                    o[Z_SZNN] = b[4] / (sum_p * sum_p);
+                    o[Z_ZP] = sum_p / (double)(int)Np_bin;   // calc_ZP :491-495
+                    o[Z_GLV] = b[0];
+                    o[Z_ZV] = b[1];
+                    o[Z_ZE] = -acc[4];
+                    o[Z_LGLZE] = b[6] / sum_p;
+                    o[Z_HGLZE] = b[7] / sum_p;
+                    o[Z_SALGLE] = acc[3] / sum_p;
+                    o[Z_SAHGLE] = acc[2] / sum_p;
+                    o[Z_LALGLE] = acc[1] / sum_p;
+                    o[Z_LAHGLE] = acc[0] / sum_p;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // =====================================================================================
+    // NGTDM
+    // =====================================================================================
+    if (do_ngt) {
+        double* o = s_out + col;
+        col += 5;
+        // IBSI: I = 0..max, row = level (ngtdm.cpp:56-61, :163-166); else rows = unique levels
+        const int NgT = greyInfo == 0 ? (Nuniq ? Ng + 1 : 0) : Nuniq;
+        unsigned long long* s_S = (unsigned long long*)s_work;   // [NgT] sum |i - mean| in units of 1/840
+        uint32_t* s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);        // [NgT]
+        double* s_P = (double*)(s_N + A.L.ng_cap + 2);            // [NgT]
+        double* s_Sd = s_P + A.L.ng_cap + 2;                      // [NgT]
+        if (NgT < 2) {                                            // ngtdm.cpp:70-78
+            for (int c = tid; c < 5; c += kBlock) o[c] = A.soft_nan;
+        } else {
+            for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
+            __syncthreads();
+            for (uint32_t p = tid; p < area; p += kBlock) {
+                uint32_t pi = s_dense[p];
+                if (pi == 0) continue;
+                int row = (int)(p / w), cl = (int)(p - (uint32_t)row * w);
+                uint32_t sum = 0, nd = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                     // N,NE,E,SE,S,SW,W,NW (ngtdm.cpp:92-139)
+                    const int oy = k == 0 || k == 1 || k == 7 ? -1 : (k == 2 || k == 6 ? 0 : 1);
+                    const int ox = k == 1 || k == 2 || k == 3 ? 1 : (k == 0 || k == 4 ? 0 : -1);
+                    int r2 = row + oy, c2 = cl + ox;
+                    if (r2 >= 0 && r2 < (int)h && c2 >= 0 && c2 < (int)w) {
+                        uint32_t q = s_dense[(uint32_t)r2 * w + c2];
+                        if (q != 0) { sum += q; nd++; }
+                    }
+                }
+                if (nd > 0) {
+                    int r = greyInfo == 0 ? (int)pi : (int)s_lvlmap[pi] - 1;
+                    // |pi - sum/nd| * 840 = |840*pi - sum*(840/nd)|, exact integers
+                    long long t = 840ll * (long long)pi - (long long)sum * (long long)(840u / nd);
+                    atomicAdd(&s_N[r], 1u);
+                    atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
+                }
+            }
+            __syncthreads();
+            // Nvc = Nvp = number of pixels with a neighbourhood (every mean is > 0), ngtdm.cpp:176-186
+            uint32_t nvc_part = 0;
+            for (int i = tid; i < NgT; i += kBlock) nvc_part += s_N[i];
+            nvc_part = (uint32_t)wave_sum_u64(nvc_part);
+            if (lane == 0) s_red[wave * 8] = (double)nvc_part;
+            __syncthreads();
+            const double Nvc = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
+            for (int i = tid; i < NgT; i += kBlock) {
+                s_P[i] = (double)s_N[i] / Nvc;
+                s_Sd[i] = (double)s_S[i] / 840.0;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                auto Iof = [=](int i) -> double { return greyInfo == 0 ? (double)i : (double)s_lv[i]; };
+                double ps = 0, ssum = 0;
+                for (int i = lane; i < NgT; i += 64) { ps += s_P[i] * s_Sd[i]; ssum += s_Sd[i]; }
+                ps = wave_sum(ps); ssum = wave_sum(ssum);
+                double c_sum = 0, b_sum = 0, x_sum = 0, s_sum = 0;
+                for (int e = lane; e < NgT * NgT; e += 64) {
+                    int i = e / NgT, j = e - i * NgT;
+                    double pi_ = s_P[i], pj = s_P[j], iv = Iof(i), jv = Iof(j);
+                    double d = iv - jv;
+                    c_sum += pi_ * pj * d * d;                                  // calc_Contrast :245-247
+                    if (pi_ != 0 && pj != 0) {
+                        b_sum += fabs(pi_ * iv - pj * jv);                       // calc_Busyness :280-283
+                        x_sum += fabs(d) * (pi_ * s_Sd[i] + pj * s_Sd[j]) / (pi_ + pj); // calc_Complexity :305
+                        s_sum += (pi_ + pj) * d * d;                             // calc_Strength :326
+                    }
+                }
+                c_sum = wave_sum(c_sum); b_sum = wave_sum(b_sum); x_sum = wave_sum(x_sum); s_sum = wave_sum(s_sum);
+                if (lane == 0) {
+                    int Ngp = Nuniq;
+                    int Ngp_p2 = Ngp > 1 ? Ngp * (Ngp - 1) : Ngp;
+                    o[0] = 1.0 / ps;                                             // calc_Coarseness :228-236
+                    o[1] = (c_sum / (double)Ngp_p2) * (ssum / Nvc);              // calc_Contrast :251-261
+                    o[2] = Ngp == 1 ? 0.0 : (b_sum == 0 ? 0.0 : ps / b_sum);     // calc_Busyness :266-291
+                    o[3] = x_sum / (double)(int)Nvc;                             // calc_Complexity :310 (Nvp)
+                    o[4] = s_sum / ssum;                                         // calc_Strength :331-335
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    __syncthreads();
+    for (int c = tid; c < A.n_cols; c += kBlock)
+        out_row[c] = s_out[c];
+}
+
+int launch_roi_texture(const TexArgs& a, void* stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)roi_features_max_lds());
+        if (e != hipSuccess)
+            return (int)e;
+        attr_set = true;
+    }
+    if (a.n_roi == 0)
+        return 0;
+    hipLaunchKernelGGL(roi_texture_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

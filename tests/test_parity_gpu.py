@@ -96,6 +96,48 @@ def test_reference_golden_fixtures_through_hip(hip_ctx):
             assert abs(got - v) <= abs(v) / 100.0, (gold, k, got, v)
 
 
+TEX = _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+
+
+@pytest.mark.parametrize("gd,ibsi", [(8, False), (64, False), (-16, False), (20, True), (100, False)])
+def test_texture_families_random_rois(hip_ctx, gd, ibsi):
+    """GLRLM + GLSZM + NGTDM (roi_texture.hip) vs oracle and the reference classes."""
+    rois = synth.random_rois(100, seed=21)
+    if ibsi:
+        rois = [dict(r, inten=(np.asarray(r["inten"]) % 9).astype(np.uint32)) for r in rois]
+        rois = [r for r in rois if np.asarray(r["inten"]).max() > 0]  # reference UB on all-zero IBSI NGTDM (ngtdm.cpp:58)
+    _check(hip_ctx, _abi.batch_from_rois(rois), TEX, _abi.default_settings(gd, ibsi))
+
+
+@pytest.mark.parametrize("fam", [_abi.FAM_GLRLM, _abi.FAM_GLSZM, _abi.FAM_NGTDM])
+def test_texture_single_family(hip_ctx, fam):
+    _check(hip_ctx, _abi.batch_from_rois(synth.random_rois(40, seed=2)), fam, _abi.default_settings(8))
+
+
+def test_all_five_families_on_benchmark_tile(hip_ctx):
+    """Config 4 feature set (*ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY*) on one tile."""
+    b = synth.tile_batch(3, irregular=True)
+    G = _check(hip_ctx, b, MASK | TEX, _abi.default_settings(8))
+    assert G.shape == (196, 185 + 80 + 16 + 5)
+
+
+def test_texture_goldens_through_hip(hip_ctx):
+    """Reference golden tables (tests/test_2d_{glrlm,glszm,ngtdm}_{regression,ibsi}.h) through the HIP path."""
+    ref = fixtures.reference_tests()
+    b = fixtures.ibsi_phantom_batch(ref)
+    cases = [(_abi.FAM_GLRLM, "glrlm_2d_regression_ref_vals", 100, False, True), (_abi.FAM_GLRLM, "glrlm_2d_ibsi_ref_vals", 128, True, True),
+             (_abi.FAM_GLSZM, "glszm_2d_regression_ref_vals", 64, False, False), (_abi.FAM_GLSZM, "glszm_2d_ibsi_ref_vals", 128, True, False),
+             (_abi.FAM_NGTDM, "ngtdm_2d_regression_ref_vals", 100, False, False), (_abi.FAM_NGTDM, "ngtdm_2d_ibsi_ref_vals", 128, True, False)]
+    for fam, gold, gd, ibsi, angled in cases:
+        s = _abi.default_settings(gd, ibsi)
+        T = hip_ctx.featurize_host(b, fam, s)
+        names = _lib.column_names(fam, s)
+        for k, v in ref["goldens"][gold].items():
+            cols = [i for i, n in enumerate(names) if n == k or n in (f"{k}_0", f"{k}_45", f"{k}_90", f"{k}_135")]
+            got = T[:, cols].sum() / (16.0 if angled else 4.0)
+            assert abs(got - v) <= abs(v) / 100.0, (gold, k, got, v)
+
+
 def test_device_resident_async_path(hip_ctx):
     """Device pointers + async launch on torch's current stream (the bench path)."""
     import torch
@@ -134,5 +176,5 @@ def test_roi_too_large_is_reported(hip_ctx):
 def test_unimplemented_family_is_an_error_not_a_fallback(hip_ctx):
     b = _abi.batch_from_rois(synth.random_rois(3))
     with pytest.raises(_lib.NyxHipError) as ei:
-        hip_ctx.featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(8))
+        hip_ctx.featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(8))  # not built yet
     assert ei.value.code == 4
