@@ -35,6 +35,13 @@ void nyxo_glszm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, ui
 void nyxo_ngtdm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
                 const nyxhip_settings* s, double* out);
 
+/* features/gabor.cpp:43-123, :333-510 -> out[gabor_n_filters]; zernike.cpp:176-363 -> out[30] */
+void nyxo_gabor_kernel(double* Gex, double f0, double sig2lam, double gamma, double theta, double fi, int n);
+void nyxo_gabor(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                const nyxhip_settings* s, double* out);
+void nyxo_zernike(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                  const nyxhip_settings* s, double* out);
+
 int nyxo_n_columns(uint32_t mask, const nyxhip_settings* s);
 
 /* Host-memory batch, same argument meaning as nyxhip_featurize_batch. */

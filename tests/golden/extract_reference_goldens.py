@@ -60,7 +60,7 @@ def main():
            "pixels": {}, "goldens": {}, "vector_goldens": {}}
     td = strip_comments(open(os.path.join(REF, "test_data.h")).read())
     px = pixel_arrays(td)
-    for k in ["pixelIntensityFeaturesTestData"] + [f"ibsi_phantom_z{z}_{kind}" for z in range(1, 5) for kind in ("intensity", "mask")]:
+    for k in ["pixelIntensityFeaturesTestData", "shape2d_morphology_intensity", "shape2d_morphology_mask"] + [f"ibsi_phantom_z{z}_{kind}" for z in range(1, 5) for kind in ("intensity", "mask")]:
         res["pixels"][k] = px[k]
 
     dsb = strip_comments(open(os.path.join(REF, "test_dsb2018_data.h")).read())

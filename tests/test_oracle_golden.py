@@ -174,3 +174,38 @@ def test_texture_families_match_reference_classes_bit_exact(gd, ibsi):
     R = po.ref_featurize(b, mask, s, n_threads=2)
     same = (A == R) | (np.isnan(A) & np.isnan(R))
     assert same.all(), np.argwhere(~same)[:10]
+
+
+def test_gabor_truth_goldens():
+    """tests/test_gabor_truth.h:27-47: 4 DSB2018 ROIs x 4 default filters, vetted vs scikit-image;
+    asserted at rel 1e-3 by the reference (test_2d_gabor_skimage.cc:17), matched exactly here."""
+    b = _abi.batch_from_rois([fixtures.dsb_roi(d) for d in REF["dsb2018"]])
+    G = po.oracle_featurize(b, _abi.FAM_GABOR, _abi.default_settings(64))
+    T = np.array(REF["gabor_truth"])
+    assert G.shape == T.shape
+    assert np.all(np.abs(G - T) <= np.abs(T) / 1000.0)
+
+
+def test_zernike_regression_golden():
+    """tests/test_2d_zernike_regression.h:12-24 on the 8x8 shape2d fixture, abs 1e-9."""
+    r = fixtures.roi_from_triplets(REF["pixels"]["shape2d_morphology_intensity"], REF["pixels"]["shape2d_morphology_mask"])
+    z = po.oracle_featurize(_abi.batch_from_rois([r]), _abi.FAM_ZERNIKE, _abi.default_settings(128))[0]
+    want = np.array(REF["vector_goldens"]["zernike_2d_regression_ref_vals"]["ZERNIKE2D"])
+    assert np.all(np.abs(z - want) <= 1e-9)
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libnyxref.so not built (needs /root/reference)")
+def test_gabor_zernike_match_reference_classes_bit_exact():
+    rois = synth.random_rois(40, seed=4, rmax=12) + [fixtures.dsb_roi(d) for d in REF["dsb2018"]]
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(64)
+    # an 8-filter bank like BASELINE.json configs[4]
+    s.gabor_n_filters = 8
+    for i in range(8):
+        s.gabor_f0[i] = [4.0, 16.0, 32.0, 64.0][i % 4]
+        s.gabor_theta[i] = np.pi * i / 8
+    mask = _abi.FAM_GABOR | _abi.FAM_ZERNIKE
+    A = po.oracle_featurize(b, mask, s)
+    R = po.ref_featurize(b, mask, s, n_threads=2)
+    same = (A == R) | (np.isnan(A) & np.isnan(R))
+    assert same.all(), np.argwhere(~same)[:10]
