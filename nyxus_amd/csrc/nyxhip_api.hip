@@ -25,6 +25,9 @@ struct nyxhip_ctx {
     bool use_user_stream = false;
     int* d_status = nullptr;
     uint32_t* d_extrema = nullptr; // [4]
+    // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
+    double* d_bank = nullptr;
+    std::vector<double> bank_key;
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
     // grow-only device staging for host-memory batches
@@ -91,7 +94,8 @@ const int kGlrlmAngles[4] = {0, 45, 90, 135}; // GLRLMFeature::rotAngles, glrlm.
 
 // families the kernels cover so far
 constexpr uint32_t kTexture = NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM | NYXHIP_FAM_NGTDM;
-constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture;
+constexpr uint32_t kShape = NYXHIP_FAM_GABOR | NYXHIP_FAM_ZERNIKE;
+constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture | kShape;
 
 bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
 {
@@ -106,6 +110,10 @@ bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
             if (a != 0 && a != 45 && a != 90 && a != 135) { why = "unsupported GLCM angle (glcm.cpp:252-254)"; return false; }
         }
         if (s->glcm_offset < 0) { why = "glcm_offset must be >= 0"; return false; }
+    }
+    if (mask & NYXHIP_FAM_GABOR) {
+        if (s->gabor_n_filters < 0 || s->gabor_n_filters > NYXHIP_MAX_GABOR_FILTERS) { why = "gabor_n_filters out of range"; return false; }
+        if (s->gabor_kersize < 1 || s->gabor_kersize > 64) { why = "gabor_kersize out of range (1..64)"; return false; }
     }
     return true;
 }
@@ -130,6 +138,10 @@ std::vector<std::string> column_names(uint32_t mask, const nyxhip_settings* s)
         for (auto n : kGlszmNames) v.push_back(n);
     if (mask & NYXHIP_FAM_NGTDM)
         for (auto n : kNgtdmNames) v.push_back(n);
+    if (mask & NYXHIP_FAM_GABOR)
+        for (int i = 0; i < s->gabor_n_filters; i++) v.push_back("GABOR_" + std::to_string(i));       // output_2_buffer.cpp:364-373
+    if (mask & NYXHIP_FAM_ZERNIKE)
+        for (int i = 0; i < kZernikeCols; i++) v.push_back("ZERNIKE2D_Z" + std::to_string(i));        // :417-427
     return v;
 }
 
@@ -222,6 +234,71 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
               std::to_string(max_px) + ", max_bbox_area=" + std::to_string(max_area) + ")";
         return NYXHIP_ERR_ROI_TOO_LARGE;
     }
+    return NYXHIP_OK;
+}
+
+// One n x n complex Gabor kernel, interleaved re/im, L1-normalised by the sum of magnitudes:
+// the formula and evaluation order of GaborFeature::Gabor (features/gabor.cpp:393-449), run
+// on the host with libm exactly as the reference does.
+void gabor_filter(double* Gex, double f0, double sig2lam, double gamma, double theta, double fi, int n)
+{
+    const double lambda = 2 * M_PI / f0, cos_theta = cos(theta), sin_theta = sin(theta), sig = sig2lam * lambda;
+    std::vector<double> tx(n + 1), ty(n + 1);
+    tx[0] = (n % 2 > 0) ? -((n - 1) / 2) : -(n / 2);
+    for (int x = 1; x < n; x++) tx[x] = tx[x - 1] + 1;
+    ty[0] = tx[0];
+    for (int y = 1; y < n; y++) ty[y] = ty[y - 1] + 1;
+    double sum = 0;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            double xte = tx[x] * cos_theta + ty[y] * sin_theta;
+            double yte = ty[y] * cos_theta - tx[x] * sin_theta;
+            double rte = xte * xte + gamma * gamma * yte * yte;
+            double ge = exp(-1 * rte / (2 * sig * sig));
+            double argm = xte * f0 + fi;
+            int idx = y * n * 2 + x * 2;
+            Gex[idx] = ge * cos(argm);
+            Gex[idx + 1] = ge * sin(argm);
+            sum += sqrt(pow(Gex[idx], 2) + pow(Gex[idx + 1], 2));
+        }
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n * 2; x++)
+            Gex[y * n * 2 + x] /= sum;
+}
+
+// Low-pass baseline filter (f0LP at theta = pi/2, gabor.cpp:79) followed by the (f0, theta) pairs.
+int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
+{
+    const int n = s->gabor_kersize, nF = s->gabor_n_filters;
+    std::vector<double> key = {s->gabor_gamma, s->gabor_sig2lam, s->gabor_f0lp, (double)n, (double)nF};
+    for (int i = 0; i < nF; i++) { key.push_back(s->gabor_f0[i]); key.push_back(s->gabor_theta[i]); }
+    if (ctx->d_bank && key == ctx->bank_key)
+        return NYXHIP_OK;
+    std::vector<double> bank((size_t)(nF + 1) * n * n * 2);
+    gabor_filter(bank.data(), s->gabor_f0lp, s->gabor_sig2lam, s->gabor_gamma, M_PI_2, 0, n);
+    for (int f = 0; f < nF; f++)
+        gabor_filter(bank.data() + (size_t)(f + 1) * n * n * 2, s->gabor_f0[f], s->gabor_sig2lam, s->gabor_gamma, s->gabor_theta[f], 0, n);
+    if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank, bank.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_bank, bank.data(), bank.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->bank_key = key;
+    return NYXHIP_OK;
+}
+
+int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, ShapeLayout& L, std::string& why)
+{
+    memset(&L, 0, sizeof(L));
+    if (!(mask & NYXHIP_FAM_GABOR))
+        return NYXHIP_OK;
+    uint32_t off = 0;
+    L.red = off; off = align16(off + 8u * kWaves * 8);
+    L.area_cap = max_area ? max_area : 1;
+    if (16ull * L.area_cap > roi_features_max_lds()) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    L.plane = off; off = align16(off + 8u * L.area_cap);
+    L.energy = off; off = align16(off + 8u * L.area_cap);
+    L.bank = off; off = align16(off + 16u * (uint32_t)(s->gabor_n_filters + 1) * s->gabor_kersize * s->gabor_kersize);
+    L.total = off;
+    if (L.total > roi_features_max_lds()) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     return NYXHIP_OK;
 }
 
@@ -338,7 +415,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
 {
     std::string why;
     const int n_cols = nyxhip_n_columns(mask, s);
-    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture;
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape;
     const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s);
     RoiArgs a;
     memset(&a, 0, sizeof(a));
@@ -374,6 +451,24 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         t.mask = mask2; t.n_cols = n_cols2; t.col0 = n_cols1;
         t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
     }
+    ShapeArgs g;
+    memset(&g, 0, sizeof(g));
+    if (mask3) {
+        if (int lrc = make_shape_layout(mask3, s, max_area, g.L, why))
+            return fail(ctx, lrc, why);
+        if (mask3 & NYXHIP_FAM_GABOR)
+            if (int brc = ensure_gabor_bank(ctx, s))
+                return brc;
+        g.n_roi = b->n_roi;
+        g.px_offset = b->px_offset; g.x = b->x; g.y = b->y; g.inten = b->inten;
+        g.bbox_w = b->bbox_w; g.bbox_h = b->bbox_h; g.min_inten = b->min_inten; g.max_inten = b->max_inten;
+        g.out = d_out; g.ld = ld; g.status = ctx->d_status;
+        g.mask = mask3;
+        g.col_gabor = n_cols1 + n_cols2;
+        g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
+        g.soft_nan = s->soft_nan;
+        g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+    }
     (void)n_cols;
 
     hipStream_t st = ctx->stream();
@@ -393,6 +488,8 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     int rc = mask1 ? launch_roi_features(a, st) : 0;
     if (rc == 0 && mask2)
         rc = launch_roi_texture(t, st);
+    if (rc == 0 && mask3)
+        rc = launch_roi_shape(g, st);
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     if (ctx->timing)
@@ -407,7 +504,7 @@ int validate(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip
     if (mask == 0 || (mask & ~NYXHIP_FAM_ALL)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
     if (mask & ~kImplemented)
         return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "requested feature family is not implemented by the HIP path yet "
-                    "(implemented: INTENSITY, GLCM, GLRLM, GLSZM, NGTDM)");
+                    "(all seven hot-path families are implemented; bad mask?)");
     std::string why;
     if (!settings_ok(s, mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
     if (b->n_roi && (!b->px_offset || !b->x || !b->y || !b->inten || !b->bbox_w || !b->bbox_h || !b->min_inten || !b->max_inten))
@@ -480,6 +577,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
+    if (ctx->d_bank) (void)hipFree(ctx->d_bank);
     if (ctx->d_stamps) {
         unsigned long long h[32];
         if (hipMemcpy(h, ctx->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -512,6 +610,8 @@ int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s)
     if (family_mask & NYXHIP_FAM_GLRLM) n += kGlrlmCols;
     if (family_mask & NYXHIP_FAM_GLSZM) n += kGlszmCols;
     if (family_mask & NYXHIP_FAM_NGTDM) n += kNgtdmCols;
+    if (family_mask & NYXHIP_FAM_GABOR) n += s->gabor_n_filters;
+    if (family_mask & NYXHIP_FAM_ZERNIKE) n += kZernikeCols;
     return n;
 }
 

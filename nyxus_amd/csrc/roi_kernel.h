@@ -101,9 +101,44 @@ struct TexArgs {
     TexLayout L;
 };
 
-// implemented in roi_features.hip / roi_texture.hip
+// ---- third kernel pair: Gabor + Zernike (roi_shape.hip) -------------------------------------
+constexpr int kZernikeCols = 30;          // ZernikeFeature::NUM_FEATURE_VALS (zernike.h:30)
+
+struct ShapeLayout {
+    uint32_t red;       // double[kWaves*8]
+    uint32_t plane;     // double[area_cap]   original intensities (0 = background)
+    uint32_t energy;    // double[area_cap]   low-pass response magnitudes
+    uint32_t bank;      // double[(F+1)*n*n*2]
+    uint32_t total;
+    uint32_t area_cap;
+};
+
+struct ShapeArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;            // subset of GABOR | ZERNIKE
+    int32_t col_gabor, col_zernike;
+    double soft_nan;
+    const double* gabor_bank; // device: (F+1) filters (low-pass first), n*n complex taps each
+    int32_t gabor_nf, gabor_n;
+    double gabor_thr;
+    ShapeLayout L;
+};
+
+// implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream);
 int launch_roi_texture(const TexArgs& a, void* stream);
+int launch_roi_shape(const ShapeArgs& a, void* stream);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

@@ -1,0 +1,285 @@
+// roi_shape.hip -- Gabor filter-bank scores and Zernike moment magnitudes for gfx950.
+//
+//   roi_gabor_kernel    one workgroup per ROI.  The ROI's bounding-box plane and the whole
+//                       complex filter bank sit in LDS; every thread produces output pixels
+//                       of the cropped full convolution, accumulating taps in exactly the
+//                       reference's (j, i) order with separate multiply and add
+//                       (/root/reference/src/nyx/features/gabor.cpp:333-390 conv_dud,
+//                       :452-510 GaborEnergy, :43-123 calculate).  The feature is a ratio of
+//                       threshold COUNTS, so one flipped pixel is a visible error: the
+//                       arithmetic is therefore kept bit-identical instead of being routed
+//                       through MFMA (fused, reordered; and on MI355X the fp64 matrix peak
+//                       equals the fp64 vector peak, so there is nothing to win).
+//                       The bank itself is built on the host with libm, like the reference
+//                       (gabor.cpp:393-449), and uploaded once per settings.
+//   roi_zernike_kernel  one workgroup per ROI, straight from the pixel cloud (background
+//                       pixels carry zero weight, so the dense plane is never needed):
+//                       integer-exact centroid moments, then each thread accumulates the
+//                       30 complex moments of order <= 9 for its pixels in registers
+//                       (features/zernike.cpp:176-343), wave/block reduction, magnitudes.
+//
+// Built with -ffp-contract=off (device_math.h).
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// =========================================================================================
+// Gabor
+// =========================================================================================
+__global__ __launch_bounds__(kBlock) void roi_gabor_kernel(const ShapeArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    double* s_red = (double*)(lds + A.L.red);
+    double* s_plane = (double*)(lds + A.L.plane);   // [area] original intensities as double, 0 = background
+    double* s_e = (double*)(lds + A.L.energy);      // [area] low-pass response magnitudes
+    double* s_bank = (double*)(lds + A.L.bank);     // [(F+1)][n*n][2]
+
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t area = w * h;
+    const int nF = A.gabor_nf, n = A.gabor_n;
+    double* const o = A.out + roi * A.ld + A.col_gabor;
+    if (npx == 0 || area > A.L.area_cap) {
+        if (tid == 0 && npx != 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        for (int c = tid; c < nF; c += kBlock)
+            o[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    if (A.max_inten[roi] == A.min_inten[roi]) {     // gabor.cpp:53-57: all zeros, not the soft NaN
+        for (int c = tid; c < nF; c += kBlock)
+            o[c] = 0.0;
+        return;
+    }
+    for (uint32_t i = tid; i < area; i += kBlock)
+        s_plane[i] = 0.0;
+    const int bank_len = (nF + 1) * n * n * 2;
+    for (int i = tid; i < bank_len; i += kBlock)
+        s_bank[i] = A.gabor_bank[i];
+    __syncthreads();
+    for (uint32_t i = tid; i < npx; i += kBlock) {
+        uint32_t px = A.x[off + i], py = A.y[off + i];
+        if (px < w && py < h)
+            s_plane[py * w + px] = (double)A.inten[off + i];
+    }
+    __syncthreads();
+
+    const int c0 = (n + 1) / 2;                     // (int)ceil(n / 2.), gabor.cpp:492
+    double maxval = 0, baseline = 0;
+    for (int f = 0; f <= nF; f++) {
+        const double* G = s_bank + (size_t)f * n * n * 2;
+        double tmax = -1.0, tmin = 1.7976931348623157e308;
+        uint32_t score = 0;
+        for (uint32_t p = tid; p < area; p += kBlock) {
+            const int b = (int)(p / w), a = (int)(p - (uint32_t)b * w);
+            const int y = c0 + b, x = c0 + a;
+            // taps (j, i) with 0 <= y-j < h and 0 <= x-i < w, ascending as in conv_dud
+            const int j0 = y - ((int)h - 1) > 0 ? y - ((int)h - 1) : 0, j1 = y < n - 1 ? y : n - 1;
+            const int i0 = x - ((int)w - 1) > 0 ? x - ((int)w - 1) : 0, i1 = x < n - 1 ? x : n - 1;
+            double re = 0.0, im = 0.0;
+            for (int j = j0; j <= j1; ++j) {
+                const double* Arow = s_plane + (uint32_t)(y - j) * w;
+                const double* Grow = G + (j * n) * 2;
+                for (int i = i0; i <= i1; ++i) {
+                    double av = Arow[x - i];
+                    re += av * Grow[2 * i];        // C[ip]   += a * wr   (gabor.cpp:374)
+                    im += av * Grow[2 * i + 1];    // C[ip+1] += a * wi   (:377)
+                }
+            }
+            const double e = sqrt(re * re + im * im);   // :505
+            if (f == 0) {
+                s_e[p] = e;
+                tmax = e > tmax ? e : tmax;
+                tmin = e < tmin ? e : tmin;
+            } else if (e / maxval > A.gabor_thr)         // :117
+                score++;
+        }
+        if (f == 0) {
+            tmax = wave_max_d(tmax);
+            tmin = wave_min_d(tmin);
+            if (lane == 0) { s_red[wave * 8] = tmax; s_red[wave * 8 + 1] = tmin; }
+            __syncthreads();
+            double mx = s_red[0], mn = s_red[1];
+            for (int wv = 1; wv < kWaves; wv++) {
+                mx = s_red[wv * 8] > mx ? s_red[wv * 8] : mx;
+                mn = s_red[wv * 8 + 1] < mn ? s_red[wv * 8 + 1] : mn;
+            }
+            __syncthreads();
+            if (mx == mn) {                               // gabor.cpp:91-96
+                for (int c = tid; c < nF; c += kBlock)
+                    o[c] = A.soft_nan;
+                return;
+            }
+            maxval = mx;
+            uint32_t cnt = 0;                             // baseline score, :99-102
+            for (uint32_t p = tid; p < area; p += kBlock)
+                cnt += s_e[p] > mn;
+            cnt = (uint32_t)wave_sum_u64(cnt);
+            if (lane == 0) s_red[wave * 8] = (double)cnt;
+            __syncthreads();
+            baseline = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
+            __syncthreads();
+        } else {
+            score = (uint32_t)wave_sum_u64(score);
+            if (lane == 0) s_red[wave * 8] = (double)score;
+            __syncthreads();
+            if (tid == 0)
+                o[f - 1] = (((s_red[0] + s_red[8]) + s_red[16]) + s_red[24]) / baseline;   // :121
+            __syncthreads();
+        }
+    }
+}
+
+// =========================================================================================
+// Zernike (order 9: 30 magnitudes)
+// =========================================================================================
+constexpr int kZL = 9;
+
+// H1/H2/H3 of zernike.cpp:234-248, constant-folded per (n, m)
+__device__ __forceinline__ constexpr double zH3(int n, int m) { return -(double)(4.0 * (m + 2.0) * (m + 1.0)) / (double)((n + m + 2.0) * (n - m)); }
+__device__ __forceinline__ constexpr double zH2(int n, int m) { return ((double)(zH3(n, m) * (n + m + 4.0) * (n - m - 2.0)) / (double)(4.0 * (m + 3.0))) + (m + 2.0); }
+__device__ __forceinline__ constexpr double zH1(int n, int m)
+{
+    return ((double)((m + 4.0) * (m + 3.0)) / 2.0) - ((m + 4.0) * zH2(n, m)) + ((double)(zH3(n, m) * (n + m + 6.0) * (n - m - 4.0)) / 8.0);
+}
+
+__global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
+{
+    __shared__ double s_red[kWaves * 64];
+    __shared__ unsigned long long s_mom[kWaves * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    double* const o = A.out + roi * A.ld + A.col_zernike;
+    if (npx == 0 || A.max_inten[roi] == A.min_inten[roi]) {   // zernike.cpp:348-356
+        for (int c = tid; c < 30; c += kBlock)
+            o[c] = npx == 0 ? __longlong_as_double(0x7ff8000000000000LL) : A.soft_nan;
+        return;
+    }
+    // centroid moments (zernike.cpp:216-230): sums of integers, exact in any order
+    unsigned long long m00 = 0, m10 = 0, m01 = 0;
+    for (uint32_t i = tid; i < npx; i += kBlock) {
+        unsigned long long v = A.inten[off + i];
+        m00 += v;
+        m10 += ((unsigned long long)A.x[off + i] + 1) * v;
+        m01 += ((unsigned long long)A.y[off + i] + 1) * v;
+    }
+    m00 = wave_sum_u64(m00); m10 = wave_sum_u64(m10); m01 = wave_sum_u64(m01);
+    if (lane == 0) { s_mom[wave * 4] = m00; s_mom[wave * 4 + 1] = m10; s_mom[wave * 4 + 2] = m01; }
+    __syncthreads();
+    unsigned long long t00 = 0, t10 = 0, t01 = 0;
+    for (int wv = 0; wv < kWaves; wv++) { t00 += s_mom[wv * 4]; t10 += s_mom[wv * 4 + 1]; t01 += s_mom[wv * 4 + 2]; }
+    const double sum = (double)t00;
+    const double m10_m00 = (double)t10 / sum, m01_m00 = (double)t01 / sum;
+    const double rad = (double)(w < h ? w : h);                // N = min(width, height), :185-195
+
+    double AR[kZL + 1][kZL + 1], AI[kZL + 1][kZL + 1];
+#pragma unroll
+    for (int n = 0; n <= kZL; n++)
+#pragma unroll
+        for (int m = 0; m <= kZL; m++) { AR[n][m] = 0.0; AI[n][m] = 0.0; }
+
+    for (uint32_t i = tid; i < npx; i += kBlock) {
+        const double x = ((double)((int)A.x[off + i] + 1) - m10_m00) / rad;   // :254
+        const double y = ((double)((int)A.y[off + i] + 1) - m01_m00) / rad;   // :262
+        const double r2 = x * x + y * y, r = sqrt(r2);
+        if (r < 2.2204460492503131e-16 || r > 1.0)
+            continue;
+        double R[kZL + 1], COST[kZL + 1], SINT[kZL + 1];
+        R[0] = 1;
+#pragma unroll
+        for (int n = 1; n <= kZL; n++) R[n] = r * R[n - 1];
+        const double a = x / r, b = y / r;
+        COST[0] = a; SINT[0] = b;
+#pragma unroll
+        for (int m = 1; m <= kZL; m++) {
+            COST[m] = a * COST[m - 1] - b * SINT[m - 1];
+            SINT[m] = a * SINT[m - 1] + b * COST[m - 1];
+        }
+        const double f = (double)A.inten[off + i] / sum;
+        double Rnm = 0, Rnm2 = 0, Rnmp2 = 0, Rnmp4 = 0;
+#pragma unroll
+        for (int n = 0; n <= kZL; n++) {
+            const double const_t = (double)(n + 1) * f / 3.14159265358979323846;
+            const double Rn = R[n];
+            if (n >= 2) Rnm2 = R[n - 2];
+#pragma unroll
+            for (int m = n; m >= 0; m -= 2) {
+                if (m == n) { Rnm = Rn; Rnmp4 = Rn; }
+                else if (m == n - 2) { Rnm = (double)n * Rn - (double)(n - 1) * Rnm2; Rnmp2 = Rnm; }
+                else { Rnm = zH1(n, m) * Rnmp4 + (zH2(n, m) + (zH3(n, m) / r2)) * Rnmp2; Rnmp4 = Rnmp2; Rnmp2 = Rnm; }
+                AR[n][m] += const_t * Rnm * COST[m];
+                AI[n][m] -= const_t * Rnm * SINT[m];
+            }
+        }
+    }
+    // reduce the 30 complex accumulators over the workgroup
+    int k = 0;
+#pragma unroll
+    for (int n = 0; n <= kZL; n++)
+#pragma unroll
+        for (int m = 0; m <= n; m++)
+            if ((n - m) % 2 == 0) {
+                double vr = wave_sum(AR[n][m]), vi = wave_sum(AI[n][m]);
+                if (lane == 0) { s_red[wave * 64 + 2 * k] = vr; s_red[wave * 64 + 2 * k + 1] = vi; }
+                k++;
+            }
+    __syncthreads();
+    if (tid < 30) {
+        double vr = ((s_red[2 * tid] + s_red[64 + 2 * tid]) + s_red[128 + 2 * tid]) + s_red[192 + 2 * tid];
+        double vi = ((s_red[2 * tid + 1] + s_red[64 + 2 * tid + 1]) + s_red[128 + 2 * tid + 1]) + s_red[192 + 2 * tid + 1];
+        o[tid] = fabs(sqrt(vr * vr + vi * vi));                // zernike.cpp:335-337
+    }
+}
+
+int launch_roi_shape(const ShapeArgs& a, void* stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)roi_features_max_lds());
+        if (e != hipSuccess)
+            return (int)e;
+        attr_set = true;
+    }
+    if (a.n_roi == 0)
+        return 0;
+    if (a.mask & NYXHIP_FAM_GABOR)
+        hipLaunchKernelGGL(roi_gabor_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    if (a.mask & NYXHIP_FAM_ZERNIKE)
+        hipLaunchKernelGGL(roi_zernike_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

@@ -173,8 +173,56 @@ def test_roi_too_large_is_reported(hip_ctx):
     assert ei.value.code == 5
 
 
-def test_unimplemented_family_is_an_error_not_a_fallback(hip_ctx):
+def test_bad_family_mask_is_an_error(hip_ctx):
     b = _abi.batch_from_rois(synth.random_rois(3))
     with pytest.raises(_lib.NyxHipError) as ei:
-        hip_ctx.featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(8))  # not built yet
-    assert ei.value.code == 4
+        hip_ctx.featurize_host(b, 1 << 9, _abi.default_settings(8))
+    assert ei.value.code == 1
+
+
+SHAPE = _abi.FAM_GABOR | _abi.FAM_ZERNIKE
+
+
+def _bank8(s):
+    """8-filter bank of BASELINE.json configs[4]: theta in {0, 22.5, ..., 157.5} deg, f0 cycling {4,16,32,64}."""
+    s.gabor_n_filters = 8
+    for i in range(8):
+        s.gabor_f0[i] = [4.0, 16.0, 32.0, 64.0][i % 4]
+        s.gabor_theta[i] = np.pi * i / 8
+    return s
+
+
+def test_gabor_zernike_reference_goldens_through_hip(hip_ctx):
+    """tests/test_gabor_truth.h:27-47 (4 DSB2018 ROIs x default bank, exact counts) and
+    tests/test_2d_zernike_regression.h:12-24 (abs 1e-9) through the HIP path."""
+    ref = fixtures.reference_tests()
+    b = _abi.batch_from_rois([fixtures.dsb_roi(d) for d in ref["dsb2018"]])
+    G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(64))
+    assert np.array_equal(G, np.array(ref["gabor_truth"]))      # count ratios: bit-exact
+    r = fixtures.roi_from_triplets(ref["pixels"]["shape2d_morphology_intensity"], ref["pixels"]["shape2d_morphology_mask"])
+    z = hip_ctx.featurize_host(_abi.batch_from_rois([r]), _abi.FAM_ZERNIKE, _abi.default_settings(128))[0]
+    want = np.array(ref["vector_goldens"]["zernike_2d_regression_ref_vals"]["ZERNIKE2D"])
+    assert np.all(np.abs(z - want) <= 1e-9)
+
+
+def test_gabor_zernike_random_and_dsb_rois(hip_ctx):
+    """Config 5 shape: DSB2018-sized ROIs, 8-orientation bank + ZERNIKE2D; Gabor is compared bit-exact."""
+    ref = fixtures.reference_tests()
+    rois = synth.random_rois(60, seed=4, rmax=12) + [fixtures.dsb_roi(d) for d in ref["dsb2018"]]
+    b = _abi.batch_from_rois(rois)
+    s = _bank8(_abi.default_settings(64))
+    names = _lib.column_names(SHAPE, s)
+    G = hip_ctx.featurize_host(b, SHAPE, s)
+    O = po.oracle_featurize(b, SHAPE, s)
+    gab = [i for i, n in enumerate(names) if n.startswith("GABOR")]
+    assert np.array_equal(G[:, gab], O[:, gab]) or ((G[:, gab] == O[:, gab]) | (np.isnan(G[:, gab]) & np.isnan(O[:, gab]))).all()
+    assert not parity.compare_tables(G, O, names)
+    if po.have_ref():
+        assert not parity.compare_tables(G, po.ref_featurize(b, SHAPE, s, 2), names)
+
+
+def test_all_seven_families_one_call(hip_ctx):
+    b = synth.tile_batch(4, irregular=True, size=512)
+    s = _bank8(_abi.default_settings(8))
+    G = _check(hip_ctx, b, _abi.FAM_ALL, s, against_ref=False)
+    assert G.shape[1] == 185 + 80 + 16 + 5 + 8 + 30
