@@ -6,5 +6,6 @@ Gabor / Zernike families, as hand-written HIP kernels for gfx950 behind the
 C ABI of ``include/nyxhip.h``.
 """
 from . import _abi  # noqa: F401
+from .nyxus import Nyxus  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/api_featurize.json: input/output pairs of the reference's own
+`Nyxus.featurize()` (the Python API on top of the hot path), captured by importing the reference
+package in the build container.  Only DATA is stored: input arrays + constructor kwargs + the
+resulting DataFrame (columns, string columns, numeric values).
+
+The reference Python package needs its compiled pybind11 backend.  It is looked up in
+$NYXUS_REF_PKG (default /tmp/nyx_oracle_pkg, built from /root/reference by the recipe in
+SURVEY.md section 8c) and must be run with the system libstdc++ preloaded:
+
+    LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 python tests/golden/make_api_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("NYXUS_REF_PKG", "/tmp/nyx_oracle_pkg"))
+import nyxus  # noqa: E402  (the REFERENCE package)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "api_featurize.json")
+
+
+def run(features, kwargs, inten, seg, names=None):
+    nyx = nyxus.Nyxus(features, **kwargs)
+    if names:
+        df = nyx.featurize(inten.copy(), seg.copy(), intensity_names=names[0], label_names=names[1])
+    else:
+        df = nyx.featurize(inten.copy(), seg.copy())
+    num = df.select_dtypes(include=[np.number])
+    return {"features": features, "kwargs": kwargs, "inten": inten.tolist(), "inten_dtype": str(inten.dtype),
+            "seg": seg.tolist(), "names": names, "columns": list(df.columns),
+            "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
+            "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
+
+
+def main():
+    cases = {}
+    # (1) README pair (/root/reference/README.md:97-109)
+    I = np.array([[1, 4, 4, 1, 1], [1, 4, 6, 1, 1], [4, 1, 6, 4, 1], [4, 4, 6, 4, 1]])
+    S = np.array([[1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 1, 1, 1, 1], [1, 1, 1, 1, 1]])
+    cases["readme_mean_median"] = run(["MEAN", "MEDIAN"], {}, I, S)
+    cases["readme_all_intensity"] = run(["*ALL_INTENSITY*"], {}, I, S)
+    cases["readme_all_glcm_gd8"] = run(["*ALL_GLCM*"], {"coarse_gray_depth": 8}, I, S)
+    # (2) seeded 48x48 multi-ROI tile, 3 images, every hot-path family; holes, a constant ROI, a zero-valued pixel
+    rng = np.random.default_rng(7)
+    inten = rng.integers(1, 4096, (3, 48, 48)).astype(np.uint32)
+    seg = np.zeros((3, 48, 48), np.uint32)
+    yy, xx = np.mgrid[0:48, 0:48]
+    k = 0
+    for (cy, cx, r) in [(10, 10, 8), (12, 34, 9), (35, 12, 10), (34, 35, 7), (24, 24, 3)]:
+        k += 1
+        seg[:, ((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r] = k
+    seg[1][(yy + xx) % 7 == 0] = 0          # holes
+    inten[2][seg[2] == 5] = 77              # constant ROI
+    inten[0, 10, 10] = 0                    # zero-valued pixel inside ROI 1
+    fam = ["*ALL_INTENSITY*", "*ALL_GLCM*", "*ALL_GLRLM*", "*ALL_GLSZM*", "*ALL_NGTDM*", "GABOR", "ZERNIKE2D"]
+    cases["tile48_all_gd8"] = run(fam, {"coarse_gray_depth": 8}, inten, seg, names=(["i0.tif", "i1.tif", "i2.tif"], ["s0.tif", "s1.tif", "s2.tif"]))
+    cases["tile48_all_gd64"] = run(fam, {}, inten[:1], seg[:1])
+    cases["tile48_ibsi"] = run(["*ALL_GLCM*", "*ALL_GLRLM*", "*ALL_NGTDM*"], {"ibsi": True}, (inten[:1] % 9 + 1).astype(np.uint32), seg[:1])
+    cases["tile48_gabor8"] = run(["GABOR"], {"gabor_freqs": [4, 16, 32, 64, 4, 16, 32, 64], "gabor_thetas": [0, 22.5, 45, 67.5, 90, 112.5, 135, 157.5]}, inten[:1], seg[:1])
+    # (3) negative / float-valued input: shift-and-cast of nyxus.py:480-489
+    ct = (rng.normal(0, 300, (1, 32, 32))).astype(np.float32)
+    sg = np.zeros((1, 32, 32), np.uint32)
+    sg[0, 4:20, 5:25] = 3
+    sg[0, 22:30, 2:12] = 9
+    cases["hounsfield_float"] = run(["*ALL_INTENSITY*"], {}, ct, sg)
+    with open(OUT, "w") as fh:
+        json.dump(cases, fh, separators=(",", ":"))
+    print("wrote", OUT, os.path.getsize(OUT), "bytes;", {k: (len(v["numeric"]), len(v["columns"])) for k, v in cases.items()})
+
+
+if __name__ == "__main__":
+    main()

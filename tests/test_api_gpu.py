@@ -1,0 +1,50 @@
+"""GPU tests of the Python face: `nyxus_amd.Nyxus.featurize` against input/output pairs captured from the
+reference's own `Nyxus.featurize()` (tests/golden/api_featurize.json, made by tests/golden/make_api_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import nyxus_amd
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_featurize.json")))
+
+
+@pytest.mark.parametrize("case", sorted(GOLD))
+def test_featurize_matches_reference_dataframe(case):
+    g = GOLD[case]
+    inten = np.array(g["inten"], dtype=np.dtype(g["inten_dtype"]))
+    seg = np.array(g["seg"])
+    nyx = nyxus_amd.Nyxus(g["features"], **g["kwargs"])
+    if g["names"]:
+        df = nyx.featurize(inten, seg, intensity_names=g["names"][0], label_names=g["names"][1])
+    else:
+        df = nyx.featurize(inten, seg)
+    assert list(df.columns) == g["columns"]                      # header: names, order, angle expansion
+    str_cols = [c for c in g["columns"] if c not in g["numeric_columns"]]
+    assert df[str_cols].values.tolist() == g["strings"]          # image / mask names, row order
+    assert df["ROI_label"].dtype == np.uint32
+    got = df[g["numeric_columns"]].values.astype(float)
+    want = np.array(g["numeric"], dtype=float)
+    exact = parity.EXACT_COLUMNS | {"ROI_label", "t_index"} | {c for c in g["numeric_columns"] if c.startswith("GABOR_")}
+    bad = parity.compare_tables(got, want, g["numeric_columns"], exact=exact)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_featurize_validation_messages():
+    nyx = nyxus_amd.Nyxus(["MEAN"])
+    with pytest.raises(ValueError, match="must be numpy.ndarray"):
+        nyx.featurize([[1]], np.zeros((1, 1)))
+    with pytest.raises(ValueError, match="same dimension"):
+        nyx.featurize(np.zeros((2, 2)), np.zeros((1, 2, 2)))
+    with pytest.raises(ValueError, match="matching dimensions"):
+        nyx.featurize(np.zeros((2, 2)), np.zeros((2, 3)))
+    with pytest.raises(ValueError, match="Invalid output type"):
+        nyx.featurize(np.zeros((2, 2)), np.zeros((2, 2)), output_type="csv")
+    with pytest.raises(ValueError, match="not served by the MI355X path"):
+        nyxus_amd.Nyxus(["PERIMETER"])
+    with pytest.raises(ValueError, match="non-negative"):
+        nyxus_amd.Nyxus(["MEAN"], coarse_gray_depth=0)
