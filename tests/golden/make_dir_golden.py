@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/api_directory.json: output of the reference's `Nyxus.featurize_directory()` on the
+reference's own TIFF test data (/root/reference/tests/python/data/{int,seg}; the four data files are
+copied verbatim to tests/golden/tiff/ as input fixtures).  Run like make_api_golden.py."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("NYXUS_REF_PKG", "/tmp/nyx_oracle_pkg"))
+import nyxus  # noqa: E402  (the REFERENCE package)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+cases = {}
+for name, feats, kw in [("intensity_glcm_gd8", ["*ALL_INTENSITY*", "*ALL_GLCM*"], {"coarse_gray_depth": 8}),
+                        ("texture_default", ["*ALL_GLRLM*", "*ALL_GLSZM*", "*ALL_NGTDM*", "ZERNIKE2D"], {})]:
+    df = nyxus.Nyxus(feats, **kw).featurize_directory(os.path.join(HERE, "tiff", "int"), os.path.join(HERE, "tiff", "seg"))
+    num = df.select_dtypes(include=[np.number])
+    cases[name] = {"features": feats, "kwargs": kw, "columns": list(df.columns),
+                   "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
+                   "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
+    print(name, df.shape)
+json.dump(cases, open(os.path.join(HERE, "api_directory.json"), "w"), separators=(",", ":"))
