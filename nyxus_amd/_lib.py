@@ -141,6 +141,27 @@ class Context:
         """Device pointers in ``cb``; enqueues the kernel on the context's stream."""
         self._check(self._lib.nyxhip_featurize_batch_async(self._h, C.byref(cb), mask, C.byref(s), C.c_void_p(out_ptr), ld))
 
+    def featurize_tile_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, max_label: Optional[int] = None):
+        """One intensity / label tile pair (host uint32 arrays) through the fused device path:
+        label scan + ROI assembly + reduce.  Returns (labels ascending, table)."""
+        inten = np.ascontiguousarray(inten, np.uint32)
+        label = np.ascontiguousarray(label, np.uint32)
+        if inten.shape != label.shape or inten.ndim != 2:
+            raise ValueError("tiles must be 2-D arrays of the same shape")
+        if max_label is None:
+            max_label = int(label.max())
+        ncol = self.n_columns(mask, s)
+        cap = max(1, min(max_label, inten.size))
+        labels = np.zeros(cap, np.uint32)
+        table = np.empty((cap, ncol), np.float64)
+        n = C.c_uint64(0)
+        if max_label == 0:
+            return labels[:0], table[:0]
+        self._check(self._lib.nyxhip_featurize_tile(self._h, inten.ctypes.data, label.ctypes.data, inten.shape[1], inten.shape[0],
+                                                    _abi.MEM_HOST, max_label, mask, C.byref(s), labels.ctypes.data, cap,
+                                                    table.ctypes.data, ncol, C.byref(n)))
+        return labels[: n.value], table[: n.value]
+
     def sync(self):
         self._check(self._lib.nyxhip_sync(self._h))
 

@@ -33,6 +33,9 @@ struct nyxhip_ctx {
     // grow-only device staging for host-memory batches
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // grow-only workspace of the fused tile path (tables, rows, clouds, table)
+    void* d_tile = nullptr;
+    size_t tile_bytes = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -575,6 +578,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_tile) (void)hipFree(ctx->d_tile);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);
@@ -736,10 +740,105 @@ void nyxhip_finalize_table(double* table, size_t n_rows, size_t n_cols, size_t l
         }
 }
 
-int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t*, const uint32_t*, uint32_t, uint32_t, int32_t, uint32_t, uint32_t,
-                          const nyxhip_settings*, uint32_t*, uint64_t, double*, size_t, uint64_t*)
+int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label, uint32_t width, uint32_t height,
+                          int32_t memory, uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,
+                          uint32_t* out_labels, uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out)
 {
-    return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "nyxhip_featurize_tile: the fused tile path is not built yet");
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    if (!inten || !label || !s || !out_labels || !out_table || !n_roi_out || width == 0 || height == 0)
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null pointer or empty tile");
+    if (family_mask == 0 || (family_mask & ~kImplemented)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
+    if (memory != NYXHIP_MEM_HOST && memory != NYXHIP_MEM_DEVICE) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
+    if (max_label == 0 || max_label > (1u << 26)) return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "max_label must be in [1, 2^26]: relabel the mask densely");
+    std::string why;
+    if (!settings_ok(s, family_mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
+    const int n_cols = nyxhip_n_columns(family_mask, s);
+    if ((int)out_ld < n_cols) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "out_ld smaller than the column count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *n_roi_out = 0;
+    hipStream_t st = ctx->stream();
+    const uint64_t npx = (uint64_t)width * height;
+    const uint32_t nlab = max_label + 1;
+    const uint64_t rows_cap = std::min<uint64_t>(max_rows, max_label);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+
+    // workspace carve-out: [tile copy (host input only)] tables, rows, meta, slide, clouds, table
+    size_t o = 0;
+    const size_t o_ti = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 4 * npx);
+    const size_t o_tl = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 4 * npx);
+    size_t o_tab[7]; for (int i = 0; i < 7; i++) { o_tab[i] = o; o = al(o + 4ull * nlab); }
+    const size_t o_rl = o; o = al(o + 4 * (rows_cap + 1));
+    const size_t o_ro = o; o = al(o + 8 * (rows_cap + 2));
+    size_t o_r6[6]; for (int i = 0; i < 6; i++) { o_r6[i] = o; o = al(o + 4 * (rows_cap + 1)); }
+    const size_t o_meta = o; o = al(o + 64);
+    const size_t o_smin = o; o = al(o + 8 * (rows_cap + 1));
+    const size_t o_smax = o; o = al(o + 8 * (rows_cap + 1));
+    const size_t o_cx = o; o = al(o + 2 * npx);          // an ROI pixel count never exceeds the tile
+    const size_t o_cy = o; o = al(o + 2 * npx);
+    const size_t o_cv = o; o = al(o + 4 * npx);
+    const size_t o_out = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 8ull * rows_cap * n_cols);
+    if (o > ctx->tile_bytes) {
+        if (ctx->d_tile) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_tile)); ctx->d_tile = nullptr; ctx->tile_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tile, o + o / 8));
+        ctx->tile_bytes = o + o / 8;
+    }
+    char* base = (char*)ctx->d_tile;
+    const uint32_t* d_inten = inten;
+    const uint32_t* d_label = label;
+    if (memory == NYXHIP_MEM_HOST) {
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_ti, inten, 4 * npx, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_tl, label, 4 * npx, hipMemcpyHostToDevice, st));
+        d_inten = (const uint32_t*)(base + o_ti);
+        d_label = (const uint32_t*)(base + o_tl);
+    }
+    TileTables T{(uint32_t*)(base + o_tab[0]), (uint32_t*)(base + o_tab[1]), (uint32_t*)(base + o_tab[2]), (uint32_t*)(base + o_tab[3]),
+                 (uint32_t*)(base + o_tab[4]), (uint32_t*)(base + o_tab[5]), (uint32_t*)(base + o_tab[6])};
+    TileRows R{(uint32_t*)(base + o_rl), (uint64_t*)(base + o_ro), (uint32_t*)(base + o_r6[0]), (uint32_t*)(base + o_r6[1]),
+               (uint32_t*)(base + o_r6[2]), (uint32_t*)(base + o_r6[3]), (uint32_t*)(base + o_r6[4]), (uint32_t*)(base + o_r6[5])};
+    uint32_t* d_meta = (uint32_t*)(base + o_meta);
+    HIP_TRY(ctx, hipMemsetAsync(d_meta, 0, 64, st));
+    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, max_label, T, R, (uint32_t)rows_cap, d_meta, ctx->d_status, st);
+    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("tile scan launch failed: ") + hipGetErrorString((hipError_t)rc));
+    uint32_t meta[8];
+    HIP_TRY(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    {
+        int stt = 0;
+        HIP_TRY(ctx, hipMemcpy(&stt, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+        if (stt) { int z = 0; HIP_TRY(ctx, hipMemcpy(ctx->d_status, &z, sizeof(int), hipMemcpyHostToDevice));
+                   return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the label tile holds a value above max_label"); }
+    }
+    const uint64_t n_roi = meta[0];
+    *n_roi_out = n_roi;
+    if (n_roi == 0) return NYXHIP_OK;
+    if (n_roi > rows_cap) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the tile (see *n_roi_out)");
+    rc = launch_tile_clouds(d_inten, d_label, width, R, (uint32_t)n_roi, (uint16_t*)(base + o_cx), (uint16_t*)(base + o_cy), (uint32_t*)(base + o_cv), st);
+    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    // in-memory (montage) semantics: the prescan leaves slide min / max at +DBL_MAX / -DBL_MAX
+    // (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
+    std::vector<double> smin(n_roi, 1.7976931348623157e308), smax(n_roi, -1.7976931348623157e308);
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_smin, smin.data(), 8 * n_roi, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_smax, smax.data(), 8 * n_roi, hipMemcpyHostToDevice, st));
+    nyxhip_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
+    b.x = (const uint16_t*)(base + o_cx); b.y = (const uint16_t*)(base + o_cy); b.inten = (const uint32_t*)(base + o_cv);
+    b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
+    b.slide_min = (const double*)(base + o_smin); b.slide_max = (const double*)(base + o_smax);
+    b.memory = NYXHIP_MEM_DEVICE;
+    double* d_out = memory == NYXHIP_MEM_HOST ? (double*)(base + o_out) : out_table;
+    const size_t d_ld = memory == NYXHIP_MEM_HOST ? (size_t)n_cols : out_ld;
+    rc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+    if (rc) return rc;
+    if (memory == NYXHIP_MEM_HOST) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(out_table, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
+                                      (size_t)n_cols * sizeof(double), n_roi, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_labels, R.label, 4 * n_roi, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(out_labels, R.label, 4 * n_roi, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return check_status(ctx);
 }
 
 int nyxhip_timing_enable(nyxhip_ctx* ctx, int on)

@@ -1,0 +1,57 @@
+"""GPU tests of the fused tile path (nyxhip_featurize_tile): device label scan + ROI assembly + reduce,
+against host assembly (nyxus_amd.roi_assembly, the restated phases 1-2) + the CPU oracle."""
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi, _lib, roi_assembly
+from oracle import pyoracle as po
+from tests import parity, synth
+
+pytestmark = pytest.mark.gpu
+DBL_MAX = 1.7976931348623157e308
+
+
+def _oracle_tile(inten, lab, mask, s):
+    b = roi_assembly.assemble(inten, lab, DBL_MAX, -DBL_MAX)   # montage semantics of the in-memory path
+    return b.roi_label, po.oracle_featurize(b, mask, s)
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+def test_benchmark_tile_end_to_end(hip_ctx, irregular):
+    lab = synth.disk_label_tile(irregular=irregular, seed=5)
+    it = synth.intensity_tile(5)
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    labels, T = hip_ctx.featurize_tile_host(it, lab, mask, s)
+    wl, wt = _oracle_tile(it, lab, mask, s)
+    assert np.array_equal(labels, wl) and len(labels) == 196          # ascending labels, one row each
+    assert not parity.compare_tables(T, wt, _lib.column_names(mask, s))
+
+
+def test_small_tile_all_families_and_sparse_labels(hip_ctx):
+    rng = np.random.default_rng(3)
+    it = rng.integers(0, 300, (96, 130)).astype(np.uint32)
+    lab = np.zeros((96, 130), np.uint32)
+    lab[5:30, 7:40] = 3
+    lab[10:20, 15:25] = 17          # nested hole -> concave ROI 3
+    lab[50:90, 60:128] = 40
+    lab[0, 129] = 41                # single pixel on the border
+    lab[60:70, 0:5] = 1000          # sparse label values
+    s = _abi.default_settings(16)
+    mask = _abi.FAM_ALL
+    labels, T = hip_ctx.featurize_tile_host(it, lab, mask, s)
+    wl, wt = _oracle_tile(it, lab, mask, s)
+    assert labels.tolist() == wl.tolist() == [3, 17, 40, 41, 1000]
+    assert not parity.compare_tables(T, wt, _lib.column_names(mask, s))
+
+
+def test_empty_and_bad_max_label(hip_ctx):
+    s = _abi.default_settings(8)
+    z = np.zeros((16, 16), np.uint32)
+    labels, T = hip_ctx.featurize_tile_host(z + 5, z, _abi.FAM_INTENSITY, s, max_label=10)
+    assert len(labels) == 0
+    lab = z.copy()
+    lab[2, 2] = 99
+    with pytest.raises(_lib.NyxHipError) as ei:
+        hip_ctx.featurize_tile_host(z + 5, lab, _abi.FAM_INTENSITY, s, max_label=10)
+    assert ei.value.code == 1
