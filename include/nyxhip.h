@@ -207,6 +207,16 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
                           uint32_t* out_labels, uint64_t max_rows,
                           double* out_table, size_t out_ld, uint64_t* n_roi_out);
 
+/* Same for a stack of n_tiles equally sized tiles stored back to back (tile t occupies rows
+ * [t*height, (t+1)*height) of one tall image).  Labels are per tile; rows come back ordered by
+ * (tile, label) -- images in input order, labels ascending, the row order of the reference's table
+ * (workflow_pythonapi.cpp:140-182 + output_2_buffer.cpp:305-306).  out_tile_index may be NULL. */
+int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label,
+                           uint32_t width, uint32_t height, uint32_t n_tiles, int32_t memory,
+                           uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,
+                           uint32_t* out_labels, uint32_t* out_tile_index, uint64_t max_rows,
+                           double* out_table, size_t out_ld, uint64_t* n_roi_out);
+
 /* ---- measurement hooks -------------------------------------------------------
  * Average device time (ms) of the dominant kernel over the launches issued since
  * the last nyxhip_timing_reset(), measured with hipEvents recorded on the launch

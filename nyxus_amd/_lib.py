@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("NYXHIP_LIB") or os.path.join(_HERE, "libnyxhip.so")
 ABI_SYMBOLS = [
     "nyxhip_abi_version", "nyxhip_default_settings", "nyxhip_init", "nyxhip_destroy", "nyxhip_last_error",
     "nyxhip_set_stream", "nyxhip_n_columns", "nyxhip_column_name", "nyxhip_featurize_batch",
-    "nyxhip_featurize_batch_async", "nyxhip_sync", "nyxhip_finalize_table", "nyxhip_featurize_tile",
+    "nyxhip_featurize_batch_async", "nyxhip_sync", "nyxhip_finalize_table", "nyxhip_featurize_tile", "nyxhip_featurize_tiles",
     "nyxhip_timing_enable", "nyxhip_timing_reset", "nyxhip_timing_get",
 ]
 
@@ -73,6 +73,10 @@ def load() -> C.CDLL:
                                           C.c_uint32, C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_uint64,
                                           C.c_void_p, C.c_size_t, P(C.c_uint64)]
     lib.nyxhip_featurize_tile.restype = C.c_int
+    lib.nyxhip_featurize_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
+                                           C.c_uint32, C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_size_t, P(C.c_uint64)]
+    lib.nyxhip_featurize_tiles.restype = C.c_int
     lib.nyxhip_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.nyxhip_timing_enable.restype = C.c_int
     lib.nyxhip_timing_reset.argtypes = [C.c_void_p]
@@ -161,6 +165,29 @@ class Context:
                                                     _abi.MEM_HOST, max_label, mask, C.byref(s), labels.ctypes.data, cap,
                                                     table.ctypes.data, ncol, C.byref(n)))
         return labels[: n.value], table[: n.value]
+
+    def featurize_tiles_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, max_label: Optional[int] = None):
+        """A stack [n_tiles, H, W] of host uint32 tiles through the fused device path.
+        Returns (tile_index, labels, table) with rows ordered by (tile, label)."""
+        inten = np.ascontiguousarray(inten, np.uint32)
+        label = np.ascontiguousarray(label, np.uint32)
+        if inten.shape != label.shape or inten.ndim != 3:
+            raise ValueError("stacks must be 3-D arrays [n_tiles, H, W] of the same shape")
+        if max_label is None:
+            max_label = int(label.max())
+        ncol = self.n_columns(mask, s)
+        nt, h, w = inten.shape
+        cap = max(1, min(max_label * nt, inten.size))
+        labels = np.zeros(cap, np.uint32)
+        tiles = np.zeros(cap, np.uint32)
+        table = np.empty((cap, ncol), np.float64)
+        n = C.c_uint64(0)
+        if max_label == 0:
+            return tiles[:0], labels[:0], table[:0]
+        self._check(self._lib.nyxhip_featurize_tiles(self._h, inten.ctypes.data, label.ctypes.data, w, h, nt, _abi.MEM_HOST, max_label,
+                                                     mask, C.byref(s), labels.ctypes.data, tiles.ctypes.data, cap, table.ctypes.data,
+                                                     ncol, C.byref(n)))
+        return tiles[: n.value], labels[: n.value], table[: n.value]
 
     def sync(self):
         self._check(self._lib.nyxhip_sync(self._h))

@@ -744,12 +744,23 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
                           int32_t memory, uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,
                           uint32_t* out_labels, uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out)
 {
+    return nyxhip_featurize_tiles(ctx, inten, label, width, height, 1, memory, max_label, family_mask, s, out_labels, nullptr,
+                                  max_rows, out_table, out_ld, n_roi_out);
+}
+
+int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label, uint32_t width, uint32_t height,
+                           uint32_t n_tiles, int32_t memory, uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,
+                           uint32_t* out_labels, uint32_t* out_tile_index, uint64_t max_rows, double* out_table, size_t out_ld,
+                           uint64_t* n_roi_out)
+{
     if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    if (n_tiles == 0) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "n_tiles must be >= 1");
     if (!inten || !label || !s || !out_labels || !out_table || !n_roi_out || width == 0 || height == 0)
         return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null pointer or empty tile");
     if (family_mask == 0 || (family_mask & ~kImplemented)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
     if (memory != NYXHIP_MEM_HOST && memory != NYXHIP_MEM_DEVICE) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
-    if (max_label == 0 || max_label > (1u << 26)) return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "max_label must be in [1, 2^26]: relabel the mask densely");
+    if (max_label == 0 || (uint64_t)(max_label + 1ull) * n_tiles > (1ull << 27))
+        return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "(max_label + 1) * n_tiles must be in [2, 2^27]: relabel the masks densely or pass fewer tiles per call");
     std::string why;
     if (!settings_ok(s, family_mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
     const int n_cols = nyxhip_n_columns(family_mask, s);
@@ -757,9 +768,10 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *n_roi_out = 0;
     hipStream_t st = ctx->stream();
-    const uint64_t npx = (uint64_t)width * height;
-    const uint32_t nlab = max_label + 1;
-    const uint64_t rows_cap = std::min<uint64_t>(max_rows, max_label);
+    const uint64_t npx = (uint64_t)width * height * n_tiles;
+    const uint32_t stride = max_label + 1;
+    const uint32_t nlab = stride * n_tiles;
+    const uint64_t rows_cap = std::min<uint64_t>(max_rows, (uint64_t)max_label * n_tiles);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 
     // workspace carve-out: [tile copy (host input only)] tables, rows, meta, slide, clouds, table
@@ -773,6 +785,8 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
     const size_t o_meta = o; o = al(o + 64);
     const size_t o_smin = o; o = al(o + 8 * (rows_cap + 1));
     const size_t o_smax = o; o = al(o + 8 * (rows_cap + 1));
+    const size_t o_lab = o; o = al(o + 4 * (rows_cap + 1));
+    const size_t o_til = o; o = al(o + 4 * (rows_cap + 1));
     const size_t o_cx = o; o = al(o + 2 * npx);          // an ROI pixel count never exceeds the tile
     const size_t o_cy = o; o = al(o + 2 * npx);
     const size_t o_cv = o; o = al(o + 4 * npx);
@@ -797,7 +811,7 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
                (uint32_t*)(base + o_r6[2]), (uint32_t*)(base + o_r6[3]), (uint32_t*)(base + o_r6[4]), (uint32_t*)(base + o_r6[5])};
     uint32_t* d_meta = (uint32_t*)(base + o_meta);
     HIP_TRY(ctx, hipMemsetAsync(d_meta, 0, 64, st));
-    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, max_label, T, R, (uint32_t)rows_cap, d_meta, ctx->d_status, st);
+    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, n_tiles, max_label, T, R, (uint32_t)rows_cap, d_meta, ctx->d_status, st);
     if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("tile scan launch failed: ") + hipGetErrorString((hipError_t)rc));
     uint32_t meta[8];
     HIP_TRY(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, st));
@@ -812,7 +826,7 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
     *n_roi_out = n_roi;
     if (n_roi == 0) return NYXHIP_OK;
     if (n_roi > rows_cap) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the tile (see *n_roi_out)");
-    rc = launch_tile_clouds(d_inten, d_label, width, R, (uint32_t)n_roi, (uint16_t*)(base + o_cx), (uint16_t*)(base + o_cy), (uint32_t*)(base + o_cv), st);
+    rc = launch_tile_clouds(d_inten, d_label, width, height, stride, R, (uint32_t)n_roi, (uint16_t*)(base + o_cx), (uint16_t*)(base + o_cy), (uint32_t*)(base + o_cv), st);
     if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     // in-memory (montage) semantics: the prescan leaves slide min / max at +DBL_MAX / -DBL_MAX
     // (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
@@ -830,12 +844,16 @@ int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t
     const size_t d_ld = memory == NYXHIP_MEM_HOST ? (size_t)n_cols : out_ld;
     rc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
     if (rc) return rc;
+    uint32_t* d_lab = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_lab) : out_labels;
+    uint32_t* d_til = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_til) : out_tile_index;
+    hipLaunchKernelGGL(tile_split_keys_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.label, stride, (uint32_t)n_roi,
+                       d_lab, (memory == NYXHIP_MEM_HOST || out_tile_index) ? d_til : nullptr);
     if (memory == NYXHIP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpy2DAsync(out_table, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
                                       (size_t)n_cols * sizeof(double), n_roi, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(out_labels, R.label, 4 * n_roi, hipMemcpyDeviceToHost, st));
-    } else {
-        HIP_TRY(ctx, hipMemcpyAsync(out_labels, R.label, 4 * n_roi, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_labels, d_lab, 4 * n_roi, hipMemcpyDeviceToHost, st));
+        if (out_tile_index)
+            HIP_TRY(ctx, hipMemcpyAsync(out_tile_index, d_til, 4 * n_roi, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return check_status(ctx);

@@ -43,10 +43,12 @@ __device__ __forceinline__ uint32_t wave_max_u32_x(uint32_t v)
     return v;
 }
 
+// The input may be a stack of n_tiles tiles of H rows each (one tall image); labels are per tile, so the
+// table index is tile * (max_label + 1) + label and coordinates are tile-relative.
 __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* __restrict__ inten, const uint32_t* __restrict__ label,
-                                                        uint32_t W, uint32_t H, uint32_t max_label, TileTables T, int* status)
+                                                        uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label, TileTables T, int* status)
 {
-    const uint64_t npx = (uint64_t)W * H;
+    const uint64_t npx = (uint64_t)W * H * n_tiles;
     const int lane = threadIdx.x & 63;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < npx; base += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t p = base + threadIdx.x;
@@ -55,9 +57,12 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* __restri
             l = label[p];
             if (l != 0) {
                 v = inten[p];
-                y = (uint32_t)(p / W);
-                x = (uint32_t)(p - (uint64_t)y * W);
+                const uint64_t yy = p / W;
+                x = (uint32_t)(p - yy * W);
+                const uint32_t t = (uint32_t)(yy / H);
+                y = (uint32_t)(yy - (uint64_t)t * H);
                 if (l > max_label) { atomicCAS(status, 0, 1 /* NYXHIP_ERR_INVALID_ARG */); l = 0; }
+                else l += t * (max_label + 1);
             }
         }
         unsigned long long todo = __ballot(l != 0);
@@ -83,8 +88,9 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* __restri
 
 // One workgroup: ascending labels -> rows; rows' CSR offsets.  meta[0] = n_roi, meta[1..2] = total pixels
 // (lo, hi), meta[3] = max area, meta[4] = max bbox area, meta[5] = max range, meta[6] = max side.
-__global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32_t max_label, TileRows R, uint32_t max_rows, uint32_t* meta)
+__global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32_t n_entries, TileRows R, uint32_t max_rows, uint32_t* meta)
 {
+    const uint32_t max_label = n_entries - 1;   // entry 0 (label 0 of tile 0) is never populated; other tiles' label 0 neither
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
     __shared__ uint32_t s_base;
@@ -137,12 +143,14 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32
 
 // One workgroup per ROI: bbox window of the tile -> SoA cloud in row-major order (deterministic).
 __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restrict__ inten, const uint32_t* __restrict__ label, uint32_t W,
-                                                        TileRows R, uint16_t* cx, uint16_t* cy, uint32_t* cv)
+                                                        uint32_t H, uint32_t stride, TileRows R, uint16_t* cx, uint16_t* cy, uint32_t* cv)
 {
     __shared__ uint32_t s_cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t row = blockIdx.x;
-    const uint32_t L = R.label[row], x0 = R.bbox_x0[row], y0 = R.bbox_y0[row], w = R.bbox_w[row], h = R.bbox_h[row];
+    // R.label holds the table index tile * stride + label; y0 is tile-relative
+    const uint32_t key = R.label[row], tile = key / stride, L = key - tile * stride;
+    const uint32_t x0 = R.bbox_x0[row], y0 = R.bbox_y0[row] + tile * H, w = R.bbox_w[row], h = R.bbox_h[row];
     const uint32_t area = w * h;
     unsigned long long out = R.px_offset[row];
     for (uint32_t p0 = 0; p0 < area; p0 += 256) {
@@ -169,25 +177,36 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
     }
 }
 
-int launch_tile_assembly_scan(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t max_label,
+// table key -> (label, tile index) for the caller
+__global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint32_t k = key[i], t = k / stride;
+        out_label[i] = k - t * stride;
+        if (out_tile) out_tile[i] = t;
+    }
+}
+
+int launch_tile_assembly_scan(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label,
                               TileTables T, TileRows R, uint32_t max_rows, uint32_t* meta, int* status, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t n = max_label + 1;
+    const uint32_t n = (max_label + 1) * n_tiles;
     hipLaunchKernelGGL(tile_init_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T, n);
-    const uint64_t npx = (uint64_t)W * H;
+    const uint64_t npx = (uint64_t)W * H * n_tiles;
     unsigned blocks = (unsigned)((npx + 255) / 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;           // grid-stride: ~16 workgroups per CU
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(blocks), dim3(256), 0, st, inten, label, W, H, max_label, T, status);
-    hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, st, T, max_label, R, max_rows, meta);
+    if (blocks > 256 * 32) blocks = 256 * 32;           // grid-stride: ~16 workgroups per CU
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(blocks), dim3(256), 0, st, inten, label, W, H, n_tiles, max_label, T, status);
+    hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, st, T, n, R, max_rows, meta);
     return (int)hipGetLastError();
 }
 
-int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W, TileRows R, uint32_t n_roi,
+int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t stride, TileRows R, uint32_t n_roi,
                        uint16_t* cx, uint16_t* cy, uint32_t* cv, void* stream)
 {
     if (n_roi == 0) return 0;
-    hipLaunchKernelGGL(roi_cloud_kernel, dim3(n_roi), dim3(256), 0, (hipStream_t)stream, inten, label, W, R, cx, cy, cv);
+    hipLaunchKernelGGL(roi_cloud_kernel, dim3(n_roi), dim3(256), 0, (hipStream_t)stream, inten, label, W, H, stride, R, cx, cy, cv);
     return (int)hipGetLastError();
 }
 

@@ -167,17 +167,16 @@ class Nyxus:
         M = label_images.astype(np.uint32)
 
         cols, sel = self._columns()
-        str_rows, num_rows = [], []
-        for k in range(I.shape[0]):
-            # the montage prescan leaves slide min/max at +/-DBL_MAX (slideprops.cpp:27-28,74-75), so
-            # COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0 in this entry point
-            labels, table = self._featurize_pair(I[k], M[k], _DBL_MAX, -_DBL_MAX)
-            for r in range(len(labels)):
-                str_rows.append([intensity_names[k], label_names[k]])
-                num_rows.append(np.concatenate(([float(labels[r]), 0.0], table[r, sel])))
+        # All images of the stack go through the fused device path in one call: label scan, ROI assembly and the
+        # reduce run on the GPU (nyxhip_featurize_tiles).  The montage prescan of the reference leaves slide
+        # min/max at +/-DBL_MAX (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
+        # in this entry point; the tile ABI implements exactly that.
+        tiles, labels, table = self._context().featurize_tiles_host(I, M, self._mask, self._settings)
+        _lib.load().nyxhip_finalize_table(table.ctypes.data, table.shape[0], table.shape[1], table.shape[1],
+                                          C.c_double(self._settings.soft_nan))
         header = ["intensity_image", "mask_image", "ROI_label", "t_index"] + cols
-        string_data = np.array(str_rows, dtype=object).reshape(-1, 2)
-        numeric_data = np.array(num_rows, dtype=np.float64).reshape(-1, 2 + len(cols))
+        string_data = np.array([[intensity_names[t], label_names[t]] for t in tiles], dtype=object).reshape(-1, 2)
+        numeric_data = np.concatenate([labels.astype(np.float64)[:, None], np.zeros((len(labels), 1)), table[:, sel]], axis=1)
         df = pd.concat([pd.DataFrame(string_data, columns=header[:2]), pd.DataFrame(numeric_data, columns=header[2:])], axis=1)
         if "ROI_label" in df.columns:
             df.ROI_label = df.ROI_label.astype(np.uint32)

@@ -55,3 +55,21 @@ def test_empty_and_bad_max_label(hip_ctx):
     with pytest.raises(_lib.NyxHipError) as ei:
         hip_ctx.featurize_tile_host(z + 5, lab, _abi.FAM_INTENSITY, s, max_label=10)
     assert ei.value.code == 1
+
+
+def test_stack_of_tiles_rows_ordered_by_tile_then_label(hip_ctx):
+    rng = np.random.default_rng(11)
+    it = rng.integers(1, 5000, (3, 64, 80)).astype(np.uint32)
+    lab = np.zeros((3, 64, 80), np.uint32)
+    lab[0, 2:20, 3:30] = 2
+    lab[0, 30:60, 40:78] = 1
+    lab[1, 10:50, 10:70] = 7          # tile 1 has one ROI
+    lab[2, 0:8, 0:8] = 1
+    lab[2, 20:40, 20:60] = 2
+    lab[2, 50:64, 0:80] = 3
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM | _abi.FAM_NGTDM
+    tiles, labels, T = hip_ctx.featurize_tiles_host(it, lab, mask, s)
+    assert tiles.tolist() == [0, 0, 1, 2, 2, 2] and labels.tolist() == [1, 2, 7, 1, 2, 3]
+    want = np.concatenate([_oracle_tile(it[k], lab[k], mask, s)[1] for k in range(3)])
+    assert not parity.compare_tables(T, want, _lib.column_names(mask, s))
