@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--tile-path-tiles", type=int, default=128, help="tiles for the informational fused tile-path measurement (0 = skip)")
     return ap.parse_args()
 
 
@@ -227,6 +228,39 @@ def main():
                              f"with {thr} threads, reduce stage only ({sec:.2f} s)" if kind == "reference"
                              else f"single-threaded C restatement ({sec:.2f} s)"),
                 "host_cpus": cores}
+        # ---- informational: the fused tile path (label scan + ROI assembly + reduce from tiles in HBM) -------
+        if world == 1 and a.tile_path_tiles > 0:
+            from tests import synth
+            nt = a.tile_path_tiles
+            lab1 = torch.from_numpy(synth.disk_label_tile().astype(np.int32)).to(dev)
+            labs = lab1.unsqueeze(0).repeat(nt, 1, 1).contiguous()
+            tin = torch.randint(1, 4096, (nt, 1024, 1024), generator=g, device=dev, dtype=torch.int32)
+            cap = nt * 196
+            t_lab = torch.empty(cap, dtype=torch.int32, device=dev)
+            t_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+            t_out = torch.empty((cap, ncol), dtype=torch.float64, device=dev)
+            nroi = C.c_uint64(0)
+            lib = _lib.load()
+
+            def tile_step():
+                rc = lib.nyxhip_featurize_tiles(ctx._h, tin.data_ptr(), labs.data_ptr(), 1024, 1024, nt, _abi.MEM_DEVICE, 196, mask,
+                                                C.byref(s), t_lab.data_ptr(), t_idx.data_ptr(), cap, t_out.data_ptr(), ncol, C.byref(nroi))
+                if rc != 0:
+                    raise RuntimeError(lib.nyxhip_last_error(ctx._h).decode())
+            tile_step()
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                tile_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - c0) / reps
+            tile_bytes = nt * (8 * 1024 * 1024 + 196 * ncol * 8)     # 8.68 MB per tile
+            rec["tile_path"] = {"value": nroi.value / dt, "unit": "ROIs/s", "tiles_per_s": nt / dt, "tiles": nt,
+                                "rois": int(nroi.value), "ms_per_call": 1e3 * dt,
+                                "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                                "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
+                                        "compaction, cloud assembly, then the same reduce kernels (one host sync inside for the ROI count)"}
         print(json.dumps(rec))
     if world > 1:
         dist.barrier()
