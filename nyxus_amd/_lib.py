@@ -44,6 +44,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C nyxus_amd/csrc).  The MI355X path has no CPU fallback.")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  If libnyxhip.so pulled in the system copy first and torch loaded its own later,
+    # the second runtime would see no GPU.  Importing torch first makes the dynamic linker resolve
+    # libnyxhip.so against the already-loaded copy.  (Pure C/C++ users of the ABI are unaffected.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     lib.nyxhip_abi_version.restype = C.c_int

@@ -172,6 +172,48 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     o = dpp_mov0<0x143, 0xC>(v); v = o > v ? o : v;
     return readlane63(v);
 }
+// ---- reductions inside one DPP row (16 lanes): butterfly over quad_perm / half-mirror / mirror -----
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.  After the four
+// steps every lane of the row holds the row total; the four rows of a wave reduce independently, which is
+// how one wave serves four GLCM angles at once (roi_features.hip).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    uint32_t lo = dpp_perm<CTRL>((uint32_t)u), hi = dpp_perm<CTRL>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_perm<0xB1>(v);
+    v += dpp_perm<0x4E>(v);
+    v += dpp_perm<0x141>(v);
+    v += dpp_perm<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
+{
+    v += dpp_perm<0xB1>(v);
+    v += dpp_perm<0x4E>(v);
+    v += dpp_perm<0x141>(v);
+    v += dpp_perm<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row16_max(double v)
+{
+    double o;
+    o = dpp_perm<0xB1>(v); v = o > v ? o : v;
+    o = dpp_perm<0x4E>(v); v = o > v ? o : v;
+    o = dpp_perm<0x141>(v); v = o > v ? o : v;
+    o = dpp_perm<0x140>(v); v = o > v ? o : v;
+    return v;
+}
+
 // neighbour lanes through DPP wave shifts (GFX9: wave_shl:1 = 0x130, wave_shr:1 = 0x138);
 // the lane without a source reads `fill`
 __device__ __forceinline__ uint32_t lane_plus1(uint32_t v, uint32_t fill)   // value of lane+1

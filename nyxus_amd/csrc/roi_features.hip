@@ -112,33 +112,36 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
     }
 }
 
-// ---- GLCM features of one angle, computed by one wave -----------------------------
-// P: Ng*Ng counts, P[center*Ng + neighbour]  (== SimpleMatrix::xy(a,b)++ with a =
-//    neighbour level, b = centre level, glcm.cpp:437-472; xy(x,y) = [y*W+x]).
-// Iv: level values I[] (glcm.cpp:388-420).  scr: 6*Ng doubles.  f: 30 outputs.
+// ---- GLCM features: one wave, one DPP row (16 lanes) per angle ------------------------------
+// The four 16-lane rows of the wave work on four angles at once; every reduction is a 4-step butterfly
+// inside the row (row16_sum), so the instruction stream is issued once for all angles.
+// Pslots: matrices of this pass, Pslots[slot*NN + center*Ng + neighbour]  (== SimpleMatrix::xy(a,b)++ with
+//    a = neighbour level, b = centre level, glcm.cpp:437-472; xy(x,y) = [y*W+x]).
+// Iv: level values I[] (glcm.cpp:388-420).  scr: 5*Ng doubles per slot.  fslots: 32 doubles per slot.
 //
-// Numerics: marginals and the x+y / |x-y| distributions are formed from exact integer
-// count sums and divided by sum_p once (the reference sums the already divided
-// elements, glcm.cpp:503-508, :523-525: same value to ~1e-16 relative); matrix-wide sums
-// are lane-strided partial sums combined by a shuffle tree (deterministic order).
-__device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, double* scr,
-                                   double soft_nan, double* f, int lane)
+// Numerics: marginals and the x+y / |x-y| distributions are formed from exact integer count sums and
+// divided by sum_p once (the reference sums the already divided elements, glcm.cpp:503-508, :523-525: same
+// value to ~1e-16 relative); matrix-wide sums are lane-strided partial sums combined in a fixed order.
+__device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, const double* Iv, double* scr_base, int scr_stride,
+                                   double soft_nan, double* fslots, int lane)
 {
     const int NN = Ng * Ng;
+    const int slot_raw = lane >> 4, l16 = lane & 15;
+    const bool live = slot_raw < n_slots;
+    const int slot = live ? slot_raw : 0;              // idle rows shadow slot 0 and never store
+    const uint32_t* P = Pslots + slot * NN;
+    double* scr = scr_base + slot * scr_stride;
+    double* f = fslots + slot * 32;
+
     // sum_p (glcm.cpp:481-484): integer counts, exact in any order
-    unsigned long long cnt_sum = 0;
-    for (int e = lane; e < NN; e += 64)
-        cnt_sum += P[e];
-    cnt_sum = wave_sum_u64(cnt_sum); // total in every lane
-    if (cnt_sum == 0) { // glcm.cpp:260-295
-        if (lane < kGlcmAngled)
-            f[lane] = soft_nan;
-        wave_sync();
-        return;
-    }
-    const double sum_p = (double)cnt_sum;
-    // per-element probabilities use one reciprocal (<= 1 ulp from cnt / sum_p); marginals and
-    // the exact-numerator features below keep true divisions
+    uint32_t csum = 0;
+    for (int e = l16; e < NN; e += 16)
+        csum += P[e];
+    csum = row16_sum(csum);
+    const bool empty = csum == 0;                      // glcm.cpp:260-295 -> soft NaN for this angle
+    const double sum_p = empty ? 1.0 : (double)csum;
+    // per-element probabilities use one reciprocal (<= 1 ulp from cnt / sum_p); marginals and the
+    // exact-numerator features below keep true divisions
     const double inv_sum_p = 1.0 / sum_p;
 
     double* pcol = scr;           // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
@@ -146,7 +149,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     double* Pxpy = scr + 2 * Ng;  // [2Ng]  glcm.cpp:503-508
     double* Pxmy = scr + 4 * Ng;  // [Ng]
 
-    for (int i = lane; i < Ng; i += 64) {
+    for (int i = l16; i < Ng; i += 16) {
         uint32_t cc = 0, rc = 0, dc = 0;
         for (int j = 0; j < Ng; j++) {
             cc += P[j * Ng + i];
@@ -157,28 +160,31 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
             if (i > 0)
                 dc += P[(x - i) * Ng + x];
         }
-        pcol[i] = (double)cc / sum_p;
-        prow[i] = (double)rc / sum_p;
-        Pxmy[i] = (double)dc / sum_p;
+        if (live) {
+            pcol[i] = (double)cc / sum_p;
+            prow[i] = (double)rc / sum_p;
+            Pxmy[i] = (double)dc / sum_p;
+        }
     }
-    for (int k = lane; k < 2 * Ng; k += 64) {
+    for (int k = l16; k < 2 * Ng; k += 16) {
         uint32_t c = 0;
         int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
         for (int x = x0; x <= x1; x++)
             c += P[x * Ng + (k - x)];
-        Pxpy[k] = (double)c / sum_p;
+        if (live)
+            Pxpy[k] = (double)c / sum_p;
     }
     wave_sync();
 
     // by_row_mean (glcm.cpp:531-536)
     double brm = 0;
-    for (int i = lane; i < Ng; i += 64)
+    for (int i = l16; i < Ng; i += 16)
         brm += pcol[i] * Iv[i];
-    brm = wave_sum(brm);
+    brm = row16_sum(brm);
 
     // ---- pass 1 over matrix elements -------------------------------------------------
     double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis_n = 0, hom2 = 0, jmax = -1;
-    for (int e = lane; e < NN; e += 64) {
+    for (int e = l16; e < NN; e += 16) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
@@ -196,11 +202,11 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         hom2 += p / (1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
         jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
     }
-    asm_ = wave_sum(asm_); contrast_n = wave_sum(contrast_n); S_r = wave_sum(S_r); S_c = wave_sum(S_c);
-    acor_n = wave_sum(acor_n); hom1 = wave_sum(hom1); ent = wave_sum(ent); dis_n = wave_sum(dis_n);
-    hom2 = wave_sum(hom2); jmax = wave_max_nonneg(jmax);
+    asm_ = row16_sum(asm_); contrast_n = row16_sum(contrast_n); S_r = row16_sum(S_r); S_c = row16_sum(S_c);
+    acor_n = row16_sum(acor_n); hom1 = row16_sum(hom1); ent = row16_sum(ent); dis_n = row16_sum(dis_n);
+    hom2 = row16_sum(hom2); jmax = row16_max(jmax);
     const double mr = S_r / sum_p, mc = S_c / sum_p; // mr == f_var's mean == JAVE (exact numerators)
-    if (lane == 0) { // results leave the registers as soon as they exist
+    if (live && l16 == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
         f[G_ENERGY] = asm_;
         f[G_CONTRAST] = contrast_n / sum_p;
@@ -216,7 +222,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
 
     // ---- pass 2: central quantities ---------------------------------------------------
     double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
-    for (int e = lane; e < NN; e += 64) {
+    for (int e = l16; e < NN; e += 16) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
@@ -238,10 +244,10 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         hxy1 += p * lg;
         hxy2 += pp * lg;
     }
-    s2r = wave_sum(s2r); s2c = wave_sum(s2c); tmp1 = wave_sum(tmp1); var_n = wave_sum(var_n);
-    cprom = wave_sum(cprom); cshade = wave_sum(cshade); ctend = wave_sum(ctend); jvar = wave_sum(jvar);
-    hxy1 = wave_sum(hxy1); hxy2 = wave_sum(hxy2);
-    if (lane == 0) {
+    s2r = row16_sum(s2r); s2c = row16_sum(s2c); tmp1 = row16_sum(tmp1); var_n = row16_sum(var_n);
+    cprom = row16_sum(cprom); cshade = row16_sum(cshade); ctend = row16_sum(ctend); jvar = row16_sum(jvar);
+    hxy1 = row16_sum(hxy1); hxy2 = row16_sum(hxy2);
+    if (live && l16 == 0) {
         f[G_VARIANCE] = var_n / sum_p;
         f[G_CLUPROM] = cprom;
         f[G_CLUSHADE] = cshade;
@@ -258,7 +264,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
     // are the last pairs calculatePxpmy writes (glcm.cpp:511-512).
     double idm = 0, dent = 0, idmn = 0, id = 0, idn = 0, iv = 0, hx = 0, davg = 0;
     const double Ng2 = (double)Ng * (double)Ng;
-    for (int k = lane; k < Ng; k += 64) {
+    for (int k = l16; k < Ng; k += 16) {
         double q = Pxmy[k];
         double kval = k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
         idm += q / (double)(1 + (k * k));                        // f_idm :685-687
@@ -272,17 +278,17 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         hx += plogp(pcol[k], pcol[k]);                           // :873-874
         davg += kval * q;                                        // f_difference_avg :791-792
     }
-    idm = wave_sum(idm); dent = wave_sum(dent); idmn = wave_sum(idmn); id = wave_sum(id);
-    idn = wave_sum(idn); iv = wave_sum(iv); hx = wave_sum(hx); davg = wave_sum(davg);
+    idm = row16_sum(idm); dent = row16_sum(dent); idmn = row16_sum(idmn); id = row16_sum(id);
+    idn = row16_sum(idn); iv = row16_sum(iv); hx = row16_sum(hx); davg = row16_sum(davg);
     const double diffAvg = davg;
     double savg = 0, sent = 0, dv = 0;
-    for (int k = lane; k < 2 * Ng - 1; k += 64) {
+    for (int k = l16; k < 2 * Ng - 1; k += 16) {
         double q = Pxpy[k];
         int x = k < Ng - 1 ? k : Ng - 1;
         savg += (Iv[x] + Iv[k - x]) * q;                         // f_savg :700-701
         sent += plogp(q, q);                                     // f_sentropy :712-716
     }
-    for (int k = lane; k < Ng; k += 64) {
+    for (int k = l16; k < Ng; k += 16) {
         // f_dvar (glcm.cpp:742-766): var[k] receives the same term Ng times, total / Ng
         double dk = (double)k - diffAvg;
         double t = dk * dk * Pxmy[k], a = 0;
@@ -290,9 +296,8 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
             a += t;
         dv += a;
     }
-    savg = wave_sum(savg); sent = wave_sum(sent); dv = wave_sum(dv);
-
-    if (lane == 0) {
+    savg = row16_sum(savg); sent = row16_sum(sent); dv = row16_sum(dv);
+    if (live && l16 == 0) {
         f[G_IDM] = idm;
         f[G_SUMAVERAGE] = savg;
         f[G_SUMENTROPY] = -sent;
@@ -305,6 +310,11 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
         f[G_IV] = iv;
         double r1 = (ent - hxy1) / hx;                // f_info_meas_corr1, glcm.cpp:880-883
         f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+    }
+    wave_sync();
+    if (live && empty && l16 < 2) {                   // blank matrix: all 30 values = soft NaN (after the stores above)
+        for (int k = l16; k < kGlcmAngled; k += 2)
+            f[k] = soft_nan;
     }
     wave_sync();
 }
@@ -324,7 +334,7 @@ __device__ void glcm_features_wave(const uint32_t* P, int Ng, const double* Iv, 
 #endif
 
 // ---- the fused kernel --------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
+__global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -871,7 +881,6 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                             int ang = A.glcm_angles[a0 + q];
                             if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                         }
-                    const int slot[4] = {slot0, slot1, slot2, slot3};
                     const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
                     const int r_begin = wave * rows_per_wave;
                     const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
@@ -880,27 +889,26 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                     const bool remap = greyInfo < 0;
                     uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
                     if (remap && cur) cur = s_lvlmap[cur];
+                    // one (centre, neighbour) pair into the matrix of its direction
+                    auto bump = [=](int sl, uint32_t c, uint32_t nbv) {
+                        if (sl >= 0 && c != 0 && nbv != 0) {
+                            uint32_t* Pq = s_P + sl * NN;
+                            atomicAdd(&Pq[(c - 1) * (uint32_t)Ng + (nbv - 1)], 1u);
+                            if (symmetric)
+                                atomicAdd(&Pq[(nbv - 1) * (uint32_t)Ng + (c - 1)], 1u);
+                        }
+                    };
                     for (int row = r_begin; row < r_end; row++) {
                         uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
                         if (remap && nxt) nxt = s_lvlmap[nxt];      // compact index + 1 (0 stays "skip")
-                        uint32_t nb[4];
-                        nb[0] = lane_plus1(cur, 0);                  // (row,   col+1)  angle 0
-                        nb[1] = lane_plus1(nxt, 0);                  // (row+1, col+1)  angle 45
-                        nb[2] = nxt;                                 // (row+1, col  )  angle 90
-                        nb[3] = lane_minus1(nxt, 0);                 // (row+1, col-1)  angle 135
-                        if (!has_right) { nb[0] = 0; nb[1] = 0; }
-                        const uint32_t rowbase = (cur - 1) * (uint32_t)Ng;
-#pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            if (slot[d] < 0)
-                                continue;
-                            if (cur != 0 && nb[d] != 0) {
-                                uint32_t* Pq = s_P + slot[d] * NN;
-                                atomicAdd(&Pq[rowbase + (nb[d] - 1)], 1u);
-                                if (symmetric)
-                                    atomicAdd(&Pq[(nb[d] - 1) * (uint32_t)Ng + (cur - 1)], 1u);
-                            }
-                        }
+                        uint32_t nb_e = lane_plus1(cur, 0);          // (row,   col+1)  angle 0
+                        uint32_t nb_se = lane_plus1(nxt, 0);         // (row+1, col+1)  angle 45
+                        uint32_t nb_sw = lane_minus1(nxt, 0);        // (row+1, col-1)  angle 135
+                        if (!has_right) { nb_e = 0; nb_se = 0; }
+                        bump(slot0, cur, nb_e);
+                        bump(slot1, cur, nb_se);
+                        bump(slot2, cur, nxt);                       // (row+1, col)    angle 90
+                        bump(slot3, cur, nb_sw);
                         cur = nxt;
                     }
                 } else
@@ -929,9 +937,8 @@ __global__ __launch_bounds__(kBlock) void roi_features_kernel(const RoiArgs A)
                 }
                 __syncthreads();
                 STAMP(11);
-                if (wave < na_pass)
-                    glcm_features_wave(s_P + wave * NN, Ng, s_I, s_scr + wave * 6 * A.L.ng_cap, A.soft_nan,
-                                       s_f + (a0 + wave) * 32, lane);
+                if (wave == 0)
+                    glcm_features_rows(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
             }
             __syncthreads();
             STAMP(12);
