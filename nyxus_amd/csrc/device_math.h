@@ -96,6 +96,20 @@ __device__ __forceinline__ uint32_t to_grayscale(uint32_t i, uint32_t min_i, uin
     return (uint32_t)pi;
 }
 
+// ---- fast fp64 division for tolerance-class features ------------------------------------------
+// a / b through v_rcp_f64 + two Newton steps + one residual correction (8 instructions instead of the
+// ~35 of the IEEE expansion); result within 1 ulp of a / b.  Callers guarantee a finite, normal, non-zero
+// b (pixel counts, 1 + k, sum_p ...).  Sites that feed bit-exact columns, or whose inf / NaN behaviour the
+// reference relies on, keep the `/` operator.
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 // ---- wave64 reductions on the DPP path -------------------------------------------------
 // Cross-lane traffic goes through DPP (VALU data-parallel primitives: row_shr within a row
 // of 16 lanes, row_bcast:15 / row_bcast:31 across rows on GFX9-family CDNA) instead of

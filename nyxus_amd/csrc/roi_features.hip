@@ -142,7 +142,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     const double sum_p = empty ? 1.0 : (double)csum;
     // per-element probabilities use one reciprocal (<= 1 ulp from cnt / sum_p); marginals and the
     // exact-numerator features below keep true divisions
-    const double inv_sum_p = 1.0 / sum_p;
+    const double inv_sum_p = fdiv(1.0, sum_p);
 
     double* pcol = scr;           // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
     double* prow = scr + Ng;      // py[j] = sum_i xy(i,j)/sum_p
@@ -161,9 +161,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
                 dc += P[(x - i) * Ng + x];
         }
         if (live) {
-            pcol[i] = (double)cc / sum_p;
-            prow[i] = (double)rc / sum_p;
-            Pxmy[i] = (double)dc / sum_p;
+            pcol[i] = fdiv((double)cc, sum_p);
+            prow[i] = fdiv((double)rc, sum_p);
+            Pxmy[i] = fdiv((double)dc, sum_p);
         }
     }
     for (int k = l16; k < 2 * Ng; k += 16) {
@@ -172,7 +172,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         for (int x = x0; x <= x1; x++)
             c += P[x * Ng + (k - x)];
         if (live)
-            Pxpy[k] = (double)c / sum_p;
+            Pxpy[k] = fdiv((double)c, sum_p);
     }
     wave_sync();
 
@@ -196,16 +196,16 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         S_c += cnt * ic;                             // f_corr mc :608
         acor_n += cnt * ir * ic;                     // f_GLCM_ACOR :961
         int adiff = r > c ? r - c : c - r;
-        hom1 += p / (1.0 + (double)adiff);           // f_homogeneity :942
+        hom1 += fdiv(p, 1.0 + (double)adiff);        // f_homogeneity :942
         ent += plogp(p, p);                          // f_entropy :734-735, JE :1160-1161, HXY :868
         dis_n += (double)adiff * cnt;                // f_GLCM_DIS :1052 (integer-exact numerator)
-        hom2 += p / (1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
+        hom2 += fdiv(p, 1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
         jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
     }
     asm_ = row16_sum(asm_); contrast_n = row16_sum(contrast_n); S_r = row16_sum(S_r); S_c = row16_sum(S_c);
     acor_n = row16_sum(acor_n); hom1 = row16_sum(hom1); ent = row16_sum(ent); dis_n = row16_sum(dis_n);
     hom2 = row16_sum(hom2); jmax = row16_max(jmax);
-    const double mr = S_r / sum_p, mc = S_c / sum_p; // mr == f_var's mean == JAVE (exact numerators)
+    const double mr = S_r / sum_p, mc = fdiv(S_c, sum_p); // mr == f_var's mean == JAVE (exact numerators)
     if (live && l16 == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
         f[G_ENERGY] = asm_;
@@ -248,7 +248,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     cprom = row16_sum(cprom); cshade = row16_sum(cshade); ctend = row16_sum(ctend); jvar = row16_sum(jvar);
     hxy1 = row16_sum(hxy1); hxy2 = row16_sum(hxy2);
     if (live && l16 == 0) {
-        f[G_VARIANCE] = var_n / sum_p;
+        f[G_VARIANCE] = fdiv(var_n, sum_p);
         f[G_CLUPROM] = cprom;
         f[G_CLUSHADE] = cshade;
         f[G_CLUTEND] = ctend;
@@ -267,12 +267,12 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     for (int k = l16; k < Ng; k += 16) {
         double q = Pxmy[k];
         double kval = k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
-        idm += q / (double)(1 + (k * k));                        // f_idm :685-687
+        idm += fdiv(q, (double)(1 + (k * k)));                   // f_idm :685-687
         if (q != 0)
             dent += plogp(q, q);                                 // f_dentropy :778-781
-        idmn += q / (1.0 + ((double)k * (double)k) / Ng2);       // :1083-1084
-        id += q / (1.0 + (double)k);                             // :1096-1097
-        idn += q / (1.0 + (double)k / (double)Ng);               // :1110-1111
+        idmn += fdiv(q, 1.0 + fdiv((double)k * (double)k, Ng2)); // :1083-1084
+        id += fdiv(q, 1.0 + (double)k);                          // :1096-1097
+        idn += fdiv(q, 1.0 + fdiv((double)k, (double)Ng));       // :1110-1111
         if (k >= 1)
             iv += q / (kval * kval);                             // :1123-1128
         hx += plogp(pcol[k], pcol[k]);                           // :873-874
@@ -303,7 +303,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         f[G_SUMENTROPY] = -sent;
         f[G_DIFENTRO] = -dent;
         f[G_DIFAVE] = diffAvg;
-        f[G_DIFVAR] = dv / (double)Ng;
+        f[G_DIFVAR] = fdiv(dv, (double)Ng);
         f[G_IDMN] = idmn;
         f[G_ID] = id;
         f[G_IDN] = idn;
@@ -589,16 +589,16 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
             o[I_INTEGRATED_INTENSITY] = tot;
             const double var = acc[1];                 // intensity.cpp:110-118
-            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
-            const double variance = dn > 1 ? var / (dn - 1) : 0.0;
-            const double variance_b = dn > 1 ? var / dn : 0.0;
+            o[I_MEAN_ABSOLUTE_DEVIATION] = fdiv(acc[0], dn);
+            const double variance = dn > 1 ? fdiv(var, dn - 1) : 0.0;
+            const double variance_b = dn > 1 ? fdiv(var, dn) : 0.0;
             const double sd = sqrt(variance);
             o[I_VARIANCE] = variance;
             o[I_VARIANCE_BIASED] = variance_b;
             o[I_STANDARD_DEVIATION] = sd;
             o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
             o[I_COV] = sd / mean;
-            o[I_STANDARD_ERROR] = sd / sqrt(dn);
+            o[I_STANDARD_ERROR] = fdiv(sd, sqrt(dn));
             if (!blank) {
                 o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
                 const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 double e = 0, u = 0;
                 for (uint32_t k = lane; k < nb; k += 64) {
                     uint32_t ck = (k < nb - 1 ? s_lbc[k + 1] : n) - s_lbc[k];
-                    double p = (double)ck / dn;
+                    double p = fdiv((double)ck, dn);
                     e += p * log2(p + 2.2e-16);
                     u += p * p;
                 }
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             if (tid == 0) {
                 o[I_ROBUST_MEAN] = mean1090;
                 o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
-                o[I_MEDIAN_ABSOLUTE_DEVIATION] = ad[1] / dn;
+                o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(ad[1], dn);
             }
         }
 
