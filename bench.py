@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--families", type=int, default=3, help="family bitmask (diagnostic; the metric is 3 = INTENSITY|GLCM)")
     ap.add_argument("--tile-path-tiles", type=int, default=128, help="tiles for the informational fused tile-path measurement (0 = skip)")
     return ap.parse_args()
 
@@ -70,7 +71,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    mask = a.families
     s = _abi.default_settings(a.gray_depth)
     ctx = _lib.Context(local_rank)
     ncol = ctx.n_columns(mask, s)

@@ -470,6 +470,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         g.col_gabor = n_cols1 + n_cols2;
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
+        g.small_rois = (max_px <= 512 && max_area <= 1024) ? 1 : 0;
         g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
     }
     (void)n_cols;

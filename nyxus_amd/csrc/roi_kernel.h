@@ -132,6 +132,7 @@ struct ShapeArgs {
     const double* gabor_bank; // device: (F+1) filters (low-pass first), n*n complex taps each
     int32_t gabor_nf, gabor_n;
     double gabor_thr;
+    int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
     ShapeLayout L;
 };
 

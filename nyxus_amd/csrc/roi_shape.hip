@@ -48,8 +48,10 @@ __device__ __forceinline__ double wave_max_d(double v)
 // =========================================================================================
 // Gabor
 // =========================================================================================
-__global__ __launch_bounds__(kBlock) void roi_gabor_kernel(const ShapeArgs A)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
 {
+    constexpr int kBlk = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t roi = blockIdx.x;
@@ -69,22 +71,22 @@ __global__ __launch_bounds__(kBlock) void roi_gabor_kernel(const ShapeArgs A)
     if (npx == 0 || area > A.L.area_cap) {
         if (tid == 0 && npx != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
-        for (int c = tid; c < nF; c += kBlock)
+        for (int c = tid; c < nF; c += kBlk)
             o[c] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
     if (A.max_inten[roi] == A.min_inten[roi]) {     // gabor.cpp:53-57: all zeros, not the soft NaN
-        for (int c = tid; c < nF; c += kBlock)
+        for (int c = tid; c < nF; c += kBlk)
             o[c] = 0.0;
         return;
     }
-    for (uint32_t i = tid; i < area; i += kBlock)
+    for (uint32_t i = tid; i < area; i += kBlk)
         s_plane[i] = 0.0;
     const int bank_len = (nF + 1) * n * n * 2;
-    for (int i = tid; i < bank_len; i += kBlock)
+    for (int i = tid; i < bank_len; i += kBlk)
         s_bank[i] = A.gabor_bank[i];
     __syncthreads();
-    for (uint32_t i = tid; i < npx; i += kBlock) {
+    for (uint32_t i = tid; i < npx; i += kBlk) {
         uint32_t px = A.x[off + i], py = A.y[off + i];
         if (px < w && py < h)
             s_plane[py * w + px] = (double)A.inten[off + i];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void roi_gabor_kernel(const ShapeArgs A)
         const double* G = s_bank + (size_t)f * n * n * 2;
         double tmax = -1.0, tmin = 1.7976931348623157e308;
         uint32_t score = 0;
-        for (uint32_t p = tid; p < area; p += kBlock) {
+        for (uint32_t p = tid; p < area; p += kBlk) {
             const int b = (int)(p / w), a = (int)(p - (uint32_t)b * w);
             const int y = c0 + b, x = c0 + a;
             // taps (j, i) with 0 <= y-j < h and 0 <= x-i < w, ascending as in conv_dud
@@ -127,31 +129,35 @@ __global__ __launch_bounds__(kBlock) void roi_gabor_kernel(const ShapeArgs A)
             if (lane == 0) { s_red[wave * 8] = tmax; s_red[wave * 8 + 1] = tmin; }
             __syncthreads();
             double mx = s_red[0], mn = s_red[1];
-            for (int wv = 1; wv < kWaves; wv++) {
+            for (int wv = 1; wv < NW; wv++) {
                 mx = s_red[wv * 8] > mx ? s_red[wv * 8] : mx;
                 mn = s_red[wv * 8 + 1] < mn ? s_red[wv * 8 + 1] : mn;
             }
             __syncthreads();
             if (mx == mn) {                               // gabor.cpp:91-96
-                for (int c = tid; c < nF; c += kBlock)
+                for (int c = tid; c < nF; c += kBlk)
                     o[c] = A.soft_nan;
                 return;
             }
             maxval = mx;
             uint32_t cnt = 0;                             // baseline score, :99-102
-            for (uint32_t p = tid; p < area; p += kBlock)
+            for (uint32_t p = tid; p < area; p += kBlk)
                 cnt += s_e[p] > mn;
             cnt = (uint32_t)wave_sum_u64(cnt);
             if (lane == 0) s_red[wave * 8] = (double)cnt;
             __syncthreads();
-            baseline = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
+            baseline = 0;
+            for (int wv = 0; wv < NW; wv++) baseline += s_red[wv * 8];
             __syncthreads();
         } else {
             score = (uint32_t)wave_sum_u64(score);
             if (lane == 0) s_red[wave * 8] = (double)score;
             __syncthreads();
-            if (tid == 0)
-                o[f - 1] = (((s_red[0] + s_red[8]) + s_red[16]) + s_red[24]) / baseline;   // :121
+            {
+                double sc = 0;
+                for (int wv = 0; wv < NW; wv++) sc += s_red[wv * 8];
+                if (tid == 0) o[f - 1] = sc / baseline;   // :121
+            }
             __syncthreads();
         }
     }
@@ -170,10 +176,12 @@ __device__ __forceinline__ constexpr double zH1(int n, int m)
     return ((double)((m + 4.0) * (m + 3.0)) / 2.0) - ((m + 4.0) * zH2(n, m)) + ((double)(zH3(n, m) * (n + m + 6.0) * (n - m - 4.0)) / 8.0);
 }
 
-__global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
 {
-    __shared__ double s_red[kWaves * 64];
-    __shared__ unsigned long long s_mom[kWaves * 4];
+    constexpr int kBlk = NW * 64;
+    __shared__ double s_red[NW * 64];
+    __shared__ unsigned long long s_mom[NW * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t roi = blockIdx.x;
     if (roi >= A.n_roi)
@@ -183,13 +191,13 @@ __global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
     const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
     double* const o = A.out + roi * A.ld + A.col_zernike;
     if (npx == 0 || A.max_inten[roi] == A.min_inten[roi]) {   // zernike.cpp:348-356
-        for (int c = tid; c < 30; c += kBlock)
+        for (int c = tid; c < 30; c += kBlk)
             o[c] = npx == 0 ? __longlong_as_double(0x7ff8000000000000LL) : A.soft_nan;
         return;
     }
     // centroid moments (zernike.cpp:216-230): sums of integers, exact in any order
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
-    for (uint32_t i = tid; i < npx; i += kBlock) {
+    for (uint32_t i = tid; i < npx; i += kBlk) {
         unsigned long long v = A.inten[off + i];
         m00 += v;
         m10 += ((unsigned long long)A.x[off + i] + 1) * v;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
     if (lane == 0) { s_mom[wave * 4] = m00; s_mom[wave * 4 + 1] = m10; s_mom[wave * 4 + 2] = m01; }
     __syncthreads();
     unsigned long long t00 = 0, t10 = 0, t01 = 0;
-    for (int wv = 0; wv < kWaves; wv++) { t00 += s_mom[wv * 4]; t10 += s_mom[wv * 4 + 1]; t01 += s_mom[wv * 4 + 2]; }
+    for (int wv = 0; wv < NW; wv++) { t00 += s_mom[wv * 4]; t10 += s_mom[wv * 4 + 1]; t01 += s_mom[wv * 4 + 2]; }
     const double sum = (double)t00;
     const double m10_m00 = (double)t10 / sum, m01_m00 = (double)t01 / sum;
     const double rad = (double)(w < h ? w : h);                // N = min(width, height), :185-195
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
 #pragma unroll
         for (int m = 0; m <= kZL; m++) { AR[n][m] = 0.0; AI[n][m] = 0.0; }
 
-    for (uint32_t i = tid; i < npx; i += kBlock) {
+    for (uint32_t i = tid; i < npx; i += kBlk) {
         const double x = ((double)((int)A.x[off + i] + 1) - m10_m00) / rad;   // :254
         const double y = ((double)((int)A.y[off + i] + 1) - m01_m00) / rad;   // :262
         const double r2 = x * x + y * y, r = sqrt(r2);
@@ -257,28 +265,37 @@ __global__ __launch_bounds__(kBlock) void roi_zernike_kernel(const ShapeArgs A)
             }
     __syncthreads();
     if (tid < 30) {
-        double vr = ((s_red[2 * tid] + s_red[64 + 2 * tid]) + s_red[128 + 2 * tid]) + s_red[192 + 2 * tid];
-        double vi = ((s_red[2 * tid + 1] + s_red[64 + 2 * tid + 1]) + s_red[128 + 2 * tid + 1]) + s_red[192 + 2 * tid + 1];
+        double vr = 0, vi = 0;
+        for (int wv = 0; wv < NW; wv++) { vr += s_red[wv * 64 + 2 * tid]; vi += s_red[wv * 64 + 2 * tid + 1]; }
         o[tid] = fabs(sqrt(vr * vr + vi * vi));                // zernike.cpp:335-337
     }
 }
 
+// Small ROIs (the DSB2018-shaped ones of BASELINE.json configs[4]: 10x9 ... 16x14 px) get one wave per ROI;
+// anything larger four waves.
 int launch_roi_shape(const ShapeArgs& a, void* stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)roi_features_max_lds());
+        hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
     }
     if (a.n_roi == 0)
         return 0;
-    if (a.mask & NYXHIP_FAM_GABOR)
-        hipLaunchKernelGGL(roi_gabor_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
-    if (a.mask & NYXHIP_FAM_ZERNIKE)
-        hipLaunchKernelGGL(roi_zernike_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const bool small = a.small_rois != 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.mask & NYXHIP_FAM_GABOR) {
+        if (small) hipLaunchKernelGGL(roi_gabor_kernel<1>, dim3((unsigned)a.n_roi), dim3(64), a.L.total, st, a);
+        else hipLaunchKernelGGL(roi_gabor_kernel<4>, dim3((unsigned)a.n_roi), dim3(256), a.L.total, st, a);
+    }
+    if (a.mask & NYXHIP_FAM_ZERNIKE) {
+        if (small) hipLaunchKernelGGL(roi_zernike_kernel<1>, dim3((unsigned)a.n_roi), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(roi_zernike_kernel<4>, dim3((unsigned)a.n_roi), dim3(256), 0, st, a);
+    }
     return (int)hipGetLastError();
 }
 
