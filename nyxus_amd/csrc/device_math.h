@@ -239,4 +239,30 @@ __device__ __forceinline__ uint32_t lane_minus1(uint32_t v, uint32_t fill)  // v
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
 
+
+// ---- synchronisation that also works when the "LDS" of a workgroup lives in the global workspace ----------
+// GS = false: plain workgroup barrier / wave-level compiler fence (LDS instructions of a wave run in issue order).
+// GS = true (large-ROI launches): the scratch is global memory; atomics execute in L2 while plain loads may hit
+// a stale line of the CU's vector L1, so every exchange point writes back and invalidates at agent scope.
+template <bool GS>
+__device__ __forceinline__ void blk_sync()
+{
+    if (GS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+    if (GS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+}
+template <bool GS>
+__device__ __forceinline__ void wav_sync()
+{
+    if (GS) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 } // namespace nyxhip

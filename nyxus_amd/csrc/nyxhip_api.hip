@@ -33,6 +33,11 @@ struct nyxhip_ctx {
     // grow-only device staging for host-memory batches
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // large-ROI (spill) pass: index list and per-workgroup global scratch
+    uint32_t* d_spill_list = nullptr;
+    size_t spill_list_bytes = 0;
+    unsigned char* d_spill = nullptr;
+    size_t spill_bytes = 0;
     // grow-only workspace of the fused tile path (tables, rows, clouds, table)
     void* d_tile = nullptr;
     size_t tile_bytes = 0;
@@ -160,11 +165,12 @@ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 // NYXHIP_ERR_UNSUPPORTED when the grey depth alone cannot be held in LDS, or
 // NYXHIP_ERR_ROI_TOO_LARGE when the batch extrema do not fit the 160 KiB of a CU.
 int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
-                uint32_t max_range, LdsLayout& L, std::string& why)
+                uint32_t max_range, LdsLayout& L, std::string& why, size_t cap = 0)
 {
     memset(&L, 0, sizeof(L));
     const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
-    const size_t cap = roi_features_max_lds();
+    const bool spill = cap != 0;               // scratch in the global workspace: only the 2 GiB offset range limits it
+    if (!spill) cap = roi_features_max_lds();
     uint32_t off = 0;
     L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
     L.red = off; off = align16(off + 8u * kWaves * 8);
@@ -177,7 +183,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     // batch's largest intensity range fits kCountCapMax entries -- then no ROI sorts and the
     // value buffer needs no power-of-two padding; otherwise ROIs with a small range still
     // count (table of kCountCapMixed) and the rest bitonic-sort a padded buffer.
-    constexpr uint32_t kCountCapMax = 16384, kCountCapMixed = 4096;
+    const uint32_t kCountCapMax = spill ? (1u << 22) : 16384u, kCountCapMixed = 4096;
     if (do_int) {
         if ((uint64_t)max_range + 1 <= kCountCapMax) {
             L.count_cap = (max_range + 1 + 63u) & ~63u;
@@ -223,7 +229,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
             while (ng > 8 && shared0 + glcm_bytes(ng, 1) > cap) ng >>= 1;
         }
         uint32_t app = 4;
-        while (app > 1 && (4ull * app * ng * ng > 64 * 1024 || shared0 + glcm_bytes(ng, app) > cap)) app >>= 1;
+        while (app > 1 && ((!spill && 4ull * app * ng * ng > 64 * 1024) || shared0 + glcm_bytes(ng, app) > cap)) app >>= 1;
         L.ng_cap = ng;
         L.app = app;
         uint32_t goff = shared0;
@@ -288,29 +294,31 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
     return NYXHIP_OK;
 }
 
-int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, ShapeLayout& L, std::string& why)
+int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, ShapeLayout& L, std::string& why, size_t cap = 0)
 {
     memset(&L, 0, sizeof(L));
+    if (cap == 0) cap = roi_features_max_lds();
     if (!(mask & NYXHIP_FAM_GABOR))
         return NYXHIP_OK;
     uint32_t off = 0;
     L.red = off; off = align16(off + 8u * kWaves * 8);
     L.area_cap = max_area ? max_area : 1;
-    if (16ull * L.area_cap > roi_features_max_lds()) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    if (16ull * L.area_cap > cap) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     L.plane = off; off = align16(off + 8u * L.area_cap);
     L.energy = off; off = align16(off + 8u * L.area_cap);
     L.bank = off; off = align16(off + 16u * (uint32_t)(s->gabor_n_filters + 1) * s->gabor_kersize * s->gabor_kersize);
     L.total = off;
-    if (L.total > roi_features_max_lds()) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    if (L.total > cap) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     return NYXHIP_OK;
 }
 
 // LDS carve-out of the texture kernel (roi_texture.hip)
 int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_area, uint32_t max_side,
-                    TexLayout& L, std::string& why)
+                    TexLayout& L, std::string& why, size_t cap = 0)
 {
     memset(&L, 0, sizeof(L));
-    const size_t cap = roi_features_max_lds();
+    const bool spill = cap != 0;
+    if (!spill) cap = roi_features_max_lds();
     const int greyInfo = s->ibsi ? 0 : s->grey_depth;
     uint32_t off = 0;
     L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
@@ -345,7 +353,7 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         size_t k = 4;
         while (k > 1 && off + 512 + k * slot > cap) k--;
         // keep the carve-out modest when four matrices would crowd out co-resident workgroups
-        while (k > 1 && 512 + k * slot > 48 * 1024) k--;
+        while (!spill && k > 1 && 512 + k * slot > 48 * 1024) k--;
         need = std::max(need, 512 + k * slot);
     }
     L.work_bytes = (uint32_t)need;
@@ -413,18 +421,34 @@ int check_status(nyxhip_ctx* ctx)
 }
 
 // Launch on device-resident arrays.
-int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+// ROIs whose pixel count / bounding box exceed the LDS caps -> index list (order irrelevant: rows are
+// addressed by ROI index).  list[0..count) ; count in *n_out.
+__global__ void classify_large_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
+                                      uint32_t cap_px, uint32_t cap_area, uint32_t cap_side, uint32_t* list, uint32_t* n_out)
 {
-    std::string why;
-    const int n_cols = nyxhip_n_columns(mask, s);
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n_roi) return;
+    uint64_t n = px_offset[i + 1] - px_offset[i];
+    uint64_t a = (uint64_t)bw[i] * bh[i];
+    uint32_t sd = bw[i] > bh[i] ? bw[i] : bh[i];
+    if (n > cap_px || a > cap_area || sd > cap_side)
+        list[atomicAdd(n_out, 1u)] = (uint32_t)i;
+}
+
+struct Extrema { uint32_t px, area, range, side; };
+
+// Fills the three argument blocks for one set of extrema; `cap` = 0 -> LDS carve-outs, else spill layouts.
+int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
+               const Extrema& E, size_t cap, RoiArgs& a, TexArgs& t, ShapeArgs& g, std::string& why)
+{
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape;
     const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s);
-    RoiArgs a;
     memset(&a, 0, sizeof(a));
+    memset(&t, 0, sizeof(t));
+    memset(&g, 0, sizeof(g));
     if (mask1) {
-        if (int lrc = make_layout(mask1, s, n_cols1, max_px, max_area, max_range, a.L, why))
-            return fail(ctx, lrc, why);
+        if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap))
+            return lrc;
         a.n_roi = b->n_roi;
         a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
         a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
@@ -442,11 +466,9 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
         a.n_hist = abs(s->grey_depth);
     }
-    TexArgs t;
-    memset(&t, 0, sizeof(t));
     if (mask2) {
-        if (int lrc = make_tex_layout(mask2, s, n_cols2, max_area, max_side, t.L, why))
-            return fail(ctx, lrc, why);
+        if (int lrc = make_tex_layout(mask2, s, n_cols2, E.area, E.side, t.L, why, cap))
+            return lrc;
         t.n_roi = b->n_roi;
         t.px_offset = b->px_offset; t.x = b->x; t.y = b->y; t.inten = b->inten;
         t.bbox_w = b->bbox_w; t.bbox_h = b->bbox_h; t.min_inten = b->min_inten; t.max_inten = b->max_inten;
@@ -454,14 +476,9 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         t.mask = mask2; t.n_cols = n_cols2; t.col0 = n_cols1;
         t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
     }
-    ShapeArgs g;
-    memset(&g, 0, sizeof(g));
     if (mask3) {
-        if (int lrc = make_shape_layout(mask3, s, max_area, g.L, why))
-            return fail(ctx, lrc, why);
-        if (mask3 & NYXHIP_FAM_GABOR)
-            if (int brc = ensure_gabor_bank(ctx, s))
-                return brc;
+        if (int lrc = make_shape_layout(mask3, s, E.area, g.L, why, cap))
+            return lrc;
         g.n_roi = b->n_roi;
         g.px_offset = b->px_offset; g.x = b->x; g.y = b->y; g.inten = b->inten;
         g.bbox_w = b->bbox_w; g.bbox_h = b->bbox_h; g.min_inten = b->min_inten; g.max_inten = b->max_inten;
@@ -470,10 +487,47 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         g.col_gabor = n_cols1 + n_cols2;
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
-        g.small_rois = (max_px <= 512 && max_area <= 1024) ? 1 : 0;
+        g.small_rois = (E.px <= 512 && E.area <= 1024) ? 1 : 0;
         g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
     }
-    (void)n_cols;
+    return NYXHIP_OK;
+}
+
+// Launch on device-resident arrays.  Normal case: one LDS-resident launch per kernel group.  When the batch
+// extrema do not fit the 160 KiB of a CU, the LDS launches run with capped carve-outs and skip the oversized
+// ROIs, which are then collected into an index list and re-run by the same kernels instantiated with their
+// scratch in a global workspace (slower, but any ROI the device memory can hold is served).
+int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
+                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+{
+    std::string why;
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape;
+    if (mask3 & NYXHIP_FAM_GABOR)
+        if (int brc = ensure_gabor_bank(ctx, s))
+            return brc;
+    const Extrema full{max_px, max_area, max_range, max_side};
+    RoiArgs a; TexArgs t; ShapeArgs g;
+    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, why);
+    bool need_spill = false;
+    Extrema capE = full;
+    if (lrc == NYXHIP_ERR_UNSUPPORTED)
+        return fail(ctx, lrc, why);
+    if (lrc == NYXHIP_ERR_ROI_TOO_LARGE) {
+        need_spill = true;
+        // LDS caps for the bulk of the batch: keep the carve-out small enough for two workgroups per CU
+        capE.px = std::min<uint32_t>(max_px, 8192);
+        capE.area = std::min<uint32_t>(max_area, 16384);
+        capE.side = std::min<uint32_t>(max_side, 256);
+        for (int tries = 0; tries < 8; tries++) {
+            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, why);
+            if (lrc != NYXHIP_ERR_ROI_TOO_LARGE) break;
+            capE.px = std::max<uint32_t>(capE.px / 2, 64); capE.area = std::max<uint32_t>(capE.area / 2, 64); capE.side = std::max<uint32_t>(capE.side / 2, 8);
+        }
+        if (lrc) return fail(ctx, lrc, why);
+        a.sp.defer_large = t.sp.defer_large = g.sp.defer_large = 1;
+        g.small_rois = 0;                          // the one-wave shape kernels are sized for uniformly small batches
+    } else if (lrc)
+        return fail(ctx, lrc, why);
 
     hipStream_t st = ctx->stream();
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -489,15 +543,63 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         ctx->ev_used++;
         HIP_TRY(ctx, hipEventRecord(e0, st));
     }
-    int rc = mask1 ? launch_roi_features(a, st) : 0;
+    const uint32_t grid = (uint32_t)b->n_roi;
+    int rc = mask1 ? launch_roi_features(a, st, grid) : 0;
     if (rc == 0 && mask2)
-        rc = launch_roi_texture(t, st);
+        rc = launch_roi_texture(t, st, grid);
     if (rc == 0 && mask3)
-        rc = launch_roi_shape(g, st);
+        rc = launch_roi_shape(g, st, grid);
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     if (ctx->timing)
         HIP_TRY(ctx, hipEventRecord(e1, st));
+    if (!need_spill)
+        return NYXHIP_OK;
+
+    // ---- spill pass ------------------------------------------------------------------------------------
+    const size_t list_bytes = 4ull * b->n_roi + 256;
+    if (list_bytes > ctx->spill_list_bytes) {
+        if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
+        ctx->spill_list_bytes = list_bytes;
+    }
+    uint32_t* d_cnt = ctx->d_spill_list;           // word 0 = count, list from word 64
+    uint32_t* d_list = ctx->d_spill_list + 64;
+    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st));
+    hipLaunchKernelGGL(classify_large_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w,
+                       b->bbox_h, capE.px, capE.area, capE.side, d_list, d_cnt);
+    uint32_t n_large = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_large, d_cnt, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_large == 0)
+        return NYXHIP_OK;
+    RoiArgs a2; TexArgs t2; ShapeArgs g2;
+    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, why);
+    if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
+    size_t stride = 0;
+    if (mask1) stride = std::max<size_t>(stride, a2.L.total);
+    if (mask2) stride = std::max<size_t>(stride, t2.L.total);
+    if (mask3 & NYXHIP_FAM_GABOR) stride = std::max<size_t>(stride, g2.L.total);
+    stride = (stride + 255) & ~(size_t)255;
+    const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
+    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, budget / std::max<size_t>(stride, 1)));
+    const size_t need = stride * chunk;
+    if (need > ctx->spill_bytes) {
+        if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, need));
+        ctx->spill_bytes = need;
+    }
+    for (uint32_t o = 0; o < n_large; o += chunk) {
+        const uint32_t nb = std::min(chunk, n_large - o);
+        a2.sp.roi_index = t2.sp.roi_index = g2.sp.roi_index = d_list + o;
+        a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = ctx->d_spill;
+        a2.sp.stride = t2.sp.stride = g2.sp.stride = stride;
+        rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
+        if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
+        if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
+        if (rc != 0)
+            return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
     return NYXHIP_OK;
 }
 
@@ -580,6 +682,8 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_tile) (void)hipFree(ctx->d_tile);
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);

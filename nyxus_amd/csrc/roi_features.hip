@@ -59,16 +59,11 @@ enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MODE, S_NG };
 // Lanes of one wave exchange data through LDS without a workgroup barrier: LDS
 // instructions of a wave execute in issue order, so only the compiler has to be
 // kept from reordering / caching across the exchange.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wav_sync<GS>() in device_math.h)
 
 // Sum N doubles across the workgroup in a fixed order (deterministic): wave shuffle
 // tree, then the four wave partials in wave order.  All threads get the totals.
-template <int N>
+template <int N, bool GS>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -80,7 +75,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid
         for (int k = 0; k < N; k++)
             s_red[wave * 8 + k] = v[k];
     }
-    __syncthreads();
+    blk_sync<GS>();
 #pragma unroll
     for (int k = 0; k < N; k++) {
         double t = s_red[k];
@@ -89,10 +84,11 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid
             t += s_red[w * 8 + k];
         v[k] = t;
     }
-    __syncthreads();
+    blk_sync<GS>();
 }
 
 // In-place ascending bitonic sort of s[0..P), P a power of two.
+template <bool GS>
 __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 {
     for (uint32_t k = 2; k <= P; k <<= 1) {
@@ -107,7 +103,7 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
                     s[l] = a;
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
         }
     }
 }
@@ -122,6 +118,7 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 // Numerics: marginals and the x+y / |x-y| distributions are formed from exact integer count sums and
 // divided by sum_p once (the reference sums the already divided elements, glcm.cpp:503-508, :523-525: same
 // value to ~1e-16 relative); matrix-wide sums are lane-strided partial sums combined in a fixed order.
+template <bool GS>
 __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, const double* Iv, double* scr_base, int scr_stride,
                                    double soft_nan, double* fslots, int lane)
 {
@@ -174,7 +171,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         if (live)
             Pxpy[k] = fdiv((double)c, sum_p);
     }
-    wave_sync();
+    wav_sync<GS>();
 
     // by_row_mean (glcm.cpp:531-536)
     double brm = 0;
@@ -311,12 +308,12 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         double r1 = (ent - hxy1) / hx;                // f_info_meas_corr1, glcm.cpp:880-883
         f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
     }
-    wave_sync();
+    wav_sync<GS>();
     if (live && empty && l16 < 2) {                   // blank matrix: all 30 values = soft NaN (after the stores above)
         for (int k = l16; k < kGlcmAngled; k += 2)
             f[k] = soft_nan;
     }
-    wave_sync();
+    wav_sync<GS>();
 }
 
 // Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
@@ -334,11 +331,13 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 #endif
 
 // ---- the fused kernel --------------------------------------------------------------
+template <bool GS>   // GS: per-workgroup scratch in the global workspace instead of LDS (large-ROI launches)
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t roi = blockIdx.x;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
 
@@ -374,6 +373,8 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
     while (P2 < n)
         P2 <<= 1;
     if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
+        if (n != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
         if (tid == 0 && n != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         for (int c = tid; c < A.n_cols; c += kBlock)
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
     }
     if (tid < 16)
         s_stat[tid] = 0.0;
-    __syncthreads();
+    blk_sync<GS>();
 
     STAMP(0);
     // ---- phase 1: the only pass over HBM ------------------------------------------------
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             s_red[wave * 8 + 0] = (double)sum;
             s_red[wave * 8 + 1] = (double)sumsq;
         }
-        __syncthreads(); // also: every s_val / s_cnt write of phase 1 is visible
+        blk_sync<GS>(); // also: every s_val / s_cnt write of phase 1 is visible
         double tot = 0, totsq = 0;
         for (int wv = 0; wv < kWaves; wv++) {
             tot += s_red[wv * 8 + 0];
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
         }
         const double mean = tot / dn;
         const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
-        __syncthreads();
+        blk_sync<GS>();
         STAMP(2);
 
         const double binW100 = (double)range / 100.;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 s_red[wave * 8 + 1] = (double)best_c;
                 s_red[wave * 8 + 2] = (double)best_i;
             }
-            __syncthreads();
+            blk_sync<GS>();
             uint32_t mc = 0, mi = 0;
             for (int wv = 0; wv < kWaves; wv++) {
                 uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
@@ -553,9 +554,9 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             woff3 = woff2 + (uint32_t)s_red[16];
             if (tid == 0)
                 s_stat[S_MODE] = (double)(vmin + mi);
-            __syncthreads();
+            blk_sync<GS>();
         } else {
-            bitonic_sort(s_val, P2, tid);
+            bitonic_sort<GS>(s_val, P2, tid);
         }
         STAMP(3);
         // C(i) = number of values <= vmin + i (counting engine)
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             acc[4] += d2 * d2 * d;
             acc[5] += d2 * d2 * d2;
         }
-        block_sum<6>(acc, s_red, tid);
+        block_sum<6, GS>(acc, s_red, tid);
         if (tid == 0) { // everything that depends only on the sums leaves the registers now
             o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
             o[I_MAX] = (double)vmax;
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                     s_red[wave * 8 + 0] = (double)best_c;
                     s_red[wave * 8 + 1] = (double)best_v;
                 }
-                __syncthreads();
+                blk_sync<GS>();
                 if (tid == 0) {
                     uint32_t mc = 0, mv = 0;
                     for (int wv = 0; wv < kWaves; wv++) {
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                     s_stat[S_MODE] = (double)mv;
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
             STAMP(6);
 
             // three independent reductions run on three different waves
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                     s_stat[S_MEDIAN] = median;
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
             STAMP(7);
 
             // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                     rb[1] += 1.0;
                 }
             }
-            block_sum<2>(rb, s_red, tid);
+            block_sum<2, GS>(rb, s_red, tid);
             const double mean1090 = rb[1] > 0 ? rb[0] / rb[1] : 0.0;
             // robust MAD (histogram.h:102-112) and median absolute deviation (intensity.cpp:156-159)
             double ad[2] = {0, 0};
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                     ad[0] += fabs(a - mean1090);
                 ad[1] += fabs(a - median);
             }
-            block_sum<2>(ad, s_red, tid);
+            block_sum<2, GS>(ad, s_red, tid);
             if (tid == 0) {
                 o[I_ROBUST_MEAN] = mean1090;
                 o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             lvl_max = wave_max_u32(lvl_max);
             if (lane == 0)
                 s_red[wave * 8] = (double)lvl_max;
-            __syncthreads(); // also orders the s_lvlmap writes of phase 1
+            blk_sync<GS>(); // also orders the s_lvlmap writes of phase 1
             if (tid == 0) {
                 int Ng;
                 if (greyInfo == 0) {
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 s_stat[S_NG] = (double)Ng;
             }
         }
-        __syncthreads();
+        blk_sync<GS>();
         const int Ng = (int)s_stat[S_NG];
         const bool too_big = (uint32_t)Ng > A.L.ng_cap;
         if (too_big && tid == 0)
@@ -855,10 +856,10 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             const int app = (int)A.L.app;
             for (int a0 = 0; a0 < na; a0 += app) {
                 const int na_pass = (na - a0) < app ? (na - a0) : app;
-                __syncthreads();
+                blk_sync<GS>();
                 for (int i = tid; i < na_pass * NN; i += kBlock)
                     s_P[i] = 0;
-                __syncthreads();
+                blk_sync<GS>();
                 STAMP(10);
                 // co-occurrence scan (glcm.cpp:431-478): LDS atomics, all angles of the pass.
                 // Rows are dealt to waves, columns to lanes (no integer division per pixel).
@@ -935,12 +936,12 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                         }
                     }
                 }
-                __syncthreads();
+                blk_sync<GS>();
                 STAMP(11);
                 if (wave == 0)
-                    glcm_features_rows(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
+                    glcm_features_rows<GS>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
             }
-            __syncthreads();
+            blk_sync<GS>();
             STAMP(12);
             // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
             for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
         }
     }
 
-    __syncthreads();
+    blk_sync<GS>();
     STAMP(13);
     for (int c = tid; c < A.n_cols; c += kBlock)
         out_row[c] = s_out[c];
@@ -976,19 +977,22 @@ size_t roi_features_max_lds()
     return 160 * 1024; // gfx950: 160 KiB per CU, all of it usable by one workgroup
 }
 
-int launch_roi_features(const RoiArgs& a, void* stream)
+int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
     }
-    if (a.n_roi == 0)
+    if (grid == 0)
         return 0;
-    hipLaunchKernelGGL(roi_features_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    if (a.sp.scratch)
+        hipLaunchKernelGGL(roi_features_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_features_kernel<false>, dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

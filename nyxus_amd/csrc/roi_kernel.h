@@ -12,6 +12,15 @@ constexpr int kGlcmAngled = 30;      // Feature2D GLCM_ASM..GLCM_VARIANCE (featu
 constexpr int kGlcmAve = 29;         // Feature2D GLCM_ASM_AVE..GLCM_SUMVARIANCE_AVE (:205-233)
 constexpr int kMaxAngles = 4;
 
+// Large-ROI ("spill") launches: the same kernels instantiated with their per-workgroup scratch in a global
+// workspace instead of LDS, run over an index list of the ROIs that do not fit the LDS carve-out.
+struct SpillArgs {
+    const uint32_t* roi_index;   // NULL: workgroup b handles ROI b; else ROI roi_index[b]
+    unsigned char* scratch;      // global scratch, `stride` bytes per workgroup (spill launches only)
+    uint64_t stride;
+    int32_t defer_large;         // LDS launch: silently skip ROIs beyond the caps (a spill launch follows)
+};
+
 // Byte offsets of the regions carved out of the workgroup's dynamic LDS; computed
 // on the host per launch (size classes differ per batch).
 struct LdsLayout {
@@ -60,6 +69,7 @@ struct RoiArgs {
     int32_t grey_depth, ibsi, glcm_grey_depth, glcm_offset, glcm_na, glcm_symmetric;
     int32_t glcm_angles[kMaxAngles];
     int32_t n_hist;          // |grey_depth| = intensity histogram bins
+    SpillArgs sp;
     LdsLayout L;
 };
 
@@ -98,6 +108,7 @@ struct TexArgs {
     int32_t col0;         // first of them inside the output row
     double soft_nan;
     int32_t grey_depth, ibsi;
+    SpillArgs sp;
     TexLayout L;
 };
 
@@ -133,6 +144,7 @@ struct ShapeArgs {
     int32_t gabor_nf, gabor_n;
     double gabor_thr;
     int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
+    SpillArgs sp;
     ShapeLayout L;
 };
 
@@ -152,9 +164,9 @@ int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W,
 __global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
-int launch_roi_features(const RoiArgs& a, void* stream);
-int launch_roi_texture(const TexArgs& a, void* stream);
-int launch_roi_shape(const ShapeArgs& a, void* stream);
+int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
+int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid);
+int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

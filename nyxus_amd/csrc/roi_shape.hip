@@ -48,13 +48,14 @@ __device__ __forceinline__ double wave_max_d(double v)
 // =========================================================================================
 // Gabor
 // =========================================================================================
-template <int NW>
+template <int NW, bool GS>   // GS: planes in the global workspace (large-ROI launches)
 __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
 {
     constexpr int kBlk = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t roi = blockIdx.x;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
     double* s_red = (double*)(lds + A.L.red);
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     const int nF = A.gabor_nf, n = A.gabor_n;
     double* const o = A.out + roi * A.ld + A.col_gabor;
     if (npx == 0 || area > A.L.area_cap) {
+        if (npx != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
         if (tid == 0 && npx != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         for (int c = tid; c < nF; c += kBlk)
@@ -85,13 +88,13 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     const int bank_len = (nF + 1) * n * n * 2;
     for (int i = tid; i < bank_len; i += kBlk)
         s_bank[i] = A.gabor_bank[i];
-    __syncthreads();
+    blk_sync<GS>();
     for (uint32_t i = tid; i < npx; i += kBlk) {
         uint32_t px = A.x[off + i], py = A.y[off + i];
         if (px < w && py < h)
             s_plane[py * w + px] = (double)A.inten[off + i];
     }
-    __syncthreads();
+    blk_sync<GS>();
 
     const int c0 = (n + 1) / 2;                     // (int)ceil(n / 2.), gabor.cpp:492
     double maxval = 0, baseline = 0;
@@ -127,13 +130,13 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
             tmax = wave_max_d(tmax);
             tmin = wave_min_d(tmin);
             if (lane == 0) { s_red[wave * 8] = tmax; s_red[wave * 8 + 1] = tmin; }
-            __syncthreads();
+            blk_sync<GS>();
             double mx = s_red[0], mn = s_red[1];
             for (int wv = 1; wv < NW; wv++) {
                 mx = s_red[wv * 8] > mx ? s_red[wv * 8] : mx;
                 mn = s_red[wv * 8 + 1] < mn ? s_red[wv * 8 + 1] : mn;
             }
-            __syncthreads();
+            blk_sync<GS>();
             if (mx == mn) {                               // gabor.cpp:91-96
                 for (int c = tid; c < nF; c += kBlk)
                     o[c] = A.soft_nan;
@@ -145,20 +148,20 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
                 cnt += s_e[p] > mn;
             cnt = (uint32_t)wave_sum_u64(cnt);
             if (lane == 0) s_red[wave * 8] = (double)cnt;
-            __syncthreads();
+            blk_sync<GS>();
             baseline = 0;
             for (int wv = 0; wv < NW; wv++) baseline += s_red[wv * 8];
-            __syncthreads();
+            blk_sync<GS>();
         } else {
             score = (uint32_t)wave_sum_u64(score);
             if (lane == 0) s_red[wave * 8] = (double)score;
-            __syncthreads();
+            blk_sync<GS>();
             {
                 double sc = 0;
                 for (int wv = 0; wv < NW; wv++) sc += s_red[wv * 8];
                 if (tid == 0) o[f - 1] = sc / baseline;   // :121
             }
-            __syncthreads();
+            blk_sync<GS>();
         }
     }
 }
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     __shared__ double s_red[NW * 64];
     __shared__ unsigned long long s_mom[NW * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t roi = blockIdx.x;
+    const uint64_t roi = blockIdx.x;   // no size limit: always part of the first (non-spill) launch
     if (roi >= A.n_roi)
         return;
     const uint64_t off = A.px_offset[roi];
@@ -273,28 +276,33 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
 
 // Small ROIs (the DSB2018-shaped ones of BASELINE.json configs[4]: 10x9 ... 16x14 px) get one wave per ROI;
 // anything larger four waves.
-int launch_roi_shape(const ShapeArgs& a, void* stream)
+int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+            e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
     }
-    if (a.n_roi == 0)
+    if (grid == 0)
         return 0;
     const bool small = a.small_rois != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (a.sp.scratch) {   // spill launch: Gabor only (Zernike has no LDS-resident state and ran with the first launch)
+        if (a.mask & NYXHIP_FAM_GABOR)
+            hipLaunchKernelGGL((roi_gabor_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
+        return (int)hipGetLastError();
+    }
     if (a.mask & NYXHIP_FAM_GABOR) {
-        if (small) hipLaunchKernelGGL(roi_gabor_kernel<1>, dim3((unsigned)a.n_roi), dim3(64), a.L.total, st, a);
-        else hipLaunchKernelGGL(roi_gabor_kernel<4>, dim3((unsigned)a.n_roi), dim3(256), a.L.total, st, a);
+        if (small) hipLaunchKernelGGL((roi_gabor_kernel<1, false>), dim3(grid), dim3(64), a.L.total, st, a);
+        else hipLaunchKernelGGL((roi_gabor_kernel<4, false>), dim3(grid), dim3(256), a.L.total, st, a);
     }
     if (a.mask & NYXHIP_FAM_ZERNIKE) {
-        if (small) hipLaunchKernelGGL(roi_zernike_kernel<1>, dim3((unsigned)a.n_roi), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(roi_zernike_kernel<4>, dim3((unsigned)a.n_roi), dim3(256), 0, st, a);
+        if (small) hipLaunchKernelGGL(roi_zernike_kernel<1>, dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(roi_zernike_kernel<4>, dim3(grid), dim3(256), 0, st, a);
     }
     return (int)hipGetLastError();
 }

@@ -32,12 +32,6 @@ enum { R_SRE = 0, R_LRE, R_GLN, R_GLNN, R_RLN, R_RLNN, R_RP, R_GLV, R_RV, R_RE, 
 enum { Z_SAE = 0, Z_LAE, Z_GLN, Z_GLNN, Z_SZN, Z_SZNN, Z_ZP, Z_GLV, Z_ZV, Z_ZE, Z_LGLZE, Z_HGLZE,
        Z_SALGLE, Z_SAHGLE, Z_LALGLE, Z_LAHGLE };
 
-__device__ __forceinline__ void wave_sync_t()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // p * fast_log10(p + EPS) / LOG10_2 with EPS = 2.2e-16 (glrlm.h:169-171, glszm.h:138-140);
 // (lg2 * c) / c == lg2 to 1 ulp, see device_math.h plogp.
@@ -49,6 +43,7 @@ __device__ __forceinline__ double plog_tex(double p)
 // ---- GLRLM features of one angle from its LDS matrix, by one wave -------------------------
 // P[row * Nr + (len-1)], rows = level indices; lv[row] = level value (PixIntens).
 // ri / rj: scratch for row / column sums.
+template <bool GS>
 __device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
                                     uint32_t Np, double* f, int lane)
 {
@@ -65,10 +60,10 @@ __device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uin
         rj[j] = sm;
     }
     tot = wave_sum_u64(tot);
-    wave_sync_t();
+    wav_sync<GS>();
     if (tot == 0) { // sum_p == 0 -> every feature 0.0 (glrlm.cpp:364-367 etc.)
         if (lane < 16) f[lane] = 0.0;
-        wave_sync_t();
+        wav_sync<GS>();
         return;
     }
     const double sum_p = (double)tot;
@@ -139,14 +134,16 @@ __device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uin
         f[R_LRLGLE] = lrl / sum_p;
         f[R_LRHGLE] = lrh / sum_p;
     }
-    wave_sync_t();
+    wav_sync<GS>();
 }
 
+template <bool GS>   // GS: scratch in the global workspace (large-ROI launches)
 __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t roi = blockIdx.x;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
     double* s_out = (double*)(lds + A.L.out);
@@ -167,6 +164,8 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                do_ngt = (A.mask & NYXHIP_FAM_NGTDM) != 0;
     const uint32_t side = w > h ? w : h;
     if (n == 0 || area > A.L.dense_cap || side > A.L.side_cap) {
+        if (n != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
         if (tid == 0 && n != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         for (int c = tid; c < A.n_cols; c += kBlock)
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         for (uint32_t i = tid; i <= Lcap + 1; i += kBlock)
             s_lvlmap[i] = 0;
     }
-    __syncthreads();
+    blk_sync<GS>();
 
     // ---- phase 1: cloud -> binned plane -----------------------------------------------------------
     uint32_t nz_orig = 0, lvl_over = 0;
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     nz_orig = (uint32_t)wave_sum_u64(nz_orig);
     lvl_over = wave_max_u32(lvl_over);
     if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
-    __syncthreads();
+    blk_sync<GS>();
     uint32_t Np_orig = 0;   // non-zero ORIGINAL pixels (glrlm.cpp:197-204)
     bool over = false;
     for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; }
@@ -221,9 +220,9 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         if (l) { s_lvlmap[l] = 1; nz_bin++; }
     }
     nz_bin = (uint32_t)wave_sum_u64(nz_bin);
-    __syncthreads();
+    blk_sync<GS>();
     if (lane == 0) s_red[wave * 8] = (double)nz_bin;
-    __syncthreads();
+    blk_sync<GS>();
     uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
     for (int wv = 0; wv < kWaves; wv++) Np_bin += (uint32_t)s_red[wv * 8];
     // sorted unique non-zero levels (glrlm.cpp:101-105, glszm.cpp:97-101, ngtdm.cpp:53-67);
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         s_stat[0] = (double)(greyInfo == 0 ? (int)mx : k);   // Ng for GLRLM / GLSZM
         s_stat[1] = (double)k;                               // Ngp = unique non-zero levels (ngtdm.cpp:150)
     }
-    __syncthreads();
+    blk_sync<GS>();
     const int Ng = (int)s_stat[0];
     const int Nuniq = (int)s_stat[1];
     const bool blank = vmin == vmax;
@@ -267,9 +266,9 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
             for (int a0 = 0; a0 < 4; a0 += per) {
-                __syncthreads();
+                blk_sync<GS>();
                 for (uint32_t i = tid; i < (uint32_t)per * slot_words; i += kBlock) s_mat[i] = 0;
-                __syncthreads();
+                blk_sync<GS>();
                 if (wave < per && a0 + wave < 4) {
                     const int ai = a0 + wave;
                     uint32_t* P = s_mat + wave * slot_words;
@@ -287,11 +286,11 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                         }
                         atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
                     }
-                    wave_sync_t();
-                    glrlm_features_wave(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
+                    wav_sync<GS>();
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
             for (int c = tid; c < 64; c += kBlock) {         // feature-major, angle-minor
                 int k = c >> 2, a = c & 3;
                 o[c] = s_f[a * 16 + k];
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 o[64 + k] = v / 4.0;
             }
         }
-        __syncthreads();
+        blk_sync<GS>();
     }
 
     // =====================================================================================
@@ -358,15 +357,15 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                         carry_v = __shfl(v, 63, 64);
                         carry_l = __shfl(lab, 63, 64);
                     }
-                    wave_sync_t();
+                    wav_sync<GS>();
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
             // zone sizes at the owners
             for (uint32_t p = tid; p < area; p += kBlock)
                 if (s_dense[p] != 0)
                     atomicAdd(&s_count[s_label[p]], 1u);
-            __syncthreads();
+            blk_sync<GS>();
             // zones -> P(i,j) multiplicities (hash), zones per level; Nz
             uint32_t nzone = 0;
             for (uint32_t p = tid; p < area; p += kBlock) {
@@ -384,17 +383,17 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 }
             }
             nzone = (uint32_t)wave_sum_u64(nzone);
-            __syncthreads();
+            blk_sync<GS>();
             if (lane == 0) s_red[wave * 8] = (double)nzone;
             // zones per size (sj): reuse s_count, keyed by size
             for (uint32_t i = tid; i <= area; i += kBlock) s_count[i] = 0;
-            __syncthreads();
+            blk_sync<GS>();
             double sum_p = 0;
             for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
             for (uint32_t i = tid; i < hcap; i += kBlock)
                 if (s_hkey[i] != 0xFFFFFFFFu)
                     atomicAdd(&s_count[s_hkey[i] & 0xFFFFFu], s_hval[i]);
-            __syncthreads();
+            blk_sync<GS>();
             if (sum_p == 0) {                                // glszm.cpp:229-233
                 for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
             } else {
@@ -419,10 +418,10 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 for (int k = 0; k < 7; k++) acc[k] = wave_sum(acc[k]);
                 if (lane == 0)
                     for (int k = 0; k < 7; k++) s_red[wave * 8 + k] = acc[k];
-                __syncthreads();
+                blk_sync<GS>();
 #pragma unroll
                 for (int k = 0; k < 7; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
-                __syncthreads();
+                blk_sync<GS>();
                 const double mu_ZV = acc[5], mu_GLV = acc[6];
                 double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < hcap; i += kBlock) {
@@ -435,8 +434,10 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 }
                 for (uint32_t j = 1 + tid; j <= area; j += kBlock) {
                     double sj = (double)s_count[j];
-                    if (sj == 0) continue;
-                    int jj = (int)j * (int)j;
+                    // j * j is an int product in the reference: it wraps for j >= 46341 and is exactly 0 at multiples of
+                    // 65536, where the empty column contributes 0.0 / 0 = NaN to SAE (Ns = bbox area, glszm.cpp:212)
+                    if (sj == 0 && (j & 0xFFFFu) != 0) continue;
+                    int jj = (int)(j * j);
                     b[2] += sj / (double)jj;                 // calc_SAE :419-428
                     b[3] += sj * (double)jj;                 // calc_LAE :430-439
                     b[4] += sj * sj;                         // calc_SZN :464-474
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 for (int k = 0; k < 8; k++) b[k] = wave_sum(b[k]);
                 if (lane == 0)
                     for (int k = 0; k < 8; k++) s_red[wave * 8 + k] = b[k];
-                __syncthreads();
+                blk_sync<GS>();
                 if (tid == 0) {
                     for (int k = 0; k < 8; k++) b[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
                     o[Z_SAE] = b[2] / sum_p;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 }
             }
         }
-        __syncthreads();
+        blk_sync<GS>();
     }
 
     // =====================================================================================
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
             for (int c = tid; c < 5; c += kBlock) o[c] = A.soft_nan;
         } else {
             for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
-            __syncthreads();
+            blk_sync<GS>();
             for (uint32_t p = tid; p < area; p += kBlock) {
                 uint32_t pi = s_dense[p];
                 if (pi == 0) continue;
@@ -516,19 +517,19 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                     atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
                 }
             }
-            __syncthreads();
+            blk_sync<GS>();
             // Nvc = Nvp = number of pixels with a neighbourhood (every mean is > 0), ngtdm.cpp:176-186
             uint32_t nvc_part = 0;
             for (int i = tid; i < NgT; i += kBlock) nvc_part += s_N[i];
             nvc_part = (uint32_t)wave_sum_u64(nvc_part);
             if (lane == 0) s_red[wave * 8] = (double)nvc_part;
-            __syncthreads();
+            blk_sync<GS>();
             const double Nvc = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
             for (int i = tid; i < NgT; i += kBlock) {
                 s_P[i] = (double)s_N[i] / Nvc;
                 s_Sd[i] = (double)s_S[i] / 840.0;
             }
-            __syncthreads();
+            blk_sync<GS>();
             if (wave == 0) {
                 auto Iof = [=](int i) -> double { return greyInfo == 0 ? (double)i : (double)s_lv[i]; };
                 double ps = 0, ssum = 0;
@@ -558,27 +559,30 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 }
             }
         }
-        __syncthreads();
+        blk_sync<GS>();
     }
 
-    __syncthreads();
+    blk_sync<GS>();
     for (int c = tid; c < A.n_cols; c += kBlock)
         out_row[c] = s_out[c];
 }
 
-int launch_roi_texture(const TexArgs& a, void* stream)
+int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
     }
-    if (a.n_roi == 0)
+    if (grid == 0)
         return 0;
-    hipLaunchKernelGGL(roi_texture_kernel, dim3((unsigned)a.n_roi), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    if (a.sp.scratch)
+        hipLaunchKernelGGL(roi_texture_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_texture_kernel<false>, dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -165,12 +165,38 @@ def test_device_resident_async_path(hip_ctx):
     assert not parity.compare_tables(G, O, _lib.column_names(MASK, s))
 
 
-def test_roi_too_large_is_reported(hip_ctx):
-    n = 70000  # > LDS capacity for the sort buffer (2^17 * 4 B)
-    rois = [dict(x=np.arange(n) % 300, y=np.arange(n) // 300, inten=np.arange(n) % 1000 + 1)]
-    with pytest.raises(_lib.NyxHipError) as ei:
-        hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK, _abi.default_settings(8))
-    assert ei.value.code == 5
+def _large_rois(seed=5):
+    rng = np.random.default_rng(seed)
+    rois = synth.random_rois(12, seed=seed)
+    n = 70000  # > LDS capacity of the sort buffer (2^17 * 4 B): served from the global workspace
+    rois.insert(3, dict(x=np.arange(n) % 300, y=np.arange(n) // 300, inten=rng.integers(1, 1000, n)))
+    yy, xx = np.mgrid[0:420, 0:380]
+    keep = ((xx - 190.0) ** 2 / 190.0**2 + (yy - 210.0) ** 2 / 210.0**2) <= 1.0
+    keep &= rng.random(keep.shape) > 0.02  # pinholes -> zones and runs are interrupted
+    rois.append(dict(x=xx[keep], y=yy[keep], inten=rng.integers(0, 60000, int(keep.sum()))))
+    return rois
+
+
+@pytest.mark.parametrize("gd", [8, -20])
+def test_rois_beyond_lds_use_global_workspace(hip_ctx, gd):
+    """ROIs larger than the 160 KiB carve-out are re-run with their scratch in HBM; the small ROIs of the
+    same batch stay on the LDS path.  Same parity bar as everything else."""
+    rois = _large_rois()
+    s = _abi.default_settings(gd)
+    mask = _abi.FAM_ALL & ~_abi.FAM_GABOR
+    b = _abi.batch_from_rois(rois)
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
+
+
+def test_large_roi_gabor_is_exact(hip_ctx):
+    rois = _large_rois(seed=9)[2:5]
+    s = _abi.default_settings(8)
+    b = _abi.batch_from_rois(rois)
+    G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+    O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+    assert np.array_equal(G, O)
 
 
 def test_bad_family_mask_is_an_error(hip_ctx):
