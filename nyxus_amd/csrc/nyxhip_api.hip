@@ -888,6 +888,9 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
     const size_t o_ro = o; o = al(o + 8 * (rows_cap + 2));
     size_t o_r6[6]; for (int i = 0; i < 6; i++) { o_r6[i] = o; o = al(o + 4 * (rows_cap + 1)); }
     const size_t o_meta = o; o = al(o + 64);
+    const size_t n_blk = (nlab + 1023) / 1024;
+    const size_t o_br = o; o = al(o + 4 * n_blk);
+    const size_t o_bp = o; o = al(o + 8 * n_blk);
     const size_t o_smin = o; o = al(o + 8 * (rows_cap + 1));
     const size_t o_smax = o; o = al(o + 8 * (rows_cap + 1));
     const size_t o_lab = o; o = al(o + 4 * (rows_cap + 1));
@@ -916,16 +919,15 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
                (uint32_t*)(base + o_r6[2]), (uint32_t*)(base + o_r6[3]), (uint32_t*)(base + o_r6[4]), (uint32_t*)(base + o_r6[5])};
     uint32_t* d_meta = (uint32_t*)(base + o_meta);
     HIP_TRY(ctx, hipMemsetAsync(d_meta, 0, 64, st));
-    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, n_tiles, max_label, T, R, (uint32_t)rows_cap, d_meta, ctx->d_status, st);
+    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, n_tiles, max_label, T, R, (uint32_t)rows_cap, d_meta,
+                                       (uint32_t*)(base + o_br), (unsigned long long*)(base + o_bp), ctx->d_status, st);
     if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("tile scan launch failed: ") + hipGetErrorString((hipError_t)rc));
     uint32_t meta[8];
     HIP_TRY(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    {
-        int stt = 0;
-        HIP_TRY(ctx, hipMemcpy(&stt, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
-        if (stt) { int z = 0; HIP_TRY(ctx, hipMemcpy(ctx->d_status, &z, sizeof(int), hipMemcpyHostToDevice));
-                   return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the label tile holds a value above max_label"); }
+    if (meta[7]) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the label tile holds a value above max_label");
     }
     const uint64_t n_roi = meta[0];
     *n_roi_out = n_roi;
@@ -933,11 +935,10 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
     if (n_roi > rows_cap) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the tile (see *n_roi_out)");
     rc = launch_tile_clouds(d_inten, d_label, width, height, stride, R, (uint32_t)n_roi, (uint16_t*)(base + o_cx), (uint16_t*)(base + o_cy), (uint32_t*)(base + o_cv), st);
     if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-    // in-memory (montage) semantics: the prescan leaves slide min / max at +DBL_MAX / -DBL_MAX
-    // (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
-    std::vector<double> smin(n_roi, 1.7976931348623157e308), smax(n_roi, -1.7976931348623157e308);
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_smin, smin.data(), 8 * n_roi, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_smax, smax.data(), 8 * n_roi, hipMemcpyHostToDevice, st));
+    uint32_t* d_lab = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_lab) : out_labels;
+    uint32_t* d_til = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_til) : out_tile_index;
+    hipLaunchKernelGGL(tile_split_keys_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.label, stride, (uint32_t)n_roi,
+                       d_lab, (memory == NYXHIP_MEM_HOST || out_tile_index) ? d_til : nullptr, (double*)(base + o_smin), (double*)(base + o_smax));
     nyxhip_batch b;
     memset(&b, 0, sizeof(b));
     b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
@@ -949,10 +950,6 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
     const size_t d_ld = memory == NYXHIP_MEM_HOST ? (size_t)n_cols : out_ld;
     rc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
     if (rc) return rc;
-    uint32_t* d_lab = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_lab) : out_labels;
-    uint32_t* d_til = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_til) : out_tile_index;
-    hipLaunchKernelGGL(tile_split_keys_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.label, stride, (uint32_t)n_roi,
-                       d_lab, (memory == NYXHIP_MEM_HOST || out_tile_index) ? d_til : nullptr);
     if (memory == NYXHIP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpy2DAsync(out_table, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
                                       (size_t)n_cols * sizeof(double), n_roi, hipMemcpyDeviceToHost, st));

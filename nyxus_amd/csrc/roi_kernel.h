@@ -158,10 +158,12 @@ struct TileRows {        // each [max_rows] (+1 for px_offset), ascending label 
     uint32_t *bbox_x0, *bbox_y0, *bbox_w, *bbox_h, *vmin, *vmax;
 };
 int launch_tile_assembly_scan(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label,
-                              TileTables T, TileRows R, uint32_t max_rows, uint32_t* meta, int* status, void* stream);
+                              TileTables T, TileRows R, uint32_t max_rows, uint32_t* meta, uint32_t* blk_rows, unsigned long long* blk_px, int* status,
+                              void* stream);
 int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t stride, TileRows R, uint32_t n_roi,
                        uint16_t* cx, uint16_t* cy, uint32_t* cv, void* stream);
-__global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile);
+__global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile, double* slide_min,
+                                       double* slide_max);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
