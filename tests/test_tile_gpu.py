@@ -73,3 +73,18 @@ def test_stack_of_tiles_rows_ordered_by_tile_then_label(hip_ctx):
     assert tiles.tolist() == [0, 0, 1, 2, 2, 2] and labels.tolist() == [1, 2, 7, 1, 2, 3]
     want = np.concatenate([_oracle_tile(it[k], lab[k], mask, s)[1] for k in range(3)])
     assert not parity.compare_tables(T, want, _lib.column_names(mask, s))
+
+
+def test_label_confetti_overflows_the_block_table(hip_ctx):
+    """Thousands of distinct labels inside one 256 x 32 scan block: the LDS label table of the scan fills up
+    and the remaining runs go straight to the global tables.  Widths that are not a multiple of the block."""
+    rng = np.random.default_rng(21)
+    H, W = 70, 300
+    lab = rng.integers(0, 3000, (H, W)).astype(np.uint32)     # ~every pixel its own run, ~7 px per label
+    it = rng.integers(0, 4096, (H, W)).astype(np.uint32)
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_INTENSITY
+    labels, T = hip_ctx.featurize_tile_host(it, lab, mask, s)
+    wl, wt = _oracle_tile(it, lab, mask, s)
+    assert np.array_equal(labels, wl)
+    assert not parity.compare_tables(T, wt, _lib.column_names(mask, s))

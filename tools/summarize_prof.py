@@ -19,19 +19,21 @@ print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f, r in rows("trace/**/*kernel_stats.csv"):
     print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 
-print("== per-dispatch kernel trace: roi_features_kernel ==")
+print("== per-dispatch kernel trace: roi_features_kernel, metric workload only (largest grid) ==")
 d = []
 for f, r in rows("trace/**/*kernel_trace.csv"):
     if "roi_features" in r.get("Kernel_Name", ""):
-        d.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+        d.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), int(r.get("Grid_Size_X") or 0), r.get("Workgroup_Size_X")))
+metric_grid = max((x[4] for x in d), default=0)
+d = [x for x in d if x[4] == metric_grid]
 if d:
     ns = [x[0] for x in d]
-    print(f"dispatches {len(d)} avg {sum(ns)/len(ns)/1e6:.3f} ms min {min(ns)/1e6:.3f} max {max(ns)/1e6:.3f}  vgpr {d[0][1]} sgpr {d[0][2]} lds {d[0][3]} grid {d[0][4]} wg {d[0][5]}")
+    print(f"dispatches {len(d)} avg {sum(ns)/len(ns)/1e6:.3f} ms min {min(ns)/1e6:.3f} max {max(ns)/1e6:.3f}  vgpr {d[0][1]} sgpr {d[0][2]} lds {d[0][3]} grid_x {d[0][4]} wg_x {d[0][5]}")
 
 print("== PMC (per dispatch of roi_features_kernel, averaged) ==")
 acc = defaultdict(list)
 for f, r in rows("pmc_*/**/*counter_collection.csv"):
-    if "roi_features" in r.get("Kernel_Name", ""):
+    if "roi_features" in r.get("Kernel_Name", "") and int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0) >= metric_grid:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k}: n={len(v)} mean={sum(v)/len(v):.6g}")
