@@ -55,7 +55,12 @@ enum {
     NYXHIP_FAM_NGTDM     = 1u << 4, /* NGTDMFeature, 5 columns                 */
     NYXHIP_FAM_GABOR     = 1u << 5, /* GaborFeature, n_gabor_filters columns   */
     NYXHIP_FAM_ZERNIKE   = 1u << 6, /* ZernikeFeature, 30 columns              */
-    NYXHIP_FAM_ALL       = 0x7Fu
+    /* the remaining dependence / distance-zone texture families */
+    NYXHIP_FAM_GLDZM     = 1u << 7, /* GLDZMFeature, 18 columns (features/gldzm.h:18-38)  */
+    NYXHIP_FAM_GLDM      = 1u << 8, /* GLDMFeature, 14 columns  (features/gldm.h:30-46)   */
+    NYXHIP_FAM_NGLDM     = 1u << 9, /* NGLDMfeature, 19 columns (features/ngldm.h:17-38)  */
+    NYXHIP_FAM_NORTH_STAR = 0x7Fu,  /* the seven families of BASELINE.json's north_star */
+    NYXHIP_FAM_ALL       = 0x3FFu
 };
 
 #define NYXHIP_MAX_GLCM_ANGLES 4

@@ -23,7 +23,11 @@ FAM_GLSZM = 1 << 3
 FAM_NGTDM = 1 << 4
 FAM_GABOR = 1 << 5
 FAM_ZERNIKE = 1 << 6
-FAM_ALL = 0x7F
+FAM_GLDZM = 1 << 7
+FAM_GLDM = 1 << 8
+FAM_NGLDM = 1 << 9
+FAM_NORTH_STAR = 0x7F
+FAM_ALL = 0x3FF
 
 MEM_HOST = 0
 MEM_DEVICE = 1

@@ -42,6 +42,15 @@ void nyxo_gabor(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, ui
 void nyxo_zernike(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
                   const nyxhip_settings* s, double* out);
 
+/* features/gldm.cpp:16-255 -> out[14]; ngldm.cpp:40-340 -> out[19] (mask: 1 = pixel of the ROI cloud);
+ * gldzm.cpp:53-420 -> out[18] (roi_area = LR::aux_area) */
+void nyxo_gldm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+               const nyxhip_settings* s, double* out);
+void nyxo_ngldm(const uint32_t* im, const uint8_t* mask, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max,
+                const nyxhip_settings* s, double* out);
+void nyxo_gldzm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max, uint32_t roi_area,
+                const nyxhip_settings* s, double* out);
+
 int nyxo_n_columns(uint32_t mask, const nyxhip_settings* s);
 
 /* Host-memory batch, same argument meaning as nyxhip_featurize_batch. */

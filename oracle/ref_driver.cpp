@@ -30,6 +30,9 @@
 #include "features/glrlm.h"
 #include "features/glszm.h"
 #include "features/ngtdm.h"
+#include "features/gldzm.h"
+#include "features/gldm.h"
+#include "features/ngldm.h"
 #include "features/gabor.h"
 #include "features/zernike.h"
 
@@ -102,7 +105,10 @@ int nyxref_n_columns(uint32_t mask, const nyxhip_settings* s)
     if (mask & NYXHIP_FAM_INTENSITY) n += 36;
     if (mask & NYXHIP_FAM_GLCM) n += 30 * s->glcm_n_angles + 29;
     if (mask & NYXHIP_FAM_GLRLM) n += 16 * 4 + 16;
+    if (mask & NYXHIP_FAM_GLDZM) n += 18;
     if (mask & NYXHIP_FAM_GLSZM) n += 16;
+    if (mask & NYXHIP_FAM_GLDM) n += 14;
+    if (mask & NYXHIP_FAM_NGLDM) n += 19;
     if (mask & NYXHIP_FAM_NGTDM) n += 5;
     if (mask & NYXHIP_FAM_GABOR) n += s->gabor_n_filters;
     if (mask & NYXHIP_FAM_ZERNIKE) n += 30;
@@ -170,8 +176,14 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
             runParallel(GLCMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_GLRLM)
             runParallel(GLRLMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & NYXHIP_FAM_GLDZM)   // reduce_trivial_rois.cpp:215-220
+            runParallel(GLDZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_GLSZM)
             runParallel(GLSZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & NYXHIP_FAM_GLDM)    // :231-236
+            runParallel(GLDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & NYXHIP_FAM_NGLDM)   // :239-244
+            runParallel(NGLDMfeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_NGTDM)
             runParallel(NGTDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_GABOR)
@@ -201,8 +213,17 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
                 for (int f = (int)Feature2D::GLRLM_SRE_AVE; f <= (int)Feature2D::GLRLM_LRHGLE_AVE; f++)
                     *p++ = lr.fvals[f][0];
             }
+            if (mask & NYXHIP_FAM_GLDZM)
+                for (int f = (int)Feature2D::GLDZM_SDE; f <= (int)Feature2D::GLDZM_ZDE; f++)
+                    *p++ = lr.fvals[f][0];
             if (mask & NYXHIP_FAM_GLSZM)
                 for (int f = (int)Feature2D::GLSZM_SAE; f <= (int)Feature2D::GLSZM_LAHGLE; f++)
+                    *p++ = lr.fvals[f][0];
+            if (mask & NYXHIP_FAM_GLDM)
+                for (int f = (int)Feature2D::GLDM_SDE; f <= (int)Feature2D::GLDM_LDHGLE; f++)
+                    *p++ = lr.fvals[f][0];
+            if (mask & NYXHIP_FAM_NGLDM)
+                for (int f = (int)Feature2D::NGLDM_LDE; f <= (int)Feature2D::NGLDM_DCENE; f++)
                     *p++ = lr.fvals[f][0];
             if (mask & NYXHIP_FAM_NGTDM)
                 for (int f = (int)Feature2D::NGTDM_COARSENESS; f <= (int)Feature2D::NGTDM_STRENGTH; f++)

@@ -8,7 +8,7 @@ image arrays and `{"FEATURE", value}` pairs are parsed out of
   /root/reference/tests/test_dsb2018_data.h    4 DSB2018 ROIs
   /root/reference/tests/test_2d_firstorder_{matlab,regression,pyradiomics}.h
   /root/reference/tests/test_2d_glcm_{regression,ibsi}.h
-  /root/reference/tests/test_2d_{glrlm,glszm,ngtdm}_{regression,ibsi}.h
+  /root/reference/tests/test_2d_{glrlm,glszm,ngtdm,gldm,ngldm,gldzm}_{regression,ibsi,mirp}.h
   /root/reference/tests/test_gabor_truth.h, test_2d_zernike_regression.h
 
 Run in the build container only (the GPU box has no /root/reference):
@@ -62,6 +62,11 @@ def main():
     px = pixel_arrays(td)
     for k in ["pixelIntensityFeaturesTestData", "shape2d_morphology_intensity", "shape2d_morphology_mask"] + [f"ibsi_phantom_z{z}_{kind}" for z in range(1, 5) for kind in ("intensity", "mask")]:
         res["pixels"][k] = px[k]
+    # fixtures of the dependence / distance-zone families
+    for k in ["cat2500_int", "cat2500_seg", "ibsi_fig3_19_ngldm_sample_image_int", "ibsi_fig3_19_ngldm_sample_image_mask",
+              "nonibsi_rayryeng_ngldm_sample_image_int", "nonibsi_rayryeng_ngldm_sample_image_mask",
+              "ibsi_fig3_17a_gldzm_sample_image_int", "ibsi_fig3_17a_gldzm_sample_image_mask"]:
+        res["pixels"][k] = px[k]
 
     dsb = strip_comments(open(os.path.join(REF, "test_dsb2018_data.h")).read())
     rois = []
@@ -74,7 +79,9 @@ def main():
 
     for f in ["test_2d_firstorder_matlab.h", "test_2d_firstorder_regression.h", "test_2d_firstorder_pyradiomics.h",
               "test_2d_glcm_regression.h", "test_2d_glcm_ibsi.h", "test_2d_glrlm_regression.h", "test_2d_glrlm_ibsi.h",
-              "test_2d_glszm_regression.h", "test_2d_glszm_ibsi.h", "test_2d_ngtdm_regression.h", "test_2d_ngtdm_ibsi.h"]:
+              "test_2d_glszm_regression.h", "test_2d_glszm_ibsi.h", "test_2d_ngtdm_regression.h", "test_2d_ngtdm_ibsi.h",
+              "test_2d_gldm_regression.h", "test_2d_gldm_ibsi.h", "test_2d_ngldm_regression.h", "test_2d_ngldm_ibsi.h",
+              "test_2d_ngldm_mirp.h", "test_2d_gldzm_ibsi.h"]:
         p = os.path.join(REF, f)
         if not os.path.exists(p):
             continue

@@ -160,6 +160,64 @@ def test_ngtdm_goldens(gold, gd, ibsi):
         assert agrees_gt(got[k], v, 100.0), (gold, k, got[k], v)
 
 
+GLDM = ["GLDM_SDE", "GLDM_LDE", "GLDM_GLN", "GLDM_DN", "GLDM_DNN", "GLDM_GLV", "GLDM_DV", "GLDM_DE", "GLDM_LGLE", "GLDM_HGLE",
+        "GLDM_SDLGLE", "GLDM_SDHGLE", "GLDM_LDLGLE", "GLDM_LDHGLE"]
+NGLDM = ["NGLDM_LDE", "NGLDM_HDE", "NGLDM_LGLCE", "NGLDM_HGLCE", "NGLDM_LDLGLE", "NGLDM_LDHGLE", "NGLDM_HDLGLE", "NGLDM_HDHGLE",
+         "NGLDM_GLNU", "NGLDM_GLNUN", "NGLDM_DCNU", "NGLDM_DCNUN", "NGLDM_DCP", "NGLDM_GLM", "NGLDM_GLV", "NGLDM_DCM", "NGLDM_DCV",
+         "NGLDM_DCENT", "NGLDM_DCENE"]
+GLDZM = ["GLDZM_SDE", "GLDZM_LDE", "GLDZM_LGLZE", "GLDZM_HGLZE", "GLDZM_SDLGLE", "GLDZM_SDHGLE", "GLDZM_LDLGLE", "GLDZM_LDHGLE",
+         "GLDZM_GLNU", "GLDZM_GLNUN", "GLDZM_ZDNU", "GLDZM_ZDNUN", "GLDZM_ZP", "GLDZM_GLM", "GLDZM_GLV", "GLDZM_ZDM", "GLDZM_ZDV",
+         "GLDZM_ZDE"]
+
+
+def test_gldm_goldens():
+    """tests/test_2d_gldm_ibsi.h:15-119 (4 phantom slices averaged, IBSI mode, 1 % tier) and
+    tests/test_2d_gldm_regression.h:22-78 (cat2500 fixture, GREYDEPTH 128 matlab binning, 0.1 % tier)."""
+    got = _phantom_mean(_abi.FAM_GLDM, _abi.default_settings(128, True), GLDM, False)
+    for k, v in REF["goldens"]["gldm_2d_ibsi_ref_vals"].items():
+        assert agrees_gt(got[k], v, 100.0), (k, got[k], v)
+    b = _abi.batch_from_rois([fixtures.roi_from_triplets(REF["pixels"]["cat2500_int"], REF["pixels"]["cat2500_seg"])])
+    T = po.oracle_featurize(b, _abi.FAM_GLDM, _abi.default_settings(128, False))[0]
+    for k, v in REF["goldens"]["gldm_2d_regression_ref_vals"].items():
+        assert agrees_gt(T[GLDM.index(k)], v), (k, T[GLDM.index(k)], v)
+
+
+@pytest.mark.parametrize("gold,tol", [("ngldm_2d_ibsi_ref_vals", 100.0), ("ngldm_2d_mirp_ref_vals", 1e9), ("ngldm_2d_regression_ref_vals", 1e9)])
+def test_ngldm_goldens(gold, tol):
+    """tests/test_2d_ngldm_common.h:28-139 (4 phantom slices averaged, GREYDEPTH 128, IBSI mode) against the IBSI table
+    (test_2d_ngldm_ibsi.h:16-35, 1 %), the mirp 2.6.0 run (test_2d_ngldm_mirp.h:26-45, 1e-9) and Nyxus' own
+    GLM / DCM pins (test_2d_ngldm_regression.h:14-18, 1e-9)."""
+    got = _phantom_mean(_abi.FAM_NGLDM, _abi.default_settings(128, True), NGLDM, False)
+    for k, v in REF["goldens"][gold].items():
+        assert agrees_gt(got[k], v, tol), (gold, k, got[k], v)
+
+
+def test_gldzm_ibsi_goldens():
+    """tests/test_2d_gldzm_ibsi.h:14-183: 4 phantom slices averaged, IBSI mode; the reference's own band is 50 %
+    (agrees_gt(..., 2.)), the restatement sits inside it because it is bit-identical to the class (next test)."""
+    got = _phantom_mean(_abi.FAM_GLDZM, _abi.default_settings(128, True), GLDZM, False)
+    for k, v in REF["goldens"]["gldzm_2d_ibsi_ref_vals"].items():
+        assert agrees_gt(got[k], v, 2.0), (k, got[k], v)
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libnyxref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("gd,ibsi", [(8, False), (64, False), (-16, False), (20, True)])
+def test_dependence_families_match_reference_classes_bit_exact(gd, ibsi):
+    rois = synth.random_rois(50, seed=9)
+    if ibsi:
+        rois = [dict(r, inten=(np.asarray(r["inten"]) % 7).astype(np.uint32)) for r in rois]
+        rois = [r for r in rois if np.asarray(r["inten"]).max() > 0]
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd, ibsi)
+    # radiomics binning (gd < 0) makes the reference's GLDZM index one row past its matrix for level-0 zones
+    # (gldzm.cpp:44-50 with :103-106): undefined behaviour, left out of the comparison
+    mask = _abi.FAM_GLDM | _abi.FAM_NGLDM | (_abi.FAM_GLDZM if gd > 0 or ibsi else 0)
+    A = po.oracle_featurize(b, mask, s)
+    R = po.ref_featurize(b, mask, s, n_threads=2)
+    same = (A == R) | (np.isnan(A) & np.isnan(R))
+    assert same.all(), np.argwhere(~same)[:10]
+
+
 @pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libnyxref.so not built (needs /root/reference)")
 @pytest.mark.parametrize("gd,ibsi", [(8, False), (64, False), (-16, False), (20, True)])
 def test_texture_families_match_reference_classes_bit_exact(gd, ibsi):
