@@ -52,8 +52,14 @@ enum class Feature2D : int {
     GLRLM_SRE_AVE, GLRLM_LRE_AVE, GLRLM_GLN_AVE, GLRLM_GLNN_AVE, GLRLM_RLN_AVE, GLRLM_RLNN_AVE, GLRLM_RP_AVE,
     GLRLM_GLV_AVE, GLRLM_RV_AVE, GLRLM_RE_AVE, GLRLM_LGLRE_AVE, GLRLM_HGLRE_AVE, GLRLM_SRLGLE_AVE,
     GLRLM_SRHGLE_AVE, GLRLM_LRLGLE_AVE, GLRLM_LRHGLE_AVE,
+    GLDZM_SDE, GLDZM_LDE, GLDZM_LGLZE, GLDZM_HGLZE, GLDZM_SDLGLE, GLDZM_SDHGLE, GLDZM_LDLGLE, GLDZM_LDHGLE, GLDZM_GLNU,
+    GLDZM_GLNUN, GLDZM_ZDNU, GLDZM_ZDNUN, GLDZM_ZP, GLDZM_GLM, GLDZM_GLV, GLDZM_ZDM, GLDZM_ZDV, GLDZM_ZDE,
     GLSZM_SAE, GLSZM_LAE, GLSZM_GLN, GLSZM_GLNN, GLSZM_SZN, GLSZM_SZNN, GLSZM_ZP, GLSZM_GLV, GLSZM_ZV, GLSZM_ZE,
     GLSZM_LGLZE, GLSZM_HGLZE, GLSZM_SALGLE, GLSZM_SAHGLE, GLSZM_LALGLE, GLSZM_LAHGLE,
+    GLDM_SDE, GLDM_LDE, GLDM_GLN, GLDM_DN, GLDM_DNN, GLDM_GLV, GLDM_DV, GLDM_DE, GLDM_LGLE, GLDM_HGLE, GLDM_SDLGLE,
+    GLDM_SDHGLE, GLDM_LDLGLE, GLDM_LDHGLE,
+    NGLDM_LDE, NGLDM_HDE, NGLDM_LGLCE, NGLDM_HGLCE, NGLDM_LDLGLE, NGLDM_LDHGLE, NGLDM_HDLGLE, NGLDM_HDHGLE, NGLDM_GLNU,
+    NGLDM_GLNUN, NGLDM_DCNU, NGLDM_DCNUN, NGLDM_DCP, NGLDM_GLM, NGLDM_GLV, NGLDM_DCM, NGLDM_DCV, NGLDM_DCENT, NGLDM_DCENE,
     NGTDM_COARSENESS, NGTDM_CONTRAST, NGTDM_BUSYNESS, NGTDM_COMPLEXITY, NGTDM_STRENGTH,
     GABOR, ZERNIKE2D,
     _COUNT_
@@ -212,7 +218,10 @@ inline void reduce_range(uint32_t mask, size_t start, size_t end, std::vector<in
         if (mask & NYXHIP_FAM_INTENSITY) put(Feature2D::COV, Feature2D::UNIFORMITY_PIU, 1);
         if (mask & NYXHIP_FAM_GLCM) { put(Feature2D::GLCM_ASM, Feature2D::GLCM_VARIANCE, na); put(Feature2D::GLCM_ASM_AVE, Feature2D::GLCM_SUMVARIANCE_AVE, 1); }
         if (mask & NYXHIP_FAM_GLRLM) { put(Feature2D::GLRLM_SRE, Feature2D::GLRLM_LRHGLE, 4); put(Feature2D::GLRLM_SRE_AVE, Feature2D::GLRLM_LRHGLE_AVE, 1); }
+        if (mask & NYXHIP_FAM_GLDZM) put(Feature2D::GLDZM_SDE, Feature2D::GLDZM_ZDE, 1);
         if (mask & NYXHIP_FAM_GLSZM) put(Feature2D::GLSZM_SAE, Feature2D::GLSZM_LAHGLE, 1);
+        if (mask & NYXHIP_FAM_GLDM) put(Feature2D::GLDM_SDE, Feature2D::GLDM_LDHGLE, 1);
+        if (mask & NYXHIP_FAM_NGLDM) put(Feature2D::NGLDM_LDE, Feature2D::NGLDM_DCENE, 1);
         if (mask & NYXHIP_FAM_NGTDM) put(Feature2D::NGTDM_COARSENESS, Feature2D::NGTDM_STRENGTH, 1);
         if (mask & NYXHIP_FAM_GABOR) put(Feature2D::GABOR, Feature2D::GABOR, s.gabor_n_filters);
         if (mask & NYXHIP_FAM_ZERNIKE) put(Feature2D::ZERNIKE2D, Feature2D::ZERNIKE2D, 30);
@@ -269,7 +278,10 @@ protected:
 NYXHIP_FAMILY_CLASS(PixelIntensityFeatures, NYXHIP_FAM_INTENSITY, COV, UNIFORMITY_PIU)
 NYXHIP_FAMILY_CLASS(GLCMFeature, NYXHIP_FAM_GLCM, GLCM_ASM, GLCM_SUMVARIANCE_AVE)
 NYXHIP_FAMILY_CLASS(GLRLMFeature, NYXHIP_FAM_GLRLM, GLRLM_SRE, GLRLM_LRHGLE_AVE)
+NYXHIP_FAMILY_CLASS(GLDZMFeature, NYXHIP_FAM_GLDZM, GLDZM_SDE, GLDZM_ZDE)
 NYXHIP_FAMILY_CLASS(GLSZMFeature, NYXHIP_FAM_GLSZM, GLSZM_SAE, GLSZM_LAHGLE)
+NYXHIP_FAMILY_CLASS(GLDMFeature, NYXHIP_FAM_GLDM, GLDM_SDE, GLDM_LDHGLE)
+NYXHIP_FAMILY_CLASS(NGLDMfeature, NYXHIP_FAM_NGLDM, NGLDM_LDE, NGLDM_DCENE)
 NYXHIP_FAMILY_CLASS(NGTDMFeature, NYXHIP_FAM_NGTDM, NGTDM_COARSENESS, NGTDM_STRENGTH)
 NYXHIP_FAMILY_CLASS(GaborFeature, NYXHIP_FAM_GABOR, GABOR, GABOR)
 NYXHIP_FAMILY_CLASS(ZernikeFeature, NYXHIP_FAM_ZERNIKE, ZERNIKE2D, ZERNIKE2D)
@@ -291,7 +303,10 @@ inline void reduce_trivial_rois_manual(std::vector<int>& PendingRoisLabels, std:
     if (PixelIntensityFeatures::required(fs)) mask |= NYXHIP_FAM_INTENSITY;
     if (GLCMFeature::required(fs)) mask |= NYXHIP_FAM_GLCM;
     if (GLRLMFeature::required(fs)) mask |= NYXHIP_FAM_GLRLM;
+    if (GLDZMFeature::required(fs)) mask |= NYXHIP_FAM_GLDZM;   // reduce_trivial_rois.cpp:215-220
     if (GLSZMFeature::required(fs)) mask |= NYXHIP_FAM_GLSZM;
+    if (GLDMFeature::required(fs)) mask |= NYXHIP_FAM_GLDM;     // :231-236
+    if (NGLDMfeature::required(fs)) mask |= NYXHIP_FAM_NGLDM;   // :239-244
     if (NGTDMFeature::required(fs)) mask |= NYXHIP_FAM_NGTDM;
     if (GaborFeature::required(fs)) mask |= NYXHIP_FAM_GABOR;
     if (ZernikeFeature::required(fs)) mask |= NYXHIP_FAM_ZERNIKE;

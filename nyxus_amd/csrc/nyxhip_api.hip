@@ -97,13 +97,22 @@ const char* kGlrlmNames[16] = {"GLRLM_SRE", "GLRLM_LRE", "GLRLM_GLN", "GLRLM_GLN
 const char* kGlszmNames[16] = {"GLSZM_SAE", "GLSZM_LAE", "GLSZM_GLN", "GLSZM_GLNN", "GLSZM_SZN", "GLSZM_SZNN", "GLSZM_ZP",
                                "GLSZM_GLV", "GLSZM_ZV", "GLSZM_ZE", "GLSZM_LGLZE", "GLSZM_HGLZE", "GLSZM_SALGLE",
                                "GLSZM_SAHGLE", "GLSZM_LALGLE", "GLSZM_LAHGLE"};
+const char* kGldzmNames[18] = {"GLDZM_SDE", "GLDZM_LDE", "GLDZM_LGLZE", "GLDZM_HGLZE", "GLDZM_SDLGLE", "GLDZM_SDHGLE", "GLDZM_LDLGLE",
+                               "GLDZM_LDHGLE", "GLDZM_GLNU", "GLDZM_GLNUN", "GLDZM_ZDNU", "GLDZM_ZDNUN", "GLDZM_ZP", "GLDZM_GLM",
+                               "GLDZM_GLV", "GLDZM_ZDM", "GLDZM_ZDV", "GLDZM_ZDE"};
+const char* kGldmNames[14] = {"GLDM_SDE", "GLDM_LDE", "GLDM_GLN", "GLDM_DN", "GLDM_DNN", "GLDM_GLV", "GLDM_DV", "GLDM_DE", "GLDM_LGLE",
+                              "GLDM_HGLE", "GLDM_SDLGLE", "GLDM_SDHGLE", "GLDM_LDLGLE", "GLDM_LDHGLE"};
+const char* kNgldmNames[19] = {"NGLDM_LDE", "NGLDM_HDE", "NGLDM_LGLCE", "NGLDM_HGLCE", "NGLDM_LDLGLE", "NGLDM_LDHGLE", "NGLDM_HDLGLE",
+                               "NGLDM_HDHGLE", "NGLDM_GLNU", "NGLDM_GLNUN", "NGLDM_DCNU", "NGLDM_DCNUN", "NGLDM_DCP", "NGLDM_GLM",
+                               "NGLDM_GLV", "NGLDM_DCM", "NGLDM_DCV", "NGLDM_DCENT", "NGLDM_DCENE"};
 const char* kNgtdmNames[5] = {"NGTDM_COARSENESS", "NGTDM_CONTRAST", "NGTDM_BUSYNESS", "NGTDM_COMPLEXITY", "NGTDM_STRENGTH"};
 const int kGlrlmAngles[4] = {0, 45, 90, 135}; // GLRLMFeature::rotAngles, glrlm.h:134
 
 // families the kernels cover so far
 constexpr uint32_t kTexture = NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM | NYXHIP_FAM_NGTDM;
 constexpr uint32_t kShape = NYXHIP_FAM_GABOR | NYXHIP_FAM_ZERNIKE;
-constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture | kShape;
+constexpr uint32_t kDependence = NYXHIP_FAM_GLDZM | NYXHIP_FAM_GLDM | NYXHIP_FAM_NGLDM;
+constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture | kShape | kDependence;
 
 bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
 {
@@ -118,6 +127,17 @@ bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
             if (a != 0 && a != 45 && a != 90 && a != 135) { why = "unsupported GLCM angle (glcm.cpp:252-254)"; return false; }
         }
         if (s->glcm_offset < 0) { why = "glcm_offset must be >= 0"; return false; }
+    }
+    if ((mask & NYXHIP_FAM_NGLDM) && !s->ibsi && s->grey_depth < 0) {
+        // ngldm.cpp:201 passes GREYDEPTH as unsigned: a negative depth becomes ~4.29e9 levels (one per intensity)
+        why = "NGLDM with a negative (radiomics) grey depth is not supported";
+        return false;
+    }
+    if ((mask & NYXHIP_FAM_GLDZM) && !s->ibsi && s->grey_depth < 0) {
+        // radiomics binning leaves level-0 background zones: the reference writes them one row past its matrix
+        // (gldzm.cpp:44-50) and its distances depend on the flood order (zeros turn VISITED, :111-116) -- undefined there
+        why = "GLDZM with a negative (radiomics) grey depth is not supported (undefined in the reference)";
+        return false;
     }
     if (mask & NYXHIP_FAM_GABOR) {
         if (s->gabor_n_filters < 0 || s->gabor_n_filters > NYXHIP_MAX_GABOR_FILTERS) { why = "gabor_n_filters out of range"; return false; }
@@ -142,8 +162,14 @@ std::vector<std::string> column_names(uint32_t mask, const nyxhip_settings* s)
             for (int a : kGlrlmAngles) v.push_back(std::string(n) + "_" + std::to_string(a)); // output_2_buffer.cpp:351-361
         for (auto n : kGlrlmNames) v.push_back(std::string(n) + "_AVE");
     }
+    if (mask & NYXHIP_FAM_GLDZM)
+        for (auto n : kGldzmNames) v.push_back(n);
     if (mask & NYXHIP_FAM_GLSZM)
         for (auto n : kGlszmNames) v.push_back(n);
+    if (mask & NYXHIP_FAM_GLDM)
+        for (auto n : kGldmNames) v.push_back(n);
+    if (mask & NYXHIP_FAM_NGLDM)
+        for (auto n : kNgldmNames) v.push_back(n);
     if (mask & NYXHIP_FAM_NGTDM)
         for (auto n : kNgtdmNames) v.push_back(n);
     if (mask & NYXHIP_FAM_GABOR)
@@ -363,6 +389,39 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     return NYXHIP_OK;
 }
 
+// Carve-out of roi_dependence_kernel (GLDZM + GLDM + NGLDM).
+int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, uint32_t max_side, DepLayout& L, std::string& why, size_t cap = 0)
+{
+    memset(&L, 0, sizeof(L));
+    if (cap == 0) cap = roi_features_max_lds();
+    const int greyInfo = s->ibsi ? 0 : s->grey_depth;
+    uint32_t off = 0;
+    L.red = off; off = align16(off + 8u * kWaves * 8);
+    L.stat = off; off = align16(off + 8u * 16);
+    L.dense_cap = max_area ? max_area : 1;
+    L.side_cap = max_side ? max_side : 1;
+    if (4ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    L.dense = off; off = align16(off + 2u * L.dense_cap + 4);
+    L.aux = off; off = align16(off + 2u * L.dense_cap + 4);
+    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
+    if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the dependence kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    L.ng_cap = L.lvl_cap + 1;
+    L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
+    L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));
+    L.lvlmap2 = off; off = align16(off + 2u * (L.lvl_cap + 4));
+    L.lv2 = off; off = align16(off + 4u * (L.ng_cap + 4));
+    L.work = off;
+    L.nd_cap = L.side_cap / 2 + 2;
+    size_t need = (size_t)4 * 9 * (L.ng_cap + 1);                       // GLDM / NGLDM matrices
+    if (mask & NYXHIP_FAM_GLDZM)                                     // union-find parents + matrix
+        need = std::max<size_t>(need, 4ull * L.dense_cap + 4ull * (size_t)L.ng_cap * L.nd_cap + 64);
+    if (off + need > cap) { why = "ROI too large for the LDS-resident dependence / distance-zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    L.work_bytes = (uint32_t)need;
+    off = align16(off + (uint32_t)need);
+    L.total = off;
+    return NYXHIP_OK;
+}
+
 __global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
                                      const uint32_t* mn, const uint32_t* mx, uint32_t* out4)
 {
@@ -439,13 +498,18 @@ struct Extrema { uint32_t px, area, range, side; };
 
 // Fills the three argument blocks for one set of extrema; `cap` = 0 -> LDS carve-outs, else spill layouts.
 int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
-               const Extrema& E, size_t cap, RoiArgs& a, TexArgs& t, ShapeArgs& g, std::string& why)
+               const Extrema& E, size_t cap, RoiArgs& a, TexArgs& t, ShapeArgs& g, DepArgs& d, std::string& why)
 {
-    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape;
-    const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s);
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
+    const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s), n_cols4 = nyxhip_n_columns(mask4, s);
     memset(&a, 0, sizeof(a));
     memset(&t, 0, sizeof(t));
     memset(&g, 0, sizeof(g));
+    memset(&d, 0, sizeof(d));
+    // Feature2D order inside the row: INTENSITY, GLCM, GLRLM, GLDZM, GLSZM, GLDM, NGLDM, NGTDM, GABOR, ZERNIKE
+    int c_glrlm = n_cols1, c_gldzm = c_glrlm + ((mask & NYXHIP_FAM_GLRLM) ? kGlrlmCols : 0);
+    int c_glszm = c_gldzm + ((mask & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0), c_gldm = c_glszm + ((mask & NYXHIP_FAM_GLSZM) ? kGlszmCols : 0);
+    int c_ngldm = c_gldm + ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0);
     if (mask1) {
         if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap))
             return lrc;
@@ -474,7 +538,20 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         t.bbox_w = b->bbox_w; t.bbox_h = b->bbox_h; t.min_inten = b->min_inten; t.max_inten = b->max_inten;
         t.out = d_out; t.ld = ld; t.status = ctx->d_status;
         t.mask = mask2; t.n_cols = n_cols2; t.col0 = n_cols1;
+        t.gap_after_glrlm = (mask & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0;
+        t.gap_after_glszm = ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0) + ((mask & NYXHIP_FAM_NGLDM) ? kNgldmCols : 0);
         t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
+    }
+    if (mask4) {
+        if (int lrc = make_dep_layout(mask4, s, E.area, E.side, d.L, why, cap))
+            return lrc;
+        d.n_roi = b->n_roi;
+        d.px_offset = b->px_offset; d.x = b->x; d.y = b->y; d.inten = b->inten;
+        d.bbox_w = b->bbox_w; d.bbox_h = b->bbox_h; d.min_inten = b->min_inten; d.max_inten = b->max_inten;
+        d.out = d_out; d.ld = ld; d.status = ctx->d_status;
+        d.mask = mask4;
+        d.col_gldzm = c_gldzm; d.col_gldm = c_gldm; d.col_ngldm = c_ngldm;
+        d.soft_nan = s->soft_nan; d.grey_depth = s->grey_depth; d.ibsi = s->ibsi;
     }
     if (mask3) {
         if (int lrc = make_shape_layout(mask3, s, E.area, g.L, why, cap))
@@ -484,7 +561,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.bbox_w = b->bbox_w; g.bbox_h = b->bbox_h; g.min_inten = b->min_inten; g.max_inten = b->max_inten;
         g.out = d_out; g.ld = ld; g.status = ctx->d_status;
         g.mask = mask3;
-        g.col_gabor = n_cols1 + n_cols2;
+        g.col_gabor = n_cols1 + n_cols2 + n_cols4;
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= 512 && E.area <= 1024) ? 1 : 0;
@@ -501,13 +578,13 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
                   size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
 {
     std::string why;
-    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape;
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
     if (mask3 & NYXHIP_FAM_GABOR)
         if (int brc = ensure_gabor_bank(ctx, s))
             return brc;
     const Extrema full{max_px, max_area, max_range, max_side};
-    RoiArgs a; TexArgs t; ShapeArgs g;
-    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, why);
+    RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
+    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why);
     bool need_spill = false;
     Extrema capE = full;
     if (lrc == NYXHIP_ERR_UNSUPPORTED)
@@ -519,12 +596,12 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         capE.area = std::min<uint32_t>(max_area, 16384);
         capE.side = std::min<uint32_t>(max_side, 256);
         for (int tries = 0; tries < 8; tries++) {
-            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, why);
+            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, d, why);
             if (lrc != NYXHIP_ERR_ROI_TOO_LARGE) break;
             capE.px = std::max<uint32_t>(capE.px / 2, 64); capE.area = std::max<uint32_t>(capE.area / 2, 64); capE.side = std::max<uint32_t>(capE.side / 2, 8);
         }
         if (lrc) return fail(ctx, lrc, why);
-        a.sp.defer_large = t.sp.defer_large = g.sp.defer_large = 1;
+        a.sp.defer_large = t.sp.defer_large = g.sp.defer_large = d.sp.defer_large = 1;
         g.small_rois = 0;                          // the one-wave shape kernels are sized for uniformly small batches
     } else if (lrc)
         return fail(ctx, lrc, why);
@@ -547,6 +624,8 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     int rc = mask1 ? launch_roi_features(a, st, grid) : 0;
     if (rc == 0 && mask2)
         rc = launch_roi_texture(t, st, grid);
+    if (rc == 0 && mask4)
+        rc = launch_roi_dependence(d, st, grid);
     if (rc == 0 && mask3)
         rc = launch_roi_shape(g, st, grid);
     if (rc != 0)
@@ -573,13 +652,14 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (n_large == 0)
         return NYXHIP_OK;
-    RoiArgs a2; TexArgs t2; ShapeArgs g2;
-    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, why);
+    RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
+    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, d2, why);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
     size_t stride = 0;
     if (mask1) stride = std::max<size_t>(stride, a2.L.total);
     if (mask2) stride = std::max<size_t>(stride, t2.L.total);
     if (mask3 & NYXHIP_FAM_GABOR) stride = std::max<size_t>(stride, g2.L.total);
+    if (mask4) stride = std::max<size_t>(stride, d2.L.total);
     stride = (stride + 255) & ~(size_t)255;
     const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
     uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, budget / std::max<size_t>(stride, 1)));
@@ -591,11 +671,12 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     }
     for (uint32_t o = 0; o < n_large; o += chunk) {
         const uint32_t nb = std::min(chunk, n_large - o);
-        a2.sp.roi_index = t2.sp.roi_index = g2.sp.roi_index = d_list + o;
-        a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = ctx->d_spill;
-        a2.sp.stride = t2.sp.stride = g2.sp.stride = stride;
+        a2.sp.roi_index = t2.sp.roi_index = g2.sp.roi_index = d2.sp.roi_index = d_list + o;
+        a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
+        a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
         rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
         if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
+        if (rc == 0 && mask4) rc = launch_roi_dependence(d2, st, nb);
         if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
@@ -717,7 +798,10 @@ int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s)
     if (family_mask & NYXHIP_FAM_INTENSITY) n += kIntensityCols;
     if (family_mask & NYXHIP_FAM_GLCM) n += kGlcmAngled * s->glcm_n_angles + kGlcmAve;
     if (family_mask & NYXHIP_FAM_GLRLM) n += kGlrlmCols;
+    if (family_mask & NYXHIP_FAM_GLDZM) n += kGldzmCols;
     if (family_mask & NYXHIP_FAM_GLSZM) n += kGlszmCols;
+    if (family_mask & NYXHIP_FAM_GLDM) n += kGldmCols;
+    if (family_mask & NYXHIP_FAM_NGLDM) n += kNgldmCols;
     if (family_mask & NYXHIP_FAM_NGTDM) n += kNgtdmCols;
     if (family_mask & NYXHIP_FAM_GABOR) n += s->gabor_n_filters;
     if (family_mask & NYXHIP_FAM_ZERNIKE) n += kZernikeCols;

@@ -1,0 +1,513 @@
+// roi_dependence.hip -- GLDZM + GLDM + NGLDM for a batch of ROIs, one 256-thread workgroup
+// per ROI, all state in LDS (or in the global workspace for ROIs beyond the LDS carve-out, GS = true).
+//
+//   GLDZM  /root/reference/src/nyx/features/gldzm.cpp:53-236 (matrix kit), :238-285 (dist2border), :300-420 (features)
+//          zones = 4-connected sets of equal binned level (the reference floods E,S,W,N with a parent stack: the full
+//          component); zone metric = min over members of the 1-based distance to the nearest zero / bbox margin along
+//          the row and the column.  Here: distances in closed form for the margins + an outward probe for zeros,
+//          components by union-find in LDS (atomicMin), zone metric by atomicMin at the root, matrix by atomics.
+//   GLDM   features/gldm.cpp:16-255: per pixel with ORIGINAL intensity != 0, dependence = 1 + # of 8-neighbours that
+//          are ROI pixels (original != 0) of the same binned level; P[level][dependence]; 14 features :300-560.
+//   NGLDM  features/ngldm.cpp:40-225: levels = to_grayscale(v, 0, max, GREYDEPTH) on the CLOUD (mask = cloud
+//          membership, zero intensities included); P[level][# matching neighbours]; 19 features :246-340.
+//
+// Binned plane as in roi_texture.hip (bin_intensities: matlab binning sends background to level 1).
+// Matrix sums are formed lane-strided by one wave and combined in a fixed order (deterministic); the reference's
+// serial sums differ from these at the 1e-15 level.
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+namespace {
+
+constexpr int kBlk = 256;
+
+__device__ __forceinline__ double plog_dep(double p)   // p * fast_log10(p + EPS) / LOG10_2, gldm.cpp:440-452 (see device_math.h plogp)
+{
+    return p * (double)fast_log2f(p + 2.2e-16);
+}
+
+constexpr uint16_t kInCloud = 0x4000, kOrigNZ = 0x8000, kLvlMask = 0x0FFF;
+
+} // namespace
+
+template <bool GS>
+__global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    double* s_red = (double*)(lds + A.L.red);
+    double* s_stat = (double*)(lds + A.L.stat);
+    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
+    uint16_t* s_aux = (uint16_t*)(lds + A.L.aux);
+    uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);    // binned level -> row + 1   (GLDM, GLDZM)
+    uint32_t* s_lv = (uint32_t*)(lds + A.L.lv);            // row -> level
+    uint16_t* s_lvlmap2 = (uint16_t*)(lds + A.L.lvlmap2);  // NGLDM level -> row + 1
+    uint32_t* s_lv2 = (uint32_t*)(lds + A.L.lv2);
+    unsigned char* s_work = lds + A.L.work;
+
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t area = w * h;
+    const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
+    double* const row_out = A.out + roi * A.ld;
+    const bool do_dzm = (A.mask & NYXHIP_FAM_GLDZM) != 0, do_dm = (A.mask & NYXHIP_FAM_GLDM) != 0, do_ng = (A.mask & NYXHIP_FAM_NGLDM) != 0;
+    const uint32_t side = w > h ? w : h;
+    auto fill_all = [&](double v) {
+        if (do_dzm) for (int c = tid; c < kGldzmCols; c += kBlk) row_out[A.col_gldzm + c] = v;
+        if (do_dm) for (int c = tid; c < kGldmCols; c += kBlk) row_out[A.col_gldm + c] = v;
+        if (do_ng) for (int c = tid; c < kNgldmCols; c += kBlk) row_out[A.col_ngldm + c] = v;
+    };
+    if (n == 0 || area > A.L.dense_cap || side > A.L.side_cap) {
+        if (n != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
+        if (tid == 0 && n != 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        fill_all(__longlong_as_double(0x7ff8000000000000LL));
+        return;
+    }
+    if (vmin == vmax) {                               // blank ROI: gldzm.cpp:199-221, gldm.cpp:20-38, ngldm.cpp:152-174
+        fill_all(A.soft_nan);
+        return;
+    }
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
+    const uint32_t Lcap = A.L.lvl_cap;
+
+    // ---- phase 0: planes ------------------------------------------------------------------------------------
+    {
+        const uint32_t bg = greyInfo > 0 ? 0x00010001u : 0u;   // matlab binning: background -> level 1 (texture_feature.h:150-154)
+        uint32_t* d32 = (uint32_t*)s_dense;
+        uint32_t* a32 = (uint32_t*)s_aux;
+        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlk) { d32[i] = bg; a32[i] = 0; }
+        for (uint32_t i = tid; i <= Lcap + 1; i += kBlk) { s_lvlmap[i] = 0; s_lvlmap2[i] = 0; }
+    }
+    blk_sync<GS>();
+    uint32_t lvl_over = 0;
+    for (uint32_t i = tid; i < n; i += kBlk) {
+        const uint32_t v = A.inten[off + i];
+        const uint32_t px = A.x[off + i], py = A.y[off + i];
+        uint32_t lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+        // NGLDM level: to_grayscale (p, 0, max, GREYDEPTH, ibsi), ngldm.cpp:44-47 / :118-121 (helpers.h:337-345)
+        uint32_t nl = A.ibsi ? v : to_grayscale(v, 0u, vmax, (uint32_t)A.grey_depth);
+        if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
+        if (nl > Lcap || nl > kLvlMask) { if (do_ng) lvl_over = 1; nl = 0; }
+        if (px < w && py < h) {
+            s_dense[py * w + px] = (uint16_t)lvl;
+            s_aux[py * w + px] = (uint16_t)(kInCloud | (v != 0 ? kOrigNZ : 0) | nl);
+            s_lvlmap2[nl] = 1;
+        }
+    }
+    lvl_over = wave_max_u32(lvl_over);
+    if (lane == 0) s_red[wave * 8] = (double)lvl_over;
+    blk_sync<GS>();
+    {
+        bool over = false;
+        for (int wv = 0; wv < kBlk / 64; wv++) over |= s_red[wv * 8] != 0;
+        if (over) {                                   // level beyond the resident capacity
+            if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
+            fill_all(__longlong_as_double(0x7ff8000000000000LL));
+            return;
+        }
+    }
+    for (uint32_t p = tid; p < area; p += kBlk) {
+        const uint32_t l = s_dense[p];
+        if (l) s_lvlmap[l] = 1;
+    }
+    blk_sync<GS>();
+    // sorted unique levels.  GLDM / GLDZM: non-zero levels of the whole plane, 1..max in IBSI mode (gldm.cpp:54-68,
+    // gldzm.cpp:73-87); NGLDM: levels of the cloud, zero included (ngldm.cpp:40-53)
+    if (tid == 0) {
+        int k = 0;
+        uint32_t mx = 0;
+        for (uint32_t l = 1; l <= Lcap; l++)
+            if (s_lvlmap[l]) {
+                mx = l;
+                if (greyInfo != 0) { s_lvlmap[l] = (uint16_t)(k + 1); s_lv[k] = l; }
+                k++;
+            }
+        if (greyInfo == 0)
+            for (uint32_t l = 1; l <= mx; l++) { s_lvlmap[l] = (uint16_t)l; s_lv[l - 1] = l; }
+        s_stat[0] = (double)(greyInfo == 0 ? (int)mx : k);
+    }
+    if (tid == 64) {
+        int k = 0;
+        for (uint32_t l = 0; l <= Lcap && l <= kLvlMask; l++)
+            if (s_lvlmap2[l]) { s_lvlmap2[l] = (uint16_t)(k + 1); s_lv2[k] = l; k++; }
+        s_stat[1] = (double)k;
+    }
+    blk_sync<GS>();
+    const int Ng = (int)s_stat[0];
+    const int Ng2 = (int)s_stat[1];
+
+    // =====================================================================================================
+    // GLDZM
+    // =====================================================================================================
+    if (do_dzm) {
+        double* o = row_out + A.col_gldzm;
+        uint32_t* s_label = (uint32_t*)s_work;                       // [area]   union-find parents, then the zone metric at the roots
+        uint32_t* s_P = s_label + A.L.dense_cap;                     // [Ng * ndmax]
+        const uint32_t ndmax = ((w < h ? w : h) + 1) / 2 + 1;
+        constexpr uint32_t kNone = 0xFFFFFFFFu, kRootTag = 0xC0000000u;
+        // distance of a pixel = min over the four axis directions of (steps to the nearest zero or to the bbox margin) + 1
+        // (dist2border :238-285); a pixel on the margin gets 1.  Closed form for the margins, outward probe for zeros
+        // (only the IBSI plane holds zeros: matlab binning has none, radiomics binning is refused by the host).
+        auto dist_of = [=](uint32_t p) {
+            const uint32_t y = p / w, x = p - y * w;
+            uint32_t best = x + 1;
+            best = w - x < best ? w - x : best;
+            best = y + 1 < best ? y + 1 : best;
+            best = h - y < best ? h - y : best;
+            if (greyInfo == 0)
+                for (uint32_t k = 1; k + 1 < best; k++)
+                    if (s_dense[p - k] == 0 || s_dense[p + k] == 0 || s_dense[p - k * w] == 0 || s_dense[p + k * w] == 0) { best = k + 1; break; }
+            return best;
+        };
+        for (uint32_t i = tid; i < (uint32_t)Ng * ndmax; i += kBlk)
+            s_P[i] = 0;
+        // 4-connected components of equal level (zeros are not zone material in IBSI mode, gldzm.cpp:103-106).
+        // (1) horizontal runs: one wave per row, 64 pixels per step; a ballot of the run-start flags gives every lane the
+        //     start of its run (highest start bit at or below the lane), so a run is born with one parent: its first pixel.
+        for (uint32_t y = wave; y < h; y += kBlk / 64) {
+            uint32_t carry = 0;                                      // start (x) of the run that crosses into this chunk
+            for (uint32_t x0 = 0; x0 < w; x0 += 64) {
+                const uint32_t x = x0 + lane;
+                const bool in = x < w;
+                const uint32_t p = y * w + (in ? x : 0);
+                const uint16_t v = in ? s_dense[p] : (uint16_t)0;
+                const bool starts = in && (x == 0 || s_dense[p - 1] != v);
+                const unsigned long long m = __ballot(starts);
+                const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                const uint32_t start = below ? x0 + 63u - (uint32_t)__clzll((long long)below) : carry;
+                if (in) s_label[p] = (greyInfo > 0 || v != 0) ? y * w + start : kNone;
+                carry = m ? x0 + 63u - (uint32_t)__clzll((long long)m) : carry;
+            }
+        }
+        blk_sync<GS>();
+        // (2) vertical adjacencies: union-find in place (larger root under the smaller, atomicMin).  A pixel merges with its
+        //     north neighbour unless the pair to its west already joined the same two runs.
+        auto find = [=](uint32_t v) { for (uint32_t l = s_label[v]; l != v; l = s_label[v]) v = l; return v; };
+        auto unite = [=](uint32_t a, uint32_t b) {
+            for (;;) {
+                a = find(a); b = find(b);
+                if (a == b) return;
+                if (a < b) { const uint32_t t = a; a = b; b = t; }      // a > b: hang a under b
+                const uint32_t old = atomicMin(&s_label[a], b);
+                if (old == a) return;                                   // a was still a root: merged
+                a = old;                                                // somebody re-parented a first: retry from there
+            }
+        };
+        for (uint32_t p = w + tid; p < area; p += kBlk) {
+            if (s_label[p] == kNone) continue;
+            const uint16_t v = s_dense[p];
+            if (s_dense[p - w] != v) continue;
+            const uint32_t x = p % w;
+            if (x > 0 && s_dense[p - 1] == v && s_dense[p - w - 1] == v) continue;
+            unite(p, p - w);
+        }
+        blk_sync<GS>();
+        for (uint32_t p = tid; p < area; p += kBlk)
+            if (s_label[p] != kNone) {
+                const uint32_t r = find(p);
+                if (r != p) s_label[p] = r;                             // writes only shorten chains: concurrent finds stay valid
+            }
+        blk_sync<GS>();
+        // (3) zone metric = min distance over the members, kept in the root's own slot as kRootTag | (0xFFFF - d) under
+        //     atomicMax (a member reads its root from its own slot, which nobody else writes)
+        for (uint32_t p = tid; p < area; p += kBlk) {
+            const uint32_t l = s_label[p];
+            if (l == kNone) continue;
+            const uint32_t d = dist_of(p);
+            atomicMax(&s_label[l >= kRootTag ? p : l], kRootTag | (0xFFFFu - d));
+        }
+        blk_sync<GS>();
+        uint32_t nd_loc = 0;
+        for (uint32_t p = tid; p < area; p += kBlk) {
+            const uint32_t l = s_label[p];
+            if (l != kNone && l >= kRootTag) {
+                const uint32_t d = 0xFFFFu - (l & 0xFFFFu);
+                const uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
+                atomicAdd(&s_P[rowi * ndmax + (d - 1)], 1u);
+                nd_loc = d > nd_loc ? d : nd_loc;
+            }
+        }
+        nd_loc = wave_max_u32(nd_loc);
+        if (lane == 0) s_red[wave * 8] = (double)nd_loc;
+        blk_sync<GS>();
+        int Nd = 0;
+        for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
+        blk_sync<GS>();
+        // features (calc_features :323-420); every level of the LUT is non-zero here
+        if (wave == 0) {
+            double Ns = 0;
+            for (int e = lane; e < Ng * Nd; e += 64) { const int g = e / Nd, d = e - g * Nd; Ns += (double)s_P[g * ndmax + d]; }
+            Ns = wave_sum(Ns);
+            double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // SDLGLE SDHGLE LDLGLE LDHGLE GLM ZDM ZDE | Mx2 Md2 placeholders
+            for (int e = lane; e < Ng * Nd; e += 64) {
+                const int g = e / Nd, d = e - g * Nd;
+                const double p = (double)s_P[g * ndmax + d];
+                if (p == 0) continue;
+                const double g_ = (double)s_lv[g], d_ = (double)(d + 1);
+                a[0] += p / g_ / g_ / d_ / d_;
+                a[1] += g_ * g_ * p / d_ / d_;
+                a[2] += d_ * d_ * p / g_ / g_;
+                a[3] += g_ * g_ * d_ * d_ * p;
+                a[4] += g_ * p;
+                a[5] += d_ * p;
+                a[6] += p / Ns * log2(p / Ns + 2.2e-16);
+            }
+            double b[6] = {0, 0, 0, 0, 0, 0};             // SDE LDE ZDNU | LGLZE HGLZE GLNU
+            for (int d = lane; d < Nd; d += 64) {
+                double m = 0;
+                for (int g = 0; g < Ng; g++) m += (double)s_P[g * ndmax + d];
+                const double dd = (double)(d + 1);
+                b[0] += m / dd / dd; b[1] += dd * dd * m; b[2] += m * m;
+            }
+            for (int g = lane; g < Ng; g += 64) {
+                double x = 0;
+                for (int d = 0; d < Nd; d++) x += (double)s_P[g * ndmax + d];
+                const double g_ = (double)s_lv[g];
+                b[3] += x / (g_ * g_); b[4] += (g_ * g_) * x; b[5] += x * x;
+            }
+#pragma unroll
+            for (int k = 0; k < 7; k++) a[k] = wave_sum(a[k]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) b[k] = wave_sum(b[k]);
+            const double GLM = a[4] / Ns, ZDM = a[5] / Ns;
+            double glv = 0, zdv = 0;
+            for (int e = lane; e < Ng * Nd; e += 64) {
+                const int g = e / Nd, d = e - g * Nd;
+                const double p = (double)s_P[g * ndmax + d] / Ns;
+                double dif = (double)s_lv[g] - GLM;
+                glv += dif * dif * p;
+                dif = (double)(d + 1) - ZDM;
+                zdv += dif * dif * p;
+            }
+            glv = wave_sum(glv); zdv = wave_sum(zdv);
+            if (lane == 0) {
+                const double zdnu = b[2] / Ns, glnu = b[5] / Ns;
+                o[0] = b[0] / Ns; o[1] = b[1] / Ns; o[2] = b[3] / Ns; o[3] = b[4] / Ns;
+                o[4] = a[0] / Ns; o[5] = a[1] / Ns; o[6] = a[2] / Ns; o[7] = a[3] / Ns;
+                o[8] = glnu; o[9] = glnu / Ns; o[10] = zdnu; o[11] = zdnu / Ns;
+                o[12] = Ns / (double)n;                    // ZP = Ns / roi_area :399
+                o[13] = GLM; o[14] = glv; o[15] = ZDM; o[16] = zdv; o[17] = -a[6];
+            }
+        }
+        blk_sync<GS>();
+    }
+
+    // =====================================================================================================
+    // GLDM
+    // =====================================================================================================
+    if (do_dm) {
+        double* o = row_out + A.col_gldm;
+        uint32_t* s_P = (uint32_t*)s_work;                           // [Ng][9]
+        for (int i = tid; i < Ng * 9; i += kBlk) s_P[i] = 0;
+        blk_sync<GS>();
+        uint32_t nd_loc = 0;
+        for (uint32_t p = tid; p < area; p += kBlk) {
+            if (!(s_aux[p] & kOrigNZ)) continue;                     // skip by ORIGINAL intensity, gldm.cpp:83-84
+            const uint32_t pi = s_dense[p];
+            const int y = (int)(p / w), x = (int)(p - (uint32_t)y * w);
+            uint32_t nd = 1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int dy = k < 3 ? -1 : (k == 3 || k == 7) ? 0 : 1;
+                const int dx = (k == 0 || k == 6 || k == 7) ? -1 : (k == 1 || k == 5) ? 0 : 1;
+                const int yy = y + dy, xx = x + dx;
+                if (yy < 0 || xx < 0 || yy >= (int)h || xx >= (int)w) continue;
+                const uint32_t q = (uint32_t)yy * w + (uint32_t)xx;
+                nd += ((s_aux[q] & kOrigNZ) && s_dense[q] == pi) ? 1u : 0u;
+            }
+            const uint32_t rowi = greyInfo == 0 ? pi - 1 : (uint32_t)s_lvlmap[pi] - 1;
+            atomicAdd(&s_P[rowi * 9 + (nd - 1)], 1u);
+            nd_loc = nd > nd_loc ? nd : nd_loc;
+        }
+        nd_loc = wave_max_u32(nd_loc);
+        if (lane == 0) s_red[wave * 8] = (double)nd_loc;
+        blk_sync<GS>();
+        int Nd = 0;
+        for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
+        if (greyInfo == 0) Nd = 9;                                   // gldm.cpp:173,208-209
+        blk_sync<GS>();
+        if (wave == 0) {
+            unsigned long long nz = 0;
+            for (int e = lane; e < Ng * 9; e += 64) nz += s_P[e];
+            nz = wave_sum_u64(nz);
+            if (nz == 0) {
+                if (lane < kGldmCols) o[lane] = A.soft_nan;          // :216-234
+            } else {
+                const double Nz = (double)nz;
+                double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};           // SDE LDE mu_g mu_d DE SDLGLE SDHGLE LDLGLE LDHGLE
+                for (int e = lane; e < Ng * 9; e += 64) {
+                    const int i = e / 9, j = e - i * 9 + 1;
+                    const double c = (double)s_P[e];
+                    if (c == 0 || j > Nd) continue;
+                    const double inten = (double)s_lv[i], jj = (double)j;
+                    a[0] += c / (jj * jj);
+                    a[1] += c * (jj * jj);
+                    a[2] += c / Nz * inten;
+                    a[3] += c / Nz * jj;
+                    a[4] += plog_dep(c / Nz);
+                    a[5] += c / (inten * inten * jj * jj);
+                    a[6] += c * (inten * inten) / (double)(j * j);
+                    a[7] += c * (double)(j * j) / (inten * inten);
+                    a[8] += c * (inten * inten * jj * jj);
+                }
+                double b[4] = {0, 0, 0, 0};                          // GLN LGLE HGLE | DN
+                for (int i = lane; i < Ng; i += 64) {
+                    double si = 0;
+                    for (int j = 0; j < Nd; j++) si += (double)s_P[i * 9 + j];
+                    const double inten = (double)s_lv[i];
+                    b[0] += si * si; b[1] += si / (inten * inten); b[2] += si * inten * inten;
+                }
+                if (lane < Nd) {
+                    double sj = 0;
+                    for (int i = 0; i < Ng; i++) sj += (double)s_P[i * 9 + lane];
+                    b[3] = sj * sj;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) a[k] = wave_sum(a[k]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) b[k] = wave_sum(b[k]);
+                const double mu_g = a[2], mu_d = a[3];
+                double glv = 0, dv = 0;
+                for (int e = lane; e < Ng * 9; e += 64) {
+                    const int i = e / 9, j = e - i * 9 + 1;
+                    const double c = (double)s_P[e];
+                    if (c == 0 || j > Nd) continue;
+                    const double dg = (double)s_lv[i] - mu_g, dd = (double)j - mu_d;
+                    glv += c / Nz * (dg * dg);
+                    dv += c / Nz * (dd * dd);
+                }
+                glv = wave_sum(glv); dv = wave_sum(dv);
+                if (lane == 0) {
+                    o[0] = a[0] / Nz; o[1] = a[1] / Nz; o[2] = b[0] / Nz; o[3] = b[3] / Nz; o[4] = b[3] / (Nz * Nz);
+                    o[5] = glv; o[6] = dv; o[7] = -a[4]; o[8] = b[1] / Nz; o[9] = b[2] / Nz;
+                    o[10] = a[5] / Nz; o[11] = a[6] / Nz; o[12] = a[7] / Nz; o[13] = a[8] / Nz;
+                }
+            }
+        }
+        blk_sync<GS>();
+    }
+
+    // =====================================================================================================
+    // NGLDM
+    // =====================================================================================================
+    if (do_ng) {
+        double* o = row_out + A.col_ngldm;
+        uint32_t* s_M = (uint32_t*)s_work;                           // [Ng2][9]
+        for (int i = tid; i < Ng2 * 9; i += kBlk) s_M[i] = 0;
+        blk_sync<GS>();
+        uint32_t dep_loc = 0;
+        for (uint32_t p = tid; p < area; p += kBlk) {
+            const uint32_t ap = s_aux[p];
+            if (!(ap & kInCloud)) continue;
+            const uint32_t c = ap & kLvlMask;
+            const int y = (int)(p / w), x = (int)(p - (uint32_t)y * w);
+            uint32_t nm = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int dy = k < 3 ? -1 : (k == 3 || k == 7) ? 0 : 1;
+                const int dx = (k == 0 || k == 6 || k == 7) ? -1 : (k == 1 || k == 5) ? 0 : 1;
+                const int yy = y + dy, xx = x + dx;
+                if (yy < 0 || xx < 0 || yy >= (int)h || xx >= (int)w) continue;
+                const uint32_t aq = s_aux[(uint32_t)yy * w + (uint32_t)xx];
+                nm += ((aq & kInCloud) && (aq & kLvlMask) == c) ? 1u : 0u;
+            }
+            atomicAdd(&s_M[((uint32_t)s_lvlmap2[c] - 1) * 9 + nm], 1u);
+            dep_loc = nm > dep_loc ? nm : dep_loc;
+        }
+        dep_loc = wave_max_u32(dep_loc);
+        if (lane == 0) s_red[wave * 8] = (double)dep_loc;
+        blk_sync<GS>();
+        int Nr = 0;
+        for (int wv = 0; wv < kBlk / 64; wv++) Nr = (int)s_red[wv * 8] > Nr ? (int)s_red[wv * 8] : Nr;
+        Nr += 1;                                                     // ngldm.cpp:142
+        blk_sync<GS>();
+        if (wave == 0) {
+            double Ns = (double)n;                                   // every cloud pixel is counted once
+            double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // LDE HDE LGLCE HGLCE LDLGLE LDHGLE HDLGLE HDHGLE GLM DCM DCENT DCENE
+            for (int e = lane; e < Ng2 * 9; e += 64) {
+                const int i = e / 9, j = e - i * 9;
+                const double sij = (double)s_M[e];
+                if (sij == 0 || j >= Nr) continue;
+                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = sij / Ns;
+                a[0] += sij / dc / dc;
+                a[1] += sij * dc * dc;
+                if (gl != 0.0) {
+                    a[2] += sij / gl / gl;
+                    a[4] += sij / dc / dc / gl / gl;
+                    a[6] += sij * dc * dc / gl / gl;
+                }
+                a[3] += sij * gl * gl;
+                a[5] += sij * gl * gl / dc / dc;
+                a[7] += sij * dc * dc * gl * gl;
+                a[8] += gl * pij;
+                a[9] += dc * pij;
+                a[10] -= pij * log(pij) / log(2.0);
+                a[11] += pij * pij;
+            }
+            double b[2] = {0, 0};                                    // sum Sg^2, sum Sr^2
+            for (int i = lane; i < Ng2; i += 64) {
+                double sg = 0;
+                for (int j = 0; j < Nr; j++) sg += (double)s_M[i * 9 + j];
+                b[0] += sg * sg;
+            }
+            if (lane < Nr) {
+                double sr = 0;
+                for (int i = 0; i < Ng2; i++) sr += (double)s_M[i * 9 + lane];
+                b[1] = sr * sr;
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) a[k] = wave_sum(a[k]);
+            b[0] = wave_sum(b[0]); b[1] = wave_sum(b[1]);
+            const double GLM = a[8], DCM = a[9];
+            double glv = 0, dcv = 0;
+            for (int e = lane; e < Ng2 * 9; e += 64) {
+                const int i = e / 9, j = e - i * 9;
+                const double sij = (double)s_M[e];
+                if (sij == 0 || j >= Nr) continue;
+                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = sij / Ns;
+                glv += (gl - GLM) * (gl - GLM) * pij;
+                dcv += (dc - DCM) * (dc - DCM) * pij;
+            }
+            glv = wave_sum(glv); dcv = wave_sum(dcv);
+            if (lane == 0) {
+                o[0] = a[0] / Ns; o[1] = a[1] / Ns; o[2] = a[2] / Ns; o[3] = a[3] / Ns; o[4] = a[4] / Ns; o[5] = a[5] / Ns;
+                o[6] = a[6] / Ns; o[7] = a[7] / Ns; o[8] = b[0] / Ns; o[9] = b[0] / (Ns * Ns); o[10] = b[1] / Ns; o[11] = b[1] / (Ns * Ns);
+                o[12] = 1.0;                                         // DCP :339
+                o[13] = GLM; o[14] = glv; o[15] = DCM; o[16] = dcv; o[17] = a[10]; o[18] = a[11];
+            }
+        }
+    }
+}
+
+int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)roi_dependence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)roi_features_max_lds());
+        if (e != hipSuccess)
+            return (int)e;
+        attr_set = true;
+    }
+    if (grid == 0)
+        return 0;
+    if (a.sp.scratch)
+        hipLaunchKernelGGL(roi_dependence_kernel<true>, dim3(grid), dim3(kBlk), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_dependence_kernel<false>, dim3(grid), dim3(kBlk), a.L.total, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

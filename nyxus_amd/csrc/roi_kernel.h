@@ -106,10 +106,52 @@ struct TexArgs {
     uint32_t mask;        // subset of GLRLM | GLSZM | NGTDM
     int32_t n_cols;       // columns this kernel writes
     int32_t col0;         // first of them inside the output row
+    int32_t gap_after_glrlm;  // columns of other kernels' families that sit between this kernel's blocks in Feature2D
+    int32_t gap_after_glszm;  //   order: GLDZM after GLRLM; GLDM + NGLDM after GLSZM
     double soft_nan;
     int32_t grey_depth, ibsi;
     SpillArgs sp;
     TexLayout L;
+};
+
+// ---- GLDZM + GLDM + NGLDM (roi_dependence.hip) ---------------------------------------------
+constexpr int kGldzmCols = 18;            // Feature2D GLDZM_SDE..GLDZM_ZDE (featureset.h:271-288)
+constexpr int kGldmCols = 14;             // Feature2D GLDM_SDE..GLDM_LDHGLE (featureset.h:309-322)
+constexpr int kNgldmCols = 19;            // Feature2D NGLDM_LDE..NGLDM_DCENE (featureset.h:325-343)
+
+struct DepLayout {
+    uint32_t red;       // double[kWaves*8]
+    uint32_t stat;      // double[16]
+    uint32_t dense;     // uint16[dense_cap]   binned plane (background = level 1 under matlab binning)
+    uint32_t aux;       // uint16[dense_cap]   cloud membership | original != 0 | NGLDM level
+    uint32_t lvlmap;    // uint16[lvl_cap+2]   binned level -> row + 1
+    uint32_t lv;        // uint32[ng_cap+2]
+    uint32_t lvlmap2;   // uint16[lvl_cap+2]   NGLDM level -> row + 1
+    uint32_t lv2;       // uint32[ng_cap+2]
+    uint32_t work;      // per-family scratch, families run one after the other
+    uint32_t total;
+    uint32_t dense_cap, side_cap, lvl_cap, ng_cap, nd_cap, work_bytes;
+};
+
+struct DepArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;        // subset of GLDZM | GLDM | NGLDM
+    int32_t col_gldzm, col_gldm, col_ngldm;   // first column of each block inside the output row
+    double soft_nan;
+    int32_t grey_depth, ibsi;
+    SpillArgs sp;
+    DepLayout L;
 };
 
 // ---- third kernel pair: Gabor + Zernike (roi_shape.hip) -------------------------------------
@@ -169,6 +211,7 @@ __global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uin
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid);
 int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid);
+int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

@@ -160,6 +160,9 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     const uint32_t area = w * h;
     const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
     double* const out_row = A.out + roi * A.ld + A.col0;
+    // local column -> column inside the row: other kernels' families (GLDZM; GLDM, NGLDM) interleave in Feature2D order
+    const int end_rlm = (A.mask & NYXHIP_FAM_GLRLM) ? 80 : 0, end_szm = end_rlm + ((A.mask & NYXHIP_FAM_GLSZM) ? 16 : 0);
+    auto gcol = [=](int c) { return c + (c >= end_rlm ? A.gap_after_glrlm : 0) + (c >= end_szm ? A.gap_after_glszm : 0); };
     const bool do_rlm = (A.mask & NYXHIP_FAM_GLRLM) != 0, do_szm = (A.mask & NYXHIP_FAM_GLSZM) != 0,
                do_ngt = (A.mask & NYXHIP_FAM_NGTDM) != 0;
     const uint32_t side = w > h ? w : h;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         if (tid == 0 && n != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         for (int c = tid; c < A.n_cols; c += kBlock)
-            out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+            out_row[gcol(c)] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     if (over) { // IBSI level beyond the LDS-resident capacity
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
         for (int c = tid; c < A.n_cols; c += kBlock)
-            out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+            out_row[gcol(c)] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
     // levels present in the plane (background included)
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
 
     blk_sync<GS>();
     for (int c = tid; c < A.n_cols; c += kBlock)
-        out_row[c] = s_out[c];
+        out_row[gcol(c)] = s_out[c];
 }
 
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)

@@ -1,7 +1,7 @@
 """Feature names, groups and column selection for the families the HIP path covers.
 
 Names and order mirror the reference's `Feature2D` enum
-(/root/reference/src/nyx/featureset.h:12-46, 174-233, 236-268, 291-306, 346-357), its user-facing
+(/root/reference/src/nyx/featureset.h:12-46, 174-233, 236-268, 271-288, 291-306, 309-343, 346-357), its user-facing
 names (src/nyx/featureset.cpp `UserFacingFeatureNames`) and group tokens
 (`UserFacing2dFeaturegroupNames`, featureset.cpp:650-665).
 """
@@ -35,6 +35,14 @@ GLRLM_AVE = [n + "_AVE" for n in GLRLM_ANGLED]
 GLSZM = ["GLSZM_SAE", "GLSZM_LAE", "GLSZM_GLN", "GLSZM_GLNN", "GLSZM_SZN", "GLSZM_SZNN", "GLSZM_ZP", "GLSZM_GLV",
          "GLSZM_ZV", "GLSZM_ZE", "GLSZM_LGLZE", "GLSZM_HGLZE", "GLSZM_SALGLE", "GLSZM_SAHGLE", "GLSZM_LALGLE",
          "GLSZM_LAHGLE"]
+GLDZM = ["GLDZM_SDE", "GLDZM_LDE", "GLDZM_LGLZE", "GLDZM_HGLZE", "GLDZM_SDLGLE", "GLDZM_SDHGLE", "GLDZM_LDLGLE", "GLDZM_LDHGLE",
+         "GLDZM_GLNU", "GLDZM_GLNUN", "GLDZM_ZDNU", "GLDZM_ZDNUN", "GLDZM_ZP", "GLDZM_GLM", "GLDZM_GLV", "GLDZM_ZDM", "GLDZM_ZDV",
+         "GLDZM_ZDE"]
+GLDM = ["GLDM_SDE", "GLDM_LDE", "GLDM_GLN", "GLDM_DN", "GLDM_DNN", "GLDM_GLV", "GLDM_DV", "GLDM_DE", "GLDM_LGLE", "GLDM_HGLE",
+        "GLDM_SDLGLE", "GLDM_SDHGLE", "GLDM_LDLGLE", "GLDM_LDHGLE"]
+NGLDM = ["NGLDM_LDE", "NGLDM_HDE", "NGLDM_LGLCE", "NGLDM_HGLCE", "NGLDM_LDLGLE", "NGLDM_LDHGLE", "NGLDM_HDLGLE", "NGLDM_HDHGLE",
+         "NGLDM_GLNU", "NGLDM_GLNUN", "NGLDM_DCNU", "NGLDM_DCNUN", "NGLDM_DCP", "NGLDM_GLM", "NGLDM_GLV", "NGLDM_DCM", "NGLDM_DCV",
+         "NGLDM_DCENT", "NGLDM_DCENE"]
 NGTDM = ["NGTDM_COARSENESS", "NGTDM_CONTRAST", "NGTDM_BUSYNESS", "NGTDM_COMPLEXITY", "NGTDM_STRENGTH"]
 
 # feature name -> family bit
@@ -49,6 +57,12 @@ for _n in GLSZM:
     FAMILY_OF[_n] = _abi.FAM_GLSZM
 for _n in NGTDM:
     FAMILY_OF[_n] = _abi.FAM_NGTDM
+for _n in GLDZM:
+    FAMILY_OF[_n] = _abi.FAM_GLDZM
+for _n in GLDM:
+    FAMILY_OF[_n] = _abi.FAM_GLDM
+for _n in NGLDM:
+    FAMILY_OF[_n] = _abi.FAM_NGLDM
 FAMILY_OF["GABOR"] = _abi.FAM_GABOR
 FAMILY_OF["ZERNIKE2D"] = _abi.FAM_ZERNIKE
 
@@ -57,12 +71,15 @@ GROUPS: Dict[str, List[str]] = {
     "*ALL_INTENSITY*": INTENSITY,
     "*ALL_GLCM*": GLCM_ANGLED + GLCM_AVE,
     "*ALL_GLRLM*": GLRLM_ANGLED + GLRLM_AVE,
+    "*ALL_GLDZM*": GLDZM,
     "*ALL_GLSZM*": GLSZM,
+    "*ALL_GLDM*": GLDM,
+    "*ALL_NGLDM*": NGLDM,
     "*ALL_NGTDM*": NGTDM,
 }
 
 # enum order of every feature code the path covers (one entry per Feature2D code)
-ENUM_ORDER: List[str] = (INTENSITY + GLCM_ANGLED + GLCM_AVE + GLRLM_ANGLED + GLRLM_AVE + GLSZM + NGTDM
+ENUM_ORDER: List[str] = (INTENSITY + GLCM_ANGLED + GLCM_AVE + GLRLM_ANGLED + GLRLM_AVE + GLDZM + GLSZM + GLDM + NGLDM + NGTDM
                          + ["GABOR", "ZERNIKE2D"])
 
 
@@ -81,7 +98,7 @@ def expand(features: List[str]) -> Tuple[int, List[str]]:
     if unknown:
         raise ValueError(
             f"feature(s) {unknown} are not served by the MI355X path. Implemented: groups {sorted(GROUPS)} and the "
-            f"individual features of the intensity, GLCM, GLRLM, GLSZM and NGTDM families, GABOR, ZERNIKE2D")
+            f"individual features of the intensity, GLCM, GLRLM, GLDZM, GLSZM, GLDM, NGLDM and NGTDM families, GABOR, ZERNIKE2D")
     if not want:
         raise ValueError("no features requested")
     ordered = [n for n in ENUM_ORDER if n in want]

@@ -87,6 +87,36 @@ static void test_gabor_truth()
     }
 }
 
+template <class F>
+static void phantom_average_check(const std::vector<Golden>& gold, double frac_tol, const char* tag)
+{   // tests/test_2d_ngldm_common.h:47-139, test_2d_gldm_ibsi.h:34-119, test_2d_gldzm_ibsi.h:92-183: the four IBSI phantom
+    // slices featurised one at a time (GREYDEPTH 128, IBSI mode) and averaged
+    Fsettings s; s.resize((int)NyxSetting::__COUNT__);
+    s[(int)NyxSetting::SOFTNAN].rval = 0.0; s[(int)NyxSetting::GREYDEPTH].ival = 128; s[(int)NyxSetting::IBSI].bval = true;
+    s[(int)NyxSetting::GLCM_GREYDEPTH].ival = 128; s[(int)NyxSetting::GLCM_OFFSET].ival = 1;
+    const NyxusPixel* I[4] = {ibsi_phantom_z1_intensity, ibsi_phantom_z2_intensity, ibsi_phantom_z3_intensity, ibsi_phantom_z4_intensity};
+    const NyxusPixel* M[4] = {ibsi_phantom_z1_mask, ibsi_phantom_z2_mask, ibsi_phantom_z3_mask, ibsi_phantom_z4_mask};
+    std::vector<LR> rois(4);
+    for (int z = 0; z < 4; z++) {
+        load_masked_test_roi_data(rois[z], I[z], M[z], 20);
+        F f; f.calculate(rois[z], s); rois[z].initialize_fvals(); f.save_value(rois[z].fvals);
+    }
+    for (const Golden& g : gold) {
+        double total = 0;
+        for (int z = 0; z < 4; z++) total += rois[z].fvals[(int)g.f][0];
+        CHECK(agrees_gt(total / 4.0, g.v, frac_tol), "%s %s got %.17g want %.17g", tag, g.name, total / 4.0, g.v);
+    }
+}
+
+static void test_dependence_families()
+{
+    phantom_average_check<GLDMFeature>(gldm_2d_ibsi_ref_vals, 100., "GLDM/IBSI");
+    phantom_average_check<NGLDMfeature>(ngldm_2d_ibsi_ref_vals, 100., "NGLDM/IBSI");
+    phantom_average_check<NGLDMfeature>(ngldm_2d_mirp_ref_vals, 1e9, "NGLDM/mirp");          // test_2d_ngldm_mirp.h:50-58
+    phantom_average_check<NGLDMfeature>(ngldm_2d_regression_ref_vals, 1e9, "NGLDM/regression");
+    phantom_average_check<GLDZMFeature>(gldzm_2d_ibsi_ref_vals, 2., "GLDZM/IBSI");           // test_2d_gldzm_ibsi.h:183
+}
+
 static void test_reduce_trivial_rois_manual()
 {   // the boundary itself: labels + roiData + FeatureSet in, fvals filled for every required family in one call
     std::unordered_map<int, LR> roiData;
@@ -120,6 +150,7 @@ int main(int argc, char** argv)
         test_firstorder_matlab();
         test_glcm_regression();
         test_gabor_truth();
+        test_dependence_families();
         test_reduce_trivial_rois_manual();
     } catch (const std::exception& e) { std::printf("EXCEPTION: %s\n", e.what()); return 2; }
     std::printf(failures ? "FAILED %d checks\n" : "ALL PASSED\n", failures);

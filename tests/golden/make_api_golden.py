@@ -60,6 +60,11 @@ def main():
     cases["tile48_all_gd64"] = run(fam, {}, inten[:1], seg[:1])
     cases["tile48_ibsi"] = run(["*ALL_GLCM*", "*ALL_GLRLM*", "*ALL_NGTDM*"], {"ibsi": True}, (inten[:1] % 9 + 1).astype(np.uint32), seg[:1])
     cases["tile48_gabor8"] = run(["GABOR"], {"gabor_freqs": [4, 16, 32, 64, 4, 16, 32, 64], "gabor_thetas": [0, 22.5, 45, 67.5, 90, 112.5, 135, 157.5]}, inten[:1], seg[:1])
+    # (2b) the dependence / distance-zone families: matlab binning and the IBSI path
+    dep = ["*ALL_GLDZM*", "*ALL_GLDM*", "*ALL_NGLDM*"]
+    cases["tile48_dep_gd8"] = run(dep, {"coarse_gray_depth": 8}, inten, seg)
+    cases["tile48_dep_gd64_mixed"] = run(["*ALL_GLRLM*", "*ALL_GLSZM*", "*ALL_NGTDM*", "MEAN"] + dep, {}, inten[:1], seg[:1])
+    cases["tile48_dep_ibsi"] = run(dep, {"ibsi": True}, (inten[:1] % 9 + 1).astype(np.uint32), seg[:1])
     # (3) negative / float-valued input: shift-and-cast of nyxus.py:480-489
     ct = (rng.normal(0, 300, (1, 32, 32))).astype(np.float32)
     sg = np.zeros((1, 32, 32), np.uint32)

@@ -17,7 +17,8 @@ def _gen_fixture():
     for name in ["pixelIntensityFeaturesTestData"] + [f"ibsi_phantom_z{z}_{k}" for z in range(1, 5) for k in ("intensity", "mask")]:
         rows = ", ".join("{%d, %d, %d}" % tuple(t) for t in ref["pixels"][name])
         out.append(f"static const NyxusPixel {name}[] = {{{rows}}};")
-    for g in ("firstorder_2d_matlab_ref_vals", "glcm_2d_regression_ref_vals"):
+    for g in ("firstorder_2d_matlab_ref_vals", "glcm_2d_regression_ref_vals", "gldm_2d_ibsi_ref_vals", "ngldm_2d_ibsi_ref_vals",
+              "ngldm_2d_mirp_ref_vals", "ngldm_2d_regression_ref_vals", "gldzm_2d_ibsi_ref_vals"):
         rows = ", ".join('{Feature2D::%s, "%s", %r}' % (k, k, v) for k, v in ref["goldens"][g].items())
         out.append(f"static const std::vector<Golden> {g} = {{{rows}}};")
     rows = ", ".join("{%d, %d, {%s}}" % (d["w"], d["h"], ", ".join(map(str, d["pixels"]))) for d in ref["dsb2018"])

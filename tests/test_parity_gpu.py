@@ -184,6 +184,8 @@ def test_rois_beyond_lds_use_global_workspace(hip_ctx, gd):
     rois = _large_rois()
     s = _abi.default_settings(gd)
     mask = _abi.FAM_ALL & ~_abi.FAM_GABOR
+    if gd < 0:      # GLDZM / NGLDM refuse radiomics binning (undefined in the reference)
+        mask &= ~(_abi.FAM_GLDZM | _abi.FAM_NGLDM)
     b = _abi.batch_from_rois(rois)
     G = hip_ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
@@ -202,7 +204,7 @@ def test_large_roi_gabor_is_exact(hip_ctx):
 def test_bad_family_mask_is_an_error(hip_ctx):
     b = _abi.batch_from_rois(synth.random_rois(3))
     with pytest.raises(_lib.NyxHipError) as ei:
-        hip_ctx.featurize_host(b, 1 << 9, _abi.default_settings(8))
+        hip_ctx.featurize_host(b, 1 << 12, _abi.default_settings(8))
     assert ei.value.code == 1
 
 
@@ -250,5 +252,95 @@ def test_gabor_zernike_random_and_dsb_rois(hip_ctx):
 def test_all_seven_families_one_call(hip_ctx):
     b = synth.tile_batch(4, irregular=True, size=512)
     s = _bank8(_abi.default_settings(8))
-    G = _check(hip_ctx, b, _abi.FAM_ALL, s, against_ref=False)
+    G = _check(hip_ctx, b, _abi.FAM_NORTH_STAR, s, against_ref=False)
     assert G.shape[1] == 185 + 80 + 16 + 5 + 8 + 30
+
+
+# ---- GLDZM + GLDM + NGLDM (roi_dependence.hip) ------------------------------------------------------
+DEP = _abi.FAM_GLDZM | _abi.FAM_GLDM | _abi.FAM_NGLDM
+
+
+@pytest.mark.parametrize("gd,ibsi", [(8, False), (64, False), (20, True), (100, False)])
+def test_dependence_families_random_rois(hip_ctx, gd, ibsi):
+    rois = synth.random_rois(100, seed=23)
+    if ibsi:
+        rois = [dict(r, inten=(np.asarray(r["inten"]) % 9).astype(np.uint32)) for r in rois]
+    _check(hip_ctx, _abi.batch_from_rois(rois), DEP, _abi.default_settings(gd, ibsi))
+
+
+def test_dependence_radiomics_binning(hip_ctx):
+    """Negative grey depth: GLDM against oracle + reference classes; GLDZM (the reference indexes one row past its matrix
+    for level-0 zones, gldzm.cpp:44-50) and NGLDM (GREYDEPTH cast to unsigned, ngldm.cpp:201) are refused."""
+    b = _abi.batch_from_rois(synth.random_rois(60, seed=4))
+    s = _abi.default_settings(-16)
+    _check(hip_ctx, b, _abi.FAM_GLDM, s)
+    for fam in (_abi.FAM_NGLDM, _abi.FAM_GLDZM):
+        with pytest.raises(_lib.NyxHipError) as ei:
+            hip_ctx.featurize_host(b, fam, s)
+        assert ei.value.code == 1
+
+
+@pytest.mark.parametrize("fam", [_abi.FAM_GLDZM, _abi.FAM_GLDM, _abi.FAM_NGLDM])
+def test_dependence_single_family_and_column_interleave(hip_ctx, fam):
+    """Each family alone, and together with the texture kernel's families whose columns it sits between
+    (Feature2D order: GLRLM, GLDZM, GLSZM, GLDM, NGLDM, NGTDM)."""
+    b = _abi.batch_from_rois(synth.random_rois(40, seed=2))
+    s = _abi.default_settings(8)
+    _check(hip_ctx, b, fam, s)
+    G = _check(hip_ctx, b, fam | TEX | _abi.FAM_INTENSITY, s)
+    names = _lib.column_names(fam | TEX | _abi.FAM_INTENSITY, s)
+    order = [n.split("_")[0] for n in names if n.split("_")[0] in ("GLRLM", "GLDZM", "GLSZM", "GLDM", "NGLDM", "NGTDM")]
+    dedup = [k for i, k in enumerate(order) if i == 0 or order[i - 1] != k]
+    assert dedup == [k for k in ("GLRLM", "GLDZM", "GLSZM", "GLDM", "NGLDM", "NGTDM") if k in dedup]
+    assert G.shape[1] == len(names)
+
+
+def test_dependence_goldens_through_hip(hip_ctx):
+    """tests/test_2d_gldm_{ibsi,regression}.h, test_2d_ngldm_{ibsi,mirp,regression}.h, test_2d_gldzm_ibsi.h through HIP."""
+    ref = fixtures.reference_tests()
+    b = fixtures.ibsi_phantom_batch(ref)
+    s = _abi.default_settings(128, True)
+    for fam, gold, tol in [(_abi.FAM_GLDM, "gldm_2d_ibsi_ref_vals", 100.0), (_abi.FAM_NGLDM, "ngldm_2d_ibsi_ref_vals", 100.0),
+                           (_abi.FAM_NGLDM, "ngldm_2d_mirp_ref_vals", 1e9), (_abi.FAM_NGLDM, "ngldm_2d_regression_ref_vals", 1e9),
+                           (_abi.FAM_GLDZM, "gldzm_2d_ibsi_ref_vals", 2.0)]:
+        T = hip_ctx.featurize_host(b, fam, s)
+        names = _lib.column_names(fam, s)
+        for k, v in ref["goldens"][gold].items():
+            got = T[:, names.index(k)].sum() / 4.0
+            assert abs(got - v) <= abs(v / tol), (gold, k, got, v)
+    cat = _abi.batch_from_rois([fixtures.roi_from_triplets(ref["pixels"]["cat2500_int"], ref["pixels"]["cat2500_seg"])])
+    s = _abi.default_settings(128, False)
+    T = hip_ctx.featurize_host(cat, _abi.FAM_GLDM, s)[0]
+    names = _lib.column_names(_abi.FAM_GLDM, s)
+    for k, v in ref["goldens"]["gldm_2d_regression_ref_vals"].items():
+        assert abs(T[names.index(k)] - v) <= abs(v / 1000.0), (k, T[names.index(k)], v)
+
+
+def test_dependence_large_rois_and_serpentine_zone(hip_ctx):
+    """ROIs beyond the LDS carve-out (global workspace) and a spiral-shaped zone (worst case for label sweeps)."""
+    rois = _large_rois(seed=7)
+    n = 41
+    sp = np.zeros((n, n), np.uint32)       # square spiral: one long 4-connected corridor of level A in a field of level B
+    dy, dx = 0, 1
+    yy = xx = 0
+    for _ in range(n * n):
+        sp[yy, xx] = 1
+        ny, nx = yy + dy, xx + dx
+        ahead2y, ahead2x = yy + 2 * dy, xx + 2 * dx
+        if not (0 <= ny < n and 0 <= nx < n) or (0 <= ahead2y < n and 0 <= ahead2x < n and sp[ahead2y, ahead2x]):
+            dy, dx = dx, -dy
+            ny, nx = yy + dy, xx + dx
+            if not (0 <= ny < n and 0 <= nx < n) or sp[ny, nx] or (0 <= yy + 2 * dy < n and 0 <= xx + 2 * dx < n and sp[yy + 2 * dy, xx + 2 * dx]):
+                break
+        yy, xx = ny, nx
+    gy, gx = np.mgrid[0:n, 0:n]
+    rois.append(dict(x=gx.ravel(), y=gy.ravel(), inten=np.where(sp.ravel() > 0, 4000, 100).astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    _check(hip_ctx, b, DEP, _abi.default_settings(8), against_ref=False)
+
+
+def test_all_ten_families_one_call(hip_ctx):
+    b = synth.tile_batch(4, irregular=True, size=512)
+    s = _bank8(_abi.default_settings(8))
+    G = _check(hip_ctx, b, _abi.FAM_ALL, s, against_ref=False)
+    assert G.shape[1] == 185 + 80 + 18 + 16 + 14 + 19 + 5 + 8 + 30
