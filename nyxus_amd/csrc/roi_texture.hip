@@ -267,30 +267,77 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
             if (tid == 0 && Ng >= 1) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
             for (int c = tid; c < 80; c += kBlock) o[c] = Ng < 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
         } else {
-            const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
-            for (int a0 = 0; a0 < 4; a0 += per) {
+            if (nslot >= 4 && side <= 64) {
+                // All four angles at once.  One line of a direction per step, one lane per pixel of the line: the ballot of
+                // "equals the next pixel" turns every run into a string of set bits, so a run's first lane reads its length
+                // off the mask (no walking, no divergence on long runs).  The 2(w + h) + ... lines of the four directions are
+                // dealt round-robin to the four waves (the diagonals have twice the lines of the axes); the next line's
+                // pixels are fetched before the current line's atomics go out.
                 blk_sync<GS>();
-                for (uint32_t i = tid; i < (uint32_t)per * slot_words; i += kBlock) s_mat[i] = 0;
+                for (uint32_t i = tid; i < 4u * slot_words; i += kBlock) s_mat[i] = 0;
                 blk_sync<GS>();
-                if (wave < per && a0 + wave < 4) {
-                    const int ai = a0 + wave;
-                    uint32_t* P = s_mat + wave * slot_words;
-                    const int dx = ai == 2 ? 0 : ai == 3 ? -1 : 1, dy = ai == 0 ? 0 : 1; // glrlm.cpp:128-176
-                    for (uint32_t p = lane; p < area; p += 64) {
-                        uint32_t v = s_dense[p];
-                        if (v == 0) continue;
-                        int row = (int)(p / w), cl = (int)(p - (uint32_t)row * w);
-                        int pr = row - dy, pc = cl - dx;
-                        if (pr >= 0 && pc >= 0 && pc < (int)w && s_dense[(uint32_t)pr * w + pc] == v)
-                            continue;                        // not the first pixel of its run
-                        int len = 1, r2 = row + dy, c2 = cl + dx;
-                        while (r2 < (int)h && c2 >= 0 && c2 < (int)w && s_dense[(uint32_t)r2 * w + c2] == v) {
-                            len++; r2 += dy; c2 += dx;
-                        }
-                        atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
+                const int nE = (int)h, nD = (int)(w + h - 1), nS = (int)w;
+                const int n_all = nE + nD + nS + nD;
+                auto fetch = [=](int gl, int& ai, int& L) -> uint32_t {   // line gl -> angle, length, this lane's level
+                    int ln = gl, x0, y0;
+                    if (ln < nE) { ai = 0; x0 = 0; y0 = ln; L = (int)w; }
+                    else if ((ln -= nE) < nD) {                            // SE: x - y = ln - (h - 1)
+                        ai = 1;
+                        const int c = ln - ((int)h - 1);
+                        x0 = c >= 0 ? c : 0; y0 = c >= 0 ? 0 : -c;
+                        L = min((int)w - x0, (int)h - y0);
+                    } else if ((ln -= nD) < nS) { ai = 2; x0 = ln; y0 = 0; L = (int)h; }
+                    else {                                                 // SW: x + y = ln
+                        ln -= nS; ai = 3;
+                        x0 = ln < (int)w ? ln : (int)w - 1; y0 = ln < (int)w ? 0 : ln - (int)w + 1;
+                        L = min(x0 + 1, (int)h - y0);
                     }
-                    wav_sync<GS>();
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
+                    const int dx = ai == 2 ? 0 : ai == 3 ? -1 : 1, dy = ai == 0 ? 0 : 1;   // glrlm.cpp:128-176
+                    return lane < L ? (uint32_t)s_dense[(uint32_t)(y0 + lane * dy) * w + (uint32_t)(x0 + lane * dx)] : 0u;
+                };
+                int ai = 0, L = 0, ai_n = 0, L_n = 0;
+                uint32_t v = wave < n_all ? fetch(wave, ai, L) : 0u;
+                for (int gl = wave; gl < n_all; gl += kWaves) {
+                    const uint32_t v_n = gl + kWaves < n_all ? fetch(gl + kWaves, ai_n, L_n) : 0u;
+                    const uint32_t nx = lane_plus1(v, 0u);
+                    const unsigned long long same = __ballot(lane + 1 < L && v != 0 && v == nx);
+                    if (v != 0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull))) {
+                        const int len = __ffsll((long long)~(same >> lane));   // 1 + trailing ones of same >> lane
+                        atomicAdd(&s_mat[(uint32_t)ai * slot_words + (uint32_t)(((int)s_lvlmap[v] - 1) * Nr + (len - 1))], 1u);
+                    }
+                    v = v_n; ai = ai_n; L = L_n;
+                }
+                blk_sync<GS>();
+                {
+                    uint32_t* P = s_mat + (uint32_t)wave * slot_words;
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + wave * 16, lane);
+                }
+            } else {
+            const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
+                for (int a0 = 0; a0 < 4; a0 += per) {
+                    blk_sync<GS>();
+                    for (uint32_t i = tid; i < (uint32_t)per * slot_words; i += kBlock) s_mat[i] = 0;
+                    blk_sync<GS>();
+                    if (wave < per && a0 + wave < 4) {
+                        const int ai = a0 + wave;
+                        uint32_t* P = s_mat + wave * slot_words;
+                        const int dx = ai == 2 ? 0 : ai == 3 ? -1 : 1, dy = ai == 0 ? 0 : 1; // glrlm.cpp:128-176
+                        for (uint32_t p = lane; p < area; p += 64) {
+                            uint32_t v = s_dense[p];
+                            if (v == 0) continue;
+                            int row = (int)(p / w), cl = (int)(p - (uint32_t)row * w);
+                            int pr = row - dy, pc = cl - dx;
+                            if (pr >= 0 && pc >= 0 && pc < (int)w && s_dense[(uint32_t)pr * w + pc] == v)
+                                continue;                        // not the first pixel of its run
+                            int len = 1, r2 = row + dy, c2 = cl + dx;
+                            while (r2 < (int)h && c2 >= 0 && c2 < (int)w && s_dense[(uint32_t)r2 * w + c2] == v) {
+                                len++; r2 += dy; c2 += dx;
+                            }
+                            atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
+                        }
+                        wav_sync<GS>();
+                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
+                    }
                 }
             }
             blk_sync<GS>();
@@ -327,8 +374,59 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
             for (uint32_t i = tid; i < area; i += kBlock) s_count[i] = 0;
             for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0xFFFFFFFFu; s_hval[i] = 0; }
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
-            // owner labels: wave 0 sweeps the rows; lanes own columns (chunks of 64)
-            if (wave == 0) {
+            blk_sync<GS>();
+            // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
+            if (wave == 0 && w <= 64) {
+                // bounding boxes up to 64 wide: the previous row's values / labels stay in registers, neighbours come
+                // through DPP lane shifts, the W chain is a segmented prefix-min in DPP steps -- no LDS on the critical path
+                uint32_t v_prev = 0, lab_prev = 0xFFFFFFFFu;
+                const bool in = (uint32_t)lane < w;
+                const uint32_t row_start = (uint32_t)lane & ~15u;
+                for (uint32_t row = 0; row < h; row++) {
+                    const uint32_t p = row * w + (uint32_t)lane;
+                    const uint32_t v = in ? (uint32_t)s_dense[p] : 0u;
+                    uint32_t lab = p;
+                    {   // N, NW, NE predecessors (final labels of the previous row; v_prev = 0 on the first row)
+                        const uint32_t vW = lane_minus1(v_prev, 0u), lW = lane_minus1(lab_prev, 0xFFFFFFFFu);
+                        const uint32_t vE = lane_plus1(v_prev, 0u), lE = lane_plus1(lab_prev, 0xFFFFFFFFu);
+                        if (v != 0) {
+                            if (v_prev == v) lab = min(lab, lab_prev);
+                            if (vW == v) lab = min(lab, lW);
+                            if (vE == v) lab = min(lab, lE);
+                        }
+                    }
+                    const uint32_t vl = lane_minus1(v, 0u);
+                    const bool start = v == 0 || vl != v;       // run starts here (or not a zone pixel); lane 0: vl = 0 != v or v == 0
+                    const unsigned long long smask = __ballot(start);
+                    const uint32_t run0 = 63u - (uint32_t)__clzll((long long)(smask & ((2ull << lane) - 1ull)));
+                    // segmented inclusive prefix-min: inside the 16-lane DPP rows, then row to row
+#define NYX_SEG_STEP(D)                                                                                                         \
+                    {                                                                                                                   \
+                        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x110 + D, 0xF, 0xF, false); /* row_shr:D */ \
+                        if ((uint32_t)lane >= run0 + D && ((uint32_t)lane & 15u) >= D) lab = min(lab, o2);                            \
+                    }
+                    NYX_SEG_STEP(1u) NYX_SEG_STEP(2u) NYX_SEG_STEP(4u) NYX_SEG_STEP(8u)
+#undef NYX_SEG_STEP
+                    {
+                        uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x2, 0xF, false);             // row_bcast15 -> row 1
+                        if (run0 < row_start) lab = min(lab, o2);
+                        o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x4, 0xF, false);                      // -> row 2
+                        if (run0 < row_start) lab = min(lab, o2);
+                        o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x8, 0xF, false);                      // -> row 3
+                        if (run0 < row_start) lab = min(lab, o2);
+                    }
+                    // zone sizes: one atomic per string of equal labels in the row
+                    const uint32_t ln = lane_plus1(lab, 0xFFFFFFFFu);
+                    const bool zp = in && v != 0;
+                    const unsigned long long same = __ballot(zp && lane < 63 && ln == lab && lane_plus1(v, 0u) != 0);
+                    if (zp) {
+                        s_label[p] = lab;
+                        if (!(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                            atomicAdd(&s_count[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
+                    }
+                    v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
+                }
+            } else if (wave == 0) {
                 for (uint32_t row = 0; row < h; row++) {
                     uint32_t carry_v = 0, carry_l = 0;       // right-most pixel of the previous chunk
                     for (uint32_t c0 = 0; c0 < w; c0 += 64) {
@@ -364,11 +462,13 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 }
             }
             blk_sync<GS>();
-            // zone sizes at the owners
-            for (uint32_t p = tid; p < area; p += kBlock)
-                if (s_dense[p] != 0)
-                    atomicAdd(&s_count[s_label[p]], 1u);
-            blk_sync<GS>();
+            // zone sizes at the owners (the DPP sweep counted on the way)
+            if (w > 64) {
+                for (uint32_t p = tid; p < area; p += kBlock)
+                    if (s_dense[p] != 0)
+                        atomicAdd(&s_count[s_label[p]], 1u);
+                blk_sync<GS>();
+            }
             // zones -> P(i,j) multiplicities (hash), zones per level; Nz
             uint32_t nzone = 0;
             for (uint32_t p = tid; p < area; p += kBlock) {
