@@ -59,8 +59,10 @@ enum {
     NYXHIP_FAM_GLDZM     = 1u << 7, /* GLDZMFeature, 18 columns (features/gldzm.h:18-38)  */
     NYXHIP_FAM_GLDM      = 1u << 8, /* GLDMFeature, 14 columns  (features/gldm.h:30-46)   */
     NYXHIP_FAM_NGLDM     = 1u << 9, /* NGLDMfeature, 19 columns (features/ngldm.h:17-38)  */
+    NYXHIP_FAM_SMOMS     = 1u << 10, /* Smoms2D_feature, 90 columns: shape moments (features/2d_geomoments.h:247-340)      */
+    NYXHIP_FAM_IMOMS     = 1u << 11, /* Imoms2D_feature, 90 columns: intensity moments (features/2d_geomoments.h:99-193)   */
     NYXHIP_FAM_NORTH_STAR = 0x7Fu,  /* the seven families of BASELINE.json's north_star */
-    NYXHIP_FAM_ALL       = 0x3FFu
+    NYXHIP_FAM_ALL       = 0xFFFu
 };
 
 #define NYXHIP_MAX_GLCM_ANGLES 4

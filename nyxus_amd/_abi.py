@@ -26,8 +26,10 @@ FAM_ZERNIKE = 1 << 6
 FAM_GLDZM = 1 << 7
 FAM_GLDM = 1 << 8
 FAM_NGLDM = 1 << 9
+FAM_SMOMS = 1 << 10
+FAM_IMOMS = 1 << 11
 FAM_NORTH_STAR = 0x7F
-FAM_ALL = 0x3FF
+FAM_ALL = 0xFFF
 
 MEM_HOST = 0
 MEM_DEVICE = 1

@@ -51,6 +51,11 @@ void nyxo_ngldm(const uint32_t* im, const uint8_t* mask, uint32_t w, uint32_t h,
 void nyxo_gldzm(const uint32_t* im, uint32_t w, uint32_t h, uint32_t aux_min, uint32_t aux_max, uint32_t roi_area,
                 const nyxhip_settings* s, double* out);
 
+/* contour.cpp:306-678 + 2d_geomoments_basic.cpp:32-376: shape (Smoms2D) and intensity (Imoms2D) moments, 90 each */
+void nyxo_geomoments(const uint16_t* x, const uint16_t* y, const uint32_t* inten, uint64_t n, uint32_t w, uint32_t h,
+                     double* out_shape, double* out_inten);
+int nyxo_contour(const uint16_t* x, const uint16_t* y, const uint32_t* inten, uint64_t n, uint32_t w, uint32_t h, int32_t* out_xy, int cap);
+
 int nyxo_n_columns(uint32_t mask, const nyxhip_settings* s);
 
 /* Host-memory batch, same argument meaning as nyxhip_featurize_batch. */

@@ -35,6 +35,8 @@
 #include "features/ngldm.h"
 #include "features/gabor.h"
 #include "features/zernike.h"
+#include "features/contour.h"
+#include "features/2d_geomoments.h"
 
 #include "../include/nyxhip.h"
 
@@ -112,6 +114,8 @@ int nyxref_n_columns(uint32_t mask, const nyxhip_settings* s)
     if (mask & NYXHIP_FAM_NGTDM) n += 5;
     if (mask & NYXHIP_FAM_GABOR) n += s->gabor_n_filters;
     if (mask & NYXHIP_FAM_ZERNIKE) n += 30;
+    if (mask & NYXHIP_FAM_SMOMS) n += 90;
+    if (mask & NYXHIP_FAM_IMOMS) n += 90;
     return n;
 }
 
@@ -172,6 +176,8 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
         auto t0 = std::chrono::steady_clock::now();
         if (mask & NYXHIP_FAM_INTENSITY)
             runParallel(PixelIntensityFeatures::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & (NYXHIP_FAM_SMOMS | NYXHIP_FAM_IMOMS))   // the moments' dependency, reduce_trivial_rois.cpp:98-111
+            runParallel(ContourFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_GLCM)
             runParallel(GLCMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_GLRLM)
@@ -190,6 +196,10 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
             runParallel(GaborFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         if (mask & NYXHIP_FAM_ZERNIKE)
             runParallel(ZernikeFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & NYXHIP_FAM_IMOMS)   // reduce_trivial_rois.cpp:320-325
+            runParallel(Imoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        if (mask & NYXHIP_FAM_SMOMS)   // :326-331
+            runParallel(Smoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
         auto t1 = std::chrono::steady_clock::now();
         if (reduce_seconds)
             *reduce_seconds = std::chrono::duration<double>(t1 - t0).count();
@@ -232,6 +242,12 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
                 put_angled(p, lr.fvals[(int)Feature2D::GABOR], (size_t)s->gabor_n_filters);
             if (mask & NYXHIP_FAM_ZERNIKE)
                 put_angled(p, lr.fvals[(int)Feature2D::ZERNIKE2D], 30);
+            if (mask & NYXHIP_FAM_SMOMS)
+                for (int f = (int)Feature2D::SPAT_MOMENT_00; f <= (int)Feature2D::WEIGHTED_HU_M7; f++)
+                    *p++ = lr.fvals[f][0];
+            if (mask & NYXHIP_FAM_IMOMS)
+                for (int f = (int)Feature2D::IMOM_RM_00; f <= (int)Feature2D::IMOM_WHU7; f++)
+                    *p++ = lr.fvals[f][0];
         }
     } catch (const std::exception& e) {
         fprintf(stderr, "nyxref_featurize_batch: %s\n", e.what());

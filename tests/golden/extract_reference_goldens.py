@@ -86,6 +86,12 @@ def main():
         if not os.path.exists(p):
             continue
         res["goldens"].update(scalar_maps(strip_comments(open(p).read())))
+    # 2-D geometric moments: lists of {Feature2D code, "name", value} (test_2d_moments_{regression,skimage}.h)
+    res["moment_goldens"] = {}
+    for f in ["test_2d_moments_regression.h", "test_2d_moments_skimage.h"]:
+        src = strip_comments(open(os.path.join(REF, f)).read())
+        for m in re.finditer(r"ref_vals_list<GeomomentGoldenValue>\s+(\w+)\s*\{(.*?)\};", src, flags=re.S):
+            res["moment_goldens"][m.group(1)] = {k: float(v) for k, v in re.findall(r"\{\s*Nyxus::Feature2D::\w+\s*,\s*\"(\w+)\"\s*,\s*([-+0-9.eE]+)\s*\}", m.group(2))}
     z = strip_comments(open(os.path.join(REF, "test_2d_zernike_regression.h")).read())
     res["vector_goldens"].update(vector_maps(z))
     g = strip_comments(open(os.path.join(REF, "test_gabor_truth.h")).read())

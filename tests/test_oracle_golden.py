@@ -267,3 +267,46 @@ def test_gabor_zernike_match_reference_classes_bit_exact():
     R = po.ref_featurize(b, mask, s, n_threads=2)
     same = (A == R) | (np.isnan(A) & np.isnan(R))
     assert same.all(), np.argwhere(~same)[:10]
+
+
+# ---- 2-D geometric moments (last item) --------------------------------------------------------------------
+def _moment_close(actual, golden):
+    # tests/test_2d_moments_common.h:152-168: |actual - golden| <= 1e-6 * max(1, |golden|, |actual|)
+    return np.isfinite(actual) and abs(actual - golden) <= 1e-6 * max(1.0, abs(golden), abs(actual))
+
+
+def _check_moment_goldens(T_shape, T_inten, lists):
+    for name in lists:
+        for k, v in REF["moment_goldens"][name].items():
+            if k in fixtures.SMOM_NAMES:
+                got = T_shape[fixtures.SMOM_NAMES.index(k)]
+            else:
+                got = T_inten[fixtures.IMOM_NAMES.index(k)]
+            assert _moment_close(got, v), (name, k, got, v)
+
+
+def test_geomoment_goldens():
+    """tests/test_2d_moments_regression.h:6-118 and test_2d_moments_skimage.h:6-211 (scikit-image 0.26.0 goldens): the
+    48 x 40 rectangle fixture (shape + intensity moments, weighted ones included -> contour + hill-descent distances) and
+    the wedge fixture (Hu invariants)."""
+    s = _abi.default_settings(256)
+    b = _abi.batch_from_rois([fixtures.geomoment_rectangle_roi(), fixtures.geomoment_wedge_roi()])
+    T = po.oracle_featurize(b, _abi.FAM_SMOMS | _abi.FAM_IMOMS, s)
+    _check_moment_goldens(T[0, :90], T[0, 90:], ["moments_2d_regression_shape_ref_vals", "moments_2d_regression_intensity_ref_vals",
+                                                  "moments_2d_skimage_shape_ref_vals", "moments_2d_skimage_intensity_ref_vals",
+                                                  "moments_2d_skimage_normraw_shape_ref_vals", "moments_2d_skimage_normraw_intensity_ref_vals"])
+    _check_moment_goldens(T[1, :90], T[1, 90:], ["moments_2d_skimage_wedge_hu_ref_vals"])
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libnyxref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed,rmax", [(9, 25), (3, 12), (5, 40)])
+def test_geomoments_match_reference_classes_bit_exact(seed, rmax):
+    """Contour tracing (contour.cpp:381-619), the hill-descent distance (pixel.cpp:40-70) and all 2 x 90 moments against
+    ContourFeature + Smoms2D_feature + Imoms2D_feature compiled in place, bit for bit."""
+    b = _abi.batch_from_rois(synth.random_rois(40, seed=seed, rmax=rmax))
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_SMOMS | _abi.FAM_IMOMS
+    A = po.oracle_featurize(b, mask, s)
+    R = po.ref_featurize(b, mask, s, n_threads=2)
+    same = (A == R) | (np.isnan(A) & np.isnan(R))
+    assert same.all(), np.argwhere(~same)[:10]
