@@ -62,6 +62,35 @@ enum class Feature2D : int {
     NGLDM_GLNUN, NGLDM_DCNU, NGLDM_DCNUN, NGLDM_DCP, NGLDM_GLM, NGLDM_GLV, NGLDM_DCM, NGLDM_DCV, NGLDM_DCENT, NGLDM_DCENE,
     NGTDM_COARSENESS, NGTDM_CONTRAST, NGTDM_BUSYNESS, NGTDM_COMPLEXITY, NGTDM_STRENGTH,
     GABOR, ZERNIKE2D,
+    // shape / intensity geometric moments (featureset.h:362-565)
+    SPAT_MOMENT_00, SPAT_MOMENT_01, SPAT_MOMENT_02, SPAT_MOMENT_03, SPAT_MOMENT_10, SPAT_MOMENT_11, SPAT_MOMENT_12,
+    SPAT_MOMENT_13, SPAT_MOMENT_20, SPAT_MOMENT_21, SPAT_MOMENT_22, SPAT_MOMENT_23, SPAT_MOMENT_30, CENTRAL_MOMENT_00,
+    CENTRAL_MOMENT_01, CENTRAL_MOMENT_02, CENTRAL_MOMENT_03, CENTRAL_MOMENT_10, CENTRAL_MOMENT_11, CENTRAL_MOMENT_12,
+    CENTRAL_MOMENT_13, CENTRAL_MOMENT_20, CENTRAL_MOMENT_21, CENTRAL_MOMENT_22, CENTRAL_MOMENT_23, CENTRAL_MOMENT_30,
+    CENTRAL_MOMENT_31, CENTRAL_MOMENT_32, CENTRAL_MOMENT_33, NORM_SPAT_MOMENT_00, NORM_SPAT_MOMENT_01,
+    NORM_SPAT_MOMENT_02, NORM_SPAT_MOMENT_03, NORM_SPAT_MOMENT_10, NORM_SPAT_MOMENT_11, NORM_SPAT_MOMENT_12,
+    NORM_SPAT_MOMENT_13, NORM_SPAT_MOMENT_20, NORM_SPAT_MOMENT_21, NORM_SPAT_MOMENT_22, NORM_SPAT_MOMENT_23,
+    NORM_SPAT_MOMENT_30, NORM_SPAT_MOMENT_31, NORM_SPAT_MOMENT_32, NORM_SPAT_MOMENT_33, NORM_CENTRAL_MOMENT_02,
+    NORM_CENTRAL_MOMENT_03, NORM_CENTRAL_MOMENT_11, NORM_CENTRAL_MOMENT_12, NORM_CENTRAL_MOMENT_20,
+    NORM_CENTRAL_MOMENT_21, NORM_CENTRAL_MOMENT_30, HU_M1, HU_M2, HU_M3, HU_M4, HU_M5, HU_M6, HU_M7,
+    WEIGHTED_SPAT_MOMENT_00, WEIGHTED_SPAT_MOMENT_01, WEIGHTED_SPAT_MOMENT_02, WEIGHTED_SPAT_MOMENT_03,
+    WEIGHTED_SPAT_MOMENT_10, WEIGHTED_SPAT_MOMENT_11, WEIGHTED_SPAT_MOMENT_12, WEIGHTED_SPAT_MOMENT_20,
+    WEIGHTED_SPAT_MOMENT_21, WEIGHTED_SPAT_MOMENT_30, WEIGHTED_CENTRAL_MOMENT_02, WEIGHTED_CENTRAL_MOMENT_03,
+    WEIGHTED_CENTRAL_MOMENT_11, WEIGHTED_CENTRAL_MOMENT_12, WEIGHTED_CENTRAL_MOMENT_20, WEIGHTED_CENTRAL_MOMENT_21,
+    WEIGHTED_CENTRAL_MOMENT_30, WT_NORM_CTR_MOM_02, WT_NORM_CTR_MOM_03, WT_NORM_CTR_MOM_11, WT_NORM_CTR_MOM_12,
+    WT_NORM_CTR_MOM_20, WT_NORM_CTR_MOM_21, WT_NORM_CTR_MOM_30, WEIGHTED_HU_M1, WEIGHTED_HU_M2, WEIGHTED_HU_M3,
+    WEIGHTED_HU_M4, WEIGHTED_HU_M5, WEIGHTED_HU_M6, WEIGHTED_HU_M7,
+    IMOM_RM_00, IMOM_RM_01, IMOM_RM_02, IMOM_RM_03, IMOM_RM_10, IMOM_RM_11, IMOM_RM_12, IMOM_RM_13, IMOM_RM_20,
+    IMOM_RM_21, IMOM_RM_22, IMOM_RM_23, IMOM_RM_30, IMOM_CM_00, IMOM_CM_01, IMOM_CM_02, IMOM_CM_03, IMOM_CM_10,
+    IMOM_CM_11, IMOM_CM_12, IMOM_CM_13, IMOM_CM_20, IMOM_CM_21, IMOM_CM_22, IMOM_CM_23, IMOM_CM_30, IMOM_CM_31,
+    IMOM_CM_32, IMOM_CM_33, IMOM_NRM_00, IMOM_NRM_01, IMOM_NRM_02, IMOM_NRM_03, IMOM_NRM_10, IMOM_NRM_11, IMOM_NRM_12,
+    IMOM_NRM_13, IMOM_NRM_20, IMOM_NRM_21, IMOM_NRM_22, IMOM_NRM_23, IMOM_NRM_30, IMOM_NRM_31, IMOM_NRM_32,
+    IMOM_NRM_33, IMOM_NCM_02, IMOM_NCM_03, IMOM_NCM_11, IMOM_NCM_12, IMOM_NCM_20, IMOM_NCM_21, IMOM_NCM_30, IMOM_HU1,
+    IMOM_HU2, IMOM_HU3, IMOM_HU4, IMOM_HU5, IMOM_HU6, IMOM_HU7, IMOM_WRM_00, IMOM_WRM_01, IMOM_WRM_02, IMOM_WRM_03,
+    IMOM_WRM_10, IMOM_WRM_11, IMOM_WRM_12, IMOM_WRM_20, IMOM_WRM_21, IMOM_WRM_30, IMOM_WCM_02, IMOM_WCM_03,
+    IMOM_WCM_11, IMOM_WCM_12, IMOM_WCM_20, IMOM_WCM_21, IMOM_WCM_30, IMOM_WNCM_02, IMOM_WNCM_03, IMOM_WNCM_11,
+    IMOM_WNCM_12, IMOM_WNCM_20, IMOM_WNCM_21, IMOM_WNCM_30, IMOM_WHU1, IMOM_WHU2, IMOM_WHU3, IMOM_WHU4, IMOM_WHU5,
+    IMOM_WHU6, IMOM_WHU7,
     _COUNT_
 };
 
@@ -225,6 +254,8 @@ inline void reduce_range(uint32_t mask, size_t start, size_t end, std::vector<in
         if (mask & NYXHIP_FAM_NGTDM) put(Feature2D::NGTDM_COARSENESS, Feature2D::NGTDM_STRENGTH, 1);
         if (mask & NYXHIP_FAM_GABOR) put(Feature2D::GABOR, Feature2D::GABOR, s.gabor_n_filters);
         if (mask & NYXHIP_FAM_ZERNIKE) put(Feature2D::ZERNIKE2D, Feature2D::ZERNIKE2D, 30);
+        if (mask & NYXHIP_FAM_SMOMS) put(Feature2D::SPAT_MOMENT_00, Feature2D::WEIGHTED_HU_M7, 1);
+        if (mask & NYXHIP_FAM_IMOMS) put(Feature2D::IMOM_RM_00, Feature2D::IMOM_WHU7, 1);
     }
 }
 
@@ -285,6 +316,9 @@ NYXHIP_FAMILY_CLASS(NGLDMfeature, NYXHIP_FAM_NGLDM, NGLDM_LDE, NGLDM_DCENE)
 NYXHIP_FAMILY_CLASS(NGTDMFeature, NYXHIP_FAM_NGTDM, NGTDM_COARSENESS, NGTDM_STRENGTH)
 NYXHIP_FAMILY_CLASS(GaborFeature, NYXHIP_FAM_GABOR, GABOR, GABOR)
 NYXHIP_FAMILY_CLASS(ZernikeFeature, NYXHIP_FAM_ZERNIKE, ZERNIKE2D, ZERNIKE2D)
+// the contour the weighted moments depend on (ContourFeature::reduce, reduce_trivial_rois.cpp:98-111) is built inside the call
+NYXHIP_FAMILY_CLASS(Smoms2D_feature, NYXHIP_FAM_SMOMS, SPAT_MOMENT_00, WEIGHTED_HU_M7)
+NYXHIP_FAMILY_CLASS(Imoms2D_feature, NYXHIP_FAM_IMOMS, IMOM_RM_00, IMOM_WHU7)
 
 // runParallel (parallel.h:23-42): the GPU batch is the parallel unit, so the slices run back to back on the
 // caller's thread -- same observable contract (every label of [0, datasetSize) reduced on return).
@@ -310,6 +344,8 @@ inline void reduce_trivial_rois_manual(std::vector<int>& PendingRoisLabels, std:
     if (NGTDMFeature::required(fs)) mask |= NYXHIP_FAM_NGTDM;
     if (GaborFeature::required(fs)) mask |= NYXHIP_FAM_GABOR;
     if (ZernikeFeature::required(fs)) mask |= NYXHIP_FAM_ZERNIKE;
+    if (Smoms2D_feature::required(fs)) mask |= NYXHIP_FAM_SMOMS;   // reduce_trivial_rois.cpp:326-331
+    if (Imoms2D_feature::required(fs)) mask |= NYXHIP_FAM_IMOMS;   // :320-325
     if (mask) reduce_range(mask, 0, PendingRoisLabels.size(), &PendingRoisLabels, &roiData, s, ds);
 }
 

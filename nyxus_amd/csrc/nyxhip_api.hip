@@ -33,6 +33,9 @@ struct nyxhip_ctx {
     // grow-only device staging for host-memory batches
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // contour + moments workspace (grow-only): contour points, contour lengths, per-pixel log distances
+    void* d_mom = nullptr;
+    size_t mom_bytes = 0;
     // large-ROI (spill) pass: index list and per-workgroup global scratch
     uint32_t* d_spill_list = nullptr;
     size_t spill_list_bytes = 0;
@@ -112,7 +115,8 @@ const int kGlrlmAngles[4] = {0, 45, 90, 135}; // GLRLMFeature::rotAngles, glrlm.
 constexpr uint32_t kTexture = NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM | NYXHIP_FAM_NGTDM;
 constexpr uint32_t kShape = NYXHIP_FAM_GABOR | NYXHIP_FAM_ZERNIKE;
 constexpr uint32_t kDependence = NYXHIP_FAM_GLDZM | NYXHIP_FAM_GLDM | NYXHIP_FAM_NGLDM;
-constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture | kShape | kDependence;
+constexpr uint32_t kMoments = NYXHIP_FAM_SMOMS | NYXHIP_FAM_IMOMS;
+constexpr uint32_t kImplemented = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM | kTexture | kShape | kDependence | kMoments;
 
 bool settings_ok(const nyxhip_settings* s, uint32_t mask, std::string& why)
 {
@@ -176,6 +180,34 @@ std::vector<std::string> column_names(uint32_t mask, const nyxhip_settings* s)
         for (int i = 0; i < s->gabor_n_filters; i++) v.push_back("GABOR_" + std::to_string(i));       // output_2_buffer.cpp:364-373
     if (mask & NYXHIP_FAM_ZERNIKE)
         for (int i = 0; i < kZernikeCols; i++) v.push_back("ZERNIKE2D_Z" + std::to_string(i));        // :417-427
+    if (mask & NYXHIP_FAM_SMOMS) {     // featureset.h:362-467
+        const char* pq13[13] = {"00", "01", "02", "03", "10", "11", "12", "13", "20", "21", "22", "23", "30"};
+        const char* pq7[7] = {"02", "03", "11", "12", "20", "21", "30"};
+        const char* pq10[10] = {"00", "01", "02", "03", "10", "11", "12", "20", "21", "30"};
+        for (auto k : pq13) v.push_back(std::string("SPAT_MOMENT_") + k);
+        for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) v.push_back("CENTRAL_MOMENT_" + std::to_string(p) + std::to_string(q));
+        for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) v.push_back("NORM_SPAT_MOMENT_" + std::to_string(p) + std::to_string(q));
+        for (auto k : pq7) v.push_back(std::string("NORM_CENTRAL_MOMENT_") + k);
+        for (int k = 1; k <= 7; k++) v.push_back("HU_M" + std::to_string(k));
+        for (auto k : pq10) v.push_back(std::string("WEIGHTED_SPAT_MOMENT_") + k);
+        for (auto k : pq7) v.push_back(std::string("WEIGHTED_CENTRAL_MOMENT_") + k);
+        for (auto k : pq7) v.push_back(std::string("WT_NORM_CTR_MOM_") + k);
+        for (int k = 1; k <= 7; k++) v.push_back("WEIGHTED_HU_M" + std::to_string(k));
+    }
+    if (mask & NYXHIP_FAM_IMOMS) {     // featureset.h:472-565
+        const char* pq13[13] = {"00", "01", "02", "03", "10", "11", "12", "13", "20", "21", "22", "23", "30"};
+        const char* pq7[7] = {"02", "03", "11", "12", "20", "21", "30"};
+        const char* pq10[10] = {"00", "01", "02", "03", "10", "11", "12", "20", "21", "30"};
+        for (auto k : pq13) v.push_back(std::string("IMOM_RM_") + k);
+        for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) v.push_back("IMOM_CM_" + std::to_string(p) + std::to_string(q));
+        for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) v.push_back("IMOM_NRM_" + std::to_string(p) + std::to_string(q));
+        for (auto k : pq7) v.push_back(std::string("IMOM_NCM_") + k);
+        for (int k = 1; k <= 7; k++) v.push_back("IMOM_HU" + std::to_string(k));
+        for (auto k : pq10) v.push_back(std::string("IMOM_WRM_") + k);
+        for (auto k : pq7) v.push_back(std::string("IMOM_WCM_") + k);
+        for (auto k : pq7) v.push_back(std::string("IMOM_WNCM_") + k);
+        for (int k = 1; k <= 7; k++) v.push_back("IMOM_WHU" + std::to_string(k));
+    }
     return v;
 }
 
@@ -570,6 +602,96 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
     return NYXHIP_OK;
 }
 
+// ROIs whose padded flag plane exceeds the LDS cap of the contour kernel -> index list
+__global__ void classify_plane_kernel(uint64_t n_roi, const uint32_t* bw, const uint32_t* bh, uint32_t cap, uint32_t* list, uint32_t* n_out)
+{
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n_roi) return;
+    if ((uint64_t)(bw[i] + 2) * (bh[i] + 2) > cap)
+        list[atomicAdd(n_out, 1u)] = (uint32_t)i;
+}
+
+// Contour + 2-D geometric moments (roi_moments.hip).  The contour of every ROI goes to a context-owned workspace at the
+// ROI's CSR offset (a contour never has more points than the ROI has pixels); the moments kernel reads it back.
+int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
+                   uint32_t max_area, uint32_t max_side)
+{
+    hipStream_t st = ctx->stream();
+    uint64_t total_px = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total_px, b->px_offset + b->n_roi, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_k = 0, o_n = al(4 * (size_t)total_px + 256), o_l = al(o_n + 4 * (size_t)b->n_roi + 256), need = al(o_l + 8 * (size_t)total_px + 256);
+    if (need > ctx->mom_bytes) {
+        if (ctx->d_mom) { HIP_TRY(ctx, hipFree(ctx->d_mom)); ctx->d_mom = nullptr; ctx->mom_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_mom, need + need / 8));
+        ctx->mom_bytes = need + need / 8;
+    }
+    char* base = (char*)ctx->d_mom;
+    MomArgs m;
+    memset(&m, 0, sizeof(m));
+    m.n_roi = b->n_roi;
+    m.px_offset = b->px_offset; m.x = b->x; m.y = b->y; m.inten = b->inten; m.bbox_w = b->bbox_w; m.bbox_h = b->bbox_h;
+    m.out = d_out; m.ld = ld; m.status = ctx->d_status;
+    m.mask = mask & kMoments;
+    m.col_smoms = nyxhip_n_columns(mask & ~kMoments, s);
+    m.col_imoms = m.col_smoms + ((mask & NYXHIP_FAM_SMOMS) ? kMomCols : 0);
+    m.ws_contour = (uint32_t*)(base + o_k); m.n_contour = (uint32_t*)(base + o_n); m.ws_L = (double*)(base + o_l);
+    const uint64_t full_plane = (uint64_t)max_area + 4ull * max_side + 4;      // (w + 2)(h + 2) <= area + 2(w + h) + 4
+    const uint32_t grid = (uint32_t)b->n_roi;
+    const uint32_t lds_cap = (uint32_t)roi_features_max_lds();
+    int rc;
+    if (full_plane <= lds_cap) {
+        m.plane_cap = (uint32_t)full_plane;
+        rc = launch_roi_contour(m, st, grid);
+    } else {
+        // the bulk of the batch from LDS (16 KiB planes keep ten waves per CU), the oversized ROIs from a global workspace
+        m.plane_cap = 16 * 1024;
+        m.sp.defer_large = 1;
+        rc = launch_roi_contour(m, st, grid);
+        if (rc == 0) {
+            const size_t list_bytes = 4ull * b->n_roi + 256;
+            if (list_bytes > ctx->spill_list_bytes) {
+                if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
+                ctx->spill_list_bytes = list_bytes;
+            }
+            uint32_t* d_cnt = ctx->d_spill_list;
+            uint32_t* d_list = ctx->d_spill_list + 64;
+            HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st));
+            hipLaunchKernelGGL(classify_plane_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, b->n_roi, b->bbox_w, b->bbox_h,
+                               m.plane_cap, d_list, d_cnt);
+            uint32_t n_large = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&n_large, d_cnt, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (n_large) {
+                if (full_plane > 0xFFFFFFF0ull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "bounding box too large for the contour plane");
+                const size_t stride = al((size_t)full_plane);
+                const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, ((size_t)4 << 30) / stride));
+                const size_t sneed = stride * chunk;
+                if (sneed > ctx->spill_bytes) {
+                    if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+                    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, sneed));
+                    ctx->spill_bytes = sneed;
+                }
+                MomArgs m2 = m;
+                m2.plane_cap = (uint32_t)full_plane;
+                m2.sp.defer_large = 0;
+                m2.sp.scratch = ctx->d_spill; m2.sp.stride = stride;
+                for (uint32_t o = 0; o < n_large && rc == 0; o += chunk) {
+                    m2.sp.roi_index = d_list + o;
+                    rc = launch_roi_contour(m2, st, std::min(chunk, n_large - o));
+                }
+            }
+        }
+    }
+    if (rc == 0)
+        rc = launch_roi_moments(m, st, grid);
+    if (rc != 0)
+        return fail(ctx, NYXHIP_ERR_HIP, std::string("moments kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return NYXHIP_OK;
+}
+
 // Launch on device-resident arrays.  Normal case: one LDS-resident launch per kernel group.  When the batch
 // extrema do not fit the 160 KiB of a CU, the LDS launches run with capped carve-outs and skip the oversized
 // ROIs, which are then collected into an index list and re-run by the same kernels instantiated with their
@@ -632,6 +754,9 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     if (ctx->timing)
         HIP_TRY(ctx, hipEventRecord(e1, st));
+    if (mask & kMoments)
+        if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_area, max_side))
+            return mrc;
     if (!need_spill)
         return NYXHIP_OK;
 
@@ -764,6 +889,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_tile) (void)hipFree(ctx->d_tile);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    if (ctx->d_mom) (void)hipFree(ctx->d_mom);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
@@ -805,6 +931,8 @@ int nyxhip_n_columns(uint32_t family_mask, const nyxhip_settings* s)
     if (family_mask & NYXHIP_FAM_NGTDM) n += kNgtdmCols;
     if (family_mask & NYXHIP_FAM_GABOR) n += s->gabor_n_filters;
     if (family_mask & NYXHIP_FAM_ZERNIKE) n += kZernikeCols;
+    if (family_mask & NYXHIP_FAM_SMOMS) n += kMomCols;
+    if (family_mask & NYXHIP_FAM_IMOMS) n += kMomCols;
     return n;
 }
 

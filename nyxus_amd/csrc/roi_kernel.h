@@ -154,6 +154,30 @@ struct DepArgs {
     DepLayout L;
 };
 
+// ---- contour + 2-D geometric moments (roi_moments.hip) -----------------------------------------
+constexpr int kMomCols = 90;              // per family: RM 13, CM 16, NRM 16, NCM 7, HU 7, WRM 10, WCM 7, WNCM 7, WHU 7
+constexpr int kMomContourLds = 4096;      // contour points the moments kernel keeps in LDS (longer contours are read from HBM)
+
+struct MomArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;            // subset of SMOMS | IMOMS
+    int32_t col_smoms, col_imoms;
+    uint32_t* ws_contour;     // [total pixels]  merged multicontour of every ROI at its CSR offset: x | y << 16, padded coordinates
+    uint32_t* n_contour;      // [n_roi]         its length
+    double* ws_L;             // [total pixels]  log(distance to contour + eps) per pixel (the contour kernel's walk stack before that)
+    uint32_t plane_cap;       // bytes of the padded flag plane one ROI may use
+    SpillArgs sp;
+};
+
 // ---- third kernel pair: Gabor + Zernike (roi_shape.hip) -------------------------------------
 constexpr int kZernikeCols = 30;          // ZernikeFeature::NUM_FEATURE_VALS (zernike.h:30)
 
@@ -212,6 +236,8 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid);
 int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid);
 int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid);
+int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid);
+int launch_roi_moments(const MomArgs& a, void* stream, uint32_t grid);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

@@ -1,0 +1,417 @@
+// roi_moments.hip -- ROI contour + 2-D geometric moments (shape: Smoms2D_feature, intensity: Imoms2D_feature),
+// SURVEY.md 8(f) #4.
+//
+//   roi_contour_kernel   /root/reference/src/nyx/features/contour.cpp:381-678  (buildRegularContour + gather_multicontour
+//                        + check_loop).  One wave per ROI.  The reference's list algebra (std::list::remove, find_cands over
+//                        the unordered list, ...) is O(C^2); here the contour candidates live as bits of a byte plane of the
+//                        padded bounding box, so "is my 4- / 8-neighbour still unordered" is one LDS read and the loop
+//                        walk is O(C).  The border trace and the loop walk are order-dependent state machines: lane 0
+//                        runs them; plane set-up, the neighbour filter and the X-crossing screen use all lanes.
+//                        Output: the merged multicontour in walk order (LR::merge_multicontour), padded coordinates
+//                        (the reference adds the bbox origin without removing the one-pixel padding, contour.cpp:673-678).
+//   roi_moments_kernel   features/2d_geomoments_basic.cpp:32-376.  One 256-thread workgroup per ROI, four passes over the
+//                        cloud (raw, central, weights + weighted raw, weighted central); the distance of a pixel to the contour
+//                        is the reference's hill descent over the ORDERED contour (features/pixel.cpp:40-70), and the
+//                        weighted intensity passes through float like the reference's vector<float> (pixel.h:8).
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+namespace {
+
+constexpr uint8_t kPix = 1, kBorder = 2, kCand = 4, kAlive = 8;
+
+__device__ __forceinline__ int dial_pos(int dx, int dy)     // contour.cpp:218-262
+{
+    if (dx > 0) return dy < 0 ? 2 : dy > 0 ? -1 : 1;
+    if (dx < 0) return dy < 0 ? 4 : dy > 0 ? -3 : 5;
+    return dy < 0 ? 3 : dy > 0 ? -2 : 0;
+}
+
+} // namespace
+
+template <bool GS>
+__global__ __launch_bounds__(64) void roi_contour_kernel(const MomArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint8_t* const img = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;   // [(w+2)*(h+2)] flag plane
+    const int lane = threadIdx.x;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    const int w = (int)A.bbox_w[roi], h = (int)A.bbox_h[roi];
+    const int W2 = w + 2, H2 = h + 2;
+    const uint32_t np = (uint32_t)W2 * (uint32_t)H2;
+    if (n == 0 || np > A.plane_cap) {
+        if (n != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
+        if (lane == 0) {
+            A.n_contour[roi] = 0;
+            if (n != 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        }
+        return;
+    }
+    uint32_t* const K = A.ws_contour + off;           // contour out: x | y << 16, padded coordinates
+    uint32_t* const stk = (uint32_t*)(A.ws_L + off);  // bifurcation stack of the loop walk (the moments kernel reuses the space)
+
+    for (uint32_t i = lane; i < np; i += 64) img[i] = 0;
+    wav_sync<GS>();
+    for (uint32_t i = lane; i < n; i += 64) {         // padded image, contour.cpp:661-666
+        const uint32_t px = A.x[off + i], py = A.y[off + i];
+        if (px < (uint32_t)w && py < (uint32_t)h) img[(px + 1) + (py + 1) * (uint32_t)W2] = kPix;
+    }
+    wav_sync<GS>();
+
+    // ---- border image: raster scan with the inside / outside state + Moore trace (contour.cpp:395-493) ----------------
+    if (lane == 0) {
+        const int nbo[8] = {-1, -3 - w, -w - 2, -1 - w, 1, 3 + w, w + 2, 1 + w};
+        const int nbn[8] = {7, 7, 1, 1, 3, 3, 5, 5};
+        bool inside = false;
+        for (uint32_t p0 = 0; p0 < np; p0++) {
+            const uint8_t v = img[p0];
+            const bool bi = (v & kBorder) != 0, pi = (v & kPix) != 0;
+            if (bi && !inside) inside = true;
+            else if (pi && inside) continue;
+            else if (!pi && inside) inside = false;
+            else if (pi && !inside) {
+                img[p0] = v | kBorder;
+                int pos = (int)p0, loc = 1, counter = 0, counter2 = 0;
+                for (;;) {
+                    const int cp = pos + nbo[loc - 1], nloc = nbn[loc - 1];
+                    if (cp < 0 || (uint32_t)cp >= np) break;
+                    const uint8_t c = img[cp];
+                    if (c & kPix) {
+                        if (cp == (int)p0) {
+                            counter++;
+                            if (nloc == 1 || counter >= 3) { inside = true; break; }
+                        }
+                        loc = nloc; pos = cp; counter2 = 0; img[cp] = c | kBorder;
+                    } else {
+                        loc = 1 + (loc % 8);
+                        if (counter2 > 8) break;
+                        counter2++;
+                    }
+                }
+            }
+        }
+    }
+    wav_sync<GS>();
+    // ---- candidates: border pixels with a border neighbour, bounds as written (:509-552) -----------------------------
+    uint32_t n_cand = 0;
+    for (uint32_t p = lane; p < np; p += 64) {
+        if (!(img[p] & kBorder)) continue;
+        const int yy = (int)(p / (uint32_t)W2), xx = (int)(p - (uint32_t)yy * (uint32_t)W2);
+        auto bb = [&](int X, int Y) { return (img[(uint32_t)X + (uint32_t)Y * (uint32_t)W2] & kBorder) != 0; };
+        bool has = false;
+        if (xx > 0) has |= bb(xx - 1, yy);
+        if (xx < w - 1) has |= bb(xx + 1, yy);
+        if (yy > 0) has |= bb(xx, yy - 1);
+        if (yy < h - 1) has |= bb(xx, yy + 1);
+        if (xx > 0 && yy > 0) has |= bb(xx - 1, yy - 1);
+        if (xx < w - 1 && yy > 0) has |= bb(xx + 1, yy - 1);
+        if (xx > 0 && yy < h - 1) has |= bb(xx - 1, yy + 1);
+        if (xx < w - 1 && yy < h - 1) has |= bb(xx + 1, yy + 1);
+        if (has) { img[p] |= (uint8_t)(kCand | kAlive); n_cand++; }
+    }
+    wav_sync<GS>();
+    // ---- X-crossing fix (:566-585): a candidate whose N, S, W, E are all still in the list leaves it; raster order matters
+    uint32_t n_x = 0;
+    for (uint32_t p = lane; p < np; p += 64)
+        if ((img[p] & kCand) && p >= (uint32_t)W2 && p + (uint32_t)W2 < np && (img[p - W2] & kCand) && (img[p + W2] & kCand) && (img[p - 1] & kCand) &&
+            (img[p + 1] & kCand))
+            n_x++;
+    n_cand = (uint32_t)wave_sum_u64(n_cand);
+    n_x = (uint32_t)wave_sum_u64(n_x);
+    n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_cand);
+    n_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_x);
+    if (lane == 0) {
+        uint32_t n_u = n_cand;
+        if (n_x != 0)
+            for (uint32_t p = (uint32_t)W2; p + (uint32_t)W2 < np; p++)
+                if ((img[p] & kAlive) && (img[p - W2] & kAlive) && (img[p + W2] & kAlive) && (img[p - 1] & kAlive) && (img[p + 1] & kAlive)) {
+                    img[p] &= (uint8_t)~kAlive;
+                    n_u--;
+                }
+        // ---- contour by contour (:587-619) with check_loop (:306-379) on the alive bits --------------------------------
+        uint32_t nK = 0, cursor = 0;
+        while (n_u != 0) {
+            while (!(img[cursor] & kAlive)) cursor++;        // U.front(): the raster-first unordered pixel
+            const int ox = (int)(cursor % (uint32_t)W2), oy = (int)(cursor / (uint32_t)W2);
+            uint32_t ns = 0, nP = 0;
+            int looplen = 0, result = -1;
+            K[nK + ns++] = (uint32_t)ox | ((uint32_t)oy << 16);
+            img[cursor] &= (uint8_t)~kAlive; n_u--;
+            int tx = ox, ty = oy;
+            while (n_u != 0) {
+                // find_cands (:193-216): straight neighbours first, else the diagonal ones; prune_cands keeps the largest dial position
+                int nc = 0, best = -100, bx = 0, by = 0;
+                auto probe = [&](int dx, int dy) {
+                    const int X = tx + dx, Y = ty + dy;
+                    if (X < 0 || Y < 0 || X >= W2 || Y >= H2) return;
+                    if (img[(uint32_t)X + (uint32_t)Y * (uint32_t)W2] & kAlive) {
+                        nc++;
+                        const int d = dial_pos(dx, dy);
+                        if (d > best) { best = d; bx = X; by = Y; }
+                    }
+                };
+                probe(1, 0); probe(-1, 0); probe(0, 1); probe(0, -1);
+                if (nc == 0) { probe(1, 1); probe(1, -1); probe(-1, 1); probe(-1, -1); }
+                if (nc > 1) stk[nP++] = (uint32_t)tx | ((uint32_t)ty << 16);
+                if (nc == 0) {
+                    const int ddx = tx - ox, ddy = ty - oy;
+                    if (ddx == 1 || ddx == -1 || ddy == 1 || ddy == -1) { looplen++; result = looplen; break; }
+                    if (nP == 0) { result = 0; break; }
+                    const uint32_t t = stk[--nP];
+                    tx = (int)(t & 0xFFFFu); ty = (int)(t >> 16);
+                } else {
+                    looplen++;
+                    tx = bx; ty = by;
+                    K[nK + ns++] = (uint32_t)tx | ((uint32_t)ty << 16);
+                    img[(uint32_t)tx + (uint32_t)ty * (uint32_t)W2] &= (uint8_t)~kAlive; n_u--;
+                }
+            }
+            if (result < 0) result = looplen;                 // the list ran empty inside the walk
+            if (result > 0) nK += ns;                         // a closed loop joins the multicontour; a failed chain is dropped
+        }
+        A.n_contour[roi] = nK;
+    }
+}
+
+// ---- moments -----------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMB = 256;
+
+// Sum N doubles across the workgroup in a fixed order; every thread gets the totals.
+template <int N, bool GS>
+__device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; k++) s_red[wave * N + k] = v[k];
+    blk_sync<GS>();
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = ((s_red[k] + s_red[N + k]) + s_red[2 * N + k]) + s_red[3 * N + k];
+    blk_sync<GS>();
+}
+
+// Pixel2::min_sqdist v2 (pixel.cpp:40-70): hill descent over the ordered contour
+__device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n)
+{
+    if (n == 0) return 0.0;
+    auto sqd = [&](size_t i) {
+        const uint32_t k = K[i];
+        const double dx = (double)(int)(k & 0xFFFFu) - (double)px, dy = (double)(int)(k >> 16) - (double)py;
+        return dx * dx + dy * dy;
+    };
+    double extrem_d = sqd(0);
+    if (n == 1) return extrem_d;
+    size_t a = 0, b = (size_t)n, extrem_i = 0;
+    int step = (int)((double)(b - a) / log((double)(b - a)));
+    do {
+        for (size_t i = a + (size_t)step; i < b; i += (size_t)step) {
+            const double d = sqd(i);
+            if (extrem_d > d) { extrem_d = d; extrem_i = i; }
+        }
+        const size_t stepL = extrem_i >= (size_t)step ? (size_t)step : extrem_i,
+                     stepR = extrem_i + (size_t)step < (size_t)n ? (size_t)step : (size_t)n - extrem_i;
+        a = extrem_i - stepL;
+        b = extrem_i + stepR;
+        step = b - a <= 10 ? 1 : (int)((double)(b - a) / log((double)(b - a)));
+    } while (b - a > 2);
+    return extrem_d;
+}
+
+__device__ __forceinline__ double ipow(double a, int b) { double r = 1.0; for (int i = 0; i < b; i++) r *= a; return r; }
+
+__device__ void hu7(double _02, double _03, double _11, double _12, double _20, double _21, double _30, double* h)
+{   // calcHu_imp, 2d_geomoments_basic.cpp:231-253
+    h[0] = _20 + _02;
+    h[1] = ipow((_20 - _02), 2) + 4 * (ipow(_11, 2));
+    h[2] = ipow((_30 - 3 * _12), 2) + ipow((3 * _21 - _03), 2);
+    h[3] = ipow((_30 + _12), 2) + ipow((_21 + _03), 2);
+    h[4] = (_30 - 3 * _12) * (_30 + _12) * (ipow(_30 + _12, 2) - 3 * ipow(_21 + _03, 2)) +
+           (3 * _21 - _03) * (_21 + _03) * (3 * ipow(_30 + _12, 2) - ipow(_21 + _03, 2));
+    h[5] = (_20 - _02) * (ipow(_30 + _12, 2) - ipow(_21 + _03, 2)) + 4 * _11 * (_30 + _12) * (_21 + _03);
+    h[6] = (3 * _21 - _03) * (_30 + _12) * (ipow(_30 + _12, 2) - 3 * ipow(_21 + _03, 2)) -
+           (_30 - 3 * _12) * (_21 + _03) * (3 * ipow(_30 + _12, 2) - ipow(_21 + _03, 2));
+}
+
+} // namespace
+
+// Column layout of one 90-wide block (Feature2D order): RM(13) CM(16) NRM(16) NCM(7) HU(7) WRM(10) WCM(7) WNCM(7) WHU(7)
+__global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
+{
+    __shared__ double s_red[4 * 16];
+    __shared__ double s_raw[2][16], s_cen[2][16], s_wraw[2][10], s_wcen[2][7];
+    __shared__ uint32_t s_K[kMomContourLds];
+    const int tid = threadIdx.x;
+    const uint64_t roi = blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    double* const row_out = A.out + roi * A.ld;
+    const bool do_s = (A.mask & NYXHIP_FAM_SMOMS) != 0, do_i = (A.mask & NYXHIP_FAM_IMOMS) != 0;
+    if (n == 0) {
+        for (int c = tid; c < 90; c += kMB) {
+            if (do_s) row_out[A.col_smoms + c] = __longlong_as_double(0x7ff8000000000000LL);
+            if (do_i) row_out[A.col_imoms + c] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        return;
+    }
+    const int nK = (int)A.n_contour[roi];
+    const uint32_t* K = A.ws_contour + off;
+    if (nK <= kMomContourLds) {
+        for (int i = tid; i < nK; i += kMB) s_K[i] = K[i];
+        K = s_K;
+    }
+    double* const L = A.ws_L + off;
+
+    // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209) ------
+    for (int var = 0; var < 2; var++) {                       // 0 = shape (INTEN = 1), 1 = intensity
+        if (!(var ? do_i : do_s)) continue;
+        double acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0;
+        for (uint32_t i = tid; i < n; i += kMB) {
+            const double X = (double)A.x[off + i], Y = (double)A.y[off + i];
+            const double I = var ? (double)A.inten[off + i] : 1.0;
+            double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
+        }
+        mom_block_sum<16, false>(acc, s_red, tid);
+        if (tid < 16) s_raw[var][tid] = acc[tid];
+    }
+    __syncthreads();
+    // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316) ------------------------------
+    for (int var = 0; var < 2; var++) {
+        if (!(var ? do_i : do_s)) continue;
+        const double ox = s_raw[var][4] / s_raw[var][0], oy = s_raw[var][1] / s_raw[var][0];
+        double acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0;
+        for (uint32_t i = tid; i < n; i += kMB) {
+            const double dx = (double)A.x[off + i] - ox, dy = (double)A.y[off + i] - oy;
+            const double I = var ? (double)A.inten[off + i] : 1.0;
+            double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
+        }
+        mom_block_sum<16, false>(acc, s_red, tid);
+        if (tid < 16) s_cen[var][tid] = acc[tid];
+    }
+    __syncthreads();
+    // ---- pass 3: log(distance to contour + eps) per pixel (:32-53), weighted raw moments (:283-296) -----------------------
+    for (uint32_t i = tid; i < n; i += kMB) {
+        const double d = sqrt(min_sqdist_v2((int)A.x[off + i], (int)A.y[off + i], K, nK));
+        L[i] = log(d + 0.001);
+    }
+    __syncthreads();
+    // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
+    const int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
+    const int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
+    for (int var = 0; var < 2; var++) {
+        if (!(var ? do_i : do_s)) continue;
+        double acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] = 0;
+        for (uint32_t i = tid; i < n; i += kMB) {
+            const double X = (double)A.x[off + i], Y = (double)A.y[off + i];
+            const double I = (double)(float)((var ? (double)A.inten[off + i] : 1.0) * L[i]);   // realintens is vector<float>
+            double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+#pragma unroll
+            for (int k = 0; k < 10; k++) acc[k] += I * xp[wr_p[k]] * yp[wr_q[k]];
+        }
+        mom_block_sum<10, false>(acc, s_red, tid);
+        if (tid < 10) s_wraw[var][tid] = acc[tid];
+    }
+    __syncthreads();
+    // ---- pass 4: weighted central moments about the weighted origin (:162-167, :318-327) -----------------------------------
+    for (int var = 0; var < 2; var++) {
+        if (!(var ? do_i : do_s)) continue;
+        const double ox = s_wraw[var][4] / s_wraw[var][0], oy = s_wraw[var][1] / s_wraw[var][0];
+        double acc[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc[k] = 0;
+        for (uint32_t i = tid; i < n; i += kMB) {
+            const double dx = (double)A.x[off + i] - ox, dy = (double)A.y[off + i] - oy;
+            const double I = (double)(float)((var ? (double)A.inten[off + i] : 1.0) * L[i]);
+            double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+#pragma unroll
+            for (int k = 0; k < 7; k++) acc[k] += I * xp[nc_p[k]] * yp[nc_q[k]];
+        }
+        mom_block_sum<7, false>(acc, s_red, tid);
+        if (tid < 7) s_wcen[var][tid] = acc[tid];
+    }
+    __syncthreads();
+    // ---- derived values and output ------------------------------------------------------------------------------------------
+    if (tid < 2 && (tid ? do_i : do_s)) {
+        const int var = tid;
+        double* o = row_out + (var ? A.col_imoms : A.col_smoms);
+        const double* raw = s_raw[var];
+        const double* cen = s_cen[var];
+        const double m00 = raw[0], w00 = s_wraw[var][0];
+        const int rm_idx[13] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+        for (int k = 0; k < 13; k++) o[k] = raw[rm_idx[k]];                                       // RM 00..23, 30
+        for (int k = 0; k < 16; k++) o[13 + k] = cen[k];                                          // CM
+        for (int k = 0; k < 16; k++) {                                                             // NRM :204-209
+            const int p = k >> 2, q = k & 3;
+            o[29 + k] = raw[k] / pow(m00, (((double)p + (double)q) / 2.0) + 1.0);
+        }
+        double nu[7], wn[7];
+        for (int k = 0; k < 7; k++) {                                                              // NCM :212-217
+            nu[k] = cen[nc_p[k] * 4 + nc_q[k]] / pow(m00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
+            o[45 + k] = nu[k];
+        }
+        hu7(nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], nu[6], o + 52);
+        for (int k = 0; k < 10; k++) o[59 + k] = s_wraw[var][k];                                   // WRM
+        for (int k = 0; k < 7; k++) o[69 + k] = s_wcen[var][k];                                    // WCM
+        for (int k = 0; k < 7; k++) {                                                              // WNCM :220-225
+            wn[k] = s_wcen[var][k] / pow(w00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
+            o[76 + k] = wn[k];
+        }
+        hu7(wn[0], wn[1], wn[2], wn[3], wn[4], wn[5], wn[6], o + 83);
+    }
+}
+
+int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)roi_contour_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        if (e != hipSuccess)
+            return (int)e;
+        attr_set = true;
+    }
+    if (grid == 0)
+        return 0;
+    if (a.sp.scratch)
+        hipLaunchKernelGGL(roi_contour_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_contour_kernel<false>, dim3(grid), dim3(64), (a.plane_cap + 15u) & ~15u, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_roi_moments(const MomArgs& a, void* stream, uint32_t grid)
+{
+    if (grid == 0)
+        return 0;
+    hipLaunchKernelGGL(roi_moments_kernel, dim3(grid), dim3(kMB), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

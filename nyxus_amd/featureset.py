@@ -45,6 +45,17 @@ NGLDM = ["NGLDM_LDE", "NGLDM_HDE", "NGLDM_LGLCE", "NGLDM_HGLCE", "NGLDM_LDLGLE",
          "NGLDM_DCENT", "NGLDM_DCENE"]
 NGTDM = ["NGTDM_COARSENESS", "NGTDM_CONTRAST", "NGTDM_BUSYNESS", "NGTDM_COMPLEXITY", "NGTDM_STRENGTH"]
 
+_PQ13 = ["00", "01", "02", "03", "10", "11", "12", "13", "20", "21", "22", "23", "30"]
+_PQ16 = ["%d%d" % (p, q) for p in range(4) for q in range(4)]
+_PQ7 = ["02", "03", "11", "12", "20", "21", "30"]
+_PQ10 = ["00", "01", "02", "03", "10", "11", "12", "20", "21", "30"]
+SMOMS = (["SPAT_MOMENT_" + k for k in _PQ13] + ["CENTRAL_MOMENT_" + k for k in _PQ16] + ["NORM_SPAT_MOMENT_" + k for k in _PQ16]
+         + ["NORM_CENTRAL_MOMENT_" + k for k in _PQ7] + ["HU_M%d" % k for k in range(1, 8)] + ["WEIGHTED_SPAT_MOMENT_" + k for k in _PQ10]
+         + ["WEIGHTED_CENTRAL_MOMENT_" + k for k in _PQ7] + ["WT_NORM_CTR_MOM_" + k for k in _PQ7] + ["WEIGHTED_HU_M%d" % k for k in range(1, 8)])
+IMOMS = (["IMOM_RM_" + k for k in _PQ13] + ["IMOM_CM_" + k for k in _PQ16] + ["IMOM_NRM_" + k for k in _PQ16] + ["IMOM_NCM_" + k for k in _PQ7]
+         + ["IMOM_HU%d" % k for k in range(1, 8)] + ["IMOM_WRM_" + k for k in _PQ10] + ["IMOM_WCM_" + k for k in _PQ7]
+         + ["IMOM_WNCM_" + k for k in _PQ7] + ["IMOM_WHU%d" % k for k in range(1, 8)])
+
 # feature name -> family bit
 FAMILY_OF: Dict[str, int] = {}
 for _n in INTENSITY:
@@ -63,6 +74,10 @@ for _n in GLDM:
     FAMILY_OF[_n] = _abi.FAM_GLDM
 for _n in NGLDM:
     FAMILY_OF[_n] = _abi.FAM_NGLDM
+for _n in SMOMS:
+    FAMILY_OF[_n] = _abi.FAM_SMOMS
+for _n in IMOMS:
+    FAMILY_OF[_n] = _abi.FAM_IMOMS
 FAMILY_OF["GABOR"] = _abi.FAM_GABOR
 FAMILY_OF["ZERNIKE2D"] = _abi.FAM_ZERNIKE
 
@@ -76,11 +91,14 @@ GROUPS: Dict[str, List[str]] = {
     "*ALL_GLDM*": GLDM,
     "*ALL_NGLDM*": NGLDM,
     "*ALL_NGTDM*": NGTDM,
+    "*GEOMOMS*": SMOMS + IMOMS,      # env_features.cpp:316-333
+    "*SGEOMOMS*": SMOMS,
+    "*IGEOMOMS*": IMOMS,
 }
 
 # enum order of every feature code the path covers (one entry per Feature2D code)
 ENUM_ORDER: List[str] = (INTENSITY + GLCM_ANGLED + GLCM_AVE + GLRLM_ANGLED + GLRLM_AVE + GLDZM + GLSZM + GLDM + NGLDM + NGTDM
-                         + ["GABOR", "ZERNIKE2D"])
+                         + ["GABOR", "ZERNIKE2D"] + SMOMS + IMOMS)
 
 
 def expand(features: List[str]) -> Tuple[int, List[str]]:

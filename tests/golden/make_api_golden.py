@@ -65,6 +65,9 @@ def main():
     cases["tile48_dep_gd8"] = run(dep, {"coarse_gray_depth": 8}, inten, seg)
     cases["tile48_dep_gd64_mixed"] = run(["*ALL_GLRLM*", "*ALL_GLSZM*", "*ALL_NGTDM*", "MEAN"] + dep, {}, inten[:1], seg[:1])
     cases["tile48_dep_ibsi"] = run(dep, {"ibsi": True}, (inten[:1] % 9 + 1).astype(np.uint32), seg[:1])
+    # (2c) 2-D geometric moments (contour + weighted moments included)
+    cases["tile48_geomoms"] = run(["*GEOMOMS*"], {}, inten[:2], seg[:2])
+    cases["tile48_sgeomoms_mixed"] = run(["*SGEOMOMS*", "IMOM_HU1", "IMOM_WHU3", "MEAN", "ZERNIKE2D"], {}, inten[:1], seg[:1])
     # (3) negative / float-valued input: shift-and-cast of nyxus.py:480-489
     ct = (rng.normal(0, 300, (1, 32, 32))).astype(np.float32)
     sg = np.zeros((1, 32, 32), np.uint32)

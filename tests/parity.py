@@ -12,8 +12,10 @@ EXACT_COLUMNS = {"MIN", "MAX", "RANGE", "MODE", "MEDIAN", "INTEGRATED_INTENSITY"
                  "UNIFORMITY_PIU", "COVERED_IMAGE_INTENSITY_RANGE", "ROBUST_MEAN"}
 
 
-def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=EXACT_COLUMNS):
-    """Returns a list of human-readable mismatches (empty = parity)."""
+def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=EXACT_COLUMNS, atol=None):
+    """Returns a list of human-readable mismatches (empty = parity).
+    atol: optional {column name: per-row absolute tolerance} for columns that are zero up to cancellation noise by
+    construction (first-order central moments), where neither a relative bound nor the column scale means anything."""
     assert got.shape == want.shape, (got.shape, want.shape)
     bad = []
     for j, name in enumerate(names):
@@ -29,6 +31,20 @@ def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=
             scale = np.nanmax(np.abs(np.where(np.isfinite(w), w, 0.0))) if len(w) else 0.0
             with np.errstate(invalid="ignore"):
                 ok |= np.abs(g - w) <= rel * np.abs(w) + 1e-9 * max(scale, 1.0) * 0 + 1e-12 * max(scale, 1.0)
+        if atol is not None and name in atol:
+            with np.errstate(invalid="ignore"):
+                ok |= np.abs(g - w) <= np.asarray(atol[name])
         for i in np.nonzero(~ok)[0][:3]:
             bad.append(f"{name} roi {i}: got {g[i]!r} want {w[i]!r}")
     return bad
+
+
+def moment_atol(b):
+    """Per-row absolute tolerances for the first-order central moments of a HostBatch: they vanish identically
+    (sum I (x - m10/m00)); what is left is rounding noise of magnitude eps * sum I |x - cx|.  Bound: 1e-9 * m00 * side."""
+    off = np.asarray(b.px_offset).astype(np.int64)
+    m00_s = np.diff(off).astype(float)
+    m00_i = np.array([np.asarray(b.inten[off[r]:off[r + 1]], dtype=float).sum() for r in range(len(m00_s))])
+    side = np.maximum(b.bbox_w, b.bbox_h).astype(float)
+    return {"CENTRAL_MOMENT_01": 1e-9 * m00_s * side, "CENTRAL_MOMENT_10": 1e-9 * m00_s * side,
+            "IMOM_CM_01": 1e-9 * m00_i * side, "IMOM_CM_10": 1e-9 * m00_i * side}

@@ -20,11 +20,12 @@ def _check(ctx, b, mask, s, against_ref=True):
     names = _lib.column_names(mask, s)
     G = ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
-    bad = parity.compare_tables(G, O, names)
+    atol = _moment_atol(b) if mask & (_abi.FAM_SMOMS | _abi.FAM_IMOMS) else None
+    bad = parity.compare_tables(G, O, names, atol=atol)
     assert not bad, "\n".join(bad[:20])
     if against_ref and po.have_ref():
         R = po.ref_featurize(b, mask, s, n_threads=2)
-        bad = parity.compare_tables(G, R, names)
+        bad = parity.compare_tables(G, R, names, atol=atol)
         assert not bad, "vs reference classes:\n" + "\n".join(bad[:20])
     return G
 
@@ -189,7 +190,7 @@ def test_rois_beyond_lds_use_global_workspace(hip_ctx, gd):
     b = _abi.batch_from_rois(rois)
     G = hip_ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
-    assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s), atol=_moment_atol(b))
 
 
 def test_large_roi_gabor_is_exact(hip_ctx):
@@ -339,8 +340,66 @@ def test_dependence_large_rois_and_serpentine_zone(hip_ctx):
     _check(hip_ctx, b, DEP, _abi.default_settings(8), against_ref=False)
 
 
-def test_all_ten_families_one_call(hip_ctx):
+def test_all_twelve_families_one_call(hip_ctx):
     b = synth.tile_batch(4, irregular=True, size=512)
     s = _bank8(_abi.default_settings(8))
     G = _check(hip_ctx, b, _abi.FAM_ALL, s, against_ref=False)
-    assert G.shape[1] == 185 + 80 + 18 + 16 + 14 + 19 + 5 + 8 + 30
+    assert G.shape[1] == 185 + 80 + 18 + 16 + 14 + 19 + 5 + 8 + 30 + 90 + 90
+
+
+# ---- SURVEY 8(f) #4, last item: contour + 2-D geometric moments (roi_moments.hip) ---------------------------------------
+MOM = _abi.FAM_SMOMS | _abi.FAM_IMOMS
+
+
+_moment_atol = parity.moment_atol
+
+
+def _check_moments(ctx, b, mask=MOM, against_ref=True):
+    s = _abi.default_settings(8)
+    names = _lib.column_names(mask, s)
+    G = ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    atol = _moment_atol(b)
+    bad = parity.compare_tables(G, O, names, atol=atol)
+    assert not bad, "\n".join(bad[:20])
+    if against_ref and po.have_ref():
+        bad = parity.compare_tables(G, po.ref_featurize(b, mask, s, n_threads=2), names, atol=atol)
+        assert not bad, "vs reference classes:\n" + "\n".join(bad[:20])
+    return G, names
+
+
+@pytest.mark.parametrize("seed,rmax", [(9, 25), (3, 12), (5, 40)])
+def test_geomoments_random_rois(hip_ctx, seed, rmax):
+    """Irregular ROIs with holes, specks and single pixels: the contour walk (bifurcations, failed chains, X-crossings) and
+    both moment families against the oracle and the reference classes."""
+    _check_moments(hip_ctx, _abi.batch_from_rois(synth.random_rois(60, seed=seed, rmax=rmax)))
+
+
+@pytest.mark.parametrize("fam", [_abi.FAM_SMOMS, _abi.FAM_IMOMS])
+def test_geomoments_single_family_and_with_others(hip_ctx, fam):
+    b = _abi.batch_from_rois(synth.random_rois(30, seed=14))
+    _check_moments(hip_ctx, b, fam)
+    _check_moments(hip_ctx, b, fam | _abi.FAM_INTENSITY | _abi.FAM_ZERNIKE | _abi.FAM_GLDM, against_ref=False)
+
+
+def test_geomoments_reference_goldens_through_hip(hip_ctx):
+    """tests/test_2d_moments_regression.h and test_2d_moments_skimage.h (rectangle + wedge fixtures, scikit-image goldens,
+    |actual - golden| <= 1e-6 * max(1, |golden|, |actual|)) through the HIP path."""
+    ref = fixtures.reference_tests()
+    b = _abi.batch_from_rois([fixtures.geomoment_rectangle_roi(), fixtures.geomoment_wedge_roi()])
+    s = _abi.default_settings(256)
+    T = hip_ctx.featurize_host(b, MOM, s)
+    names = _lib.column_names(MOM, s)
+    assert names == fixtures.SMOM_NAMES + fixtures.IMOM_NAMES
+    for lst, row in [("moments_2d_regression_shape_ref_vals", 0), ("moments_2d_regression_intensity_ref_vals", 0),
+                     ("moments_2d_skimage_shape_ref_vals", 0), ("moments_2d_skimage_intensity_ref_vals", 0),
+                     ("moments_2d_skimage_normraw_shape_ref_vals", 0), ("moments_2d_skimage_normraw_intensity_ref_vals", 0),
+                     ("moments_2d_skimage_wedge_hu_ref_vals", 1)]:
+        for k, v in ref["moment_goldens"][lst].items():
+            got = T[row, names.index(k)]
+            assert np.isfinite(got) and abs(got - v) <= 1e-6 * max(1.0, abs(v), abs(got)), (lst, k, got, v)
+
+
+def test_geomoments_benchmark_tile_and_large_rois(hip_ctx):
+    _check_moments(hip_ctx, synth.tile_batch(2, irregular=True), against_ref=False)
+    _check_moments(hip_ctx, _abi.batch_from_rois(_large_rois(seed=3)), against_ref=False)   # contour planes beyond LDS
