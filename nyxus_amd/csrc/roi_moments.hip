@@ -5,8 +5,9 @@
 //                        + check_loop).  One wave per ROI.  The reference's list algebra (std::list::remove, find_cands over
 //                        the unordered list, ...) is O(C^2); here the contour candidates live as bits of a byte plane of the
 //                        padded bounding box, so "is my 4- / 8-neighbour still unordered" is one LDS read and the loop
-//                        walk is O(C).  The border trace and the loop walk are order-dependent state machines: lane 0
-//                        runs them; plane set-up, the neighbour filter and the X-crossing screen use all lanes.
+//                        walk is O(C).  The border traces are order-dependent state machines replayed by lane 0 (run starts
+//                        come from ballots); the loop walk keeps its state wave-uniform and probes the 8 neighbours with 8 lanes;
+//                        plane set-up, the neighbour filter and the X-crossing screen use all lanes.
 //                        Output: the merged multicontour in walk order (LR::merge_multicontour), padded coordinates
 //                        (the reference adds the bbox origin without removing the one-pixel padding, contour.cpp:673-678).
 //   roi_moments_kernel   features/2d_geomoments_basic.cpp:32-376.  One 256-thread workgroup per ROI, four passes over the
@@ -68,39 +69,49 @@ __global__ __launch_bounds__(64) void roi_contour_kernel(const MomArgs A)
     wav_sync<GS>();
 
     // ---- border image: raster scan with the inside / outside state + Moore trace (contour.cpp:395-493) ----------------
-    if (lane == 0) {
+    // The scan's `inside` flag is false after every blank position, so it only lives inside a horizontal run of pixels:
+    // at the run's first pixel the scan is outside; a border mark switches it inside for the rest of the run, an unmarked
+    // pixel starts a trace (which switches it inside when the trace closes).  Run starts are found 64 positions at a
+    // time with a ballot; lane 0 replays the state machine on each run in raster order (traces change the marks).
+    {
         const int nbo[8] = {-1, -3 - w, -w - 2, -1 - w, 1, 3 + w, w + 2, 1 + w};
         const int nbn[8] = {7, 7, 1, 1, 3, 3, 5, 5};
-        bool inside = false;
-        for (uint32_t p0 = 0; p0 < np; p0++) {
-            const uint8_t v = img[p0];
-            const bool bi = (v & kBorder) != 0, pi = (v & kPix) != 0;
-            if (bi && !inside) inside = true;
-            else if (pi && inside) continue;
-            else if (!pi && inside) inside = false;
-            else if (pi && !inside) {
-                img[p0] = v | kBorder;
-                int pos = (int)p0, loc = 1, counter = 0, counter2 = 0;
-                for (;;) {
-                    const int cp = pos + nbo[loc - 1], nloc = nbn[loc - 1];
-                    if (cp < 0 || (uint32_t)cp >= np) break;
-                    const uint8_t c = img[cp];
-                    if (c & kPix) {
-                        if (cp == (int)p0) {
-                            counter++;
-                            if (nloc == 1 || counter >= 3) { inside = true; break; }
+        for (uint32_t base = 0; base < np; base += 64) {
+            const uint32_t p = base + (uint32_t)lane;
+            const bool run_start = p < np && (img[p] & kPix) && !(p > 0 && (img[p - 1] & kPix));
+            unsigned long long m = __ballot(run_start);
+            if (lane == 0)
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    bool inside = false;
+                    for (uint32_t p0 = base + (uint32_t)b; !inside; p0++) {
+                        const uint8_t v = img[p0];
+                        if (!(v & kPix)) break;                       // the run is over: outside again
+                        if (v & kBorder) { inside = true; break; }    // entering an already discovered border
+                        img[p0] = v | kBorder;                        // undiscovered border point: trace around it
+                        int pos = (int)p0, loc = 1, counter = 0, counter2 = 0;
+                        for (;;) {
+                            const int cp = pos + nbo[loc - 1], nloc = nbn[loc - 1];
+                            if (cp < 0 || (uint32_t)cp >= np) break;
+                            const uint8_t c = img[cp];
+                            if (c & kPix) {
+                                if (cp == (int)p0) {
+                                    counter++;
+                                    if (nloc == 1 || counter >= 3) { inside = true; break; }
+                                }
+                                loc = nloc; pos = cp; counter2 = 0; img[cp] = c | kBorder;
+                            } else {
+                                loc = 1 + (loc % 8);
+                                if (counter2 > 8) break;
+                                counter2++;
+                            }
                         }
-                        loc = nloc; pos = cp; counter2 = 0; img[cp] = c | kBorder;
-                    } else {
-                        loc = 1 + (loc % 8);
-                        if (counter2 > 8) break;
-                        counter2++;
                     }
                 }
-            }
+            wav_sync<GS>();
         }
     }
-    wav_sync<GS>();
     // ---- candidates: border pixels with a border neighbour, bounds as written (:509-552) -----------------------------
     uint32_t n_cand = 0;
     for (uint32_t p = lane; p < np; p += 64) {
@@ -129,57 +140,71 @@ __global__ __launch_bounds__(64) void roi_contour_kernel(const MomArgs A)
     n_x = (uint32_t)wave_sum_u64(n_x);
     n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_cand);
     n_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_x);
-    if (lane == 0) {
-        uint32_t n_u = n_cand;
-        if (n_x != 0)
+    uint32_t n_u = n_cand;
+    if (n_x != 0) {
+        if (lane == 0)
             for (uint32_t p = (uint32_t)W2; p + (uint32_t)W2 < np; p++)
                 if ((img[p] & kAlive) && (img[p - W2] & kAlive) && (img[p + W2] & kAlive) && (img[p - 1] & kAlive) && (img[p + 1] & kAlive)) {
                     img[p] &= (uint8_t)~kAlive;
                     n_u--;
                 }
-        // ---- contour by contour (:587-619) with check_loop (:306-379) on the alive bits --------------------------------
-        uint32_t nK = 0, cursor = 0;
-        while (n_u != 0) {
-            while (!(img[cursor] & kAlive)) cursor++;        // U.front(): the raster-first unordered pixel
-            const int ox = (int)(cursor % (uint32_t)W2), oy = (int)(cursor / (uint32_t)W2);
-            uint32_t ns = 0, nP = 0;
-            int looplen = 0, result = -1;
-            K[nK + ns++] = (uint32_t)ox | ((uint32_t)oy << 16);
-            img[cursor] &= (uint8_t)~kAlive; n_u--;
-            int tx = ox, ty = oy;
-            while (n_u != 0) {
-                // find_cands (:193-216): straight neighbours first, else the diagonal ones; prune_cands keeps the largest dial position
-                int nc = 0, best = -100, bx = 0, by = 0;
-                auto probe = [&](int dx, int dy) {
-                    const int X = tx + dx, Y = ty + dy;
-                    if (X < 0 || Y < 0 || X >= W2 || Y >= H2) return;
-                    if (img[(uint32_t)X + (uint32_t)Y * (uint32_t)W2] & kAlive) {
-                        nc++;
-                        const int d = dial_pos(dx, dy);
-                        if (d > best) { best = d; bx = X; by = Y; }
-                    }
-                };
-                probe(1, 0); probe(-1, 0); probe(0, 1); probe(0, -1);
-                if (nc == 0) { probe(1, 1); probe(1, -1); probe(-1, 1); probe(-1, -1); }
-                if (nc > 1) stk[nP++] = (uint32_t)tx | ((uint32_t)ty << 16);
-                if (nc == 0) {
-                    const int ddx = tx - ox, ddy = ty - oy;
-                    if (ddx == 1 || ddx == -1 || ddy == 1 || ddy == -1) { looplen++; result = looplen; break; }
-                    if (nP == 0) { result = 0; break; }
-                    const uint32_t t = stk[--nP];
-                    tx = (int)(t & 0xFFFFu); ty = (int)(t >> 16);
-                } else {
-                    looplen++;
-                    tx = bx; ty = by;
-                    K[nK + ns++] = (uint32_t)tx | ((uint32_t)ty << 16);
-                    img[(uint32_t)tx + (uint32_t)ty * (uint32_t)W2] &= (uint8_t)~kAlive; n_u--;
-                }
-            }
-            if (result < 0) result = looplen;                 // the list ran empty inside the walk
-            if (result > 0) nK += ns;                         // a closed loop joins the multicontour; a failed chain is dropped
-        }
-        A.n_contour[roi] = nK;
+        n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_u);
+        wav_sync<GS>();
     }
+    // ---- contour by contour (:587-619) with check_loop (:306-379) on the alive bits.  The walk state is wave-uniform;
+    //      lanes 0-3 probe the straight neighbours and lanes 4-7 the diagonal ones, each group ordered by falling dial
+    //      position (W 5, N 3, E 1, S -2; NW 4, NE 2, SE -1, SW -3), so prune_cands' winner is the lowest set lane.
+    const int pdx = lane == 0 ? -1 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? -1 : lane == 5 ? 1 : lane == 6 ? 1 : -1;
+    const int pdy = lane == 0 ? 0 : lane == 1 ? -1 : lane == 2 ? 0 : lane == 3 ? 1 : lane == 4 ? -1 : lane == 5 ? -1 : lane == 6 ? 1 : 1;
+    uint32_t nK = 0, cursor = 0;
+    while (n_u != 0) {
+        for (;;) {                                                // U.front(): the raster-first unordered pixel
+            const uint32_t p = cursor + (uint32_t)lane;
+            const unsigned long long m = __ballot(p < np && (img[p] & kAlive));
+            if (m) { cursor += (uint32_t)__ffsll((long long)m) - 1; break; }
+            cursor += 64;
+        }
+        const int ox = (int)(cursor % (uint32_t)W2), oy = (int)(cursor / (uint32_t)W2);
+        uint32_t ns = 0, nP = 0;
+        int looplen = 0, result = -1;
+        if (lane == 0) { K[nK] = (uint32_t)ox | ((uint32_t)oy << 16); img[cursor] &= (uint8_t)~kAlive; }
+        ns = 1; n_u--;
+        int tx = ox, ty = oy;
+        wav_sync<GS>();
+        while (n_u != 0) {
+            const int X = tx + pdx, Y = ty + pdy;                 // padded coordinates: every neighbour of a pixel is inside the plane
+            const bool alive = lane < 8 && X >= 0 && Y >= 0 && X < W2 && Y < H2 && (img[(uint32_t)X + (uint32_t)Y * (uint32_t)W2] & kAlive);
+            const uint32_t m = (uint32_t)__ballot(alive);
+            const uint32_t cands = (m & 0xFu) ? (m & 0xFu) : (m >> 4);   // find_cands :193-216: straight neighbours first
+            const bool diag = (m & 0xFu) == 0;
+            const int nc = __popc(cands);
+            if (nc > 1) { if (lane == 0) stk[nP] = (uint32_t)tx | ((uint32_t)ty << 16); nP++; }
+            if (nc == 0) {
+                const int ddx = tx - ox, ddy = ty - oy;
+                if (ddx == 1 || ddx == -1 || ddy == 1 || ddy == -1) { looplen++; result = looplen; break; }
+                if (nP == 0) { result = 0; break; }
+                --nP;
+                uint32_t t = lane == 0 ? stk[nP] : 0u;
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                tx = (int)(t & 0xFFFFu); ty = (int)(t >> 16);
+            } else {
+                const int k = (__ffs((int)cands) - 1) + (diag ? 4 : 0);
+                const int bdx = k == 0 ? -1 : k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 0 : k == 4 ? -1 : k == 5 ? 1 : k == 6 ? 1 : -1;
+                const int bdy = k == 0 ? 0 : k == 1 ? -1 : k == 2 ? 0 : k == 3 ? 1 : k == 4 ? -1 : k == 5 ? -1 : k == 6 ? 1 : 1;
+                looplen++;
+                tx += bdx; ty += bdy;
+                if (lane == 0) {
+                    K[nK + ns] = (uint32_t)tx | ((uint32_t)ty << 16);
+                    img[(uint32_t)tx + (uint32_t)ty * (uint32_t)W2] &= (uint8_t)~kAlive;
+                }
+                ns++; n_u--;
+                wav_sync<GS>();
+            }
+        }
+        if (result < 0) result = looplen;                         // the list ran empty inside the walk
+        if (result > 0) nK += ns;                                 // a closed loop joins the multicontour; a failed chain is dropped
+    }
+    if (lane == 0) A.n_contour[roi] = nK;
 }
 
 // ---- moments -----------------------------------------------------------------------------------------------------------
@@ -203,8 +228,16 @@ __device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int
     blk_sync<GS>();
 }
 
-// Pixel2::min_sqdist v2 (pixel.cpp:40-70): hill descent over the ordered contour
-__device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n)
+// (int)(m / log(m)) for the window widths m the hill descent meets; m <= 10 -> 1 (pixel.cpp:47,66)
+__device__ __forceinline__ int descent_step(size_t m, const uint16_t* tab, int tab_n)
+{
+    if (m <= 10) return 1;
+    if ((int)m < tab_n) return (int)tab[m];
+    return (int)((double)m / log((double)m));
+}
+
+// Pixel2::min_sqdist v2 (pixel.cpp:40-70): hill descent over the ordered contour.  step0 = (int)(n / log(n)).
+__device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n, int step0, const uint16_t* tab, int tab_n)
 {
     if (n == 0) return 0.0;
     auto sqd = [&](size_t i) {
@@ -215,7 +248,7 @@ __device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n)
     double extrem_d = sqd(0);
     if (n == 1) return extrem_d;
     size_t a = 0, b = (size_t)n, extrem_i = 0;
-    int step = (int)((double)(b - a) / log((double)(b - a)));
+    int step = step0;
     do {
         for (size_t i = a + (size_t)step; i < b; i += (size_t)step) {
             const double d = sqd(i);
@@ -225,7 +258,7 @@ __device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n)
                      stepR = extrem_i + (size_t)step < (size_t)n ? (size_t)step : (size_t)n - extrem_i;
         a = extrem_i - stepL;
         b = extrem_i + stepR;
-        step = b - a <= 10 ? 1 : (int)((double)(b - a) / log((double)(b - a)));
+        step = descent_step(b - a, tab, tab_n);
     } while (b - a > 2);
     return extrem_d;
 }
@@ -248,11 +281,12 @@ __device__ void hu7(double _02, double _03, double _11, double _12, double _20, 
 } // namespace
 
 // Column layout of one 90-wide block (Feature2D order): RM(13) CM(16) NRM(16) NCM(7) HU(7) WRM(10) WCM(7) WNCM(7) WHU(7)
-__global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
+__global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
 {
     __shared__ double s_red[4 * 16];
     __shared__ double s_raw[2][16], s_cen[2][16], s_wraw[2][10], s_wcen[2][7];
     __shared__ uint32_t s_K[kMomContourLds];
+    __shared__ uint16_t s_step[kMomStepTab];
     const int tid = threadIdx.x;
     const uint64_t roi = blockIdx.x;
     if (roi >= A.n_roi)
@@ -276,16 +310,22 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
     }
     double* const L = A.ws_L + off;
 
-    // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209) ------
-    for (int var = 0; var < 2; var++) {                       // 0 = shape (INTEN = 1), 1 = intensity
-        if (!(var ? do_i : do_s)) continue;
+    // window width -> step of the hill descent (first step from n, later ones from windows of at most two steps)
+    const int step0 = nK >= 2 ? (int)((double)nK / log((double)nK)) : 1;
+    const int tab_n = min(kMomStepTab, 2 * step0 + 2);
+    for (int m = 11 + tid; m < tab_n; m += kMB) s_step[m] = (uint16_t)(int)((double)m / log((double)m));
+
+    // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209);
+    //      one sweep per variant (0 = shape, INTEN = 1; 1 = intensity): 16 accumulators stay in registers
+#pragma unroll 1
+    for (int var = 0; var < 2; var++) {
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
         for (uint32_t i = tid; i < n; i += kMB) {
             const double X = (double)A.x[off + i], Y = (double)A.y[off + i];
             const double I = var ? (double)A.inten[off + i] : 1.0;
-            double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+            const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -295,9 +335,9 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
         if (tid < 16) s_raw[var][tid] = acc[tid];
     }
     __syncthreads();
-    // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316) ------------------------------
+    // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316); each variant has its own origin
+#pragma unroll 1
     for (int var = 0; var < 2; var++) {
-        if (!(var ? do_i : do_s)) continue;
         const double ox = s_raw[var][4] / s_raw[var][0], oy = s_raw[var][1] / s_raw[var][0];
         double acc[16];
 #pragma unroll
@@ -305,7 +345,7 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
         for (uint32_t i = tid; i < n; i += kMB) {
             const double dx = (double)A.x[off + i] - ox, dy = (double)A.y[off + i] - oy;
             const double I = var ? (double)A.inten[off + i] : 1.0;
-            double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+            const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -315,47 +355,59 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
         if (tid < 16) s_cen[var][tid] = acc[tid];
     }
     __syncthreads();
-    // ---- pass 3: log(distance to contour + eps) per pixel (:32-53), weighted raw moments (:283-296) -----------------------
-    for (uint32_t i = tid; i < n; i += kMB) {
-        const double d = sqrt(min_sqdist_v2((int)A.x[off + i], (int)A.y[off + i], K, nK));
-        L[i] = log(d + 0.001);
-    }
-    __syncthreads();
     // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
-    const int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
-    const int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
-    for (int var = 0; var < 2; var++) {
-        if (!(var ? do_i : do_s)) continue;
-        double acc[10];
+    constexpr int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
+    constexpr int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
+    // ---- pass 3: log(distance to contour + eps) per pixel (:32-53) and the weighted raw moments (:283-296); the weighted
+    //      intensity passes through float (realintens is a vector<float>)
+    {
+        double as[10], ai[10];
 #pragma unroll
-        for (int k = 0; k < 10; k++) acc[k] = 0;
+        for (int k = 0; k < 10; k++) { as[k] = 0; ai[k] = 0; }
         for (uint32_t i = tid; i < n; i += kMB) {
-            const double X = (double)A.x[off + i], Y = (double)A.y[off + i];
-            const double I = (double)(float)((var ? (double)A.inten[off + i] : 1.0) * L[i]);   // realintens is vector<float>
-            double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+            const uint32_t xi = A.x[off + i], yi = A.y[off + i];
+            const double lg = log(sqrt(min_sqdist_v2((int)xi, (int)yi, K, nK, step0, s_step, tab_n)) + 0.001);
+            L[i] = lg;
+            const double X = (double)xi, Y = (double)yi;
+            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)A.inten[off + i] * lg);
+            const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
 #pragma unroll
-            for (int k = 0; k < 10; k++) acc[k] += I * xp[wr_p[k]] * yp[wr_q[k]];
+            for (int k = 0; k < 10; k++) {
+                as[k] += Ws * xp[wr_p[k]] * yp[wr_q[k]];
+                ai[k] += Wi * xp[wr_p[k]] * yp[wr_q[k]];
+            }
         }
-        mom_block_sum<10, false>(acc, s_red, tid);
-        if (tid < 10) s_wraw[var][tid] = acc[tid];
+        mom_block_sum<10, false>(as, s_red, tid);
+        mom_block_sum<10, false>(ai, s_red, tid);
+        if (tid < 10) { s_wraw[0][tid] = as[tid]; s_wraw[1][tid] = ai[tid]; }
     }
     __syncthreads();
     // ---- pass 4: weighted central moments about the weighted origin (:162-167, :318-327) -----------------------------------
-    for (int var = 0; var < 2; var++) {
-        if (!(var ? do_i : do_s)) continue;
-        const double ox = s_wraw[var][4] / s_wraw[var][0], oy = s_wraw[var][1] / s_wraw[var][0];
-        double acc[7];
+    {
+        const double oxs = s_wraw[0][4] / s_wraw[0][0], oys = s_wraw[0][1] / s_wraw[0][0];
+        const double oxi = s_wraw[1][4] / s_wraw[1][0], oyi = s_wraw[1][1] / s_wraw[1][0];
+        double as[7], ai[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) acc[k] = 0;
+        for (int k = 0; k < 7; k++) { as[k] = 0; ai[k] = 0; }
         for (uint32_t i = tid; i < n; i += kMB) {
-            const double dx = (double)A.x[off + i] - ox, dy = (double)A.y[off + i] - oy;
-            const double I = (double)(float)((var ? (double)A.inten[off + i] : 1.0) * L[i]);
-            double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+            const double X = (double)A.x[off + i], Y = (double)A.y[off + i], lg = L[i];
+            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)A.inten[off + i] * lg);
+            {
+                const double dx = X - oxs, dy = Y - oys;
+                const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
 #pragma unroll
-            for (int k = 0; k < 7; k++) acc[k] += I * xp[nc_p[k]] * yp[nc_q[k]];
+                for (int k = 0; k < 7; k++) as[k] += Ws * xp[nc_p[k]] * yp[nc_q[k]];
+            }
+            {
+                const double dx = X - oxi, dy = Y - oyi;
+                const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+#pragma unroll
+                for (int k = 0; k < 7; k++) ai[k] += Wi * xp[nc_p[k]] * yp[nc_q[k]];
+            }
         }
-        mom_block_sum<7, false>(acc, s_red, tid);
-        if (tid < 7) s_wcen[var][tid] = acc[tid];
+        mom_block_sum<7, false>(as, s_red, tid);
+        mom_block_sum<7, false>(ai, s_red, tid);
+        if (tid < 7) { s_wcen[0][tid] = as[tid]; s_wcen[1][tid] = ai[tid]; }
     }
     __syncthreads();
     // ---- derived values and output ------------------------------------------------------------------------------------------
@@ -365,14 +417,14 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
         const double* raw = s_raw[var];
         const double* cen = s_cen[var];
         const double m00 = raw[0], w00 = s_wraw[var][0];
-        const int rm_idx[13] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
-        for (int k = 0; k < 13; k++) o[k] = raw[rm_idx[k]];                                       // RM 00..23, 30
+        for (int k = 0; k < 13; k++) o[k] = raw[k];                                       // RM 00..23, 30
         for (int k = 0; k < 16; k++) o[13 + k] = cen[k];                                          // CM
         for (int k = 0; k < 16; k++) {                                                             // NRM :204-209
             const int p = k >> 2, q = k & 3;
             o[29 + k] = raw[k] / pow(m00, (((double)p + (double)q) / 2.0) + 1.0);
         }
         double nu[7], wn[7];
+#pragma unroll
         for (int k = 0; k < 7; k++) {                                                              // NCM :212-217
             nu[k] = cen[nc_p[k] * 4 + nc_q[k]] / pow(m00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
             o[45 + k] = nu[k];
@@ -380,6 +432,7 @@ __global__ __launch_bounds__(kMB) void roi_moments_kernel(const MomArgs A)
         hu7(nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], nu[6], o + 52);
         for (int k = 0; k < 10; k++) o[59 + k] = s_wraw[var][k];                                   // WRM
         for (int k = 0; k < 7; k++) o[69 + k] = s_wcen[var][k];                                    // WCM
+#pragma unroll
         for (int k = 0; k < 7; k++) {                                                              // WNCM :220-225
             wn[k] = s_wcen[var][k] / pow(w00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
             o[76 + k] = wn[k];
