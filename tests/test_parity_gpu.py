@@ -403,3 +403,42 @@ def test_geomoments_reference_goldens_through_hip(hip_ctx):
 def test_geomoments_benchmark_tile_and_large_rois(hip_ctx):
     _check_moments(hip_ctx, synth.tile_batch(2, irregular=True), against_ref=False)
     _check_moments(hip_ctx, _abi.batch_from_rois(_large_rois(seed=3)), against_ref=False)   # contour planes beyond LDS
+
+
+def test_geomoments_adversarial_masks(hip_ctx):
+    """Contour logic on shapes that stress it: noise at several densities, checkerboards, crosses, rings, striped noise,
+    thick diagonals with specks (tools/contour_fuzz.py runs the long version).  Rows whose weighted mass
+    w00 = sum I log(d + eps) cancels to < 5 % of m00 are left out: their normalised weighted columns divide by powers of w00."""
+    rng = np.random.default_rng(2)
+    rois = []
+    for k in range(300):
+        h, w = rng.integers(1, 40, 2)
+        kind = k % 6
+        yy, xx = np.mgrid[0:h, 0:w]
+        if kind == 0:
+            m = rng.random((h, w)) < rng.choice([0.1, 0.3, 0.5, 0.7, 0.9])
+        elif kind == 1:
+            m = (xx + yy) % 2 == 0
+        elif kind == 2:
+            m = np.zeros((h, w), bool); m[rng.integers(0, h), :] = True; m[:, rng.integers(0, w)] = True
+        elif kind == 3:
+            r = np.hypot(xx - w / 2, yy - h / 2); m = (r < min(h, w) / 2) & (r > min(h, w) / 4)
+        elif kind == 4:
+            m = rng.random((h, w)) < 0.6; m[1:-1:2, :] = False
+        else:
+            m = (np.abs(xx - yy) <= 1) | (rng.random((h, w)) < 0.05)
+        if not m.any():
+            m[0, 0] = True
+        ys, xs = np.nonzero(m)
+        rois.append(dict(x=xs - xs.min(), y=ys - ys.min(), inten=rng.integers(1, 500, len(xs)).astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(8)
+    names = _lib.column_names(MOM, s)
+    G = hip_ctx.featurize_host(b, MOM, s)
+    O = po.oracle_featurize(b, MOM, s)
+    ok = (np.abs(O[:, names.index("WEIGHTED_SPAT_MOMENT_00")]) >= 0.05 * O[:, names.index("SPAT_MOMENT_00")]) & \
+         (np.abs(O[:, names.index("IMOM_WRM_00")]) >= 0.05 * O[:, names.index("IMOM_RM_00")])
+    assert ok.sum() > 200
+    atol = {k: v[ok] for k, v in parity.moment_atol(b).items()}
+    bad = parity.compare_tables(G[ok], O[ok], names, atol=atol)
+    assert not bad, "\n".join(bad[:20])
