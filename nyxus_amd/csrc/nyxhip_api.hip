@@ -526,12 +526,18 @@ __global__ void classify_large_kernel(uint64_t n_roi, const uint64_t* px_offset,
         list[atomicAdd(n_out, 1u)] = (uint32_t)i;
 }
 
+__global__ void iota_kernel(uint32_t n, uint32_t* out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 struct Extrema { uint32_t px, area, range, side; };
 
 // Fills the three argument blocks for one set of extrema; `cap` = 0 -> LDS carve-outs, else spill layouts.
 int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
-               const Extrema& E, size_t cap, RoiArgs& a, TexArgs& t, ShapeArgs& g, DepArgs& d, std::string& why)
-{
+               const Extrema& E, size_t cap, RoiArgs& a, TexArgs& t, ShapeArgs& g, DepArgs& d, std::string& why, uint32_t groups = 0xF)
+{   // groups: bit 0 features (INTENSITY + GLCM), 1 texture, 2 shape, 3 dependence -- the kernel groups to build (columns always follow `mask`)
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
     const int n_cols1 = nyxhip_n_columns(mask1, s), n_cols2 = nyxhip_n_columns(mask2, s), n_cols4 = nyxhip_n_columns(mask4, s);
     memset(&a, 0, sizeof(a));
@@ -542,7 +548,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
     int c_glrlm = n_cols1, c_gldzm = c_glrlm + ((mask & NYXHIP_FAM_GLRLM) ? kGlrlmCols : 0);
     int c_glszm = c_gldzm + ((mask & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0), c_gldm = c_glszm + ((mask & NYXHIP_FAM_GLSZM) ? kGlszmCols : 0);
     int c_ngldm = c_gldm + ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0);
-    if (mask1) {
+    if (mask1 && (groups & 1)) {
         if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap))
             return lrc;
         a.n_roi = b->n_roi;
@@ -562,7 +568,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
         a.n_hist = abs(s->grey_depth);
     }
-    if (mask2) {
+    if (mask2 && (groups & 2)) {
         if (int lrc = make_tex_layout(mask2, s, n_cols2, E.area, E.side, t.L, why, cap))
             return lrc;
         t.n_roi = b->n_roi;
@@ -574,7 +580,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         t.gap_after_glszm = ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0) + ((mask & NYXHIP_FAM_NGLDM) ? kNgldmCols : 0);
         t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
     }
-    if (mask4) {
+    if (mask4 && (groups & 8)) {
         if (int lrc = make_dep_layout(mask4, s, E.area, E.side, d.L, why, cap))
             return lrc;
         d.n_roi = b->n_roi;
@@ -585,7 +591,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         d.col_gldzm = c_gldzm; d.col_gldm = c_gldm; d.col_ngldm = c_ngldm;
         d.soft_nan = s->soft_nan; d.grey_depth = s->grey_depth; d.ibsi = s->ibsi;
     }
-    if (mask3) {
+    if (mask3 && (groups & 4)) {
         if (int lrc = make_shape_layout(mask3, s, E.area, g.L, why, cap))
             return lrc;
         g.n_roi = b->n_roi;
@@ -706,7 +712,20 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
             return brc;
     const Extrema full{max_px, max_area, max_range, max_side};
     RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
-    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why);
+    uint32_t groups = 0xF;
+    bool feat_all_gs = false;
+    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why, groups);
+    if (lrc == NYXHIP_ERR_UNSUPPORTED && mask1) {
+        // a GLCM grey depth whose matrix does not fit LDS next to any ROI: the whole INTENSITY + GLCM group runs from the
+        // global workspace instead (slow, but every depth the matrices' 2 GiB offset range allows is served)
+        RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
+        std::string why2;
+        if (build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
+            feat_all_gs = true;
+            groups = 0xE;
+            lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why, groups);
+        }
+    }
     bool need_spill = false;
     Extrema capE = full;
     if (lrc == NYXHIP_ERR_UNSUPPORTED)
@@ -718,7 +737,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         capE.area = std::min<uint32_t>(max_area, 16384);
         capE.side = std::min<uint32_t>(max_side, 256);
         for (int tries = 0; tries < 8; tries++) {
-            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, d, why);
+            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, d, why, groups);
             if (lrc != NYXHIP_ERR_ROI_TOO_LARGE) break;
             capE.px = std::max<uint32_t>(capE.px / 2, 64); capE.area = std::max<uint32_t>(capE.area / 2, 64); capE.side = std::max<uint32_t>(capE.side / 2, 8);
         }
@@ -743,7 +762,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         HIP_TRY(ctx, hipEventRecord(e0, st));
     }
     const uint32_t grid = (uint32_t)b->n_roi;
-    int rc = mask1 ? launch_roi_features(a, st, grid) : 0;
+    int rc = (mask1 && !feat_all_gs) ? launch_roi_features(a, st, grid) : 0;
     if (rc == 0 && mask2)
         rc = launch_roi_texture(t, st, grid);
     if (rc == 0 && mask4)
@@ -757,6 +776,33 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     if (mask & kMoments)
         if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_area, max_side))
             return mrc;
+    if (feat_all_gs) {
+        const size_t list_bytes = 4ull * b->n_roi + 256;
+        if (list_bytes > ctx->spill_list_bytes) {
+            if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
+            ctx->spill_list_bytes = list_bytes;
+        }
+        uint32_t* d_list = ctx->d_spill_list + 64;
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, (uint32_t)b->n_roi, d_list);
+        RoiArgs a3; TexArgs t3; ShapeArgs g3; DepArgs d3;
+        lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a3, t3, g3, d3, why, 1);
+        if (lrc) return fail(ctx, lrc, "global workspace: " + why);
+        const size_t stride3 = ((size_t)a3.L.total + 255) & ~(size_t)255;
+        const uint32_t chunk3 = (uint32_t)std::max<size_t>(1, std::min<size_t>(b->n_roi, ((size_t)4 << 30) / stride3));
+        if (stride3 * chunk3 > ctx->spill_bytes) {
+            if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, stride3 * chunk3));
+            ctx->spill_bytes = stride3 * chunk3;
+        }
+        a3.sp.scratch = ctx->d_spill; a3.sp.stride = stride3;
+        for (uint32_t o = 0; o < (uint32_t)b->n_roi; o += chunk3) {
+            a3.sp.roi_index = d_list + o;
+            rc = launch_roi_features(a3, st, std::min(chunk3, (uint32_t)b->n_roi - o));
+            if (rc != 0)
+                return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+        }
+    }
     if (!need_spill)
         return NYXHIP_OK;
 
@@ -778,10 +824,10 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     if (n_large == 0)
         return NYXHIP_OK;
     RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
-    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, d2, why);
+    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, d2, why, groups);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
     size_t stride = 0;
-    if (mask1) stride = std::max<size_t>(stride, a2.L.total);
+    if (mask1 && !feat_all_gs) stride = std::max<size_t>(stride, a2.L.total);
     if (mask2) stride = std::max<size_t>(stride, t2.L.total);
     if (mask3 & NYXHIP_FAM_GABOR) stride = std::max<size_t>(stride, g2.L.total);
     if (mask4) stride = std::max<size_t>(stride, d2.L.total);
@@ -799,7 +845,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         a2.sp.roi_index = t2.sp.roi_index = g2.sp.roi_index = d2.sp.roi_index = d_list + o;
         a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
         a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
-        rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
+        rc = (mask1 && !feat_all_gs) ? launch_roi_features(a2, st, nb) : 0;
         if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
         if (rc == 0 && mask4) rc = launch_roi_dependence(d2, st, nb);
         if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);

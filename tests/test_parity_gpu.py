@@ -442,3 +442,13 @@ def test_geomoments_adversarial_masks(hip_ctx):
     atol = {k: v[ok] for k, v in parity.moment_atol(b).items()}
     bad = parity.compare_tables(G[ok], O[ok], names, atol=atol)
     assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("gd", [255, 256])
+def test_glcm_grey_depth_beyond_lds_runs_from_the_global_workspace(hip_ctx, gd):
+    """A 256-level co-occurrence matrix (4 x 256 KiB for the four angles) cannot sit in a CU's LDS: the INTENSITY + GLCM
+    group then runs with its scratch in HBM for every ROI; the other families of the call keep their LDS kernels."""
+    b = _abi.batch_from_rois(synth.random_rois(24, seed=31))
+    s = _abi.default_settings(gd)
+    _check(hip_ctx, b, MASK, s)
+    _check(hip_ctx, b, MASK | _abi.FAM_GLRLM | _abi.FAM_NGTDM, s, against_ref=False)
