@@ -61,8 +61,12 @@ class Nyxus:
         if kwargs.get("anisotropy_x", 1.0) != 1.0 or kwargs.get("anisotropy_y", 1.0) != 1.0:
             raise ValueError("anisotropy is outside the MI355X hot path (SURVEY.md section 8)")
 
-        self._mask, self._requested = featureset.expand(list(features))
+        self._features = list(features)
+        self._mask, self._requested = featureset.expand(self._features)
         self._settings = _abi.default_settings(int(coarse_gray_depth), bool(kwargs.get("ibsi", False)))
+        self._env = {"neighbor_distance": neighbor_distance, "pixels_per_micron": pixels_per_micron, "n_feature_calc_threads": n_threads,
+                     "dynamic_range": kwargs.get("dynamic_range", 10000), "min_intensity": kwargs.get("min_intensity", 0.0),
+                     "max_intensity": kwargs.get("max_intensity", 1.0), "ram_limit": kwargs.get("ram_limit", -1), "verbose": verb}
         self.set_gabor_feature_params(
             kersize=kwargs.get("gabor_kersize", 16), gamma=kwargs.get("gabor_gamma", 0.1),
             sig2lam=kwargs.get("gabor_sig2lam", 0.8), f0=kwargs.get("gabor_f0", 0.1),
@@ -195,22 +199,26 @@ class Nyxus:
             raise ValueError(f"Invalid output type {output_type}. Valid output types are {self._valid_output_types}.")
         if output_type != "pandas":
             raise ValueError("arrowipc / parquet writers are outside the MI355X hot path (SURVEY.md section 8); use 'pandas'")
-        from . import tiff_ingest
         rx = re.compile(file_pattern)
         files = sorted(f for f in os.listdir(intensity_dir) if rx.fullmatch(f) and os.path.isfile(os.path.join(label_dir, f)))
+        return self._featurize_file_pairs([os.path.join(intensity_dir, f) for f in files], [os.path.join(label_dir, f) for f in files])
+
+    def _featurize_file_pairs(self, intensity_files: list, mask_files: list):
+        import pandas as pd
+        from . import tiff_ingest
         cols, sel = self._columns()
         str_rows, num_rows = [], []
-        for f in files:
-            I = tiff_ingest.read_tiff(os.path.join(intensity_dir, f))
-            M = tiff_ingest.read_tiff(os.path.join(label_dir, f)).astype(np.uint32)
+        for fi, fm in zip(intensity_files, mask_files):
+            I = tiff_ingest.read_tiff(fi)
+            M = tiff_ingest.read_tiff(fm).astype(np.uint32)
             if I.shape != M.shape:
-                raise ValueError(f"{f}: intensity and mask images differ in shape")
+                raise ValueError(f"{fi}: intensity and mask images differ in shape")
             # slide prescan: min/max of the intensities under any mask (scan_slide_props, slideprops.cpp:456-...)
             fg = I[M != 0]
             smin, smax = (float(fg.min()), float(fg.max())) if fg.size else (0.0, 0.0)
             labels, table = self._featurize_pair(I.astype(np.uint32), M, smin, smax)
             for r in range(len(labels)):
-                str_rows.append([f, f])
+                str_rows.append([os.path.basename(fi), os.path.basename(fm)])
                 num_rows.append(np.concatenate(([float(labels[r]), 0.0], table[r, sel])))
         header = ["intensity_image", "mask_image", "ROI_label", "t_index"] + cols
         string_data = np.array(str_rows, dtype=object).reshape(-1, 2)
@@ -219,3 +227,118 @@ class Nyxus:
         if "ROI_label" in df.columns:
             df.ROI_label = df.ROI_label.astype(np.uint32)
         return df
+
+    def featurize_files(self, intensity_files: list, mask_files: list, single_roi: bool, output_type: Optional[str] = "pandas",
+                        output_path: Optional[str] = ""):
+        """Image file pairs passed as lists (reference nyxus.py:524-593)."""
+        if intensity_files is None:
+            raise IOError("The list of intensity file paths is empty")
+        if mask_files is None and not single_roi:
+            raise IOError("The list of segment file paths is empty. Supply mask images or set single_roi to True")
+        if output_type not in self._valid_output_types:
+            raise ValueError(f"Invalid output type {output_type}. Valid output types are {self._valid_output_types}")
+        if output_type != "pandas":
+            raise ValueError("arrowipc / parquet writers are outside the MI355X hot path (SURVEY.md section 8); use 'pandas'")
+        if single_roi:
+            raise ValueError("single-ROI (whole-slide) featurization is outside the MI355X hot path (SURVEY.md section 8)")
+        if len(intensity_files) != len(mask_files):
+            raise ValueError("intensity_files and mask_files must have the same length")
+        return self._featurize_file_pairs(list(intensity_files), list(mask_files))
+
+    # -- parameters (reference nyxus.py:264-300, :521-522, :703-868) -------------------------------------------------------
+    def use_gpu_device(self, gpu_device_id: int):
+        self._device = max(int(gpu_device_id), 0)
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def set_metaparam(self, paramval: str):
+        """Feature-specific parameter, e.g. "glcm/greydepth=25" (env_metaparams.cpp:63-246)."""
+        err = None
+        sides = paramval.split("=")
+        if len(sides) != 2:
+            err = f'syntax error in "{paramval}": expecting <paramName>=<paramVal>'
+        else:
+            path = sides[0].split("/")
+            if len(path) == 2 and path[0] == "glcm" and path[1] in ("greydepth", "offset"):
+                try:
+                    v = int(sides[1])
+                except ValueError:
+                    err = f'error: cannot parse value "{sides[1]}" of glcm/{path[1]}: expecting an integer'
+                else:
+                    if path[1] == "greydepth":
+                        self._settings.glcm_grey_depth = v     # the degenerate-ROI guard's depth (glcm.cpp:23)
+                    else:
+                        self._settings.glcm_offset = v
+            elif len(path) == 2 and path[0] == "glcm":
+                err = f'error: unrecognized feature parameter of feature glcm: "{path[1]}"'
+            elif len(path) == 2:
+                err = f'error: unrecognized feature "{path[0]}"' if not path[0].startswith("3") else "3-D features are outside the MI355X hot path"
+            else:
+                err = f'syntax error in <paramName>=<paramVal> of "{paramval}": expecting <paramName> to be <feature name>/<parameter name>'
+        if err:
+            raise ValueError(f"Invalid metaparameter value {paramval}: {err}")
+
+    def get_metaparam(self, paramname: str):
+        path = paramname.split("/")
+        if len(path) == 2 and path[0] == "glcm" and path[1] == "greydepth":
+            return float(self._settings.glcm_grey_depth)
+        if len(path) == 2 and path[0] == "glcm" and path[1] == "offset":
+            return float(self._settings.glcm_offset)
+        raise NameError(f"Invalid metaparameter name {paramname}: error: unrecognized feature parameter")
+
+    def set_environment_params(self, **params):
+        valid_params = ["features", "neighbor_distance", "pixels_per_micron", "coarse_gray_depth", "n_feature_calc_threads", "use_gpu_device",
+                        "verbose", "dynamic_range", "min_intensity", "max_intensity", "ram_limit"]
+        for key in params:
+            if key not in valid_params:
+                raise ValueError(f"Invalid environment parameter {key}. Value parameters are {params}")
+        if params.get("features"):
+            self._features = list(params["features"])
+            self._mask, self._requested = featureset.expand(self._features)
+        if params.get("coarse_gray_depth", 0) != 0:      # 0 = "leave as is" (new_bindings_py.cpp set_environment_params_imp)
+            gd = int(params["coarse_gray_depth"])
+            self._settings.grey_depth = gd
+            self._settings.glcm_grey_depth = gd
+        if params.get("use_gpu_device", -1) >= 0:
+            self.use_gpu_device(params["use_gpu_device"])
+        for k, absent in (("neighbor_distance", -1), ("pixels_per_micron", -1), ("n_feature_calc_threads", 0), ("dynamic_range", -1),
+                          ("min_intensity", -1), ("max_intensity", -1), ("ram_limit", -1)):
+            if k in params and params[k] != absent:      # the reference passes these sentinels for "not given" (nyxus.py:745-755)
+                self._env[k] = params[k]
+        if "verbose" in params:
+            self._env["verbose"] = params["verbose"]
+
+    def set_params(self, **params):
+        available = ["features", "neighbor_distance", "pixels_per_micron", "coarse_gray_depth", "n_feature_calc_threads", "use_gpu_device",
+                     "ibsi", "dynamic_range", "min_intensity", "max_intensity", "ram_limit", "verbose"]
+        env, gab = {}, {}
+        for key, value in params.items():
+            if key.startswith("gabor_"):
+                gab[key[len("gabor_"):]] = value
+            elif key == "ibsi":
+                self._settings.ibsi = 1 if value else 0
+            elif key not in available:
+                raise ValueError("Invalid parameter: ", key)
+            else:
+                env[key] = value
+        if gab:
+            self.set_gabor_feature_params(**gab)
+        if env:
+            self.set_environment_params(**env)
+
+    def get_params(self, *args):
+        s = self._settings
+        params = {"features": list(self._features), "neighbor_distance": self._env["neighbor_distance"],
+                  "pixels_per_micron": self._env["pixels_per_micron"], "coarse_gray_depth": int(s.grey_depth),
+                  "n_feature_calc_threads": self._env["n_feature_calc_threads"], "ibsi": bool(s.ibsi),
+                  "gabor_kersize": int(s.gabor_kersize), "gabor_gamma": float(s.gabor_gamma), "gabor_sig2lam": float(s.gabor_sig2lam),
+                  "gabor_f0": float(s.gabor_f0lp), "gabor_thold": float(s.gabor_graythr),
+                  "gabor_freqs": [float(s.gabor_f0[i]) for i in range(s.gabor_n_filters)],
+                  "gabor_thetas": [float(s.gabor_theta[i]) * 180.0 / 3.14159265358979323846 for i in range(s.gabor_n_filters)],   # rad2deg
+                  "dynamic_range": self._env["dynamic_range"], "min_intensity": self._env["min_intensity"],
+                  "max_intensity": self._env["max_intensity"], "ram_limit": self._env["ram_limit"],
+                  "using_gpu": True, "gpu_device_id": self._device}
+        if not args:
+            return params
+        return {k: params[k] for k in args if k in params}

@@ -21,4 +21,14 @@ for name, feats, kw in [("intensity_glcm_gd8", ["*ALL_INTENSITY*", "*ALL_GLCM*"]
                    "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
                    "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
     print(name, df.shape)
+# featurize_files on the same fixture, the dependence / distance-zone families and the moments (file order as given)
+ints = sorted(os.listdir(os.path.join(HERE, "tiff", "int")))
+nyx = nyxus.Nyxus(["*ALL_GLDZM*", "*ALL_GLDM*", "*ALL_NGLDM*", "*SGEOMOMS*", "IMOM_HU1"], coarse_gray_depth=16)
+df = nyx.featurize_files([os.path.join(HERE, "tiff", "int", f) for f in ints], [os.path.join(HERE, "tiff", "seg", f) for f in ints], False)
+num = df.select_dtypes(include=[np.number])
+cases["files_dep_moments_gd16"] = {"features": ["*ALL_GLDZM*", "*ALL_GLDM*", "*ALL_NGLDM*", "*SGEOMOMS*", "IMOM_HU1"], "kwargs": {"coarse_gray_depth": 16},
+                                   "files": ints, "columns": list(df.columns),
+                                   "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
+                                   "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
+print("files", df.shape, nyx.get_params("coarse_gray_depth", "gabor_thetas"))
 json.dump(cases, open(os.path.join(HERE, "api_directory.json"), "w"), separators=(",", ":"))

@@ -71,3 +71,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dp, f)
+
+
+def test_python_parameter_surface_without_a_gpu():
+    """set_params / get_params / set_metaparam / get_metaparam of the reference's Nyxus class (nyxus.py:264-300, :769-868):
+    pure bookkeeping, no device needed."""
+    import nyxus_amd
+    n = nyxus_amd.Nyxus(["*ALL_GLCM*", "MEAN"], coarse_gray_depth=8)
+    assert n.get_params("coarse_gray_depth", "ibsi") == {"coarse_gray_depth": 8, "ibsi": False}
+    n.set_metaparam("glcm/offset=2")
+    assert n.get_metaparam("glcm/offset") == 2.0 and n.get_metaparam("glcm/greydepth") == 8.0
+    n.set_params(gabor_gamma=0.2, gabor_thetas=[0, 30], gabor_freqs=[4, 8], ibsi=True, coarse_gray_depth=16, features=["*ALL_GLDM*"])
+    p = n.get_params()
+    assert p["coarse_gray_depth"] == 16 and p["ibsi"] is True and p["features"] == ["*ALL_GLDM*"]
+    assert abs(p["gabor_gamma"] - 0.2) < 1e-7 and [round(t, 4) for t in p["gabor_thetas"]] == [0.0, 30.0] and p["gabor_freqs"] == [4.0, 8.0]
+    for bad, exc in ((lambda: n.set_metaparam("glcm/bogus=1"), ValueError), (lambda: n.set_metaparam("glcm/offset"), ValueError),
+                     (lambda: n.get_metaparam("glrlm/x"), NameError), (lambda: n.set_params(bogus=1), ValueError),
+                     (lambda: n.featurize_files(None, None, False), IOError), (lambda: n.featurize_files([], [], True), ValueError)):
+        with pytest.raises(exc):
+            bad()
