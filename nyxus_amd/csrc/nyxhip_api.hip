@@ -267,7 +267,8 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     L.val = off;
     if (4ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     off = align16(off + 4u * L.sort_cap);
-    L.cnt = off; off = align16(off + 4u * L.count_cap);
+    L.cnt16 = (do_int && max_px < 65536u) ? 1u : 0u;   // counts and per-wave prefix sums stay below 65536
+    L.cnt = off; off = align16(off + (L.cnt16 ? 2u : 4u) * L.count_cap + 16);
     if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         auto glcm_bytes = [&](uint32_t ng, uint32_t app) -> size_t {

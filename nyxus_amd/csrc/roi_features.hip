@@ -118,12 +118,17 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 // Numerics: marginals and the x+y / |x-y| distributions are formed from exact integer count sums and
 // divided by sum_p once (the reference sums the already divided elements, glcm.cpp:503-508, :523-525: same
 // value to ~1e-16 relative); matrix-wide sums are lane-strided partial sums combined in a fixed order.
-template <bool GS>
+// reductions over the LW lanes that share a matrix; every lane of the group gets the result
+template <int LW> __device__ __forceinline__ double slot_sum(double v) { return LW == 16 ? row16_sum(v) : wave_sum(v); }
+template <int LW> __device__ __forceinline__ uint32_t slot_sum(uint32_t v) { return LW == 16 ? row16_sum(v) : (uint32_t)wave_sum_u64(v); }
+template <int LW> __device__ __forceinline__ double slot_max(double v) { return LW == 16 ? row16_max(v) : wave_max_nonneg(v); }
+
+template <bool GS, int LW>
 __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, const double* Iv, double* scr_base, int scr_stride,
                                    double soft_nan, double* fslots, int lane)
 {
     const int NN = Ng * Ng;
-    const int slot_raw = lane >> 4, l16 = lane & 15;
+    const int slot_raw = lane / LW, l16 = lane % LW;   // LW lanes per matrix: 16 (one DPP row per angle) or 64 (a wave per angle)
     const bool live = slot_raw < n_slots;
     const int slot = live ? slot_raw : 0;              // idle rows shadow slot 0 and never store
     const uint32_t* P = Pslots + slot * NN;
@@ -132,9 +137,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 
     // sum_p (glcm.cpp:481-484): integer counts, exact in any order
     uint32_t csum = 0;
-    for (int e = l16; e < NN; e += 16)
+    for (int e = l16; e < NN; e += LW)
         csum += P[e];
-    csum = row16_sum(csum);
+    csum = slot_sum<LW>(csum);
     const bool empty = csum == 0;                      // glcm.cpp:260-295 -> soft NaN for this angle
     const double sum_p = empty ? 1.0 : (double)csum;
     // per-element probabilities use one reciprocal (<= 1 ulp from cnt / sum_p); marginals and the
@@ -146,7 +151,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     double* Pxpy = scr + 2 * Ng;  // [2Ng]  glcm.cpp:503-508
     double* Pxmy = scr + 4 * Ng;  // [Ng]
 
-    for (int i = l16; i < Ng; i += 16) {
+    for (int i = l16; i < Ng; i += LW) {
         uint32_t cc = 0, rc = 0, dc = 0;
         for (int j = 0; j < Ng; j++) {
             cc += P[j * Ng + i];
@@ -163,7 +168,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
             Pxmy[i] = fdiv((double)dc, sum_p);
         }
     }
-    for (int k = l16; k < 2 * Ng; k += 16) {
+    for (int k = l16; k < 2 * Ng; k += LW) {
         uint32_t c = 0;
         int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
         for (int x = x0; x <= x1; x++)
@@ -175,13 +180,13 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 
     // by_row_mean (glcm.cpp:531-536)
     double brm = 0;
-    for (int i = l16; i < Ng; i += 16)
+    for (int i = l16; i < Ng; i += LW)
         brm += pcol[i] * Iv[i];
-    brm = row16_sum(brm);
+    brm = slot_sum<LW>(brm);
 
     // ---- pass 1 over matrix elements -------------------------------------------------
     double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis_n = 0, hom2 = 0, jmax = -1;
-    for (int e = l16; e < NN; e += 16) {
+    for (int e = l16; e < NN; e += LW) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
@@ -199,9 +204,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         hom2 += fdiv(p, 1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
         jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
     }
-    asm_ = row16_sum(asm_); contrast_n = row16_sum(contrast_n); S_r = row16_sum(S_r); S_c = row16_sum(S_c);
-    acor_n = row16_sum(acor_n); hom1 = row16_sum(hom1); ent = row16_sum(ent); dis_n = row16_sum(dis_n);
-    hom2 = row16_sum(hom2); jmax = row16_max(jmax);
+    asm_ = slot_sum<LW>(asm_); contrast_n = slot_sum<LW>(contrast_n); S_r = slot_sum<LW>(S_r); S_c = slot_sum<LW>(S_c);
+    acor_n = slot_sum<LW>(acor_n); hom1 = slot_sum<LW>(hom1); ent = slot_sum<LW>(ent); dis_n = slot_sum<LW>(dis_n);
+    hom2 = slot_sum<LW>(hom2); jmax = slot_max<LW>(jmax);
     const double mr = S_r / sum_p, mc = fdiv(S_c, sum_p); // mr == f_var's mean == JAVE (exact numerators)
     if (live && l16 == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
@@ -219,7 +224,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 
     // ---- pass 2: central quantities ---------------------------------------------------
     double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
-    for (int e = l16; e < NN; e += 16) {
+    for (int e = l16; e < NN; e += LW) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
@@ -241,9 +246,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         hxy1 += p * lg;
         hxy2 += pp * lg;
     }
-    s2r = row16_sum(s2r); s2c = row16_sum(s2c); tmp1 = row16_sum(tmp1); var_n = row16_sum(var_n);
-    cprom = row16_sum(cprom); cshade = row16_sum(cshade); ctend = row16_sum(ctend); jvar = row16_sum(jvar);
-    hxy1 = row16_sum(hxy1); hxy2 = row16_sum(hxy2);
+    s2r = slot_sum<LW>(s2r); s2c = slot_sum<LW>(s2c); tmp1 = slot_sum<LW>(tmp1); var_n = slot_sum<LW>(var_n);
+    cprom = slot_sum<LW>(cprom); cshade = slot_sum<LW>(cshade); ctend = slot_sum<LW>(ctend); jvar = slot_sum<LW>(jvar);
+    hxy1 = slot_sum<LW>(hxy1); hxy2 = slot_sum<LW>(hxy2);
     if (live && l16 == 0) {
         f[G_VARIANCE] = fdiv(var_n, sum_p);
         f[G_CLUPROM] = cprom;
@@ -261,7 +266,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     // are the last pairs calculatePxpmy writes (glcm.cpp:511-512).
     double idm = 0, dent = 0, idmn = 0, id = 0, idn = 0, iv = 0, hx = 0, davg = 0;
     const double Ng2 = (double)Ng * (double)Ng;
-    for (int k = l16; k < Ng; k += 16) {
+    for (int k = l16; k < Ng; k += LW) {
         double q = Pxmy[k];
         double kval = k == 0 ? 0.0 : fabs(Iv[Ng - 1] - Iv[Ng - 1 - k]);
         idm += fdiv(q, (double)(1 + (k * k)));                   // f_idm :685-687
@@ -275,17 +280,17 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         hx += plogp(pcol[k], pcol[k]);                           // :873-874
         davg += kval * q;                                        // f_difference_avg :791-792
     }
-    idm = row16_sum(idm); dent = row16_sum(dent); idmn = row16_sum(idmn); id = row16_sum(id);
-    idn = row16_sum(idn); iv = row16_sum(iv); hx = row16_sum(hx); davg = row16_sum(davg);
+    idm = slot_sum<LW>(idm); dent = slot_sum<LW>(dent); idmn = slot_sum<LW>(idmn); id = slot_sum<LW>(id);
+    idn = slot_sum<LW>(idn); iv = slot_sum<LW>(iv); hx = slot_sum<LW>(hx); davg = slot_sum<LW>(davg);
     const double diffAvg = davg;
     double savg = 0, sent = 0, dv = 0;
-    for (int k = l16; k < 2 * Ng - 1; k += 16) {
+    for (int k = l16; k < 2 * Ng - 1; k += LW) {
         double q = Pxpy[k];
         int x = k < Ng - 1 ? k : Ng - 1;
         savg += (Iv[x] + Iv[k - x]) * q;                         // f_savg :700-701
         sent += plogp(q, q);                                     // f_sentropy :712-716
     }
-    for (int k = l16; k < Ng; k += 16) {
+    for (int k = l16; k < Ng; k += LW) {
         // f_dvar (glcm.cpp:742-766): var[k] receives the same term Ng times, total / Ng
         double dk = (double)k - diffAvg;
         double t = dk * dk * Pxmy[k], a = 0;
@@ -293,7 +298,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
             a += t;
         dv += a;
     }
-    savg = row16_sum(savg); sent = row16_sum(sent); dv = row16_sum(dv);
+    savg = slot_sum<LW>(savg); sent = slot_sum<LW>(sent); dv = slot_sum<LW>(dv);
     if (live && l16 == 0) {
         f[G_IDM] = idm;
         f[G_SUMAVERAGE] = savg;
@@ -331,8 +336,12 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 #endif
 
 // ---- the fused kernel --------------------------------------------------------------
-template <bool GS>   // GS: per-workgroup scratch in the global workspace instead of LDS (large-ROI launches)
-__global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
+// GS: per-workgroup scratch in the global workspace instead of LDS (large-ROI launches).
+// C16: the counting table holds 16-bit entries (every ROI of the launch has fewer than 65536 pixels): half the LDS, so
+// that -- in the build that asks the compiler for <= 96 VGPRs (roi_features_kernel_occ5) -- five workgroups instead of four
+// share a CU.
+template <bool GS, bool C16>
+__device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
@@ -400,7 +409,8 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
     if (do_int) {
         if (use_count) {
             uint4* c4 = (uint4*)s_cnt;             // count_cap is a multiple of 64 entries
-            for (uint32_t i = tid; i < (range + 4) / 4; i += kBlock)
+            const uint32_t n16 = C16 ? (range + 8) / 8 : (range + 4) / 4;   // 16-byte stores
+            for (uint32_t i = tid; i < n16; i += kBlock)
                 c4[i] = make_uint4(0, 0, 0, 0);
         } else {
             for (uint32_t i = n + tid; i < P2; i += kBlock)
@@ -438,7 +448,11 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 sum += v[u];
                 sumsq += (uint32_t)(v[u] * v[u]); // unsigned-int product, wraps (intensity.cpp:90)
                 if (use_count)
-                    atomicAdd(&s_cnt[v[u] - vmin], 1u);
+                {
+                    const uint32_t ci = v[u] - vmin;
+                    if (C16) atomicAdd(&s_cnt[ci >> 1], 1u << (16 * (ci & 1u)));   // halves never carry: a count is < 65536
+                    else atomicAdd(&s_cnt[ci], 1u);
+                }
             }
             if (do_glcm) {
                 uint32_t lvl = 0;
@@ -503,7 +517,12 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
             for (uint32_t t = 0; t < Q; t += 256) {
                 uint32_t i = base + t + 4 * lane;
                 uint4 c4 = make_uint4(0, 0, 0, 0);
-                if (i + 3 <= range)
+                if (C16) {                                    // four 16-bit entries = one 8-byte access (padding is zero)
+                    if (i <= range) {
+                        const uint2 pk = *(const uint2*)((const uint16_t*)s_cnt + i);
+                        c4 = make_uint4(pk.x & 0xFFFFu, pk.x >> 16, pk.y & 0xFFFFu, pk.y >> 16);
+                    }
+                } else if (i + 3 <= range)
                     c4 = *(const uint4*)&s_cnt[i];
                 else {
                     if (i <= range) c4.x = s_cnt[i];
@@ -523,7 +542,10 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 }
                 uint32_t excl = carry + sc - c4.w;
                 c4.x += excl; c4.y += excl; c4.z += excl; c4.w += excl;
-                if (i + 3 <= range)
+                if (C16) {
+                    if (i <= range)
+                        *(uint2*)((uint16_t*)s_cnt + i) = make_uint2(c4.x | (c4.y << 16), c4.z | (c4.w << 16));
+                } else if (i + 3 <= range)
                     *(uint4*)&s_cnt[i] = c4;
                 else {
                     if (i <= range) s_cnt[i] = c4.x;
@@ -562,7 +584,7 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
         // C(i) = number of values <= vmin + i (counting engine)
         auto cum = [=](uint32_t i) -> uint32_t {
             uint32_t wq = i / Q;
-            return s_cnt[i] + (wq == 0 ? 0u : wq == 1 ? woff1 : wq == 2 ? woff2 : woff3);
+            return (C16 ? (uint32_t)((const uint16_t*)s_cnt)[i] : s_cnt[i]) + (wq == 0 ? 0u : wq == 1 ? woff1 : wq == 2 ? woff2 : woff3);
         };
 
         // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183;
@@ -938,8 +960,12 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
                 }
                 blk_sync<GS>();
                 STAMP(11);
-                if (wave == 0)
-                    glcm_features_rows<GS>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
+                if (Ng <= 16) {                      // small matrices: the four angles share one wave's instruction stream
+                    if (wave == 0)
+                        glcm_features_rows<GS, 16>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
+                } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells
+                    glcm_features_rows<GS, 64>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * A.L.ng_cap, 6 * (int)A.L.ng_cap,
+                                               A.soft_nan, s_f + (a0 + wave) * 32, lane);
             }
             blk_sync<GS>();
             STAMP(12);
@@ -972,6 +998,18 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
     STAMP(14);
 }
 
+template <bool GS, bool C16>
+__global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
+{
+    roi_features_body<GS, C16>(A);
+}
+
+// the same body under a 96-VGPR budget: five workgroups per CU when their LDS fits (16-bit counting table)
+__global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
+{
+    roi_features_body<false, true>(A);
+}
+
 size_t roi_features_max_lds()
 {
     return 160 * 1024; // gfx950: 160 KiB per CU, all of it usable by one workgroup
@@ -981,18 +1019,28 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
-        if (e != hipSuccess)
-            return (int)e;
+        const void* fns[3] = {(const void*)roi_features_kernel<false, false>, (const void*)roi_features_kernel<false, true>,
+                              (const void*)roi_features_kernel_occ5};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+            if (e != hipSuccess)
+                return (int)e;
+        }
         attr_set = true;
     }
     if (grid == 0)
         return 0;
-    if (a.sp.scratch)
-        hipLaunchKernelGGL(roi_features_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    const bool c16 = a.L.cnt16 != 0;
+    if (a.sp.scratch) {
+        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((roi_features_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    } else if (c16 && 5u * a.L.total <= roi_features_max_lds())      // five workgroups fit a CU: the 96-VGPR build
+        hipLaunchKernelGGL(roi_features_kernel_occ5, dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (c16)
+        hipLaunchKernelGGL((roi_features_kernel<false, true>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else
-        hipLaunchKernelGGL(roi_features_kernel<false>, dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((roi_features_kernel<false, false>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     return (int)hipGetLastError();
 }
 
