@@ -265,9 +265,11 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     }
     const uint32_t shared0 = off;
     L.val = off;
-    if (4ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    off = align16(off + 4u * L.sort_cap);
-    L.cnt16 = (do_int && max_px < 65536u) ? 1u : 0u;   // counts and per-wave prefix sums stay below 65536
+    // 16-bit tables: every ROI of the launch counts (range below the table) and has fewer than 65536 pixels, so counts,
+    // per-wave prefix sums and the values' offsets from the ROI minimum all fit 16 bits
+    L.cnt16 = (do_int && max_px < 65536u && (uint64_t)max_range + 1 <= kCountCapMax && max_range < 65536u) ? 1u : 0u;
+    if ((L.cnt16 ? 2ull : 4ull) * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    off = align16(off + (L.cnt16 ? 2u : 4u) * L.sort_cap + 16);
     L.cnt = off; off = align16(off + (L.cnt16 ? 2u : 4u) * L.count_cap + 16);
     if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;

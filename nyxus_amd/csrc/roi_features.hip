@@ -24,6 +24,7 @@
 //
 // Built with -ffp-contract=off (see device_math.h).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "../../include/nyxhip.h"
@@ -337,7 +338,8 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 
 // ---- the fused kernel --------------------------------------------------------------
 // GS: per-workgroup scratch in the global workspace instead of LDS (large-ROI launches).
-// C16: the counting table holds 16-bit entries (every ROI of the launch has fewer than 65536 pixels): half the LDS, so
+// C16: the counting table holds 16-bit entries and the value buffer 16-bit offsets from the ROI minimum (every ROI of the
+// launch has fewer than 65536 pixels and an intensity range the counting engine covers): half the LDS, so
 // that -- in the build that asks the compiler for <= 96 VGPRs (roi_features_kernel_occ5) -- five workgroups instead of four
 // share a CU.
 template <bool GS, bool C16>
@@ -444,7 +446,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             if (i >= n)
                 continue;
             if (do_int) {
-                s_val[i] = v[u];
+                if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v[u] - vmin);   // C16 launches: every ROI counts, range < 16384
+                else s_val[i] = v[u];
                 sum += v[u];
                 sumsq += (uint32_t)(v[u] * v[u]); // unsigned-int product, wraps (intensity.cpp:90)
                 if (use_count)
@@ -591,7 +594,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         // M2..M4 of moments.h:53-74 equal the plain central sums)
         double acc[6] = {0, 0, 0, 0, 0, 0};
         for (uint32_t i = tid; i < n; i += kBlock) {
-            double d = (double)s_val[i] - mean;
+            double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]) - mean;
             double d2 = d * d;
             acc[0] += fabs(d);
             acc[1] += d2;
@@ -785,7 +788,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             const double p10 = s_stat[S_P10], p90 = s_stat[S_P90], median = s_stat[S_MEDIAN];
             double rb[2] = {0, 0};
             for (uint32_t i = tid; i < n; i += kBlock) {
-                double a = (double)s_val[i];
+                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90) {
                     rb[0] += a;
                     rb[1] += 1.0;
@@ -796,7 +799,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             // robust MAD (histogram.h:102-112) and median absolute deviation (intensity.cpp:156-159)
             double ad[2] = {0, 0};
             for (uint32_t i = tid; i < n; i += kBlock) {
-                double a = (double)s_val[i];
+                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90)
                     ad[0] += fabs(a - mean1090);
                 ad[1] += fabs(a - median);
@@ -1004,10 +1007,16 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
     roi_features_body<GS, C16>(A);
 }
 
-// the same body under a 96-VGPR budget: five workgroups per CU when their LDS fits (16-bit counting table)
+// the same body under tighter VGPR budgets (96 / 80): five or six workgroups per CU when their LDS fits (16-bit tables)
+template <bool C16>
 __global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
 {
-    roi_features_body<false, true>(A);
+    roi_features_body<false, C16>(A);
+}
+template <bool C16>
+__global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiArgs A)
+{
+    roi_features_body<false, C16>(A);
 }
 
 size_t roi_features_max_lds()
@@ -1019,8 +1028,9 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[3] = {(const void*)roi_features_kernel<false, false>, (const void*)roi_features_kernel<false, true>,
-                              (const void*)roi_features_kernel_occ5};
+        const void* fns[6] = {(const void*)roi_features_kernel<false, false>, (const void*)roi_features_kernel<false, true>,
+                              (const void*)roi_features_kernel_occ5<true>, (const void*)roi_features_kernel_occ6<true>,
+                              (const void*)roi_features_kernel_occ5<false>, (const void*)roi_features_kernel_occ6<false>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -1035,12 +1045,20 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     if (a.sp.scratch) {
         if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
         else hipLaunchKernelGGL((roi_features_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-    } else if (c16 && 5u * a.L.total <= roi_features_max_lds())      // five workgroups fit a CU: the 96-VGPR build
-        hipLaunchKernelGGL(roi_features_kernel_occ5, dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else if (c16)
-        hipLaunchKernelGGL((roi_features_kernel<false, true>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else
-        hipLaunchKernelGGL((roi_features_kernel<false, false>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    } else {
+        // occupancy follows the carve-out: 6 / 5 / 4 workgroups per CU with builds held to 80 / 96 / 128 VGPRs
+        const size_t lds = roi_features_max_lds();
+        const int occ = 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
+        if (c16) {
+            if (occ == 6) hipLaunchKernelGGL(roi_features_kernel_occ6<true>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+            else if (occ == 5) hipLaunchKernelGGL(roi_features_kernel_occ5<true>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+            else hipLaunchKernelGGL((roi_features_kernel<false, true>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+        } else {
+            if (occ == 6) hipLaunchKernelGGL(roi_features_kernel_occ6<false>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+            else if (occ == 5) hipLaunchKernelGGL(roi_features_kernel_occ5<false>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+            else hipLaunchKernelGGL((roi_features_kernel<false, false>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+        }
+    }
     return (int)hipGetLastError();
 }
 
