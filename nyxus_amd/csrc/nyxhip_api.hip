@@ -33,6 +33,9 @@ struct nyxhip_ctx {
     // grow-only device staging for host-memory batches
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // split GLCM: exported co-occurrence counts + matrix orders (grow-only)
+    uint32_t* d_glcm_ws = nullptr;
+    size_t glcm_ws_bytes = 0;
     // contour + moments workspace (grow-only): contour points, contour lengths, per-pixel log distances
     void* d_mom = nullptr;
     size_t mom_bytes = 0;
@@ -570,6 +573,22 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
         for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
         a.n_hist = abs(s->grey_depth);
+        // small matrices (order <= 16, all angles in one pass, matlab or IBSI level values 1..Ng): the features run as their
+        // own launch with one wave per ROI (glcm_features_kernel); the counts travel through a context-owned workspace
+        const int gi = s->ibsi ? 0 : s->grey_depth;
+        if ((mask1 & NYXHIP_FAM_GLCM) && cap == 0 && gi >= 0 && a.L.ng_cap <= 16 && (int)a.L.app >= s->glcm_n_angles && s->glcm_n_angles > 0) {
+            const size_t stride = (size_t)s->glcm_n_angles * a.L.ng_cap * a.L.ng_cap;
+            const size_t need = 4 * (stride + 1) * (size_t)b->n_roi + 256;
+            if (need > ctx->glcm_ws_bytes) {
+                if (ctx->d_glcm_ws) { (void)hipFree(ctx->d_glcm_ws); ctx->d_glcm_ws = nullptr; ctx->glcm_ws_bytes = 0; }
+                if (hipMalloc((void**)&ctx->d_glcm_ws, need) == hipSuccess) ctx->glcm_ws_bytes = need;
+            }
+            if (ctx->d_glcm_ws && ctx->glcm_ws_bytes >= need) {
+                a.glcm_ng = ctx->d_glcm_ws;
+                a.glcm_ws = ctx->d_glcm_ws + ((b->n_roi + 63) & ~(uint64_t)63);
+                a.glcm_ws_stride = (uint32_t)stride;
+            }
+        }
     }
     if (mask2 && (groups & 2)) {
         if (int lrc = make_tex_layout(mask2, s, n_cols2, E.area, E.side, t.L, why, cap))
@@ -939,6 +958,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_tile) (void)hipFree(ctx->d_tile);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_mom) (void)hipFree(ctx->d_mom);
+    if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);

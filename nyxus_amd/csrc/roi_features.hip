@@ -384,6 +384,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     while (P2 < n)
         P2 <<= 1;
     if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
+        if (!GS && A.glcm_ws && tid == 0)
+            A.glcm_ng[roi] = 0;                       // nothing for glcm_features_kernel (a deferred ROI gets its features in the spill launch)
         if (n != 0 && A.sp.defer_large)
             return;                                   // handled by the spill launch that follows
         if (tid == 0 && n != 0)
@@ -869,6 +871,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             for (int i = tid; i < Ng; i += kBlock)
                 s_I[i] = (double)(i + 1);
 
+        const bool split = !GS && A.glcm_ws != nullptr && !degenerate && !too_big;
+        if (!GS && A.glcm_ws && tid == 0)
+            A.glcm_ng[roi] = split ? (uint32_t)Ng : 0u;
         if (degenerate) {
             for (int c = tid; c < ncol_g; c += kBlock)
                 o[c] = A.soft_nan;
@@ -963,7 +968,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 }
                 blk_sync<GS>();
                 STAMP(11);
-                if (Ng <= 16) {                      // small matrices: the four angles share one wave's instruction stream
+                if (split) {                         // the host set this up only when every angle fits one pass
+                    uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
+                    for (int i = tid; i < na_pass * NN; i += kBlock)
+                        dst[i] = s_P[i];
+                } else if (Ng <= 16) {               // small matrices: the four angles share one wave's instruction stream
                     if (wave == 0)
                         glcm_features_rows<GS, 16>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
                 } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells
@@ -973,10 +982,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             blk_sync<GS>();
             STAMP(12);
             // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
+            if (!split)
             for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
                 int k = c / na, a = c - k * na;
                 o[c] = s_f[a * 32 + k];
             }
+            if (!split)
             for (int j = tid; j < kGlcmAve; j += kBlock) {
                 // calc_ave (glcm.cpp:1205-1214): libstdc++ std::reduce folds four at a time
                 int k = c_glcm_ave_order[j];
@@ -1019,6 +1030,60 @@ __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiA
     roi_features_body<false, C16>(A);
 }
 
+// ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
+// One wave per ROI, the four angles in the wave's four DPP rows (glcm_features_rows<.., 16>), four ROIs per workgroup: every
+// lane of every wave works, where the same code inside roi_features_kernel leaves three of four waves waiting.  Input: the
+// co-occurrence counts roi_features_kernel exported (na * Ng^2 words per ROI, <= 4 KiB); output: the ROI's GLCM columns.
+__global__ __launch_bounds__(kBlock, 6) void glcm_features_kernel(const RoiArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = (uint64_t)blockIdx.x * kWaves + wave;
+    if (roi >= A.n_roi)
+        return;
+    const int Ng = (int)A.glcm_ng[roi];
+    if (Ng == 0)
+        return;                                       // degenerate / skipped ROI: roi_features_kernel wrote the columns
+    const int na = A.glcm_na, ngc = (int)A.L.ng_cap, NN = Ng * Ng;
+    // per-wave carve-out: counts [na * ngc^2] u32 | level values [ngc] | scratch [4][6 * ngc] | features [4][32]  (doubles)
+    const size_t per_wave = (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15) + 8ull * (ngc + kMaxAngles * 6 * ngc + kMaxAngles * 32);
+    unsigned char* base = lds_raw + (size_t)wave * per_wave;
+    uint32_t* s_P = (uint32_t*)base;
+    double* s_I = (double*)(base + (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15));
+    double* s_scr = s_I + ngc;
+    double* s_f = s_scr + kMaxAngles * 6 * ngc;
+    const uint32_t* src = A.glcm_ws + roi * A.glcm_ws_stride;
+    for (int i = lane; i < na * NN; i += 64) s_P[i] = src[i];
+    for (int i = lane; i < Ng; i += 64) s_I[i] = (double)(i + 1);      // level values of the matlab / IBSI paths (glcm.cpp:400-408)
+    wav_sync<false>();
+    glcm_features_rows<false, 16>(s_P, na, Ng, s_I, s_scr, 6 * ngc, A.soft_nan, s_f, lane);
+    wav_sync<false>();
+    double* o = A.out + roi * A.ld + A.col_glcm;
+    for (int c = lane; c < kGlcmAngled * na; c += 64) {           // feature-major, angle-minor (output_2_buffer.cpp:336-346)
+        const int k = c / na, a = c - k * na;
+        o[c] = s_f[a * 32 + k];
+    }
+    for (int j = lane; j < kGlcmAve; j += 64) {                   // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+        const int k = c_glcm_ave_order[j];
+        double init = 0.0;
+        int a = 0;
+        for (; na - a >= 4; a += 4) {
+            const double v1 = s_f[a * 32 + k] + s_f[(a + 1) * 32 + k];
+            const double v2 = s_f[(a + 2) * 32 + k] + s_f[(a + 3) * 32 + k];
+            init = init + (v1 + v2);
+        }
+        for (; a < na; a++)
+            init = init + s_f[a * 32 + k];
+        o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+    }
+}
+
+size_t glcm_features_lds(uint32_t ng_cap)
+{
+    const size_t per_wave = (((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15) + 8ull * (ng_cap + kMaxAngles * 6 * ng_cap + kMaxAngles * 32);
+    return per_wave * kWaves;
+}
+
 size_t roi_features_max_lds()
 {
     return 160 * 1024; // gfx950: 160 KiB per CU, all of it usable by one workgroup
@@ -1059,6 +1124,8 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
             else hipLaunchKernelGGL((roi_features_kernel<false, false>), dim3(grid), dim3(kBlock), a.L.total, st, a);
         }
     }
+    if (a.glcm_ws && !a.sp.scratch)
+        hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
     return (int)hipGetLastError();
 }
 

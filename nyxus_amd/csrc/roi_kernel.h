@@ -70,6 +70,10 @@ struct RoiArgs {
     int32_t grey_depth, ibsi, glcm_grey_depth, glcm_offset, glcm_na, glcm_symmetric;
     int32_t glcm_angles[kMaxAngles];
     int32_t n_hist;          // |grey_depth| = intensity histogram bins
+    // split GLCM (small matrices): this kernel exports the co-occurrence counts, glcm_features_kernel derives the features
+    uint32_t* glcm_ws;       // [n_roi][glcm_ws_stride] counts, angle-major; NULL = features inside this kernel
+    uint32_t* glcm_ng;       // [n_roi] matrix order of the ROI, 0 = nothing to derive (degenerate / skipped ROI)
+    uint32_t glcm_ws_stride; // words per ROI = n_angles * ng_cap^2
     SpillArgs sp;
     LdsLayout L;
 };
