@@ -342,7 +342,8 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 // launch has fewer than 65536 pixels and an intensity range the counting engine covers): half the LDS, so
 // that -- in the build that asks the compiler for <= 96 VGPRs (roi_features_kernel_occ5) -- five workgroups instead of four
 // share a CU.
-template <bool GS, bool C16>
+// SPLIT: the launch exports the GLCM counts for glcm_features_kernel; the in-kernel feature code is compiled out.
+template <bool GS, bool C16, bool SPLIT>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -384,7 +385,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     while (P2 < n)
         P2 <<= 1;
     if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
-        if (!GS && A.glcm_ws && tid == 0)
+        if (SPLIT && tid == 0)
             A.glcm_ng[roi] = 0;                       // nothing for glcm_features_kernel (a deferred ROI gets its features in the spill launch)
         if (n != 0 && A.sp.defer_large)
             return;                                   // handled by the spill launch that follows
@@ -871,8 +872,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             for (int i = tid; i < Ng; i += kBlock)
                 s_I[i] = (double)(i + 1);
 
-        const bool split = !GS && A.glcm_ws != nullptr && !degenerate && !too_big;
-        if (!GS && A.glcm_ws && tid == 0)
+        const bool split = SPLIT && !degenerate && !too_big;
+        if (SPLIT && tid == 0)
             A.glcm_ng[roi] = split ? (uint32_t)Ng : 0u;
         if (degenerate) {
             for (int c = tid; c < ncol_g; c += kBlock)
@@ -968,10 +969,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 }
                 blk_sync<GS>();
                 STAMP(11);
-                if (split) {                         // the host set this up only when every angle fits one pass
+                if (SPLIT) {                         // the host sets this up only when every angle fits one pass
                     uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
                     for (int i = tid; i < na_pass * NN; i += kBlock)
                         dst[i] = s_P[i];
+                } else if (SPLIT) {
                 } else if (Ng <= 16) {               // small matrices: the four angles share one wave's instruction stream
                     if (wave == 0)
                         glcm_features_rows<GS, 16>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
@@ -982,12 +984,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             blk_sync<GS>();
             STAMP(12);
             // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
-            if (!split)
+            if (!SPLIT)
             for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
                 int k = c / na, a = c - k * na;
                 o[c] = s_f[a * 32 + k];
             }
-            if (!split)
+            if (!SPLIT)
             for (int j = tid; j < kGlcmAve; j += kBlock) {
                 // calc_ave (glcm.cpp:1205-1214): libstdc++ std::reduce folds four at a time
                 int k = c_glcm_ave_order[j];
@@ -1012,22 +1014,22 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     STAMP(14);
 }
 
-template <bool GS, bool C16>
+template <bool GS, bool C16, bool SPLIT>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
 {
-    roi_features_body<GS, C16>(A);
+    roi_features_body<GS, C16, SPLIT>(A);
 }
 
 // the same body under tighter VGPR budgets (96 / 80): five or six workgroups per CU when their LDS fits (16-bit tables)
-template <bool C16>
+template <bool C16, bool SPLIT>
 __global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
 {
-    roi_features_body<false, C16>(A);
+    roi_features_body<false, C16, SPLIT>(A);
 }
-template <bool C16>
+template <bool C16, bool SPLIT>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiArgs A)
 {
-    roi_features_body<false, C16>(A);
+    roi_features_body<false, C16, SPLIT>(A);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
@@ -1089,13 +1091,15 @@ size_t roi_features_max_lds()
     return 160 * 1024; // gfx950: 160 KiB per CU, all of it usable by one workgroup
 }
 
-int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
+namespace {
+
+template <bool C16, bool SPLIT>
+int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[6] = {(const void*)roi_features_kernel<false, false>, (const void*)roi_features_kernel<false, true>,
-                              (const void*)roi_features_kernel_occ5<true>, (const void*)roi_features_kernel_occ6<true>,
-                              (const void*)roi_features_kernel_occ5<false>, (const void*)roi_features_kernel_occ6<false>};
+        const void* fns[3] = {(const void*)roi_features_kernel<false, C16, SPLIT>, (const void*)roi_features_kernel_occ5<C16, SPLIT>,
+                              (const void*)roi_features_kernel_occ6<C16, SPLIT>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -1103,30 +1107,36 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
         }
         attr_set = true;
     }
+    // occupancy follows the carve-out: 6 / 5 / 4 workgroups per CU with builds held to 80 / 96 / 128 VGPRs
+    const size_t lds = roi_features_max_lds();
+    const int occ = 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
+    if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else hipLaunchKernelGGL((roi_features_kernel<false, C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace
+
+int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
+{
     if (grid == 0)
         return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = a.L.cnt16 != 0;
     if (a.sp.scratch) {
-        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((roi_features_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-    } else {
-        // occupancy follows the carve-out: 6 / 5 / 4 workgroups per CU with builds held to 80 / 96 / 128 VGPRs
-        const size_t lds = roi_features_max_lds();
-        const int occ = 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
-        if (c16) {
-            if (occ == 6) hipLaunchKernelGGL(roi_features_kernel_occ6<true>, dim3(grid), dim3(kBlock), a.L.total, st, a);
-            else if (occ == 5) hipLaunchKernelGGL(roi_features_kernel_occ5<true>, dim3(grid), dim3(kBlock), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_features_kernel<false, true>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-        } else {
-            if (occ == 6) hipLaunchKernelGGL(roi_features_kernel_occ6<false>, dim3(grid), dim3(kBlock), a.L.total, st, a);
-            else if (occ == 5) hipLaunchKernelGGL(roi_features_kernel_occ5<false>, dim3(grid), dim3(kBlock), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_features_kernel<false, false>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-        }
+        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((roi_features_kernel<true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        return (int)hipGetLastError();
     }
-    if (a.glcm_ws && !a.sp.scratch)
+    const bool split = a.glcm_ws != nullptr;
+    int rc = c16 ? (split ? launch_lds_variant<true, true>(a, st, grid) : launch_lds_variant<true, false>(a, st, grid))
+                 : (split ? launch_lds_variant<false, true>(a, st, grid) : launch_lds_variant<false, false>(a, st, grid));
+    if (rc == 0 && split) {
         hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
-    return (int)hipGetLastError();
+        rc = (int)hipGetLastError();
+    }
+    return rc;
 }
 
 } // namespace nyxhip
