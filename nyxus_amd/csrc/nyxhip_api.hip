@@ -233,7 +233,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     const bool spill = cap != 0;               // scratch in the global workspace: only the 2 GiB offset range limits it
     if (!spill) cap = roi_features_max_lds();
     uint32_t off = 0;
-    L.out = off; off = align16(off + 8u * (uint32_t)n_cols);
+    L.out = off;                               // (the kernel writes its output row in place: no staging copy)
     L.red = off; off = align16(off + 8u * kWaves * 8);
     L.stat = off; off = align16(off + 8u * 16);
     L.lb100 = off; off = align16(off + 4u * 104);

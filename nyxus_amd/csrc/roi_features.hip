@@ -124,7 +124,9 @@ template <int LW> __device__ __forceinline__ double slot_sum(double v) { return 
 template <int LW> __device__ __forceinline__ uint32_t slot_sum(uint32_t v) { return LW == 16 ? row16_sum(v) : (uint32_t)wave_sum_u64(v); }
 template <int LW> __device__ __forceinline__ double slot_max(double v) { return LW == 16 ? row16_max(v) : wave_max_nonneg(v); }
 
-template <bool GS, int LW>
+// TAG only separates instantiations: a non-inlined copy inherits the register budget of its loosest caller, and
+// glcm_features_kernel (128 VGPRs) must not loosen the copy roi_features_kernel's 80-VGPR builds call.
+template <bool GS, int LW, int TAG = 0>
 __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, const double* Iv, double* scr_base, int scr_stride,
                                    double soft_nan, double* fslots, int lane)
 {
@@ -353,7 +355,6 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     if (roi >= A.n_roi)
         return;
 
-    double* s_out = (double*)(lds + A.L.out);
     double* s_red = (double*)(lds + A.L.red);
     double* s_stat = (double*)(lds + A.L.stat);
     uint32_t* s_lb100 = (uint32_t*)(lds + A.L.lb100);
@@ -400,9 +401,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
     const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
 
-    // ---- phase 0: clear LDS state ---------------------------------------------------
+    // ---- phase 0: clear LDS state; the output row is written in place (zeros first: features that are skipped stay 0; every
+    //      later store to the row is separated from these by a workgroup barrier) ----------------------------------------
     for (int c = tid; c < A.n_cols; c += kBlock)
-        s_out[c] = 0.0;
+        out_row[c] = 0.0;
     if (do_glcm) {
         uint32_t* d32 = (uint32_t*)s_dense;       // region is 16-byte aligned and padded
         for (uint32_t i = tid; i < (area + 1) / 2; i += kBlock)
@@ -480,7 +482,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // first-order intensity
     // =====================================================================================
     if (do_int) {
-        double* o = s_out + A.col_intensity;
+        double* o = out_row + A.col_intensity;
         const double dn = (double)n;
         // integer sums are exact in any order (the reference's double accumulation is
         // exact too while partial sums stay below 2^53)
@@ -823,7 +825,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // GLCM
     // =====================================================================================
     if (do_glcm) {
-        double* o = s_out + A.col_glcm;
+        double* o = out_row + A.col_glcm;
         const int na = A.glcm_na;
         const int ncol_g = kGlcmAngled * na + kGlcmAve;
         // degenerate guard (glcm.cpp:27-95) uses GLCM_GREYDEPTH
@@ -1007,10 +1009,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
     }
 
-    blk_sync<GS>();
     STAMP(13);
-    for (int c = tid; c < A.n_cols; c += kBlock)
-        out_row[c] = s_out[c];
     STAMP(14);
 }
 
@@ -1031,12 +1030,17 @@ __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiA
 {
     roi_features_body<false, C16, SPLIT>(A);
 }
+template <bool C16, bool SPLIT>
+__global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiArgs A)
+{
+    roi_features_body<false, C16, SPLIT>(A);
+}
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
 // One wave per ROI, the four angles in the wave's four DPP rows (glcm_features_rows<.., 16>), four ROIs per workgroup: every
 // lane of every wave works, where the same code inside roi_features_kernel leaves three of four waves waiting.  Input: the
 // co-occurrence counts roi_features_kernel exported (na * Ng^2 words per ROI, <= 4 KiB); output: the ROI's GLCM columns.
-__global__ __launch_bounds__(kBlock, 6) void glcm_features_kernel(const RoiArgs A)
+__global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(kBlock, 6) void glcm_features_kernel(const RoiArgs 
     for (int i = lane; i < na * NN; i += 64) s_P[i] = src[i];
     for (int i = lane; i < Ng; i += 64) s_I[i] = (double)(i + 1);      // level values of the matlab / IBSI paths (glcm.cpp:400-408)
     wav_sync<false>();
-    glcm_features_rows<false, 16>(s_P, na, Ng, s_I, s_scr, 6 * ngc, A.soft_nan, s_f, lane);
+    glcm_features_rows<false, 16, 1>(s_P, na, Ng, s_I, s_scr, 6 * ngc, A.soft_nan, s_f, lane);
     wav_sync<false>();
     double* o = A.out + roi * A.ld + A.col_glcm;
     for (int c = lane; c < kGlcmAngled * na; c += 64) {           // feature-major, angle-minor (output_2_buffer.cpp:336-346)
@@ -1098,8 +1102,8 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[3] = {(const void*)roi_features_kernel<false, C16, SPLIT>, (const void*)roi_features_kernel_occ5<C16, SPLIT>,
-                              (const void*)roi_features_kernel_occ6<C16, SPLIT>};
+        const void* fns[4] = {(const void*)roi_features_kernel<false, C16, SPLIT>, (const void*)roi_features_kernel_occ5<C16, SPLIT>,
+                              (const void*)roi_features_kernel_occ6<C16, SPLIT>, (const void*)roi_features_kernel_occ7<C16, SPLIT>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -1107,10 +1111,12 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
         }
         attr_set = true;
     }
-    // occupancy follows the carve-out: 6 / 5 / 4 workgroups per CU with builds held to 80 / 96 / 128 VGPRs
+    // occupancy follows the carve-out: 7 / 6 / 5 / 4 workgroups per CU with builds held to 72 / 80 / 96 / 128 VGPRs
     const size_t lds = roi_features_max_lds();
-    const int occ = 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
-    if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    int occ = 7u * a.L.total <= lds ? 7 : 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
+    if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : atoi(e);   // tuning knob (bench experiments)
+    if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else hipLaunchKernelGGL((roi_features_kernel<false, C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     return (int)hipGetLastError();
