@@ -259,8 +259,15 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     // the dense plane is written during the load phase and stays separate.
     L.dense_cap = do_glcm ? max_area : 0;
     L.dense = off;
-    if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    off = align16(off + 2u * L.dense_cap);
+    {   // 8-bit plane: matlab binning up to 16 levels in a launch that also gets the 16-bit tables and the split GLCM features
+        // (build_args sets the split up under the same conditions) -- the carve-out of the benchmark ROI then fits 8 times per CU
+        const int gi = s->ibsi ? 0 : s->grey_depth;
+        const bool c16_pred = do_int && max_px < 65536u && (uint64_t)max_range + 1 <= kCountCapMax && max_range < 65536u;
+        const bool split_pred = do_glcm && !spill && gi > 0 && gi <= 16 && s->glcm_n_angles > 0;
+        L.dense8 = (c16_pred && split_pred) ? 1u : 0u;
+    }
+    if ((L.dense8 ? 1ull : 2ull) * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    off = align16(off + (L.dense8 ? 1u : 2u) * L.dense_cap + 8);
     if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         L.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0;
@@ -583,7 +590,11 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
                 if (ctx->d_glcm_ws) { (void)hipFree(ctx->d_glcm_ws); ctx->d_glcm_ws = nullptr; ctx->glcm_ws_bytes = 0; }
                 if (hipMalloc((void**)&ctx->d_glcm_ws, need) == hipSuccess) ctx->glcm_ws_bytes = need;
             }
-            if (ctx->d_glcm_ws && ctx->glcm_ws_bytes >= need) {
+            if (!(ctx->d_glcm_ws && ctx->glcm_ws_bytes >= need)) {
+                why = "out of device memory for the GLCM count workspace";
+                return NYXHIP_ERR_HIP;
+            }
+            {
                 a.glcm_ng = ctx->d_glcm_ws;
                 a.glcm_ws = ctx->d_glcm_ws + ((b->n_roi + 63) & ~(uint64_t)63);
                 a.glcm_ws_stride = (uint32_t)stride;

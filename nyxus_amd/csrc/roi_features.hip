@@ -24,6 +24,7 @@
 //
 // Built with -ffp-contract=off (see device_math.h).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
@@ -345,7 +346,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 // that -- in the build that asks the compiler for <= 96 VGPRs (roi_features_kernel_occ5) -- five workgroups instead of four
 // share a CU.
 // SPLIT: the launch exports the GLCM counts for glcm_features_kernel; the in-kernel feature code is compiled out.
-template <bool GS, bool C16, bool SPLIT>
+// D8: the binned bounding-box plane holds 8-bit levels (grey depth <= 254); with C16 and SPLIT this brings the benchmark's
+// carve-out under 20 KiB: eight workgroups per CU.
+template <bool GS, bool C16, bool SPLIT, bool D8>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -360,7 +363,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     uint32_t* s_lb100 = (uint32_t*)(lds + A.L.lb100);
     uint32_t* s_lbc = (uint32_t*)(lds + A.L.lbc);
     uint32_t* s_val = (uint32_t*)(lds + A.L.val);
-    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
+    using dense_t = typename std::conditional<D8, uint8_t, uint16_t>::type;
+    dense_t* s_dense = (dense_t*)(lds + A.L.dense);
     uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);
     uint32_t* s_P = (uint32_t*)(lds + A.L.P);
     double* s_g = (double*)(lds + A.L.gscr);
@@ -386,7 +390,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     while (P2 < n)
         P2 <<= 1;
     if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
-        if (SPLIT && tid == 0)
+        if (SPLIT && A.glcm_ng && tid == 0)
             A.glcm_ng[roi] = 0;                       // nothing for glcm_features_kernel (a deferred ROI gets its features in the spill launch)
         if (n != 0 && A.sp.defer_large)
             return;                                   // handled by the spill launch that follows
@@ -407,7 +411,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         out_row[c] = 0.0;
     if (do_glcm) {
         uint32_t* d32 = (uint32_t*)s_dense;       // region is 16-byte aligned and padded
-        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlock)
+        for (uint32_t i = tid; i < (D8 ? (area + 3) / 4 : (area + 1) / 2); i += kBlock)
             d32[i] = 0;
         if (greyInfo < 0)
             for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
@@ -472,7 +476,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     lvl_max = lvl > lvl_max ? lvl : lvl_max;
                 }
                 if (px[u] < w && py[u] < h)
-                    s_dense[py[u] * w + px[u]] = (uint16_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+                    s_dense[py[u] * w + px[u]] = (dense_t)(lvl > (D8 ? 0xFFu : 0xFFFFu) ? (D8 ? 0xFFu : 0xFFFFu) : lvl);
             }
         }
     }
@@ -1013,27 +1017,31 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     STAMP(14);
 }
 
-template <bool GS, bool C16, bool SPLIT>
+template <bool GS, bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
 {
-    roi_features_body<GS, C16, SPLIT>(A);
+    roi_features_body<GS, C16, SPLIT, D8>(A);
 }
 
 // the same body under tighter VGPR budgets (96 / 80): five or six workgroups per CU when their LDS fits (16-bit tables)
-template <bool C16, bool SPLIT>
+template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT>(A);
+    roi_features_body<false, C16, SPLIT, D8>(A);
 }
-template <bool C16, bool SPLIT>
+template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT>(A);
+    roi_features_body<false, C16, SPLIT, D8>(A);
 }
-template <bool C16, bool SPLIT>
+template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT>(A);
+    roi_features_body<false, C16, SPLIT, D8>(A);
+}
+__global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
+{
+    roi_features_body<false, true, true, true>(A);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
@@ -1097,13 +1105,14 @@ size_t roi_features_max_lds()
 
 namespace {
 
-template <bool C16, bool SPLIT>
+template <bool C16, bool SPLIT, bool D8>
 int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {(const void*)roi_features_kernel<false, C16, SPLIT>, (const void*)roi_features_kernel_occ5<C16, SPLIT>,
-                              (const void*)roi_features_kernel_occ6<C16, SPLIT>, (const void*)roi_features_kernel_occ7<C16, SPLIT>};
+        const void* fns[5] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
+                              (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
+                              (const void*)roi_features_kernel_occ8};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -1111,14 +1120,17 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
         }
         attr_set = true;
     }
-    // occupancy follows the carve-out: 7 / 6 / 5 / 4 workgroups per CU with builds held to 72 / 80 / 96 / 128 VGPRs
+    // occupancy follows the carve-out: 8 / 7 / 6 / 5 / 4 workgroups per CU with builds held to 64 / 72 / 80 / 96 / 128 VGPRs
     const size_t lds = roi_features_max_lds();
-    int occ = 7u * a.L.total <= lds ? 7 : 6u * a.L.total <= lds ? 6 : 5u * a.L.total <= lds ? 5 : 4;
-    if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : atoi(e);   // tuning knob (bench experiments)
-    if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else hipLaunchKernelGGL((roi_features_kernel<false, C16, SPLIT>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    int occ = 4;
+    for (int o = (C16 && SPLIT && D8) ? 8 : 7; o > 4; o--)
+        if ((size_t)o * a.L.total <= lds) { occ = o; break; }
+    if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
+    if (occ == 8) hipLaunchKernelGGL(roi_features_kernel_occ8, dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else hipLaunchKernelGGL((roi_features_kernel<false, C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1131,13 +1143,17 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = a.L.cnt16 != 0;
     if (a.sp.scratch) {
-        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((roi_features_kernel<true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((roi_features_kernel<true, false, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
         return (int)hipGetLastError();
     }
     const bool split = a.glcm_ws != nullptr;
-    int rc = c16 ? (split ? launch_lds_variant<true, true>(a, st, grid) : launch_lds_variant<true, false>(a, st, grid))
-                 : (split ? launch_lds_variant<false, true>(a, st, grid) : launch_lds_variant<false, false>(a, st, grid));
+    // dense8 is set by the host only together with the 16-bit tables and the split; an intensity-only launch never touches
+    // the GLCM code, so it can run the fully compact build (and its 64-VGPR tier) as well
+    const bool d8 = a.L.dense8 != 0 || (c16 && !(a.mask & NYXHIP_FAM_GLCM));
+    int rc = d8 ? launch_lds_variant<true, true, true>(a, st, grid)
+           : c16 ? (split ? launch_lds_variant<true, true, false>(a, st, grid) : launch_lds_variant<true, false, false>(a, st, grid))
+                 : (split ? launch_lds_variant<false, true, false>(a, st, grid) : launch_lds_variant<false, false, false>(a, st, grid));
     if (rc == 0 && split) {
         hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
         rc = (int)hipGetLastError();

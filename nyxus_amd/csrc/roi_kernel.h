@@ -39,6 +39,7 @@ struct LdsLayout {
     uint32_t sort_cap;   // >= max_px (a power of two when the sort engine may run)
     uint32_t count_cap;  // intensity ranges below this use the counting engine (0 = never)
     uint32_t cnt16;      // 1: 16-bit counting table (every ROI of the launch has < 65536 pixels)
+    uint32_t dense8;     // 1: 8-bit binned plane (grey depth <= 254; only together with cnt16 and the split GLCM launch)
     uint32_t dense_cap;  // >= max bbox area
     uint32_t ng_cap;     // max GLCM matrix order held in LDS
     uint32_t lvl_cap;    // number of radiomics bins
