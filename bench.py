@@ -181,7 +181,8 @@ def main():
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "roi_features_kernel", "kernel_ms": kern_ms, "launches": int(n_launch),
+                         "kernel": "roi_features_kernel (+ glcm_features_kernel: one launch group, timed together)" if mask == 3 else "reduce launch group",
+                         "kernel_ms": kern_ms, "launches": int(n_launch),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
 

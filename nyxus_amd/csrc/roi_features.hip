@@ -504,6 +504,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
         const double mean = tot / dn;
         const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
+        if (tid == 0) {                                // the sums' own outputs leave the registers right away
+            o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
+            o[I_MAX] = (double)vmax;
+            o[I_RANGE] = (double)vmax - (double)vmin;
+            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
+                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
+            o[I_MEAN] = mean;                          // intensity.cpp:95-99
+            o[I_ENERGY] = totsq;
+            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
+            o[I_INTEGRATED_INTENSITY] = tot;
+            if (!blank)
+                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
+        }
         blk_sync<GS>();
         STAMP(2);
 
@@ -614,15 +627,6 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
         block_sum<6, GS>(acc, s_red, tid);
         if (tid == 0) { // everything that depends only on the sums leaves the registers now
-            o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
-            o[I_MAX] = (double)vmax;
-            o[I_RANGE] = (double)vmax - (double)vmin;
-            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
-                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
-            o[I_MEAN] = mean;                          // intensity.cpp:95-99
-            o[I_ENERGY] = totsq;
-            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
-            o[I_INTEGRATED_INTENSITY] = tot;
             const double var = acc[1];                 // intensity.cpp:110-118
             o[I_MEAN_ABSOLUTE_DEVIATION] = fdiv(acc[0], dn);
             const double variance = dn > 1 ? fdiv(var, dn - 1) : 0.0;
@@ -635,7 +639,6 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             o[I_COV] = sd / mean;
             o[I_STANDARD_ERROR] = fdiv(sd, sqrt(dn));
             if (!blank) {
-                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
                 const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
                 if (M2 != 0.0) {
                     o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / (M2 * sqrt(M2)) : 0.0;   // pow(M2, 1.5)

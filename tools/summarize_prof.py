@@ -30,6 +30,19 @@ if d:
     ns = [x[0] for x in d]
     print(f"dispatches {len(d)} avg {sum(ns)/len(ns)/1e6:.3f} ms min {min(ns)/1e6:.3f} max {max(ns)/1e6:.3f}  vgpr {d[0][1]} sgpr {d[0][2]} lds {d[0][3]} grid_x {d[0][4]} wg_x {d[0][5]}")
 
+# the launch group bench.py times with HIP events = roi_features_kernel (+ glcm_features_kernel when the GLCM features run
+# as their own launch): average duration of each on the metric workload, and their sum
+g = []
+for f, r in rows("trace/**/*kernel_trace.csv"):
+    if "glcm_features_kernel" in r.get("Kernel_Name", ""):
+        g.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r.get("Grid_Size_X") or 0)))
+if g:
+    gmax = max(x[1] for x in g)
+    gn = [x[0] for x in g if x[1] == gmax]
+    k1 = sum(ns) / len(ns) / 1e6 if d else 0.0
+    k2 = sum(gn) / len(gn) / 1e6
+    print(f"== launch group: roi_features_kernel {k1:.3f} ms + glcm_features_kernel {k2:.3f} ms = {k1 + k2:.3f} ms ==")
+
 print("== PMC (per dispatch of roi_features_kernel, averaged) ==")
 acc = defaultdict(list)
 for f, r in rows("pmc_*/**/*counter_collection.csv"):
