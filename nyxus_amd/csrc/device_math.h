@@ -159,6 +159,17 @@ __device__ __forceinline__ T wave_sum_t(T v)
     v += dpp_mov0<0x143, 0xC>(v);   // rows 2,3 += lane 31
     return readlane63(v);
 }
+// inclusive prefix sum over the 64 lanes (the same six DPP steps, without the broadcast)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v)
+{
+    v += dpp_mov0<0x111, 0xF>(v);
+    v += dpp_mov0<0x112, 0xF>(v);
+    v += dpp_mov0<0x114, 0xF>(v);
+    v += dpp_mov0<0x118, 0xF>(v);
+    v += dpp_mov0<0x142, 0xA>(v);
+    v += dpp_mov0<0x143, 0xC>(v);
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_t<double>(v); }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) { return wave_sum_t<unsigned long long>(v); }
 

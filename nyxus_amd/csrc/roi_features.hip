@@ -559,12 +559,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 if (c4.z > best_c) { best_c = c4.z; best_i = i + 2; }
                 if (c4.w > best_c) { best_c = c4.w; best_i = i + 3; }
                 c4.y += c4.x; c4.z += c4.y; c4.w += c4.z;
-                uint32_t sc = c4.w;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    uint32_t up = __shfl_up(sc, d, 64);
-                    if (lane >= d) sc += up;
-                }
+                const uint32_t sc = wave_scan_u32(c4.w);
                 uint32_t excl = carry + sc - c4.w;
                 c4.x += excl; c4.y += excl; c4.z += excl; c4.w += excl;
                 if (C16) {
@@ -577,13 +572,14 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     if (i + 1 <= range) s_cnt[i + 1] = c4.y;
                     if (i + 2 <= range) s_cnt[i + 2] = c4.z;
                 }
-                carry += __shfl(sc, 63, 64);
+                carry += readlane63(sc);
             }
             // wave-level best (count desc, index asc)
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                uint32_t oc = __shfl_down(best_c, d, 64), oi = __shfl_down(best_i, d, 64);
-                if (oc > best_c || (oc == best_c && oi < best_i)) { best_c = oc; best_i = oi; }
+            {   // (count desc, index asc) as one key: the largest count wins, ties go to the smallest index
+                const uint32_t mc_w = wave_max_u32(best_c);
+                const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
+                best_i = ~wave_max_u32(~cand);                  // min over the lanes that hold the maximum
+                best_c = mc_w;
             }
             if (lane == 0) {
                 s_red[wave * 8 + 0] = (double)carry;
@@ -926,15 +922,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     const int r_begin = wave * rows_per_wave;
                     const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                     const bool in_col = lane < (int)w;
-                    const bool has_right = lane + 1 < (int)w;
                     const bool remap = greyInfo < 0;
                     uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
                     if (remap && cur) cur = s_lvlmap[cur];
-                    // one (centre, neighbour) pair into the matrix of its direction
-                    auto bump = [=](int sl, uint32_t c, uint32_t nbv) {
-                        if (sl >= 0 && c != 0 && nbv != 0) {
-                            uint32_t* Pq = s_P + sl * NN;
-                            atomicAdd(&Pq[(c - 1) * (uint32_t)Ng + (nbv - 1)], 1u);
+                    // one (centre, neighbour) pair into the matrix of its direction.  The centre's row offset is shared by the
+                    // four directions; lanes beyond the last column hold level 0, so the right-hand neighbours of the last column
+                    // are "skip" without a separate test.
+                    uint32_t* const P0 = slot0 >= 0 ? s_P + slot0 * NN : nullptr;
+                    uint32_t* const P1 = slot1 >= 0 ? s_P + slot1 * NN : nullptr;
+                    uint32_t* const P2m = slot2 >= 0 ? s_P + slot2 * NN : nullptr;
+                    uint32_t* const P3 = slot3 >= 0 ? s_P + slot3 * NN : nullptr;
+                    auto bump = [=](uint32_t* Pq, uint32_t cbase, uint32_t c, uint32_t nbv) {
+                        if (Pq != nullptr && nbv != 0) {
+                            atomicAdd(&Pq[cbase + nbv - 1], 1u);
                             if (symmetric)
                                 atomicAdd(&Pq[(nbv - 1) * (uint32_t)Ng + (c - 1)], 1u);
                         }
@@ -942,14 +942,16 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     for (int row = r_begin; row < r_end; row++) {
                         uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
                         if (remap && nxt) nxt = s_lvlmap[nxt];      // compact index + 1 (0 stays "skip")
-                        uint32_t nb_e = lane_plus1(cur, 0);          // (row,   col+1)  angle 0
-                        uint32_t nb_se = lane_plus1(nxt, 0);         // (row+1, col+1)  angle 45
-                        uint32_t nb_sw = lane_minus1(nxt, 0);        // (row+1, col-1)  angle 135
-                        if (!has_right) { nb_e = 0; nb_se = 0; }
-                        bump(slot0, cur, nb_e);
-                        bump(slot1, cur, nb_se);
-                        bump(slot2, cur, nxt);                       // (row+1, col)    angle 90
-                        bump(slot3, cur, nb_sw);
+                        const uint32_t nb_e = lane_plus1(cur, 0);    // (row,   col+1)  angle 0
+                        const uint32_t nb_se = lane_plus1(nxt, 0);   // (row+1, col+1)  angle 45
+                        const uint32_t nb_sw = lane_minus1(nxt, 0);  // (row+1, col-1)  angle 135
+                        if (cur != 0) {
+                            const uint32_t cbase = (cur - 1) * (uint32_t)Ng;
+                            bump(P0, cbase, cur, nb_e);
+                            bump(P1, cbase, cur, nb_se);
+                            bump(P2m, cbase, cur, nxt);              // (row+1, col)    angle 90
+                            bump(P3, cbase, cur, nb_sw);
+                        }
                         cur = nxt;
                     }
                 } else
