@@ -439,15 +439,18 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // four pixels per thread per trip: all global loads of a trip are issued before the first
     // use, so one HBM round trip covers 1024 pixels of the workgroup
     constexpr int kU = 4;
+    const uint32_t* const pin = A.inten + off;
+    const uint16_t* const pxs = A.x + off;
+    const uint16_t* const pys = A.y + off;
     for (uint32_t base = 0; base < n; base += kU * kBlock) {
         uint32_t v[kU], px[kU], py[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
             uint32_t i = base + u * kBlock + tid;
             bool ok = i < n;
-            v[u] = ok ? A.inten[off + i] : 0u;
-            px[u] = (ok && do_glcm) ? (uint32_t)A.x[off + i] : 0u;
-            py[u] = (ok && do_glcm) ? (uint32_t)A.y[off + i] : 0u;
+            v[u] = ok ? pin[i] : 0u;                // uniform base + 32-bit lane offset
+            px[u] = (ok && do_glcm) ? (uint32_t)pxs[i] : 0u;
+            py[u] = (ok && do_glcm) ? (uint32_t)pys[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kU; u++) {
@@ -473,10 +476,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         : greyInfo < 0 ? bin_radiomix(v[u], vmin, vmax, -greyInfo) : v[u];
                     if (greyInfo < 0)
                         s_lvlmap[lvl] = 1;
-                    lvl_max = lvl > lvl_max ? lvl : lvl_max;
+                    if (greyInfo <= 0)                 // only the IBSI / radiomics paths derive the matrix order from the data
+                        lvl_max = lvl > lvl_max ? lvl : lvl_max;
                 }
                 if (px[u] < w && py[u] < h)
-                    s_dense[py[u] * w + px[u]] = (dense_t)(lvl > (D8 ? 0xFFu : 0xFFFFu) ? (D8 ? 0xFFu : 0xFFFFu) : lvl);
+                    s_dense[py[u] * w + px[u]] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
             }
         }
     }
@@ -794,29 +798,30 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
             // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
             const double p10 = s_stat[S_P10], p90 = s_stat[S_P90], median = s_stat[S_MEDIAN];
-            double rb[2] = {0, 0};
+            // sweep 1: sum and count inside [p10, p90], and the median absolute deviation (it only needs the median)
+            double rb[3] = {0, 0, 0};
             for (uint32_t i = tid; i < n; i += kBlock) {
                 double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90) {
                     rb[0] += a;
                     rb[1] += 1.0;
                 }
+                rb[2] += fabs(a - median);
             }
-            block_sum<2, GS>(rb, s_red, tid);
+            block_sum<3, GS>(rb, s_red, tid);
             const double mean1090 = rb[1] > 0 ? rb[0] / rb[1] : 0.0;
-            // robust MAD (histogram.h:102-112) and median absolute deviation (intensity.cpp:156-159)
-            double ad[2] = {0, 0};
+            // sweep 2: robust MAD about that mean (histogram.h:102-112)
+            double ad[1] = {0};
             for (uint32_t i = tid; i < n; i += kBlock) {
                 double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90)
                     ad[0] += fabs(a - mean1090);
-                ad[1] += fabs(a - median);
             }
-            block_sum<2, GS>(ad, s_red, tid);
+            block_sum<1, GS>(ad, s_red, tid);
             if (tid == 0) {
                 o[I_ROBUST_MEAN] = mean1090;
                 o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
-                o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(ad[1], dn);
+                o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(rb[2], dn);
             }
         }
 
