@@ -365,13 +365,26 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
     return NYXHIP_OK;
 }
 
-int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, ShapeLayout& L, std::string& why, size_t cap = 0)
+int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, uint32_t max_side, ShapeLayout& L, std::string& why, size_t cap = 0)
 {
     memset(&L, 0, sizeof(L));
+    const bool spill = cap != 0;
     if (cap == 0) cap = roi_features_max_lds();
     if (!(mask & NYXHIP_FAM_GABOR))
         return NYXHIP_OK;
     uint32_t off = 0;
+    if (!spill && s->gabor_kersize == 16) {
+        // register-tiled kernel: one zero-padded u32 plane, (roundup(w, 8) + 16) x (h + 15) words <= area + 38 side + 345
+        L.tiled = 1;
+        L.red = off; off = align16(off + 8u * kWaves * NYXHIP_MAX_GABOR_FILTERS);
+        L.area_cap = max_area ? max_area : 1;
+        L.side_cap = max_side ? max_side : 1;
+        const uint64_t words = (uint64_t)L.area_cap + 38ull * L.side_cap + 345;
+        if (4ull * words + off > cap) { why = "ROI bounding box too large for the LDS-resident Gabor plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+        L.plane = off; off = align16(off + 4u * (uint32_t)words);
+        L.total = off;
+        return NYXHIP_OK;
+    }
     L.red = off; off = align16(off + 8u * kWaves * 8);
     L.area_cap = max_area ? max_area : 1;
     if (16ull * L.area_cap > cap) { why = "ROI bounding box too large for the LDS-resident Gabor planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
@@ -625,7 +638,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         d.soft_nan = s->soft_nan; d.grey_depth = s->grey_depth; d.ibsi = s->ibsi;
     }
     if (mask3 && (groups & 4)) {
-        if (int lrc = make_shape_layout(mask3, s, E.area, g.L, why, cap))
+        if (int lrc = make_shape_layout(mask3, s, E.area, E.side, g.L, why, cap))
             return lrc;
         g.n_roi = b->n_roi;
         g.px_offset = b->px_offset; g.x = b->x; g.y = b->y; g.inten = b->inten;

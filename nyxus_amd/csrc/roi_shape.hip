@@ -166,6 +166,151 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     }
 }
 
+// ---- register-tiled variant for the default 16 x 16 kernel ------------------------------------
+// Every thread owns T consecutive output pixels of one row.  For one tap row j it loads the T + 16 image words its outputs
+// touch ONCE (16-byte LDS reads from a zero-padded u32 plane) and keeps them in registers; the 16 complex taps of the row are
+// wave-uniform and come through scalar loads, so the inner loop is nothing but the reference's separate multiplies and adds
+// (4 VALU operations per tap and output, the floor for bit-identical arithmetic) instead of three LDS reads per tap.
+// Out-of-box taps read a padding zero: adding a * 0 leaves every non-zero partial sum untouched and a zero sum zero, so the
+// response is bit-identical to the reference's clipped loops (gabor.cpp:333-390), in the same (j, i) order.
+// The low-pass energies are not kept: count(e > min) = area - count(e == min), carried through the min reduction.
+typedef const double __attribute__((address_space(4))) * bank_ptr_t;
+
+template <int T, int NW>
+__global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArgs A)
+{
+    constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
+    if (roi >= A.n_roi)
+        return;
+    double* s_red = (double*)(lds_raw + A.L.red);
+    uint32_t* s_plane = (uint32_t*)(lds_raw + A.L.plane);   // [(h + 15)][pitch] original intensities, zero padding
+
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t area = w * h;
+    const int nF = A.gabor_nf;
+    double* const o = A.out + roi * A.ld + A.col_gabor;
+    if (npx == 0 || area > A.L.area_cap || (w > h ? w : h) > A.L.side_cap) {
+        if (npx != 0 && A.sp.defer_large)
+            return;                                   // handled by the spill launch that follows
+        if (tid == 0 && npx != 0)
+            atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        for (int c = tid; c < nF; c += kBlk)
+            o[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    if (A.max_inten[roi] == A.min_inten[roi]) {     // gabor.cpp:53-57: all zeros, not the soft NaN
+        for (int c = tid; c < nF; c += kBlk)
+            o[c] = 0.0;
+        return;
+    }
+    // tap (j, i) of output (a, b) reads image (a + 8 - i, b + 8 - j): 7 padding rows above, 8 below, 8 padding columns
+    // left, >= 8 right; padded column = image column + 8, padded row = image row + 7
+    const uint32_t tpr = (w + T - 1) / T;             // tiles per row
+    const uint32_t pitch = tpr * T + 16;              // multiple of 4 words
+    const uint32_t words = pitch * (h + 15);
+    {
+        uint4* p4 = (uint4*)s_plane;
+        for (uint32_t i = tid; i < words / 4; i += kBlk)
+            p4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < npx; i += kBlk) {
+        uint32_t px = A.x[off + i], py = A.y[off + i];
+        if (px < w && py < h)
+            s_plane[(py + 7) * pitch + px + 8] = A.inten[off + i];
+    }
+    __syncthreads();
+
+    const bank_ptr_t bank = (bank_ptr_t)(uintptr_t)A.gabor_bank;
+    const uint32_t ntiles = tpr * h;
+    double maxval = 0;
+    double tmax = -1.0, tmin = 1.7976931348623157e308;
+    uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
+
+    for (int f = 0; f <= nF; f++) {
+        const bank_ptr_t G = bank + (size_t)f * N * N * 2;
+        uint32_t sc = 0;
+        for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
+            const uint32_t b = tile / tpr, a0 = (tile - b * tpr) * T;
+            double re[T], im[T];
+#pragma unroll
+            for (int t = 0; t < T; t++) { re[t] = 0.0; im[t] = 0.0; }
+            const uint32_t* row = s_plane + (b + 15) * pitch + a0;      // tap row j reads padded row b + 15 - j
+#pragma unroll 1
+            for (int j = 0; j < N; j++, row -= pitch) {
+                double win[T + 16];
+#pragma unroll
+                for (int q = 0; q < W4; q++) {
+                    const uint4 u = ((const uint4*)row)[q];
+                    win[4 * q + 0] = (double)u.x; win[4 * q + 1] = (double)u.y;
+                    win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
+                }
+                const bank_ptr_t Gj = G + j * N * 2;
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const double gr = Gj[2 * i], gi = Gj[2 * i + 1];
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        const double av = win[t + 16 - i];   // padded column a0 + t + 16 - i = image column a0 + t + 8 - i
+                        re[t] += av * gr;                    // C[ip]   += a * wr   (gabor.cpp:374)
+                        im[t] += av * gi;                    // C[ip+1] += a * wi   (:377)
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                if (a0 + t >= w)
+                    continue;
+                const double e = sqrt(re[t] * re[t] + im[t] * im[t]);   // :505
+                if (f == 0) {
+                    tmax = e > tmax ? e : tmax;
+                    if (e < tmin) { tmin = e; n_min = 1; }
+                    else if (e == tmin) n_min++;
+                } else if (e / maxval > A.gabor_thr)                    // :117
+                    sc++;
+            }
+        }
+        if (f == 0) {
+            tmax = wave_max_d(tmax);
+            const double wmin = wave_min_d(tmin);
+            const uint32_t wcnt = (uint32_t)wave_sum_u64(tmin == wmin ? n_min : 0u);
+            if (lane == 0) { s_red[wave * 8] = tmax; s_red[wave * 8 + 1] = wmin; s_red[wave * 8 + 2] = (double)wcnt; }
+            __syncthreads();
+            double mx = s_red[0], mn = s_red[1];
+            for (int wv = 1; wv < NW; wv++) {
+                mx = s_red[wv * 8] > mx ? s_red[wv * 8] : mx;
+                mn = s_red[wv * 8 + 1] < mn ? s_red[wv * 8 + 1] : mn;
+            }
+            uint32_t at_min = 0;
+            for (int wv = 0; wv < NW; wv++)
+                if (s_red[wv * 8 + 1] == mn) at_min += (uint32_t)s_red[wv * 8 + 2];
+            __syncthreads();
+            if (mx == mn) {                               // gabor.cpp:91-96
+                for (int c = tid; c < nF; c += kBlk)
+                    o[c] = A.soft_nan;
+                return;
+            }
+            maxval = mx;
+            n_min = area - at_min;                        // baseline score, :99-102: pixels with e > min
+        } else {
+            const uint32_t tot = (uint32_t)wave_sum_u64(sc);
+            if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + f - 1] = (double)tot;   // [wave][filter]; read after the final barrier
+        }
+    }
+    const double baseline = (double)n_min;
+    __syncthreads();
+    for (int k = tid; k < nF; k += kBlk) {
+        double scv = 0;
+        for (int wv = 0; wv < NW; wv++) scv += s_red[wv * NYXHIP_MAX_GABOR_FILTERS + k];
+        o[k] = scv / baseline;                            // :121
+    }
+}
+
 // =========================================================================================
 // Zernike (order 9: 30 magnitudes)
 // =========================================================================================
@@ -283,6 +428,10 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_gabor_tiled_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_gabor_tiled_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
@@ -296,7 +445,10 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             hipLaunchKernelGGL((roi_gabor_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
         return (int)hipGetLastError();
     }
-    if (a.mask & NYXHIP_FAM_GABOR) {
+    if ((a.mask & NYXHIP_FAM_GABOR) && a.L.tiled) {
+        if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1>), dim3(grid), dim3(64), a.L.total, st, a);
+        else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4>), dim3(grid), dim3(256), a.L.total, st, a);
+    } else if (a.mask & NYXHIP_FAM_GABOR) {
         if (small) hipLaunchKernelGGL((roi_gabor_kernel<1, false>), dim3(grid), dim3(64), a.L.total, st, a);
         else hipLaunchKernelGGL((roi_gabor_kernel<4, false>), dim3(grid), dim3(256), a.L.total, st, a);
     }
