@@ -229,6 +229,49 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
     v += dpp_perm<0x140>(v);
     return v;
 }
+// ---- transposed wave sum: 64 per-lane slots, lane L ends up with the wave total of slot L ------------------------
+// Each step pairs the lanes and halves the slot list (one partner keeps the lower half, the other the upper half, each adds
+// what the partner held of its half): 32 + 16 + 8 + 4 + 2 + 1 = 63 exchanges instead of 64 six-step butterflies.  The two
+// cross-row steps are gfx950's v_permlane32_swap / v_permlane16_swap (swap the odd 32- / 16-lane rows of the first operand
+// with the even rows of the second: no select needed), the four in-row steps are DPP moves.
+__device__ __forceinline__ void permlane32_swap(double& a, double& b)
+{
+    unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)ua, (uint32_t)ub, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ void permlane16_swap(double& a, double& b)
+{
+    unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ua, (uint32_t)ub, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+template <int CTRL, int HALF>
+__device__ __forceinline__ void transpose_sum_step(double* v, bool upper)
+{
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+        const double keep = upper ? v[k + HALF] : v[k];
+        const double send = upper ? v[k] : v[k + HALF];
+        v[k] = keep + dpp_perm<CTRL>(send);
+    }
+}
+__device__ __forceinline__ double wave_transpose_sum64(double (&v)[64], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 32; k++) { permlane32_swap(v[k], v[k + 32]); v[k] += v[k + 32]; }   // lanes >= 32 now hold slots 32..63
+#pragma unroll
+    for (int k = 0; k < 16; k++) { permlane16_swap(v[k], v[k + 16]); v[k] += v[k + 16]; }   // odd rows: + 16
+    transpose_sum_step<0x140, 8>(v, (lane & 8) != 0);     // row_mirror: lane i <-> 15 - i
+    transpose_sum_step<0x141, 4>(v, (lane & 4) != 0);     // row_half_mirror: i <-> 7 - i
+    transpose_sum_step<0x4E, 2>(v, (lane & 2) != 0);      // quad_perm [2,3,0,1]
+    transpose_sum_step<0xB1, 1>(v, (lane & 1) != 0);      // quad_perm [1,0,3,2]
+    return v[0];
+}
 __device__ __forceinline__ double row16_max(double v)
 {
     double o;

@@ -640,6 +640,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
     if (mask3 && (groups & 4)) {
         if (int lrc = make_shape_layout(mask3, s, E.area, E.side, g.L, why, cap))
             return lrc;
+        g.L.zern_px_cap = std::min<uint32_t>((E.px + 3u) & ~3u, 4096);   // <= 32 KiB of dynamic LDS in the Zernike kernel
         g.n_roi = b->n_roi;
         g.px_offset = b->px_offset; g.x = b->x; g.y = b->y; g.inten = b->inten;
         g.bbox_w = b->bbox_w; g.bbox_h = b->bbox_h; g.min_inten = b->min_inten; g.max_inten = b->max_inten;

@@ -195,6 +195,7 @@ struct ShapeLayout {
     uint32_t bank;      // double[(F+1)*n*n*2]
     uint32_t total;
     uint32_t area_cap;
+    uint32_t zern_px_cap; // Zernike: pixels of a cloud staged in LDS (larger clouds are re-read from HBM)
     uint32_t side_cap;  // tiled layout only
     uint32_t tiled;     // 1: `plane` is the zero-padded u32 plane of roi_gabor_tiled_kernel (16 x 16 kernels, LDS launches);
                         //    no energy plane and no bank copy

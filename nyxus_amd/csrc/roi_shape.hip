@@ -330,6 +330,9 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     constexpr int kBlk = NW * 64;
     __shared__ double s_red[NW * 64];
     __shared__ unsigned long long s_mom[NW * 4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t* const s_xy = (uint32_t*)lds_raw;                 // [zern_px_cap] x | y << 16 of the staged cloud
+    uint32_t* const s_v = s_xy + A.L.zern_px_cap;              // [zern_px_cap] intensities
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t roi = blockIdx.x;   // no size limit: always part of the first (non-spill) launch
     if (roi >= A.n_roi)
@@ -344,12 +347,17 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
         return;
     }
     // centroid moments (zernike.cpp:216-230): sums of integers, exact in any order
+    // The same sweep stages the cloud in LDS (when it fits), so that the moment sweep below is not one HBM round trip per
+    // pixel and lane.
+    const bool staged = npx <= A.L.zern_px_cap;
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
     for (uint32_t i = tid; i < npx; i += kBlk) {
-        unsigned long long v = A.inten[off + i];
+        const uint32_t vi = A.inten[off + i], xi = A.x[off + i], yi = A.y[off + i];
+        if (staged) { s_xy[i] = xi | (yi << 16); s_v[i] = vi; }
+        unsigned long long v = vi;
         m00 += v;
-        m10 += ((unsigned long long)A.x[off + i] + 1) * v;
-        m01 += ((unsigned long long)A.y[off + i] + 1) * v;
+        m10 += ((unsigned long long)xi + 1) * v;
+        m01 += ((unsigned long long)yi + 1) * v;
     }
     m00 = wave_sum_u64(m00); m10 = wave_sum_u64(m10); m01 = wave_sum_u64(m01);
     if (lane == 0) { s_mom[wave * 4] = m00; s_mom[wave * 4 + 1] = m10; s_mom[wave * 4 + 2] = m01; }
@@ -359,6 +367,10 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     const double sum = (double)t00;
     const double m10_m00 = (double)t10 / sum, m01_m00 = (double)t01 / sum;
     const double rad = (double)(w < h ? w : h);                // N = min(width, height), :185-195
+    // pixel weight / (sum * pi) as one multiplier (the reference divides by both per (n, pixel): :298; 1-2 ulp apart, the
+    // moments carry a 1e-5 tolerance).  Everything that DECIDES something -- x, y, r and the unit-disc test -- keeps the
+    // reference's exact divisions.
+    const double inv_sum_pi = 1.0 / (sum * 3.14159265358979323846);
 
     double AR[kZL + 1][kZL + 1], AI[kZL + 1][kZL + 1];
 #pragma unroll
@@ -367,8 +379,11 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
         for (int m = 0; m <= kZL; m++) { AR[n][m] = 0.0; AI[n][m] = 0.0; }
 
     for (uint32_t i = tid; i < npx; i += kBlk) {
-        const double x = ((double)((int)A.x[off + i] + 1) - m10_m00) / rad;   // :254
-        const double y = ((double)((int)A.y[off + i] + 1) - m01_m00) / rad;   // :262
+        uint32_t xi, yi, vi;
+        if (staged) { const uint32_t xy = s_xy[i]; xi = xy & 0xFFFFu; yi = xy >> 16; vi = s_v[i]; }
+        else { xi = A.x[off + i]; yi = A.y[off + i]; vi = A.inten[off + i]; }
+        const double x = ((double)((int)xi + 1) - m10_m00) / rad;   // :254
+        const double y = ((double)((int)yi + 1) - m01_m00) / rad;   // :262
         const double r2 = x * x + y * y, r = sqrt(r2);
         if (r < 2.2204460492503131e-16 || r > 1.0)
             continue;
@@ -376,41 +391,53 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
         R[0] = 1;
 #pragma unroll
         for (int n = 1; n <= kZL; n++) R[n] = r * R[n - 1];
-        const double a = x / r, b = y / r;
+        {   // from here on nothing decides anything: products feed sums directly (contraction allowed, 1e-5 tolerance)
+#pragma clang fp contract(fast)
+        const double inv_r = 1.0 / r, inv_r2 = inv_r * inv_r;
+        const double a = x * inv_r, b = y * inv_r;
         COST[0] = a; SINT[0] = b;
 #pragma unroll
         for (int m = 1; m <= kZL; m++) {
             COST[m] = a * COST[m - 1] - b * SINT[m - 1];
             SINT[m] = a * SINT[m - 1] + b * COST[m - 1];
         }
-        const double f = (double)A.inten[off + i] / sum;
+        const double f = (double)vi * inv_sum_pi;
         double Rnm = 0, Rnm2 = 0, Rnmp2 = 0, Rnmp4 = 0;
 #pragma unroll
         for (int n = 0; n <= kZL; n++) {
-            const double const_t = (double)(n + 1) * f / 3.14159265358979323846;
+            const double const_t = (double)(n + 1) * f;
             const double Rn = R[n];
             if (n >= 2) Rnm2 = R[n - 2];
 #pragma unroll
             for (int m = n; m >= 0; m -= 2) {
                 if (m == n) { Rnm = Rn; Rnmp4 = Rn; }
                 else if (m == n - 2) { Rnm = (double)n * Rn - (double)(n - 1) * Rnm2; Rnmp2 = Rnm; }
-                else { Rnm = zH1(n, m) * Rnmp4 + (zH2(n, m) + (zH3(n, m) / r2)) * Rnmp2; Rnmp4 = Rnmp2; Rnmp2 = Rnm; }
-                AR[n][m] += const_t * Rnm * COST[m];
-                AI[n][m] -= const_t * Rnm * SINT[m];
+                else { Rnm = zH1(n, m) * Rnmp4 + (zH2(n, m) + (zH3(n, m) * inv_r2)) * Rnmp2; Rnmp4 = Rnmp2; Rnmp2 = Rnm; }
+                const double cr = const_t * Rnm;
+                AR[n][m] += cr * COST[m];
+                AI[n][m] -= cr * SINT[m];
             }
         }
+        }
     }
-    // reduce the 30 complex accumulators over the workgroup
-    int k = 0;
+    // reduce the 30 complex accumulators over the workgroup: slot 2k = real, 2k + 1 = imaginary part of moment k, summed
+    // across the wave by one transposed reduction (lane L receives the total of slot L)
+    {
+        double slots[64];
+        int k = 0;
 #pragma unroll
-    for (int n = 0; n <= kZL; n++)
+        for (int n = 0; n <= kZL; n++)
 #pragma unroll
-        for (int m = 0; m <= n; m++)
-            if ((n - m) % 2 == 0) {
-                double vr = wave_sum(AR[n][m]), vi = wave_sum(AI[n][m]);
-                if (lane == 0) { s_red[wave * 64 + 2 * k] = vr; s_red[wave * 64 + 2 * k + 1] = vi; }
-                k++;
-            }
+            for (int m = 0; m <= n; m++)
+                if ((n - m) % 2 == 0) {
+                    slots[2 * k] = AR[n][m];
+                    slots[2 * k + 1] = AI[n][m];
+                    k++;
+                }
+#pragma unroll
+        for (int q = 60; q < 64; q++) slots[q] = 0.0;
+        s_red[wave * 64 + lane] = wave_transpose_sum64(slots, lane);
+    }
     __syncthreads();
     if (tid < 30) {
         double vr = 0, vi = 0;
@@ -453,8 +480,8 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         else hipLaunchKernelGGL((roi_gabor_kernel<4, false>), dim3(grid), dim3(256), a.L.total, st, a);
     }
     if (a.mask & NYXHIP_FAM_ZERNIKE) {
-        if (small) hipLaunchKernelGGL(roi_zernike_kernel<1>, dim3(grid), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(roi_zernike_kernel<4>, dim3(grid), dim3(256), 0, st, a);
+        if (small) hipLaunchKernelGGL(roi_zernike_kernel<1>, dim3(grid), dim3(64), 8u * a.L.zern_px_cap, st, a);
+        else hipLaunchKernelGGL(roi_zernike_kernel<4>, dim3(grid), dim3(256), 8u * a.L.zern_px_cap, st, a);
     }
     return (int)hipGetLastError();
 }
