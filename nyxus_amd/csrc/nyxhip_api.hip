@@ -426,7 +426,14 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         double bound = sqrt(2.0 * (double)L.ng_cap * (double)L.dense_cap) + (double)L.ng_cap;
         uint32_t distinct = (uint32_t)std::min((double)L.dense_cap, bound) + 1;
         L.hash_cap = pow2ceil(2 * distinct);
-        size_t szm = 4ull * L.dense_cap + 4ull * (L.dense_cap + 8) + 8ull * L.hash_cap + 4ull * (L.ng_cap + 4);
+        // zone sizes (16-bit entries, two per word, while a size fits), hash, zones per level; the owner-label plane only
+        // exists for boxes wider than one wave (the DPP sweep of narrower boxes keeps labels in registers)
+        L.szm_c16 = (!spill && L.dense_cap < 65535u) ? 1 : 0;
+        size_t szm = 0;
+        L.szm_count = (uint32_t)szm; szm += ((L.szm_c16 ? 2ull : 4ull) * (L.dense_cap + 8) + 15) & ~15ull;
+        L.szm_hkey = (uint32_t)szm; szm += 8ull * L.hash_cap + 4ull * (L.ng_cap + 4);
+        szm = (szm + 15) & ~15ull;
+        L.szm_label = (uint32_t)szm; if (L.side_cap > 64) szm += 4ull * L.dense_cap;
         L.szm_ok = (off + szm <= cap) ? 1 : 0;
         if (!L.szm_ok) { why = "ROI too large for the LDS-resident GLSZM zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
         need = std::max(need, szm);

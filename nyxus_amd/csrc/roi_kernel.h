@@ -94,6 +94,8 @@ struct TexLayout {
     uint32_t work;      // per-family scratch, families run one after the other
     uint32_t total;
     uint32_t dense_cap, side_cap, lvl_cap, ng_cap, hash_cap, work_bytes, szm_ok;
+    uint32_t szm_c16;   // GLSZM zone-size table holds 16-bit entries (dense_cap < 65536, LDS launches): two per word
+    uint32_t szm_count, szm_hkey, szm_label;   // offsets inside `work`: sizes, hash keys (values follow), owner labels (only when side_cap > 64)
 };
 
 struct TexArgs {

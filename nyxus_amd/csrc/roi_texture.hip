@@ -21,6 +21,7 @@
 // HBM traffic: the ROI cloud in (8 B/px), 101 doubles out; everything else is LDS.
 // Built with -ffp-contract=off (device_math.h).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "../../include/nyxhip.h"
@@ -137,8 +138,11 @@ __device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uin
     wav_sync<GS>();
 }
 
-template <bool GS>   // GS: scratch in the global workspace (large-ROI launches)
-__global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
+// GS: scratch in the global workspace (large-ROI launches).  OCC: workgroups per CU the register budget is cut for -- the
+// serial stretches of this kernel (the GLSZM row sweep, the hash probes) are latency-bound, so when six carve-outs fit a
+// CU the 80-register build (a few spills) beats the 106-register one by 20-25 %.
+template <bool GS, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
@@ -207,9 +211,14 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     lvl_over = wave_max_u32(lvl_over);
     if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
     blk_sync<GS>();
-    uint32_t Np_orig = 0;   // non-zero ORIGINAL pixels (glrlm.cpp:197-204)
+    // The two pixel counts are needed once each, much later: they wait in s_stat instead of occupying registers through
+    // the whole kernel.
     bool over = false;
-    for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; }
+    {
+        uint32_t Np_orig = 0;   // non-zero ORIGINAL pixels (glrlm.cpp:197-204)
+        for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; }
+        if (tid == 0) s_stat[2] = (double)Np_orig;
+    }
     if (over) { // IBSI level beyond the LDS-resident capacity
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
         for (int c = tid; c < A.n_cols; c += kBlock)
@@ -226,8 +235,11 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     blk_sync<GS>();
     if (lane == 0) s_red[wave * 8] = (double)nz_bin;
     blk_sync<GS>();
-    uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
-    for (int wv = 0; wv < kWaves; wv++) Np_bin += (uint32_t)s_red[wv * 8];
+    if (tid == 0) {
+        uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
+        for (int wv = 0; wv < kWaves; wv++) Np_bin += (uint32_t)s_red[wv * 8];
+        s_stat[3] = (double)Np_bin;
+    }
     // sorted unique non-zero levels (glrlm.cpp:101-105, glszm.cpp:97-101, ngtdm.cpp:53-67);
     // IBSI: I = 1..max (GLRLM/GLSZM) and 0..max (NGTDM)
     if (tid == 0) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                 blk_sync<GS>();
                 {
                     uint32_t* P = s_mat + (uint32_t)wave * slot_words;
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + wave * 16, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, lane);
                 }
             } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                             atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
                         }
                         wav_sync<GS>();
-                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, Np_orig, s_f + ai * 16, lane);
+                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, lane);
                     }
                 }
             }
@@ -359,19 +371,29 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
     if (do_szm) {
         double* o = s_out + col;
         col += 16;
-        uint32_t* s_label = (uint32_t*)s_work;               // [area] owner index of each pixel
-        uint32_t* s_count = s_label + A.L.dense_cap;         // [area] zone size at the owner / later zones per size
-        uint32_t* s_hkey = s_count + A.L.dense_cap + 4;      // [hcap] (row << 20 | size), 0xFFFFFFFF = empty
+        uint32_t* s_count = (uint32_t*)(s_work + A.L.szm_count);   // [area + 1] zone size at the owner / later zones per size
+        uint32_t* s_hkey = (uint32_t*)(s_work + A.L.szm_hkey);     // [hcap] (row << 20 | size), 0xFFFFFFFF = empty
         uint32_t* s_hval = s_hkey + A.L.hash_cap;            // [hcap] multiplicity P(i,j)
         uint32_t* s_si = s_hval + A.L.hash_cap;              // [Ng] zones per level
+        uint32_t* s_label = (uint32_t*)(s_work + A.L.szm_label);   // [area] owner index of each pixel (boxes wider than 64 only)
         const uint32_t hcap = A.L.hash_cap;
+        // zone-size table: 16-bit entries packed two per word while every size fits (halves never carry: a count is <= area)
+        const bool c16 = A.L.szm_c16 != 0;
+        auto cnt_add = [=](uint32_t idx, uint32_t inc) {
+            if (c16) atomicAdd(&s_count[idx >> 1], inc << (16u * (idx & 1u)));
+            else atomicAdd(&s_count[idx], inc);
+        };
+        auto cnt_get = [=](uint32_t idx) -> uint32_t {
+            return c16 ? (uint32_t)((const uint16_t*)s_count)[idx] : s_count[idx];
+        };
+        const uint32_t cnt_words = c16 ? (area + 2) / 2 : area + 1;
         if (blank) {                                         // glszm.cpp:61-65
             for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
         } else if (A.L.szm_ok == 0 || area > (1u << 20) - 1) {
             if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
             for (int c = tid; c < 16; c += kBlock) o[c] = __longlong_as_double(0x7ff8000000000000LL);
         } else {
-            for (uint32_t i = tid; i < area; i += kBlock) s_count[i] = 0;
+            for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
             for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0xFFFFFFFFu; s_hval[i] = 0; }
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
             blk_sync<GS>();
@@ -419,11 +441,8 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                     const uint32_t ln = lane_plus1(lab, 0xFFFFFFFFu);
                     const bool zp = in && v != 0;
                     const unsigned long long same = __ballot(zp && lane < 63 && ln == lab && lane_plus1(v, 0u) != 0);
-                    if (zp) {
-                        s_label[p] = lab;
-                        if (!(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                            atomicAdd(&s_count[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
-                    }
+                    if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                        cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
                     v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
                 }
             } else if (wave == 0) {
@@ -466,13 +485,13 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
             if (w > 64) {
                 for (uint32_t p = tid; p < area; p += kBlock)
                     if (s_dense[p] != 0)
-                        atomicAdd(&s_count[s_label[p]], 1u);
+                        cnt_add(s_label[p], 1u);
                 blk_sync<GS>();
             }
             // zones -> P(i,j) multiplicities (hash), zones per level; Nz
             uint32_t nzone = 0;
             for (uint32_t p = tid; p < area; p += kBlock) {
-                uint32_t sz = s_count[p];
+                uint32_t sz = cnt_get(p);
                 if (sz == 0) continue;
                 nzone++;
                 uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
@@ -489,13 +508,13 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
             blk_sync<GS>();
             if (lane == 0) s_red[wave * 8] = (double)nzone;
             // zones per size (sj): reuse s_count, keyed by size
-            for (uint32_t i = tid; i <= area; i += kBlock) s_count[i] = 0;
+            for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
             blk_sync<GS>();
             double sum_p = 0;
             for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
             for (uint32_t i = tid; i < hcap; i += kBlock)
                 if (s_hkey[i] != 0xFFFFFFFFu)
-                    atomicAdd(&s_count[s_hkey[i] & 0xFFFFFu], s_hval[i]);
+                    cnt_add(s_hkey[i] & 0xFFFFFu, s_hval[i]);
             blk_sync<GS>();
             if (sum_p == 0) {                                // glszm.cpp:229-233
                 for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                     b[1] += p * (dz * dz);                   // calc_ZV :512-524
                 }
                 for (uint32_t j = 1 + tid; j <= area; j += kBlock) {
-                    double sj = (double)s_count[j];
+                    double sj = (double)cnt_get(j);
                     // j * j is an int product in the reference: it wraps for j >= 46341 and is exactly 0 at multiples of
                     // 65536, where the empty column contributes 0.0 / 0 = NaN to SAE (Ns = bbox area, glszm.cpp:212)
                     if (sj == 0 && (j & 0xFFFFu) != 0) continue;
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
                     o[Z_GLNN] = b[5] / (sum_p * sum_p);
                     o[Z_SZN] = b[4] / sum_p;
                     o[Z_SZNN] = b[4] / (sum_p * sum_p);
-                    o[Z_ZP] = sum_p / (double)(int)Np_bin;   // calc_ZP :491-495
+                    o[Z_ZP] = sum_p / (double)(int)(uint32_t)s_stat[3];   // calc_ZP :491-495
                     o[Z_GLV] = b[0];
                     o[Z_ZV] = b[1];
                     o[Z_ZE] = -acc[4];
@@ -670,12 +689,21 @@ __global__ __launch_bounds__(kBlock) void roi_texture_kernel(const TexArgs A)
         out_row[gcol(c)] = s_out[c];
 }
 
+static int tex_max_occ()   // diagnostic knob: NYXHIP_TEX_OCC=4 keeps the 106-register build
+{
+    static const int v = [] { const char* e = getenv("NYXHIP_TEX_OCC"); return e && *e ? atoi(e) : 6; }();
+    return v;
+}
+
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)roi_features_max_lds());
         if (e != hipSuccess)
             return (int)e;
         attr_set = true;
@@ -683,9 +711,11 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
     if (grid == 0)
         return 0;
     if (a.sp.scratch)
-        hipLaunchKernelGGL(roi_texture_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else if (tex_max_occ() >= 6 && 6ull * (a.L.total + 256) <= roi_features_max_lds())
+        hipLaunchKernelGGL((roi_texture_kernel<false, 6>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(roi_texture_kernel<false>, dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((roi_texture_kernel<false, 4>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
