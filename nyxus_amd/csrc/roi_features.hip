@@ -335,6 +335,8 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         if (tid == 0 && A.stamps) atomicAdd(&A.stamps[i], t__ - t_prev__);                \
         t_prev__ = __builtin_readcyclecounter();                                          \
     } while (0)
+#elif defined(NYX_EXIT_AT)   // diagnostic build: the kernel ends at phase NYX_EXIT_AT (results are wrong by design; tools/pmc_exit.sh)
+#define STAMP(i) do { if ((i) == NYX_EXIT_AT) return; } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
