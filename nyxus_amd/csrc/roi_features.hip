@@ -155,6 +155,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     double* Pxpy = scr + 2 * Ng;  // [2Ng]  glcm.cpp:503-508
     double* Pxmy = scr + 4 * Ng;  // [Ng]
 
+    uint32_t dis_cnt = 0;                              // sum |r - c| * count = sum_k k * count(|x - y| = k): f_GLCM_DIS numerator, exact
     for (int i = l16; i < Ng; i += LW) {
         uint32_t cc = 0, rc = 0, dc = 0;
         for (int j = 0; j < Ng; j++) {
@@ -166,6 +167,7 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
             if (i > 0)
                 dc += P[(x - i) * Ng + x];
         }
+        dis_cnt += (uint32_t)i * dc;
         if (live) {
             pcol[i] = fdiv((double)cc, sum_p);
             prow[i] = fdiv((double)rc, sum_p);
@@ -189,7 +191,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     brm = slot_sum<LW>(brm);
 
     // ---- pass 1 over matrix elements -------------------------------------------------
-    double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, hom1 = 0, ent = 0, dis_n = 0, hom2 = 0, jmax = -1;
+    // HOM1 = sum p / (1 + |r - c|) and HOM2 = sum p / (1 + |r - c|^2) are the sums ID and IDM take over the |x - y|
+    // distribution below (same terms grouped by k; <= 1e-15 relative apart), so the two divisions per cell are not repeated here.
+    double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, ent = 0, jmax = -1;
     for (int e = l16; e < NN; e += LW) {
         int r = e / Ng, c = e - r * Ng;
         double cnt = (double)P[e];
@@ -201,24 +205,18 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
         S_r += cnt * ir;                             // f_corr mr :601, f_var mean :662, JAVE :1144
         S_c += cnt * ic;                             // f_corr mc :608
         acor_n += cnt * ir * ic;                     // f_GLCM_ACOR :961
-        int adiff = r > c ? r - c : c - r;
-        hom1 += fdiv(p, 1.0 + (double)adiff);        // f_homogeneity :942
         ent += plogp(p, p);                          // f_entropy :734-735, JE :1160-1161, HXY :868
-        dis_n += (double)adiff * cnt;                // f_GLCM_DIS :1052 (integer-exact numerator)
-        hom2 += fdiv(p, 1.0 + (double)adiff * (double)adiff); // f_GLCM_HOM2 :1069
         jmax = p > jmax ? p : jmax;                  // f_GLCM_JMAX :1178-1179
     }
     asm_ = slot_sum<LW>(asm_); contrast_n = slot_sum<LW>(contrast_n); S_r = slot_sum<LW>(S_r); S_c = slot_sum<LW>(S_c);
-    acor_n = slot_sum<LW>(acor_n); hom1 = slot_sum<LW>(hom1); ent = slot_sum<LW>(ent); dis_n = slot_sum<LW>(dis_n);
-    hom2 = slot_sum<LW>(hom2); jmax = slot_max<LW>(jmax);
+    acor_n = slot_sum<LW>(acor_n); ent = slot_sum<LW>(ent); jmax = slot_max<LW>(jmax);
+    const double dis_n = (double)slot_sum<LW>(dis_cnt);   // f_GLCM_DIS :1052
     const double mr = S_r / sum_p, mc = fdiv(S_c, sum_p); // mr == f_var's mean == JAVE (exact numerators)
     if (live && l16 == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
         f[G_ENERGY] = asm_;
         f[G_CONTRAST] = contrast_n / sum_p;
         f[G_ACOR] = acor_n / sum_p;
-        f[G_HOM1] = hom1;
-        f[G_HOM2] = hom2;
         f[G_ENTROPY] = -ent;
         f[G_JE] = -ent;
         f[G_DIS] = dis_n / sum_p;
@@ -305,6 +303,8 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     savg = slot_sum<LW>(savg); sent = slot_sum<LW>(sent); dv = slot_sum<LW>(dv);
     if (live && l16 == 0) {
         f[G_IDM] = idm;
+        f[G_HOM2] = idm;                              // f_GLCM_HOM2 :1069 == f_idm over p_{x-y}
+        f[G_HOM1] = id;                               // f_homogeneity :942 == f_GLCM_ID over p_{x-y}
         f[G_SUMAVERAGE] = savg;
         f[G_SUMENTROPY] = -sent;
         f[G_DIFENTRO] = -dent;
