@@ -201,7 +201,11 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32
 __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restrict__ inten, const uint32_t* __restrict__ label, uint32_t W,
                                                         uint32_t H, uint32_t stride, TileRows R, uint16_t* cx, uint16_t* cy, uint32_t* cv)
 {
-    __shared__ uint32_t s_cnt[4];
+    // Four 256-pixel chunks of the window per trip: every label / intensity load of a trip is issued before the first
+    // ballot (the intensity unconditionally -- one HBM round trip per trip instead of two per chunk), and one barrier
+    // pair ranks 1024 pixels.  (bx, by) advance incrementally: one integer division per thread and ROI.
+    constexpr int U = 4;
+    __shared__ uint32_t s_cnt[U * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t row = blockIdx.x;
     // R.label holds the table index tile * stride + label; y0 is tile-relative
@@ -209,26 +213,43 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
     const uint32_t x0 = R.bbox_x0[row], y0 = R.bbox_y0[row] + tile * H, w = R.bbox_w[row], h = R.bbox_h[row];
     const uint32_t area = w * h;
     unsigned long long out = R.px_offset[row];
-    for (uint32_t p0 = 0; p0 < area; p0 += 256) {
-        const uint32_t p = p0 + tid;
-        bool hit = false;
-        uint32_t bx = 0, by = 0, v = 0;
-        if (p < area) {
-            by = p / w; bx = p - by * w;
-            const uint64_t g = (uint64_t)(y0 + by) * W + (x0 + bx);
-            hit = label[g] == L;
-            if (hit) v = inten[g];
+    const uint32_t step_y = 256u / w, step_x = 256u - step_y * w;     // 256 pixels further along the window
+    uint32_t by = (uint32_t)tid / w, bx = (uint32_t)tid - by * w;
+    const uint32_t* const lab_base = label + (uint64_t)y0 * W + x0;
+    const uint32_t* const int_base = inten + (uint64_t)y0 * W + x0;
+    for (uint32_t p0 = 0; p0 < area; p0 += 256 * U) {
+        uint32_t lb[U], v[U], xs[U], ys[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t p = p0 + (uint32_t)u * 256u + (uint32_t)tid;
+            xs[u] = bx; ys[u] = by;
+            const uint64_t g = (uint64_t)by * W + bx;
+            const bool ok = p < area;
+            lb[u] = ok ? lab_base[g] : ~L;
+            v[u] = ok ? int_base[g] : 0u;
+            bx += step_x; by += step_y;
+            if (bx >= w) { bx -= w; by++; }
         }
-        const unsigned long long bal = __ballot(hit);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+        unsigned long long bal[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bal[u] = __ballot(lb[u] == L);
+            if (lane == 0) s_cnt[u * 4 + wave] = (uint32_t)__popcll(bal[u]);
+        }
         __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (int w2 = 0; w2 < 4; w2++) { if (w2 < wave) before += s_cnt[w2]; total += s_cnt[w2]; }
-        if (hit) {
-            const unsigned long long o = out + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            cx[o] = (uint16_t)bx; cy[o] = (uint16_t)by; cv[o] = v;
+        uint32_t run = 0;                               // hits of this trip before the current (chunk, wave), in window order
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) {
+                if (w2 == wave && lb[u] == L) {
+                    const unsigned long long o = out + run + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
+                    cx[o] = (uint16_t)xs[u]; cy[o] = (uint16_t)ys[u]; cv[o] = v[u];
+                }
+                run += s_cnt[u * 4 + w2];
+            }
         }
-        out += total;
+        out += run;
         __syncthreads();
     }
 }
