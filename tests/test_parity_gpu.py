@@ -452,3 +452,43 @@ def test_glcm_grey_depth_beyond_lds_runs_from_the_global_workspace(hip_ctx, gd):
     s = _abi.default_settings(gd)
     _check(hip_ctx, b, MASK, s)
     _check(hip_ctx, b, MASK | _abi.FAM_GLRLM | _abi.FAM_NGTDM, s, against_ref=False)
+
+
+def _edge_shape_rois(seed=31):
+    rng = np.random.default_rng(seed)
+    rois = []
+    for (w, h) in [(1, 1), (1, 40), (40, 1), (2, 3), (7, 9), (8, 8), (9, 17), (15, 16), (16, 15), (17, 64), (64, 64), (65, 33), (33, 70)]:
+        m = np.ones((h, w), bool)
+        if w > 4 and h > 4:
+            m &= rng.random((h, w)) > 0.2
+            m[0, 0] = m[h - 1, w - 1] = True          # keep the bounding box
+        ys, xs = np.nonzero(m)
+        rois.append(dict(x=xs, y=ys, inten=rng.integers(1, 60000, len(xs)).astype(np.uint32)))
+    yy, xx = np.mgrid[0:61, 0:61]
+    ys, xs = np.nonzero((xx - 30) ** 2 + (yy - 30) ** 2 <= 900)
+    rois.append(dict(x=xs, y=ys, inten=rng.integers(1, 4096, len(xs)).astype(np.uint32)))   # the metric ROI shape
+    return rois
+
+
+def test_gabor_tiled_kernel_edge_shapes_exact(hip_ctx):
+    """roi_gabor_tiled_kernel (16 x 16 bank): widths that are not a multiple of the 8-pixel tile, single rows / columns,
+    boxes narrower than the kernel, the metric disk -- count ratios bit-exact against the oracle and the reference."""
+    b = _abi.batch_from_rois(_edge_shape_rois())
+    for s in (_abi.default_settings(8), _bank8(_abi.default_settings(8))):
+        G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+        O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+        assert ((G == O) | (np.isnan(G) & np.isnan(O))).all()
+        if po.have_ref():
+            Rf = po.ref_featurize(b, _abi.FAM_GABOR, s, 2)
+            assert ((G == Rf) | (np.isnan(G) & np.isnan(Rf))).all()
+
+
+@pytest.mark.parametrize("n", [9, 20])
+def test_gabor_other_kernel_sizes_exact(hip_ctx, n):
+    """Bank sizes other than 16 take the generic Gabor kernel."""
+    b = _abi.batch_from_rois(_edge_shape_rois(seed=32))
+    s = _abi.default_settings(8)
+    s.gabor_kersize = n
+    G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+    O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+    assert ((G == O) | (np.isnan(G) & np.isnan(O))).all()
