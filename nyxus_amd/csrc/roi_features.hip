@@ -350,7 +350,10 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 // SPLIT: the launch exports the GLCM counts for glcm_features_kernel; the in-kernel feature code is compiled out.
 // D8: the binned bounding-box plane holds 8-bit levels (grey depth <= 254); with C16 and SPLIT this brings the benchmark's
 // carve-out under 20 KiB: eight workgroups per CU.
-template <bool GS, bool C16, bool SPLIT, bool D8>
+// FAM: family set known at compile time -- 0: read A.mask; 1: INTENSITY + GLCM under matlab binning with <= 16 levels (what
+// make_layout's dense8 stands for); 2: INTENSITY alone.  The 64-VGPR tier is only launched for 1 and 2, so the run-time
+// switches are compile-time facts there and their branches disappear from the pixel loops.
+template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -376,8 +379,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
     const uint32_t area = w * h;
     const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
-    const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0;
-    const bool do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
+    constexpr bool FAST = FAM == 1;
+    const bool do_int = FAM != 0 || (A.mask & NYXHIP_FAM_INTENSITY) != 0;
+    const bool do_glcm = FAM == 1 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);
     double* const out_row = A.out + roi * A.ld;
 #ifdef NYX_STAMP
     unsigned long long t_prev__ = __builtin_readcyclecounter();
@@ -385,7 +389,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
     // order-statistics engine for this ROI: counting table when [vmin, vmax] fits
     const uint32_t range = vmax - vmin;
-    const bool use_count = do_int && A.L.count_cap != 0 && range < A.L.count_cap;
+    const bool use_count = C16 ? do_int : (do_int && A.L.count_cap != 0 && range < A.L.count_cap);   // C16: every ROI of the launch counts
     uint32_t* s_cnt = (uint32_t*)(lds + A.L.cnt);
     // smallest power of two >= n (sort length of the fallback engine)
     uint32_t P2 = 1;
@@ -405,6 +409,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
     // grey binning used by the co-occurrence scan (glcm.cpp:354,379-385)
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    if (FAST) __builtin_assume(greyInfo > 0 && greyInfo <= 16);
     const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
 
     // ---- phase 0: clear LDS state; the output row is written in place (zeros first: features that are skipped stay 0; every
@@ -1051,9 +1056,10 @@ __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiA
 {
     roi_features_body<false, C16, SPLIT, D8>(A);
 }
+template <int FAM>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, true, true>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM>(A);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
@@ -1122,9 +1128,9 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[5] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
+        const void* fns[6] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
                               (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
-                              (const void*)roi_features_kernel_occ8};
+                              (const void*)roi_features_kernel_occ8<1>, (const void*)roi_features_kernel_occ8<2>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -1134,11 +1140,16 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
     }
     // occupancy follows the carve-out: 8 / 7 / 6 / 5 / 4 workgroups per CU with builds held to 64 / 72 / 80 / 96 / 128 VGPRs
     const size_t lds = roi_features_max_lds();
+    // the 64-VGPR tier exists for the two compile-time family sets only
+    const bool int_only = !(a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY);
+    const bool int_glcm = (a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY) && a.L.dense8 && a.glcm_ws != nullptr && !a.ibsi &&
+                          a.grey_depth > 0 && a.grey_depth <= 16;
     int occ = 4;
-    for (int o = (C16 && SPLIT && D8) ? 8 : 7; o > 4; o--)
+    for (int o = (C16 && SPLIT && D8 && (int_only || int_glcm)) ? 8 : 7; o > 4; o--)
         if ((size_t)o * a.L.total <= lds) { occ = o; break; }
     if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
-    if (occ == 8) hipLaunchKernelGGL(roi_features_kernel_occ8, dim3(grid), dim3(kBlock), a.L.total, st, a);
+    if (occ == 8 && int_only) hipLaunchKernelGGL(roi_features_kernel_occ8<2>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 8) hipLaunchKernelGGL(roi_features_kernel_occ8<1>, dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
