@@ -445,19 +445,21 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     uint32_t lvl_max = 0;
     // four pixels per thread per trip: all global loads of a trip are issued before the first
     // use, so one HBM round trip covers 1024 pixels of the workgroup
+    // The cloud is read through buffer descriptors sized to this ROI (raw buffers, num_records in bytes): lanes past the last
+    // pixel get 0 from the bounds check of the load itself -- no compare, branch or 64-bit address per load, and the twelve
+    // loads of a trip issue back to back.
     constexpr int kU = 4;
-    const uint32_t* const pin = A.inten + off;
-    const uint16_t* const pxs = A.x + off;
-    const uint16_t* const pys = A.y + off;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(A.inten + off), 0, (int)(n * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + off), 0, (int)(n * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(A.y + off), 0, (int)(n * 2u), 0x00020000);
     for (uint32_t base = 0; base < n; base += kU * kBlock) {
         uint32_t v[kU], px[kU], py[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            uint32_t i = base + u * kBlock + tid;
-            bool ok = i < n;
-            v[u] = ok ? pin[i] : 0u;                // uniform base + 32-bit lane offset
-            px[u] = (ok && do_glcm) ? (uint32_t)pxs[i] : 0u;
-            py[u] = (ok && do_glcm) ? (uint32_t)pys[i] : 0u;
+            const uint32_t i = base + u * kBlock + tid;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_v, (int)(i * 4u), 0, 0);
+            px[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_x, (int)(i * 2u), 0, 0) : 0u;
+            py[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_y, (int)(i * 2u), 0, 0) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kU; u++) {
