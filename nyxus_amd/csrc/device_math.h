@@ -260,6 +260,34 @@ __device__ __forceinline__ void transpose_sum_step(double* v, bool upper)
         v[k] = keep + dpp_perm<CTRL>(send);
     }
 }
+// 8 slots: lane L returns the wave total of slot (L >> 3) & 7 -- 3 halving exchanges, then a 3-step butterfly over the 8
+// lanes that share a slot (34 instructions instead of 8 six-step butterflies).
+__device__ __forceinline__ double wave_transpose_sum8(double (&v)[8], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) { permlane32_swap(v[k], v[k + 4]); v[k] += v[k + 4]; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) { permlane16_swap(v[k], v[k + 2]); v[k] += v[k + 2]; }
+    transpose_sum_step<0x140, 1>(v, (lane & 8) != 0);
+    double t = v[0];
+    t += dpp_perm<0x141>(t);
+    t += dpp_perm<0x4E>(t);
+    t += dpp_perm<0xB1>(t);
+    return t;
+}
+// 4 slots: lane L returns the wave total of slot (L >> 4) & 3.
+__device__ __forceinline__ double wave_transpose_sum4(double (&v)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) { permlane32_swap(v[k], v[k + 2]); v[k] += v[k + 2]; }
+    permlane16_swap(v[0], v[1]);
+    double t = v[0] + v[1];
+    t += dpp_perm<0x140>(t);
+    t += dpp_perm<0x141>(t);
+    t += dpp_perm<0x4E>(t);
+    t += dpp_perm<0xB1>(t);
+    return t;
+}
 __device__ __forceinline__ double wave_transpose_sum64(double (&v)[64], int lane)
 {
 #pragma unroll

@@ -69,13 +69,29 @@ template <int N, bool GS>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    if (N > 4) {                                     // transposed wave sums: the lane group of slot k ends up with its total
+        double t[8];
 #pragma unroll
-    for (int k = 0; k < N; k++)
-        v[k] = wave_sum(v[k]);
-    if (lane == 0) {
+        for (int k = 0; k < 8; k++) t[k] = k < N ? v[k] : 0.0;
+        const double tot = wave_transpose_sum8(t, lane);
+        if ((lane & 7) == 0 && (lane >> 3) < N)
+            s_red[wave * 8 + (lane >> 3)] = tot;
+    } else if (N > 2) {
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[k] = k < N ? v[k] : 0.0;
+        const double tot = wave_transpose_sum4(t);
+        if ((lane & 15) == 0 && (lane >> 4) < N)
+            s_red[wave * 8 + (lane >> 4)] = tot;
+    } else {
 #pragma unroll
         for (int k = 0; k < N; k++)
-            s_red[wave * 8 + k] = v[k];
+            v[k] = wave_sum(v[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                s_red[wave * 8 + k] = v[k];
+        }
     }
     blk_sync<GS>();
 #pragma unroll
