@@ -260,6 +260,20 @@ __device__ __forceinline__ void transpose_sum_step(double* v, bool upper)
         v[k] = keep + dpp_perm<CTRL>(send);
     }
 }
+// 16 slots: lane L returns the wave total of slot (L >> 2) & 15.
+__device__ __forceinline__ double wave_transpose_sum16(double (&v)[16], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) { permlane32_swap(v[k], v[k + 8]); v[k] += v[k + 8]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { permlane16_swap(v[k], v[k + 4]); v[k] += v[k + 4]; }
+    transpose_sum_step<0x140, 2>(v, (lane & 8) != 0);
+    transpose_sum_step<0x141, 1>(v, (lane & 4) != 0);
+    double t = v[0];
+    t += dpp_perm<0x4E>(t);
+    t += dpp_perm<0xB1>(t);
+    return t;
+}
 // 8 slots: lane L returns the wave total of slot (L >> 3) & 7 -- 3 halving exchanges, then a 3-step butterfly over the 8
 // lanes that share a slot (34 instructions instead of 8 six-step butterflies).
 __device__ __forceinline__ double wave_transpose_sum8(double (&v)[8], int lane)

@@ -217,11 +217,26 @@ template <int N, bool GS>
 __device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    if (N > 8) {                                      // transposed wave sums (device_math.h): slot k's total lands in its lane group
+        static_assert(N <= 16, "mom_block_sum: at most 16 sums");
+        double t[16];
 #pragma unroll
-    for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
-    if (lane == 0)
+        for (int k = 0; k < 16; k++) t[k] = k < N ? v[k] : 0.0;
+        const double tot = wave_transpose_sum16(t, lane);
+        if ((lane & 3) == 0 && (lane >> 2) < N) s_red[wave * N + (lane >> 2)] = tot;
+    } else if (N > 4) {
+        double t[8];
 #pragma unroll
-        for (int k = 0; k < N; k++) s_red[wave * N + k] = v[k];
+        for (int k = 0; k < 8; k++) t[k] = k < N ? v[k] : 0.0;
+        const double tot = wave_transpose_sum8(t, lane);
+        if ((lane & 7) == 0 && (lane >> 3) < N) s_red[wave * N + (lane >> 3)] = tot;
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < N; k++) s_red[wave * N + k] = v[k];
+    }
     blk_sync<GS>();
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = ((s_red[k] + s_red[N + k]) + s_red[2 * N + k]) + s_red[3 * N + k];
