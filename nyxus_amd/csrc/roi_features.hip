@@ -465,6 +465,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // pixel get 0 from the bounds check of the load itself -- no compare, branch or 64-bit address per load, and the twelve
     // loads of a trip issue back to back.
     constexpr int kU = 4;
+    const bool small_v = vmax < (1u << 24);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(A.inten + off), 0, (int)(n * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + off), 0, (int)(n * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(A.y + off), 0, (int)(n * 2u), 0x00020000);
@@ -486,7 +487,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v[u] - vmin);   // C16 launches: every ROI counts, range < 16384
                 else s_val[i] = v[u];
                 sum += v[u];
-                sumsq += (uint32_t)(v[u] * v[u]); // unsigned-int product, wraps (intensity.cpp:90)
+                // unsigned-int product, wraps (intensity.cpp:90).  v_mul_lo_u32 issues at quarter rate; below 2^24 the 24-bit
+                // multiply returns the same low 32 bits at full rate (uniform choice per ROI).
+                sumsq += small_v ? __umul24(v[u], v[u]) : (uint32_t)(v[u] * v[u]);
                 if (use_count)
                 {
                     const uint32_t ci = v[u] - vmin;
@@ -505,7 +508,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         lvl_max = lvl > lvl_max ? lvl : lvl_max;
                 }
                 if (px[u] < w && py[u] < h)
-                    s_dense[py[u] * w + px[u]] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
+                    s_dense[__umul24(py[u], w) + px[u]] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
             }
         }
     }
@@ -966,7 +969,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         if (Pq != nullptr && nbv != 0) {
                             atomicAdd(&Pq[cbase + nbv - 1], 1u);
                             if (symmetric)
-                                atomicAdd(&Pq[(nbv - 1) * (uint32_t)Ng + (c - 1)], 1u);
+                                atomicAdd(&Pq[__umul24(nbv - 1, (uint32_t)Ng) + (c - 1)], 1u);
                         }
                     };
                     for (int row = r_begin; row < r_end; row++) {
@@ -976,7 +979,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         const uint32_t nb_se = lane_plus1(nxt, 0);   // (row+1, col+1)  angle 45
                         const uint32_t nb_sw = lane_minus1(nxt, 0);  // (row+1, col-1)  angle 135
                         if (cur != 0) {
-                            const uint32_t cbase = (cur - 1) * (uint32_t)Ng;
+                            const uint32_t cbase = __umul24(cur - 1, (uint32_t)Ng);   // levels and orders are far below 2^24
                             bump(P0, cbase, cur, nb_e);
                             bump(P1, cbase, cur, nb_se);
                             bump(P2m, cbase, cur, nxt);              // (row+1, col)    angle 90
