@@ -956,36 +956,40 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                     const bool in_col = lane < (int)w;
                     const bool remap = greyInfo < 0;
-                    uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
-                    if (remap && cur) cur = s_lvlmap[cur];
+                    // Levels travel through the loop as byte offsets (4 * level, 0 = skip): a cell address is then
+                    // matrix base + row offset + neighbour offset -- one three-operand add per pair.
+                    uint32_t cur4 = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
+                    if (remap && cur4) cur4 = s_lvlmap[cur4];
+                    cur4 <<= 2;
                     // one (centre, neighbour) pair into the matrix of its direction.  The centre's row offset is shared by the
                     // four directions; lanes beyond the last column hold level 0, so the right-hand neighbours of the last column
-                    // are "skip" without a separate test.
-                    uint32_t* const P0 = slot0 >= 0 ? s_P + slot0 * NN : nullptr;
-                    uint32_t* const P1 = slot1 >= 0 ? s_P + slot1 * NN : nullptr;
-                    uint32_t* const P2m = slot2 >= 0 ? s_P + slot2 * NN : nullptr;
-                    uint32_t* const P3 = slot3 >= 0 ? s_P + slot3 * NN : nullptr;
-                    auto bump = [=](uint32_t* Pq, uint32_t cbase, uint32_t c, uint32_t nbv) {
-                        if (Pq != nullptr && nbv != 0) {
-                            atomicAdd(&Pq[cbase + nbv - 1], 1u);
+                    // are "skip" without a separate test.  B_q = matrix q minus one element (levels are 1-based).
+                    char* const B0 = slot0 >= 0 ? (char*)(s_P + slot0 * NN) - 4 : nullptr;
+                    char* const B1 = slot1 >= 0 ? (char*)(s_P + slot1 * NN) - 4 : nullptr;
+                    char* const B2 = slot2 >= 0 ? (char*)(s_P + slot2 * NN) - 4 : nullptr;
+                    char* const B3 = slot3 >= 0 ? (char*)(s_P + slot3 * NN) - 4 : nullptr;
+                    auto bump = [=](char* Bq, uint32_t rowb, uint32_t c4, uint32_t nb4) {
+                        if (Bq != nullptr && nb4 != 0) {
+                            atomicAdd((uint32_t*)(Bq + rowb + nb4), 1u);
                             if (symmetric)
-                                atomicAdd(&Pq[__umul24(nbv - 1, (uint32_t)Ng) + (c - 1)], 1u);
+                                atomicAdd((uint32_t*)(Bq + __umul24(nb4 - 4, (uint32_t)Ng) + c4), 1u);
                         }
                     };
                     for (int row = r_begin; row < r_end; row++) {
-                        uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
-                        if (remap && nxt) nxt = s_lvlmap[nxt];      // compact index + 1 (0 stays "skip")
-                        const uint32_t nb_e = lane_plus1(cur, 0);    // (row,   col+1)  angle 0
-                        const uint32_t nb_se = lane_plus1(nxt, 0);   // (row+1, col+1)  angle 45
-                        const uint32_t nb_sw = lane_minus1(nxt, 0);  // (row+1, col-1)  angle 135
-                        if (cur != 0) {
-                            const uint32_t cbase = __umul24(cur - 1, (uint32_t)Ng);   // levels and orders are far below 2^24
-                            bump(P0, cbase, cur, nb_e);
-                            bump(P1, cbase, cur, nb_se);
-                            bump(P2m, cbase, cur, nxt);              // (row+1, col)    angle 90
-                            bump(P3, cbase, cur, nb_sw);
+                        uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                        if (remap && nxt4) nxt4 = s_lvlmap[nxt4];   // compact index + 1 (0 stays "skip")
+                        nxt4 <<= 2;
+                        const uint32_t nb_e = lane_plus1(cur4, 0);   // (row,   col+1)  angle 0
+                        const uint32_t nb_se = lane_plus1(nxt4, 0);  // (row+1, col+1)  angle 45
+                        const uint32_t nb_sw = lane_minus1(nxt4, 0); // (row+1, col-1)  angle 135
+                        if (cur4 != 0) {
+                            const uint32_t rowb = __umul24(cur4 - 4, (uint32_t)Ng);   // 4 * (level - 1) * Ng; far below 2^24
+                            bump(B0, rowb, cur4, nb_e);
+                            bump(B1, rowb, cur4, nb_se);
+                            bump(B2, rowb, cur4, nxt4);              // (row+1, col)    angle 90
+                            bump(B3, rowb, cur4, nb_sw);
                         }
-                        cur = nxt;
+                        cur4 = nxt4;
                     }
                 } else
                 for (int row = wave; row < (int)h; row += kWaves) {
