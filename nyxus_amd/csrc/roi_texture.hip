@@ -44,8 +44,11 @@ __device__ __forceinline__ double plog_tex(double p)
 // ---- GLRLM features of one angle from its LDS matrix, by one wave -------------------------
 // P[row * Nr + (len-1)], rows = level indices; lv[row] = level value (PixIntens).
 // ri / rj: scratch for row / column sums.
+// Always inlined: as a real call (shared by kernels built for different register budgets, reached with SGPRs spilled to VGPR
+// lanes) this function produced wrong GLRLM rows / faults in the global-workspace launches and a wrong GLSZM_ZP in the
+// 80-register build (tools/spill_probe.py, tests/test_parity_gpu.py::test_glrlm_alone_on_spilled_rois).
 template <bool GS>
-__device__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
+__device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
                                     uint32_t Np, double* f, int lane)
 {
     unsigned long long tot = 0;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (int c = tid; c < 16; c += kBlock) o[c] = __longlong_as_double(0x7ff8000000000000LL);
         } else {
             for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
-            for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0xFFFFFFFFu; s_hval[i] = 0; }
+            for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0; s_hval[i] = 0; }   // key 0 = empty (a size is >= 1)
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
             blk_sync<GS>();
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
@@ -488,7 +491,11 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         cnt_add(s_label[p], 1u);
                 blk_sync<GS>();
             }
-            // zones -> P(i,j) multiplicities (hash), zones per level; Nz
+            // zones -> P(i,j) multiplicities (hash), zones per level; Nz.
+            // The table is an ORDERED linear-probing hash (Amble & Knuth): a key is displaced only by a larger one, so the
+            // final layout is a function of the key SET, not of the order in which the lanes win their atomics -- the
+            // floating-point sums over the table below then run in the same order on every launch (bit-reproducible output).
+            // Keys first (atomicMax carries a displaced key onward), multiplicities in a second sweep once the layout is final.
             uint32_t nzone = 0;
             for (uint32_t p = tid; p < area; p += kBlock) {
                 uint32_t sz = cnt_get(p);
@@ -496,13 +503,24 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 nzone++;
                 uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
                 atomicAdd(&s_si[rowi], 1u);
-                uint32_t key = (rowi << 20) | sz;
-                uint32_t hsl = (key * 2654435761u) & (hcap - 1);
+                uint32_t k = (rowi << 20) | sz;
+                uint32_t hsl = (k * 2654435761u) & (hcap - 1);
                 for (;;) {
-                    uint32_t prev = atomicCAS(&s_hkey[hsl], 0xFFFFFFFFu, key);
-                    if (prev == 0xFFFFFFFFu || prev == key) { atomicAdd(&s_hval[hsl], 1u); break; }
+                    const uint32_t old = atomicMax(&s_hkey[hsl], k);
+                    if (old == k || old == 0) break;     // already present / placed in an empty slot
+                    if (old < k) k = old;                // placed here: the displaced key moves on
                     hsl = (hsl + 1) & (hcap - 1);
                 }
+            }
+            blk_sync<GS>();
+            for (uint32_t p = tid; p < area; p += kBlock) {
+                uint32_t sz = cnt_get(p);
+                if (sz == 0) continue;
+                const uint32_t key = (((uint32_t)s_lvlmap[s_dense[p]] - 1) << 20) | sz;
+                uint32_t hsl = (key * 2654435761u) & (hcap - 1);
+                while (s_hkey[hsl] != key)
+                    hsl = (hsl + 1) & (hcap - 1);
+                atomicAdd(&s_hval[hsl], 1u);
             }
             nzone = (uint32_t)wave_sum_u64(nzone);
             blk_sync<GS>();
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             double sum_p = 0;
             for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
             for (uint32_t i = tid; i < hcap; i += kBlock)
-                if (s_hkey[i] != 0xFFFFFFFFu)
+                if (s_hkey[i] != 0)
                     cnt_add(s_hkey[i] & 0xFFFFFu, s_hval[i]);
             blk_sync<GS>();
             if (sum_p == 0) {                                // glszm.cpp:229-233
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 double acc[7] = {0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < hcap; i += kBlock) {
                     uint32_t key = s_hkey[i];
-                    if (key == 0xFFFFFFFFu) continue;
+                    if (key == 0) continue;
                     double p = (double)s_hval[i];
                     double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
                     double i2 = inten * inten, j2 = jd * jd;
@@ -548,7 +566,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < hcap; i += kBlock) {
                     uint32_t key = s_hkey[i];
-                    if (key == 0xFFFFFFFFu) continue;
+                    if (key == 0) continue;
                     double p = (double)s_hval[i] / sum_p;
                     double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
                     b[0] += p * (dg * dg);                   // calc_GLV :497-510

@@ -492,3 +492,29 @@ def test_gabor_other_kernel_sizes_exact(hip_ctx, n):
     G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
     O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
     assert ((G == O) | (np.isnan(G) & np.isnan(O))).all()
+
+
+@pytest.mark.parametrize("fam", [_abi.FAM_GLRLM, _abi.FAM_GLSZM, _abi.FAM_NGTDM, _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM])
+@pytest.mark.parametrize("gd", [8, -20])
+def test_texture_families_alone_on_spilled_rois(hip_ctx, fam, gd):
+    """Each texture family ALONE over a batch that mixes LDS-sized ROIs with ROIs that take the global workspace: the carve-out
+    (hence the register tier of roi_texture_kernel) depends on the family set, so the combinations are not covered by the
+    all-families tests.  GLRLM alone used to return zero rows for the spilled ROIs."""
+    b = _abi.batch_from_rois(_large_rois())
+    s = _abi.default_settings(gd)
+    G = hip_ctx.featurize_host(b, fam, s)
+    O = po.oracle_featurize(b, fam, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(fam, s))
+
+
+@pytest.mark.parametrize("gd", [17, 20, 32, 48, -8, -24])
+def test_glcm_in_kernel_features_at_tight_register_tiers(hip_ctx, gd):
+    """Grey depths above 16 (and radiomics binning) keep the GLCM features inside roi_features_kernel; with small ROIs the
+    carve-out is small enough for the 72/80/96-register builds."""
+    rois = synth.random_rois(120, seed=77, rmax=14)
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd)
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
