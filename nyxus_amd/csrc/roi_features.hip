@@ -369,7 +369,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 // FAM: family set known at compile time -- 0: read A.mask; 1: INTENSITY + GLCM under matlab binning with <= 16 levels (what
 // make_layout's dense8 stands for); 2: INTENSITY alone.  The 64-VGPR tier is only launched for 1 and 2, so the run-time
 // switches are compile-time facts there and their branches disappear from the pixel loops.
-template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0>
+// TIER: occupancy tier of the calling kernel; it only tags the kernel's private copy of glcm_features_rows (kRowsTag), so
+// that caller and callee are always compiled for the same register budget.
+template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -396,6 +398,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     const uint32_t area = w * h;
     const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
     constexpr bool FAST = FAM == 1;
+    constexpr int kRowsTag = 16 + TIER * 4 + (C16 ? 2 : 0) + (D8 ? 1 : 0);
     const bool do_int = FAM != 0 || (A.mask & NYXHIP_FAM_INTENSITY) != 0;
     const bool do_glcm = FAM == 1 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);
     double* const out_row = A.out + roi * A.ld;
@@ -1024,9 +1027,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 } else if (SPLIT) {
                 } else if (Ng <= 16) {               // small matrices: the four angles share one wave's instruction stream
                     if (wave == 0)
-                        glcm_features_rows<GS, 16>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
+                        glcm_features_rows<GS, 16, kRowsTag>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
                 } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells
-                    glcm_features_rows<GS, 64>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * A.L.ng_cap, 6 * (int)A.L.ng_cap,
+                    glcm_features_rows<GS, 64, kRowsTag>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * A.L.ng_cap, 6 * (int)A.L.ng_cap,
                                                A.soft_nan, s_f + (a0 + wave) * 32, lane);
             }
             blk_sync<GS>();
@@ -1069,22 +1072,22 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 5>(A);
 }
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 6>(A);
 }
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 7>(A);
 }
 template <int FAM>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, FAM == 1, true, FAM>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM, 8>(A);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
