@@ -566,7 +566,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
         // Q = entries of the counting table scanned per wave (multiple of 256)
         const uint32_t Q = ((range + 1 + kWaves * 256 - 1) / (kWaves * 256)) * 256;
-        uint32_t woff1 = 0, woff2 = 0, woff3 = 0; // prefix offsets of waves 1..3 (wave 0 starts at 0)
+        uint32_t* const s_woff = (uint32_t*)(s_stat + 8);   // [4] prefix offsets of the waves' table quarters (kept in LDS: as
+                                                            // registers they were live across the whole intensity block and spilled)
         if (use_count) {
             // ---- counting engine: per-wave inclusive prefix sums over s_cnt, in place (each
             // lane owns 4 consecutive entries of a 256-entry tile: one 16-byte LDS access each
@@ -627,11 +628,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
                 if (c > mc) { mc = c; mi = i; } // waves cover ascending value ranges
             }
-            woff1 = (uint32_t)s_red[0];
-            woff2 = woff1 + (uint32_t)s_red[8];
-            woff3 = woff2 + (uint32_t)s_red[16];
-            if (tid == 0)
+            if (tid == 0) {
+                const uint32_t woff1 = (uint32_t)s_red[0], woff2 = woff1 + (uint32_t)s_red[8], woff3 = woff2 + (uint32_t)s_red[16];
+                s_woff[0] = 0; s_woff[1] = woff1; s_woff[2] = woff2; s_woff[3] = woff3;
                 s_stat[S_MODE] = (double)(vmin + mi);
+            }
             blk_sync<GS>();
         } else {
             bitonic_sort<GS>(s_val, P2, tid);
@@ -639,8 +640,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         STAMP(3);
         // C(i) = number of values <= vmin + i (counting engine)
         auto cum = [=](uint32_t i) -> uint32_t {
-            uint32_t wq = i / Q;
-            return (C16 ? (uint32_t)((const uint16_t*)s_cnt)[i] : s_cnt[i]) + (wq == 0 ? 0u : wq == 1 ? woff1 : wq == 2 ? woff2 : woff3);
+            const uint32_t wq = (uint32_t)(i >= Q) + (uint32_t)(i >= 2 * Q) + (uint32_t)(i >= 3 * Q);   // i / Q without the division
+            return (C16 ? (uint32_t)((const uint16_t*)s_cnt)[i] : s_cnt[i]) + s_woff[wq];
         };
 
         // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183;
@@ -868,7 +869,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         const int na = A.glcm_na;
         const int ncol_g = kGlcmAngled * na + kGlcmAve;
         // degenerate guard (glcm.cpp:27-95) uses GLCM_GREYDEPTH
-        const bool degenerate = bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth);
+        // (the extrema pass through readfirstlane so that their conversions to double are redone here instead of being kept
+        // -- spilled -- since the load phase)
+        const uint32_t vmin_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmin), vmax_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmax);
+        const bool degenerate = bin_pixel(vmin_g, vmin_g, vmax_g, A.glcm_grey_depth) == bin_pixel(vmax_g, vmin_g, vmax_g, A.glcm_grey_depth);
 
         // matrix order and level values (glcm.cpp:388-420)
         double* s_I = s_g;                       // [ng_cap] level values
