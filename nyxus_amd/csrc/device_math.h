@@ -229,6 +229,23 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
     v += dpp_perm<0x140>(v);
     return v;
 }
+// ---- (row, column) of a linear index that advances by a fixed stride -----------------------------------------------
+// p = first, first + stride, ... over a plane of width w: one integer division per thread and loop instead of one per pixel
+// (a u32 division is ~25 instructions, two of them quarter-rate multiplies).
+struct RowCol {
+    uint32_t row, col, step_r, step_c, w;
+    __device__ __forceinline__ RowCol(uint32_t first, uint32_t stride, uint32_t width) : w(width)
+    {
+        row = first / width; col = first - row * width;
+        step_r = stride / width; step_c = stride - step_r * width;
+    }
+    __device__ __forceinline__ void advance()
+    {
+        col += step_c; row += step_r;
+        if (col >= w) { col -= w; row++; }
+    }
+};
+
 // ---- transposed wave sum: 64 per-lane slots, lane L ends up with the wave total of slot L ------------------------
 // Each step pairs the lanes and halves the slot list (one partner keeps the lower half, the other the upper half, each adds
 // what the partner held of its half): 32 + 16 + 8 + 4 + 2 + 1 = 63 exchanges instead of 64 six-step butterflies.  The two

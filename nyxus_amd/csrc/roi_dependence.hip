@@ -160,8 +160,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         // distance of a pixel = min over the four axis directions of (steps to the nearest zero or to the bbox margin) + 1
         // (dist2border :238-285); a pixel on the margin gets 1.  Closed form for the margins, outward probe for zeros
         // (only the IBSI plane holds zeros: matlab binning has none, radiomics binning is refused by the host).
-        auto dist_of = [=](uint32_t p) {
-            const uint32_t y = p / w, x = p - y * w;
+        auto dist_of = [=](uint32_t p, uint32_t y, uint32_t x) {
             uint32_t best = x + 1;
             best = w - x < best ? w - x : best;
             best = y + 1 < best ? y + 1 : best;
@@ -205,11 +204,12 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 a = old;                                                // somebody re-parented a first: retry from there
             }
         };
-        for (uint32_t p = w + tid; p < area; p += kBlk) {
+        RowCol rc_v(w + (uint32_t)tid, kBlk, w);
+        for (uint32_t p = w + tid; p < area; p += kBlk, rc_v.advance()) {
             if (s_label[p] == kNone) continue;
             const uint16_t v = s_dense[p];
             if (s_dense[p - w] != v) continue;
-            const uint32_t x = p % w;
+            const uint32_t x = rc_v.col;
             if (x > 0 && s_dense[p - 1] == v && s_dense[p - w - 1] == v) continue;
             unite(p, p - w);
         }
@@ -222,10 +222,11 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         blk_sync<GS>();
         // (3) zone metric = min distance over the members, kept in the root's own slot as kRootTag | (0xFFFF - d) under
         //     atomicMax (a member reads its root from its own slot, which nobody else writes)
-        for (uint32_t p = tid; p < area; p += kBlk) {
+        RowCol rc_d((uint32_t)tid, kBlk, w);
+        for (uint32_t p = tid; p < area; p += kBlk, rc_d.advance()) {
             const uint32_t l = s_label[p];
             if (l == kNone) continue;
-            const uint32_t d = dist_of(p);
+            const uint32_t d = dist_of(p, rc_d.row, rc_d.col);
             atomicMax(&s_label[l >= kRootTag ? p : l], kRootTag | (0xFFFFu - d));
         }
         blk_sync<GS>();
@@ -313,10 +314,11 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int i = tid; i < Ng * 9; i += kBlk) s_P[i] = 0;
         blk_sync<GS>();
         uint32_t nd_loc = 0;
-        for (uint32_t p = tid; p < area; p += kBlk) {
+        RowCol rc_dm((uint32_t)tid, kBlk, w);
+        for (uint32_t p = tid; p < area; p += kBlk, rc_dm.advance()) {
             if (!(s_aux[p] & kOrigNZ)) continue;                     // skip by ORIGINAL intensity, gldm.cpp:83-84
             const uint32_t pi = s_dense[p];
-            const int y = (int)(p / w), x = (int)(p - (uint32_t)y * w);
+            const int y = (int)rc_dm.row, x = (int)rc_dm.col;
             uint32_t nd = 1;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -408,11 +410,12 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int i = tid; i < Ng2 * 9; i += kBlk) s_M[i] = 0;
         blk_sync<GS>();
         uint32_t dep_loc = 0;
-        for (uint32_t p = tid; p < area; p += kBlk) {
+        RowCol rc_ng((uint32_t)tid, kBlk, w);
+        for (uint32_t p = tid; p < area; p += kBlk, rc_ng.advance()) {
             const uint32_t ap = s_aux[p];
             if (!(ap & kInCloud)) continue;
             const uint32_t c = ap & kLvlMask;
-            const int y = (int)(p / w), x = (int)(p - (uint32_t)y * w);
+            const int y = (int)rc_ng.row, x = (int)rc_ng.col;
             uint32_t nm = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {

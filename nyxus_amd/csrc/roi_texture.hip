@@ -634,10 +634,11 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         } else {
             for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
             blk_sync<GS>();
-            for (uint32_t p = tid; p < area; p += kBlock) {
+            RowCol rc((uint32_t)tid, kBlock, w);
+            for (uint32_t p = tid; p < area; p += kBlock, rc.advance()) {
                 uint32_t pi = s_dense[p];
                 if (pi == 0) continue;
-                int row = (int)(p / w), cl = (int)(p - (uint32_t)row * w);
+                const int row = (int)rc.row, cl = (int)rc.col;
                 uint32_t sum = 0, nd = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {                     // N,NE,E,SE,S,SW,W,NW (ngtdm.cpp:92-139)
