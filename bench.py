@@ -112,15 +112,13 @@ def main():
     ctx.set_stream(stream.cuda_stream)       # kernels + events on torch's current stream
     gather = TableGather(ncol, dst=0) if world > 1 else None
 
+    # The path shards by ROI with no exchange step: the timed region holds no collective.  The one collective of a
+    # multi-GPU job -- the gather of the final feature table to rank 0 (north_star) -- runs once after the timed steps and
+    # is reported on its own (`table_gather`): at 290 MB of table per 3.5 ms step a per-step gather would measure the
+    # xGMI link (~60 GB/s per peer), not the reduce path.
     def step(i):
         out = outs[i & 1]
         ctx.featurize_device_async(cb, mask, s, out.data_ptr(), ncol)
-        if gather is not None:
-            if i > 0:
-                gather.finish()              # previous step's gather overlapped this launch
-            # ProcessGroupNCCL orders the collective after the work already queued on the
-            # current stream (this step's kernel); async_op leaves the next launch free to overlap
-            gather.start(out, rows_per_rank=[n_roi] * world)
         return out
 
     def fence():
@@ -130,16 +128,12 @@ def main():
 
     for i in range(a.warmup):
         step(i)
-    if gather is not None and a.warmup:
-        gather.finish()
     fence()
     ctx.timing(True)
     t0 = time.perf_counter()
     last = None
     for i in range(a.steps):
         last = step(i)
-    if gather is not None:
-        gather.finish()
     fence()
     t1 = time.perf_counter()
     ctx.sync()                               # raises on a device-side error flag
@@ -150,6 +144,20 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    gather_ms = None
+    gather_err = None
+    if gather is not None:                   # final table -> rank 0, once, outside the timed region
+        try:
+            g0 = time.perf_counter()
+            gather.start(last, rows_per_rank=[n_roi] * world)
+            full = gather.finish()
+            fence()
+            gather_ms = 1e3 * (time.perf_counter() - g0)
+            if rank == 0 and full is not None and tuple(full.shape) != (n_roi * world, ncol):
+                gather_err = f"gathered table has shape {tuple(full.shape)}"
+            del full
+        except Exception as e:               # the bench line is still printed; the failure is part of it
+            gather_err = repr(e)
 
     if rank == 0:
         total_rois = n_roi * world * a.steps
@@ -177,7 +185,8 @@ def main():
                                    f"(disk r=30, {n_px_roi} px, bbox {side}x{side}), intensities U[1,4095]; "
                                    "reduce stage on pre-assembled ROI clouds resident in HBM",
                        "rois_per_step_per_gpu": n_roi, "n_columns": ncol,
-                       "sharding": f"{world} rank(s), tiles block-partitioned, RCCL gather of the table to rank 0"
+                       "sharding": f"{world} rank(s), tiles block-partitioned, no collective in the timed region; "
+                                   "final table gathered to rank 0 over RCCL afterwards (table_gather)"
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -186,6 +195,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
 
+        if gather_ms is not None or gather_err is not None:
+            gb = n_roi * world * ncol * 8 / 1e9
+            rec["table_gather"] = {"ms": gather_ms, "GB": gb, "GBps": (gb / (gather_ms * 1e-3)) if gather_ms else None, "error": gather_err,
+                                   "what": "one RCCL gather of the last step's table (all ranks -> rank 0), outside the timed region"}
         # ---- parity spot check of what was timed (first tile of the last step) -----------------
         if not a.no_check:
             from oracle import pyoracle as po
