@@ -768,18 +768,23 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
     uint32_t groups = 0xF;
     bool feat_all_gs = false;
-    int lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why, groups);
-    if (lrc == NYXHIP_ERR_UNSUPPORTED && mask1) {
-        // a GLCM grey depth whose matrix does not fit LDS next to any ROI: the whole INTENSITY + GLCM group runs from the
-        // global workspace instead (slow, but every depth the matrices' 2 GiB offset range allows is served)
-        RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
-        std::string why2;
-        if (build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
-            feat_all_gs = true;
-            groups = 0xE;
-            lrc = build_args(ctx, b, mask, s, d_out, ld, full, 0, a, t, g, d, why, groups);
+    // Builds the LDS argument blocks for one set of extrema.  A GLCM grey depth whose matrix does not fit LDS next to any ROI
+    // sends the whole INTENSITY + GLCM group to the global workspace instead (slow, but every depth the matrices' 2 GiB
+    // offset range allows is served); the other groups keep their LDS launches.
+    auto try_build = [&](const Extrema& E) -> int {
+        int rc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+        if (rc == NYXHIP_ERR_UNSUPPORTED && mask1 && !feat_all_gs) {
+            RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
+            std::string why2;
+            if (build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
+                feat_all_gs = true;
+                groups = 0xE;
+                rc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+            }
         }
-    }
+        return rc;
+    };
+    int lrc = try_build(full);
     bool need_spill = false;
     Extrema capE = full;
     if (lrc == NYXHIP_ERR_UNSUPPORTED)
@@ -791,7 +796,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         capE.area = std::min<uint32_t>(max_area, 16384);
         capE.side = std::min<uint32_t>(max_side, 256);
         for (int tries = 0; tries < 8; tries++) {
-            lrc = build_args(ctx, b, mask, s, d_out, ld, capE, 0, a, t, g, d, why, groups);
+            lrc = try_build(capE);
             if (lrc != NYXHIP_ERR_ROI_TOO_LARGE) break;
             capE.px = std::max<uint32_t>(capE.px / 2, 64); capE.area = std::max<uint32_t>(capE.area / 2, 64); capE.side = std::max<uint32_t>(capE.side / 2, 8);
         }

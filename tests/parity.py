@@ -31,7 +31,7 @@ def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=
             scale = np.nanmax(np.abs(np.where(np.isfinite(w), w, 0.0))) if len(w) else 0.0
             with np.errstate(invalid="ignore"):
                 ok |= np.abs(g - w) <= rel * np.abs(w) + 1e-9 * max(scale, 1.0) * 0 + 1e-12 * max(scale, 1.0)
-        if base == "GLCM_INFOMEAS2":
+        if base in ("GLCM_INFOMEAS2", "GLCM_INFOMEAS2_AVE"):
             # sqrt(|1 - exp(-2 (HXY2 - HXY))|): when the matrix is (numerically) a product of its marginals the argument is
             # +-1 ulp of cancellation noise and the value is 0 or sqrt(2^-52 .. 2^-50) = 1.5e-8 .. 3e-8 on either side
             # (the reference itself lands on both); on the feature's [0, 1] scale that is an absolute 1e-7.
@@ -52,5 +52,16 @@ def moment_atol(b):
     m00_s = np.diff(off).astype(float)
     m00_i = np.array([np.asarray(b.inten[off[r]:off[r + 1]], dtype=float).sum() for r in range(len(m00_s))])
     side = np.maximum(b.bbox_w, b.bbox_h).astype(float)
-    return {"CENTRAL_MOMENT_01": 1e-9 * m00_s * side, "CENTRAL_MOMENT_10": 1e-9 * m00_s * side,
-            "IMOM_CM_01": 1e-9 * m00_i * side, "IMOM_CM_10": 1e-9 * m00_i * side}
+    tol = {"CENTRAL_MOMENT_01": 1e-9 * m00_s * side, "CENTRAL_MOMENT_10": 1e-9 * m00_s * side,
+           "IMOM_CM_01": 1e-9 * m00_i * side, "IMOM_CM_10": 1e-9 * m00_i * side}
+    # Higher central moments: sums of m00 terms of size up to (side / 2)^(p + q) that cancel for symmetric shapes (odd orders
+    # of an ellipse vanish identically); what survives is rounding noise ~ eps * sum |terms|.  Floor: 1e-13 of that sum's
+    # bound -- eight orders below the 1e-5 relative bound that applies whenever the moment is not a cancellation.
+    for p in range(4):
+        for q in range(4):
+            if p + q < 2:
+                continue
+            scale = 1e-13 * (side / 2.0) ** (p + q)
+            tol["CENTRAL_MOMENT_%d%d" % (p, q)] = scale * m00_s
+            tol["IMOM_CM_%d%d" % (p, q)] = scale * m00_i
+    return tol

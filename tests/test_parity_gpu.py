@@ -518,3 +518,17 @@ def test_glcm_in_kernel_features_at_tight_register_tiers(hip_ctx, gd):
     G = hip_ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
     assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
+
+
+@pytest.mark.parametrize("mask", [_abi.FAM_INTENSITY | _abi.FAM_GLCM, _abi.FAM_GLCM | _abi.FAM_GLSZM | _abi.FAM_GLDM])
+def test_deep_glcm_with_a_spilled_roi(hip_ctx, mask):
+    """A grey depth whose co-occurrence matrix does not fit LDS (200 levels) in a batch that ALSO holds a ROI for the global
+    workspace: the INTENSITY + GLCM group must fall back to the workspace in the spill flow too (it used to refuse)."""
+    rng = np.random.default_rng(5)
+    ys, xs = np.nonzero(np.ones((300, 280), bool))
+    rois = synth.random_rois(10, seed=3, rmax=14) + [dict(x=xs, y=ys, inten=rng.integers(1, 4096, len(xs)).astype(np.uint32))]
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(200)
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
