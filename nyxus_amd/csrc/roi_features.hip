@@ -68,7 +68,7 @@ enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MODE, S_NG };
 template <int N, bool GS>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (N > 4) {                                     // transposed wave sums: the lane group of slot k ends up with its total
         double t[8];
 #pragma unroll
@@ -376,7 +376,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
 __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t roi = (uint64_t)blockIdx.x * kWaves + wave;
     if (roi >= A.n_roi)
         return;

@@ -216,7 +216,7 @@ constexpr int kMB = 256;
 template <int N, bool GS>
 __device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int tid)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (N > 8) {                                      // transposed wave sums (device_math.h): slot k's total lands in its lane group
         static_assert(N <= 16, "mom_block_sum: at most 16 sums");
         double t[16];

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     constexpr int kBlk = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
 {
     constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
     if (roi >= A.n_roi)
         return;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* const s_xy = (uint32_t*)lds_raw;                 // [zern_px_cap] x | y << 16 of the staged cloud
     uint32_t* const s_v = s_xy + A.L.zern_px_cap;              // [zern_px_cap] intensities
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t roi = blockIdx.x;   // no size limit: always part of the first (non-spill) launch
     if (roi >= A.n_roi)
         return;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) void tile_block_sums_kernel(TileTables T, uin
 {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t l = blockIdx.x * 1024u + tid;
     const uint32_t cnt = (l >= 1 && l < n_entries) ? T.cnt[l] : 0;
     const uint32_t rows = (uint32_t)__popcll(__ballot(cnt != 0));
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32
 {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // rows / pixels of all preceding blocks
     uint32_t pre_r = 0; unsigned long long pre_p = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += 1024) { pre_r += blk_rows[b]; pre_p += blk_px[b]; }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
     // pair ranks 1024 pixels.  (bx, by) advance incrementally: one integer division per thread and ROI.
     constexpr int U = 4;
     __shared__ uint32_t s_cnt[U * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t row = blockIdx.x;
     // R.label holds the table index tile * stride + label; y0 is tile-relative
     const uint32_t key = R.label[row], tile = key / stride, L = key - tile * stride;
