@@ -380,6 +380,19 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         uint32_t* s_si = s_hval + A.L.hash_cap;              // [Ng] zones per level
         uint32_t* s_label = (uint32_t*)(s_work + A.L.szm_label);   // [area] owner index of each pixel (boxes wider than 64 only)
         const uint32_t hcap = A.L.hash_cap;
+        // P(i,j) cells: sizes <= S sit in a direct [level][size] table (one atomic per zone), larger ones in the ordered hash.
+        // Every pass over the cells walks hash slots first, then the table: a fixed order on every launch.
+        const uint32_t S = A.L.szm_small;                     // 0 or 32
+        uint32_t* s_small = (uint32_t*)(s_work + A.L.szm_smalltab);
+        const uint32_t n_cells = hcap + (uint32_t)Ng * S;
+        auto cell = [=](uint32_t i, uint32_t& key, uint32_t& val) {
+            if (i < hcap) { key = s_hkey[i]; val = s_hval[i]; }
+            else {
+                const uint32_t idx = i - hcap;
+                val = s_small[idx];
+                key = val ? ((idx >> 5) << 20) | ((idx & 31u) + 1u) : 0u;    // S == 32 whenever this branch exists
+            }
+        };
         // zone-size table: 16-bit entries packed two per word while every size fits (halves never carry: a count is <= area)
         const bool c16 = A.L.szm_c16 != 0;
         auto cnt_add = [=](uint32_t idx, uint32_t inc) {
@@ -398,6 +411,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         } else {
             for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
             for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0; s_hval[i] = 0; }   // key 0 = empty (a size is >= 1)
+            for (uint32_t i = tid; i < (uint32_t)Ng * S; i += kBlock) s_small[i] = 0;
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
             blk_sync<GS>();
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 nzone++;
                 uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
                 atomicAdd(&s_si[rowi], 1u);
+                if (sz <= S) { atomicAdd(&s_small[rowi * 32u + (sz - 1u)], 1u); continue; }
                 uint32_t k = (rowi << 20) | sz;
                 uint32_t hsl = (k * 2654435761u) & (hcap - 1);
                 for (;;) {
@@ -515,7 +530,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             blk_sync<GS>();
             for (uint32_t p = tid; p < area; p += kBlock) {
                 uint32_t sz = cnt_get(p);
-                if (sz == 0) continue;
+                if (sz <= S) continue;                   // no zone here, or counted in the direct table
                 const uint32_t key = (((uint32_t)s_lvlmap[s_dense[p]] - 1) << 20) | sz;
                 uint32_t hsl = (key * 2654435761u) & (hcap - 1);
                 while (s_hkey[hsl] != key)
@@ -530,19 +545,23 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             blk_sync<GS>();
             double sum_p = 0;
             for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
-            for (uint32_t i = tid; i < hcap; i += kBlock)
-                if (s_hkey[i] != 0)
-                    cnt_add(s_hkey[i] & 0xFFFFFu, s_hval[i]);
+            for (uint32_t i = tid; i < n_cells; i += kBlock) {
+                uint32_t key, val;
+                cell(i, key, val);
+                if (key != 0)
+                    cnt_add(key & 0xFFFFFu, val);
+            }
             blk_sync<GS>();
             if (sum_p == 0) {                                // glszm.cpp:229-233
                 for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
             } else {
                 // calc_sums_of_P :342-395 over the non-zero cells
                 double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t i = tid; i < hcap; i += kBlock) {
-                    uint32_t key = s_hkey[i];
+                for (uint32_t i = tid; i < n_cells; i += kBlock) {
+                    uint32_t key, val;
+                    cell(i, key, val);
                     if (key == 0) continue;
-                    double p = (double)s_hval[i];
+                    double p = (double)val;
                     double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
                     double i2 = inten * inten, j2 = jd * jd;
                     acc[0] += p * i2 * j2;                   // f_LAHGLE
@@ -564,10 +583,11 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 blk_sync<GS>();
                 const double mu_ZV = acc[5], mu_GLV = acc[6];
                 double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t i = tid; i < hcap; i += kBlock) {
-                    uint32_t key = s_hkey[i];
+                for (uint32_t i = tid; i < n_cells; i += kBlock) {
+                    uint32_t key, val;
+                    cell(i, key, val);
                     if (key == 0) continue;
-                    double p = (double)s_hval[i] / sum_p;
+                    double p = (double)val / sum_p;
                     double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
                     b[0] += p * (dg * dg);                   // calc_GLV :497-510
                     b[1] += p * (dz * dz);                   // calc_ZV :512-524
