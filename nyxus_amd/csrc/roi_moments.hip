@@ -347,7 +347,10 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
                 for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
         }
         mom_block_sum<16, false>(acc, s_red, tid);
-        if (tid < 16) s_raw[var][tid] = acc[tid];
+        if (tid == 0) {                                  // compile-time indices only: a run-time index would send the array to scratch
+#pragma unroll
+            for (int k = 0; k < 16; k++) s_raw[var][k] = acc[k];
+        }
     }
     __syncthreads();
     // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316); each variant has its own origin
@@ -367,7 +370,10 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
                 for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
         }
         mom_block_sum<16, false>(acc, s_red, tid);
-        if (tid < 16) s_cen[var][tid] = acc[tid];
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) s_cen[var][k] = acc[k];
+        }
     }
     __syncthreads();
     // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
@@ -394,7 +400,10 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         }
         mom_block_sum<10, false>(as, s_red, tid);
         mom_block_sum<10, false>(ai, s_red, tid);
-        if (tid < 10) { s_wraw[0][tid] = as[tid]; s_wraw[1][tid] = ai[tid]; }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) { s_wraw[0][k] = as[k]; s_wraw[1][k] = ai[k]; }
+        }
     }
     __syncthreads();
     // ---- pass 4: weighted central moments about the weighted origin (:162-167, :318-327) -----------------------------------
@@ -422,7 +431,10 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         }
         mom_block_sum<7, false>(as, s_red, tid);
         mom_block_sum<7, false>(ai, s_red, tid);
-        if (tid < 7) { s_wcen[0][tid] = as[tid]; s_wcen[1][tid] = ai[tid]; }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) { s_wcen[0][k] = as[k]; s_wcen[1][k] = ai[k]; }
+        }
     }
     __syncthreads();
     // ---- derived values and output ------------------------------------------------------------------------------------------
