@@ -705,7 +705,7 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
     const uint32_t grid = (uint32_t)b->n_roi;
     const uint32_t lds_cap = (uint32_t)roi_features_max_lds();
     int rc;
-    if (full_plane <= lds_cap) {
+    if ((uint64_t)kContourWaves * ((full_plane + 15) & ~15ull) <= lds_cap) {   // kContourWaves planes per workgroup
         m.plane_cap = (uint32_t)full_plane;
         rc = launch_roi_contour(m, st, grid);
     } else {

@@ -168,7 +168,10 @@ constexpr int kMomCols = 90;              // per family: RM 13, CM 16, NRM 16, N
 constexpr int kMomStepTab = 2048;         // hill-descent step table (window width -> step)
 constexpr int kMomContourLds = 4096;      // contour points the moments kernel keeps in LDS (longer contours are read from HBM)
 
+constexpr int kContourWaves = 4;     // ROIs (waves) per workgroup of roi_contour_kernel
+
 struct MomArgs {
+    uint32_t grid_rois;       // contour launch: ROI slots of the launch (kContourWaves per workgroup)
     uint64_t n_roi;
     const uint64_t* px_offset;
     const uint16_t* x;

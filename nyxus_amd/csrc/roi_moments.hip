@@ -35,12 +35,16 @@ __device__ __forceinline__ int dial_pos(int dx, int dy)     // contour.cpp:218-2
 } // namespace
 
 template <bool GS>
-__global__ __launch_bounds__(64) void roi_contour_kernel(const MomArgs A)
+__global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const MomArgs A)
 {
+    // one wave per ROI, kContourWaves ROIs per workgroup (the waves never meet: no workgroup barrier in this kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint8_t* const img = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;   // [(w+2)*(h+2)] flag plane
-    const int lane = threadIdx.x;
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
+    const int lane = threadIdx.x & 63, wslot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t slot = (uint64_t)blockIdx.x * kContourWaves + (uint64_t)wslot;
+    if (slot >= A.grid_rois)
+        return;
+    uint8_t* const img = GS ? A.sp.scratch + (size_t)slot * A.sp.stride : lds_raw + (size_t)wslot * ((A.plane_cap + 15u) & ~15u);   // [(w+2)*(h+2)] flag plane
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[slot] : slot;
     if (roi >= A.n_roi)
         return;
     const uint64_t off = A.px_offset[roi];
@@ -73,42 +77,45 @@ __global__ __launch_bounds__(64) void roi_contour_kernel(const MomArgs A)
     // at the run's first pixel the scan is outside; a border mark switches it inside for the rest of the run, an unmarked
     // pixel starts a trace (which switches it inside when the trace closes).  Run starts are found 64 positions at a
     // time with a ballot; lane 0 replays the state machine on each run in raster order (traces change the marks).
+    // The trace itself (:432-470) probes the eight neighbours one at a time, clockwise from `loc`, until it meets a pixel.
+    // Here lanes 0-7 read the eight neighbours in that order at once and a ballot gives the number of misses before the hit:
+    // one LDS round trip per contour step instead of one per probe.  Direction d = 0..7 is W, NW, N, NE, E, SE, S, SW
+    // (offsets -1, -W2-1, -W2, -W2+1, +1, W2+1, W2, W2-1 of the reference's table); after a hit in direction d the search
+    // restarts at loc = {7,7,1,1,3,3,5,5}[d].  Nine misses in a row (no neighbour at all) end the trace like `counter2 > 8`.
     {
-        const int nbo[8] = {-1, -3 - w, -w - 2, -1 - w, 1, 3 + w, w + 2, 1 + w};
-        const int nbn[8] = {7, 7, 1, 1, 3, 3, 5, 5};
+        constexpr uint32_t kDx = 0x1A90u, kDy = 0xA901u;             // (dx + 1), (dy + 1) of direction d in bits 2d, 2d + 1
         for (uint32_t base = 0; base < np; base += 64) {
             const uint32_t p = base + (uint32_t)lane;
             const bool run_start = p < np && (img[p] & kPix) && !(p > 0 && (img[p - 1] & kPix));
             unsigned long long m = __ballot(run_start);
-            if (lane == 0)
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    bool inside = false;
-                    for (uint32_t p0 = base + (uint32_t)b; !inside; p0++) {
-                        const uint8_t v = img[p0];
-                        if (!(v & kPix)) break;                       // the run is over: outside again
-                        if (v & kBorder) { inside = true; break; }    // entering an already discovered border
-                        img[p0] = v | kBorder;                        // undiscovered border point: trace around it
-                        int pos = (int)p0, loc = 1, counter = 0, counter2 = 0;
-                        for (;;) {
-                            const int cp = pos + nbo[loc - 1], nloc = nbn[loc - 1];
-                            if (cp < 0 || (uint32_t)cp >= np) break;
-                            const uint8_t c = img[cp];
-                            if (c & kPix) {
-                                if (cp == (int)p0) {
-                                    counter++;
-                                    if (nloc == 1 || counter >= 3) { inside = true; break; }
-                                }
-                                loc = nloc; pos = cp; counter2 = 0; img[cp] = c | kBorder;
-                            } else {
-                                loc = 1 + (loc % 8);
-                                if (counter2 > 8) break;
-                                counter2++;
-                            }
+            while (m) {                                               // wave-uniform from here on
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                bool inside = false;
+                for (uint32_t p0 = base + (uint32_t)b; !inside; p0++) {
+                    const uint8_t v = img[p0];
+                    if (!(v & kPix)) break;                           // the run is over: outside again
+                    if (v & kBorder) { inside = true; break; }        // entering an already discovered border
+                    if (lane == 0) img[p0] = v | kBorder;             // undiscovered border point: trace around it
+                    int pos = (int)p0, loc = 1, counter = 0;
+                    for (;;) {
+                        const int d = (loc - 1 + lane) & 7;
+                        const int cpl = pos + ((int)((kDy >> (2 * d)) & 3u) - 1) * W2 + ((int)((kDx >> (2 * d)) & 3u) - 1);
+                        const bool hit = lane < 8 && cpl >= 0 && (uint32_t)cpl < np && (img[cpl] & kPix);
+                        const uint32_t hm = (uint32_t)__ballot(hit) & 0xFFu;
+                        if (hm == 0) break;
+                        const int dk = (loc - 1 + (__ffs((int)hm) - 1)) & 7;
+                        const int cp = pos + ((int)((kDy >> (2 * dk)) & 3u) - 1) * W2 + ((int)((kDx >> (2 * dk)) & 3u) - 1);
+                        const int nloc = ((dk & ~1) + 7) & 7;
+                        if (cp == (int)p0) {
+                            counter++;
+                            if (nloc == 1 || counter >= 3) { inside = true; break; }
                         }
+                        loc = nloc; pos = cp;
+                        if (lane == 0) img[cp] |= kBorder;
                     }
                 }
+            }
             wav_sync<GS>();
         }
     }
@@ -479,10 +486,13 @@ int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid)
     }
     if (grid == 0)
         return 0;
+    MomArgs b = a;
+    b.grid_rois = grid;
+    const uint32_t wgs = (grid + kContourWaves - 1) / kContourWaves;
     if (a.sp.scratch)
-        hipLaunchKernelGGL(roi_contour_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(roi_contour_kernel<true>, dim3(wgs), dim3(64 * kContourWaves), 0, (hipStream_t)stream, b);
     else
-        hipLaunchKernelGGL(roi_contour_kernel<false>, dim3(grid), dim3(64), (a.plane_cap + 15u) & ~15u, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(roi_contour_kernel<false>, dim3(wgs), dim3(64 * kContourWaves), kContourWaves * ((a.plane_cap + 15u) & ~15u), (hipStream_t)stream, b);
     return (int)hipGetLastError();
 }
 
