@@ -283,48 +283,53 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (int c = tid; c < 80; c += kBlock) o[c] = Ng < 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
         } else {
             if (nslot >= 4 && side <= 64) {
-                // All four angles at once.  One line of a direction per step, one lane per pixel of the line: the ballot of
-                // "equals the next pixel" turns every run into a string of set bits, so a run's first lane reads its length
-                // off the mask (no walking, no divergence on long runs).  The 2(w + h) + ... lines of the four directions are
-                // dealt round-robin to the four waves (the diagonals have twice the lines of the axes); the next line's
-                // pixels are fetched before the current line's atomics go out.
+                // One wave per direction, one lane per column, one step per row (h steps instead of one step per line of
+                // the direction -- the two diagonals alone have 2 (w + h - 1) lines).
+                //   E  (wave 0): the ballot of "equals the next pixel" turns every run of a row into a string of set bits; a
+                //                run's first lane reads its length off the mask.
+                //   SE, S, SW (waves 1-3): every lane carries the run (value, length) that ends on its line in the previous
+                //                row; for the diagonals the pair moves one lane right / left per row through a DPP wave shift.
+                //                A run is counted when its line ends or the value changes.  A pair that is shifted past the
+                //                last column lands on a lane that always reads level 0 and is counted there; the pairs that
+                //                would leave the wave (lane 0 for SW, lane 63 of a 64-wide box for SE) are counted before
+                //                the shift.
+                // Each wave fills and then reads its own matrix: no workgroup barrier between the scan and the features.
                 blk_sync<GS>();
                 for (uint32_t i = tid; i < 4u * slot_words; i += kBlock) s_mat[i] = 0;
                 blk_sync<GS>();
-                const int nE = (int)h, nD = (int)(w + h - 1), nS = (int)w;
-                const int n_all = nE + nD + nS + nD;
-                auto fetch = [=](int gl, int& ai, int& L) -> uint32_t {   // line gl -> angle, length, this lane's level
-                    int ln = gl, x0, y0;
-                    if (ln < nE) { ai = 0; x0 = 0; y0 = ln; L = (int)w; }
-                    else if ((ln -= nE) < nD) {                            // SE: x - y = ln - (h - 1)
-                        ai = 1;
-                        const int c = ln - ((int)h - 1);
-                        x0 = c >= 0 ? c : 0; y0 = c >= 0 ? 0 : -c;
-                        L = min((int)w - x0, (int)h - y0);
-                    } else if ((ln -= nD) < nS) { ai = 2; x0 = ln; y0 = 0; L = (int)h; }
-                    else {                                                 // SW: x + y = ln
-                        ln -= nS; ai = 3;
-                        x0 = ln < (int)w ? ln : (int)w - 1; y0 = ln < (int)w ? 0 : ln - (int)w + 1;
-                        L = min(x0 + 1, (int)h - y0);
-                    }
-                    const int dx = ai == 2 ? 0 : ai == 3 ? -1 : 1, dy = ai == 0 ? 0 : 1;   // glrlm.cpp:128-176
-                    return lane < L ? (uint32_t)s_dense[(uint32_t)(y0 + lane * dy) * w + (uint32_t)(x0 + lane * dx)] : 0u;
-                };
-                int ai = 0, L = 0, ai_n = 0, L_n = 0;
-                uint32_t v = wave < n_all ? fetch(wave, ai, L) : 0u;
-                for (int gl = wave; gl < n_all; gl += kWaves) {
-                    const uint32_t v_n = gl + kWaves < n_all ? fetch(gl + kWaves, ai_n, L_n) : 0u;
-                    const uint32_t nx = lane_plus1(v, 0u);
-                    const unsigned long long same = __ballot(lane + 1 < L && v != 0 && v == nx);
-                    if (v != 0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull))) {
-                        const int len = __ffsll((long long)~(same >> lane));   // 1 + trailing ones of same >> lane
-                        atomicAdd(&s_mat[(uint32_t)ai * slot_words + (uint32_t)(((int)s_lvlmap[v] - 1) * Nr + (len - 1))], 1u);
-                    }
-                    v = v_n; ai = ai_n; L = L_n;
-                }
-                blk_sync<GS>();
                 {
-                    uint32_t* P = s_mat + (uint32_t)wave * slot_words;
+                    uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
+                    const bool in_col = (uint32_t)lane < w;
+                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&P[(uint32_t)(((int)s_lvlmap[rv] - 1) * Nr) + (rl - 1u)], 1u); };
+                    if (wave == 0) {
+                        for (uint32_t row = 0; row < h; row++) {
+                            const uint32_t v = in_col ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u;
+                            const uint32_t nx = lane_plus1(v, 0u);
+                            const unsigned long long same = __ballot((uint32_t)lane + 1 < w && v != 0 && v == nx);
+                            if (v != 0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                                count_run(v, (uint32_t)__ffsll((long long)~(same >> lane)));   // 1 + trailing ones of same >> lane
+                        }
+                    } else {
+                        const int dx = wave == 1 ? 1 : wave == 2 ? 0 : -1;                   // glrlm.cpp:128-176
+                        uint32_t rv = 0, rl = 0;
+                        for (uint32_t row = 0; row < h; row++) {
+                            if (dx == 1) {
+                                if (w == 64 && lane == 63 && rv != 0) count_run(rv, rl);
+                                rv = lane_minus1(rv, 0u); rl = lane_minus1(rl, 0u);
+                            } else if (dx == -1) {
+                                if (lane == 0 && rv != 0) count_run(rv, rl);
+                                rv = lane_plus1(rv, 0u); rl = lane_plus1(rl, 0u);
+                            }
+                            const uint32_t v = in_col ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u;
+                            if (v != 0 && v == rv) rl++;
+                            else {
+                                if (rv != 0) count_run(rv, rl);
+                                rv = v; rl = v != 0 ? 1u : 0u;
+                            }
+                        }
+                        if (rv != 0) count_run(rv, rl);
+                    }
+                    wav_sync<GS>();
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, lane);
                 }
             } else {

@@ -532,3 +532,26 @@ def test_deep_glcm_with_a_spilled_roi(hip_ctx, mask):
     G = hip_ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
     assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
+
+
+@pytest.mark.parametrize("gd", [3, 8])
+def test_texture_row_scans_at_edge_widths(hip_ctx, gd):
+    """GLRLM (one wave per direction, run state shifted along the diagonals), GLSZM (row sweep) and NGTDM on boxes of width 1, 2,
+    63 and 64 -- the widths at which a diagonal run leaves the wave -- with few grey levels, so that long runs exist."""
+    rng = np.random.default_rng(17)
+    rois = []
+    for (w, h) in [(1, 1), (1, 30), (30, 1), (2, 2), (2, 40), (63, 5), (64, 5), (63, 63), (64, 64), (64, 1), (5, 64), (40, 64)]:
+        m = np.ones((h, w), bool)
+        if w > 3 and h > 3:
+            m &= rng.random((h, w)) > 0.1
+            m[0, 0] = m[0, w - 1] = m[h - 1, 0] = m[h - 1, w - 1] = True
+        ys, xs = np.nonzero(m)
+        v = rng.integers(1, 4, len(xs)) * 1000                    # three well-separated intensities -> long runs under any binning
+        rois.append(dict(x=xs, y=ys, inten=v.astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd)
+    G = hip_ctx.featurize_host(b, TEX, s)
+    O = po.oracle_featurize(b, TEX, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(TEX, s))
+    if po.have_ref():
+        assert not parity.compare_tables(G, po.ref_featurize(b, TEX, s, 2), _lib.column_names(TEX, s))
