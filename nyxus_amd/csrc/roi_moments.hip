@@ -15,6 +15,7 @@
 //                        is the reference's hill descent over the ORDERED contour (features/pixel.cpp:40-70), and the
 //                        weighted intensity passes through float like the reference's vector<float> (pixel.h:8).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "../../include/nyxhip.h"
@@ -259,30 +260,41 @@ __device__ __forceinline__ int descent_step(size_t m, const uint16_t* tab, int t
 }
 
 // Pixel2::min_sqdist v2 (pixel.cpp:40-70): hill descent over the ordered contour.  step0 = (int)(n / log(n)).
-__device__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n, int step0, const uint16_t* tab, int tab_n)
+// SMALL: every coordinate is below 2^15, so the squared distances are exact in 32-bit integers (24-bit multiplies) and the
+// whole search runs on integer compares; otherwise the distances are formed in double like the reference's.  The index
+// arithmetic is 32-bit either way (a contour has fewer points than the ROI has pixels).
+template <bool SMALL>
+__device__ __forceinline__ double min_sqdist_v2(int px, int py, const uint32_t* K, int n, int step0, const uint16_t* tab, int tab_n)
 {
     if (n == 0) return 0.0;
-    auto sqd = [&](size_t i) {
+    using dist_t = typename std::conditional<SMALL, uint32_t, double>::type;
+    auto sqd = [&](uint32_t i) -> dist_t {
         const uint32_t k = K[i];
-        const double dx = (double)(int)(k & 0xFFFFu) - (double)px, dy = (double)(int)(k >> 16) - (double)py;
-        return dx * dx + dy * dy;
+        if (SMALL) {
+            const int dx = (int)(k & 0xFFFFu) - px, dy = (int)(k >> 16) - py;
+            return (dist_t)(__umul24((uint32_t)(dx < 0 ? -dx : dx), (uint32_t)(dx < 0 ? -dx : dx)) +
+                            __umul24((uint32_t)(dy < 0 ? -dy : dy), (uint32_t)(dy < 0 ? -dy : dy)));
+        } else {
+            const double dx = (double)(int)(k & 0xFFFFu) - (double)px, dy = (double)(int)(k >> 16) - (double)py;
+            return (dist_t)(dx * dx + dy * dy);
+        }
     };
-    double extrem_d = sqd(0);
-    if (n == 1) return extrem_d;
-    size_t a = 0, b = (size_t)n, extrem_i = 0;
-    int step = step0;
+    dist_t extrem_d = sqd(0);
+    if (n == 1) return (double)extrem_d;
+    uint32_t a = 0, b = (uint32_t)n, extrem_i = 0;
+    uint32_t step = (uint32_t)step0;
     do {
-        for (size_t i = a + (size_t)step; i < b; i += (size_t)step) {
-            const double d = sqd(i);
+        for (uint32_t i = a + step; i < b; i += step) {
+            const dist_t d = sqd(i);
             if (extrem_d > d) { extrem_d = d; extrem_i = i; }
         }
-        const size_t stepL = extrem_i >= (size_t)step ? (size_t)step : extrem_i,
-                     stepR = extrem_i + (size_t)step < (size_t)n ? (size_t)step : (size_t)n - extrem_i;
+        const uint32_t stepL = extrem_i >= step ? step : extrem_i,
+                       stepR = extrem_i + step < (uint32_t)n ? step : (uint32_t)n - extrem_i;
         a = extrem_i - stepL;
         b = extrem_i + stepR;
-        step = descent_step(b - a, tab, tab_n);
+        step = (uint32_t)descent_step((size_t)(b - a), tab, tab_n);
     } while (b - a > 2);
-    return extrem_d;
+    return (double)extrem_d;
 }
 
 __device__ __forceinline__ double ipow(double a, int b) { double r = 1.0; for (int i = 0; i < b; i++) r *= a; return r; }
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         return;
     }
     const int nK = (int)A.n_contour[roi];
+    const bool small_xy = A.bbox_w[roi] + 2u < 32768u && A.bbox_h[roi] + 2u < 32768u;   // integer distances are exact (min_sqdist_v2)
     const uint32_t* K = A.ws_contour + off;
     if (nK <= kMomContourLds) {
         for (int i = tid; i < nK; i += kMB) s_K[i] = K[i];
@@ -394,7 +407,8 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         for (int k = 0; k < 10; k++) { as[k] = 0; ai[k] = 0; }
         for (uint32_t i = tid; i < n; i += kMB) {
             const uint32_t xi = A.x[off + i], yi = A.y[off + i];
-            const double lg = log(sqrt(min_sqdist_v2((int)xi, (int)yi, K, nK, step0, s_step, tab_n)) + 0.001);
+            const double lg = log(sqrt(small_xy ? min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
+                                                : min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)) + 0.001);
             L[i] = lg;
             const double X = (double)xi, Y = (double)yi;
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)A.inten[off + i] * lg);
