@@ -659,6 +659,35 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         } else {
             for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
             blk_sync<GS>();
+            if (w <= 64) {
+                // One lane per column, each wave a block of rows; the rows above / below travel in registers and the
+                // horizontal neighbours come through DPP lane shifts (level 0 = outside the box or not a pixel: skipped, like
+                // the bounds tests and the q != 0 test of the stencil below).  One LDS read per pixel instead of nine.
+                const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                const int r_begin = wave * rows_per_wave;
+                const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                const bool in_col = (uint32_t)lane < w;
+                auto load_row = [=](int r) -> uint32_t { return (in_col && r >= 0 && r < (int)h) ? (uint32_t)s_dense[(uint32_t)r * w + (uint32_t)lane] : 0u; };
+                uint32_t prv = load_row(r_begin - 1), cur = load_row(r_begin);
+                for (int row = r_begin; row < r_end; row++) {
+                    const uint32_t nxt = load_row(row + 1);
+                    const uint32_t pw = lane_minus1(prv, 0u), pe = lane_plus1(prv, 0u), cw = lane_minus1(cur, 0u), ce = lane_plus1(cur, 0u),
+                                   nw = lane_minus1(nxt, 0u), ne = lane_plus1(nxt, 0u);
+                    const uint32_t sum = ((pw + prv) + (pe + cw)) + ((ce + nw) + (nxt + ne));
+                    const uint32_t nd = (uint32_t)(pw != 0) + (uint32_t)(prv != 0) + (uint32_t)(pe != 0) + (uint32_t)(cw != 0) + (uint32_t)(ce != 0) +
+                                        (uint32_t)(nw != 0) + (uint32_t)(nxt != 0) + (uint32_t)(ne != 0);
+                    if (cur != 0 && nd > 0) {
+                        const int r = greyInfo == 0 ? (int)cur : (int)s_lvlmap[cur] - 1;
+                        // 840 / nd for nd = 1..8: 840 420 280 210 168 140 120 105 (ten bits each)
+                        const uint32_t q = nd <= 4 ? ((840u | (420u << 10) | (280u << 20)) >> (10u * (nd - 1u)) & 1023u) | (nd == 4 ? 210u : 0u)
+                                                   : (((168u | (140u << 10) | (120u << 20)) >> (10u * (nd - 5u))) & 1023u) | (nd == 8 ? 105u : 0u);
+                        const long long t = 840ll * (long long)cur - (long long)sum * (long long)q;
+                        atomicAdd(&s_N[r], 1u);
+                        atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
+                    }
+                    prv = cur; cur = nxt;
+                }
+            } else {
             RowCol rc((uint32_t)tid, kBlock, w);
             for (uint32_t p = tid; p < area; p += kBlock, rc.advance()) {
                 uint32_t pi = s_dense[p];
@@ -682,6 +711,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     atomicAdd(&s_N[r], 1u);
                     atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
                 }
+            }
             }
             blk_sync<GS>();
             // Nvc = Nvp = number of pixels with a neighbourhood (every mean is > 0), ngtdm.cpp:176-186
