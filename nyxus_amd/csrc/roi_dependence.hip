@@ -314,6 +314,34 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int i = tid; i < Ng * 9; i += kBlk) s_P[i] = 0;
         blk_sync<GS>();
         uint32_t nd_loc = 0;
+        if (w <= 64) {
+            // one lane per column, a block of rows per wave: the rows above / below travel in registers, horizontal neighbours
+            // come through DPP lane shifts.  code = level + 1 for a pixel that takes part, 0 otherwise (outside the box, or
+            // ORIGINAL intensity 0): a neighbour depends on the centre iff the codes are equal.
+            const int rows_per_wave = ((int)h + kBlk / 64 - 1) / (kBlk / 64);
+            const int r_begin = wave * rows_per_wave;
+            const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+            const bool in_col = (uint32_t)lane < w;
+            auto code_row = [=](int r) -> uint32_t {
+                if (!(in_col && r >= 0 && r < (int)h)) return 0u;
+                const uint32_t q = (uint32_t)r * w + (uint32_t)lane;
+                return (s_aux[q] & kOrigNZ) ? (uint32_t)s_dense[q] + 1u : 0u;
+            };
+            uint32_t prv = code_row(r_begin - 1), cur = code_row(r_begin);
+            for (int row = r_begin; row < r_end; row++) {
+                const uint32_t nxt = code_row(row + 1);
+                const uint32_t nd = 1u + (uint32_t)(lane_minus1(prv, 0u) == cur) + (uint32_t)(prv == cur) + (uint32_t)(lane_plus1(prv, 0u) == cur) +
+                                    (uint32_t)(lane_minus1(cur, 0u) == cur) + (uint32_t)(lane_plus1(cur, 0u) == cur) +
+                                    (uint32_t)(lane_minus1(nxt, 0u) == cur) + (uint32_t)(nxt == cur) + (uint32_t)(lane_plus1(nxt, 0u) == cur);
+                if (cur != 0) {
+                    const uint32_t pi = cur - 1u;
+                    const uint32_t rowi = greyInfo == 0 ? pi - 1 : (uint32_t)s_lvlmap[pi] - 1;
+                    atomicAdd(&s_P[rowi * 9 + (nd - 1)], 1u);
+                    nd_loc = nd > nd_loc ? nd : nd_loc;
+                }
+                prv = cur; cur = nxt;
+            }
+        } else {
         RowCol rc_dm((uint32_t)tid, kBlk, w);
         for (uint32_t p = tid; p < area; p += kBlk, rc_dm.advance()) {
             if (!(s_aux[p] & kOrigNZ)) continue;                     // skip by ORIGINAL intensity, gldm.cpp:83-84
@@ -332,6 +360,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             const uint32_t rowi = greyInfo == 0 ? pi - 1 : (uint32_t)s_lvlmap[pi] - 1;
             atomicAdd(&s_P[rowi * 9 + (nd - 1)], 1u);
             nd_loc = nd > nd_loc ? nd : nd_loc;
+        }
         }
         nd_loc = wave_max_u32(nd_loc);
         if (lane == 0) s_red[wave * 8] = (double)nd_loc;
@@ -410,6 +439,29 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int i = tid; i < Ng2 * 9; i += kBlk) s_M[i] = 0;
         blk_sync<GS>();
         uint32_t dep_loc = 0;
+        if (w <= 64) {                                               // same row-stepped stencil; code = cloud level + 1
+            const int rows_per_wave = ((int)h + kBlk / 64 - 1) / (kBlk / 64);
+            const int r_begin = wave * rows_per_wave;
+            const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+            const bool in_col = (uint32_t)lane < w;
+            auto code_row = [=](int r) -> uint32_t {
+                if (!(in_col && r >= 0 && r < (int)h)) return 0u;
+                const uint32_t ap = s_aux[(uint32_t)r * w + (uint32_t)lane];
+                return (ap & kInCloud) ? (ap & kLvlMask) + 1u : 0u;
+            };
+            uint32_t prv = code_row(r_begin - 1), cur = code_row(r_begin);
+            for (int row = r_begin; row < r_end; row++) {
+                const uint32_t nxt = code_row(row + 1);
+                const uint32_t nm = (uint32_t)(lane_minus1(prv, 0u) == cur) + (uint32_t)(prv == cur) + (uint32_t)(lane_plus1(prv, 0u) == cur) +
+                                    (uint32_t)(lane_minus1(cur, 0u) == cur) + (uint32_t)(lane_plus1(cur, 0u) == cur) +
+                                    (uint32_t)(lane_minus1(nxt, 0u) == cur) + (uint32_t)(nxt == cur) + (uint32_t)(lane_plus1(nxt, 0u) == cur);
+                if (cur != 0) {
+                    atomicAdd(&s_M[((uint32_t)s_lvlmap2[cur - 1u] - 1) * 9 + nm], 1u);
+                    dep_loc = nm > dep_loc ? nm : dep_loc;
+                }
+                prv = cur; cur = nxt;
+            }
+        } else {
         RowCol rc_ng((uint32_t)tid, kBlk, w);
         for (uint32_t p = tid; p < area; p += kBlk, rc_ng.advance()) {
             const uint32_t ap = s_aux[p];
@@ -428,6 +480,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             }
             atomicAdd(&s_M[((uint32_t)s_lvlmap2[c] - 1) * 9 + nm], 1u);
             dep_loc = nm > dep_loc ? nm : dep_loc;
+        }
         }
         dep_loc = wave_max_u32(dep_loc);
         if (lane == 0) s_red[wave * 8] = (double)dep_loc;
