@@ -77,29 +77,29 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
         double r = (double)ri[i];
         uint32_t in2 = lv[i] * lv[i];                 // unsigned-int product as in the reference
         gln += r * r;                                  // calc_GLN :431-461
-        mu_g += r / sum_p * (double)lv[i];             // calc_GLV mu :602-609
-        lgl += r / (double)in2;                        // calc_LGLRE :712-741
+        mu_g += fdiv(r, sum_p) * (double)lv[i];        // calc_GLV mu :602-609
+        lgl += fdiv(r, (double)in2);                   // calc_LGLRE :712-741
         hgl += r * (double)in2;                        // calc_HGLRE :744-773
     }
     double sre = 0, lre = 0, rln = 0, mu_r = 0;
     for (int j = lane; j < Nr; j += 64) {
         double c = (double)rj[j];
         int jj = j + 1;
-        sre += c / (double)(jj * jj);                  // calc_SRE :378-385
+        sre += fdiv(c, (double)(jj * jj));             // calc_SRE :378-385
         lre += c * (double)jj * (double)jj;            // calc_LRE :411-418 (integer-exact)
         rln += c * c;                                  // calc_RLN :499-529
-        mu_r += c / sum_p * (double)jj;                // calc_RV mu :649-655
+        mu_r += fdiv(c, sum_p) * (double)jj;           // calc_RV mu :649-655
     }
     gln = wave_sum(gln); mu_g = wave_sum(mu_g); lgl = wave_sum(lgl); hgl = wave_sum(hgl);
     sre = wave_sum(sre); lre = wave_sum(lre); rln = wave_sum(rln); mu_r = wave_sum(mu_r);
     double glv = 0, rv = 0;
     for (int i = lane; i < Ng; i += 64) {
         double d = (double)lv[i] - mu_g;
-        glv += (double)ri[i] / sum_p * (d * d);        // calc_GLV :611-620
+        glv += fdiv((double)ri[i], sum_p) * (d * d);   // calc_GLV :611-620
     }
     for (int j = lane; j < Nr; j += 64) {
         double d = (double)(j + 1) - mu_r;
-        rv += (double)rj[j] / sum_p * (d * d);         // calc_RV :657-665
+        rv += fdiv((double)rj[j], sum_p) * (d * d);    // calc_RV :657-665
     }
     glv = wave_sum(glv); rv = wave_sum(rv);
     // cell-level sums
@@ -113,10 +113,10 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
         double cnt = (double)c;
         uint32_t in2 = lv[i] * lv[i];
         uint32_t j2 = (uint32_t)jj * (uint32_t)jj;
-        re += plog_tex(cnt / sum_p);                   // calc_RE :693-699
+        re += plog_tex(fdiv(cnt, sum_p));              // calc_RE :693-699
         srl += cnt / (double)(uint32_t)(in2 * j2);     // calc_SRLGLE :790-797
-        srh += cnt * (double)in2 / (double)(jj * jj);  // calc_SRHGLE :822-829
-        lrl += cnt * (double)(jj * jj) / (double)in2;  // calc_LRLGLE :855-862
+        srh += fdiv(cnt * (double)in2, (double)(jj * jj));  // calc_SRHGLE :822-829
+        lrl += fdiv(cnt * (double)(jj * jj), (double)in2);  // calc_LRLGLE :855-862
         lrh += cnt * (double)(uint32_t)(in2 * j2);     // calc_LRHGLE :887-894
     }
     re = wave_sum(re); srl = wave_sum(srl); srh = wave_sum(srh); lrl = wave_sum(lrl); lrh = wave_sum(lrh);
@@ -570,12 +570,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
                     double i2 = inten * inten, j2 = jd * jd;
                     acc[0] += p * i2 * j2;                   // f_LAHGLE
-                    acc[1] += p * j2 / i2;                   // f_LALGLE
-                    acc[2] += p * i2 / j2;                   // f_SAHGLE
-                    acc[3] += p / (i2 * j2);                 // f_SALGLE
-                    acc[4] += plog_tex(p / sum_p);           // f_ZE
-                    acc[5] += p / sum_p * jd;                // mu_ZV
-                    acc[6] += p / sum_p * inten;             // mu_GLV
+                    const double pn = fdiv(p, sum_p);        // (levels, sizes and sum_p are >= 1: fdiv's domain)
+                    acc[1] += fdiv(p * j2, i2);              // f_LALGLE
+                    acc[2] += fdiv(p * i2, j2);              // f_SAHGLE
+                    acc[3] += fdiv(p, i2 * j2);              // f_SALGLE
+                    acc[4] += plog_tex(pn);                  // f_ZE
+                    acc[5] += pn * jd;                       // mu_ZV
+                    acc[6] += pn * inten;                    // mu_GLV
                 }
                 // block reduction (fixed order)
 #pragma unroll
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     uint32_t key, val;
                     cell(i, key, val);
                     if (key == 0) continue;
-                    double p = (double)val / sum_p;
+                    double p = fdiv((double)val, sum_p);
                     double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
                     b[0] += p * (dg * dg);                   // calc_GLV :497-510
                     b[1] += p * (dz * dz);                   // calc_ZV :512-524
