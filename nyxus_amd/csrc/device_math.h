@@ -229,6 +229,36 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
     v += dpp_perm<0x140>(v);
     return v;
 }
+// ---- one pass over a ROI's pixel cloud ---------------------------------------------------------------------------
+// Calls f(i, intensity, x, y) for this thread's pixels i = tid, tid + BLK, ...  Four pixels per trip, read through buffer
+// descriptors sized to the ROI (the bounds check belongs to the load: no compare / branch / 64-bit address per load) and
+// all twelve loads of a trip issued before the first use -- one HBM round trip per 4 * BLK pixels of the workgroup instead
+// of one per pixel and lane.
+template <int BLK, typename F>
+__device__ __forceinline__ void for_each_cloud_pixel(const uint32_t* inten, const uint16_t* x, const uint16_t* y, uint32_t n, int tid, F&& f)
+{
+    constexpr int kU = 4;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)inten, 0, (int)(n * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(n * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(n * 2u), 0x00020000);
+    for (uint32_t base = 0; base < n; base += kU * BLK) {
+        uint32_t v[kU], px[kU], py[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const uint32_t i = base + (uint32_t)(u * BLK) + (uint32_t)tid;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_v, (int)(i * 4u), 0, 0);
+            px[u] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_x, (int)(i * 2u), 0, 0);
+            py[u] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_y, (int)(i * 2u), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const uint32_t i = base + (uint32_t)(u * BLK) + (uint32_t)tid;
+            if (i < n)
+                f(i, v[u], px[u], py[u]);
+        }
+    }
+}
+
 // ---- (row, column) of a linear index that advances by a fixed stride -----------------------------------------------
 // p = first, first + stride, ... over a plane of width w: one integer division per thread and loop instead of one per pixel
 // (a u32 division is ~25 instructions, two of them quarter-rate multiplies).

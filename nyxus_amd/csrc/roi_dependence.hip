@@ -92,9 +92,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     }
     blk_sync<GS>();
     uint32_t lvl_over = 0;
-    for (uint32_t i = tid; i < n; i += kBlk) {
-        const uint32_t v = A.inten[off + i];
-        const uint32_t px = A.x[off + i], py = A.y[off + i];
+    for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         uint32_t lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
         // NGLDM level: to_grayscale (p, 0, max, GREYDEPTH, ibsi), ngldm.cpp:44-47 / :118-121 (helpers.h:337-345)
         uint32_t nl = A.ibsi ? v : to_grayscale(v, 0u, vmax, (uint32_t)A.grey_depth);
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             s_aux[py * w + px] = (uint16_t)(kInCloud | (v != 0 ? kOrigNZ : 0) | nl);
             s_lvlmap2[nl] = 1;
         }
-    }
+    });
     lvl_over = wave_max_u32(lvl_over);
     if (lane == 0) s_red[wave * 8] = (double)lvl_over;
     blk_sync<GS>();

@@ -225,11 +225,10 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
             p4[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (uint32_t i = tid; i < npx; i += kBlk) {
-        uint32_t px = A.x[off + i], py = A.y[off + i];
+    for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         if (px < w && py < h)
-            s_plane[(py + 7) * pitch + px + 8] = A.inten[off + i];
-    }
+            s_plane[(py + 7) * pitch + px + 8] = v;
+    });
     __syncthreads();
 
     const bank_ptr_t bank = (bank_ptr_t)(uintptr_t)A.gabor_bank;
@@ -362,14 +361,13 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     // pixel and lane.
     const bool staged = npx <= A.L.zern_px_cap;
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
-    for (uint32_t i = tid; i < npx; i += kBlk) {
-        const uint32_t vi = A.inten[off + i], xi = A.x[off + i], yi = A.y[off + i];
+    for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
         if (staged) { s_xy[i] = xi | (yi << 16); s_v[i] = vi; }
         unsigned long long v = vi;
         m00 += v;
         m10 += ((unsigned long long)xi + 1) * v;
         m01 += ((unsigned long long)yi + 1) * v;
-    }
+    });
     m00 = wave_sum_u64(m00); m10 = wave_sum_u64(m10); m01 = wave_sum_u64(m01);
     if (lane == 0) { s_mom[wave * 4] = m00; s_mom[wave * 4 + 1] = m10; s_mom[wave * 4 + 2] = m01; }
     __syncthreads();

@@ -201,15 +201,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
 
     // ---- phase 1: cloud -> binned plane -----------------------------------------------------------
     uint32_t nz_orig = 0, lvl_over = 0;
-    for (uint32_t i = tid; i < n; i += kBlock) {
-        uint32_t v = A.inten[off + i];
-        uint32_t px = A.x[off + i], py = A.y[off + i];
+    for_each_cloud_pixel<kBlock>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         uint32_t lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
         nz_orig += v != 0;
         if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
         if (px < w && py < h)
-            s_dense[py * w + px] = (uint16_t)lvl;
-    }
+            s_dense[__umul24(py, w) + px] = (uint16_t)lvl;
+    });
     nz_orig = (uint32_t)wave_sum_u64(nz_orig);
     lvl_over = wave_max_u32(lvl_over);
     if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
