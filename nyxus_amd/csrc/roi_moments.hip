@@ -67,10 +67,9 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
 
     for (uint32_t i = lane; i < np; i += 64) img[i] = 0;
     wav_sync<GS>();
-    for (uint32_t i = lane; i < n; i += 64) {         // padded image, contour.cpp:661-666
-        const uint32_t px = A.x[off + i], py = A.y[off + i];
+    for_each_cloud_pixel<64>(A.inten + off, A.x + off, A.y + off, n, lane, [&](uint32_t, uint32_t, uint32_t px, uint32_t py) {   // padded image, contour.cpp:661-666
         if (px < (uint32_t)w && py < (uint32_t)h) img[(px + 1) + (py + 1) * (uint32_t)W2] = kPix;
-    }
+    });
     wav_sync<GS>();
 
     // ---- border image: raster scan with the inside / outside state + Moore trace (contour.cpp:395-493) ----------------
@@ -357,15 +356,15 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
-        for (uint32_t i = tid; i < n; i += kMB) {
-            const double X = (double)A.x[off + i], Y = (double)A.y[off + i];
-            const double I = var ? (double)A.inten[off + i] : 1.0;
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
+            const double X = (double)xi, Y = (double)yi;
+            const double I = var ? (double)vi : 1.0;
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
-        }
+        });
         mom_block_sum<16, false>(acc, s_red, tid);
         if (tid == 0) {                                  // compile-time indices only: a run-time index would send the array to scratch
 #pragma unroll
@@ -380,15 +379,15 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
-        for (uint32_t i = tid; i < n; i += kMB) {
-            const double dx = (double)A.x[off + i] - ox, dy = (double)A.y[off + i] - oy;
-            const double I = var ? (double)A.inten[off + i] : 1.0;
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
+            const double dx = (double)xi - ox, dy = (double)yi - oy;
+            const double I = var ? (double)vi : 1.0;
             const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
-        }
+        });
         mom_block_sum<16, false>(acc, s_red, tid);
         if (tid == 0) {
 #pragma unroll
@@ -405,20 +404,19 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         double as[10], ai[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) { as[k] = 0; ai[k] = 0; }
-        for (uint32_t i = tid; i < n; i += kMB) {
-            const uint32_t xi = A.x[off + i], yi = A.y[off + i];
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double lg = log(sqrt(small_xy ? min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
                                                 : min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)) + 0.001);
             L[i] = lg;
             const double X = (double)xi, Y = (double)yi;
-            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)A.inten[off + i] * lg);
+            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
 #pragma unroll
             for (int k = 0; k < 10; k++) {
                 as[k] += Ws * xp[wr_p[k]] * yp[wr_q[k]];
                 ai[k] += Wi * xp[wr_p[k]] * yp[wr_q[k]];
             }
-        }
+        });
         mom_block_sum<10, false>(as, s_red, tid);
         mom_block_sum<10, false>(ai, s_red, tid);
         if (tid == 0) {
@@ -434,9 +432,9 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         double as[7], ai[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) { as[k] = 0; ai[k] = 0; }
-        for (uint32_t i = tid; i < n; i += kMB) {
-            const double X = (double)A.x[off + i], Y = (double)A.y[off + i], lg = L[i];
-            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)A.inten[off + i] * lg);
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+            const double X = (double)xi, Y = (double)yi, lg = L[i];
+            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             {
                 const double dx = X - oxs, dy = Y - oys;
                 const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
 #pragma unroll
                 for (int k = 0; k < 7; k++) ai[k] += Wi * xp[nc_p[k]] * yp[nc_q[k]];
             }
-        }
+        });
         mom_block_sum<7, false>(as, s_red, tid);
         mom_block_sum<7, false>(ai, s_red, tid);
         if (tid == 0) {
