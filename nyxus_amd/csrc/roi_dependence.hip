@@ -40,7 +40,9 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
     const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
+    const int solo = (int)(roi & 3u);    // the wave that runs this ROI's single-wave stretches (spreads them over the four SIMDs)
     if (roi >= A.n_roi)
         return;
     double* s_red = (double*)(lds + A.L.red);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
         blk_sync<GS>();
         // features (calc_features :323-420); every level of the LUT is non-zero here
-        if (wave == 0) {
+        if (wave == solo) {
             double Ns = 0;
             for (int e = lane; e < Ng * Nd; e += 64) { const int g = e / Nd, d = e - g * Nd; Ns += (double)s_P[g * ndmax + d]; }
             Ns = wave_sum(Ns);
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
         if (greyInfo == 0) Nd = 9;                                   // gldm.cpp:173,208-209
         blk_sync<GS>();
-        if (wave == 0) {
+        if (wave == solo) {
             unsigned long long nz = 0;
             for (int e = lane; e < Ng * 9; e += 64) nz += s_P[e];
             nz = wave_sum_u64(nz);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int wv = 0; wv < kBlk / 64; wv++) Nr = (int)s_red[wv * 8] > Nr ? (int)s_red[wv * 8] : Nr;
         Nr += 1;                                                     // ngldm.cpp:142
         blk_sync<GS>();
-        if (wave == 0) {
+        if (wave == solo) {
             double Ns = (double)n;                                   // every cloud pixel is counted once
             double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // LDE HDE LGLCE HGLCE LDLGLE LDHGLE HDLGLE HDHGLE GLM DCM DCENT DCENE
             for (int e = lane; e < Ng2 * 9; e += 64) {

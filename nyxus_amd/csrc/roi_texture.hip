@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     // local column -> column inside the row: other kernels' families (GLDZM; GLDM, NGLDM) interleave in Feature2D order
     const int end_rlm = (A.mask & NYXHIP_FAM_GLRLM) ? 80 : 0, end_szm = end_rlm + ((A.mask & NYXHIP_FAM_GLSZM) ? 16 : 0);
     auto gcol = [=](int c) { return c + (c >= end_rlm ? A.gap_after_glrlm : 0) + (c >= end_szm ? A.gap_after_glszm : 0); };
+    const int solo = (int)(roi & 3u);                  // the wave that runs this ROI's single-wave stretches
     const bool do_rlm = (A.mask & NYXHIP_FAM_GLRLM) != 0, do_szm = (A.mask & NYXHIP_FAM_GLSZM) != 0,
                do_ngt = (A.mask & NYXHIP_FAM_NGTDM) != 0;
     const uint32_t side = w > h ? w : h;
@@ -418,7 +419,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
             blk_sync<GS>();
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
-            if (wave == 0 && w <= 64) {
+            // (the one-wave stretches of this kernel rotate over the four waves -- hence the four SIMDs -- by ROI: with six
+            //  workgroups per CU a fixed wave 0 would pile all of them onto one SIMD)
+            if (wave == solo && w <= 64) {
                 // bounding boxes up to 64 wide: the previous row's values / labels stay in registers, neighbours come
                 // through DPP lane shifts, the W chain is a segmented prefix-min in DPP steps -- no LDS on the critical path
                 uint32_t v_prev = 0, lab_prev = 0xFFFFFFFFu;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
                     v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
                 }
-            } else if (wave == 0) {
+            } else if (wave == solo) {
                 for (uint32_t row = 0; row < h; row++) {
                     uint32_t carry_v = 0, carry_l = 0;       // right-most pixel of the previous chunk
                     for (uint32_t c0 = 0; c0 < w; c0 += 64) {
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 s_Sd[i] = (double)s_S[i] / 840.0;
             }
             blk_sync<GS>();
-            if (wave == 0) {
+            if (wave == solo) {
                 auto Iof = [=](int i) -> double { return greyInfo == 0 ? (double)i : (double)s_lv[i]; };
                 double ps = 0, ssum = 0;
                 for (int i = lane; i < NgT; i += 64) { ps += s_P[i] * s_Sd[i]; ssum += s_Sd[i]; }
