@@ -162,13 +162,16 @@ class Nyxus:
         if label_images.shape[0] != len(label_names):
             raise ValueError("Number of segmentation names must be the same as the number of images.")
         # Hounsfield-style input: shift to non-negative, then the unsigned casts (nyxus.py:480-489)
+        # (an unsigned array has no negative minimum to look for, and uint32 input is handed over without a copy: at the
+        # device rates of this path every avoidable host pass over the images shows)
         I = intensity_images
-        min_raw = np.min(intensity_images)
-        if min_raw < 0:
-            I = I - min_raw
+        if not np.issubdtype(I.dtype, np.unsignedinteger):
+            min_raw = np.min(I)
+            if min_raw < 0:
+                I = I - min_raw
         if I.dtype != np.uint32:
             I = I.astype(np.uint32)
-        M = label_images.astype(np.uint32)
+        M = label_images if label_images.dtype == np.uint32 else label_images.astype(np.uint32)
 
         cols, sel = self._columns()
         # All images of the stack go through the fused device path in one call: label scan, ROI assembly and the
@@ -178,12 +181,14 @@ class Nyxus:
         tiles, labels, table = self._context().featurize_tiles_host(I, M, self._mask, self._settings)
         _lib.load().nyxhip_finalize_table(table.ctypes.data, table.shape[0], table.shape[1], table.shape[1],
                                           C.c_double(self._settings.soft_nan))
-        header = ["intensity_image", "mask_image", "ROI_label", "t_index"] + cols
-        string_data = np.array([[intensity_names[t], label_names[t]] for t in tiles], dtype=object).reshape(-1, 2)
-        numeric_data = np.concatenate([labels.astype(np.float64)[:, None], np.zeros((len(labels), 1)), table[:, sel]], axis=1)
-        df = pd.concat([pd.DataFrame(string_data, columns=header[:2]), pd.DataFrame(numeric_data, columns=header[2:])], axis=1)
-        if "ROI_label" in df.columns:
-            df.ROI_label = df.ROI_label.astype(np.uint32)
+        # [intensity_image, mask_image, ROI_label (uint32), t_index, features...]: the feature block is wrapped as it is, the
+        # four leading columns are inserted in front of it (no per-row Python work, no float round trip of the labels)
+        ti = np.asarray(tiles, dtype=np.intp)
+        df = pd.DataFrame(table[:, sel], columns=cols)
+        df.insert(0, "t_index", np.zeros(len(labels)))
+        df.insert(0, "ROI_label", np.asarray(labels, dtype=np.uint32))
+        df.insert(0, "mask_image", np.asarray(label_names, dtype=object)[ti] if len(ti) else np.empty(0, dtype=object))
+        df.insert(0, "intensity_image", np.asarray(intensity_names, dtype=object)[ti] if len(ti) else np.empty(0, dtype=object))
         return df
 
     def featurize_directory(self, intensity_dir: str, label_dir: Optional[str] = None, file_pattern: Optional[str] = ".*",
