@@ -257,36 +257,38 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 const double p = (double)s_P[g * ndmax + d];
                 if (p == 0) continue;
                 const double g_ = (double)s_lv[g], d_ = (double)(d + 1);
-                a[0] += p / g_ / g_ / d_ / d_;
-                a[1] += g_ * g_ * p / d_ / d_;
-                a[2] += d_ * d_ * p / g_ / g_;
+                // (the divisors of this tail -- level values, distances, Ns -- are all >= 1: fdiv's domain; tolerance-class sums)
+                a[0] += fdiv(fdiv(fdiv(fdiv(p, g_), g_), d_), d_);
+                a[1] += fdiv(fdiv(g_ * g_ * p, d_), d_);
+                a[2] += fdiv(fdiv(d_ * d_ * p, g_), g_);
                 a[3] += g_ * g_ * d_ * d_ * p;
                 a[4] += g_ * p;
                 a[5] += d_ * p;
-                a[6] += p / Ns * log2(p / Ns + 2.2e-16);
+                const double pn = fdiv(p, Ns);
+                a[6] += pn * log2(pn + 2.2e-16);
             }
             double b[6] = {0, 0, 0, 0, 0, 0};             // SDE LDE ZDNU | LGLZE HGLZE GLNU
             for (int d = lane; d < Nd; d += 64) {
                 double m = 0;
                 for (int g = 0; g < Ng; g++) m += (double)s_P[g * ndmax + d];
                 const double dd = (double)(d + 1);
-                b[0] += m / dd / dd; b[1] += dd * dd * m; b[2] += m * m;
+                b[0] += fdiv(fdiv(m, dd), dd); b[1] += dd * dd * m; b[2] += m * m;
             }
             for (int g = lane; g < Ng; g += 64) {
                 double x = 0;
                 for (int d = 0; d < Nd; d++) x += (double)s_P[g * ndmax + d];
                 const double g_ = (double)s_lv[g];
-                b[3] += x / (g_ * g_); b[4] += (g_ * g_) * x; b[5] += x * x;
+                b[3] += fdiv(x, g_ * g_); b[4] += (g_ * g_) * x; b[5] += x * x;
             }
 #pragma unroll
             for (int k = 0; k < 7; k++) a[k] = wave_sum(a[k]);
 #pragma unroll
             for (int k = 0; k < 6; k++) b[k] = wave_sum(b[k]);
-            const double GLM = a[4] / Ns, ZDM = a[5] / Ns;
+            const double GLM = fdiv(a[4], Ns), ZDM = fdiv(a[5], Ns);
             double glv = 0, zdv = 0;
             for (int e = lane; e < Ng * Nd; e += 64) {
                 const int g = e / Nd, d = e - g * Nd;
-                const double p = (double)s_P[g * ndmax + d] / Ns;
+                const double p = fdiv((double)s_P[g * ndmax + d], Ns);
                 double dif = (double)s_lv[g] - GLM;
                 glv += dif * dif * p;
                 dif = (double)(d + 1) - ZDM;
@@ -294,11 +296,11 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             }
             glv = wave_sum(glv); zdv = wave_sum(zdv);
             if (lane == 0) {
-                const double zdnu = b[2] / Ns, glnu = b[5] / Ns;
-                o[0] = b[0] / Ns; o[1] = b[1] / Ns; o[2] = b[3] / Ns; o[3] = b[4] / Ns;
-                o[4] = a[0] / Ns; o[5] = a[1] / Ns; o[6] = a[2] / Ns; o[7] = a[3] / Ns;
-                o[8] = glnu; o[9] = glnu / Ns; o[10] = zdnu; o[11] = zdnu / Ns;
-                o[12] = Ns / (double)n;                    // ZP = Ns / roi_area :399
+                const double zdnu = fdiv(b[2], Ns), glnu = fdiv(b[5], Ns);
+                o[0] = fdiv(b[0], Ns); o[1] = fdiv(b[1], Ns); o[2] = fdiv(b[3], Ns); o[3] = fdiv(b[4], Ns);
+                o[4] = fdiv(a[0], Ns); o[5] = fdiv(a[1], Ns); o[6] = fdiv(a[2], Ns); o[7] = fdiv(a[3], Ns);
+                o[8] = glnu; o[9] = fdiv(glnu, Ns); o[10] = zdnu; o[11] = fdiv(zdnu, Ns);
+                o[12] = fdiv(Ns, (double)n);               // ZP = Ns / roi_area :399
                 o[13] = GLM; o[14] = glv; o[15] = ZDM; o[16] = zdv; o[17] = -a[6];
             }
         }
@@ -383,14 +385,15 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                     const double c = (double)s_P[e];
                     if (c == 0 || j > Nd) continue;
                     const double inten = (double)s_lv[i], jj = (double)j;
-                    a[0] += c / (jj * jj);
+                    const double cn = fdiv(c, Nz);                    // (levels, dependence counts and Nz are >= 1: fdiv's domain)
+                    a[0] += fdiv(c, jj * jj);
                     a[1] += c * (jj * jj);
-                    a[2] += c / Nz * inten;
-                    a[3] += c / Nz * jj;
-                    a[4] += plog_dep(c / Nz);
-                    a[5] += c / (inten * inten * jj * jj);
-                    a[6] += c * (inten * inten) / (double)(j * j);
-                    a[7] += c * (double)(j * j) / (inten * inten);
+                    a[2] += cn * inten;
+                    a[3] += cn * jj;
+                    a[4] += plog_dep(cn);
+                    a[5] += fdiv(c, inten * inten * jj * jj);
+                    a[6] += fdiv(c * (inten * inten), (double)(j * j));
+                    a[7] += fdiv(c * (double)(j * j), inten * inten);
                     a[8] += c * (inten * inten * jj * jj);
                 }
                 double b[4] = {0, 0, 0, 0};                          // GLN LGLE HGLE | DN
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                     double si = 0;
                     for (int j = 0; j < Nd; j++) si += (double)s_P[i * 9 + j];
                     const double inten = (double)s_lv[i];
-                    b[0] += si * si; b[1] += si / (inten * inten); b[2] += si * inten * inten;
+                    b[0] += si * si; b[1] += fdiv(si, inten * inten); b[2] += si * inten * inten;
                 }
                 if (lane < Nd) {
                     double sj = 0;
@@ -496,16 +499,16 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 const int i = e / 9, j = e - i * 9;
                 const double sij = (double)s_M[e];
                 if (sij == 0 || j >= Nr) continue;
-                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = sij / Ns;
-                a[0] += sij / dc / dc;
+                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = fdiv(sij, Ns);   // (dc, Ns >= 1; gl is tested below)
+                a[0] += fdiv(fdiv(sij, dc), dc);
                 a[1] += sij * dc * dc;
                 if (gl != 0.0) {
-                    a[2] += sij / gl / gl;
-                    a[4] += sij / dc / dc / gl / gl;
-                    a[6] += sij * dc * dc / gl / gl;
+                    a[2] += fdiv(fdiv(sij, gl), gl);
+                    a[4] += fdiv(fdiv(fdiv(fdiv(sij, dc), dc), gl), gl);
+                    a[6] += fdiv(fdiv(sij * dc * dc, gl), gl);
                 }
                 a[3] += sij * gl * gl;
-                a[5] += sij * gl * gl / dc / dc;
+                a[5] += fdiv(fdiv(sij * gl * gl, dc), dc);
                 a[7] += sij * dc * dc * gl * gl;
                 a[8] += gl * pij;
                 a[9] += dc * pij;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 const int i = e / 9, j = e - i * 9;
                 const double sij = (double)s_M[e];
                 if (sij == 0 || j >= Nr) continue;
-                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = sij / Ns;
+                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = fdiv(sij, Ns);
                 glv += (gl - GLM) * (gl - GLM) * pij;
                 dcv += (dc - DCM) * (dc - DCM) * pij;
             }
