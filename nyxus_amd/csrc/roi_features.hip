@@ -227,15 +227,15 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     asm_ = slot_sum<LW>(asm_); contrast_n = slot_sum<LW>(contrast_n); S_r = slot_sum<LW>(S_r); S_c = slot_sum<LW>(S_c);
     acor_n = slot_sum<LW>(acor_n); ent = slot_sum<LW>(ent); jmax = slot_max<LW>(jmax);
     const double dis_n = (double)slot_sum<LW>(dis_cnt);   // f_GLCM_DIS :1052
-    const double mr = S_r / sum_p, mc = fdiv(S_c, sum_p); // mr == f_var's mean == JAVE (exact numerators)
+    const double mr = fdiv(S_r, sum_p), mc = fdiv(S_c, sum_p); // mr == f_var's mean == JAVE (exact numerators)
     if (live && l16 == 0) { // results leave the registers as soon as they exist
         f[G_ASM] = asm_;
         f[G_ENERGY] = asm_;
-        f[G_CONTRAST] = contrast_n / sum_p;
-        f[G_ACOR] = acor_n / sum_p;
+        f[G_CONTRAST] = fdiv(contrast_n, sum_p);
+        f[G_ACOR] = fdiv(acor_n, sum_p);
         f[G_ENTROPY] = -ent;
         f[G_JE] = -ent;
-        f[G_DIS] = dis_n / sum_p;
+        f[G_DIS] = fdiv(dis_n, sum_p);
         f[G_JMAX] = jmax;
         f[G_JAVE] = mr;
     }
