@@ -90,11 +90,10 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     for (int i = tid; i < bank_len; i += kBlk)
         s_bank[i] = A.gabor_bank[i];
     blk_sync<GS>();
-    for (uint32_t i = tid; i < npx; i += kBlk) {
-        uint32_t px = A.x[off + i], py = A.y[off + i];
+    for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         if (px < w && py < h)
-            s_plane[py * w + px] = (double)A.inten[off + i];
-    }
+            s_plane[py * w + px] = (double)v;
+    });
     blk_sync<GS>();
 
     const int c0 = (n + 1) / 2;                     // (int)ceil(n / 2.), gabor.cpp:492
