@@ -210,8 +210,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     // HOM1 = sum p / (1 + |r - c|) and HOM2 = sum p / (1 + |r - c|^2) are the sums ID and IDM take over the |x - y|
     // distribution below (same terms grouped by k; <= 1e-15 relative apart), so the two divisions per cell are not repeated here.
     double asm_ = 0, contrast_n = 0, S_r = 0, S_c = 0, acor_n = 0, ent = 0, jmax = -1;
-    for (int e = l16; e < NN; e += LW) {
-        int r = e / Ng, c = e - r * Ng;
+    RowCol rc1((uint32_t)l16, (uint32_t)LW, (uint32_t)Ng);   // (row, column) of the cell without a division per cell
+    for (int e = l16; e < NN; e += LW, rc1.advance()) {
+        const int r = (int)rc1.row, c = (int)rc1.col;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
         double ir = Iv[r], ic = Iv[c];
@@ -242,8 +243,9 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
 
     // ---- pass 2: central quantities ---------------------------------------------------
     double s2r = 0, s2c = 0, tmp1 = 0, var_n = 0, cprom = 0, cshade = 0, ctend = 0, jvar = 0, hxy1 = 0, hxy2 = 0;
-    for (int e = l16; e < NN; e += LW) {
-        int r = e / Ng, c = e - r * Ng;
+    RowCol rc2((uint32_t)l16, (uint32_t)LW, (uint32_t)Ng);
+    for (int e = l16; e < NN; e += LW, rc2.advance()) {
+        const int r = (int)rc2.row, c = (int)rc2.col;
         double cnt = (double)P[e];
         double p = cnt * inv_sum_p;
         double ir = Iv[r], ic = Iv[c];
