@@ -252,8 +252,9 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             for (int e = lane; e < Ng * Nd; e += 64) { const int g = e / Nd, d = e - g * Nd; Ns += (double)s_P[g * ndmax + d]; }
             Ns = wave_sum(Ns);
             double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // SDLGLE SDHGLE LDLGLE LDHGLE GLM ZDM ZDE | Mx2 Md2 placeholders
-            for (int e = lane; e < Ng * Nd; e += 64) {
-                const int g = e / Nd, d = e - g * Nd;
+            RowCol rcz((uint32_t)lane, 64u, (uint32_t)Nd);
+            for (int e = lane; e < Ng * Nd; e += 64, rcz.advance()) {
+                const int g = (int)rcz.row, d = (int)rcz.col;
                 const double p = (double)s_P[g * ndmax + d];
                 if (p == 0) continue;
                 const double g_ = (double)s_lv[g], d_ = (double)(d + 1);

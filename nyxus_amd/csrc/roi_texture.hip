@@ -105,11 +105,12 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
     // cell-level sums
     double re = 0, srl = 0, srh = 0, lrl = 0, lrh = 0;
     const int NN = Ng * Nr;
-    for (int e = lane; e < NN; e += 64) {
+    RowCol rc((uint32_t)lane, 64u, (uint32_t)Nr);       // (level row, run length - 1) of the cell without a division per cell
+    for (int e = lane; e < NN; e += 64, rc.advance()) {
         uint32_t c = P[e];
         if (c == 0)
             continue;                                  // zero cells add +-0 in the reference
-        int i = e / Nr, jj = e - i * Nr + 1;
+        const int i = (int)rc.row, jj = (int)rc.col + 1;
         double cnt = (double)c;
         uint32_t in2 = lv[i] * lv[i];
         uint32_t j2 = (uint32_t)jj * (uint32_t)jj;
