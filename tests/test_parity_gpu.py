@@ -555,3 +555,34 @@ def test_texture_row_scans_at_edge_widths(hip_ctx, gd):
     assert not parity.compare_tables(G, O, _lib.column_names(TEX, s))
     if po.have_ref():
         assert not parity.compare_tables(G, po.ref_featurize(b, TEX, s, 2), _lib.column_names(TEX, s))
+
+
+def test_output_is_bit_reproducible(hip_ctx):
+    """Twenty repeated calls of all twelve families: identical bits every time (the GLSZM cell table is an ordered hash, every
+    other accumulation is integer or runs in a fixed order) -- a first-come hash made GLSZM_ZE / GLV / SALGLE move by 1-2 ulp."""
+    b = _abi.batch_from_rois(synth.random_rois(120, seed=5, rmax=25))
+    s = _abi.default_settings(8)
+    first = hip_ctx.featurize_host(b, _abi.FAM_ALL, s)
+    for _ in range(20):
+        again = hip_ctx.featurize_host(b, _abi.FAM_ALL, s)
+        assert ((again == first) | (np.isnan(again) & np.isnan(first))).all()
+
+
+def test_gabor_fused_variant_matches_on_noisy_fields():
+    """NYXHIP_GABOR_FUSED=1 (one FMA per tap) in a child process: on noisy intensity fields the count ratios equal the default
+    (exact) kernel's.  (On tie-laden flat fields they may not: tools/gabor_fuzz.py; that is why the variant is opt-in.)"""
+    import os, subprocess, sys, tempfile
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, '.')\n"
+            "from nyxus_amd import _abi, _lib\n"
+            "from tests import synth\n"
+            "b = _abi.batch_from_rois(synth.random_rois(150, seed=9, rmax=28))\n"
+            "np.save(sys.argv[1], _lib.Context(0).featurize_host(b, _abi.FAM_GABOR, _abi.default_settings(8)))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = {}
+        for tag, env in (("exact", {}), ("fused", {"NYXHIP_GABOR_FUSED": "1"})):
+            path = os.path.join(d, tag + ".npy")
+            subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=dict(os.environ, **env))
+            out[tag] = np.load(path)
+    assert np.array_equal(out["exact"], out["fused"])
