@@ -9,15 +9,23 @@ the tile count of BASELINE.json configs[1]/[2]) x 196 ROIs per tile (14x14 disks
 radius 30 -> 2821 px, bbox 61x61), intensities uniform in [1, 4095],
 coarse_gray_depth=8, GLCM angles {0,45,90,135}, offset 1, matlab binning.
 
-Per rank (one process per GPU): the same number of tiles (weak scaling); after every
-step the rank's feature-table block is gathered on rank 0 with one RCCL gather that
-overlaps the next step's kernel (nyxus_amd/sharding.py).  Output: ONE JSON line on
-rank 0 (contract in the task statement) plus `roofline` and `cpu_baseline` objects.
+Per rank (one process per GPU): the same number of tiles (weak scaling), no collective in
+the timed region; the one exchange of a job -- the gather of the final feature table to
+rank 0 (RCCL) -- runs once after the timed steps and is reported as `table_gather`.
+Output: ONE JSON line on rank 0 (contract in the task statement) plus `roofline` and
+`cpu_baseline` objects.
+
+Launching: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment makes
+this process a launcher: it never touches the GPU, starts N child ranks of this same script
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) and exits with the
+worst child status.  Under torchrun (WORLD_SIZE already set) every process is a rank.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,7 +49,74 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--families", type=int, default=3, help="family bitmask (diagnostic; the metric is 3 = INTENSITY|GLCM)")
     ap.add_argument("--tile-path-tiles", type=int, default=128, help="tiles for the informational fused tile-path measurement (0 = skip)")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST HOOK (tests/test_bench_launcher.py): no GPU, gloo; every rank fills a rank-coded table on the CPU so that "
+                         "the launcher, the barrier / max-over-ranks timing and the table gather can run here; the line says \"stub\": true")
     return ap.parse_args()
+
+
+def launch(a) -> int:
+    """`--gpus N` without a rendezvous in the environment: start N ranks of this script, one per GPU.
+    The launcher itself never initialises HIP (children are fresh processes, nothing is exec'ed over a GPU process)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            c = p.poll()
+            if c is None:
+                continue
+            pending.remove(p)
+            if c != 0:
+                rc = rc or c
+                for q in pending:                 # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def run_stub(a, world, rank):
+    """Test hook: the distributed skeleton of the bench (shard ranges, fence, max-over-ranks time, table gather) on gloo."""
+    import torch
+    import torch.distributed as dist
+    from nyxus_amd.sharding import TableGather, shard_range
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncol, rois_per_tile = 4, 3
+    if a.tiles < 0:
+        raise ValueError("--tiles must be >= 0")
+    lo, hi = shard_range(a.tiles * world, rank, world)          # weak scaling: a.tiles per rank
+    rows = torch.tensor([[t * 1000.0 + r + 0.001 * c for c in range(ncol)] for t in range(lo, hi) for r in range(rois_per_tile)],
+                        dtype=torch.float64).reshape(-1, ncol)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = rows.clone()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    g = TableGather(ncol, dst=0)
+    g.start(last)
+    full = g.finish()
+    if rank == 0:
+        want = [t * 1000.0 + r for t in range(a.tiles * world) for r in range(rois_per_tile)]
+        ok = full.shape[0] == len(want) and bool((full[:, 0].floor() == torch.tensor(want, dtype=torch.float64)).all())
+        print(json.dumps({"metric": "stub", "stub": True, "value": None, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(full.shape[0]), "row_order_ok": ok}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def disk_cloud(radius=30):
@@ -56,14 +131,18 @@ def disk_cloud(radius=30):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(a))                      # nothing GPU-related has been imported at this point
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.stub:
+        return run_stub(a, world, rank)
     import torch
     import torch.distributed as dist
     from nyxus_amd import _abi, _lib
     from nyxus_amd.sharding import TableGather
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
@@ -149,7 +228,7 @@ def main():
     if gather is not None:                   # final table -> rank 0, once, outside the timed region
         try:
             g0 = time.perf_counter()
-            gather.start(last, rows_per_rank=[n_roi] * world)
+            gather.start(last, rows_per_rank=[n_roi] * world, producer=ctx)
             full = gather.finish()
             fence()
             gather_ms = 1e3 * (time.perf_counter() - g0)

@@ -225,9 +225,10 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
                            double* out_table, size_t out_ld, uint64_t* n_roi_out);
 
 /* ---- measurement hooks -------------------------------------------------------
- * Average device time (ms) of the dominant kernel over the launches issued since
- * the last nyxhip_timing_reset(), measured with hipEvents recorded on the launch
- * stream around each kernel.  Used by bench.py for `roofline.achieved`. */
+ * Average device time (ms) per featurize call since the last nyxhip_timing_reset(),
+ * measured with hipEvents recorded on the launch stream around EVERYTHING the call
+ * enqueues (all kernel groups, the moments pair, the large-ROI passes).  Used by
+ * bench.py for `roofline.achieved`. */
 int nyxhip_timing_enable(nyxhip_ctx* ctx, int on);
 int nyxhip_timing_reset(nyxhip_ctx* ctx);
 int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launches);

@@ -760,8 +760,8 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
 // extrema do not fit the 160 KiB of a CU, the LDS launches run with capped carve-outs and skip the oversized
 // ROIs, which are then collected into an index list and re-run by the same kernels instantiated with their
 // scratch in a global workspace (slower, but any ROI the device memory can hold is served).
-int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
+                      size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
 {
     std::string why;
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
@@ -811,19 +811,6 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         return fail(ctx, lrc, why);
 
     hipStream_t st = ctx->stream();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        if (ctx->ev_used == ctx->ev.size()) {
-            hipEvent_t x, y;
-            HIP_TRY(ctx, hipEventCreate(&x));
-            HIP_TRY(ctx, hipEventCreate(&y));
-            ctx->ev.push_back({x, y});
-        }
-        e0 = ctx->ev[ctx->ev_used].first;
-        e1 = ctx->ev[ctx->ev_used].second;
-        ctx->ev_used++;
-        HIP_TRY(ctx, hipEventRecord(e0, st));
-    }
     const uint32_t grid = (uint32_t)b->n_roi;
     int rc = (mask1 && !feat_all_gs) ? launch_roi_features(a, st, grid) : 0;
     if (rc == 0 && mask2)
@@ -834,8 +821,6 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
         rc = launch_roi_shape(g, st, grid);
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-    if (ctx->timing)
-        HIP_TRY(ctx, hipEventRecord(e1, st));
     if (mask & kMoments)
         if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_area, max_side))
             return mrc;
@@ -916,6 +901,28 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
     return NYXHIP_OK;
+}
+
+// launch_device_all between two events on the launch stream: the timing hooks of include/nyxhip.h cover EVERY kernel the call
+// enqueues (the LDS launch groups, the moments pair, the global-workspace and large-ROI passes), on every return path.
+int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
+                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+{
+    if (!ctx->timing)
+        return launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side);
+    hipStream_t st = ctx->stream();
+    if (ctx->ev_used == ctx->ev.size()) {
+        hipEvent_t x, y;
+        HIP_TRY(ctx, hipEventCreate(&x));
+        HIP_TRY(ctx, hipEventCreate(&y));
+        ctx->ev.push_back({x, y});
+    }
+    hipEvent_t e0 = ctx->ev[ctx->ev_used].first, e1 = ctx->ev[ctx->ev_used].second;
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    const int rc = launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side);
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    ctx->ev_used++;
+    return rc;
 }
 
 int validate(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* out, size_t ld)

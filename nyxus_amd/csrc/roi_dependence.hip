@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include "device_math.h"
 #include "roi_kernel.h"
+#include "launch_util.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -553,14 +554,12 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
 
 int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_dependence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)roi_features_max_lds());
-        if (e != hipSuccess)
-            return (int)e;
-        attr_set = true;
-    }
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
+        return (int)hipFuncSetAttribute((const void*)roi_dependence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)roi_features_max_lds());
+    }))
+        return orc;
     if (grid == 0)
         return 0;
     if (a.sp.scratch)

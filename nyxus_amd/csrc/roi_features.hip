@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
+#include "launch_util.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -1160,8 +1161,8 @@ namespace {
 template <bool C16, bool SPLIT, bool D8>
 int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
         const void* fns[6] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
                               (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
                               (const void*)roi_features_kernel_occ8<1>, (const void*)roi_features_kernel_occ8<2>};
@@ -1170,8 +1171,9 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
             if (e != hipSuccess)
                 return (int)e;
         }
-        attr_set = true;
-    }
+        return 0;
+    }))
+        return orc;
     // occupancy follows the carve-out: 8 / 7 / 6 / 5 / 4 workgroups per CU with builds held to 64 / 72 / 80 / 96 / 128 VGPRs
     const size_t lds = roi_features_max_lds();
     // the 64-VGPR tier exists for the two compile-time family sets only

@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "device_math.h"
 #include "roi_kernel.h"
+#include "launch_util.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -489,13 +490,11 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
 
 int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)roi_contour_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
-        if (e != hipSuccess)
-            return (int)e;
-        attr_set = true;
-    }
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
+        return (int)hipFuncSetAttribute((const void*)roi_contour_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
+    }))
+        return orc;
     if (grid == 0)
         return 0;
     MomArgs b = a;

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
+#include "launch_util.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -458,8 +459,8 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
 // anything larger four waves.
 int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
         hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -468,10 +469,9 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
-        if (e != hipSuccess)
-            return (int)e;
-        attr_set = true;
-    }
+        return (int)e;
+    }))
+        return orc;
     if (grid == 0)
         return 0;
     const bool small = a.small_rois != 0;

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
+#include "launch_util.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -774,17 +775,16 @@ static int tex_max_occ()   // diagnostic knob: NYXHIP_TEX_OCC=4 keeps the 106-re
 
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
         hipError_t e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)roi_features_max_lds());
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)roi_features_max_lds());
-        if (e != hipSuccess)
-            return (int)e;
-        attr_set = true;
-    }
+        return (int)e;
+    }))
+        return orc;
     if (grid == 0)
         return 0;
     if (a.sp.scratch)

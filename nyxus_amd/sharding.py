@@ -30,7 +30,13 @@ class TableGather:
     """Gathers [rows_r x n_cols] float64 blocks (rows_r may differ per rank) on `dst`.
 
     start() enqueues the collective (async) so that the next batch's kernels overlap it;
-    finish() waits and returns the concatenated table on dst (None elsewhere)."""
+    finish() waits and returns the concatenated table on dst (None elsewhere).
+
+    Ordering: the collective runs on torch's stream, the feature kernels on the producing context's stream (its own
+    non-blocking stream unless Context.set_stream() pointed it at torch's).  Pass the context as `producer`: start() then
+    waits for its kernels (Context.sync()) before the table is handed to the collective.  Without it the caller must have
+    synchronised already.  A table that is still being gathered must not be overwritten by the next batch: alternate
+    between two output tables (bench.py does)."""
 
     def __init__(self, n_cols: int, dst: int = 0, group=None):
         self.n_cols = n_cols
@@ -43,8 +49,10 @@ class TableGather:
         self._rows: Optional[List[int]] = None
         self._local = None
 
-    def start(self, local: torch.Tensor, rows_per_rank: Optional[List[int]] = None):
+    def start(self, local: torch.Tensor, rows_per_rank: Optional[List[int]] = None, producer=None):
         assert local.dim() == 2 and local.shape[1] == self.n_cols and local.dtype == torch.float64
+        if producer is not None:
+            producer.sync()               # the table is complete (and the device error word checked) before it is sent
         if self.world == 1:
             self._local = local
             return
@@ -77,3 +85,26 @@ class TableGather:
         if self.rank != self.dst:
             return None
         return torch.cat([b[:r] for b, r in zip(self._bufs, self._rows)], dim=0)
+
+
+def gather_rows(local_keys: torch.Tensor, local_table: torch.Tensor, dst: int = 0, group=None, producer=None):
+    """The exchange step of a sharded job: every rank holds the rows of its contiguous image range -- `local_keys`
+    int64 [rows, 2] = (image index, ROI label), `local_table` float64 [rows, n_cols] -- and rank `dst` receives all of them in
+    rank order, i.e. images in input order and labels ascending inside an image, the row order of the reference's table
+    (/root/reference/src/nyx/output_2_buffer.cpp:305-306).  Returns (keys, table) on dst, (None, None) elsewhere."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        if producer is not None:
+            producer.sync()
+        return local_keys, local_table
+    cnt = torch.tensor([local_table.shape[0]], dtype=torch.int64, device=local_table.device)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt, group=group)
+    rows = [int(c.item()) for c in allc]
+    g = TableGather(local_table.shape[1], dst=dst, group=group)
+    g.start(local_table, rows_per_rank=rows, producer=producer)
+    table = g.finish()
+    gk = TableGather(2, dst=dst, group=group)
+    gk.start(local_keys.to(torch.float64), rows_per_rank=rows)      # labels < 2^32 and image indices are exact in float64
+    keys = gk.finish()
+    return (keys.to(torch.int64), table) if table is not None else (None, None)

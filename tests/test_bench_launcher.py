@@ -1,0 +1,36 @@
+"""`python bench.py --gpus N` must start N ranks by itself (the driver's SCALE command shape), without the launcher
+touching the GPU.  Driven here with the bench's CPU stub (gloo): the launcher, the barrier / max-over-ranks timing and
+the table gather are the real code paths; only the per-rank step is replaced."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout           # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    rec = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--tiles", "5", "--stub"])
+    assert rec["stub"] is True and rec["n_gpus"] == 2 and rec["steps"] == 3
+    assert rec["rows"] == 2 * 5 * 3 and rec["row_order_ok"]       # weak scaling: 5 tiles per rank, rows in (tile, label) order
+
+
+def test_single_rank_needs_no_launcher():
+    rec = _run(["--gpus", "1", "--steps", "2", "--tiles", "4", "--stub"])
+    assert rec["n_gpus"] == 1 and rec["rows"] == 12 and rec["row_order_ok"]
+
+
+def test_launcher_reports_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--tiles", "-7"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
