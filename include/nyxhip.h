@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NYXHIP_ABI_VERSION 1
+#define NYXHIP_ABI_VERSION 2   /* 2: tile ABI v2 (nyxhip_tiles), sharded entry; every v1 symbol is kept */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -197,27 +197,83 @@ void nyxhip_finalize_table(double* table, size_t n_rows, size_t n_cols, size_t l
 /* ---- fused tile path ("next" row: phases 1-2 + reduce on the device) ---------
  * Replaces gatherRoisMetricsInMemory (src/nyx/phase1.cpp:373-409) +
  * scanTrivialRoisInMemory (src/nyx/phase2_2d.cpp:637-684) +
- * allocateTrivialRoisBuffers (:427-465) + reduce_trivial_rois_manual for one
- * intensity/label tile pair already in device or host memory.
+ * allocateTrivialRoisBuffers (:427-465) + the RAM batching of
+ * processTrivialRoisInMemory (:686-770) + reduce_trivial_rois_manual for a stack
+ * of equally sized intensity/label tile pairs in device or host memory.
  *
- * Pass 1 (nyxhip_tile_scan): per-label area / min / max / bounding box.
- *   Returns the number of distinct non-zero labels in *n_roi_out; labels come
- *   back sorted ascending (row order of save_features_2_buffer).
- * Pass 2 (nyxhip_featurize_tile): one workgroup per ROI reads its bounding-box
- *   window of the tile; rows of out_table follow ascending label.
- * `max_label` bounds the label values present (labels are dense small ints in
- * segmentation masks); the scan uses a [max_label+1] device table. */
+ * Tile t occupies rows [t*height, (t+1)*height) of one tall image.  Labels are
+ * per tile and may be ANY non-zero 32-bit values (the reference keys ROIs through
+ * hash containers, roi_cache.h / phase1.cpp:373-409): nothing is sized by label
+ * magnitude.  Rows come back ordered by (tile, label) -- images in input order,
+ * labels ascending, the row order of the reference's table
+ * (workflow_pythonapi.cpp:140-182 + output_2_buffer.cpp:305-306).
+ *
+ * Tiles keep the caller's unsigned element type (the reference casts everything to
+ * uint32 on the host, nyxus.py:486-489; here the cast happens in the kernels, so
+ * H2D carries the image's own bytes). */
+enum { NYXHIP_U8 = 1, NYXHIP_U16 = 2, NYXHIP_U32 = 4 };   /* element size in bytes */
+
+/* Slide min / max behind COVERED_IMAGE_INTENSITY_RANGE (intensity.cpp:72-77):
+ * MONTAGE  = the in-memory API: the montage prescan leaves them at +/-DBL_MAX
+ *            (slideprops.cpp:27-28,74-75), the feature is range / -inf = -0.0;
+ * PER_TILE = one tile is one slide: min / max of the intensities under any mask
+ *            (scan_slide_props, slideprops.cpp:456-...), computed on the device;
+ * GIVEN    = per-tile values from the caller (a slide cut into several tiles). */
+enum { NYXHIP_SLIDE_MONTAGE = 0, NYXHIP_SLIDE_PER_TILE = 1, NYXHIP_SLIDE_GIVEN = 2 };
+
+typedef struct nyxhip_tiles {
+    const void* inten;          /* [n_tiles][height][width] of inten_dtype             */
+    const void* label;          /* [n_tiles][height][width] of label_dtype, 0 = no ROI */
+    int32_t inten_dtype;        /* NYXHIP_U8 | NYXHIP_U16 | NYXHIP_U32                 */
+    int32_t label_dtype;
+    uint32_t width, height, n_tiles;
+    int32_t memory;             /* NYXHIP_MEM_HOST | NYXHIP_MEM_DEVICE (tiles AND outputs) */
+    int32_t slide_mode;         /* NYXHIP_SLIDE_*                                      */
+    const double* slide_min;    /* host [n_tiles], NYXHIP_SLIDE_GIVEN only             */
+    const double* slide_max;
+    uint64_t max_device_bytes;  /* device workspace budget of the call -- the counterpart of the
+                                   reference's ram_limit batching (phase2_2d.cpp:694-705): the stack
+                                   is processed in chunks of tiles that fit; 0 = half of the free
+                                   device memory                                       */
+} nyxhip_tiles;
+
+/* Host tiles: chunk c+1 is copied to the device while chunk c is being reduced (two device
+ * staging slots, copies and kernels on different streams).
+ * Outputs (host memory when tiles->memory == NYXHIP_MEM_HOST, else device memory):
+ * out_labels / out_tile_index (may be NULL) / out_table hold up to max_rows rows.  When the
+ * stack has more ROIs, NYXHIP_ERR_INVALID_ARG is returned and *n_roi_out holds the count.
+ * Host memory only: out_table == NULL asks the library to keep the result in the context;
+ * *n_roi_out then sizes the caller's buffers for nyxhip_fetch_result(). */
+int nyxhip_featurize_tiles_v2(nyxhip_ctx* ctx, const nyxhip_tiles* tiles, uint32_t family_mask,
+                              const nyxhip_settings* s, uint32_t* out_labels, uint32_t* out_tile_index,
+                              uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out);
+/* Copies the result kept by the last nyxhip_featurize_tiles_v2(out_table == NULL) call and frees it. */
+int nyxhip_fetch_result(nyxhip_ctx* ctx, uint32_t* out_labels, uint32_t* out_tile_index,
+                        double* out_table, size_t out_ld);
+
+/* One node, several GPUs: the stack (HOST memory) is block-partitioned over the contexts
+ * (context g gets tiles [g*n/G, (g+1)*n/G) -- ROIs are independent, the label vector is
+ * already sliced like this by the reference's runParallel, parallel.h:34-41), each context
+ * is driven by its own host thread, and the rows are returned in stack order as above.
+ * Contexts may sit on the same or on different devices.  out_table == NULL: see
+ * nyxhip_fetch_result_sharded(). */
+int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyxhip_tiles* tiles,
+                                   uint32_t family_mask, const nyxhip_settings* s,
+                                   uint32_t* out_labels, uint32_t* out_tile_index, uint64_t max_rows,
+                                   double* out_table, size_t out_ld, uint64_t* n_roi_out);
+/* out_table == NULL above keeps every context's rows in the context; this copies them out in
+ * stack order (sum of the counts = the *n_roi_out of that call) and frees them. */
+int nyxhip_fetch_result_sharded(nyxhip_ctx* const* ctxs, int n_ctx, uint32_t* out_labels,
+                                uint32_t* out_tile_index, double* out_table, size_t out_ld);
+
+/* v1 entry points (uint32 tiles, montage slide semantics).  `max_label` is only validated:
+ * a label above it is NYXHIP_ERR_INVALID_ARG; pass 0xFFFFFFFF to accept every value. */
 int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label,
                           uint32_t width, uint32_t height, int32_t memory,
                           uint32_t max_label, uint32_t family_mask,
                           const nyxhip_settings* s,
                           uint32_t* out_labels, uint64_t max_rows,
                           double* out_table, size_t out_ld, uint64_t* n_roi_out);
-
-/* Same for a stack of n_tiles equally sized tiles stored back to back (tile t occupies rows
- * [t*height, (t+1)*height) of one tall image).  Labels are per tile; rows come back ordered by
- * (tile, label) -- images in input order, labels ascending, the row order of the reference's table
- * (workflow_pythonapi.cpp:140-182 + output_2_buffer.cpp:305-306).  out_tile_index may be NULL. */
 int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label,
                            uint32_t width, uint32_t height, uint32_t n_tiles, int32_t memory,
                            uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,

@@ -34,6 +34,9 @@ FAM_ALL = 0xFFF
 MEM_HOST = 0
 MEM_DEVICE = 1
 
+U8, U16, U32 = 1, 2, 4                       # tile element types (bytes per element)
+SLIDE_MONTAGE, SLIDE_PER_TILE, SLIDE_GIVEN = 0, 1, 2
+
 MAX_GLCM_ANGLES = 4
 MAX_GABOR_FILTERS = 16
 
@@ -83,6 +86,25 @@ class Batch(C.Structure):
         ("max_bbox_area", C.c_uint32),
         ("max_inten_range", C.c_uint32),
         ("max_bbox_side", C.c_uint32),
+    ]
+
+
+class Tiles(C.Structure):
+    """``nyxhip_tiles`` (include/nyxhip.h)."""
+
+    _fields_ = [
+        ("inten", C.c_void_p),
+        ("label", C.c_void_p),
+        ("inten_dtype", C.c_int32),
+        ("label_dtype", C.c_int32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("n_tiles", C.c_uint32),
+        ("memory", C.c_int32),
+        ("slide_mode", C.c_int32),
+        ("slide_min", C.c_void_p),
+        ("slide_max", C.c_void_p),
+        ("max_device_bytes", C.c_uint64),
     ]
 
 

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "nyxhip_set_stream", "nyxhip_n_columns", "nyxhip_column_name", "nyxhip_featurize_batch",
     "nyxhip_featurize_batch_async", "nyxhip_sync", "nyxhip_finalize_table", "nyxhip_featurize_tile", "nyxhip_featurize_tiles",
     "nyxhip_timing_enable", "nyxhip_timing_reset", "nyxhip_timing_get",
+    "nyxhip_featurize_tiles_v2", "nyxhip_fetch_result", "nyxhip_featurize_tiles_sharded", "nyxhip_fetch_result_sharded",
 ]
 
 
@@ -85,6 +86,16 @@ def load() -> C.CDLL:
                                            C.c_uint32, C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_size_t, P(C.c_uint64)]
     lib.nyxhip_featurize_tiles.restype = C.c_int
+    lib.nyxhip_featurize_tiles_v2.argtypes = [C.c_void_p, P(_abi.Tiles), C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_size_t, P(C.c_uint64)]
+    lib.nyxhip_featurize_tiles_v2.restype = C.c_int
+    lib.nyxhip_fetch_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.nyxhip_fetch_result.restype = C.c_int
+    lib.nyxhip_featurize_tiles_sharded.argtypes = [P(C.c_void_p), C.c_int, P(_abi.Tiles), C.c_uint32, P(_abi.Settings), C.c_void_p, C.c_void_p,
+                                                   C.c_uint64, C.c_void_p, C.c_size_t, P(C.c_uint64)]
+    lib.nyxhip_featurize_tiles_sharded.restype = C.c_int
+    lib.nyxhip_fetch_result_sharded.argtypes = [P(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.nyxhip_fetch_result_sharded.restype = C.c_int
     lib.nyxhip_timing_enable.argtypes = [C.c_void_p, C.c_int]
     lib.nyxhip_timing_enable.restype = C.c_int
     lib.nyxhip_timing_reset.argtypes = [C.c_void_p]
@@ -154,48 +165,65 @@ class Context:
         self._check(self._lib.nyxhip_featurize_batch_async(self._h, C.byref(cb), mask, C.byref(s), C.c_void_p(out_ptr), ld))
 
     def featurize_tile_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, max_label: Optional[int] = None):
-        """One intensity / label tile pair (host uint32 arrays) through the fused device path:
-        label scan + ROI assembly + reduce.  Returns (labels ascending, table)."""
-        inten = np.ascontiguousarray(inten, np.uint32)
-        label = np.ascontiguousarray(label, np.uint32)
+        """One intensity / label tile pair (host arrays) through the fused device path: label scan + ROI assembly + reduce.
+        Returns (labels ascending, table).  `max_label` (v1 semantics): a label above it is an error."""
         if inten.shape != label.shape or inten.ndim != 2:
             raise ValueError("tiles must be 2-D arrays of the same shape")
-        if max_label is None:
-            max_label = int(label.max())
-        ncol = self.n_columns(mask, s)
-        cap = max(1, min(max_label, inten.size))
-        labels = np.zeros(cap, np.uint32)
-        table = np.empty((cap, ncol), np.float64)
-        n = C.c_uint64(0)
-        if max_label == 0:
-            return labels[:0], table[:0]
-        self._check(self._lib.nyxhip_featurize_tile(self._h, inten.ctypes.data, label.ctypes.data, inten.shape[1], inten.shape[0],
-                                                    _abi.MEM_HOST, max_label, mask, C.byref(s), labels.ctypes.data, cap,
-                                                    table.ctypes.data, ncol, C.byref(n)))
-        return labels[: n.value], table[: n.value]
+        if max_label is not None:
+            inten = np.ascontiguousarray(inten, np.uint32)
+            label = np.ascontiguousarray(label, np.uint32)
+            ncol = self.n_columns(mask, s)
+            cap = max(1, min(max_label, inten.size))
+            labels = np.zeros(cap, np.uint32)
+            table = np.empty((cap, ncol), np.float64)
+            n = C.c_uint64(0)
+            self._check(self._lib.nyxhip_featurize_tile(self._h, inten.ctypes.data, label.ctypes.data, inten.shape[1], inten.shape[0],
+                                                        _abi.MEM_HOST, max_label, mask, C.byref(s), labels.ctypes.data, cap,
+                                                        table.ctypes.data, ncol, C.byref(n)))
+            return labels[: n.value], table[: n.value]
+        _, labels, table = self.featurize_tiles_host(inten[None], label[None], mask, s)
+        return labels, table
 
-    def featurize_tiles_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, max_label: Optional[int] = None):
-        """A stack [n_tiles, H, W] of host uint32 tiles through the fused device path.
-        Returns (tile_index, labels, table) with rows ordered by (tile, label)."""
-        inten = np.ascontiguousarray(inten, np.uint32)
-        label = np.ascontiguousarray(label, np.uint32)
+    def featurize_tiles_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, slide_mode: int = _abi.SLIDE_MONTAGE,
+                             slide_min=None, slide_max=None, max_device_bytes: int = 0, contexts: Optional[list] = None):
+        """A stack [n_tiles, H, W] of host tiles through the fused device path (nyxhip_featurize_tiles_v2).  uint8 / uint16 /
+        uint32 arrays are handed over as they are (the kernels widen); anything else is cast to uint32 first.  Label values are
+        arbitrary.  Returns (tile_index, labels, table) with rows ordered by (tile, label), sized by the ROI count the device
+        scan found.  `contexts`: more contexts (one per GPU) -> nyxhip_featurize_tiles_sharded block-partitions the stack."""
         if inten.shape != label.shape or inten.ndim != 3:
             raise ValueError("stacks must be 3-D arrays [n_tiles, H, W] of the same shape")
-        if max_label is None:
-            max_label = int(label.max())
+        dt = {np.dtype(np.uint8): _abi.U8, np.dtype(np.uint16): _abi.U16, np.dtype(np.uint32): _abi.U32}
+        inten = np.ascontiguousarray(inten if inten.dtype in dt else inten.astype(np.uint32))
+        label = np.ascontiguousarray(label if label.dtype in dt else label.astype(np.uint32))
         ncol = self.n_columns(mask, s)
         nt, h, w = inten.shape
-        cap = max(1, min(max_label * nt, inten.size))
-        labels = np.zeros(cap, np.uint32)
-        tiles = np.zeros(cap, np.uint32)
-        table = np.empty((cap, ncol), np.float64)
+        t = _abi.Tiles()
+        t.inten = inten.ctypes.data; t.label = label.ctypes.data
+        t.inten_dtype = dt[inten.dtype]; t.label_dtype = dt[label.dtype]
+        t.width = w; t.height = h; t.n_tiles = nt; t.memory = _abi.MEM_HOST; t.slide_mode = slide_mode
+        keep = []
+        if slide_mode == _abi.SLIDE_GIVEN:
+            keep = [np.ascontiguousarray(slide_min, np.float64), np.ascontiguousarray(slide_max, np.float64)]
+            if keep[0].shape != (nt,) or keep[1].shape != (nt,):
+                raise ValueError("slide_min / slide_max must hold one value per tile")
+            t.slide_min = keep[0].ctypes.data; t.slide_max = keep[1].ctypes.data
+        t.max_device_bytes = int(max_device_bytes)
         n = C.c_uint64(0)
-        if max_label == 0:
-            return tiles[:0], labels[:0], table[:0]
-        self._check(self._lib.nyxhip_featurize_tiles(self._h, inten.ctypes.data, label.ctypes.data, w, h, nt, _abi.MEM_HOST, max_label,
-                                                     mask, C.byref(s), labels.ctypes.data, tiles.ctypes.data, cap, table.ctypes.data,
-                                                     ncol, C.byref(n)))
-        return tiles[: n.value], labels[: n.value], table[: n.value]
+        if nt == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, ncol))
+        ctxs = [self] + [c for c in (contexts or []) if c is not self]
+        if len(ctxs) > 1:
+            arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+            self._check(self._lib.nyxhip_featurize_tiles_sharded(arr, len(ctxs), C.byref(t), mask, C.byref(s), None, None, 0, None, 0, C.byref(n)))
+            labels = np.zeros(n.value, np.uint32); tiles = np.zeros(n.value, np.uint32); table = np.empty((n.value, ncol), np.float64)
+            self._check(self._lib.nyxhip_fetch_result_sharded(arr, len(ctxs), labels.ctypes.data, tiles.ctypes.data, table.ctypes.data, ncol))
+            return tiles, labels, table
+        self._check(self._lib.nyxhip_featurize_tiles_v2(self._h, C.byref(t), mask, C.byref(s), None, None, 0, None, 0, C.byref(n)))
+        labels = np.zeros(n.value, np.uint32)
+        tiles = np.zeros(n.value, np.uint32)
+        table = np.empty((n.value, ncol), np.float64)
+        self._check(self._lib.nyxhip_fetch_result(self._h, labels.ctypes.data, tiles.ctypes.data, table.ctypes.data, ncol))
+        return tiles, labels, table
 
     def sync(self):
         self._check(self._lib.nyxhip_sync(self._h))

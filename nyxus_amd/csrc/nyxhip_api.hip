@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 #include "../../include/nyxhip.h"
 #include "roi_kernel.h"
@@ -44,9 +45,20 @@ struct nyxhip_ctx {
     size_t spill_list_bytes = 0;
     unsigned char* d_spill = nullptr;
     size_t spill_bytes = 0;
-    // grow-only workspace of the fused tile path (tables, rows, clouds, table)
+    // grow-only workspaces of the fused tile path: scan tables + rows | clouds | two staging slots for host tiles
     void* d_tile = nullptr;
     size_t tile_bytes = 0;
+    void* d_cloud = nullptr;
+    size_t cloud_bytes = 0;
+    void* d_slot[2] = {nullptr, nullptr};
+    size_t slot_bytes[2] = {0, 0};
+    hipStream_t copy_stream = nullptr;         // H2D of the next chunk runs beside the kernels of the current one
+    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    uint32_t tile_cap_hint = 0;                // per-tile table size that served the last call
+    // result kept for nyxhip_fetch_result() (host-memory calls with out_table == NULL)
+    std::vector<uint32_t> res_label, res_tile;
+    std::vector<double> res_table;
+    size_t res_cols = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -569,6 +581,12 @@ __global__ void iota_kernel(uint32_t n, uint32_t* out)
     if (i < n) out[i] = i;
 }
 
+__global__ void add_offset_kernel(const uint32_t* in, uint32_t add, uint32_t n, uint32_t* out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+
 struct Extrema { uint32_t px, area, range, side; };
 
 // Fills the three argument blocks for one set of extrema; `cap` = 0 -> LDS carve-outs, else spill layouts.
@@ -1004,6 +1022,13 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_tile) (void)hipFree(ctx->d_tile);
+    if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->d_slot[k]) (void)hipFree(ctx->d_slot[k]);
+        if (ctx->slot_ready[k]) (void)hipEventDestroy(ctx->slot_ready[k]);
+        if (ctx->slot_free[k]) (void)hipEventDestroy(ctx->slot_free[k]);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_mom) (void)hipFree(ctx->d_mom);
     if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
@@ -1174,6 +1199,373 @@ void nyxhip_finalize_table(double* table, size_t n_rows, size_t n_cols, size_t l
         }
 }
 
+// ---- fused tile path -----------------------------------------------------------------------------------------------------
+static int grow(nyxhip_ctx* ctx, void** p, size_t* have, size_t need, hipStream_t st)
+{
+    if (need <= *have) return NYXHIP_OK;
+    if (*p) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *have = 0; }
+    const size_t want = need + need / 8 + (1 << 16);
+    HIP_TRY(ctx, hipMalloc(p, want));
+    *have = want;
+    return NYXHIP_OK;
+}
+
+static uint32_t log2u(uint32_t v) { uint32_t k = 0; while ((1u << k) < v) k++; return k; }
+
+// Per-tile table size to start with: room for one ROI per 512 pixels (a 1024 x 1024 tile: 2048 slots for ~200 ROIs); a tile
+// with more labels than slots makes the scan raise the overflow flag and the chunk is rescanned with four times the slots.
+static uint32_t first_tile_cap(uint64_t tile_px)
+{
+    uint64_t c = tile_px / 512;
+    if (c < 256) c = 256;
+    if (c > (1u << 22)) c = 1u << 22;
+    return pow2ceil((uint32_t)c);
+}
+
+// Device workspace of one chunk besides the staging slots and the clouds (which are sized after the scan).
+static size_t chunk_table_bytes(uint32_t nt, uint32_t cap)
+{
+    const size_t ent = (size_t)nt * cap;
+    return ent * 32 + ent * (12 * 4 + 8 + 16) + (size_t)nt * 16 + (ent / 1024 + 2) * 12 + (1 << 16);
+}
+
+// One chunk of tiles resident on the device -> rows in d_lab / d_til / d_out (device).  *n_roi_out rows are produced; more than
+// rows_cap -> nothing is written beyond rows_cap and the caller reports the shortage.
+static int tiles_chunk(nyxhip_ctx* ctx, const void* d_inten, int dtI, const void* d_label, int dtL, uint32_t W, uint32_t H, uint32_t nt,
+                       int slide_mode, const double* h_smin, const double* h_smax, uint32_t family_mask, const nyxhip_settings* s,
+                       uint64_t rows_cap, uint32_t* d_lab, uint32_t* d_til, uint32_t tile_base, double* d_out, size_t d_ld, uint32_t label_limit,
+                       uint64_t* n_roi_out, hipStream_t st)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    uint32_t cap = ctx->tile_cap_hint ? ctx->tile_cap_hint : first_tile_cap((uint64_t)W * H);
+    const uint64_t tile_px = (uint64_t)W * H;
+    const uint32_t cap_max = pow2ceil((uint32_t)std::min<uint64_t>(2 * tile_px, 1u << 30));
+    if (cap > cap_max) cap = cap_max;
+    uint32_t meta[16];
+    TileRows R;
+    char* base = nullptr;
+    for (;;) {
+        const uint64_t ent = (uint64_t)nt * cap;
+        if (ent > (1ull << 31)) return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "too many ROIs per tile for one chunk: lower max_device_bytes so that fewer tiles share a chunk");
+        const uint64_t rc_rows = ent;                                    // every ROI occupies a slot: this many rows always suffice
+        size_t o = 0;
+        size_t o_h[8]; for (int i = 0; i < 8; i++) { o_h[i] = o; o = al(o + 4 * ent); }
+        size_t o_u[10]; for (int i = 0; i < 10; i++) { o_u[i] = o; o = al(o + 4 * (rc_rows + 1)); }
+        size_t o_r[10]; for (int i = 0; i < 10; i++) { o_r[i] = o; o = al(o + 4 * (rc_rows + 1)); }
+        const size_t o_ro = o; o = al(o + 8 * (rc_rows + 2));
+        const size_t o_smin = o; o = al(o + 8 * (rc_rows + 1));
+        const size_t o_smax = o; o = al(o + 8 * (rc_rows + 1));
+        const size_t o_meta = o; o = al(o + 64);
+        const size_t n_blk = (size_t)((ent + 1023) / 1024);
+        const size_t o_br = o; o = al(o + 4 * n_blk);
+        const size_t o_bp = o; o = al(o + 8 * n_blk);
+        const size_t o_trb = o; o = al(o + 4 * ((size_t)nt + 1));
+        const size_t o_tpb = o; o = al(o + 8 * ((size_t)nt + 1));
+        const size_t o_sin = o; o = al(o + 16 * (size_t)nt);
+        if (int grc = grow(ctx, &ctx->d_tile, &ctx->tile_bytes, o, st)) return grc;
+        base = (char*)ctx->d_tile;
+        TileHash T{(uint32_t*)(base + o_h[0]), (uint32_t*)(base + o_h[1]), (uint32_t*)(base + o_h[2]), (uint32_t*)(base + o_h[3]),
+                   (uint32_t*)(base + o_h[4]), (uint32_t*)(base + o_h[5]), (uint32_t*)(base + o_h[6]), (uint32_t*)(base + o_h[7]), cap, 32u - log2u(cap)};
+        TileRows U{(uint32_t*)(base + o_u[0]), (uint32_t*)(base + o_u[1]), (uint32_t*)(base + o_u[2]), nullptr, (uint32_t*)(base + o_u[3]),
+                   (uint32_t*)(base + o_u[4]), (uint32_t*)(base + o_u[5]), (uint32_t*)(base + o_u[6]), (uint32_t*)(base + o_u[7]), (uint32_t*)(base + o_u[8]),
+                   nullptr, nullptr};
+        R = TileRows{(uint32_t*)(base + o_r[0]), (uint32_t*)(base + o_r[1]), (uint32_t*)(base + o_r[2]), (uint64_t*)(base + o_ro), (uint32_t*)(base + o_r[3]),
+                     (uint32_t*)(base + o_r[4]), (uint32_t*)(base + o_r[5]), (uint32_t*)(base + o_r[6]), (uint32_t*)(base + o_r[7]), (uint32_t*)(base + o_r[8]),
+                     (double*)(base + o_smin), (double*)(base + o_smax)};
+        uint32_t* d_meta = (uint32_t*)(base + o_meta);
+        HIP_TRY(ctx, hipMemsetAsync(d_meta, 0, 64, st));
+        const double* d_smin = nullptr; const double* d_smax = nullptr;
+        if (slide_mode == NYXHIP_SLIDE_GIVEN) {
+            HIP_TRY(ctx, hipMemcpyAsync(base + o_sin, h_smin, 8 * (size_t)nt, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(base + o_sin + 8 * (size_t)nt, h_smax, 8 * (size_t)nt, hipMemcpyHostToDevice, st));
+            d_smin = (const double*)(base + o_sin); d_smax = d_smin + nt;
+        }
+        int rc = launch_tile_assembly_scan(d_inten, dtI, d_label, dtL, W, H, nt, T, U, R, (uint32_t)std::min<uint64_t>(rc_rows, 0xFFFFFFFFu), d_meta,
+                                           (uint32_t*)(base + o_br), (unsigned long long*)(base + o_bp), (uint32_t*)(base + o_trb),
+                                           (unsigned long long*)(base + o_tpb), st);
+        if (rc == 0)
+            rc = launch_tile_rank(U, (const uint32_t*)(base + o_trb), (const unsigned long long*)(base + o_tpb), R, (uint32_t)std::min<uint64_t>(rc_rows, 0xFFFFFFFFu),
+                                  nt, cap, slide_mode, d_smin, d_smax, st);
+        if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("tile scan launch failed: ") + hipGetErrorString((hipError_t)rc));
+        HIP_TRY(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (meta[7] == 1) {                                  // a tile holds more labels than its table has slots
+            if (cap >= cap_max) return fail(ctx, NYXHIP_ERR_HIP, "tile table overflow at the maximum table size");
+            cap = cap * 4 > cap_max ? cap_max : cap * 4;
+            continue;
+        }
+        break;
+    }
+    ctx->tile_cap_hint = cap;
+    if (meta[7] == 2)
+        return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "an ROI's bounding box is wider or taller than 65535 pixels (coordinates inside a box are 16-bit)");
+    if (meta[8] > label_limit)
+        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the label tile holds a value above max_label");
+    const uint64_t n_roi = meta[0];
+    *n_roi_out = n_roi;
+    if (n_roi == 0 || n_roi > rows_cap) return NYXHIP_OK;
+    const uint64_t npx = ((uint64_t)meta[2] << 32) | meta[1];
+    // clouds (8 B per ROI pixel) for the reduce kernels
+    size_t c = 0;
+    const size_t o_cx = c; c = al(c + 2 * npx);
+    const size_t o_cy = c; c = al(c + 2 * npx);
+    const size_t o_cv = c; c = al(c + 4 * npx);
+    if (int grc = grow(ctx, &ctx->d_cloud, &ctx->cloud_bytes, c, st)) return grc;
+    char* cb = (char*)ctx->d_cloud;
+    int rc = launch_tile_clouds(d_inten, dtI, d_label, dtL, W, H, R, (uint32_t)n_roi, (uint16_t*)(cb + o_cx), (uint16_t*)(cb + o_cy), (uint32_t*)(cb + o_cv), st);
+    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    HIP_TRY(ctx, hipMemcpyAsync(d_lab, R.label, 4 * n_roi, hipMemcpyDeviceToDevice, st));
+    if (d_til) {
+        if (tile_base == 0) HIP_TRY(ctx, hipMemcpyAsync(d_til, R.tile, 4 * n_roi, hipMemcpyDeviceToDevice, st));
+        else hipLaunchKernelGGL(add_offset_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.tile, tile_base, (uint32_t)n_roi, d_til);
+    }
+    nyxhip_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
+    b.x = (const uint16_t*)(cb + o_cx); b.y = (const uint16_t*)(cb + o_cy); b.inten = (const uint32_t*)(cb + o_cv);
+    b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
+    b.slide_min = R.slide_min; b.slide_max = R.slide_max;
+    b.memory = NYXHIP_MEM_DEVICE;
+    return launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+}
+
+static int tiles_validate(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint64_t* n_roi_out)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    if (!t || !s || !n_roi_out) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null tiles / settings / n_roi_out");
+    if (t->n_tiles == 0) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "n_tiles must be >= 1");
+    if (!t->inten || !t->label || t->width == 0 || t->height == 0) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null pointer or empty tile");
+    auto dt_ok = [](int d) { return d == NYXHIP_U8 || d == NYXHIP_U16 || d == NYXHIP_U32; };
+    if (!dt_ok(t->inten_dtype) || !dt_ok(t->label_dtype)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "tile element types must be NYXHIP_U8 / U16 / U32");
+    if (family_mask == 0 || (family_mask & ~kImplemented)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
+    if (t->memory != NYXHIP_MEM_HOST && t->memory != NYXHIP_MEM_DEVICE) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
+    if (t->slide_mode < NYXHIP_SLIDE_MONTAGE || t->slide_mode > NYXHIP_SLIDE_GIVEN) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad slide_mode");
+    if (t->slide_mode == NYXHIP_SLIDE_GIVEN && (!t->slide_min || !t->slide_max)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "NYXHIP_SLIDE_GIVEN needs slide_min and slide_max");
+    std::string why;
+    if (!settings_ok(s, family_mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
+    return NYXHIP_OK;
+}
+
+// The whole stack in chunks.  label_limit: v1's max_label (validated only).
+static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint32_t* out_labels, uint32_t* out_tile_index,
+                     uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit)
+{
+    if (int vrc = tiles_validate(ctx, t, family_mask, s, n_roi_out)) return vrc;
+    const int n_cols = nyxhip_n_columns(family_mask, s);
+    const bool host = t->memory == NYXHIP_MEM_HOST;
+    const bool keep = host && out_table == nullptr;                  // result stays in the context (nyxhip_fetch_result)
+    if (!keep && (!out_labels || !out_table)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null output pointers");
+    if (!keep && (int)out_ld < n_cols) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "out_ld smaller than the column count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *n_roi_out = 0;
+    hipStream_t st = ctx->stream();
+    const uint32_t W = t->width, H = t->height;
+    const uint64_t tile_px = (uint64_t)W * H;
+    const size_t tile_in_bytes = (size_t)tile_px * (size_t)(t->inten_dtype + t->label_dtype);
+    // ---- chunking (the reference batches ROIs by ram_limit, phase2_2d.cpp:694-705): per tile the scan tables and rows, the
+    // clouds (<= 8 B per pixel), the table rows and -- host input -- two staging copies of the tile
+    size_t budget = (size_t)t->max_device_bytes;
+    if (budget == 0) {
+        size_t fr = 0, tot = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&fr, &tot));
+        budget = (fr + ctx->tile_bytes + ctx->cloud_bytes + ctx->slot_bytes[0] + ctx->slot_bytes[1]) / 2;
+    }
+    const uint32_t cap0 = ctx->tile_cap_hint ? ctx->tile_cap_hint : first_tile_cap(tile_px);
+    const size_t per_tile = chunk_table_bytes(1, cap0) + 8 * (size_t)tile_px + (size_t)cap0 * 8 * n_cols / 8 + (host ? 2 * tile_in_bytes : 0);
+    uint64_t chunk = std::max<uint64_t>(1, budget / std::max<size_t>(per_tile, 1));
+    if (host) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, ((size_t)512 << 20) / tile_in_bytes));   // <= 512 MiB per copy: the pipeline needs chunks
+    if (chunk > t->n_tiles) chunk = t->n_tiles;
+    if (host && t->n_tiles >= 4 && chunk > (t->n_tiles + 1) / 2) chunk = (t->n_tiles + 1) / 2;                 // at least two chunks to overlap
+    while ((uint64_t)chunk * cap0 > (1ull << 30) && chunk > 1) chunk /= 2;
+
+    if (keep) { ctx->res_label.clear(); ctx->res_tile.clear(); ctx->res_table.clear(); ctx->res_cols = (size_t)n_cols; }
+    uint64_t rows_done = 0;
+    bool short_out = false;
+    if (!host) {
+        for (uint64_t t0 = 0; t0 < t->n_tiles; t0 += chunk) {
+            const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
+            const char* di = (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype;
+            const char* dl = (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype;
+            const uint64_t room = rows_done < max_rows ? max_rows - rows_done : 0;
+            uint64_t n = 0;
+            int rc = tiles_chunk(ctx, di, t->inten_dtype, dl, t->label_dtype, W, H, nt, t->slide_mode, t->slide_min ? t->slide_min + t0 : nullptr,
+                                 t->slide_max ? t->slide_max + t0 : nullptr, family_mask, s, short_out ? 0 : room, out_labels + rows_done,
+                                 out_tile_index ? out_tile_index + rows_done : nullptr, (uint32_t)t0, out_table + rows_done * out_ld, out_ld, label_limit, &n, st);
+            if (rc) return rc;
+            if (n > room) short_out = true;
+            rows_done += n;
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        *n_roi_out = rows_done;
+        if (short_out) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the stack (see *n_roi_out)");
+        return check_status(ctx);
+    }
+
+    // ---- host tiles: copy chunk c + 1 while chunk c is reduced --------------------------------------------------------------
+    if (!ctx->copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_ready[k], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_free[k], hipEventDisableTiming));
+        }
+    }
+    const size_t slot_need = (size_t)chunk * tile_in_bytes + 512;
+    const uint64_t n_chunks = (t->n_tiles + chunk - 1) / chunk;
+    for (int k = 0; k < (n_chunks > 1 ? 2 : 1); k++)
+        if (int grc = grow(ctx, &ctx->d_slot[k], &ctx->slot_bytes[k], slot_need, st)) return grc;
+    auto slot_inten = [&](int k) { return (char*)ctx->d_slot[k]; };
+    auto slot_label = [&](int k, uint32_t nt) { return (char*)ctx->d_slot[k] + (((size_t)nt * tile_px * t->inten_dtype + 255) & ~(size_t)255); };
+    auto upload = [&](uint64_t c) -> int {                                  // chunk c -> slot c & 1 on the copy stream
+        const int k = (int)(c & 1);
+        const uint64_t t0 = c * chunk;
+        const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
+        if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
+        HIP_TRY(ctx, hipMemcpyAsync(slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype,
+                                    hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype,
+                                    hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
+        return NYXHIP_OK;
+    };
+    if (int urc = upload(0)) return urc;
+    // per-chunk device outputs: labels, tile indices, table (grow-only, part of the cloud workspace is not reusable: separate block)
+    std::vector<uint32_t> h_lab, h_til;
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        const int k = (int)(c & 1);
+        const uint64_t t0 = c * chunk;
+        const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->slot_ready[k], 0));
+        uint64_t n = 0;
+        // the chunk's rows are produced in a device block owned by the context (d_stage), then copied out.  Its size follows the
+        // ROI density seen so far (first chunk: 256 per tile); a denser chunk is rescanned once with the room it asked for.
+        const uint64_t est_rows = std::max<uint64_t>((uint64_t)nt * 256, t0 ? (rows_done * 5 / 4 / t0 + 1) * nt : 0);
+        size_t need = (size_t)est_rows * (8 * (size_t)n_cols + 8) + 1024;
+        int rc;
+        for (;;) {
+            if (int grc = ensure_stage(ctx, need)) return grc;
+            const uint64_t cap_rows = (ctx->stage_bytes - 1024) / (8 * (size_t)n_cols + 8);
+            double* d_out = (double*)ctx->d_stage;
+            uint32_t* d_lab = (uint32_t*)((char*)ctx->d_stage + (((size_t)cap_rows * 8 * n_cols + 255) & ~(size_t)255));
+            uint32_t* d_til = d_lab + cap_rows;
+            rc = tiles_chunk(ctx, slot_inten(k), t->inten_dtype, slot_label(k, nt), t->label_dtype, W, H, nt, t->slide_mode,
+                             t->slide_min ? t->slide_min + t0 : nullptr, t->slide_max ? t->slide_max + t0 : nullptr, family_mask, s, cap_rows, d_lab, d_til,
+                             (uint32_t)t0, d_out, (size_t)n_cols, label_limit, &n, st);
+            if (rc) return rc;
+            if (n > cap_rows) { HIP_TRY(ctx, hipStreamSynchronize(st)); need = (size_t)n * (8 * (size_t)n_cols + 8) + 4096; continue; }
+            HIP_TRY(ctx, hipEventRecord(ctx->slot_free[k], st));
+            if (c + 1 < n_chunks)
+                if (int urc = upload(c + 1)) return urc;                    // host-side copy of the next chunk runs beside this chunk's kernels
+            const uint64_t room = rows_done < max_rows ? max_rows - rows_done : 0;
+            if (keep) {
+                const size_t r0 = ctx->res_label.size();
+                ctx->res_label.resize(r0 + n); ctx->res_tile.resize(r0 + n); ctx->res_table.resize((r0 + n) * (size_t)n_cols);
+                if (n) {
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_table.data() + r0 * (size_t)n_cols, d_out, 8 * n * (size_t)n_cols, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_label.data() + r0, d_lab, 4 * n, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_tile.data() + r0, d_til, 4 * n, hipMemcpyDeviceToHost, st));
+                }
+            } else if (n <= room && !short_out) {
+                if (n) {
+                    HIP_TRY(ctx, hipMemcpy2DAsync(out_table + rows_done * out_ld, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
+                                                  (size_t)n_cols * sizeof(double), n, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipMemcpyAsync(out_labels + rows_done, d_lab, 4 * n, hipMemcpyDeviceToHost, st));
+                    if (out_tile_index) HIP_TRY(ctx, hipMemcpyAsync(out_tile_index + rows_done, d_til, 4 * n, hipMemcpyDeviceToHost, st));
+                }
+            } else
+                short_out = true;
+            HIP_TRY(ctx, hipStreamSynchronize(st));                         // the chunk's rows are on the host; d_stage is free for the next one
+            break;
+        }
+        rows_done += n;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    *n_roi_out = rows_done;
+    if (short_out) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the stack (see *n_roi_out)");
+    return check_status(ctx);
+}
+
+int nyxhip_featurize_tiles_v2(nyxhip_ctx* ctx, const nyxhip_tiles* tiles, uint32_t family_mask, const nyxhip_settings* s, uint32_t* out_labels,
+                              uint32_t* out_tile_index, uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out)
+{
+    return tiles_run(ctx, tiles, family_mask, s, out_labels, out_tile_index, max_rows, out_table, out_ld, n_roi_out, 0xFFFFFFFFu);
+}
+
+int nyxhip_fetch_result(nyxhip_ctx* ctx, uint32_t* out_labels, uint32_t* out_tile_index, double* out_table, size_t out_ld)
+{
+    if (!ctx) return NYXHIP_ERR_INVALID_ARG;
+    const size_t n = ctx->res_label.size(), nc = ctx->res_cols;
+    if (n && (!out_labels || !out_table || out_ld < nc)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null output pointers or out_ld smaller than the column count");
+    for (size_t r = 0; r < n; r++)
+        memcpy(out_table + r * out_ld, ctx->res_table.data() + r * nc, nc * sizeof(double));
+    if (n) memcpy(out_labels, ctx->res_label.data(), 4 * n);
+    if (n && out_tile_index) memcpy(out_tile_index, ctx->res_tile.data(), 4 * n);
+    std::vector<uint32_t>().swap(ctx->res_label); std::vector<uint32_t>().swap(ctx->res_tile); std::vector<double>().swap(ctx->res_table);
+    return NYXHIP_OK;
+}
+
+int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyxhip_tiles* tiles, uint32_t family_mask, const nyxhip_settings* s,
+                                   uint32_t* out_labels, uint32_t* out_tile_index, uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return NYXHIP_ERR_INVALID_ARG;
+    nyxhip_ctx* c0 = ctxs[0];
+    if (!tiles || !n_roi_out) return fail(c0, NYXHIP_ERR_INVALID_ARG, "null tiles / n_roi_out");
+    if (tiles->memory != NYXHIP_MEM_HOST) return fail(c0, NYXHIP_ERR_INVALID_ARG, "the sharded entry takes host-memory stacks (every context copies its own share)");
+    const bool keep = out_table == nullptr;                              // results stay in the contexts (nyxhip_fetch_result_sharded)
+    if (!keep && !out_labels) return fail(c0, NYXHIP_ERR_INVALID_ARG, "null output pointers");
+    for (int g = 0; g < n_ctx; g++)
+        if (!ctxs[g]) return fail(c0, NYXHIP_ERR_INVALID_ARG, "null context in the list");
+    const int G = (int)std::min<uint64_t>((uint64_t)n_ctx, tiles->n_tiles ? tiles->n_tiles : 1);
+    // contiguous block partition (the first n % G contexts get one tile more); every context keeps its rows, which are then
+    // laid out back to back in context order = stack order
+    std::vector<int> rcs(G, 0);
+    std::vector<uint64_t> cnt(G, 0), lo(G + 1, 0);
+    const uint64_t q = tiles->n_tiles / G, r = tiles->n_tiles % G;
+    for (int g = 0; g < G; g++) lo[g + 1] = lo[g] + q + ((uint64_t)g < r ? 1 : 0);
+    const uint64_t tile_px = (uint64_t)tiles->width * tiles->height;
+    for (int g = 0; g < n_ctx; g++) { std::vector<uint32_t>().swap(ctxs[g]->res_label); std::vector<uint32_t>().swap(ctxs[g]->res_tile); std::vector<double>().swap(ctxs[g]->res_table); }
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; g++)
+        th.emplace_back([&, g]() {
+            nyxhip_tiles part = *tiles;
+            part.n_tiles = (uint32_t)(lo[g + 1] - lo[g]);
+            part.inten = (const char*)tiles->inten + (size_t)lo[g] * tile_px * tiles->inten_dtype;
+            part.label = (const char*)tiles->label + (size_t)lo[g] * tile_px * tiles->label_dtype;
+            if (tiles->slide_min) part.slide_min = tiles->slide_min + lo[g];
+            if (tiles->slide_max) part.slide_max = tiles->slide_max + lo[g];
+            if (part.n_tiles == 0) { rcs[g] = 0; return; }
+            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu);
+            for (auto& ti : ctxs[g]->res_tile) ti += (uint32_t)lo[g];          // tile indices of the whole stack
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) return g == 0 ? rcs[g] : fail(c0, rcs[g], std::string("context ") + std::to_string(g) + ": " + ctxs[g]->err);
+    uint64_t total = 0;
+    for (int g = 0; g < G; g++) total += cnt[g];
+    *n_roi_out = total;
+    if (keep) return NYXHIP_OK;
+    if (total > max_rows) {
+        for (int g = 0; g < G; g++) { std::vector<uint32_t>().swap(ctxs[g]->res_label); std::vector<uint32_t>().swap(ctxs[g]->res_tile); std::vector<double>().swap(ctxs[g]->res_table); }
+        return fail(c0, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the stack (see *n_roi_out)");
+    }
+    return nyxhip_fetch_result_sharded(ctxs, n_ctx, out_labels, out_tile_index, out_table, out_ld);
+}
+
+int nyxhip_fetch_result_sharded(nyxhip_ctx* const* ctxs, int n_ctx, uint32_t* out_labels, uint32_t* out_tile_index, double* out_table, size_t out_ld)
+{
+    if (!ctxs || n_ctx < 1) return NYXHIP_ERR_INVALID_ARG;
+    uint64_t row = 0;
+    for (int g = 0; g < n_ctx; g++) {
+        if (!ctxs[g]) return NYXHIP_ERR_INVALID_ARG;
+        const uint64_t n = ctxs[g]->res_label.size();
+        if (n) {
+            int rc = nyxhip_fetch_result(ctxs[g], out_labels + row, out_tile_index ? out_tile_index + row : nullptr, out_table + row * out_ld, out_ld);
+            if (rc) return rc;
+        }
+        row += n;
+    }
+    return NYXHIP_OK;
+}
+
 int nyxhip_featurize_tile(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_t* label, uint32_t width, uint32_t height,
                           int32_t memory, uint32_t max_label, uint32_t family_mask, const nyxhip_settings* s,
                           uint32_t* out_labels, uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out)
@@ -1188,106 +1580,12 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
                            uint64_t* n_roi_out)
 {
     if (!ctx) return NYXHIP_ERR_INVALID_ARG;
-    if (n_tiles == 0) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "n_tiles must be >= 1");
-    if (!inten || !label || !s || !out_labels || !out_table || !n_roi_out || width == 0 || height == 0)
-        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null pointer or empty tile");
-    if (family_mask == 0 || (family_mask & ~kImplemented)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
-    if (memory != NYXHIP_MEM_HOST && memory != NYXHIP_MEM_DEVICE) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
-    if (max_label == 0 || (uint64_t)(max_label + 1ull) * n_tiles > (1ull << 27))
-        return fail(ctx, NYXHIP_ERR_UNSUPPORTED, "(max_label + 1) * n_tiles must be in [2, 2^27]: relabel the masks densely or pass fewer tiles per call");
-    std::string why;
-    if (!settings_ok(s, family_mask, why)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, why);
-    const int n_cols = nyxhip_n_columns(family_mask, s);
-    if ((int)out_ld < n_cols) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "out_ld smaller than the column count");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    *n_roi_out = 0;
-    hipStream_t st = ctx->stream();
-    const uint64_t npx = (uint64_t)width * height * n_tiles;
-    const uint32_t stride = max_label + 1;
-    const uint32_t nlab = stride * n_tiles;
-    const uint64_t rows_cap = std::min<uint64_t>(max_rows, (uint64_t)max_label * n_tiles);
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-
-    // workspace carve-out: [tile copy (host input only)] tables, rows, meta, slide, clouds, table
-    size_t o = 0;
-    const size_t o_ti = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 4 * npx);
-    const size_t o_tl = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 4 * npx);
-    size_t o_tab[7]; for (int i = 0; i < 7; i++) { o_tab[i] = o; o = al(o + 4ull * nlab); }
-    const size_t o_rl = o; o = al(o + 4 * (rows_cap + 1));
-    const size_t o_ro = o; o = al(o + 8 * (rows_cap + 2));
-    size_t o_r6[6]; for (int i = 0; i < 6; i++) { o_r6[i] = o; o = al(o + 4 * (rows_cap + 1)); }
-    const size_t o_meta = o; o = al(o + 64);
-    const size_t n_blk = (nlab + 1023) / 1024;
-    const size_t o_br = o; o = al(o + 4 * n_blk);
-    const size_t o_bp = o; o = al(o + 8 * n_blk);
-    const size_t o_smin = o; o = al(o + 8 * (rows_cap + 1));
-    const size_t o_smax = o; o = al(o + 8 * (rows_cap + 1));
-    const size_t o_lab = o; o = al(o + 4 * (rows_cap + 1));
-    const size_t o_til = o; o = al(o + 4 * (rows_cap + 1));
-    const size_t o_cx = o; o = al(o + 2 * npx);          // an ROI pixel count never exceeds the tile
-    const size_t o_cy = o; o = al(o + 2 * npx);
-    const size_t o_cv = o; o = al(o + 4 * npx);
-    const size_t o_out = o; if (memory == NYXHIP_MEM_HOST) o = al(o + 8ull * rows_cap * n_cols);
-    if (o > ctx->tile_bytes) {
-        if (ctx->d_tile) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_tile)); ctx->d_tile = nullptr; ctx->tile_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->d_tile, o + o / 8));
-        ctx->tile_bytes = o + o / 8;
-    }
-    char* base = (char*)ctx->d_tile;
-    const uint32_t* d_inten = inten;
-    const uint32_t* d_label = label;
-    if (memory == NYXHIP_MEM_HOST) {
-        HIP_TRY(ctx, hipMemcpyAsync(base + o_ti, inten, 4 * npx, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(base + o_tl, label, 4 * npx, hipMemcpyHostToDevice, st));
-        d_inten = (const uint32_t*)(base + o_ti);
-        d_label = (const uint32_t*)(base + o_tl);
-    }
-    TileTables T{(uint32_t*)(base + o_tab[0]), (uint32_t*)(base + o_tab[1]), (uint32_t*)(base + o_tab[2]), (uint32_t*)(base + o_tab[3]),
-                 (uint32_t*)(base + o_tab[4]), (uint32_t*)(base + o_tab[5]), (uint32_t*)(base + o_tab[6])};
-    TileRows R{(uint32_t*)(base + o_rl), (uint64_t*)(base + o_ro), (uint32_t*)(base + o_r6[0]), (uint32_t*)(base + o_r6[1]),
-               (uint32_t*)(base + o_r6[2]), (uint32_t*)(base + o_r6[3]), (uint32_t*)(base + o_r6[4]), (uint32_t*)(base + o_r6[5])};
-    uint32_t* d_meta = (uint32_t*)(base + o_meta);
-    HIP_TRY(ctx, hipMemsetAsync(d_meta, 0, 64, st));
-    int rc = launch_tile_assembly_scan(d_inten, d_label, width, height, n_tiles, max_label, T, R, (uint32_t)rows_cap, d_meta,
-                                       (uint32_t*)(base + o_br), (unsigned long long*)(base + o_bp), ctx->d_status, st);
-    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("tile scan launch failed: ") + hipGetErrorString((hipError_t)rc));
-    uint32_t meta[8];
-    HIP_TRY(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (meta[7]) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
-        return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the label tile holds a value above max_label");
-    }
-    const uint64_t n_roi = meta[0];
-    *n_roi_out = n_roi;
-    if (n_roi == 0) return NYXHIP_OK;
-    if (n_roi > rows_cap) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the tile (see *n_roi_out)");
-    rc = launch_tile_clouds(d_inten, d_label, width, height, stride, R, (uint32_t)n_roi, (uint16_t*)(base + o_cx), (uint16_t*)(base + o_cy), (uint32_t*)(base + o_cv), st);
-    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-    uint32_t* d_lab = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_lab) : out_labels;
-    uint32_t* d_til = memory == NYXHIP_MEM_HOST ? (uint32_t*)(base + o_til) : out_tile_index;
-    hipLaunchKernelGGL(tile_split_keys_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.label, stride, (uint32_t)n_roi,
-                       d_lab, (memory == NYXHIP_MEM_HOST || out_tile_index) ? d_til : nullptr, (double*)(base + o_smin), (double*)(base + o_smax));
-    nyxhip_batch b;
-    memset(&b, 0, sizeof(b));
-    b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
-    b.x = (const uint16_t*)(base + o_cx); b.y = (const uint16_t*)(base + o_cy); b.inten = (const uint32_t*)(base + o_cv);
-    b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
-    b.slide_min = (const double*)(base + o_smin); b.slide_max = (const double*)(base + o_smax);
-    b.memory = NYXHIP_MEM_DEVICE;
-    double* d_out = memory == NYXHIP_MEM_HOST ? (double*)(base + o_out) : out_table;
-    const size_t d_ld = memory == NYXHIP_MEM_HOST ? (size_t)n_cols : out_ld;
-    rc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
-    if (rc) return rc;
-    if (memory == NYXHIP_MEM_HOST) {
-        HIP_TRY(ctx, hipMemcpy2DAsync(out_table, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
-                                      (size_t)n_cols * sizeof(double), n_roi, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(out_labels, d_lab, 4 * n_roi, hipMemcpyDeviceToHost, st));
-        if (out_tile_index)
-            HIP_TRY(ctx, hipMemcpyAsync(out_tile_index, d_til, 4 * n_roi, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    return check_status(ctx);
+    if (!out_labels || !out_table) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null pointer or empty tile");
+    nyxhip_tiles t;
+    memset(&t, 0, sizeof(t));
+    t.inten = inten; t.label = label; t.inten_dtype = NYXHIP_U32; t.label_dtype = NYXHIP_U32;
+    t.width = width; t.height = height; t.n_tiles = n_tiles; t.memory = memory; t.slide_mode = NYXHIP_SLIDE_MONTAGE;
+    return tiles_run(ctx, &t, family_mask, s, out_labels, out_tile_index, max_rows, out_table, out_ld, n_roi_out, max_label);
 }
 
 int nyxhip_timing_enable(nyxhip_ctx* ctx, int on)

@@ -647,21 +647,16 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             return (C16 ? (uint32_t)((const uint16_t*)s_cnt)[i] : s_cnt[i]) + s_woff[wq];
         };
 
-        // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183;
-        // M2..M4 of moments.h:53-74 equal the plain central sums)
+        // central sums over the LDS-resident values (intensity.cpp:102-109, :177-183; M2..M4 of moments.h:53-74 equal the
+        // plain central sums).  C16 launches take them in ONE fused sweep together with the robust statistics, after the
+        // percentiles (see below); a blank ROI (all zeros) has every sum equal to zero and needs no sweep at all.
+#ifdef NYX_NO_FUSED      // diagnostic builds (A/B timing)
+        constexpr bool FUSED = false;
+#else
+        constexpr bool FUSED = C16 && !GS;
+#endif
         double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t i = tid; i < n; i += kBlock) {
-            double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]) - mean;
-            double d2 = d * d;
-            acc[0] += fabs(d);
-            acc[1] += d2;
-            acc[2] += d2 * d;
-            acc[3] += d2 * d2;
-            acc[4] += d2 * d2 * d;
-            acc[5] += d2 * d2 * d2;
-        }
-        block_sum<6, GS>(acc, s_red, tid);
-        if (tid == 0) { // everything that depends only on the sums leaves the registers now
+        auto central_outputs = [&](const double (&acc)[6]) {   // everything that depends only on the sums (single lane)
             const double var = acc[1];                 // intensity.cpp:110-118
             o[I_MEAN_ABSOLUTE_DEVIATION] = fdiv(acc[0], dn);
             const double variance = dn > 1 ? fdiv(var, dn - 1) : 0.0;
@@ -686,6 +681,23 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 denom = dn * (sd2 * sd2 * sd2);
                 o[I_HYPERFLATNESS] = denom == 0. ? 0. : acc[5] / denom;
             }
+        };
+        if (!FUSED || blank) {
+            if (!blank) {
+                for (uint32_t i = tid; i < n; i += kBlock) {
+                    double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]) - mean;
+                    double d2 = d * d;
+                    acc[0] += fabs(d);
+                    acc[1] += d2;
+                    acc[2] += d2 * d;
+                    acc[3] += d2 * d2;
+                    acc[4] += d2 * d2 * d;
+                    acc[5] += d2 * d2 * d2;
+                }
+                block_sum<6, GS>(acc, s_red, tid);
+            }
+            if (tid == 0)
+                central_outputs(acc);
         }
         STAMP(4);
 
@@ -833,6 +845,87 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
             // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
             const double p10 = s_stat[S_P10], p90 = s_stat[S_P90], median = s_stat[S_MEDIAN];
+            if (FUSED) {
+                // ---- one sweep over the resident values: central sums (fp64, fused multiply-adds: the sums are tolerance-class,
+                // DESIGN 4.6) + the robust statistics in exact integer arithmetic on the 16-bit offsets x = v - vmin:
+                //   a >= p10 && a <= p90  <=>  lox <= x <= hix  with  lox = ceil(p10) - vmin, hix = floor(p90) - vmin  (a is an integer)
+                //   sum |a - median| = sum |2x - m2x| / 2,  m2x = 2 (median - vmin)  (an integer: the median is k or k + 1/2)
+                // Every partial sum fits 32 bits: n < 65536 and x < 16384 in a C16 launch.
+                uint32_t lox = 0x80000000u, span = 0;                       // empty range unless the bounds say otherwise (NaN: empty)
+                if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
+                    const double cl = ceil(p10), fl = floor(p90);
+                    const uint32_t lo_v = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_v = fl >= (double)vmax ? vmax : (uint32_t)fl;
+                    if (lo_v <= hi_v) { lox = lo_v - vmin; span = hi_v - lo_v; }
+                }
+                lox = (uint32_t)__builtin_amdgcn_readfirstlane((int)lox);
+                span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
+                const uint32_t m2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((median - (double)vmin) * 2.0));
+                uint32_t sx = 0, sad = 0;
+                for (uint32_t i = tid; i < n; i += kBlock) {
+                    const uint32_t x = ((const uint16_t*)s_val)[i];
+                    const double d = (double)(vmin + x) - mean;
+                    const double d2 = d * d;
+                    acc[0] += fabs(d);
+                    acc[1] = __builtin_fma(d, d, acc[1]);
+                    acc[2] = __builtin_fma(d2, d, acc[2]);
+                    acc[3] = __builtin_fma(d2, d2, acc[3]);
+                    const double d4 = d2 * d2;
+                    acc[4] = __builtin_fma(d4, d, acc[4]);
+                    acc[5] = __builtin_fma(d4, d2, acc[5]);
+                    sx += (x - lox) <= span ? x : 0u;
+                    const uint32_t x2 = x << 1;
+                    sad += x2 > m2x ? x2 - m2x : m2x - x2;
+                }
+                // workgroup totals: the two integer sums through 32-bit DPP wave sums (slots 6, 7 of the exchange area), the six
+                // fp64 sums through the transposed wave sum (slots 0..5); one barrier pair for all eight
+                {
+                    const uint32_t wsx = wave_sum_t<uint32_t>(sx), wsad = wave_sum_t<uint32_t>(sad);
+                    if (lane == 0) {
+                        s_red[wave * 8 + 6] = (double)wsx;
+                        s_red[wave * 8 + 7] = (double)wsad;
+                    }
+                }
+                {
+                    double t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) t[k] = k < 6 ? acc[k] : 0.0;
+                    const double tot = wave_transpose_sum8(t, lane);
+                    if ((lane & 7) == 0 && (lane >> 3) < 6)
+                        s_red[wave * 8 + (lane >> 3)] = tot;
+                }
+                blk_sync<GS>();
+                // every thread needs the in-range sum (sweep 2) and the population of [p10, p90] (read off the cumulative table);
+                // the other totals are read by the one lane that derives the outputs -- no barrier follows: the next exchange
+                // (sweep 2's) goes through its own scratch (the percentile bounds, dead by now)
+                const double Sx = (s_red[6] + s_red[8 + 6]) + (s_red[16 + 6] + s_red[24 + 6]);
+                const uint32_t K = span == 0 && lox == 0x80000000u ? 0u : cum(lox + span) - (lox ? cum(lox - 1) : 0u);
+                const double dK = (double)K;
+                if (tid == 0) {
+                    double a6[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        a6[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                        asm volatile("" : "+v"(a6[k]) :: "memory");   // one total at a time: 28 reads in flight (or their adds sunk into the output code) would spill
+                    }
+                    const double sadt = (s_red[7] + s_red[8 + 7]) + (s_red[16 + 7] + s_red[24 + 7]);
+                    central_outputs(a6);
+                    o[I_ROBUST_MEAN] = K ? (Sx + dK * (double)vmin) / dK : 0.0;   // exact integer sum / count, as the reference's
+                    o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(sadt * 0.5, dn);
+                }
+                // sweep 2: robust MAD about mean1090 = S / K (histogram.h:102-112): sum |a - S/K| = sum |K x - Sx| / K, exact in integers
+                const uint32_t Ku = K, Sxu = (uint32_t)Sx;
+                unsigned long long ad = 0;
+                for (uint32_t i = tid; i < n; i += kBlock) {
+                    const uint32_t x = ((const uint16_t*)s_val)[i];
+                    const uint32_t t = (uint32_t)__umul24(Ku, x);            // < 2^30
+                    const uint32_t dlt = t > Sxu ? t - Sxu : Sxu - t;
+                    ad += (x - lox) <= span ? dlt : 0u;
+                }
+                double ad1[1] = {(double)ad};
+                block_sum<1, GS>(ad1, (double*)s_lb100, tid);
+                if (tid == 0)
+                    o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? fdiv(fdiv(ad1[0], dK), dK) : 0.0;
+            } else {
             // sweep 1: sum and count inside [p10, p90], and the median absolute deviation (it only needs the median)
             double rb[3] = {0, 0, 0};
             for (uint32_t i = tid; i < n; i += kBlock) {
@@ -857,6 +950,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 o[I_ROBUST_MEAN] = mean1090;
                 o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
                 o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(rb[2], dn);
+            }
             }
         }
 
@@ -916,7 +1010,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         const bool too_big = (uint32_t)Ng > A.L.ng_cap;
         if (too_big && tid == 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
-        if (greyInfo >= 0 && !too_big)
+        if (!SPLIT && greyInfo >= 0 && !too_big)
             for (int i = tid; i < Ng; i += kBlock)
                 s_I[i] = (double)(i + 1);
 
@@ -985,10 +1079,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                                 atomicAdd((uint32_t*)(Bq + __umul24(nb4 - 4, (uint32_t)Ng) + c4), 1u);
                         }
                     };
-                    for (int row = r_begin; row < r_end; row++) {
-                        uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
-                        if (remap && nxt4) nxt4 = s_lvlmap[nxt4];   // compact index + 1 (0 stays "skip")
-                        nxt4 <<= 2;
+                    // one row of pairs: `cur4` = this row's levels, `nxt4` = the row below, both as byte offsets (0 = skip)
+                    auto pair_row = [&](uint32_t cur4, uint32_t nxt4) {
                         const uint32_t nb_e = lane_plus1(cur4, 0);   // (row,   col+1)  angle 0
                         const uint32_t nb_se = lane_plus1(nxt4, 0);  // (row+1, col+1)  angle 45
                         const uint32_t nb_sw = lane_minus1(nxt4, 0); // (row+1, col-1)  angle 135
@@ -999,6 +1091,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                             bump(B2, rowb, cur4, nxt4);              // (row+1, col)    angle 90
                             bump(B3, rowb, cur4, nb_sw);
                         }
+                    };
+                    for (int row = r_begin; row < r_end; row++) {
+                        uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                        if (remap && nxt4) nxt4 = s_lvlmap[nxt4];   // compact index + 1 (0 stays "skip")
+                        nxt4 <<= 2;
+                        pair_row(cur4, nxt4);
                         cur4 = nxt4;
                     }
                 } else

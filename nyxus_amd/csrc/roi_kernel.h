@@ -231,22 +231,25 @@ struct ShapeArgs {
     ShapeLayout L;
 };
 
-// ---- device-side ROI assembly for one tile (tile_assembly.hip) -------------------------------
-struct TileTables {      // each [max_label + 1], indexed by label value
-    uint32_t *cnt, *vmin, *vmax, *xmin, *xmax, *ymin, *ymax;
+// ---- device-side ROI assembly for a stack of tiles (tile_assembly.hip) -------------------------
+struct TileHash {        // per-tile open-addressing tables, each [n_tiles * cap]; key = label, 0 = empty slot
+    uint32_t *key, *cnt, *vmin, *vmax, *xmin, *xmax, *ymin, *ymax;
+    uint32_t cap;        // slots per tile (a power of two)
+    uint32_t shift;      // 32 - log2(cap)
 };
-struct TileRows {        // each [max_rows] (+1 for px_offset), ascending label order
-    uint32_t* label;
+struct TileRows {        // one entry per ROI ([max_rows], px_offset [max_rows + 1]); sorted rows: (tile, label) ascending
+    uint32_t *tile, *label, *area;
     uint64_t* px_offset;
     uint32_t *bbox_x0, *bbox_y0, *bbox_w, *bbox_h, *vmin, *vmax;
+    double *slide_min, *slide_max;
 };
-int launch_tile_assembly_scan(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label,
-                              TileTables T, TileRows R, uint32_t max_rows, uint32_t* meta, uint32_t* blk_rows, unsigned long long* blk_px, int* status,
-                              void* stream);
-int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t stride, TileRows R, uint32_t n_roi,
+int launch_tile_assembly_scan(const void* inten, int dt_inten, const void* label, int dt_label, uint32_t W, uint32_t H, uint32_t n_tiles,
+                              TileHash T, TileRows U, TileRows R, uint32_t max_rows, uint32_t* meta, uint32_t* blk_rows, unsigned long long* blk_px,
+                              uint32_t* tile_row_begin, unsigned long long* tile_px_begin, void* stream);
+int launch_tile_rank(TileRows U, const uint32_t* tile_row_begin, const unsigned long long* tile_px_begin, TileRows R, uint32_t max_rows, uint32_t n_tiles,
+                     uint32_t max_rows_per_tile, int slide_mode, const double* smin, const double* smax, void* stream);
+int launch_tile_clouds(const void* inten, int dt_inten, const void* label, int dt_label, uint32_t W, uint32_t H, TileRows R, uint32_t n_roi,
                        uint16_t* cx, uint16_t* cy, uint32_t* cv, void* stream);
-__global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile, double* slide_min,
-                                       double* slide_max);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);

@@ -1,41 +1,39 @@
 // tile_assembly.hip -- phases 1-2 of the in-memory workflow on the device.
 //
-// Replaces, for one intensity/label tile pair resident in HBM:
+// Replaces, for a stack of intensity/label tile pairs resident in HBM:
 //   gatherRoisMetricsInMemory  /root/reference/src/nyx/phase1.cpp:373-409  + feed_pixel_2_metrics
 //                              src/nyx/pixel_feed.cpp:19-43   -> per-label area, min, max, AABB
 //   scanTrivialRoisInMemory    src/nyx/phase2_2d.cpp:637-684  -> per-ROI pixel clouds
-// The reference does both with a serial scan and a hash-map lookup per pixel; here:
-//   tile_scan_kernel     one coalesced pass over the tile in 256 x 32 blocks; per-column label runs are
-//                        accumulated in registers, merged per block in an LDS hash table, and only the
-//                        table's live entries reach the global [max_label+1] tables;
-//   tile_compact_kernel  labels present -> rows in ascending label order (the row order of
-//                        save_features_2_buffer, output_2_buffer.cpp:305-306), CSR offsets by prefix sum;
-//   roi_cloud_kernel     one workgroup per ROI scans its bounding-box window of the tile in row-major
-//                        order and writes the ROI's SoA cloud with a ballot-ranked (deterministic)
-//                        compaction.
-// HBM traffic per tile: 8 B/px read by the scan + the bbox windows (L2-resident re-read) + 8 B per ROI
-// pixel written as clouds.
+// The reference does both with a serial scan and a hash-map lookup per pixel (`unordered_map<int, LR>`, roi_cache.h), so
+// label VALUES are arbitrary 32-bit numbers there.  Here too: nothing is sized by the label magnitude.
+//   tile_scan_kernel     one coalesced pass over the tiles in 256 x 32 blocks; per-column label runs are accumulated in
+//                        registers, merged per block in an LDS hash table, and only that table's live entries reach the
+//                        per-tile open-addressing tables in HBM (key = label, `cap` slots per tile);
+//   tile_compact_kernel  occupied slots -> rows grouped by tile (slot order), per-tile row / pixel bases by prefix sums;
+//   tile_rank_kernel     ascending label order inside every tile (the row order of save_features_2_buffer,
+//                        output_2_buffer.cpp:305-306) by counting: rank = #labels of the tile below mine, CSR offset = pixels of
+//                        those; the tile's prescan extrema (scan_slide_props, slideprops.cpp:456-...) fall out of the same loop;
+//   roi_cloud_kernel     one workgroup per ROI scans its bounding-box window of the tile in row-major order and writes the
+//                        ROI's SoA cloud with a ballot-ranked (deterministic) compaction.
+// Tiles keep the caller's element type (8 / 16 / 32-bit unsigned): the kernels are instantiated per type pair, so H2D and the
+// scan move the image's own bytes.
+// HBM traffic per tile: (sizeof intensity + sizeof label) B/px read by the scan + the bbox windows (L2-resident re-read)
+// + 8 B per ROI pixel written as clouds (only for the families that need clouds: see nyxhip_api.hip).
 #include <hip/hip_runtime.h>
 #include "device_math.h"
 #include "roi_kernel.h"
 
 namespace nyxhip {
 
-__global__ void tile_init_tables_kernel(TileTables T, uint32_t n)
+__global__ void tile_init_tables_kernel(TileHash T, uint64_t n)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i < n) {
-        T.cnt[i] = 0; T.vmin[i] = 0xFFFFFFFFu; T.vmax[i] = 0;
+        T.key[i] = 0; T.cnt[i] = 0; T.vmin[i] = 0xFFFFFFFFu; T.vmax[i] = 0;
         T.xmin[i] = 0xFFFFFFFFu; T.xmax[i] = 0; T.ymin[i] = 0xFFFFFFFFu; T.ymax[i] = 0;
     }
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32_masked(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
-    return v;
-}
 __device__ __forceinline__ uint32_t wave_max_u32_x(uint32_t v)
 {
 #pragma unroll
@@ -43,17 +41,15 @@ __device__ __forceinline__ uint32_t wave_max_u32_x(uint32_t v)
     return v;
 }
 
-// The input may be a stack of n_tiles tiles of H rows each (one tall image); labels are per tile, so the
-// table index is tile * (max_label + 1) + label and coordinates are tile-relative.
-//
 // One workgroup owns a kScanCols x kScanRows block of one tile; a thread walks one column of the block and keeps
 // the statistics of its current label run in registers (ROIs are compact: a column crosses a ROI once).  Runs
-// are merged in an LDS hash table keyed by label, and only the table's few live entries go to the global
-// [n_tiles * (max_label + 1)] tables: ~7 global atomics per (ROI, block) instead of per (ROI, row segment).
+// are merged in an LDS hash table keyed by label, and only the table's few live entries go to the tile's global
+// table: ~7 global atomics per (ROI, block) instead of per (ROI, row segment).
 constexpr int kScanCols = 256, kScanRows = 32, kScanCap = 512, kScanProbes = 32;
 
-__global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const uint32_t* __restrict__ inten, const uint32_t* __restrict__ label,
-                                                              uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label, TileTables T, int* status)
+template <typename TI, typename TL>
+__global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const TI* __restrict__ inten, const TL* __restrict__ label, uint32_t W, uint32_t H,
+                                                              uint32_t n_tiles, TileHash T, uint32_t* meta)
 {
     __shared__ uint32_t s_key[kScanCap], s_cnt[kScanCap], s_vmin[kScanCap], s_vmax[kScanCap], s_xmin[kScanCap], s_xmax[kScanCap],
         s_ymin[kScanCap], s_ymax[kScanCap];
@@ -67,10 +63,27 @@ __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const uint32_t* __
     const uint32_t x = blockIdx.x * kScanCols + tid;
     const uint32_t y_begin = blockIdx.y * kScanRows;
     const uint32_t y_end = y_begin + kScanRows < H ? y_begin + kScanRows : H;
-    const uint32_t tbase = tile * (max_label + 1);
+    const uint64_t tbase = (uint64_t)tile * T.cap;
+    const uint32_t capm = T.cap - 1;
 
+    // one run (or one LDS entry) into the tile's global table: linear probing, the slot is claimed by CAS on the label
+    auto to_global = [&](uint32_t l, uint32_t cnt, uint32_t mn, uint32_t mx, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+        uint32_t h = (l * 2654435761u) >> T.shift;
+        for (uint32_t probe = 0; probe <= capm; probe++) {
+            const uint64_t g = tbase + h;
+            const uint32_t prev = atomicCAS(&T.key[g], 0u, l);
+            if (prev == 0u || prev == l) {
+                atomicAdd(&T.cnt[g], cnt);
+                atomicMin(&T.vmin[g], mn); atomicMax(&T.vmax[g], mx);
+                atomicMin(&T.xmin[g], x0); atomicMax(&T.xmax[g], x1);
+                atomicMin(&T.ymin[g], y0); atomicMax(&T.ymax[g], y1);
+                return;
+            }
+            h = (h + 1) & capm;
+        }
+        atomicMax(&meta[7], 1u);                         // the tile holds more labels than its table has slots: the host retries with a larger one
+    };
     auto flush = [&](uint32_t l, uint32_t cnt, uint32_t mn, uint32_t mx, uint32_t y0, uint32_t y1) {
-        if (l > max_label) { atomicCAS(status, 0, 1 /* NYXHIP_ERR_INVALID_ARG */); return; }
         uint32_t h = (l * 2654435761u) >> 23;            // 9 bits
         for (int probe = 0; probe < kScanProbes; probe++) {
             const uint32_t prev = atomicCAS(&s_key[h], 0u, l);
@@ -83,11 +96,7 @@ __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const uint32_t* __
             }
             h = (h + 1) & (kScanCap - 1);
         }
-        const uint32_t g = tbase + l;                    // table crowded (label confetti): straight to the global tables
-        atomicAdd(&T.cnt[g], cnt);
-        atomicMin(&T.vmin[g], mn); atomicMax(&T.vmax[g], mx);
-        atomicMin(&T.xmin[g], x); atomicMax(&T.xmax[g], x);
-        atomicMin(&T.ymin[g], y0); atomicMax(&T.ymax[g], y1);
+        to_global(l, cnt, mn, mx, x, x, y0, y1);         // block table crowded (label confetti): straight to the global table
     };
 
     if (x < W) {
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const uint32_t* __
             for (int k = 0; k < 8; k++) {                // all loads of the batch in flight before first use
                 const uint32_t y = yb + k;
                 const bool in = y < y_end;
-                l[k] = in ? label[col + (uint64_t)y * W] : 0u;
-                v[k] = in ? inten[col + (uint64_t)y * W] : 0u;
+                l[k] = in ? (uint32_t)label[col + (uint64_t)y * W] : 0u;
+                v[k] = in ? (uint32_t)inten[col + (uint64_t)y * W] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -118,26 +127,23 @@ __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const uint32_t* __
     for (int i = tid; i < kScanCap; i += kScanCols) {
         const uint32_t l = s_key[i];
         if (l == 0) continue;
-        const uint32_t g = tbase + l;
-        atomicAdd(&T.cnt[g], s_cnt[i]);
-        atomicMin(&T.vmin[g], s_vmin[i]); atomicMax(&T.vmax[g], s_vmax[i]);
-        atomicMin(&T.xmin[g], s_xmin[i]); atomicMax(&T.xmax[g], s_xmax[i]);
-        atomicMin(&T.ymin[g], s_ymin[i]); atomicMax(&T.ymax[g], s_ymax[i]);
+        to_global(l, s_cnt[i], s_vmin[i], s_vmax[i], s_xmin[i], s_xmax[i], s_ymin[i], s_ymax[i]);
     }
 }
 
-// Labels present -> rows in ascending (tile, label) order; rows' CSR offsets.  Two launches over 1024-entry
-// blocks of the tables: per-block (row count, pixel count), then every block sums its predecessors' partials
-// (a few hundred values) and places its own rows.
-// meta[0] = n_roi, meta[1..2] = total pixels (lo, hi), meta[3] = max area, meta[4] = max bbox area,
-// meta[5] = max range, meta[6] = max side, meta[7] = scan status.
-__global__ __launch_bounds__(1024) void tile_block_sums_kernel(TileTables T, uint32_t n_entries, uint32_t* blk_rows, unsigned long long* blk_px)
+// Occupied slots -> rows grouped by tile (slot order inside a tile), the tiles' row / pixel bases.  Two launches over
+// 1024-entry blocks of the tables: per-block (row count, pixel count), then every block sums its predecessors' partials and
+// places its own rows.
+// meta[0] = n_roi, meta[1..2] = total pixels (lo, hi), meta[3] = max area, meta[4] = max bbox area, meta[5] = max range,
+// meta[6] = max side, meta[7] = status (1 = a tile's table overflowed, 2 = a bounding box wider / taller than 65535),
+// meta[8] = largest label value present.
+__global__ __launch_bounds__(1024) void tile_block_sums_kernel(TileHash T, uint64_t n_entries, uint32_t* blk_rows, unsigned long long* blk_px)
 {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t l = blockIdx.x * 1024u + tid;
-    const uint32_t cnt = (l >= 1 && l < n_entries) ? T.cnt[l] : 0;
+    const uint64_t e = blockIdx.x * 1024ull + tid;
+    const uint32_t cnt = (e < n_entries && T.key[e] != 0) ? T.cnt[e] : 0;
     const uint32_t rows = (uint32_t)__popcll(__ballot(cnt != 0));
     const unsigned long long px = wave_sum_u64(cnt);
     if (lane == 0) { s_w[wave] = rows; s_wpx[wave] = px; }
@@ -149,8 +155,9 @@ __global__ __launch_bounds__(1024) void tile_block_sums_kernel(TileTables T, uin
     }
 }
 
-__global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32_t n_entries, TileRows R, uint32_t max_rows, uint32_t* meta,
-                                                            const uint32_t* blk_rows, const unsigned long long* blk_px, const int* status)
+__global__ __launch_bounds__(1024) void tile_compact_kernel(TileHash T, uint64_t n_entries, uint32_t n_tiles, TileRows U, uint32_t max_rows, uint32_t* meta,
+                                                            const uint32_t* blk_rows, const unsigned long long* blk_px, uint32_t* tile_row_begin,
+                                                            unsigned long long* tile_px_begin)
 {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
@@ -165,8 +172,9 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32
     for (int w = 0; w < 16; w++) { base_r += s_w[w]; base_p += s_wpx[w]; }
     __syncthreads();
 
-    const uint32_t l = blockIdx.x * 1024u + tid;
-    const uint32_t cnt = (l >= 1 && l < n_entries) ? T.cnt[l] : 0;
+    const uint64_t e = blockIdx.x * 1024ull + tid;
+    const bool in = e < n_entries;
+    const uint32_t cnt = (in && T.key[e] != 0) ? T.cnt[e] : 0;
     const bool present = cnt != 0;
     const unsigned long long bal = __ballot(present);
     const uint32_t rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -179,27 +187,90 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileTables T, uint32
     for (int w2 = 0; w2 < wave; w2++) { wbase += s_w[w2]; wpx += s_wpx[w2]; }
     const uint32_t row = base_r + wbase + rank_in_wave;
     const unsigned long long off = base_p + wpx + pxs - cnt;
-    uint32_t mx_area = 0, mx_box = 0, mx_rng = 0, mx_side = 0;
+    if (in && (e & (T.cap - 1)) == 0) {                 // first slot of a tile: its rows / pixels start here
+        const uint32_t t = (uint32_t)(e / T.cap);
+        tile_row_begin[t] = row; tile_px_begin[t] = off;
+    }
+    uint32_t mx_area = 0, mx_box = 0, mx_rng = 0, mx_side = 0, mx_lab = 0;
     if (present && row < max_rows) {
-        const uint32_t w = T.xmax[l] - T.xmin[l] + 1, h = T.ymax[l] - T.ymin[l] + 1;
-        R.label[row] = l; R.px_offset[row] = off;
-        R.bbox_x0[row] = T.xmin[l]; R.bbox_y0[row] = T.ymin[l]; R.bbox_w[row] = w; R.bbox_h[row] = h;
-        R.vmin[row] = T.vmin[l]; R.vmax[row] = T.vmax[l];
-        mx_area = cnt; mx_box = w * h; mx_rng = T.vmax[l] - T.vmin[l]; mx_side = w > h ? w : h;
+        const uint32_t w = T.xmax[e] - T.xmin[e] + 1, h = T.ymax[e] - T.ymin[e] + 1;
+        U.tile[row] = (uint32_t)(e / T.cap); U.label[row] = T.key[e]; U.area[row] = cnt;
+        U.bbox_x0[row] = T.xmin[e]; U.bbox_y0[row] = T.ymin[e]; U.bbox_w[row] = w; U.bbox_h[row] = h;
+        U.vmin[row] = T.vmin[e]; U.vmax[row] = T.vmax[e];
+        const unsigned long long box = (unsigned long long)w * h;
+        mx_area = cnt; mx_box = box > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)box; mx_rng = T.vmax[e] - T.vmin[e]; mx_side = w > h ? w : h;
+        mx_lab = T.key[e];
     }
     mx_area = wave_max_u32_x(mx_area); mx_box = wave_max_u32_x(mx_box); mx_rng = wave_max_u32_x(mx_rng); mx_side = wave_max_u32_x(mx_side);
-    if (lane == 0 && bal) { atomicMax(&meta[3], mx_area); atomicMax(&meta[4], mx_box); atomicMax(&meta[5], mx_rng); atomicMax(&meta[6], mx_side); }
+    mx_lab = wave_max_u32_x(mx_lab);
+    if (lane == 0 && bal) {
+        atomicMax(&meta[3], mx_area); atomicMax(&meta[4], mx_box); atomicMax(&meta[5], mx_rng); atomicMax(&meta[6], mx_side); atomicMax(&meta[8], mx_lab);
+        if (mx_side > 65535u) atomicMax(&meta[7], 2u);  // coordinates inside a bounding box are 16-bit
+    }
     if (blockIdx.x == gridDim.x - 1 && tid == 1023) {   // last thread of the last block knows the totals
         const uint32_t n_roi = row + (present ? 1u : 0u);
         const unsigned long long tot = off + cnt;
-        meta[0] = n_roi; meta[1] = (uint32_t)tot; meta[2] = (uint32_t)(tot >> 32); meta[7] = (uint32_t)*status;
-        if (n_roi <= max_rows) R.px_offset[n_roi] = tot;
+        meta[0] = n_roi; meta[1] = (uint32_t)tot; meta[2] = (uint32_t)(tot >> 32);
+        tile_row_begin[n_tiles] = n_roi; tile_px_begin[n_tiles] = tot;
     }
 }
 
+// Rows of one tile, slot order -> ascending label order, by counting (a tile of the benchmark holds ~200 ROIs: one 256-thread
+// block and 200 LDS broadcast reads per thread; a slide with 10^5 ROIs spreads over grid.y blocks of 256 rows each).
+// slide_mode: 0 = montage semantics of the in-memory API (slide min / max stay at +/- DBL_MAX, slideprops.cpp:27-28,74-75, so
+// COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0); 1 = one tile is one slide: min / max over the intensities under any mask
+// (scan_slide_props, slideprops.cpp:456-...) = extrema over the tile's ROIs; 2 = given per tile by the caller.
+__global__ __launch_bounds__(256) void tile_rank_kernel(TileRows U, const uint32_t* __restrict__ tile_row_begin,
+                                                        const unsigned long long* __restrict__ tile_px_begin, TileRows R, uint32_t max_rows,
+                                                        int slide_mode, const double* __restrict__ smin_in, const double* __restrict__ smax_in)
+{
+    __shared__ uint32_t s_l[256], s_c[256], s_mn[256], s_mx[256];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t b = tile_row_begin[tile], e = tile_row_begin[tile + 1];
+    const uint32_t n_t = (e > max_rows ? max_rows : e) - (b > max_rows ? max_rows : b);
+    if (blockIdx.y * 256u >= n_t)
+        return;
+    const uint32_t i = blockIdx.y * 256u + tid;
+    const bool mine = i < n_t;
+    const uint32_t my_l = mine ? U.label[b + i] : 0xFFFFFFFFu;
+    uint32_t rank = 0, mn = 0xFFFFFFFFu, mx = 0;
+    unsigned long long off = 0;
+    for (uint32_t j0 = 0; j0 < n_t; j0 += 256) {
+        __syncthreads();
+        const bool has = j0 + tid < n_t;
+        s_l[tid] = has ? U.label[b + j0 + tid] : 0xFFFFFFFFu;
+        s_c[tid] = has ? U.area[b + j0 + tid] : 0u;
+        s_mn[tid] = has ? U.vmin[b + j0 + tid] : 0xFFFFFFFFu;
+        s_mx[tid] = has ? U.vmax[b + j0 + tid] : 0u;
+        __syncthreads();
+        const uint32_t m = n_t - j0 < 256u ? n_t - j0 : 256u;
+        for (uint32_t j = 0; j < m; j++) {
+            const bool lt = s_l[j] < my_l;
+            rank += lt ? 1u : 0u;
+            off += lt ? s_c[j] : 0u;
+            mn = s_mn[j] < mn ? s_mn[j] : mn;
+            mx = s_mx[j] > mx ? s_mx[j] : mx;
+        }
+    }
+    if (!mine)
+        return;
+    const uint32_t src = b + i, row = b + rank;
+    R.tile[row] = tile; R.label[row] = my_l; R.area[row] = U.area[src];
+    R.px_offset[row] = tile_px_begin[tile] + off;
+    R.bbox_x0[row] = U.bbox_x0[src]; R.bbox_y0[row] = U.bbox_y0[src]; R.bbox_w[row] = U.bbox_w[src]; R.bbox_h[row] = U.bbox_h[src];
+    R.vmin[row] = U.vmin[src]; R.vmax[row] = U.vmax[src];
+    const double DBL_MAX_ = 1.7976931348623157e308;
+    R.slide_min[row] = slide_mode == 0 ? DBL_MAX_ : slide_mode == 1 ? (double)mn : smin_in[tile];
+    R.slide_max[row] = slide_mode == 0 ? -DBL_MAX_ : slide_mode == 1 ? (double)mx : smax_in[tile];
+    if (row + 1 == tile_row_begin[gridDim.x])           // last row of the stack closes the CSR offsets
+        R.px_offset[row + 1] = tile_px_begin[gridDim.x];
+}
+
 // One workgroup per ROI: bbox window of the tile -> SoA cloud in row-major order (deterministic).
-__global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restrict__ inten, const uint32_t* __restrict__ label, uint32_t W,
-                                                        uint32_t H, uint32_t stride, TileRows R, uint16_t* cx, uint16_t* cy, uint32_t* cv)
+template <typename TI, typename TL>
+__global__ __launch_bounds__(256) void roi_cloud_kernel(const TI* __restrict__ inten, const TL* __restrict__ label, uint32_t W, uint32_t H, TileRows R,
+                                                        uint16_t* cx, uint16_t* cy, uint32_t* cv)
 {
     // Four 256-pixel chunks of the window per trip: every label / intensity load of a trip is issued before the first
     // ballot (the intensity unconditionally -- one HBM round trip per trip instead of two per chunk), and one barrier
@@ -208,32 +279,34 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
     __shared__ uint32_t s_cnt[U * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t row = blockIdx.x;
-    // R.label holds the table index tile * stride + label; y0 is tile-relative
-    const uint32_t key = R.label[row], tile = key / stride, L = key - tile * stride;
-    const uint32_t x0 = R.bbox_x0[row], y0 = R.bbox_y0[row] + tile * H, w = R.bbox_w[row], h = R.bbox_h[row];
-    const uint32_t area = w * h;
+    const uint32_t tile = R.tile[row], L = R.label[row];
+    const uint32_t x0 = R.bbox_x0[row], w = R.bbox_w[row], h = R.bbox_h[row];
+    const uint64_t y0 = R.bbox_y0[row] + (uint64_t)tile * H;            // y0 is tile-relative
+    const uint64_t area = (uint64_t)w * h;
     unsigned long long out = R.px_offset[row];
     const uint32_t step_y = 256u / w, step_x = 256u - step_y * w;     // 256 pixels further along the window
     uint32_t by = (uint32_t)tid / w, bx = (uint32_t)tid - by * w;
-    const uint32_t* const lab_base = label + (uint64_t)y0 * W + x0;
-    const uint32_t* const int_base = inten + (uint64_t)y0 * W + x0;
-    for (uint32_t p0 = 0; p0 < area; p0 += 256 * U) {
+    const TL* const lab_base = label + y0 * W + x0;
+    const TI* const int_base = inten + y0 * W + x0;
+    for (uint64_t p0 = 0; p0 < area; p0 += 256 * U) {
         uint32_t lb[U], v[U], xs[U], ys[U];
+        bool hit[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t p = p0 + (uint32_t)u * 256u + (uint32_t)tid;
+            const uint64_t p = p0 + (uint32_t)u * 256u + (uint32_t)tid;
             xs[u] = bx; ys[u] = by;
             const uint64_t g = (uint64_t)by * W + bx;
             const bool ok = p < area;
-            lb[u] = ok ? lab_base[g] : ~L;
-            v[u] = ok ? int_base[g] : 0u;
+            lb[u] = ok ? (uint32_t)lab_base[g] : 0u;                   // 0 is never a ROI label
+            v[u] = ok ? (uint32_t)int_base[g] : 0u;
             bx += step_x; by += step_y;
             if (bx >= w) { bx -= w; by++; }
         }
         unsigned long long bal[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            bal[u] = __ballot(lb[u] == L);
+            hit[u] = lb[u] == L;
+            bal[u] = __ballot(hit[u]);
             if (lane == 0) s_cnt[u * 4 + wave] = (uint32_t)__popcll(bal[u]);
         }
         __syncthreads();
@@ -242,7 +315,7 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
         for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int w2 = 0; w2 < 4; w2++) {
-                if (w2 == wave && lb[u] == L) {
+                if (w2 == wave && hit[u]) {
                     const unsigned long long o = out + run + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
                     cx[o] = (uint16_t)xs[u]; cy[o] = (uint16_t)ys[u]; cv[o] = v[u];
                 }
@@ -254,43 +327,69 @@ __global__ __launch_bounds__(256) void roi_cloud_kernel(const uint32_t* __restri
     }
 }
 
-// table key -> (label, tile index) for the caller; also the per-ROI slide extrema of the in-memory (montage)
-// path: its prescan leaves slide min / max at +DBL_MAX / -DBL_MAX (slideprops.cpp:27-28,74-75), so
-// COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
-__global__ void tile_split_keys_kernel(const uint32_t* key, uint32_t stride, uint32_t n, uint32_t* out_label, uint32_t* out_tile, double* slide_min,
-                                       double* slide_max)
+namespace {
+// element-type dispatch: dt = 1 / 2 / 4 bytes per element
+template <typename F>
+int with_types(int dt_inten, int dt_label, F&& f)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        uint32_t k = key[i], t = k / stride;
-        out_label[i] = k - t * stride;
-        if (out_tile) out_tile[i] = t;
-        slide_min[i] = 1.7976931348623157e308;
-        slide_max[i] = -1.7976931348623157e308;
+#define NYX_TL(TI)                                                                  \
+    switch (dt_label) {                                                             \
+    case 1: return f((const TI*)nullptr, (const uint8_t*)nullptr);                  \
+    case 2: return f((const TI*)nullptr, (const uint16_t*)nullptr);                 \
+    case 4: return f((const TI*)nullptr, (const uint32_t*)nullptr);                 \
+    default: return (int)hipErrorInvalidValue;                                      \
     }
+    switch (dt_inten) {
+    case 1: NYX_TL(uint8_t)
+    case 2: NYX_TL(uint16_t)
+    case 4: NYX_TL(uint32_t)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef NYX_TL
 }
+} // namespace
 
-int launch_tile_assembly_scan(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t max_label,
-                              TileTables T, TileRows R, uint32_t max_rows, uint32_t* meta, uint32_t* blk_rows, unsigned long long* blk_px, int* status,
-                              void* stream)
+int launch_tile_assembly_scan(const void* inten, int dt_inten, const void* label, int dt_label, uint32_t W, uint32_t H, uint32_t n_tiles,
+                              TileHash T, TileRows U, TileRows R, uint32_t max_rows, uint32_t* meta, uint32_t* blk_rows, unsigned long long* blk_px,
+                              uint32_t* tile_row_begin, unsigned long long* tile_px_begin, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t n = (max_label + 1) * n_tiles;
-    hipLaunchKernelGGL(tile_init_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T, n);
+    const uint64_t n = (uint64_t)T.cap * n_tiles;
+    hipLaunchKernelGGL(tile_init_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, T, n);
     const dim3 grid((W + kScanCols - 1) / kScanCols, (H + kScanRows - 1) / kScanRows, n_tiles);
-    hipLaunchKernelGGL(tile_scan_kernel, grid, dim3(kScanCols), 0, st, inten, label, W, H, n_tiles, max_label, T, status);
-    const unsigned nb = (n + 1023) / 1024;
+    int rc = with_types(dt_inten, dt_label, [&](auto* ti, auto* tl) -> int {
+        using TI = std::remove_const_t<std::remove_pointer_t<decltype(ti)>>;
+        using TL = std::remove_const_t<std::remove_pointer_t<decltype(tl)>>;
+        hipLaunchKernelGGL((tile_scan_kernel<TI, TL>), grid, dim3(kScanCols), 0, st, (const TI*)inten, (const TL*)label, W, H, n_tiles, T, meta);
+        return 0;
+    });
+    if (rc) return rc;
+    const unsigned nb = (unsigned)((n + 1023) / 1024);
     hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(1024), 0, st, T, n, blk_rows, blk_px);
-    hipLaunchKernelGGL(tile_compact_kernel, dim3(nb), dim3(1024), 0, st, T, n, R, max_rows, meta, blk_rows, blk_px, status);
+    hipLaunchKernelGGL(tile_compact_kernel, dim3(nb), dim3(1024), 0, st, T, n, n_tiles, U, max_rows, meta, blk_rows, blk_px, tile_row_begin, tile_px_begin);
     return (int)hipGetLastError();
 }
 
-int launch_tile_clouds(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t stride, TileRows R, uint32_t n_roi,
+int launch_tile_rank(TileRows U, const uint32_t* tile_row_begin, const unsigned long long* tile_px_begin, TileRows R, uint32_t max_rows, uint32_t n_tiles,
+                     uint32_t max_rows_per_tile, int slide_mode, const double* smin, const double* smax, void* stream)
+{
+    const unsigned gy = (max_rows_per_tile + 255) / 256;
+    hipLaunchKernelGGL(tile_rank_kernel, dim3(n_tiles, gy ? gy : 1), dim3(256), 0, (hipStream_t)stream, U, tile_row_begin, tile_px_begin, R, max_rows,
+                       slide_mode, smin, smax);
+    return (int)hipGetLastError();
+}
+
+int launch_tile_clouds(const void* inten, int dt_inten, const void* label, int dt_label, uint32_t W, uint32_t H, TileRows R, uint32_t n_roi,
                        uint16_t* cx, uint16_t* cy, uint32_t* cv, void* stream)
 {
     if (n_roi == 0) return 0;
-    hipLaunchKernelGGL(roi_cloud_kernel, dim3(n_roi), dim3(256), 0, (hipStream_t)stream, inten, label, W, H, stride, R, cx, cy, cv);
-    return (int)hipGetLastError();
+    int rc = with_types(dt_inten, dt_label, [&](auto* ti, auto* tl) -> int {
+        using TI = std::remove_const_t<std::remove_pointer_t<decltype(ti)>>;
+        using TL = std::remove_const_t<std::remove_pointer_t<decltype(tl)>>;
+        hipLaunchKernelGGL((roi_cloud_kernel<TI, TL>), dim3(n_roi), dim3(256), 0, (hipStream_t)stream, (const TI*)inten, (const TL*)label, W, H, R, cx, cy, cv);
+        return 0;
+    });
+    return rc ? rc : (int)hipGetLastError();
 }
 
 } // namespace nyxhip

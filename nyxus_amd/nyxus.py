@@ -3,8 +3,7 @@
 Mirrors `class Nyxus` of /root/reference/src/nyx/python/nyxus/nyxus.py: constructor keyword whitelist and
 checks (:162-246), `featurize` (:385-519: argument validation, 2-D -> 3-D promotion, default names, the
 negative-intensity shift and uint32 casts, DataFrame layout), `featurize_directory` (:303-382).
-The feature reduce itself is `nyxhip_featurize_batch` (include/nyxhip.h); ROI assembly is
-`roi_assembly.assemble`.  Features outside the hot-path families raise ValueError -- there is no CPU path.
+Label scan, ROI assembly and the feature reduce all run on the device (`nyxhip_featurize_tiles_v2`, include/nyxhip.h).  Features outside the hot-path families raise ValueError -- there is no CPU path.
 """
 from __future__ import annotations
 
@@ -17,13 +16,14 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _abi, _lib, featureset, roi_assembly
+from . import _abi, _lib, featureset
 
 _VALID_KEYS = {
     "neighbor_distance", "pixels_per_micron", "coarse_gray_depth", "n_feature_calc_threads", "use_gpu_device", "ibsi",
     "gabor_kersize", "gabor_gamma", "gabor_sig2lam", "gabor_f0", "gabor_thold", "gabor_thetas", "gabor_freqs",
     "channel_signature", "parent_channel", "child_channel", "aggregate", "dynamic_range", "min_intensity",
-    "max_intensity", "ram_limit", "verbose", "anisotropy_x", "anisotropy_y", "mergerois", "preserve_hu"}
+    "max_intensity", "ram_limit", "verbose", "anisotropy_x", "anisotropy_y", "mergerois", "preserve_hu",
+    "gpu_devices"}     # gpu_devices: this package's one addition -- several GPUs of the node share a featurize() call
 
 _DBL_MAX = sys.float_info.max
 
@@ -73,7 +73,14 @@ class Nyxus:
             thold=kwargs.get("gabor_thold", 0.025), thetas=kwargs.get("gabor_thetas", [0, 45, 90, 135]),
             freqs=kwargs.get("gabor_freqs", [4, 16, 32, 64]))
         self._device = max(int(use_gpu_device), 0)   # the GPU is the only compute path of this package
+        # Multi-GPU: `gpu_devices=[0, 1, ...]` block-partitions the image stack of a featurize() call over one context per listed
+        # device (nyxhip_featurize_tiles_sharded; ROIs are independent -- the reference slices its label vector the same way,
+        # parallel.h:34-41); rows come back in (image, label) order whatever the device count.
+        self._devices = [int(d) for d in kwargs.get("gpu_devices", [])] or None
+        if self._devices:
+            self._device = self._devices[0]
         self._ctx: Optional[_lib.Context] = None
+        self._extra_ctx: List[_lib.Context] = []
         self._valid_output_types = ["pandas", "arrowipc", "parquet"]
         self.error_message = ""
 
@@ -110,23 +117,28 @@ class Nyxus:
     def _context(self) -> _lib.Context:
         if self._ctx is None:
             self._ctx = _lib.Context(self._device)    # raises without a GPU / library: no CPU fallback
+            self._extra_ctx = [_lib.Context(d) for d in (self._devices or [])[1:]]
         return self._ctx
+
+    def _device_budget(self) -> int:
+        """`ram_limit` (megabytes, reference nyxus.py:148; the reference batches ROIs by it, phase2_2d.cpp:694-705) bounds the
+        device workspace of a call; unset (-1) lets the library take half of the free device memory."""
+        rl = self._env.get("ram_limit", -1)
+        return int(rl) << 20 if rl is not None and rl > 0 else 0
+
+    def _featurize_stack(self, I: np.ndarray, M: np.ndarray, slide_mode: int):
+        ctx = self._context()
+        tiles, labels, table = ctx.featurize_tiles_host(I, M, self._mask, self._settings, slide_mode=slide_mode,
+                                                        max_device_bytes=self._device_budget(), contexts=self._extra_ctx)
+        _lib.load().nyxhip_finalize_table(table.ctypes.data, table.shape[0], table.shape[1], table.shape[1],
+                                          C.c_double(self._settings.soft_nan))
+        return tiles, labels, table
 
     def _columns(self):
         names = _lib.column_names(self._mask, self._settings)
         angles = [self._settings.glcm_angles[i] for i in range(self._settings.glcm_n_angles)]
         sel = featureset.column_selector(self._requested, names, angles)
         return [names[i] for i in sel], sel
-
-    def _featurize_pair(self, inten: np.ndarray, label: np.ndarray, slide_min, slide_max):
-        batch = roi_assembly.assemble(inten, label, slide_min, slide_max)
-        if batch is None:
-            return np.zeros((0,), np.uint32), np.zeros((0, 0))
-        table = self._context().featurize_host(batch, self._mask, self._settings)
-        # NaN / inf -> noval (force_finite_number, helpers.h:376-382; save_features_2_buffer applies it per value)
-        _lib.load().nyxhip_finalize_table(table.ctypes.data, table.shape[0], table.shape[1], table.shape[1],
-                                          C.c_double(self._settings.soft_nan))
-        return batch.roi_label, table
 
     def featurize(self, intensity_images: np.ndarray, label_images: np.ndarray, intensity_names: list = [],
                   label_names: list = [], output_type: Optional[str] = "pandas", output_path: Optional[str] = ""):
@@ -164,23 +176,22 @@ class Nyxus:
         # Hounsfield-style input: shift to non-negative, then the unsigned casts (nyxus.py:480-489)
         # (an unsigned array has no negative minimum to look for, and uint32 input is handed over without a copy: at the
         # device rates of this path every avoidable host pass over the images shows)
+        # uint8 / uint16 / uint32 images are handed over as they are -- the kernels widen, H2D carries the image's own bytes
         I = intensity_images
         if not np.issubdtype(I.dtype, np.unsignedinteger):
             min_raw = np.min(I)
             if min_raw < 0:
                 I = I - min_raw
-        if I.dtype != np.uint32:
+        if I.dtype not in (np.uint8, np.uint16, np.uint32):
             I = I.astype(np.uint32)
-        M = label_images if label_images.dtype == np.uint32 else label_images.astype(np.uint32)
+        M = label_images if label_images.dtype in (np.uint8, np.uint16, np.uint32) else label_images.astype(np.uint32)
 
         cols, sel = self._columns()
         # All images of the stack go through the fused device path in one call: label scan, ROI assembly and the
-        # reduce run on the GPU (nyxhip_featurize_tiles).  The montage prescan of the reference leaves slide
-        # min/max at +/-DBL_MAX (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE = range / -inf = -0.0
-        # in this entry point; the tile ABI implements exactly that.
-        tiles, labels, table = self._context().featurize_tiles_host(I, M, self._mask, self._settings)
-        _lib.load().nyxhip_finalize_table(table.ctypes.data, table.shape[0], table.shape[1], table.shape[1],
-                                          C.c_double(self._settings.soft_nan))
+        # reduce run on the GPU (nyxhip_featurize_tiles_v2), in chunks that fit the device budget.  The montage prescan of
+        # the reference leaves slide min/max at +/-DBL_MAX (slideprops.cpp:27-28,74-75), so COVERED_IMAGE_INTENSITY_RANGE
+        # = range / -inf = -0.0 in this entry point: NYXHIP_SLIDE_MONTAGE.
+        tiles, labels, table = self._featurize_stack(I, M, _abi.SLIDE_MONTAGE)
         # [intensity_image, mask_image, ROI_label (uint32), t_index, features...]: the feature block is wrapped as it is, the
         # four leading columns are inserted in front of it (no per-row Python work, no float round trip of the labels)
         ti = np.asarray(tiles, dtype=np.intp)
@@ -209,29 +220,65 @@ class Nyxus:
         return self._featurize_file_pairs([os.path.join(intensity_dir, f) for f in files], [os.path.join(label_dir, f) for f in files])
 
     def _featurize_file_pairs(self, intensity_files: list, mask_files: list):
+        """File pairs through the device front end: every slide is one tile of a NYXHIP_SLIDE_PER_TILE call, i.e. the label scan,
+        the slide prescan (min / max of the intensities under any mask: scan_slide_props, slideprops.cpp:456-...), ROI assembly
+        and the reduce all run on the GPU; consecutive slides of equal shape and element type share a call."""
         import pandas as pd
         from . import tiff_ingest
         cols, sel = self._columns()
-        str_rows, num_rows = [], []
+        blocks, names_i, names_m, lab_all = [], [], [], []
+
+        def flush(stack_i, stack_m, fis, fms):
+            if not stack_i:
+                return
+            tiles, labels, table = self._featurize_stack(np.stack(stack_i), np.stack(stack_m), _abi.SLIDE_PER_TILE)
+            ti = np.asarray(tiles, dtype=np.intp)
+            blocks.append(table[:, sel])
+            lab_all.append(np.asarray(labels, dtype=np.uint32))
+            names_i.append(np.asarray([os.path.basename(f) for f in fis], dtype=object)[ti])
+            names_m.append(np.asarray([os.path.basename(f) for f in fms], dtype=object)[ti])
+
+        si, sm, fis, fms = [], [], [], []
         for fi, fm in zip(intensity_files, mask_files):
             I = tiff_ingest.read_tiff(fi)
-            M = tiff_ingest.read_tiff(fm).astype(np.uint32)
+            M = tiff_ingest.read_tiff(fm)
             if I.shape != M.shape:
                 raise ValueError(f"{fi}: intensity and mask images differ in shape")
-            # slide prescan: min/max of the intensities under any mask (scan_slide_props, slideprops.cpp:456-...)
-            fg = I[M != 0]
-            smin, smax = (float(fg.min()), float(fg.max())) if fg.size else (0.0, 0.0)
-            labels, table = self._featurize_pair(I.astype(np.uint32), M, smin, smax)
-            for r in range(len(labels)):
-                str_rows.append([os.path.basename(fi), os.path.basename(fm)])
-                num_rows.append(np.concatenate(([float(labels[r]), 0.0], table[r, sel])))
-        header = ["intensity_image", "mask_image", "ROI_label", "t_index"] + cols
-        string_data = np.array(str_rows, dtype=object).reshape(-1, 2)
-        numeric_data = np.array(num_rows, dtype=np.float64).reshape(-1, 2 + len(cols))
-        df = pd.concat([pd.DataFrame(string_data, columns=header[:2]), pd.DataFrame(numeric_data, columns=header[2:])], axis=1)
-        if "ROI_label" in df.columns:
-            df.ROI_label = df.ROI_label.astype(np.uint32)
+            if I.dtype not in (np.uint8, np.uint16, np.uint32):
+                I = I.astype(np.uint32)
+            if M.dtype not in (np.uint8, np.uint16, np.uint32):
+                M = M.astype(np.uint32)
+            if si and (I.shape != si[0].shape or I.dtype != si[0].dtype or M.dtype != sm[0].dtype or len(si) * I.nbytes > (1 << 30)):
+                flush(si, sm, fis, fms)
+                si, sm, fis, fms = [], [], [], []
+            si.append(I); sm.append(M); fis.append(fi); fms.append(fm)
+        flush(si, sm, fis, fms)
+        n = sum(len(l) for l in lab_all)
+        df = pd.DataFrame(np.concatenate(blocks) if blocks else np.zeros((0, len(cols))), columns=cols)
+        df.insert(0, "t_index", np.zeros(n))
+        df.insert(0, "ROI_label", np.concatenate(lab_all) if lab_all else np.zeros(0, np.uint32))
+        df.insert(0, "mask_image", np.concatenate(names_m) if names_m else np.empty(0, dtype=object))
+        df.insert(0, "intensity_image", np.concatenate(names_i) if names_i else np.empty(0, dtype=object))
         return df
+
+    @staticmethod
+    def to_csv(df, path: str) -> None:
+        """Writes a feature DataFrame in the format of the reference's CSV writer (save_features_2_csv,
+        /root/reference/src/nyx/output_2_csv.cpp:420-755): a header of double-quoted column names (:470-484); per ROI the two
+        file names double-quoted (std::filesystem::path streams quoted, :563), ROI label and time index as integers (:573) and
+        every feature value through printf("%g") (:430, :595) -- NaN / inf were already replaced by the table writer."""
+        cols = list(df.columns)
+        str_cols = [c for c in ("intensity_image", "mask_image") if c in cols]
+        int_cols = [c for c in ("ROI_label", "t_index") if c in cols]
+        val_cols = [c for c in cols if c not in str_cols and c not in int_cols]
+        with open(path, "w", buffering=32768) as fh:
+            fh.write(",".join('"%s"' % c for c in cols) + "\n")
+            S = df[str_cols].values
+            Iv = df[int_cols].values.astype(np.int64)
+            V = df[val_cols].values.astype(np.float64)
+            for r in range(len(df)):
+                parts = ['"%s"' % v for v in S[r]] + ["%d" % v for v in Iv[r]] + ["%g" % v for v in V[r]]
+                fh.write(",".join(parts) + "\n")
 
     def featurize_files(self, intensity_files: list, mask_files: list, single_roi: bool, output_type: Optional[str] = "pandas",
                         output_path: Optional[str] = ""):

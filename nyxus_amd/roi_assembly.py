@@ -40,6 +40,8 @@ def assemble(inten: np.ndarray, label: np.ndarray, slide_min=None, slide_max=Non
     vmin = np.minimum.reduceat(vals, start)
     vmax = np.maximum.reduceat(vals, start)
     counts = np.diff(bounds)
+    if np.any(xmax - xmin > 65535) or np.any(ymax - ymin > 65535):
+        raise ValueError("an ROI's bounding box is wider or taller than 65536 pixels: coordinates inside a box are 16-bit (NYXHIP_ERR_ROI_TOO_LARGE)")
     rel_x = (xs - np.repeat(xmin, counts)).astype(np.uint16)
     rel_y = (ys - np.repeat(ymin, counts)).astype(np.uint16)
     n = len(uniq)

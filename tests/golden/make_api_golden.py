@@ -22,15 +22,17 @@ import nyxus  # noqa: E402  (the REFERENCE package)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "api_featurize.json")
 
 
-def run(features, kwargs, inten, seg, names=None):
+def run(features, kwargs, inten, seg, names=None, metaparams=None):
     nyx = nyxus.Nyxus(features, **kwargs)
+    for mp in metaparams or []:
+        nyx.set_metaparam(mp)
     if names:
         df = nyx.featurize(inten.copy(), seg.copy(), intensity_names=names[0], label_names=names[1])
     else:
         df = nyx.featurize(inten.copy(), seg.copy())
     num = df.select_dtypes(include=[np.number])
     return {"features": features, "kwargs": kwargs, "inten": inten.tolist(), "inten_dtype": str(inten.dtype),
-            "seg": seg.tolist(), "names": names, "columns": list(df.columns),
+            "seg": seg.tolist(), "names": names, "metaparams": metaparams or [], "columns": list(df.columns),
             "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
             "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
 
@@ -74,6 +76,26 @@ def main():
     sg[0, 4:20, 5:25] = 3
     sg[0, 22:30, 2:12] = 9
     cases["hounsfield_float"] = run(["*ALL_INTENSITY*"], {}, ct, sg)
+    # (4) SURVEY 8(b) fixture (2): the 4-slice 4x5 IBSI phantom of the reference's own API test
+    # (/root/reference/tests/python/test_data.py:3-49; call shape and asserted values /root/reference/tests/python/test_nyxus.py:410-447)
+    ph_i = np.array([[[1, 4, 4, 1, 1], [1, 4, 6, 1, 1], [4, 1, 6, 4, 1], [4, 4, 6, 4, 1]],
+                     [[1, 4, 4, 1, 1], [1, 1, 6, 1, 1], [1, 1, 3, 1, 1], [4, 4, 6, 1, 1]],
+                     [[1, 4, 4, 1, 1], [1, 1, 1, 1, 1], [1, 1, 6, 1, 1], [1, 1, 6, 1, 1]],
+                     [[1, 4, 4, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 6, 1, 1]]])
+    ph_s = np.array([[[1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1]],
+                     [[1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 1, 1, 1, 1], [1, 1, 1, 1, 1]],
+                     [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 0, 1, 1], [1, 1, 1, 1, 1]],
+                     [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1]]])
+    ibsi16 = ["GLCM_ASM", "GLCM_CONTRAST", "GLCM_CORRELATION", "GLCM_DIFAVE", "GLCM_DIFENTRO", "GLCM_DIFVAR", "GLCM_ENERGY", "GLCM_ENTROPY",
+              "GLCM_HOM1", "GLCM_INFOMEAS1", "GLCM_INFOMEAS2", "GLCM_IDM", "GLCM_SUMAVERAGE", "GLCM_SUMENTROPY", "GLCM_SUMVARIANCE", "GLCM_VARIANCE"]
+    nm = ["test_name_1", "test_name_2", "test_name_3", "test_name_4"]
+    cases["ibsi_phantom_3d"] = run(ibsi16, {"ibsi": True}, ph_i, ph_s, names=(nm, nm), metaparams=["glcm/greydepth=100", "glcm/offset=1"])
+    cases["ibsi_phantom_2d_all_glcm"] = run(["*ALL_GLCM*"], {"ibsi": True}, ph_i[0], ph_s[0], names=(nm[:1], nm[:1]))
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if only:                                   # add / refresh the named cases, keep the others as captured
+        old = json.load(open(OUT))
+        old.update({k: cases[k] for k in only})
+        cases = old
     with open(OUT, "w") as fh:
         json.dump(cases, fh, separators=(",", ":"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", {k: (len(v["numeric"]), len(v["columns"])) for k, v in cases.items()})

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/nyxhip.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert lib.nyxhip_abi_version() == 1
+    assert lib.nyxhip_abi_version() == 2
 
 
 def test_struct_layout_matches_header_defaults():

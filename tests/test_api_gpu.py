@@ -19,6 +19,8 @@ def test_featurize_matches_reference_dataframe(case):
     inten = np.array(g["inten"], dtype=np.dtype(g["inten_dtype"]))
     seg = np.array(g["seg"])
     nyx = nyxus_amd.Nyxus(g["features"], **g["kwargs"])
+    for mp in g.get("metaparams", []):
+        nyx.set_metaparam(mp)
     if g["names"]:
         df = nyx.featurize(inten, seg, intensity_names=g["names"][0], label_names=g["names"][1])
     else:
