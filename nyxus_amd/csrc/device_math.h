@@ -117,8 +117,9 @@ __device__ __forceinline__ double fdiv(double a, double b)
 // After the six steps lane 63 holds the wave total; v_readlane broadcasts it.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_mov0(uint32_t v)
-{   // lanes without a source (or masked rows) read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+{   // lanes without a source (or masked rows) read 0.  With every row enabled the zero comes from bound_ctrl and the
+    // destination needs no initialisation (one v_mov less per move); masked rows keep `old`, so those steps pass an explicit 0.
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov0(double v)
@@ -382,6 +383,19 @@ __device__ __forceinline__ uint32_t lane_minus1(uint32_t v, uint32_t fill)  // v
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
 
+
+// 24-bit multiply that stays one: hipcc turns __umul24 of provably small operands into a plain 32-bit multiply, and
+// v_mul_lo_u32 issues at a quarter of the rate.  `b` is wave-uniform (an SGPR operand).
+__device__ __forceinline__ uint32_t mul_u24_su(uint32_t a, uint32_t b_uniform)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b_uniform), "v"(a));
+    return r;
+}
+
+// the same with zero fill through bound_ctrl (no initialisation of the destination)
+__device__ __forceinline__ uint32_t lane_plus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t lane_minus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 
 // ---- synchronisation that also works when the "LDS" of a workgroup lives in the global workspace ----------
 // GS = false: plain workgroup barrier / wave-level compiler fence (LDS instructions of a wave run in issue order).

@@ -316,7 +316,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         L.ng_cap = ng;
         L.app = app;
         uint32_t goff = shared0;
-        L.P = goff; goff = align16(goff + 4u * app * ng * ng);
+        L.P = goff; goff = align16(goff + 4u * app * (ng <= 16 ? (ng + 1) * (ng + 1) : ng * ng));   // split launches count with a skip row / column
         L.gscr = goff; goff = align16(goff + 8u * (25u * ng + 128));
         if (goff > off) off = goff;
     }

@@ -475,7 +475,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(A.inten + off), 0, (int)(n * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + off), 0, (int)(n * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(A.y + off), 0, (int)(n * 2u), 0x00020000);
-    for (uint32_t base = 0; base < n; base += kU * kBlock) {
+    // Per-pixel work of the pass.  Three facts that hold for a whole trip (1024 pixels) or a whole ROI are compile-time
+    // parameters of the body, so that the common case carries no per-pixel test for them:
+    //   FULL  every lane of the trip has a pixel (all trips but the last);
+    //   NZ    the ROI has no zero intensity (vmin > 0): the co-occurrence scan's "original intensity 0 is skipped" test vanishes;
+    //   TINY  vmax < 2^15: the four values / squares of a trip sum in 32 bits, one 64-bit add per trip instead of per pixel.
+    auto trip = [&](auto full_c, auto nz_c, auto tiny_c, uint32_t base) {
+        constexpr bool FULL = decltype(full_c)::value, NZ = decltype(nz_c)::value, TINY = decltype(tiny_c)::value;
         uint32_t v[kU], px[kU], py[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
@@ -484,18 +490,21 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             px[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_x, (int)(i * 2u), 0, 0) : 0u;
             py[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_y, (int)(i * 2u), 0, 0) : 0u;
         }
+        uint32_t s32 = 0, q32 = 0;
+        const uint32_t i0 = base + tid;
+        uint16_t* const val16 = (uint16_t*)s_val + i0;
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            uint32_t i = base + u * kBlock + tid;
-            if (i >= n)
+            if (!FULL && i0 + u * kBlock >= n)
                 continue;
             if (do_int) {
-                if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v[u] - vmin);   // C16 launches: every ROI counts, range < 16384
-                else s_val[i] = v[u];
-                sum += v[u];
+                if (C16) val16[u * kBlock] = (uint16_t)(v[u] - vmin);       // C16 launches: every ROI counts, range < 16384
+                else s_val[i0 + u * kBlock] = v[u];
                 // unsigned-int product, wraps (intensity.cpp:90).  v_mul_lo_u32 issues at quarter rate; below 2^24 the 24-bit
                 // multiply returns the same low 32 bits at full rate (uniform choice per ROI).
-                sumsq += small_v ? __umul24(v[u], v[u]) : (uint32_t)(v[u] * v[u]);
+                const uint32_t sq = (TINY || small_v) ? (uint32_t)__umul24(v[u], v[u]) : (uint32_t)(v[u] * v[u]);
+                if (TINY) { s32 += v[u]; q32 += sq; }
+                else { sum += v[u]; sumsq += sq; }
                 if (use_count)
                 {
                     const uint32_t ci = v[u] - vmin;
@@ -505,7 +514,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             }
             if (do_glcm) {
                 uint32_t lvl = 0;
-                if (v[u] != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
+                if (NZ || v[u] != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
+                    if (FAST) {         // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already
+                        const uint32_t sc = (uint32_t)floor(mslope * (double)v[u] + 1.0);
+                        lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
+                    } else
                     lvl = greyInfo > 0 ? bin_matlab(v[u], mslope, greyInfo)
                         : greyInfo < 0 ? bin_radiomix(v[u], vmin, vmax, -greyInfo) : v[u];
                     if (greyInfo < 0)
@@ -513,9 +526,24 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     if (greyInfo <= 0)                 // only the IBSI / radiomics paths derive the matrix order from the data
                         lvl_max = lvl > lvl_max ? lvl : lvl_max;
                 }
-                if (px[u] < w && py[u] < h)
-                    s_dense[__umul24(py[u], w) + px[u]] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
+                // a cell index inside the plane is all the store needs to be safe (coordinates beyond the box are the caller's
+                // contract violation; they cannot leave the plane)
+                const uint32_t cell = __umul24(py[u], w) + px[u];
+                if (cell < area)
+                    s_dense[cell] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
             }
+        }
+        if (TINY) { sum += s32; sumsq += q32; }
+    };
+    {
+        using T = std::true_type; using F = std::false_type;
+        const bool nz = vmin > 0, tiny = vmax < (1u << 15);
+        uint32_t base = 0;
+        if (nz && tiny) {
+            for (; base + kU * kBlock <= n; base += kU * kBlock) trip(T{}, T{}, T{}, base);
+            if (base < n) trip(F{}, T{}, T{}, base);
+        } else {
+            for (; base < n; base += kU * kBlock) trip(F{}, F{}, F{}, base);
         }
     }
 
@@ -861,9 +889,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
                 const uint32_t m2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((median - (double)vmin) * 2.0));
                 uint32_t sx = 0, sad = 0;
-                for (uint32_t i = tid; i < n; i += kBlock) {
-                    const uint32_t x = ((const uint16_t*)s_val)[i];
-                    const double d = (double)(vmin + x) - mean;
+                const double meanx = mean - (double)vmin;       // deviations are taken in the offset domain: d = x - (mean - vmin)
+                auto px1 = [&](uint32_t x) {
+                    const double d = (double)x - meanx;
                     const double d2 = d * d;
                     acc[0] += fabs(d);
                     acc[1] = __builtin_fma(d, d, acc[1]);
@@ -875,7 +903,15 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     sx += (x - lox) <= span ? x : 0u;
                     const uint32_t x2 = x << 1;
                     sad += x2 > m2x ? x2 - m2x : m2x - x2;
-                }
+                };
+                // the trip count is wave-uniform (n / 256 full trips, then the lanes below n % 256 once more): the loop control
+                // runs on the scalar unit and costs no vector instruction per value
+                const uint16_t* const pv = (const uint16_t*)s_val + tid;
+                const uint32_t n_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n / kBlock)), n_rem = n - n_full * kBlock;
+                for (uint32_t k = 0; k < n_full; k++)
+                    px1(pv[k * kBlock]);
+                if ((uint32_t)tid < n_rem)
+                    px1(pv[n_full * kBlock]);
                 // workgroup totals: the two integer sums through 32-bit DPP wave sums (slots 6, 7 of the exchange area), the six
                 // fp64 sums through the transposed wave sum (slots 0..5); one barrier pair for all eight
                 {
@@ -913,14 +949,18 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(sadt * 0.5, dn);
                 }
                 // sweep 2: robust MAD about mean1090 = S / K (histogram.h:102-112): sum |a - S/K| = sum |K x - Sx| / K, exact in integers
-                const uint32_t Ku = K, Sxu = (uint32_t)Sx;
+                const uint32_t Ku = K, Sxu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Sx);
                 unsigned long long ad = 0;
-                for (uint32_t i = tid; i < n; i += kBlock) {
-                    const uint32_t x = ((const uint16_t*)s_val)[i];
+                auto px2 = [&](uint32_t x) {
                     const uint32_t t = (uint32_t)__umul24(Ku, x);            // < 2^30
-                    const uint32_t dlt = t > Sxu ? t - Sxu : Sxu - t;
+                    uint32_t dlt;
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dlt) : "v"(t), "s"(Sxu));   // |t - Sx| in one instruction
                     ad += (x - lox) <= span ? dlt : 0u;
-                }
+                };
+                for (uint32_t k = 0; k < n_full; k++)
+                    px2(pv[k * kBlock]);
+                if ((uint32_t)tid < n_rem)
+                    px2(pv[n_full * kBlock]);
                 double ad1[1] = {(double)ad};
                 block_sum<1, GS>(ad1, (double*)s_lb100, tid);
                 if (tid == 0)
@@ -1029,8 +1069,17 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             const int app = (int)A.L.app;
             for (int a0 = 0; a0 < na; a0 += app) {
                 const int na_pass = (na - a0) < app ? (na - a0) : app;
+                // Split launches on the lane-per-column path count into matrices of order Ng + 1 indexed by the level itself:
+                // column 0 (row 0 under symmetry) collects the pairs whose NEIGHBOUR is skipped (level 0: background, zero
+                // intensity, outside the box) -- the ROI's rim, spread over the centres' levels -- so the sweep has one test per
+                // centre instead of one per pair; the export below drops the extra row / column.  (Skipped CENTRES are masked
+                // out: sent to a cell of their own, a third of the box's lanes would pile on it and the LDS serialises same-
+                // address adds -- measured: 2.3 -> 3.4 ms per 196 k ROIs.)
+                const bool dpp = A.glcm_offset == 1 && w <= 64;
+                const bool trash = SPLIT && dpp;
+                const int NG1 = Ng + 1, cells = trash ? NG1 * NG1 : NN;
                 blk_sync<GS>();
-                for (int i = tid; i < na_pass * NN; i += kBlock)
+                for (int i = tid; i < na_pass * cells; i += kBlock)
                     s_P[i] = 0;
                 blk_sync<GS>();
                 STAMP(10);
@@ -1043,7 +1092,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
                     ddy[q] = ang == 0 ? 0 : A.glcm_offset;
                 }
-                if (A.glcm_offset == 1 && w <= 64) {
+                if (dpp) {
                     // one lane per column: horizontal neighbours come from DPP lane shifts, the
                     // row below is read once and becomes the next iteration's centre row; each
                     // wave owns a contiguous block of rows.  slot[d] = matrix of this pass that
@@ -1068,6 +1117,54 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     // one (centre, neighbour) pair into the matrix of its direction.  The centre's row offset is shared by the
                     // four directions; lanes beyond the last column hold level 0, so the right-hand neighbours of the last column
                     // are "skip" without a separate test.  B_q = matrix q minus one element (levels are 1-based).
+                    if (trash) {
+                        // branch-free sweep: address = matrix + 4 * (centre * (Ng + 1) + neighbour), every lane, every pair
+                        // (matrix offsets and the "angle present" flags pass through readfirstlane: kept in SGPRs, the four tests
+                        // of a row are scalar branches and cost no vector instruction)
+                        const uint32_t ng1 = (uint32_t)__builtin_amdgcn_readfirstlane(NG1);
+                        const int has0 = __builtin_amdgcn_readfirstlane(slot0 >= 0), has1 = __builtin_amdgcn_readfirstlane(slot1 >= 0),
+                                  has2 = __builtin_amdgcn_readfirstlane(slot2 >= 0), has3 = __builtin_amdgcn_readfirstlane(slot3 >= 0),
+                                  sym = __builtin_amdgcn_readfirstlane(symmetric ? 1 : 0);
+                        char* const T0 = (char*)(s_P + (slot0 >= 0 ? slot0 : 0) * cells);
+                        char* const T1 = (char*)(s_P + (slot1 >= 0 ? slot1 : 0) * cells);
+                        char* const T2 = (char*)(s_P + (slot2 >= 0 ? slot2 : 0) * cells);
+                        char* const T3 = (char*)(s_P + (slot3 >= 0 ? slot3 : 0) * cells);
+                        if (has0 && has1 && has2 && has3 && !sym) {
+                            // the usual request -- four angles, asymmetric: nothing but the four adds per row
+                            for (int row = r_begin; row < r_end; row++) {
+                                uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                                nxt4 <<= 2;
+                                const uint32_t nb_e = lane_plus1_z(cur4), nb_se = lane_plus1_z(nxt4), nb_sw = lane_minus1_z(nxt4);
+                                if (cur4 != 0) {      // skipped centres (a third of a disk's box) stay out: piled on one cell their adds serialise
+                                    const uint32_t rowb = mul_u24_su(cur4, ng1);
+                                    atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
+                                    atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
+                                    atomicAdd((uint32_t*)(T2 + rowb + nxt4), 1u);
+                                    atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
+                                }
+                                cur4 = nxt4;
+                            }
+                        } else
+                        for (int row = r_begin; row < r_end; row++) {
+                            uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                            nxt4 <<= 2;
+                            const uint32_t nb_e = lane_plus1_z(cur4), nb_se = lane_plus1_z(nxt4), nb_sw = lane_minus1_z(nxt4);
+                            const uint32_t rowb = mul_u24_su(cur4, ng1);
+                            if (cur4 != 0) {
+                            if (has0) atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
+                            if (has1) atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
+                            if (has2) atomicAdd((uint32_t*)(T2 + rowb + nxt4), 1u);
+                            if (has3) atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
+                            }
+                            if (sym && cur4 != 0) {
+                                if (has0) atomicAdd((uint32_t*)(T0 + mul_u24_su(nb_e, ng1) + cur4), 1u);
+                                if (has1) atomicAdd((uint32_t*)(T1 + mul_u24_su(nb_se, ng1) + cur4), 1u);
+                                if (has2) atomicAdd((uint32_t*)(T2 + mul_u24_su(nxt4, ng1) + cur4), 1u);
+                                if (has3) atomicAdd((uint32_t*)(T3 + mul_u24_su(nb_sw, ng1) + cur4), 1u);
+                            }
+                            cur4 = nxt4;
+                        }
+                    } else {
                     char* const B0 = slot0 >= 0 ? (char*)(s_P + slot0 * NN) - 4 : nullptr;
                     char* const B1 = slot1 >= 0 ? (char*)(s_P + slot1 * NN) - 4 : nullptr;
                     char* const B2 = slot2 >= 0 ? (char*)(s_P + slot2 * NN) - 4 : nullptr;
@@ -1099,6 +1196,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         pair_row(cur4, nxt4);
                         cur4 = nxt4;
                     }
+                    }
                 } else
                 for (int row = wave; row < (int)h; row += kWaves) {
                     for (int col = lane; col < (int)w; col += 64) {
@@ -1127,6 +1225,16 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 STAMP(11);
                 if (SPLIT) {                         // the host sets this up only when every angle fits one pass
                     uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
+                    if (trash) {
+                        // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
+                        // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the rounding of the product.
+                        const float inv_nn = 1.0f / (float)NN, inv_ng = 1.0f / (float)Ng;
+                        for (int i = tid; i < na_pass * NN; i += kBlock) {
+                            const int q = (int)(((float)i + 0.5f) * inv_nn), rem = i - q * NN;
+                            const int r = (int)(((float)rem + 0.5f) * inv_ng), c = rem - r * Ng;
+                            dst[i] = s_P[q * cells + (r + 1) * NG1 + c + 1];
+                        }
+                    } else
                     for (int i = tid; i < na_pass * NN; i += kBlock)
                         dst[i] = s_P[i];
                 } else if (SPLIT) {
