@@ -344,6 +344,186 @@ __device__ void glcm_features_rows(const uint32_t* Pslots, int n_slots, int Ng, 
     wav_sync<GS>();
 }
 
+// ---- GLCM features of small matrices, one wave per ROI (glcm_features_kernel) ---------------------------------------------
+// The kernel is bound by vector-instruction issue (every VALU operation occupies its SIMD for four cycles, whatever the
+// type), so this routine is organised around the instruction count: level values are I[i] = i + 1 (matlab / IBSI), hence
+//   * everything that only needs the marginal distributions is a sum over <= 16 lanes, one term each:  the means, CONTRAST,
+//     DIS, VARIANCE, the correlation variances and JVAR from the row / column counts, the cluster sums and the sum features
+//     from p_{x+y}, the difference features from p_{x-y} (integer numerators stay exact);
+//   * only ASM, ACOR, ENTROPY, JMAX, the covariance term and the two HXY sums visit the cells;
+//   * the partial sums of a phase are reduced together by a transposed exchange inside the 16-lane row (n values cost about
+//     n + 3 exchanges instead of 4 n), land in LDS and are finished by one lane per angle.
+// Same quantities as glcm_features_rows (features/glcm.cpp:487-1202), regrouped; deviations stay at the 1e-15 level.
+__device__ __forceinline__ double row16_transpose_sum8(double (&v)[8], int l)
+{   // lane l of the row returns the row total of slot (l >> 1) & 7
+    transpose_sum_step<0x140, 4>(v, (l & 8) != 0);
+    transpose_sum_step<0x141, 2>(v, (l & 4) != 0);
+    transpose_sum_step<0x4E, 1>(v, (l & 2) != 0);
+    double t = v[0];
+    t += dpp_perm<0xB1>(t);
+    return t;
+}
+__device__ __forceinline__ double row16_transpose_sum16(double (&v)[16], int l)
+{   // lane l of the row returns the row total of slot l
+    transpose_sum_step<0x140, 8>(v, (l & 8) != 0);
+    transpose_sum_step<0x141, 4>(v, (l & 4) != 0);
+    transpose_sum_step<0x4E, 2>(v, (l & 2) != 0);
+    transpose_sum_step<0xB1, 1>(v, (l & 1) != 0);
+    return v[0];
+}
+
+__device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int n_slots, int Ng, double* scr_base, int scr_stride, double soft_nan,
+                                                     double* fslots, double* sums, int lane)
+{
+    const int NN = Ng * Ng;
+    const int slot_raw = lane >> 4, l = lane & 15;
+    const bool live = slot_raw < n_slots;
+    const int slot = live ? slot_raw : 0;              // idle rows shadow slot 0 and never store
+    const uint32_t* P = Pslots + slot * NN;
+    double* pcol_s = scr_base + slot * scr_stride;     // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
+    double* prow_s = pcol_s + Ng;                      // py[j] = sum_i xy(i,j)/sum_p
+    double* Pxpy = pcol_s + 2 * Ng;                    // [2Ng]  glcm.cpp:503-508
+    double* f = fslots + slot * 32;
+    double* sm = sums + slot * 32;
+
+    // ---- marginal counts: lane i < Ng owns column i, row i and the diagonal pair |x - y| = i ------------------------------
+    uint32_t cc = 0, rc = 0, dc = 0;
+    if (l < Ng) {
+        for (int j = 0; j < Ng; j++) {
+            cc += P[j * Ng + l];
+            rc += P[l * Ng + j];
+        }
+        for (int x = l; x < Ng; x++) {
+            dc += P[x * Ng + (x - l)];
+            if (l > 0)
+                dc += P[(x - l) * Ng + x];
+        }
+    }
+    const uint32_t l1 = (uint32_t)l + 1u;
+    const uint32_t csum = row16_sum(rc);               // sum_p (glcm.cpp:481-484)
+    const uint32_t Sr_i = row16_sum(rc * l1), Sc_i = row16_sum(cc * l1);          // f_corr mr :601, mc :608 (exact numerators)
+    const uint32_t con_i = row16_sum(dc * (uint32_t)(l * l)), dis_i = row16_sum(dc * (uint32_t)l);   // f_contrast :579, f_GLCM_DIS :1052
+    const bool empty = csum == 0;                      // glcm.cpp:260-295 -> soft NaN for this angle
+    const double sum_p = empty ? 1.0 : (double)csum;
+    const double inv_sum_p = fdiv(1.0, sum_p);
+    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
+    const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
+    if (live && l < Ng) { pcol_s[l] = pcol; prow_s[l] = prow; }
+    for (int k = l; k < 2 * Ng - 1; k += 16) {
+        uint32_t c = 0;
+        const int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
+        for (int x = x0; x <= x1; x++)
+            c += P[x * Ng + (k - x)];
+        if (live) Pxpy[k] = fdiv((double)c, sum_p);
+    }
+    wav_sync<false>();
+
+    // ---- the cell pass ---------------------------------------------------------------------------------------------------
+    double asm_ = 0, ent = 0, hxy1 = 0, hxy2 = 0, cov = 0, jmax = -1;
+    uint32_t acor_i = 0;
+    RowCol rcw((uint32_t)l, 16u, (uint32_t)Ng);
+    for (int e = l; e < NN; e += 16, rcw.advance()) {
+        const uint32_t r = rcw.row, c = rcw.col, cnt = P[e];
+        const double p = (double)cnt * inv_sum_p;
+        asm_ = __builtin_fma(p, p, asm_);                            // f_asm :555 / f_energy :927-928
+        acor_i += cnt * ((r + 1u) * (c + 1u));                       // f_GLCM_ACOR :961 (integer-exact)
+        ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);       // f_entropy :734-735, JE :1160-1161, HXY :868
+        jmax = p > jmax ? p : jmax;                                  // f_GLCM_JMAX :1178-1179
+        cov = __builtin_fma(((double)(r + 1u) - mr) * ((double)(c + 1u) - mc), p, cov);   // f_corr :633
+        const double pp = pcol_s[c] * prow_s[r];                     // px[i]*py[j], i = column, j = row (:869, :909)
+        const double lg = (double)fast_log2f(pp + 0.000000001);
+        hxy1 = __builtin_fma(p, lg, hxy1);
+        hxy2 = __builtin_fma(pp, lg, hxy2);
+    }
+    const double hx_t = l < Ng ? plogp(pcol, pcol) : 0.0;             // :873-874
+    {
+        double t8[8] = {asm_, ent, hxy1, hxy2, cov, hx_t, 0.0, 0.0};
+        const double tot = row16_transpose_sum8(t8, l);
+        if (live && (l & 1) == 0) sm[l >> 1] = tot;
+    }
+    jmax = row16_max(jmax);
+    acor_i = row16_sum(acor_i);
+
+    // ---- one term per lane: features of the marginal distributions ---------------------------------------------------------
+    double t16[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t16[k] = 0.0;
+    if (l < Ng) {
+        const double dr = (double)l1 - mr, dcl = (double)l1 - mc, dr2 = dr * dr;
+        t16[0] = prow * dr2;                                         // f_corr :617
+        t16[1] = pcol * (dcl * dcl);                                 // :626
+        t16[2] = (double)rc * dr2;                                   // f_var :672
+        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199 (x = column, +1 index)
+        const double q = pxmy, kd = (double)l, Ngd = (double)Ng;
+        t16[4] = fdiv(q, (double)(1 + l * l));                       // f_idm :685-687
+        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
+        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
+        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
+        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
+        t16[9] = l >= 1 ? q / (kd * kd) : 0.0;                       // :1123-1128
+        t16[10] = kd * q;                                            // f_difference_avg :791-792
+    }
+    for (int k = l; k < 2 * Ng - 1; k += 16) {
+        const double q = Pxpy[k], ks = (double)(k + 2);              // I[x] + I[k - x] = k + 2
+        t16[11] += ks * q;                                           // f_savg :700-701
+        t16[12] += plogp(q, q);                                      // f_sentropy :712-716
+        const double m = ks - mc - mc, m2 = m * m;                   // by_row_mean (:531-536) = mc; CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+        t16[13] += m2 * m2 * q;
+        t16[14] += m2 * m * q;
+        t16[15] += m2 * q;
+    }
+    {
+        const double tot = row16_transpose_sum16(t16, l);
+        if (live) sm[8 + l] = tot;
+    }
+    wav_sync<false>();
+    // f_dvar (glcm.cpp:742-766): every k receives the same term Ng times and the total is divided by Ng
+    const double davg = sm[8 + 10];
+    double dv = 0;
+    if (l < Ng) { const double dk = (double)l - davg; dv = dk * dk * pxmy; }
+    dv = row16_sum(dv);
+
+    if (live && l == 0) {
+        const double asm_t = sm[0], ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], cov_t = sm[4], hx = sm[5];
+        f[G_ASM] = asm_t;
+        f[G_ENERGY] = asm_t;
+        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
+        f[G_ACOR] = fdiv((double)acor_i, sum_p);
+        f[G_ENTROPY] = -ent_t;
+        f[G_JE] = -ent_t;
+        f[G_DIS] = fdiv((double)dis_i, sum_p);
+        f[G_JMAX] = jmax;
+        f[G_JAVE] = mr;
+        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
+        f[G_CLUPROM] = sm[8 + 13];
+        f[G_CLUSHADE] = sm[8 + 14];
+        f[G_CLUTEND] = sm[8 + 15];
+        f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
+        f[G_JVAR] = sm[8 + 3];
+        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
+        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
+        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
+        f[G_IDM] = sm[8 + 4];
+        f[G_HOM2] = sm[8 + 4];                        // f_GLCM_HOM2 :1069 == f_idm over p_{x-y}
+        f[G_HOM1] = sm[8 + 7];                        // f_homogeneity :942 == f_GLCM_ID over p_{x-y}
+        f[G_SUMAVERAGE] = sm[8 + 11];
+        f[G_SUMENTROPY] = -sm[8 + 12];
+        f[G_DIFENTRO] = -sm[8 + 5];
+        f[G_DIFAVE] = davg;
+        f[G_DIFVAR] = dv;
+        f[G_IDMN] = sm[8 + 6];
+        f[G_ID] = sm[8 + 7];
+        f[G_IDN] = sm[8 + 8];
+        f[G_IV] = sm[8 + 9];
+        const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
+        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+        if (empty)                                    // blank matrix: all 30 values = soft NaN
+            for (int k = 0; k < kGlcmAngled; k++)
+                f[k] = soft_nan;
+    }
+    wav_sync<false>();
+}
+
 // Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
 // workgroup adds the cycles spent between consecutive stamps to A.stamps[phase].  The
 // product build compiles the macro away.
@@ -1318,22 +1498,21 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
     if (Ng == 0)
         return;                                       // degenerate / skipped ROI: roi_features_kernel wrote the columns
     const int na = A.glcm_na, ngc = (int)A.L.ng_cap, NN = Ng * Ng;
-    // per-wave carve-out: counts [na * ngc^2] u32 | level values [ngc] | scratch [4][6 * ngc] | features [4][32]  (doubles)
-    const size_t per_wave = (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15) + 8ull * (ngc + kMaxAngles * 6 * ngc + kMaxAngles * 32);
+    // per-wave carve-out: counts [na * ngc^2] u32 | (unused) [ngc] | marginals [4][6 * ngc] | features [4][32] | sums [4][32]  (doubles)
+    const size_t per_wave = (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15) + 8ull * (ngc + kMaxAngles * 6 * ngc + 2 * kMaxAngles * 32);
     unsigned char* base = lds_raw + (size_t)wave * per_wave;
     uint32_t* s_P = (uint32_t*)base;
-    double* s_I = (double*)(base + (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15));
-    double* s_scr = s_I + ngc;
+    double* s_scr = (double*)(base + (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15)) + ngc;
     double* s_f = s_scr + kMaxAngles * 6 * ngc;
     const uint32_t* src = A.glcm_ws + roi * A.glcm_ws_stride;
     for (int i = lane; i < na * NN; i += 64) s_P[i] = src[i];
-    for (int i = lane; i < Ng; i += 64) s_I[i] = (double)(i + 1);      // level values of the matlab / IBSI paths (glcm.cpp:400-408)
     wav_sync<false>();
-    glcm_features_rows<false, 16, 1>(s_P, na, Ng, s_I, s_scr, 6 * ngc, A.soft_nan, s_f, lane);
+    glcm_features_wave16(s_P, na, Ng, s_scr, 6 * ngc, A.soft_nan, s_f, s_f + kMaxAngles * 32, lane);   // level values I[i] = i + 1 (glcm.cpp:400-408)
     wav_sync<false>();
     double* o = A.out + roi * A.ld + A.col_glcm;
+    const int sh = na == 4 ? 2 : na == 2 ? 1 : na == 1 ? 0 : -1;  // the usual angle counts split c = k * na + a by a shift
     for (int c = lane; c < kGlcmAngled * na; c += 64) {           // feature-major, angle-minor (output_2_buffer.cpp:336-346)
-        const int k = c / na, a = c - k * na;
+        const int k = sh >= 0 ? c >> sh : c / na, a = c - k * na;
         o[c] = s_f[a * 32 + k];
     }
     for (int j = lane; j < kGlcmAve; j += 64) {                   // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
@@ -1353,7 +1532,7 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
 
 size_t glcm_features_lds(uint32_t ng_cap)
 {
-    const size_t per_wave = (((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15) + 8ull * (ng_cap + kMaxAngles * 6 * ng_cap + kMaxAngles * 32);
+    const size_t per_wave = (((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15) + 8ull * (ng_cap + kMaxAngles * 6 * ng_cap + 2 * kMaxAngles * 32);
     return per_wave * kWaves;
 }
 
