@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--families", type=int, default=3, help="family bitmask (diagnostic; the metric is 3 = INTENSITY|GLCM)")
     ap.add_argument("--tile-path-tiles", type=int, default=128, help="tiles for the informational fused tile-path measurement (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (grey depth 64, configs 4 and 5)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST HOOK (tests/test_bench_launcher.py): no GPU, gloo; every rank fills a rank-coded table on the CPU so that "
                          "the launcher, the barrier / max-over-ranks timing and the table gather can run here; the line says \"stub\": true")
@@ -247,10 +248,12 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):            # PMC-derived HBM bytes per launch, see profiles/README.md
+        if os.path.exists(tpath):            # PMC-derived HBM bytes per launch (profiles/README.md); only valid for the kernel source it was measured on
             try:
+                import hashlib
                 tj = json.load(open(tpath))
-                if tj.get("tiles") == a.tiles and tj.get("gray_depth") == a.gray_depth:
+                src = hashlib.sha256(open(os.path.join(ROOT, "nyxus_amd", "csrc", "roi_features.hip"), "rb").read()).hexdigest()
+                if tj.get("tiles") == a.tiles and tj.get("gray_depth") == a.gray_depth and tj.get("kernel_source_sha256") == src:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -322,6 +325,65 @@ def main():
                              f"with {thr} threads, reduce stage only ({sec:.2f} s)" if kind == "reference"
                              else f"single-threaded C restatement ({sec:.2f} s)"),
                 "host_cpus": cores}
+        # ---- informational legs on the same resident batch: the reference's DEFAULT grey depth, BASELINE.json configs[3] and [4] ----
+        if world == 1 and not a.no_extras and mask == 3:
+            def timed(msk, st, cbatch, n_rows, reps=3):
+                nc = ctx.n_columns(msk, st)
+                o = torch.empty((n_rows, nc), dtype=torch.float64, device=dev)
+                ctx.featurize_device_async(cbatch, msk, st, o.data_ptr(), nc)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.featurize_device_async(cbatch, msk, st, o.data_ptr(), nc)
+                torch.cuda.synchronize()
+                ctx.sync()
+                return (time.perf_counter() - c0) / reps, nc
+            s64 = _abi.default_settings(64)
+            dt64, _ = timed(mask, s64, cb, n_roi)
+            rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64,
+                                    "what": "the metric workload at the reference's default coarse_gray_depth=64 (64 x 64 co-occurrence matrices, 64 histogram bins)"}
+            m4 = _abi.FAM_INTENSITY | _abi.FAM_GLCM | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+            dt4, nc4 = timed(m4, s, cb, n_roi)
+            b4 = n_px * 8 + n_roi * nc4 * 8
+            rec["config4"] = {"value": n_roi / dt4, "unit": "ROIs/s", "ms_per_step": 1e3 * dt4, "n_columns": nc4,
+                              "roofline": {"bound": "hbm", "achieved": b4 / dt4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b4 / dt4 / 1e9 / HBM_PEAK_GBS,
+                                           "algorithmic_bytes_per_launch": b4},
+                              "what": "BASELINE.json configs[3] per GPU: *ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY* (gd 8) on the same 1000 tiles"}
+            try:
+                from tests import fixtures
+                rng5 = np.random.default_rng(5)
+                rois5 = []
+                for _k in range(6000):
+                    for d5 in fixtures.reference_tests()["dsb2018"]:
+                        r5 = fixtures.dsb_roi(d5)
+                        v5 = r5["inten"].astype(np.int64)
+                        v5 = np.where(v5 > 0, np.clip(v5 + rng5.integers(-8, 9, len(v5)), 1, 255), 0).astype(np.uint32)
+                        m5 = v5 > 0
+                        rois5.append(dict(x=r5["x"][m5], y=r5["y"][m5], inten=v5[m5]))
+                hb5 = _abi.batch_from_rois(rois5)
+                s5 = _abi.default_settings(64)
+                s5.gabor_n_filters = 8
+                for i5 in range(8):
+                    s5.gabor_f0[i5] = [4.0, 16.0, 32.0, 64.0][i5 % 4]
+                    s5.gabor_theta[i5] = np.pi * i5 / 8
+                keep5 = {k5: torch.from_numpy(getattr(hb5, k5).view({2: np.int16, 4: np.int32, 8: np.int64}[getattr(hb5, k5).dtype.itemsize])).to(dev)
+                         for k5 in ("px_offset", "x", "y", "inten", "bbox_w", "bbox_h", "min_inten", "max_inten")}
+                cb5 = hb5.c_struct()
+                for k5, t5 in keep5.items():
+                    setattr(cb5, k5, t5.data_ptr())
+                cb5.slide_min = None; cb5.slide_max = None; cb5.memory = _abi.MEM_DEVICE
+                m5k = _abi.FAM_GABOR | _abi.FAM_ZERNIKE
+                dt5, _ = timed(m5k, s5, cb5, hb5.n_roi)
+                # Gabor 2*2*w*h*n^2 flops per filter (complex MAC on a real image; 8 filters + the low-pass), Zernike 2*55 per pixel
+                fl5 = float(np.sum(9.0 * 4.0 * hb5.bbox_w.astype(np.float64) * hb5.bbox_h * 256.0) + 110.0 * hb5.n_px)
+                rec["config5"] = {"value": hb5.n_roi / dt5, "unit": "ROIs/s", "ms_per_step": 1e3 * dt5, "rois": int(hb5.n_roi), "mean_px": hb5.n_px / hb5.n_roi,
+                                  "roofline": {"bound": "fp64 vector", "achieved": fl5 / dt5 / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl5 / dt5 / 1e12 / 78.6,
+                                               "algorithmic_flops_per_launch": fl5,
+                                               "note": "fp64 matrix peak = fp64 vector peak on MI355X (MI355X_MICROARCH.md); the direct convolution is bit-exact with the reference, DESIGN 4.3"},
+                                  "what": "BASELINE.json configs[4]: GABOR (8-filter bank, 16x16) + ZERNIKE2D on DSB2018-shaped ROIs (fixture shapes replicated with seeded noise)"}
+                del keep5
+            except Exception as e5:           # informational leg: never costs the headline line
+                rec["config5"] = {"error": repr(e5)}
         # ---- informational: the fused tile path (label scan + ROI assembly + reduce from tiles in HBM) -------
         if world == 1 and a.tile_path_tiles > 0:
             from tests import synth
@@ -355,26 +417,21 @@ def main():
                                 "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                         "compaction, cloud assembly, then the same reduce kernels (one host sync inside for the ROI count)"}
-            # PCIe-inclusive variant (what Nyxus.featurize() pays): the same call on pageable host tiles
-            nh = min(nt, 32)
-            h_in = tin[:nh].cpu().numpy().view(np.uint32)
-            h_lab = labs[:nh].cpu().numpy().view(np.uint32)
-            h_out = np.empty((nh * 196, ncol), np.float64)
-            h_l = np.empty(nh * 196, np.uint32)
-            h_t = np.empty(nh * 196, np.uint32)
-
-            def host_step():
-                rc = lib.nyxhip_featurize_tiles(ctx._h, h_in.ctypes.data, h_lab.ctypes.data, 1024, 1024, nh, _abi.MEM_HOST, 196, mask,
-                                                C.byref(s), h_l.ctypes.data, h_t.ctypes.data, nh * 196, h_out.ctypes.data, ncol, C.byref(nroi))
-                if rc != 0:
-                    raise RuntimeError(lib.nyxhip_last_error(ctx._h).decode())
-            host_step()
-            c0 = time.perf_counter()
-            for _ in range(2):
-                host_step()
-            dth = (time.perf_counter() - c0) / 2
-            rec["tile_path"]["pcie_inclusive"] = {"value": nroi.value / dth, "unit": "ROIs/s", "tiles": nh, "ms_per_call": 1e3 * dth,
-                                                  "what": "same call with pageable host tiles in and the host table out (H2D + D2H inside)"}
+            # PCIe-inclusive variants (what Nyxus.featurize() pays): host tiles in, host table out, through the chunked
+            # copy / compute pipeline of nyxhip_featurize_tiles_v2 -- uint32 tiles, and the same images in the element types a
+            # microscope hands over (uint16 intensities, uint8 labels: H2D carries 3 B per pixel instead of 8)
+            nh = min(nt, 64)
+            h_in32 = tin[:nh].cpu().numpy().view(np.uint32)
+            h_lab32 = labs[:nh].cpu().numpy().view(np.uint32)
+            for tag, hi, hl in (("pcie_inclusive", h_in32, h_lab32), ("pcie_inclusive_u16_u8", h_in32.astype(np.uint16), h_lab32.astype(np.uint8))):
+                ctx.featurize_tiles_host(hi, hl, mask, s)
+                c0 = time.perf_counter()
+                for _ in range(2):
+                    _, hl_out, _ = ctx.featurize_tiles_host(hi, hl, mask, s)
+                dth = (time.perf_counter() - c0) / 2
+                rec["tile_path"][tag] = {"value": len(hl_out) / dth, "unit": "ROIs/s", "tiles": nh, "ms_per_call": 1e3 * dth,
+                                         "host_GBps": (hi.nbytes + hl.nbytes) / dth / 1e9,
+                                         "what": "pageable host tiles (" + str(hi.dtype) + " intensity, " + str(hl.dtype) + " labels) in, host table out"}
         print(json.dumps(rec))
     if world > 1:
         dist.barrier()

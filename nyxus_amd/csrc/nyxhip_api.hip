@@ -1420,6 +1420,8 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         const uint64_t t0 = c * chunk;
         const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
         if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
+        // (pageable source: the runtime stages / pins on the fly, 20-45 GB/s measured; a hand-rolled pinned double buffer filled
+        // by host threads was slower on the same arrays -- 15-31 GB/s -- and is not used)
         HIP_TRY(ctx, hipMemcpyAsync(slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype,
                                     hipMemcpyHostToDevice, ctx->copy_stream));
         HIP_TRY(ctx, hipMemcpyAsync(slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype,
