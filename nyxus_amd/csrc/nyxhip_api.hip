@@ -278,6 +278,12 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         const bool split_pred = do_glcm && !spill && gi > 0 && gi <= 16 && s->glcm_n_angles > 0;
         L.dense8 = (c16_pred && split_pred) ? 1u : 0u;
     }
+    {   // the reference's default grey depth on LDS launches: 16-bit matrices + 8-bit plane (roi_features_kernel_g16)
+        const int gi = s->ibsi ? 0 : s->grey_depth;
+        const bool c16_pred = (!do_int || (uint64_t)max_range + 1 <= kCountCapMax) && max_range < 65536u;
+        L.g16 = (do_glcm && !spill && gi > 16 && gi <= 64 && max_px < 32768u && c16_pred && s->glcm_n_angles > 0) ? 1u : 0u;
+        if (L.g16) L.dense8 = 1;
+    }
     if ((L.dense8 ? 1ull : 2ull) * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     off = align16(off + (L.dense8 ? 1u : 2u) * L.dense_cap + 8);
     if (do_glcm) {
@@ -293,7 +299,14 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     if ((L.cnt16 ? 2ull : 4ull) * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     off = align16(off + (L.cnt16 ? 2u : 4u) * L.sort_cap + 16);
     L.cnt = off; off = align16(off + (L.cnt16 ? 2u : 4u) * L.count_cap + 16);
-    if (do_glcm) {
+    if (do_glcm && L.g16) {
+        const uint32_t ng = (uint32_t)s->grey_depth, cellsw = ((ng + 1) * (ng + 1) + 1) / 2;
+        L.ng_cap = ng; L.app = 4;
+        uint32_t goff = shared0;
+        L.P = goff; goff = align16(goff + 4u * 4u * cellsw);
+        L.gscr = goff; goff = align16(goff + 8u * (ng + 2u * kMaxAngles * 32u + kMaxAngles * ng));   // (unused) | features | sums | row marginals
+        if (goff > off) off = goff;
+    } else if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         auto glcm_bytes = [&](uint32_t ng, uint32_t app) -> size_t {
             return (size_t)align16(4u * app * ng * ng) + 8ull * (25ull * ng + 128);

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "launch_util.h"
@@ -524,6 +525,166 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     wav_sync<false>();
 }
 
+// ---- GLCM features of a matrix of up to 64 levels: one wave per angle, lane = column (the reference's default grey depth) ----
+// Same organisation as glcm_features_wave16 (marginal sums carry everything they can, only ASM / ACOR / ENTROPY / JMAX / the
+// covariance term / HXY1 / HXY2 visit the cells), on the 16-bit matrices of the G16 launches: element (centre, neighbour) of
+// level values 1..Ng sits at P[centre * S + neighbour], S = Ng + 1 (row 0 / column 0 collect the skipped pairs).
+// Level values are I[i] = i + 1 (matlab binning).  prow_s: [Ng] doubles of LDS (row marginals, broadcast to the lanes per row).
+__device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int Ng, double* prow_s, double soft_nan, double* f, double* sm, int lane)
+{
+    const int S = Ng + 1;
+    const bool act = lane < Ng;                        // lane l owns column l, row l and the diagonal pair |x - y| = l
+    uint32_t cc = 0, rc = 0, dc = 0;
+    if (act) {
+        const uint16_t* pc = P + S + lane + 1;         // (row 1, column lane + 1)
+        const uint16_t* pr = P + (lane + 1) * S + 1;   // (row lane + 1, column 1)
+        for (int j = 0; j < Ng; j++) {
+            cc += pc[j * S];
+            rc += pr[j];
+        }
+        for (int x = lane; x < Ng; x++) {
+            dc += P[(x + 1) * S + (x - lane) + 1];
+            if (lane > 0)
+                dc += P[(x - lane + 1) * S + x + 1];
+        }
+    }
+    const uint32_t l1 = (uint32_t)lane + 1u;
+    const uint32_t csum = wave_sum_t<uint32_t>(rc);    // sum_p (glcm.cpp:481-484)
+    const uint32_t Sr_i = wave_sum_t<uint32_t>(rc * l1), Sc_i = wave_sum_t<uint32_t>(cc * l1);
+    const uint32_t con_i = wave_sum_t<uint32_t>(dc * (uint32_t)(lane * lane)), dis_i = wave_sum_t<uint32_t>(dc * (uint32_t)lane);
+    const bool empty = csum == 0;
+    const double sum_p = empty ? 1.0 : (double)csum;
+    const double inv_sum_p = fdiv(1.0, sum_p);
+    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
+    const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
+    if (act) prow_s[lane] = prow;
+    // p_{x+y}: lane k owns k and k + 64 (k <= 2 Ng - 2)
+    double pxpy[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = lane + 64 * u;
+        if (k < 2 * Ng - 1) {
+            uint32_t c = 0;
+            const int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
+            for (int x = x0; x <= x1; x++)
+                c += P[(x + 1) * S + (k - x) + 1];
+            pxpy[u] = fdiv((double)c, sum_p);
+        }
+    }
+    wav_sync<false>();
+
+    // ---- the cell pass: lane = column, rows in sequence ------------------------------------------------------------------------
+    double asm_ = 0, ent = 0, hxy1 = 0, hxy2 = 0, cov = 0, jmax = -1;
+    uint32_t acor_i = 0, rc1 = 0;
+    const double dcl = (double)l1 - mc;
+    const uint16_t* pcell = P + S + lane + 1;
+    for (int r = 0; r < Ng; r++) {
+        const uint32_t cnt = act ? pcell[r * S] : 0u;
+        const double pr = prow_s[r];
+        rc1 += l1;                                                   // (r + 1) * (c + 1)
+        const double p = (double)cnt * inv_sum_p;
+        asm_ = __builtin_fma(p, p, asm_);                            // f_asm :555 / f_energy :927-928
+        acor_i += cnt * rc1;                                         // f_GLCM_ACOR :961 (integer-exact)
+        ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);       // f_entropy :734-735, JE :1160-1161, HXY :868
+        jmax = p > jmax ? p : jmax;                                  // f_GLCM_JMAX :1178-1179
+        cov = __builtin_fma(((double)(r + 1) - mr) * dcl, p, cov);   // f_corr :633
+        const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
+        const double lg = (double)fast_log2f(pp + 0.000000001);
+        hxy1 = __builtin_fma(p, lg, hxy1);
+        hxy2 = __builtin_fma(pp, lg, hxy2);
+    }
+    const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
+    {
+        double t8[8] = {asm_, ent, hxy1, hxy2, cov, hx_t, 0.0, 0.0};
+        const double tot = wave_transpose_sum8(t8, lane);            // lane L holds the total of slot (L >> 3) & 7
+        if ((lane & 7) == 0) sm[lane >> 3] = tot;
+    }
+    jmax = wave_max_nonneg(jmax < 0 ? 0.0 : jmax);
+    acor_i = wave_sum_t<uint32_t>(acor_i);
+
+    // ---- one term per lane: features of the marginal distributions -----------------------------------------------------------
+    double t16[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t16[k] = 0.0;
+    if (act) {
+        const double dr = (double)l1 - mr, dr2 = dr * dr;
+        t16[0] = prow * dr2;                                         // f_corr :617
+        t16[1] = pcol * (dcl * dcl);                                 // :626
+        t16[2] = (double)rc * dr2;                                   // f_var :672
+        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
+        const double q = pxmy, kd = (double)lane, Ngd = (double)Ng;
+        t16[4] = fdiv(q, (double)(1 + lane * lane));                 // f_idm :685-687
+        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
+        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
+        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
+        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
+        t16[9] = lane >= 1 ? q / (kd * kd) : 0.0;                    // :1123-1128
+        t16[10] = kd * q;                                            // f_difference_avg :791-792
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = lane + 64 * u;
+        if (k < 2 * Ng - 1) {
+            const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
+            t16[11] += ks * q;                                       // f_savg :700-701
+            t16[12] += plogp(q, q);                                  // f_sentropy :712-716
+            const double m = ks - mc - mc, m2 = m * m;               // by_row_mean (:531-536) = mc; CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+            t16[13] += m2 * m2 * q;
+            t16[14] += m2 * m * q;
+            t16[15] += m2 * q;
+        }
+    }
+    {
+        const double tot = wave_transpose_sum16(t16, lane);          // lane L holds the total of slot (L >> 2) & 15
+        if ((lane & 3) == 0) sm[8 + (lane >> 2)] = tot;
+    }
+    wav_sync<false>();
+    const double davg = sm[8 + 10];
+    double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
+    if (act) { const double dk = (double)lane - davg; dv = dk * dk * pxmy; }
+    dv = wave_sum(dv);
+
+    if (lane == 0) {
+        const double asm_t = sm[0], ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], cov_t = sm[4], hx = sm[5];
+        f[G_ASM] = asm_t;
+        f[G_ENERGY] = asm_t;
+        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
+        f[G_ACOR] = fdiv((double)acor_i, sum_p);
+        f[G_ENTROPY] = -ent_t;
+        f[G_JE] = -ent_t;
+        f[G_DIS] = fdiv((double)dis_i, sum_p);
+        f[G_JMAX] = jmax;
+        f[G_JAVE] = mr;
+        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
+        f[G_CLUPROM] = sm[8 + 13];
+        f[G_CLUSHADE] = sm[8 + 14];
+        f[G_CLUTEND] = sm[8 + 15];
+        f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
+        f[G_JVAR] = sm[8 + 3];
+        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
+        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
+        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
+        f[G_IDM] = sm[8 + 4];
+        f[G_HOM2] = sm[8 + 4];
+        f[G_HOM1] = sm[8 + 7];
+        f[G_SUMAVERAGE] = sm[8 + 11];
+        f[G_SUMENTROPY] = -sm[8 + 12];
+        f[G_DIFENTRO] = -sm[8 + 5];
+        f[G_DIFAVE] = davg;
+        f[G_DIFVAR] = dv;
+        f[G_IDMN] = sm[8 + 6];
+        f[G_ID] = sm[8 + 7];
+        f[G_IDN] = sm[8 + 8];
+        f[G_IV] = sm[8 + 9];
+        const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
+        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+        if (empty)                                    // blank matrix: all 30 values = soft NaN (glcm.cpp:260-295)
+            for (int k = 0; k < kGlcmAngled; k++)
+                f[k] = soft_nan;
+    }
+    wav_sync<false>();
+}
+
 // Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
 // workgroup adds the cycles spent between consecutive stamps to A.stamps[phase].  The
 // product build compiles the macro away.
@@ -554,7 +715,7 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
 // switches are compile-time facts there and their branches disappear from the pixel loops.
 // TIER: occupancy tier of the calling kernel; it only tags the kernel's private copy of glcm_features_rows (kRowsTag), so
 // that caller and callee are always compiled for the same register budget.
-template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4>
+template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -612,6 +773,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // grey binning used by the co-occurrence scan (glcm.cpp:354,379-385)
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
     if (FAST) __builtin_assume(greyInfo > 0 && greyInfo <= 16);
+    if (G16) __builtin_assume(greyInfo > 16 && greyInfo <= 64);     // G16: matlab binning, 17..64 levels, 16-bit matrices (see the GLCM block)
     const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)vmax - 0.) : 0.0;
 
     // ---- phase 0: clear LDS state; the output row is written in place (zeros first: features that are skipped stay 0; every
@@ -695,7 +857,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             if (do_glcm) {
                 uint32_t lvl = 0;
                 if (NZ || v[u] != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
-                    if (FAST) {         // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already
+                    if (FAST || G16) {  // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already
                         const uint32_t sc = (uint32_t)floor(mslope * (double)v[u] + 1.0);
                         lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
                     } else
@@ -1243,6 +1405,102 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         } else if (too_big) {
             for (int c = tid; c < ncol_g; c += kBlock)
                 o[c] = __longlong_as_double(0x7ff8000000000000LL);
+        } else if (G16) {
+            // ---- the reference's default grey depth (17..64 matlab levels) --------------------------------------------------------
+            // Four 64 x 64 u32 matrices are 64 KiB of LDS: one workgroup per CU, four waves to hide every latency.  A cell count is
+            // below 65536 here (the launch's ROIs have < 32768 pixels), so the matrices hold 16-bit cells, two per word, added to
+            // with a shifted increment (halves never carry); order Ng + 1, indexed by the level itself -- column 0 takes the pairs
+            // with a skipped neighbour, as in the split launches.  With the marginal-based feature routine (no 25 Ng doubles of
+            // scratch per angle) the carve-out drops from ~87 to ~43 KiB: three workgroups per CU.
+            const int NG1 = Ng + 1, cellsw = (NG1 * NG1 + 1) >> 1;    // words per matrix
+            const bool symmetric = A.glcm_symmetric != 0;
+            double* s_sum = s_f + kMaxAngles * 32;
+            double* s_prow = s_sum + kMaxAngles * 32;                 // [kMaxAngles][Ng]
+            blk_sync<GS>();
+            for (int i = tid; i < na * cellsw; i += kBlock)
+                s_P[i] = 0;
+            blk_sync<GS>();
+            STAMP(10);
+            auto bump16 = [&](uint32_t* M, uint32_t idx) { atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
+            if (A.glcm_offset == 1 && w <= 64) {
+                int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+                for (int q = 0; q < kMaxAngles; q++)
+                    if (q < na) {
+                        const int ang = A.glcm_angles[q];
+                        if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                    }
+                const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                const int r_begin = wave * rows_per_wave;
+                const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                const bool in_col = lane < (int)w;
+                uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
+                for (int row = r_begin; row < r_end; row++) {
+                    const uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                    const uint32_t nb_e = lane_plus1_z(cur), nb_se = lane_plus1_z(nxt), nb_sw = lane_minus1_z(nxt);
+                    if (cur != 0) {
+                        const uint32_t rowi = cur * (uint32_t)NG1;
+                        if (slot0 >= 0) bump16(s_P + slot0 * cellsw, rowi + nb_e);
+                        if (slot1 >= 0) bump16(s_P + slot1 * cellsw, rowi + nb_se);
+                        if (slot2 >= 0) bump16(s_P + slot2 * cellsw, rowi + nxt);
+                        if (slot3 >= 0) bump16(s_P + slot3 * cellsw, rowi + nb_sw);
+                        if (symmetric) {
+                            if (slot0 >= 0) bump16(s_P + slot0 * cellsw, nb_e * (uint32_t)NG1 + cur);
+                            if (slot1 >= 0) bump16(s_P + slot1 * cellsw, nb_se * (uint32_t)NG1 + cur);
+                            if (slot2 >= 0) bump16(s_P + slot2 * cellsw, nxt * (uint32_t)NG1 + cur);
+                            if (slot3 >= 0) bump16(s_P + slot3 * cellsw, nb_sw * (uint32_t)NG1 + cur);
+                        }
+                    }
+                    cur = nxt;
+                }
+            } else {
+                for (int row = wave; row < (int)h; row += kWaves)
+                    for (int col = lane; col < (int)w; col += 64) {
+                        const uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
+                        if (lb == 0)
+                            continue;
+#pragma unroll
+                        for (int q = 0; q < kMaxAngles; q++) {
+                            if (q >= na)
+                                break;
+                            const int ang = A.glcm_angles[q];                 // glcm.cpp:234-255
+                            const int dx = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset, dy = ang == 0 ? 0 : A.glcm_offset;
+                            const int r2 = row + dy, c2 = col + dx;
+                            if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
+                                continue;
+                            const uint32_t la = s_dense[(uint32_t)r2 * w + (uint32_t)c2];
+                            if (la == 0)
+                                continue;
+                            bump16(s_P + q * cellsw, lb * (uint32_t)NG1 + la);
+                            if (symmetric)
+                                bump16(s_P + q * cellsw, la * (uint32_t)NG1 + lb);
+                        }
+                    }
+            }
+            blk_sync<GS>();
+            STAMP(11);
+            if (wave < na)
+                glcm_features_wave64_u16((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_prow + (size_t)wave * Ng, A.soft_nan, s_f + wave * 32,
+                                         s_sum + wave * 32, lane);
+            blk_sync<GS>();
+            STAMP(12);
+            for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
+                int k = c / na, a = c - k * na;
+                o[c] = s_f[a * 32 + k];
+            }
+            for (int j = tid; j < kGlcmAve; j += kBlock) {               // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+                int k = c_glcm_ave_order[j];
+                double init = 0.0;
+                int a = 0;
+                for (; na - a >= 4; a += 4) {
+                    double v1 = s_f[a * 32 + k] + s_f[(a + 1) * 32 + k];
+                    double v2 = s_f[(a + 2) * 32 + k] + s_f[(a + 3) * 32 + k];
+                    init = init + (v1 + v2);
+                }
+                for (; a < na; a++)
+                    init = init + s_f[a * 32 + k];
+                o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+            }
         } else {
             const int NN = Ng * Ng;
             const bool symmetric = A.glcm_symmetric || greyInfo <= 0; // glcm.cpp:475
@@ -1483,6 +1741,12 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
     roi_features_body<false, true, FAM == 1, true, FAM, 8>(A);
 }
 
+// the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
+__global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiArgs A)
+{
+    roi_features_body<false, true, false, true, 0, 9, true>(A);
+}
+
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
 // One wave per ROI, the four angles in the wave's four DPP rows (glcm_features_rows<.., 16>), four ROIs per workgroup: every
 // lane of every wave works, where the same code inside roi_features_kernel leaves three of four waves waiting.  Input: the
@@ -1589,6 +1853,14 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     if (a.sp.scratch) {
         if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
         else hipLaunchKernelGGL((roi_features_kernel<true, false, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] features launch: g16 %u dense8 %u cnt16 %u ng_cap %u app %u total %u mask %u gd %d\n", a.L.g16, a.L.dense8, a.L.cnt16, a.L.ng_cap, a.L.app, a.L.total, a.mask, a.grey_depth);
+    if (a.L.g16) {
+        static DeviceOnce optin;
+        if (int orc = optin.run([]() -> int { return (int)hipFuncSetAttribute((const void*)roi_features_kernel_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); }))
+            return orc;
+        hipLaunchKernelGGL(roi_features_kernel_g16, dim3(grid), dim3(kBlock), a.L.total, st, a);
         return (int)hipGetLastError();
     }
     const bool split = a.glcm_ws != nullptr;

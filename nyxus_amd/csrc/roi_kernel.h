@@ -44,6 +44,7 @@ struct LdsLayout {
     uint32_t ng_cap;     // max GLCM matrix order held in LDS
     uint32_t lvl_cap;    // number of radiomics bins
     uint32_t app;        // angles per co-occurrence pass (4, 2 or 1)
+    uint32_t g16;        // 1: matlab binning with 17..64 levels, 16-bit co-occurrence cells, marginal-based features (roi_features_kernel_g16)
 };
 
 struct RoiArgs {

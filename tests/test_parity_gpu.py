@@ -586,3 +586,29 @@ def test_gabor_fused_variant_matches_on_noisy_fields():
             subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=dict(os.environ, **env))
             out[tag] = np.load(path)
     assert np.array_equal(out["exact"], out["fused"])
+
+
+# ---- the reference's default grey depth (17..64 matlab levels): 16-bit matrices + marginal-based features (roi_features_kernel_g16) ----
+@pytest.mark.parametrize("irregular", [False, True])
+@pytest.mark.parametrize("gd", [64, 33, 17])
+def test_benchmark_tile_default_grey_depth(hip_ctx, gd, irregular):
+    b = synth.tile_batch(2, irregular=irregular)
+    s = _abi.default_settings(gd)
+    G = _check(hip_ctx, b, MASK, s)
+    assert G.shape == (196, 185)
+
+
+@pytest.mark.parametrize("gd,na,sym,offset,mask", [(64, 4, 0, 1, MASK), (40, 3, 1, 1, MASK), (64, 2, 0, 2, MASK), (17, 1, 1, 3, _abi.FAM_GLCM),
+                                                   (64, 4, 0, 1, _abi.FAM_GLCM), (50, 4, 1, 1, _abi.FAM_GLCM)])
+def test_default_grey_depth_variants(hip_ctx, gd, na, sym, offset, mask):
+    """Small-range ROIs (so that the 16-bit launch is the one taken), angle subsets, symmetric matrices, offsets beyond 1 (the
+    generic sweep of the 16-bit path), GLCM alone; zero-valued pixels, constant and blank ROIs come with random_rois."""
+    rois = synth.random_rois(90, seed=23, value_modes=(4096, 256, 8, 1000))
+    rois.append(dict(x=list(range(70)) * 3, y=[0] * 70 + [1] * 70 + [2] * 70, inten=list(np.random.default_rng(1).integers(1, 500, 210))))   # wider than one wave
+    s = _abi.default_settings(gd)
+    s.glcm_n_angles = na
+    for i, a in enumerate((0, 45, 90, 135)[4 - na:]):
+        s.glcm_angles[i] = a
+    s.glcm_symmetric = sym
+    s.glcm_offset = offset
+    _check(hip_ctx, _abi.batch_from_rois(rois), mask, s)
