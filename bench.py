@@ -417,6 +417,25 @@ def main():
                                 "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                         "compaction, cloud assembly, then the same reduce kernels (one host sync inside for the ROI count)"}
+            # CPU baseline of THIS leg: the reference's in-memory workflow end to end (its two serial label scans with a hash-map
+            # lookup per pixel + ROI buffers + the multithreaded reduce) on a bounded sample of the same tiles
+            if not a.no_cpu_baseline:
+                from oracle import pyoracle as po
+                if po.have_ref():
+                    cores = os.cpu_count() or 1
+                    thr = max(1, min(cores, 32))
+                    ns = min(nt, 16)
+                    tmc = []
+                    c0 = time.perf_counter()
+                    _, cl, _ = po.ref_featurize_tiles(tin[:ns].cpu().numpy().view(np.uint32), labs[:ns].cpu().numpy().view(np.uint32), mask, s,
+                                                      n_threads=thr, timing=tmc)
+                    wall = time.perf_counter() - c0
+                    rec["tile_path"]["cpu_baseline"] = {
+                        "value": len(cl) / (tmc[0] + tmc[1]), "unit": "ROIs/s", "cores": thr, "kind": "reference", "host_cpus": cores,
+                        "scan_seconds": tmc[0], "reduce_seconds": tmc[1], "wall_seconds": wall,
+                        "sample": f"{ns} of the same tiles ({len(cl)} ROIs): the reference's in-memory workflow per image pair -- phase-1 and phase-2 "
+                                  "label scans (serial, hash-map lookup per pixel: phase1.cpp:373-409, phase2_2d.cpp:637-684), ROI buffers, then "
+                                  f"the runParallel reduce with {thr} threads (oracle/ref_driver.cpp nyxref_featurize_tiles)"}
             # PCIe-inclusive variants (what Nyxus.featurize() pays): host tiles in, host table out, through the chunked
             # copy / compute pipeline of nyxhip_featurize_tiles_v2 -- uint32 tiles, and the same images in the element types a
             # microscope hands over (uint16 intensities, uint8 labels: H2D carries 3 B per pixel instead of 8)

@@ -54,11 +54,15 @@ struct nyxhip_ctx {
     size_t slot_bytes[2] = {0, 0};
     hipStream_t copy_stream = nullptr;         // H2D of the next chunk runs beside the kernels of the current one
     hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    WindowSrc win_next = {};                   // set by the tile path for its next launch_device call: read ROIs from their tile windows
     uint32_t tile_cap_hint = 0;                // per-tile table size that served the last call
-    // result kept for nyxhip_fetch_result() (host-memory calls with out_table == NULL)
-    std::vector<uint32_t> res_label, res_tile;
-    std::vector<double> res_table;
-    size_t res_cols = 0;
+    // result kept for nyxhip_fetch_result() (host-memory calls with out_table == NULL): device-resident, grow-only
+    //   [res_cap x res_cols] doubles | [res_cap] labels | [res_cap] tile indices
+    void* d_res = nullptr;
+    size_t res_cap = 0, res_rows = 0, res_cols = 0;
+    double* res_table() const { return (double*)d_res; }
+    uint32_t* res_label() const { return (uint32_t*)((char*)d_res + (((size_t)res_cap * res_cols * 8 + 255) & ~(size_t)255)); }
+    uint32_t* res_tile() const { return res_label() + res_cap; }
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -625,6 +629,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         a.slide_min = b->slide_min; a.slide_max = b->slide_max;
         a.out = d_out; a.ld = ld; a.status = ctx->d_status;
         a.stamps = ctx->d_stamps;
+        if (cap == 0) a.win = ctx->win_next;   // LDS launches only (the tile path asks for windows only when everything fits LDS)
         a.mask = mask1; a.n_cols = n_cols1;
         int c = 0;
         a.col_intensity = a.col_glcm = -1;
@@ -1036,6 +1041,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_tile) (void)hipFree(ctx->d_tile);
     if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
+    if (ctx->d_res) (void)hipFree(ctx->d_res);
     for (int k = 0; k < 2; k++) {
         if (ctx->d_slot[k]) (void)hipFree(ctx->d_slot[k]);
         if (ctx->slot_ready[k]) (void)hipEventDestroy(ctx->slot_ready[k]);
@@ -1225,11 +1231,11 @@ static int grow(nyxhip_ctx* ctx, void** p, size_t* have, size_t need, hipStream_
 
 static uint32_t log2u(uint32_t v) { uint32_t k = 0; while ((1u << k) < v) k++; return k; }
 
-// Per-tile table size to start with: room for one ROI per 512 pixels (a 1024 x 1024 tile: 2048 slots for ~200 ROIs); a tile
+// Per-tile table size to start with: one slot per 1024 pixels (a 1024 x 1024 tile: 1024 slots for ~200 ROIs); a tile
 // with more labels than slots makes the scan raise the overflow flag and the chunk is rescanned with four times the slots.
 static uint32_t first_tile_cap(uint64_t tile_px)
 {
-    uint64_t c = tile_px / 512;
+    uint64_t c = tile_px / 1024;
     if (c < 256) c = 256;
     if (c > (1u << 22)) c = 1u << 22;
     return pow2ceil((uint32_t)c);
@@ -1318,15 +1324,26 @@ static int tiles_chunk(nyxhip_ctx* ctx, const void* d_inten, int dtI, const void
     *n_roi_out = n_roi;
     if (n_roi == 0 || n_roi > rows_cap) return NYXHIP_OK;
     const uint64_t npx = ((uint64_t)meta[2] << 32) | meta[1];
-    // clouds (8 B per ROI pixel) for the reduce kernels
+    // INTENSITY / GLCM alone, every ROI LDS-sized: the feature kernel reads the ROIs' windows of the tiles itself and no cloud is
+    // materialised (8 B per ROI pixel written and read back otherwise).  Any other family, or ROIs beyond LDS: clouds.
+    static const bool no_window = [] { const char* e = getenv("NYXHIP_NO_WINDOW"); return e && *e && *e != '0'; }();   // A/B and tests
+    bool window = !no_window && (family_mask & ~(uint32_t)(NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) == 0;
+    if (window) {
+        LdsLayout Lt; std::string why_t;
+        window = make_layout(family_mask, s, nyxhip_n_columns(family_mask, s), meta[3], meta[4], meta[5], Lt, why_t) == NYXHIP_OK;
+    }
     size_t c = 0;
     const size_t o_cx = c; c = al(c + 2 * npx);
     const size_t o_cy = c; c = al(c + 2 * npx);
     const size_t o_cv = c; c = al(c + 4 * npx);
-    if (int grc = grow(ctx, &ctx->d_cloud, &ctx->cloud_bytes, c, st)) return grc;
-    char* cb = (char*)ctx->d_cloud;
-    int rc = launch_tile_clouds(d_inten, dtI, d_label, dtL, W, H, R, (uint32_t)n_roi, (uint16_t*)(cb + o_cx), (uint16_t*)(cb + o_cy), (uint32_t*)(cb + o_cv), st);
-    if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    char* cb = nullptr;
+    int rc = 0;
+    if (!window) {
+        if (int grc = grow(ctx, &ctx->d_cloud, &ctx->cloud_bytes, c, st)) return grc;
+        cb = (char*)ctx->d_cloud;
+        rc = launch_tile_clouds(d_inten, dtI, d_label, dtL, W, H, R, (uint32_t)n_roi, (uint16_t*)(cb + o_cx), (uint16_t*)(cb + o_cy), (uint32_t*)(cb + o_cv), st);
+        if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_lab, R.label, 4 * n_roi, hipMemcpyDeviceToDevice, st));
     if (d_til) {
         if (tile_base == 0) HIP_TRY(ctx, hipMemcpyAsync(d_til, R.tile, 4 * n_roi, hipMemcpyDeviceToDevice, st));
@@ -1335,11 +1352,15 @@ static int tiles_chunk(nyxhip_ctx* ctx, const void* d_inten, int dtI, const void
     nyxhip_batch b;
     memset(&b, 0, sizeof(b));
     b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
-    b.x = (const uint16_t*)(cb + o_cx); b.y = (const uint16_t*)(cb + o_cy); b.inten = (const uint32_t*)(cb + o_cv);
+    if (!window) { b.x = (const uint16_t*)(cb + o_cx); b.y = (const uint16_t*)(cb + o_cy); b.inten = (const uint32_t*)(cb + o_cv); }
     b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
     b.slide_min = R.slide_min; b.slide_max = R.slide_max;
     b.memory = NYXHIP_MEM_DEVICE;
-    return launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+    if (window)
+        ctx->win_next = WindowSrc{d_inten, d_label, dtI, dtL, W, H, R.tile, R.label, R.bbox_x0, R.bbox_y0};
+    const int lrc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+    ctx->win_next = WindowSrc{};
+    return lrc;
 }
 
 static int tiles_validate(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint64_t* n_roi_out)
@@ -1359,9 +1380,34 @@ static int tiles_validate(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t famil
     return NYXHIP_OK;
 }
 
+// Room for `rows` result rows of n_cols columns in the context's device-resident result (rows already there are kept).
+static int res_reserve(nyxhip_ctx* ctx, size_t rows, size_t n_cols, hipStream_t st)
+{
+    if (ctx->d_res && ctx->res_cols == n_cols && rows <= ctx->res_cap) return NYXHIP_OK;
+    const bool carry = ctx->d_res && ctx->res_cols == n_cols && ctx->res_rows > 0;
+    const size_t cap = std::max(rows, carry ? ctx->res_cap * 2 : (size_t)0);
+    const size_t bytes = (((size_t)cap * n_cols * 8 + 255) & ~(size_t)255) + 8 * cap + 256;
+    void* nb = nullptr;
+    HIP_TRY(ctx, hipMalloc(&nb, bytes));
+    void* const od = ctx->d_res;
+    const double* o_tab = od ? ctx->res_table() : nullptr;
+    const uint32_t* o_lab = od ? ctx->res_label() : nullptr;
+    const uint32_t* o_til = od ? ctx->res_tile() : nullptr;
+    const size_t o_rows = ctx->res_rows;
+    ctx->d_res = nb; ctx->res_cap = cap; ctx->res_cols = n_cols;
+    if (carry) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->res_table(), o_tab, o_rows * n_cols * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->res_label(), o_lab, o_rows * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->res_tile(), o_til, o_rows * 4, hipMemcpyDeviceToDevice, st));
+    } else
+        ctx->res_rows = 0;
+    if (od) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(od)); }
+    return NYXHIP_OK;
+}
+
 // The whole stack in chunks.  label_limit: v1's max_label (validated only).
 static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint32_t* out_labels, uint32_t* out_tile_index,
-                     uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit)
+                     uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit, uint32_t tile_index_base = 0)
 {
     if (int vrc = tiles_validate(ctx, t, family_mask, s, n_roi_out)) return vrc;
     const int n_cols = nyxhip_n_columns(family_mask, s);
@@ -1391,7 +1437,7 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
     if (host && t->n_tiles >= 4 && chunk > (t->n_tiles + 1) / 2) chunk = (t->n_tiles + 1) / 2;                 // at least two chunks to overlap
     while ((uint64_t)chunk * cap0 > (1ull << 30) && chunk > 1) chunk /= 2;
 
-    if (keep) { ctx->res_label.clear(); ctx->res_tile.clear(); ctx->res_table.clear(); ctx->res_cols = (size_t)n_cols; }
+    if (keep) ctx->res_rows = 0;
     uint64_t rows_done = 0;
     bool short_out = false;
     if (!host) {
@@ -1433,8 +1479,6 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         const uint64_t t0 = c * chunk;
         const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
         if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
-        // (pageable source: the runtime stages / pins on the fly, 20-45 GB/s measured; a hand-rolled pinned double buffer filled
-        // by host threads was slower on the same arrays -- 15-31 GB/s -- and is not used)
         HIP_TRY(ctx, hipMemcpyAsync(slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype,
                                     hipMemcpyHostToDevice, ctx->copy_stream));
         HIP_TRY(ctx, hipMemcpyAsync(slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype,
@@ -1442,9 +1486,19 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
         return NYXHIP_OK;
     };
+    // Pin the caller's arrays for the call: a pinned source makes the chunk copies true DMA transfers that overlap the kernels
+    // (50-57 GB/s measured); left pageable, an asynchronous copy goes through the runtime's staging path at 8-20 GB/s.  The
+    // runtime keeps the pinning cached across calls on the same buffer (first call ~22 us/MB, later ones ~0.01 ms).
+    struct Pin {
+        void* p[2] = {nullptr, nullptr};
+        ~Pin() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
+    } pin;
+    {
+        const size_t bi = (size_t)t->n_tiles * tile_px * t->inten_dtype, bl = (size_t)t->n_tiles * tile_px * t->label_dtype;
+        if (hipHostRegister((void*)t->inten, bi, hipHostRegisterDefault) == hipSuccess) pin.p[0] = (void*)t->inten; else (void)hipGetLastError();
+        if (hipHostRegister((void*)t->label, bl, hipHostRegisterDefault) == hipSuccess) pin.p[1] = (void*)t->label; else (void)hipGetLastError();
+    }
     if (int urc = upload(0)) return urc;
-    // per-chunk device outputs: labels, tile indices, table (grow-only, part of the cloud workspace is not reusable: separate block)
-    std::vector<uint32_t> h_lab, h_til;
     for (uint64_t c = 0; c < n_chunks; c++) {
         const int k = (int)(c & 1);
         const uint64_t t0 = c * chunk;
@@ -1457,28 +1511,30 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         size_t need = (size_t)est_rows * (8 * (size_t)n_cols + 8) + 1024;
         int rc;
         for (;;) {
-            if (int grc = ensure_stage(ctx, need)) return grc;
-            const uint64_t cap_rows = (ctx->stage_bytes - 1024) / (8 * (size_t)n_cols + 8);
-            double* d_out = (double*)ctx->d_stage;
-            uint32_t* d_lab = (uint32_t*)((char*)ctx->d_stage + (((size_t)cap_rows * 8 * n_cols + 255) & ~(size_t)255));
-            uint32_t* d_til = d_lab + cap_rows;
+            uint64_t cap_rows;
+            double* d_out; uint32_t *d_lab, *d_til;
+            if (keep) {                                   // rows are appended to the context's device-resident result: no copy, no sync per chunk
+                if (int grc = res_reserve(ctx, (size_t)(rows_done + std::max<uint64_t>(est_rows, n)), (size_t)n_cols, st)) return grc;
+                cap_rows = ctx->res_cap - rows_done;
+                d_out = ctx->res_table() + rows_done * (size_t)n_cols; d_lab = ctx->res_label() + rows_done; d_til = ctx->res_tile() + rows_done;
+            } else {
+                if (int grc = ensure_stage(ctx, need)) return grc;
+                cap_rows = (ctx->stage_bytes - 1024) / (8 * (size_t)n_cols + 8);
+                d_out = (double*)ctx->d_stage;
+                d_lab = (uint32_t*)((char*)ctx->d_stage + (((size_t)cap_rows * 8 * n_cols + 255) & ~(size_t)255));
+                d_til = d_lab + cap_rows;
+            }
             rc = tiles_chunk(ctx, slot_inten(k), t->inten_dtype, slot_label(k, nt), t->label_dtype, W, H, nt, t->slide_mode,
                              t->slide_min ? t->slide_min + t0 : nullptr, t->slide_max ? t->slide_max + t0 : nullptr, family_mask, s, cap_rows, d_lab, d_til,
-                             (uint32_t)t0, d_out, (size_t)n_cols, label_limit, &n, st);
+                             tile_index_base + (uint32_t)t0, d_out, (size_t)n_cols, label_limit, &n, st);
             if (rc) return rc;
             if (n > cap_rows) { HIP_TRY(ctx, hipStreamSynchronize(st)); need = (size_t)n * (8 * (size_t)n_cols + 8) + 4096; continue; }
             HIP_TRY(ctx, hipEventRecord(ctx->slot_free[k], st));
             if (c + 1 < n_chunks)
-                if (int urc = upload(c + 1)) return urc;                    // host-side copy of the next chunk runs beside this chunk's kernels
+                if (int urc = upload(c + 1)) return urc;                    // the next chunk's DMA runs beside this chunk's kernels
             const uint64_t room = rows_done < max_rows ? max_rows - rows_done : 0;
             if (keep) {
-                const size_t r0 = ctx->res_label.size();
-                ctx->res_label.resize(r0 + n); ctx->res_tile.resize(r0 + n); ctx->res_table.resize((r0 + n) * (size_t)n_cols);
-                if (n) {
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_table.data() + r0 * (size_t)n_cols, d_out, 8 * n * (size_t)n_cols, hipMemcpyDeviceToHost, st));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_label.data() + r0, d_lab, 4 * n, hipMemcpyDeviceToHost, st));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->res_tile.data() + r0, d_til, 4 * n, hipMemcpyDeviceToHost, st));
-                }
+                ctx->res_rows = (size_t)(rows_done + n);
             } else if (n <= room && !short_out) {
                 if (n) {
                     HIP_TRY(ctx, hipMemcpy2DAsync(out_table + rows_done * out_ld, out_ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),
@@ -1486,14 +1542,17 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
                     HIP_TRY(ctx, hipMemcpyAsync(out_labels + rows_done, d_lab, 4 * n, hipMemcpyDeviceToHost, st));
                     if (out_tile_index) HIP_TRY(ctx, hipMemcpyAsync(out_tile_index + rows_done, d_til, 4 * n, hipMemcpyDeviceToHost, st));
                 }
-            } else
+                HIP_TRY(ctx, hipStreamSynchronize(st));                     // the chunk's rows are on the host; d_stage is free for the next one
+            } else {
                 short_out = true;
-            HIP_TRY(ctx, hipStreamSynchronize(st));                         // the chunk's rows are on the host; d_stage is free for the next one
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+            }
             break;
         }
         rows_done += n;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     *n_roi_out = rows_done;
     if (short_out) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the stack (see *n_roi_out)");
     return check_status(ctx);
@@ -1508,13 +1567,17 @@ int nyxhip_featurize_tiles_v2(nyxhip_ctx* ctx, const nyxhip_tiles* tiles, uint32
 int nyxhip_fetch_result(nyxhip_ctx* ctx, uint32_t* out_labels, uint32_t* out_tile_index, double* out_table, size_t out_ld)
 {
     if (!ctx) return NYXHIP_ERR_INVALID_ARG;
-    const size_t n = ctx->res_label.size(), nc = ctx->res_cols;
+    const size_t n = ctx->res_rows, nc = ctx->res_cols;
     if (n && (!out_labels || !out_table || out_ld < nc)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null output pointers or out_ld smaller than the column count");
-    for (size_t r = 0; r < n; r++)
-        memcpy(out_table + r * out_ld, ctx->res_table.data() + r * nc, nc * sizeof(double));
-    if (n) memcpy(out_labels, ctx->res_label.data(), 4 * n);
-    if (n && out_tile_index) memcpy(out_tile_index, ctx->res_tile.data(), 4 * n);
-    std::vector<uint32_t>().swap(ctx->res_label); std::vector<uint32_t>().swap(ctx->res_tile); std::vector<double>().swap(ctx->res_table);
+    if (n) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream();
+        HIP_TRY(ctx, hipMemcpy2DAsync(out_table, out_ld * sizeof(double), ctx->res_table(), nc * sizeof(double), nc * sizeof(double), n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(out_labels, ctx->res_label(), 4 * n, hipMemcpyDeviceToHost, st));
+        if (out_tile_index) HIP_TRY(ctx, hipMemcpyAsync(out_tile_index, ctx->res_tile(), 4 * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    ctx->res_rows = 0;                                 // (the device block is kept for the next call)
     return NYXHIP_OK;
 }
 
@@ -1537,7 +1600,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
     const uint64_t q = tiles->n_tiles / G, r = tiles->n_tiles % G;
     for (int g = 0; g < G; g++) lo[g + 1] = lo[g] + q + ((uint64_t)g < r ? 1 : 0);
     const uint64_t tile_px = (uint64_t)tiles->width * tiles->height;
-    for (int g = 0; g < n_ctx; g++) { std::vector<uint32_t>().swap(ctxs[g]->res_label); std::vector<uint32_t>().swap(ctxs[g]->res_tile); std::vector<double>().swap(ctxs[g]->res_table); }
+    for (int g = 0; g < n_ctx; g++) ctxs[g]->res_rows = 0;
     std::vector<std::thread> th;
     for (int g = 0; g < G; g++)
         th.emplace_back([&, g]() {
@@ -1548,8 +1611,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
             if (tiles->slide_min) part.slide_min = tiles->slide_min + lo[g];
             if (tiles->slide_max) part.slide_max = tiles->slide_max + lo[g];
             if (part.n_tiles == 0) { rcs[g] = 0; return; }
-            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu);
-            for (auto& ti : ctxs[g]->res_tile) ti += (uint32_t)lo[g];          // tile indices of the whole stack
+            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu, (uint32_t)lo[g]);   // tile indices of the whole stack
         });
     for (auto& t : th) t.join();
     for (int g = 0; g < G; g++)
@@ -1559,7 +1621,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
     *n_roi_out = total;
     if (keep) return NYXHIP_OK;
     if (total > max_rows) {
-        for (int g = 0; g < G; g++) { std::vector<uint32_t>().swap(ctxs[g]->res_label); std::vector<uint32_t>().swap(ctxs[g]->res_tile); std::vector<double>().swap(ctxs[g]->res_table); }
+        for (int g = 0; g < G; g++) ctxs[g]->res_rows = 0;
         return fail(c0, NYXHIP_ERR_INVALID_ARG, "max_rows is smaller than the number of ROIs in the stack (see *n_roi_out)");
     }
     return nyxhip_fetch_result_sharded(ctxs, n_ctx, out_labels, out_tile_index, out_table, out_ld);
@@ -1571,7 +1633,7 @@ int nyxhip_fetch_result_sharded(nyxhip_ctx* const* ctxs, int n_ctx, uint32_t* ou
     uint64_t row = 0;
     for (int g = 0; g < n_ctx; g++) {
         if (!ctxs[g]) return NYXHIP_ERR_INVALID_ARG;
-        const uint64_t n = ctxs[g]->res_label.size();
+        const uint64_t n = ctxs[g]->res_rows;
         if (n) {
             int rc = nyxhip_fetch_result(ctxs[g], out_labels + row, out_tile_index ? out_tile_index + row : nullptr, out_table + row * out_ld, out_ld);
             if (rc) return rc;

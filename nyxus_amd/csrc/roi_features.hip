@@ -877,7 +877,86 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
         if (TINY) { sum += s32; sumsq += q32; }
     };
-    {
+    if (!GS && A.win.inten != nullptr) {
+        // ---- window mode (fused tile path): the ROI's pixels are read straight from the tile -- the bounding-box window in
+        // row-major order, a pixel belongs to the ROI when its label matches -- instead of from a materialised cloud
+        // (roi_cloud_kernel wrote 8 B per ROI pixel that this pass then read back).  Every wave takes a contiguous quarter of
+        // the window; a label-only pre-pass counts each quarter's members so that a pixel's index in s_val is its rank in
+        // window order: exactly the index it has in the cloud, so all that follows is bit-identical to the batch path.
+        const uint32_t L = A.win.label[roi], x0 = A.win.x0[roi];
+        const uint64_t row0 = (uint64_t)A.win.tile[roi] * A.win.H + A.win.y0[roi];
+        const uint64_t org = row0 * A.win.W + x0;
+        const int dtl = A.win.dt_label, dti = A.win.dt_inten;
+        // element offsets inside the window stay below 2^32 (a tile has fewer pixels than that): one 64-bit base per ROI,
+        // 32-bit offsets per lane, advanced by a wave-uniform stride plus the row wrap
+        const char* const lab0 = (const char*)A.win.lab + org * (uint64_t)dtl;
+        const char* const int0 = (const char*)A.win.inten + org * (uint64_t)dti;
+        auto ld = [](const char* p, uint32_t i, int dt) -> uint32_t {
+            return dt == 4 ? ((const uint32_t*)p)[i] : dt == 2 ? (uint32_t)((const uint16_t*)p)[i] : (uint32_t)((const uint8_t*)p)[i];
+        };
+        const uint32_t Wt = A.win.W;
+        const uint32_t cw = ((area + kBlock - 1) / kBlock) * 64u;               // pixels per wave (a multiple of 64)
+        const uint32_t p_begin = (uint32_t)wave * cw, p_end = p_begin + cw < area ? p_begin + cw : area;
+        const uint32_t step_y = 64u / w, step_x = 64u - step_y * w;
+        const uint32_t step_o = step_y * Wt + step_x, wrap_o = Wt - w;          // offset advance per 64 pixels, extra when the column wraps
+        const uint32_t by0 = (p_begin + (uint32_t)lane) / w, bx0 = (p_begin + (uint32_t)lane) - by0 * w;
+        const uint32_t off0 = by0 * Wt + bx0;
+        uint32_t hits = 0;
+        {
+            uint32_t bx = bx0, o32 = off0;
+            for (uint32_t p = p_begin; p < p_end; p += 64) {
+                const bool in = p + (uint32_t)lane < p_end;
+                const uint32_t lb = in ? ld(lab0, o32, dtl) : 0u;
+                hits += (uint32_t)__popcll(__ballot(in && lb == L));
+                bx += step_x; o32 += step_o;
+                if (bx >= w) { bx -= w; o32 += wrap_o; }
+            }
+        }
+        uint32_t* const s_hits = (uint32_t*)(s_stat + 12);                      // (s_stat is free until the sums)
+        if (lane == 0) s_hits[wave] = hits;
+        blk_sync<GS>();
+        uint32_t rank0 = 0;
+        for (int wv = 0; wv < wave; wv++) rank0 += s_hits[wv];
+        const bool nz = vmin > 0;
+        uint32_t bx = bx0, by = by0, o32 = off0;
+        for (uint32_t p = p_begin; p < p_end; p += 64) {
+            const bool in = p + (uint32_t)lane < p_end;
+            const uint32_t lb = in ? ld(lab0, o32, dtl) : 0u;
+            const uint32_t v = in ? ld(int0, o32, dti) : 0u;
+            const bool hit = in && lb == L;
+            const unsigned long long bal = __ballot(hit);
+            const uint32_t i = rank0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            rank0 += (uint32_t)__popcll(bal);
+            if (hit && i < n) {
+                if (do_int) {
+                    if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
+                    else s_val[i] = v;
+                    sum += v;
+                    sumsq += small_v ? (uint32_t)__umul24(v, v) : (uint32_t)(v * v);
+                    if (use_count) {
+                        const uint32_t ci = v - vmin;
+                        if (C16) atomicAdd(&s_cnt[ci >> 1], 1u << (16 * (ci & 1u)));
+                        else atomicAdd(&s_cnt[ci], 1u);
+                    }
+                }
+                if (do_glcm) {
+                    uint32_t lvl = 0;
+                    if (nz || v != 0) {
+                        if (FAST || G16) {
+                            const uint32_t sc = (uint32_t)floor(mslope * (double)v + 1.0);
+                            lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
+                        } else
+                        lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+                        if (greyInfo < 0) s_lvlmap[lvl] = 1;
+                        if (greyInfo <= 0) lvl_max = lvl > lvl_max ? lvl : lvl_max;
+                    }
+                    s_dense[__umul24(by, w) + bx] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+                }
+            }
+            bx += step_x; by += step_y; o32 += step_o;
+            if (bx >= w) { bx -= w; by++; o32 += wrap_o; }
+        }
+    } else {
         using T = std::true_type; using F = std::false_type;
         const bool nz = vmin > 0, tiny = vmax < (1u << 15);
         uint32_t base = 0;

@@ -47,6 +47,19 @@ struct LdsLayout {
     uint32_t g16;        // 1: matlab binning with 17..64 levels, 16-bit co-occurrence cells, marginal-based features (roi_features_kernel_g16)
 };
 
+// Window source of the fused tile path: when `inten` is set the feature kernel reads an ROI's pixels from its bounding-box
+// window of the tile stack (label match) instead of from x / y / inten clouds.
+struct WindowSrc {
+    const void* inten;           // tile stack [n_tiles][H][W], element size dt_inten
+    const void* lab;             // label stack, element size dt_label
+    int32_t dt_inten, dt_label;
+    uint32_t W, H;
+    const uint32_t* tile;        // [n_roi] tile of the ROI
+    const uint32_t* label;       // [n_roi] its label value
+    const uint32_t* x0;          // [n_roi] bounding-box origin inside the tile
+    const uint32_t* y0;
+};
+
 struct RoiArgs {
     uint64_t n_roi;
     const uint64_t* px_offset;
@@ -77,6 +90,7 @@ struct RoiArgs {
     uint32_t* glcm_ng;       // [n_roi] matrix order of the ROI, 0 = nothing to derive (degenerate / skipped ROI)
     uint32_t glcm_ws_stride; // words per ROI = n_angles * ng_cap^2
     SpillArgs sp;
+    WindowSrc win;
     LdsLayout L;
 };
 

@@ -162,6 +162,10 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileHash T, uint64_t
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_wpx[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // an empty block (nine in ten at the usual load) only has bookkeeping to do when a tile starts in it or it is the last one
+    const bool has_tile_start = ((blockIdx.x * 1024ull) % T.cap == 0) || T.cap < 1024;
+    if (blk_rows[blockIdx.x] == 0 && !has_tile_start && blockIdx.x != gridDim.x - 1)
+        return;
     // rows / pixels of all preceding blocks
     uint32_t pre_r = 0; unsigned long long pre_p = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += 1024) { pre_r += blk_rows[b]; pre_p += blk_px[b]; }

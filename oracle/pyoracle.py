@@ -59,6 +59,9 @@ def ref_lib():
         lib.nyxref_featurize_batch.argtypes = [C.POINTER(_abi.Batch), C.c_uint32, C.POINTER(_abi.Settings),
                                                C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         lib.nyxref_featurize_batch.restype = C.c_int
+        lib.nyxref_featurize_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_abi.Settings), C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        lib.nyxref_featurize_tiles.restype = C.c_int
         _ref = lib
     return _ref
 
@@ -87,3 +90,29 @@ def ref_featurize(batch: _abi.HostBatch, mask: int, s: _abi.Settings, n_threads:
     if timing is not None:
         timing.append(sec.value)
     return out
+
+
+def ref_featurize_tiles(inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, n_threads: int = 1, max_rows: Optional[int] = None,
+                        timing: Optional[list] = None):
+    """The reference's in-memory workflow on a stack [n_tiles, H, W] of uint32 tiles, scans included (oracle/ref_driver.cpp
+    nyxref_featurize_tiles).  Returns (tile_index, labels, table); timing receives [scan_seconds, reduce_seconds]."""
+    lib = ref_lib()
+    inten = np.ascontiguousarray(inten, np.uint32)
+    label = np.ascontiguousarray(label, np.uint32)
+    nt, h, w = inten.shape
+    ncol = lib.nyxref_n_columns(mask, C.byref(s))
+    cap = int(max_rows) if max_rows is not None else 4096 * nt
+    labels = np.zeros(cap, np.uint32)
+    tiles = np.zeros(cap, np.uint32)
+    out = np.full((cap, ncol), np.nan, np.float64)
+    n = C.c_uint64(0)
+    sec = (C.c_double * 2)()
+    rc = lib.nyxref_featurize_tiles(inten.ctypes.data, label.ctypes.data, w, h, nt, mask, C.byref(s), n_threads, labels.ctypes.data, tiles.ctypes.data,
+                                    out.ctypes.data, ncol, cap, C.byref(n), sec)
+    if rc != 0:
+        raise RuntimeError(f"reference tile driver: status {rc}")
+    if n.value > cap:
+        raise RuntimeError(f"reference tile driver: {n.value} rows, room for {cap}")
+    if timing is not None:
+        timing.extend([sec[0], sec[1]])
+    return tiles[: n.value], labels[: n.value], out[: n.value]

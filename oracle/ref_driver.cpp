@@ -21,6 +21,8 @@
 #include <map>
 #include <vector>
 #include <unordered_map>
+#include <unordered_set>
+#include <algorithm>
 
 #include "roi_cache.h"
 #include "dataset.h"
@@ -97,6 +99,83 @@ inline void put_angled(double*& p, const std::vector<double>& v, size_t n)
         *p++ = i < v.size() ? v[i] : 0.0;
 }
 
+// reduce_trivial_rois_manual -> reduce_trivial_2d (reduce_trivial_rois.cpp:772-777, :62-413): one runParallel per requested family
+void reduce_ladder(uint32_t mask, int n_threads, std::vector<int>& L, std::unordered_map<int, LR>& roiData, const Fsettings& fst, const Dataset& ds)
+{
+    size_t jobSize = L.size(), workPerThread = jobSize / (size_t)n_threads;
+    if (mask & NYXHIP_FAM_INTENSITY)
+        runParallel(PixelIntensityFeatures::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & (NYXHIP_FAM_SMOMS | NYXHIP_FAM_IMOMS))   // the moments' dependency, reduce_trivial_rois.cpp:98-111
+        runParallel(ContourFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GLCM)
+        runParallel(GLCMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GLRLM)
+        runParallel(GLRLMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GLDZM)   // reduce_trivial_rois.cpp:215-220
+        runParallel(GLDZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GLSZM)
+        runParallel(GLSZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GLDM)    // :231-236
+        runParallel(GLDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_NGLDM)   // :239-244
+        runParallel(NGLDMfeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_NGTDM)
+        runParallel(NGTDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_GABOR)
+        runParallel(GaborFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_ZERNIKE)
+        runParallel(ZernikeFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_IMOMS)   // reduce_trivial_rois.cpp:320-325
+        runParallel(Imoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+    if (mask & NYXHIP_FAM_SMOMS)   // :326-331
+        runParallel(Smoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+}
+
+// one row in the table layout of save_features_2_buffer (enum order, angle expansion); raw values
+void put_row(const LR& lr, uint32_t mask, const nyxhip_settings* s, double* p)
+{
+    if (mask & NYXHIP_FAM_INTENSITY)
+        for (auto f : kIntensity) *p++ = lr.fvals[(int)f][0];
+    if (mask & NYXHIP_FAM_GLCM) {
+        size_t na = (size_t)s->glcm_n_angles;
+        for (int f = (int)Feature2D::GLCM_ASM; f <= (int)Feature2D::GLCM_VARIANCE; f++)
+            put_angled(p, lr.fvals[f], na);
+        for (int f = (int)Feature2D::GLCM_ASM_AVE; f <= (int)Feature2D::GLCM_SUMVARIANCE_AVE; f++)
+            *p++ = lr.fvals[f][0];
+    }
+    if (mask & NYXHIP_FAM_GLRLM) {
+        for (int f = (int)Feature2D::GLRLM_SRE; f <= (int)Feature2D::GLRLM_LRHGLE; f++)
+            put_angled(p, lr.fvals[f], 4);
+        for (int f = (int)Feature2D::GLRLM_SRE_AVE; f <= (int)Feature2D::GLRLM_LRHGLE_AVE; f++)
+            *p++ = lr.fvals[f][0];
+    }
+    if (mask & NYXHIP_FAM_GLDZM)
+        for (int f = (int)Feature2D::GLDZM_SDE; f <= (int)Feature2D::GLDZM_ZDE; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_GLSZM)
+        for (int f = (int)Feature2D::GLSZM_SAE; f <= (int)Feature2D::GLSZM_LAHGLE; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_GLDM)
+        for (int f = (int)Feature2D::GLDM_SDE; f <= (int)Feature2D::GLDM_LDHGLE; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_NGLDM)
+        for (int f = (int)Feature2D::NGLDM_LDE; f <= (int)Feature2D::NGLDM_DCENE; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_NGTDM)
+        for (int f = (int)Feature2D::NGTDM_COARSENESS; f <= (int)Feature2D::NGTDM_STRENGTH; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_GABOR)
+        put_angled(p, lr.fvals[(int)Feature2D::GABOR], (size_t)s->gabor_n_filters);
+    if (mask & NYXHIP_FAM_ZERNIKE)
+        put_angled(p, lr.fvals[(int)Feature2D::ZERNIKE2D], 30);
+    if (mask & NYXHIP_FAM_SMOMS)
+        for (int f = (int)Feature2D::SPAT_MOMENT_00; f <= (int)Feature2D::WEIGHTED_HU_M7; f++)
+            *p++ = lr.fvals[f][0];
+    if (mask & NYXHIP_FAM_IMOMS)
+        for (int f = (int)Feature2D::IMOM_RM_00; f <= (int)Feature2D::IMOM_WHU7; f++)
+            *p++ = lr.fvals[f][0];
+}
+
 } // namespace
 
 extern "C" {
@@ -171,86 +250,99 @@ int nyxref_featurize_batch(const nyxhip_batch* b, uint32_t mask, const nyxhip_se
             lr.initialize_fvals();
         }
 
-        // reduce_trivial_rois_manual, reduce_trivial_rois.cpp:772-777
-        size_t jobSize = L.size(), workPerThread = jobSize / (size_t)n_threads;
         auto t0 = std::chrono::steady_clock::now();
-        if (mask & NYXHIP_FAM_INTENSITY)
-            runParallel(PixelIntensityFeatures::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & (NYXHIP_FAM_SMOMS | NYXHIP_FAM_IMOMS))   // the moments' dependency, reduce_trivial_rois.cpp:98-111
-            runParallel(ContourFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GLCM)
-            runParallel(GLCMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GLRLM)
-            runParallel(GLRLMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GLDZM)   // reduce_trivial_rois.cpp:215-220
-            runParallel(GLDZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GLSZM)
-            runParallel(GLSZMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GLDM)    // :231-236
-            runParallel(GLDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_NGLDM)   // :239-244
-            runParallel(NGLDMfeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_NGTDM)
-            runParallel(NGTDMFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_GABOR)
-            runParallel(GaborFeature::reduce, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_ZERNIKE)
-            runParallel(ZernikeFeature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_IMOMS)   // reduce_trivial_rois.cpp:320-325
-            runParallel(Imoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
-        if (mask & NYXHIP_FAM_SMOMS)   // :326-331
-            runParallel(Smoms2D_feature::parallel_process_1_batch, n_threads, workPerThread, jobSize, &L, &roiData, fst, ds);
+        reduce_ladder(mask, n_threads, L, roiData, fst, ds);
         auto t1 = std::chrono::steady_clock::now();
         if (reduce_seconds)
             *reduce_seconds = std::chrono::duration<double>(t1 - t0).count();
 
-        // table layout of save_features_2_buffer (enum order, angle expansion); raw values
-        for (uint64_t r = 0; r < b->n_roi; r++) {
-            const LR& lr = roiData[(int)r + 1];
-            double* p = out + r * ld;
-            if (mask & NYXHIP_FAM_INTENSITY)
-                for (auto f : kIntensity) *p++ = lr.fvals[(int)f][0];
-            if (mask & NYXHIP_FAM_GLCM) {
-                size_t na = (size_t)s->glcm_n_angles;
-                for (int f = (int)Feature2D::GLCM_ASM; f <= (int)Feature2D::GLCM_VARIANCE; f++)
-                    put_angled(p, lr.fvals[f], na);
-                for (int f = (int)Feature2D::GLCM_ASM_AVE; f <= (int)Feature2D::GLCM_SUMVARIANCE_AVE; f++)
-                    *p++ = lr.fvals[f][0];
-            }
-            if (mask & NYXHIP_FAM_GLRLM) {
-                for (int f = (int)Feature2D::GLRLM_SRE; f <= (int)Feature2D::GLRLM_LRHGLE; f++)
-                    put_angled(p, lr.fvals[f], 4);
-                for (int f = (int)Feature2D::GLRLM_SRE_AVE; f <= (int)Feature2D::GLRLM_LRHGLE_AVE; f++)
-                    *p++ = lr.fvals[f][0];
-            }
-            if (mask & NYXHIP_FAM_GLDZM)
-                for (int f = (int)Feature2D::GLDZM_SDE; f <= (int)Feature2D::GLDZM_ZDE; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_GLSZM)
-                for (int f = (int)Feature2D::GLSZM_SAE; f <= (int)Feature2D::GLSZM_LAHGLE; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_GLDM)
-                for (int f = (int)Feature2D::GLDM_SDE; f <= (int)Feature2D::GLDM_LDHGLE; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_NGLDM)
-                for (int f = (int)Feature2D::NGLDM_LDE; f <= (int)Feature2D::NGLDM_DCENE; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_NGTDM)
-                for (int f = (int)Feature2D::NGTDM_COARSENESS; f <= (int)Feature2D::NGTDM_STRENGTH; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_GABOR)
-                put_angled(p, lr.fvals[(int)Feature2D::GABOR], (size_t)s->gabor_n_filters);
-            if (mask & NYXHIP_FAM_ZERNIKE)
-                put_angled(p, lr.fvals[(int)Feature2D::ZERNIKE2D], 30);
-            if (mask & NYXHIP_FAM_SMOMS)
-                for (int f = (int)Feature2D::SPAT_MOMENT_00; f <= (int)Feature2D::WEIGHTED_HU_M7; f++)
-                    *p++ = lr.fvals[f][0];
-            if (mask & NYXHIP_FAM_IMOMS)
-                for (int f = (int)Feature2D::IMOM_RM_00; f <= (int)Feature2D::IMOM_WHU7; f++)
-                    *p++ = lr.fvals[f][0];
-        }
+        for (uint64_t r = 0; r < b->n_roi; r++)
+            put_row(roiData[(int)r + 1], mask, s, out + r * ld);
     } catch (const std::exception& e) {
         fprintf(stderr, "nyxref_featurize_batch: %s\n", e.what());
+        return NYXHIP_ERR_HIP;
+    }
+    return NYXHIP_OK;
+}
+
+/* The reference's in-memory workflow for a stack of uint32 tiles, end to end on the CPU (the tile-inclusive baseline of bench.py):
+ * per image pair, as featurize_montage does (workflow_pythonapi.cpp:140-182),
+ *   phase 1  gatherRoisMetricsInMemory (phase1.cpp:373-409): column-major scan, feed_pixel_2_metrics (pixel_feed.cpp:19-43:
+ *            hash-set / hash-map lookup per pixel, init_label_record_3 / update_label_record_3, features_calc_workflow.cpp:65-105);
+ *   phase 2  scanTrivialRoisInMemory (phase2_2d.cpp:637-684): second column-major scan, binary search in the sorted batch labels,
+ *            feed_pixel_2_cache_LR (pixel_feed.cpp:71-74); allocateTrivialRoisBuffers (phase2_2d.cpp:427-465);
+ *   reduce   reduce_trivial_rois_manual -> the runParallel ladder (the real feature classes).
+ * The two scans are restated here on the reference's own LR / Pixel2 / AABB classes (their translation units need the whole
+ * Environment); the reduce is the reference's code.  Rows: tiles in order, labels ascending.  Returns the row count in *n_rows
+ * (rows beyond max_rows are computed but not stored); seconds[0] = scans + buffers (serial, as in the reference), seconds[1] = reduce. */
+int nyxref_featurize_tiles(const uint32_t* inten, const uint32_t* label, uint32_t W, uint32_t H, uint32_t n_tiles, uint32_t mask,
+                           const nyxhip_settings* s, int n_threads, uint32_t* out_labels, uint32_t* out_tiles, double* out, size_t ld,
+                           uint64_t max_rows, uint64_t* n_rows, double* seconds)
+{
+    if (!inten || !label || !s || n_threads < 1 || !n_rows)
+        return NYXHIP_ERR_INVALID_ARG;
+    try {
+        apply_statics(s);
+        Fsettings fst = make_settings(s);
+        Dataset ds;
+        double t_scan = 0, t_red = 0;
+        uint64_t rows = 0;
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            const uint32_t* I = inten + (size_t)t * W * H;
+            const uint32_t* Lb = label + (size_t)t * W * H;
+            auto t0 = std::chrono::steady_clock::now();
+            std::unordered_set<int> uniqueLabels;
+            std::unordered_map<int, LR> roiData;
+            for (size_t col = 0; col < W; col++)                   // phase 1
+                for (size_t row = 0; row < H; row++) {
+                    const int lab = (int)Lb[row * W + col];
+                    if (!lab) continue;
+                    const PixIntens v = I[row * W + col];
+                    if (uniqueLabels.find(lab) == uniqueLabels.end()) {
+                        uniqueLabels.insert(lab);
+                        LR nr(lab);
+                        nr.slide_idx = -1;                          // montage: no slide properties (slideprops.cpp:27-28)
+                        nr.aux_area = 1; nr.aux_min = nr.aux_max = v; nr.init_aabb((StatsInt)col, (StatsInt)row);
+                        roiData[lab] = nr;
+                    } else {
+                        LR& r = roiData[lab];
+                        r.aux_area++; r.aux_min = std::min(r.aux_min, v); r.aux_max = std::max(r.aux_max, v); r.update_aabb((StatsInt)col, (StatsInt)row);
+                    }
+                }
+            std::vector<int> L(uniqueLabels.begin(), uniqueLabels.end());
+            std::sort(L.begin(), L.end());
+            for (size_t col = 0; col < W; col++)                   // phase 2
+                for (size_t row = 0; row < H; row++) {
+                    const int lab = (int)Lb[row * W + col];
+                    if (!lab) continue;
+                    if (!std::binary_search(L.begin(), L.end(), lab)) continue;
+                    roiData[lab].raw_pixels.push_back(Pixel2((StatsInt)col, (StatsInt)row, I[row * W + col]));
+                }
+            for (int lab : L) {                                    // allocateTrivialRoisBuffers
+                LR& r = roiData[lab];
+                r.make_nonanisotropic_aabb();
+                r.aux_image_matrix.allocate(r.aabb.get_width(), r.aabb.get_height());
+                r.aux_image_matrix.calculate_from_pixelcloud(r.raw_pixels, r.aabb);
+                r.initialize_fvals();
+            }
+            auto t1 = std::chrono::steady_clock::now();
+            reduce_ladder(mask, n_threads, L, roiData, fst, ds);
+            auto t2 = std::chrono::steady_clock::now();
+            t_scan += std::chrono::duration<double>(t1 - t0).count();
+            t_red += std::chrono::duration<double>(t2 - t1).count();
+            for (int lab : L) {
+                if (rows < max_rows && out) {
+                    put_row(roiData[lab], mask, s, out + rows * ld);
+                    if (out_labels) out_labels[rows] = (uint32_t)lab;
+                    if (out_tiles) out_tiles[rows] = t;
+                }
+                rows++;
+            }
+        }
+        *n_rows = rows;
+        if (seconds) { seconds[0] = t_scan; seconds[1] = t_red; }
+    } catch (const std::exception& e) {
+        fprintf(stderr, "nyxref_featurize_tiles: %s\n", e.what());
         return NYXHIP_ERR_HIP;
     }
     return NYXHIP_OK;

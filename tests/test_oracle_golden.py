@@ -310,3 +310,32 @@ def test_geomoments_match_reference_classes_bit_exact(seed, rmax):
     R = po.ref_featurize(b, mask, s, n_threads=2)
     same = (A == R) | (np.isnan(A) & np.isnan(R))
     assert same.all(), np.argwhere(~same)[:10]
+
+
+def test_reference_tile_workflow_equals_assembly_plus_oracle():
+    """oracle/ref_driver.cpp nyxref_featurize_tiles (the reference's in-memory workflow with its two label scans, bench.py's
+    tile-inclusive CPU baseline) against host assembly + the C oracle: same rows, same order, same values."""
+    from oracle import pyoracle as po
+    if not po.have_ref():
+        import pytest
+        pytest.skip("oracle/_ref not built")
+    from nyxus_amd import roi_assembly
+    from tests import synth
+    rng = np.random.default_rng(4)
+    lab = synth.disk_label_tile(size=128, pitch=32, radius=12)
+    I = rng.integers(0, 4096, (2, 128, 128)).astype(np.uint32)
+    M = np.stack([lab, lab * 5]).astype(np.uint32)
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    tm = []
+    t, l, T = po.ref_featurize_tiles(I, M, mask, s, n_threads=2, timing=tm)
+    assert len(tm) == 2 and tm[0] > 0 and tm[1] > 0
+    row = 0
+    for k in range(2):
+        b = roi_assembly.assemble(I[k], M[k], None, None)
+        O = po.oracle_featurize(b, mask, s)
+        n = len(b.roi_label)
+        assert np.array_equal(l[row:row + n], b.roi_label) and np.all(t[row:row + n] == k)
+        assert np.array_equal(T[row:row + n], O, equal_nan=True)
+        row += n
+    assert row == len(l)

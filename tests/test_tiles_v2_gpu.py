@@ -157,3 +157,31 @@ def test_nyxus_gpu_devices_and_ram_limit():
     b = nyxus_amd.Nyxus(["*ALL_INTENSITY*", "*ALL_GLCM*"], coarse_gray_depth=8, gpu_devices=[0, 0], ram_limit=8).featurize(I, M)
     assert list(a.columns) == list(b.columns) and a.shape == b.shape == (96, 4 + 36 + 149)
     assert a.equals(b)
+
+
+@pytest.mark.parametrize("gd", [8, 64])
+def test_window_mode_is_bit_identical_to_cloud_mode(hip_ctx, gd):
+    """INTENSITY / GLCM alone read the ROIs' windows of the tiles inside the feature kernel; any other family makes the tile path
+    materialise clouds first.  Both must give the same bits for the shared columns (a pixel's index in the kernel's value
+    buffer is its rank in window order either way)."""
+    rng = np.random.default_rng(21)
+    s = _abi.default_settings(gd)
+    h, w = 200, 260
+    M = np.zeros((3, h, w), np.uint16)
+    for t in range(3):
+        for k in range(1, 40):                                   # random overlapping blobs: concave ROIs, holes, border contact
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 30)
+            yy, xx = np.ogrid[:h, :w]
+            M[t][((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r) & (rng.random((h, w)) > 0.05)] = k * 7
+    I = rng.integers(0, 3000, (3, h, w)).astype(np.uint16)
+    I[0][M[0] == 7] = 55                                          # a constant ROI
+    I[1][M[1] == 14] = 0                                          # a blank ROI
+    t1, l1, T1 = hip_ctx.featurize_tiles_host(I, M, MASK, s)                         # window mode
+    t2, l2, T2 = hip_ctx.featurize_tiles_host(I, M, MASK | _abi.FAM_NGTDM, s)        # cloud mode (NGTDM needs clouds)
+    assert np.array_equal(t1, t2) and np.array_equal(l1, l2) and len(l1) > 60
+    n1 = _lib.column_names(MASK, s)
+    n2 = _lib.column_names(MASK | _abi.FAM_NGTDM, s)
+    sel = [n2.index(c) for c in n1]
+    assert np.array_equal(T1, T2[:, sel], equal_nan=True)
+    wt, wl, want = _oracle_stack(I, M, MASK, s)
+    assert not parity.compare_tables(T1, want, n1)
