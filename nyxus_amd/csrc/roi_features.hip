@@ -977,21 +977,25 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         const double dn = (double)n;
         // integer sums are exact in any order (the reference's double accumulation is
         // exact too while partial sums stay below 2^53)
-        sum = wave_sum_u64(sum);
+        if ((unsigned long long)n * vmax < (1ull << 32))           // the whole ROI's sum fits 32 bits: one-instruction DPP steps
+            sum = wave_sum_t<uint32_t>((uint32_t)sum);
+        else
+            sum = wave_sum_u64(sum);
         sumsq = wave_sum_u64(sumsq);
         if (lane == 0) {
             s_red[wave * 8 + 0] = (double)sum;
             s_red[wave * 8 + 1] = (double)sumsq;
         }
         blk_sync<GS>(); // also: every s_val / s_cnt write of phase 1 is visible
-        double tot = 0, totsq = 0;
-        for (int wv = 0; wv < kWaves; wv++) {
-            tot += s_red[wv * 8 + 0];
-            totsq += s_red[wv * 8 + 1];
-        }
-        const double mean = tot / dn;
         const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
         if (tid == 0) {                                // the sums' own outputs leave the registers right away
+            double tot = 0, totsq = 0;
+            for (int wv = 0; wv < kWaves; wv++) {
+                tot += s_red[wv * 8 + 0];
+                totsq += s_red[wv * 8 + 1];
+            }
+            const double mean = tot / dn;              // the one IEEE division; every other thread reads the mean after the barrier
+            s_stat[S_MEAN] = mean;
             o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
             o[I_MAX] = (double)vmax;
             o[I_RANGE] = (double)vmax - (double)vmin;
@@ -1005,6 +1009,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
         }
         blk_sync<GS>();
+        const double mean = s_stat[S_MEAN];
         STAMP(2);
 
         const double binW100 = (double)range / 100.;
@@ -1227,7 +1232,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 const int i0 = lane, i1 = lane + 64;
                 const uint32_t r0 = s_lb100[i0], e0 = (i0 < 99 ? s_lb100[i0 + 1] : n);
                 const uint32_t r1 = i1 < 100 ? s_lb100[i1] : 0u, e1 = i1 < 100 ? (i1 < 99 ? s_lb100[i1 + 1] : n) : 0u;
-                double pq[6];
+                // the six winners are found with the whole wave (two ballots each); lane q then interpolates percentile q -- one
+                // division per lane instead of six per wave -- and lane 0 collects the values
+                int mywin = -1;
+                double mycnt = 0;
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
                     const double frac = q == 0 ? 0.01 : q == 1 ? 0.1 : q == 2 ? 0.25 : q == 3 ? 0.75 : q == 4 ? 0.9 : 0.99;
@@ -1236,12 +1244,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     bool m1 = i1 < 100 && (double)r1 <= cnt_p && cnt_p <= (double)e1;
                     unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
                     int win = b1 ? 64 + (63 - __clzll((long long)b1)) : (b0 ? 63 - __clzll((long long)b0) : -1);
-                    double pv = 0;
-                    if (win >= 0) {
-                        uint32_t rs = s_lb100[win], bi = (win < 99 ? s_lb100[win + 1] : n) - rs;
-                        pv = (cnt_p - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)win;
-                    }
-                    pq[q] = pv;
+                    if (lane == q) { mywin = win; mycnt = cnt_p; }
+                }
+                double pv = 0;
+                if (mywin >= 0) {
+                    uint32_t rs = s_lb100[mywin], bi = (mywin < 99 ? s_lb100[mywin + 1] : n) - rs;
+                    pv = (mycnt - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)mywin;
+                }
+                double pq[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const unsigned long long u = (unsigned long long)__double_as_longlong(pv);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, q), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), q);
+                    pq[q] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
                 }
                 if (lane == 0) {
                     o[I_P01] = pq[0]; o[I_P10] = pq[1]; o[I_P25] = pq[2]; o[I_P75] = pq[3]; o[I_P90] = pq[4]; o[I_P99] = pq[5];
@@ -1269,15 +1284,23 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // median (histogram.h:268-287): order statistics n/2 and n/2-1
                 uint32_t hi_v, lo_v;
                 if (use_count) {
-                    uint32_t k = lane == 0 ? n / 2 : (n / 2 ? n / 2 - 1 : 0);
-                    uint32_t lo = 0, hi = range; // smallest i with C(i) > k
-                    while (lo < hi) {
-                        uint32_t mid = (lo + hi) >> 1;
-                        if (cum(mid) > k) hi = mid; else lo = mid + 1;
-                    }
-                    uint32_t val = vmin + lo;
-                    hi_v = __shfl(val, 0, 64);
-                    lo_v = __shfl(val, 1, 64);
+                    // smallest i with C(i) > k, for k = n/2 and n/2 - 1: a 64-way search -- every lane probes one position of the
+                    // current interval, a ballot finds the first hit -- two rounds for ranges up to 4096, three up to 2^18
+                    auto kth = [&](uint32_t k) -> uint32_t {
+                        uint32_t lo = 0, span = range + 1;                  // the answer lies in [lo, lo + span)
+                        while (span > 1) {
+                            const uint32_t B = (span + 63) >> 6;
+                            uint32_t i = lo + ((uint32_t)lane + 1) * B - 1;   // last position of this lane's block
+                            if (i > range) i = range;
+                            const unsigned long long hit = __ballot(cum(i) > k);
+                            const uint32_t first = hit ? (uint32_t)__builtin_ctzll(hit) : 63u;
+                            lo += first * B;
+                            span = lo + B > range + 1 ? range + 1 - lo : B;
+                        }
+                        return lo;
+                    };
+                    hi_v = vmin + kth(n / 2);
+                    lo_v = vmin + kth(n / 2 ? n / 2 - 1 : 0);
                 } else {
                     hi_v = s_val[n / 2];
                     lo_v = s_val[n / 2 ? n / 2 - 1 : 0];
