@@ -32,3 +32,25 @@ cases["files_dep_moments_gd16"] = {"features": ["*ALL_GLDZM*", "*ALL_GLDM*", "*A
                                    "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
 print("files", df.shape, nyx.get_params("coarse_gray_depth", "gabor_thetas"))
 json.dump(cases, open(os.path.join(HERE, "api_directory.json"), "w"), separators=(",", ":"))
+
+# A synthetic 4096 x 4096 slide stored as a TILED TIFF (1024 x 1024 deflate tiles, ROIs crossing the tile borders, sparse label
+# values): the files are written from the seeded recipe of tests/synth.py (the test does the same), only the reference's
+# DataFrame is stored -- tests/golden/api_directory_tiled.json.
+import tempfile  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests import synth  # noqa: E402
+tiled = {}
+with tempfile.TemporaryDirectory() as tmp:
+    os.makedirs(os.path.join(tmp, "int")); os.makedirs(os.path.join(tmp, "seg"))
+    I, L = synth.slide4096(0)
+    synth.write_tiled_tiff(os.path.join(tmp, "int", "slide0.ome.tif"), I)
+    synth.write_tiled_tiff(os.path.join(tmp, "seg", "slide0.ome.tif"), L)
+    feats = ["*ALL_INTENSITY*", "GLCM_ASM", "GLCM_CONTRAST", "GLCM_CORRELATION", "GLCM_ENTROPY", "GLCM_INFOMEAS1", "GLCM_SUMAVERAGE"]
+    kw = {"coarse_gray_depth": 8}
+    df = nyxus.Nyxus(feats, **kw).featurize_directory(os.path.join(tmp, "int"), os.path.join(tmp, "seg"))
+    num = df.select_dtypes(include=[np.number])
+    tiled["slide4096_tiled_gd8"] = {"features": feats, "kwargs": kw, "slide_seed": 0, "columns": list(df.columns),
+                                    "strings": df[[c for c in df.columns if c not in num.columns]].values.tolist(),
+                                    "numeric_columns": list(num.columns), "numeric": num.values.astype(float).tolist()}
+    print("slide4096", df.shape)
+json.dump(tiled, open(os.path.join(HERE, "api_directory_tiled.json"), "w"), separators=(",", ":"))

@@ -94,3 +94,78 @@ def random_rois(n_roi: int, seed: int = 0, rmax: int = 25, value_modes=(4096, 25
             d["slide_max"] = float(2 ** 16)
         rois.append(d)
     return rois
+
+
+def write_tiled_tiff(path: str, arr: np.ndarray, tile: int = 1024, strips: bool = False, rows_per_strip: int = 64) -> None:
+    """Minimal classic-TIFF writer for tests: one grayscale page of uint8 / uint16 / uint32 samples, stored as deflate-compressed
+    TILES (default; what the reference's NyxusGrayscaleTiffTileLoader reads) or STRIPS (NyxusGrayscaleTiffStripLoader)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(arr)
+    h, w = a.shape
+    bits = a.dtype.itemsize * 8
+    chunks = []
+    if strips:
+        for y in range(0, h, rows_per_strip):
+            chunks.append(zlib.compress(a[y:y + rows_per_strip].tobytes(), 6))
+    else:
+        for y in range(0, h, tile):
+            for x in range(0, w, tile):
+                t = np.zeros((tile, tile), a.dtype)
+                blk = a[y:y + tile, x:x + tile]
+                t[:blk.shape[0], :blk.shape[1]] = blk
+                chunks.append(zlib.compress(t.tobytes(), 6))
+    n = len(chunks)
+    tags = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, bits), (259, 3, 1, 8), (262, 3, 1, 1), (277, 3, 1, 1), (284, 3, 1, 1), (339, 3, 1, 1)]
+    if strips:
+        tags += [(278, 4, 1, rows_per_strip), (273, 4, n, None), (279, 4, n, None)]
+    else:
+        tags += [(322, 4, 1, tile), (323, 4, 1, tile), (324, 4, n, None), (325, 4, n, None)]
+    tags.sort()
+    ifd_off = 8
+    ifd_size = 2 + 12 * len(tags) + 4
+    arr_off = ifd_off + ifd_size                  # the two LONG arrays (offsets, byte counts), then the data
+    data_off = arr_off + 8 * n
+    offs, pos = [], data_off
+    for c in chunks:
+        offs.append(pos)
+        pos += len(c)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<2sHI", b"II", 42, ifd_off))
+        fh.write(struct.pack("<H", len(tags)))
+        for tag, typ, cnt, val in tags:
+            if val is None:                       # offsets first, byte counts second
+                first = tag in (273, 324)
+                v = (arr_off if first else arr_off + 4 * n) if n > 1 else (offs[0] if first else len(chunks[0]))
+                fh.write(struct.pack("<HHII", tag, typ, cnt, v))
+            elif typ == 3:
+                fh.write(struct.pack("<HHIHH", tag, typ, cnt, val, 0))
+            else:
+                fh.write(struct.pack("<HHII", tag, typ, cnt, val))
+        fh.write(struct.pack("<I", 0))
+        fh.write(struct.pack("<%dI" % n, *offs))
+        fh.write(struct.pack("<%dI" % n, *[len(c) for c in chunks]))
+        for c in chunks:
+            fh.write(c)
+
+
+def slide4096(seed: int = 0, size: int = 4096, pitch: int = 256):
+    """A synthetic slide for the tiled-TIFF path: blocky 12-bit intensities (8 x 8 blocks, so that the deflate tiles stay small)
+    with a little per-pixel structure, and a 16 x 16 grid of disks of radius 20..110 -- many cross the 1024-pixel TIFF tile
+    borders; label values are sparse (multiples of 1000)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    blk = rng.integers(1, 4000, (size // 8, size // 8)).astype(np.uint32)
+    inten = (np.kron(blk, np.ones((8, 8), np.uint32)) + ((xx * 3 + yy * 5) % 17)).astype(np.uint16)
+    lab = np.zeros((size, size), np.uint32)
+    k = 0
+    for gy in range(size // pitch):
+        for gx in range(size // pitch):
+            k += 1
+            cy = gy * pitch + pitch // 2 + int(rng.integers(-10, 11))
+            cx = gx * pitch + pitch // 2 + int(rng.integers(-10, 11))
+            r = int(rng.integers(20, 111))
+            y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, size), max(cx - r, 0), min(cx + r + 1, size)
+            m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
+            lab[y0:y1, x0:x1][m] = 1000 * k
+    return inten, lab

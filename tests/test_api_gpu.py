@@ -83,3 +83,24 @@ def test_featurize_directory_matches_reference(case):
             if cm in cols and m00 in cols}
     bad = parity.compare_tables(got, want, cols, exact=parity.EXACT_COLUMNS | {"ROI_label", "t_index"}, atol=atol)
     assert not bad, "\n".join(bad[:20])
+
+
+def test_featurize_directory_on_a_tiled_4096_slide(tmp_path):
+    """A 4096 x 4096 slide stored as 1024 x 1024 deflate tiles (written from the seeded recipe of tests/synth.py), ROIs crossing
+    the TIFF tile borders, sparse label values up to 256000, ROIs of up to 38 k pixels: native tile-by-tile decode ->
+    device scan / prescan / reduce, against the reference package's DataFrame (tests/golden/api_directory_tiled.json)."""
+    from tests import synth
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_directory_tiled.json")))["slide4096_tiled_gd8"]
+    os.makedirs(tmp_path / "int"); os.makedirs(tmp_path / "seg")
+    I, L = synth.slide4096(g["slide_seed"])
+    synth.write_tiled_tiff(str(tmp_path / "int" / "slide0.ome.tif"), I)
+    synth.write_tiled_tiff(str(tmp_path / "seg" / "slide0.ome.tif"), L)
+    df = nyxus_amd.Nyxus(g["features"], **g["kwargs"]).featurize_directory(str(tmp_path / "int"), str(tmp_path / "seg"))
+    assert list(df.columns) == g["columns"]
+    str_cols = [c for c in g["columns"] if c not in g["numeric_columns"]]
+    assert df[str_cols].values.tolist() == g["strings"]
+    got = df[g["numeric_columns"]].values.astype(float)
+    want = np.array(g["numeric"], dtype=float)
+    assert got.shape == want.shape == (256, len(g["numeric_columns"]))
+    bad = parity.compare_tables(got, want, g["numeric_columns"], exact=parity.EXACT_COLUMNS | {"ROI_label", "t_index"})
+    assert not bad, "\n".join(bad[:20])
