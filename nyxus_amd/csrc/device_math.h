@@ -374,12 +374,17 @@ __device__ __forceinline__ double row16_max(double v)
 
 // neighbour lanes through DPP wave shifts (GFX9: wave_shl:1 = 0x130, wave_shr:1 = 0x138);
 // the lane without a source reads `fill`
+// (a literal zero fill comes from bound_ctrl: the destination then needs no initialising move)
 __device__ __forceinline__ uint32_t lane_plus1(uint32_t v, uint32_t fill)   // value of lane+1
 {
+    if (__builtin_constant_p(fill) && fill == 0)
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
 }
 __device__ __forceinline__ uint32_t lane_minus1(uint32_t v, uint32_t fill)  // value of lane-1
 {
+    if (__builtin_constant_p(fill) && fill == 0)
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
 

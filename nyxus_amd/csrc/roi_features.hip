@@ -420,17 +420,21 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     wav_sync<false>();
 
     // ---- the cell pass ---------------------------------------------------------------------------------------------------
-    double asm_ = 0, ent = 0, hxy1 = 0, hxy2 = 0, cov = 0, jmax = -1;
-    uint32_t acor_i = 0;
+    // What a cell contributes on its own is integer work: ASM = sum cnt^2 / sum_p^2, ACOR and the covariance term from
+    // sum cnt (r+1)(c+1) (the numerator  acor * sum_p - S_r * S_c  is an exact integer below 2^53), JMAX from the largest
+    // count; only the entropy term p lg(p + eps) and the two HXY terms need the float log.
+    double ent = 0, hxy1 = 0, hxy2 = 0, asm_d = 0;
+    uint32_t acor_i = 0, asm_i = 0, cmax = 0;
+    const bool big = csum >= 65536u;                                   // (symmetric matrices of ROIs beyond 32767 pixels)
     RowCol rcw((uint32_t)l, 16u, (uint32_t)Ng);
     for (int e = l; e < NN; e += 16, rcw.advance()) {
         const uint32_t r = rcw.row, c = rcw.col, cnt = P[e];
         const double p = (double)cnt * inv_sum_p;
-        asm_ = __builtin_fma(p, p, asm_);                            // f_asm :555 / f_energy :927-928
+        if (big) asm_d = __builtin_fma(p, p, asm_d);                 // f_asm :555 / f_energy :927-928
+        else asm_i += cnt * cnt;                                     //   (sum cnt^2 <= (sum cnt)^2 < 2^32 while sum_p < 65536)
         acor_i += cnt * ((r + 1u) * (c + 1u));                       // f_GLCM_ACOR :961 (integer-exact)
+        cmax = cnt > cmax ? cnt : cmax;                              // f_GLCM_JMAX :1178-1179
         ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);       // f_entropy :734-735, JE :1160-1161, HXY :868
-        jmax = p > jmax ? p : jmax;                                  // f_GLCM_JMAX :1178-1179
-        cov = __builtin_fma(((double)(r + 1u) - mr) * ((double)(c + 1u) - mc), p, cov);   // f_corr :633
         const double pp = pcol_s[c] * prow_s[r];                     // px[i]*py[j], i = column, j = row (:869, :909)
         const double lg = (double)fast_log2f(pp + 0.000000001);
         hxy1 = __builtin_fma(p, lg, hxy1);
@@ -438,12 +442,24 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     }
     const double hx_t = l < Ng ? plogp(pcol, pcol) : 0.0;             // :873-874
     {
-        double t8[8] = {asm_, ent, hxy1, hxy2, cov, hx_t, 0.0, 0.0};
-        const double tot = row16_transpose_sum8(t8, l);
-        if (live && (l & 1) == 0) sm[l >> 1] = tot;
+        double t4[4] = {ent, hxy1, hxy2, hx_t};
+        transpose_sum_step<0x140, 2>(t4, (l & 8) != 0);              // lane l of the row ends with the row total of slot (l >> 2) & 3
+        transpose_sum_step<0x141, 1>(t4, (l & 4) != 0);
+        double tot = t4[0];
+        tot += dpp_perm<0x4E>(tot);
+        tot += dpp_perm<0xB1>(tot);
+        if (live && (l & 3) == 0) sm[1 + (l >> 2)] = tot;            // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
     }
-    jmax = row16_max(jmax);
     acor_i = row16_sum(acor_i);
+    asm_i = row16_sum(asm_i);
+    if (big) asm_d = row16_sum(asm_d);
+    {
+        uint32_t o;
+        o = dpp_perm<0xB1>(cmax); cmax = o > cmax ? o : cmax;
+        o = dpp_perm<0x4E>(cmax); cmax = o > cmax ? o : cmax;
+        o = dpp_perm<0x141>(cmax); cmax = o > cmax ? o : cmax;
+        o = dpp_perm<0x140>(cmax); cmax = o > cmax ? o : cmax;
+    }
 
     // ---- one term per lane: features of the marginal distributions ---------------------------------------------------------
     double t16[16];
@@ -485,7 +501,9 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     dv = row16_sum(dv);
 
     if (live && l == 0) {
-        const double asm_t = sm[0], ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], cov_t = sm[4], hx = sm[5];
+        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
+        const double asm_t = big ? asm_d : (double)asm_i * inv_sum_p * inv_sum_p;
+        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
         f[G_ASM] = asm_t;
         f[G_ENERGY] = asm_t;
         f[G_CONTRAST] = fdiv((double)con_i, sum_p);
@@ -493,7 +511,7 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
         f[G_ENTROPY] = -ent_t;
         f[G_JE] = -ent_t;
         f[G_DIS] = fdiv((double)dis_i, sum_p);
-        f[G_JMAX] = jmax;
+        f[G_JMAX] = (double)cmax * inv_sum_p;
         f[G_JAVE] = mr;
         f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
         f[G_CLUPROM] = sm[8 + 13];
@@ -574,40 +592,52 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     wav_sync<false>();
 
     // ---- the cell pass: lane = column, rows in sequence ------------------------------------------------------------------------
-    double asm_ = 0, ent = 0, hxy1 = 0, hxy2 = 0, cov = 0, jmax = -1;
-    uint32_t acor_i = 0, rc1 = 0;
-    const double dcl = (double)l1 - mc;
+    // A cell's own quantities are integer work (ASM = sum cnt^2 / sum_p^2, ACOR and the covariance numerator
+    // acor * sum_p - S_r * S_c exactly, JMAX from the largest count; sum_p < 65536 in a G16 launch, so every sum fits 32 bits);
+    // the entropy term p lg(p + eps) depends on the count alone: the 16 smallest counts -- all of them on a textured ROI -- come
+    // from a table built once per angle; only the two HXY terms need a float log per cell.
+    double* const Tent = sm + 32 - 16;                               // sm[16..31]: entropy terms of counts 0..15 (batch 2 uses sm[8..23] later)
+    if (lane < 16) {
+        const double pk = (double)lane * inv_sum_p;
+        Tent[lane] = pk * (double)fast_log2f(pk + 0.000000001);
+    }
+    wav_sync<false>();
+    double ent = 0, hxy1 = 0, hxy2 = 0;
+    uint32_t acor_i = 0, asm_i = 0, cmax = 0, rc1 = 0;
     const uint16_t* pcell = P + S + lane + 1;
     for (int r = 0; r < Ng; r++) {
         const uint32_t cnt = act ? pcell[r * S] : 0u;
         const double pr = prow_s[r];
         rc1 += l1;                                                   // (r + 1) * (c + 1)
-        const double p = (double)cnt * inv_sum_p;
-        asm_ = __builtin_fma(p, p, asm_);                            // f_asm :555 / f_energy :927-928
+        asm_i += cnt * cnt;                                          // f_asm :555 / f_energy :927-928
         acor_i += cnt * rc1;                                         // f_GLCM_ACOR :961 (integer-exact)
-        ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);       // f_entropy :734-735, JE :1160-1161, HXY :868
-        jmax = p > jmax ? p : jmax;                                  // f_GLCM_JMAX :1178-1179
-        cov = __builtin_fma(((double)(r + 1) - mr) * dcl, p, cov);   // f_corr :633
+        cmax = cnt > cmax ? cnt : cmax;                              // f_GLCM_JMAX :1178-1179
+        const double p = (double)cnt * inv_sum_p;
+        double et = Tent[cnt < 15u ? cnt : 15u];
+        if (cnt >= 15u) et = p * (double)fast_log2f(p + 0.000000001);
+        ent += et;                                                   // f_entropy :734-735, JE :1160-1161, HXY :868
         const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
         const double lg = (double)fast_log2f(pp + 0.000000001);
         hxy1 = __builtin_fma(p, lg, hxy1);
         hxy2 = __builtin_fma(pp, lg, hxy2);
     }
     const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
+    wav_sync<false>();                                               // the table is dead: sm[16..23] belong to batch 2 from here on
     {
-        double t8[8] = {asm_, ent, hxy1, hxy2, cov, hx_t, 0.0, 0.0};
-        const double tot = wave_transpose_sum8(t8, lane);            // lane L holds the total of slot (L >> 3) & 7
-        if ((lane & 7) == 0) sm[lane >> 3] = tot;
+        double t4[4] = {ent, hxy1, hxy2, hx_t};
+        const double tot = wave_transpose_sum4(t4);                  // lane L holds the total of slot (L >> 4) & 3
+        if ((lane & 15) == 0) sm[1 + (lane >> 4)] = tot;             // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
     }
-    jmax = wave_max_nonneg(jmax < 0 ? 0.0 : jmax);
     acor_i = wave_sum_t<uint32_t>(acor_i);
+    asm_i = wave_sum_t<uint32_t>(asm_i);
+    cmax = wave_max_u32(cmax);
 
     // ---- one term per lane: features of the marginal distributions -----------------------------------------------------------
     double t16[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) t16[k] = 0.0;
     if (act) {
-        const double dr = (double)l1 - mr, dr2 = dr * dr;
+        const double dr = (double)l1 - mr, dr2 = dr * dr, dcl = (double)l1 - mc;
         t16[0] = prow * dr2;                                         // f_corr :617
         t16[1] = pcol * (dcl * dcl);                                 // :626
         t16[2] = (double)rc * dr2;                                   // f_var :672
@@ -645,7 +675,9 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     dv = wave_sum(dv);
 
     if (lane == 0) {
-        const double asm_t = sm[0], ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], cov_t = sm[4], hx = sm[5];
+        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
+        const double asm_t = (double)asm_i * inv_sum_p * inv_sum_p;
+        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
         f[G_ASM] = asm_t;
         f[G_ENERGY] = asm_t;
         f[G_CONTRAST] = fdiv((double)con_i, sum_p);
@@ -653,7 +685,7 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
         f[G_ENTROPY] = -ent_t;
         f[G_JE] = -ent_t;
         f[G_DIS] = fdiv((double)dis_i, sum_p);
-        f[G_JMAX] = jmax;
+        f[G_JMAX] = (double)cmax * inv_sum_p;
         f[G_JAVE] = mr;
         f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
         f[G_CLUPROM] = sm[8 + 13];
