@@ -315,7 +315,10 @@ __device__ void hu7(double _02, double _03, double _11, double _12, double _20, 
 } // namespace
 
 // Column layout of one 90-wide block (Feature2D order): RM(13) CM(16) NRM(16) NCM(7) HU(7) WRM(10) WCM(7) WNCM(7) WHU(7)
-__global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
+#ifndef NYX_MOM_OCC
+#define NYX_MOM_OCC 4
+#endif
+__global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const MomArgs A)
 {
     __shared__ double s_red[4 * 16];
     __shared__ double s_raw[2][16], s_cen[2][16], s_wraw[2][10], s_wcen[2][7];
@@ -352,19 +355,31 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
 
     // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209);
     //      one sweep per variant (0 = shape, INTEN = 1; 1 = intensity): 16 accumulators stay in registers
+    // (the kernel is bound by vector-instruction issue: a term I x^p y^q is (I x^p) -- four products per pixel -- times y^q,
+    //  accumulated with one fused multiply-add; the shape variant has I = 1 and skips the first product; a variant whose family
+    //  is not requested is not swept at all)
 #pragma unroll 1
     for (int var = 0; var < 2; var++) {
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
+        if (var ? do_i : do_s)
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double X = (double)xi, Y = (double)yi;
-            const double I = var ? (double)vi : 1.0;
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+            if (var) {
+                const double I = (double)vi;
+                const double ix[4] = {I, I * xp[1], I * xp[2], I * xp[3]};
 #pragma unroll
-            for (int p = 0; p < 4; p++)
+                for (int p = 0; p < 4; p++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
+                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = q ? __builtin_fma(ix[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + ix[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
+            }
         });
         mom_block_sum<16, false>(acc, s_red, tid);
         if (tid == 0) {                                  // compile-time indices only: a run-time index would send the array to scratch
@@ -380,14 +395,23 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
+        if (var ? do_i : do_s)
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double dx = (double)xi - ox, dy = (double)yi - oy;
-            const double I = var ? (double)vi : 1.0;
-            const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+            const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
+            if (var) {
+                const double I = (double)vi;
+                const double ix[4] = {I, I * xp[1], I * xp[2], I * xp[3]};
 #pragma unroll
-            for (int p = 0; p < 4; p++)
+                for (int p = 0; p < 4; p++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[p * 4 + q] += I * xp[p] * yp[q];
+                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = q ? __builtin_fma(ix[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + ix[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
+            }
         });
         mom_block_sum<16, false>(acc, s_red, tid);
         if (tid == 0) {
@@ -412,10 +436,11 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
             const double X = (double)xi, Y = (double)yi;
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+            const double sx[4] = {Ws, Ws * xp[1], Ws * xp[2], Ws * xp[3]}, ix[4] = {Wi, Wi * xp[1], Wi * xp[2], Wi * xp[3]};
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                as[k] += Ws * xp[wr_p[k]] * yp[wr_q[k]];
-                ai[k] += Wi * xp[wr_p[k]] * yp[wr_q[k]];
+                as[k] = wr_q[k] ? __builtin_fma(sx[wr_p[k]], yp[wr_q[k]], as[k]) : as[k] + sx[wr_p[k]];
+                ai[k] = wr_q[k] ? __builtin_fma(ix[wr_p[k]], yp[wr_q[k]], ai[k]) : ai[k] + ix[wr_p[k]];
             }
         });
         mom_block_sum<10, false>(as, s_red, tid);
@@ -438,15 +463,17 @@ __global__ __launch_bounds__(kMB, 4) void roi_moments_kernel(const MomArgs A)
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             {
                 const double dx = X - oxs, dy = Y - oys;
-                const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+                const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
+                const double wx[4] = {Ws, Ws * xp[1], Ws * xp[2], Ws * xp[3]};
 #pragma unroll
-                for (int k = 0; k < 7; k++) as[k] += Ws * xp[nc_p[k]] * yp[nc_q[k]];
+                for (int k = 0; k < 7; k++) as[k] = nc_q[k] ? __builtin_fma(wx[nc_p[k]], yp[nc_q[k]], as[k]) : as[k] + wx[nc_p[k]];
             }
             {
                 const double dx = X - oxi, dy = Y - oyi;
-                const double xp[4] = {1.0, 1.0 * dx, 1.0 * dx * dx, 1.0 * dx * dx * dx}, yp[4] = {1.0, 1.0 * dy, 1.0 * dy * dy, 1.0 * dy * dy * dy};
+                const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
+                const double wx[4] = {Wi, Wi * xp[1], Wi * xp[2], Wi * xp[3]};
 #pragma unroll
-                for (int k = 0; k < 7; k++) ai[k] += Wi * xp[nc_p[k]] * yp[nc_q[k]];
+                for (int k = 0; k < 7; k++) ai[k] = nc_q[k] ? __builtin_fma(wx[nc_p[k]], yp[nc_q[k]], ai[k]) : ai[k] + wx[nc_p[k]];
             }
         });
         mom_block_sum<7, false>(as, s_red, tid);
