@@ -1,0 +1,19 @@
+"""profiles/hbm_traffic.json from a tools/profile_bench.sh run: python tools/update_traffic.py <tag>  (reads gpurun_out/prof_<tag>/summary.txt).
+bench.py reports the value as `roofline.traffic` only while nyxus_amd/csrc/roi_features.hip still hashes to what was measured."""
+import hashlib, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+txt = open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "summary.txt")).read()
+fetch = float(re.search(r"FETCH_SIZE: n=\d+ mean=([0-9.e+]+)", txt).group(1))
+write = float(re.search(r"WRITE_SIZE: n=\d+ mean=([0-9.e+]+)", txt).group(1))
+kern = re.search(r"launch group: roi_features_kernel ([0-9.]+) ms \+ glcm_features_kernel ([0-9.]+) ms", txt)
+rec = {"round": tag, "kernel": "roi_features_kernel_occ8<1>", "tiles": 1000, "gray_depth": 8,
+       "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+       "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+       "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
+       "rocprof_kernel_ms": [float(kern.group(1)), float(kern.group(2))] if kern else None,
+       "kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, "nyxus_amd", "csrc", "roi_features.hip"), "rb").read()).hexdigest(),
+       "collected": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), bench.py --steps 5 --warmup 2; "
+                    f"metric-workload dispatches only (profiles/{tag}_summary.txt)"}
+json.dump(rec, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+print(rec["hbm_bytes_per_launch"], rec["kernel_source_sha256"][:12])
