@@ -110,6 +110,23 @@ __device__ __forceinline__ double fdiv(double a, double b)
     return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
+// 1 / b and 1 / sqrt(x) for tolerance-class features: hardware estimate + two Newton steps (within 1-2 ulp).  Callers
+// guarantee a finite, normal, positive argument.
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+__device__ __forceinline__ double frsq(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);          // 1 - x y^2
+    y = __builtin_fma(y * 0.5, e, y);
+    e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * 0.5, e, y);
+}
+
 // ---- wave64 reductions on the DPP path -------------------------------------------------
 // Cross-lane traffic goes through DPP (VALU data-parallel primitives: row_shr within a row
 // of 16 lanes, row_bcast:15 / row_bcast:31 across rows on GFX9-family CDNA) instead of
@@ -398,7 +415,24 @@ __device__ __forceinline__ uint32_t mul_u24_su(uint32_t a, uint32_t b_uniform)
     return r;
 }
 
+// clamp of a per-lane value to wave-uniform bounds lo <= hi: the median of the three, one instruction
+__device__ __forceinline__ uint32_t med3_u32_ss(uint32_t x, uint32_t lo_uniform, uint32_t hi_uniform)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo_uniform), "s"(hi_uniform));   // (one scalar operand per VOP3 on gfx9)
+    return r;
+}
+
 // the same with zero fill through bound_ctrl (no initialisation of the destination)
+// Word of a 16-bit counting table that holds entry ci (two entries per word): base + ((ci & ~1) << 1).  The mask is opaque to
+// the compiler so that the shift and the base add stay one v_lshl_add_u32 (it otherwise canonicalises to shift, mask, add).
+__device__ __forceinline__ uint32_t* cnt16_word(uint32_t* tab, uint32_t ci)
+{
+    uint32_t t;
+    asm("v_and_b32 %0, -2, %1" : "=v"(t) : "v"(ci));
+    return (uint32_t*)((char*)tab + (t << 1));
+}
+
 __device__ __forceinline__ uint32_t lane_plus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_minus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 

@@ -289,7 +289,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         if (L.g16) L.dense8 = 1;
     }
     if ((L.dense8 ? 1ull : 2ull) * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    off = align16(off + (L.dense8 ? 1u : 2u) * L.dense_cap + 8);
+    off = align16(off + (L.dense8 ? 1u * L.dense_cap + 64 + 8 : 2u * L.dense_cap + 8));   // 8-bit planes: + a zero row of 64 bytes + the out-of-box cell
     if (do_glcm) {
         const int greyInfo = s->ibsi ? 0 : s->grey_depth;
         L.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0;
@@ -336,6 +336,13 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         L.P = goff; goff = align16(goff + 4u * app * (ng <= 16 ? (ng + 1) * (ng + 1) : ng * ng));   // split launches count with a skip row / column
         L.gscr = goff; goff = align16(goff + 8u * (25u * ng + 128));
         if (goff > off) off = goff;
+    }
+    if (L.dense8) {
+        // 8-bit plane launches keep the plane at the START of the carve-out (the kernel then needs no base add per store):
+        // [fixed | plane | ...] becomes [plane | fixed | ...], everything behind the two stays where it is
+        const uint32_t dsz = align16(L.dense_cap + 64 + 8);   // the plane's bytes (dense8 implies GLCM; L.dense is 16-byte aligned)
+        L.out += dsz; L.red += dsz; L.stat += dsz; L.lb100 += dsz; L.lbc += dsz;
+        L.dense = 0;
     }
     L.total = off;
     if (L.total > cap) {

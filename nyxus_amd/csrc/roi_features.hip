@@ -747,6 +747,8 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
 // switches are compile-time facts there and their branches disappear from the pixel loops.
 // TIER: occupancy tier of the calling kernel; it only tags the kernel's private copy of glcm_features_rows (kRowsTag), so
 // that caller and callee are always compiled for the same register budget.
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;     // a byte at an absolute LDS address
+
 template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
@@ -763,7 +765,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     uint32_t* s_lbc = (uint32_t*)(lds + A.L.lbc);
     uint32_t* s_val = (uint32_t*)(lds + A.L.val);
     using dense_t = typename std::conditional<D8, uint8_t, uint16_t>::type;
-    dense_t* s_dense = (dense_t*)(lds + A.L.dense);
+    dense_t* s_dense = (dense_t*)(lds + (D8 ? 0u : A.L.dense));     // 8-bit plane launches: the plane opens the carve-out (make_layout)
     uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);
     uint32_t* s_P = (uint32_t*)(lds + A.L.P);
     double* s_g = (double*)(lds + A.L.gscr);
@@ -814,7 +816,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         out_row[c] = 0.0;
     if (do_glcm) {
         uint32_t* d32 = (uint32_t*)s_dense;       // region is 16-byte aligned and padded
-        for (uint32_t i = tid; i < (D8 ? (area + 3) / 4 : (area + 1) / 2); i += kBlock)
+        // (8-bit planes: 64 more zero bytes behind the last row -- the "row below" of the last row and the cell every lane beyond the
+        //  box reads in the co-occurrence sweep; the cell that takes out-of-box coordinates lies behind them)
+        for (uint32_t i = tid; i < (D8 ? (area + 64 + 3) / 4 : (area + 1) / 2); i += kBlock)
             d32[i] = 0;
         if (greyInfo < 0)
             for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
@@ -882,15 +886,15 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 if (use_count)
                 {
                     const uint32_t ci = v[u] - vmin;
-                    if (C16) atomicAdd(&s_cnt[ci >> 1], 1u << (16 * (ci & 1u)));   // halves never carry: a count is < 65536
+                    if (C16) atomicAdd(cnt16_word(s_cnt, ci), 1u << (16 * (ci & 1u)));   // halves never carry: a count is < 65536
                     else atomicAdd(&s_cnt[ci], 1u);
                 }
             }
             if (do_glcm) {
                 uint32_t lvl = 0;
                 if (NZ || v[u] != 0) { // original-intensity 0 is skipped by the scan (glcm.cpp:445)
-                    if (FAST || G16) {  // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already
-                        const uint32_t sc = (uint32_t)floor(mslope * (double)v[u] + 1.0);
+                    if (FAST || G16) {  // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already (the conversion truncates: floor of a positive value)
+                        const uint32_t sc = (uint32_t)(mslope * (double)v[u] + 1.0);
                         lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
                     } else
                     lvl = greyInfo > 0 ? bin_matlab(v[u], mslope, greyInfo)
@@ -903,8 +907,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // a cell index inside the plane is all the store needs to be safe (coordinates beyond the box are the caller's
                 // contract violation; they cannot leave the plane)
                 const uint32_t cell = __umul24(py[u], w) + px[u];
-                if (cell < area)
-                    s_dense[cell] = D8 ? (dense_t)lvl : (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);   // D8: matlab levels <= 16
+                if (D8)                                    // the plane is padded: cell `area` takes whatever violates the contract
+                    *(lds_u8_t*)(cell < area ? cell : area + 64) = (uint8_t)lvl;   // D8: matlab levels <= 64; the plane starts at LDS address 0 (launcher-checked)
+                else if (cell < area)
+                    s_dense[cell] = (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
             }
         }
         if (TINY) { sum += s32; sumsq += q32; }
@@ -967,7 +973,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     sumsq += small_v ? (uint32_t)__umul24(v, v) : (uint32_t)(v * v);
                     if (use_count) {
                         const uint32_t ci = v - vmin;
-                        if (C16) atomicAdd(&s_cnt[ci >> 1], 1u << (16 * (ci & 1u)));
+                        if (C16) atomicAdd(cnt16_word(s_cnt, ci), 1u << (16 * (ci & 1u)));
                         else atomicAdd(&s_cnt[ci], 1u);
                     }
                 }
@@ -975,7 +981,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     uint32_t lvl = 0;
                     if (nz || v != 0) {
                         if (FAST || G16) {
-                            const uint32_t sc = (uint32_t)floor(mslope * (double)v + 1.0);
+                            const uint32_t sc = (uint32_t)(mslope * (double)v + 1.0);
                             lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
                         } else
                         lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
@@ -1064,6 +1070,41 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             // on ties: histogram.h:289-309) falls out of the same sweep
             uint32_t carry = 0, best_c = 0, best_i = 0;
             const uint32_t base = wave * Q;
+            if (C16) {
+                // 16-bit tables: a lane's four entries arrive as two words and stay packed.  No half ever carries into its
+                // neighbour (every partial sum is a pixel count < 65536), so plain 32-bit adds work on both halves at once:
+                //   A = x + (x << 16) = (c0, c0+c1),  B likewise for (c2, c3),  lane total T = (A + B) >> 16;
+                //   the scanned totals are replicated into both halves and added to A and B in one instruction each.
+                // Mode: key = count << 16 | (0xFFFF - index) -- the largest key is the largest count and, among equals, the smallest
+                // index (an index is < 16384 here).  Four running maxima, one per entry of the lane, share the lane's base index;
+                // the 1, 2, 3 they are off by are subtracted once after the loop.
+                uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+                uint32_t inv = 0xFFFFu - (base + 4u * (uint32_t)lane);
+                const uint2* src = (const uint2*)((const uint16_t*)s_cnt + base + 4u * (uint32_t)lane);
+                uint32_t i = base + 4u * (uint32_t)lane;
+                for (uint32_t t = 0; t < Q; t += 256, i += 256, inv -= 256, src += 64) {
+                    uint2 pk = make_uint2(0, 0);
+                    const bool live = i <= range;
+                    if (live) pk = *src;
+                    k0 = max(k0, (pk.x << 16) | inv);
+                    k1 = max(k1, (pk.x & 0xFFFF0000u) | inv);
+                    k2 = max(k2, (pk.y << 16) | inv);
+                    k3 = max(k3, (pk.y & 0xFFFF0000u) | inv);
+                    const uint32_t Apk = pk.x + (pk.x << 16), Bpk = pk.y + (pk.y << 16);
+                    const uint32_t T = (Apk + Bpk) >> 16;
+                    const uint32_t sc = wave_scan_u32(T);
+                    const uint32_t excl = carry + sc - T;
+                    const uint32_t E = excl | (excl << 16);
+                    const uint32_t Ah = __builtin_amdgcn_perm(Apk, Apk, 0x03020302u);     // (A.hi, A.hi)
+                    if (live)
+                        *(uint2*)src = make_uint2(Apk + E, Bpk + E + Ah);
+                    carry += readlane63(sc);
+                }
+                k1 -= 1; k2 -= 2; k3 -= 3;                 // (a key with count 0 never wins: the ROI has a pixel)
+                const uint32_t key = wave_max_u32(max(max(k0, k1), max(k2, k3)));
+                best_c = key >> 16;
+                best_i = 0xFFFFu - (key & 0xFFFFu);
+            } else
             for (uint32_t t = 0; t < Q; t += 256) {
                 uint32_t i = base + t + 4 * lane;
                 uint4 c4 = make_uint4(0, 0, 0, 0);
@@ -1100,7 +1141,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 carry += readlane63(sc);
             }
             // wave-level best (count desc, index asc)
-            {   // (count desc, index asc) as one key: the largest count wins, ties go to the smallest index
+            if (!C16) {   // (count desc, index asc) as one key: the largest count wins, ties go to the smallest index
                 const uint32_t mc_w = wave_max_u32(best_c);
                 const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
                 best_i = ~wave_max_u32(~cand);                  // min over the lanes that hold the maximum
@@ -1112,12 +1153,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 s_red[wave * 8 + 2] = (double)best_i;
             }
             blk_sync<GS>();
-            uint32_t mc = 0, mi = 0;
-            for (int wv = 0; wv < kWaves; wv++) {
-                uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
-                if (c > mc) { mc = c; mi = i; } // waves cover ascending value ranges
-            }
             if (tid == 0) {
+                uint32_t mc = 0, mi = 0;
+                for (int wv = 0; wv < kWaves; wv++) {
+                    uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
+                    if (c > mc) { mc = c; mi = i; } // waves cover ascending value ranges
+                }
                 const uint32_t woff1 = (uint32_t)s_red[0], woff2 = woff1 + (uint32_t)s_red[8], woff3 = woff2 + (uint32_t)s_red[16];
                 s_woff[0] = 0; s_woff[1] = woff1; s_woff[2] = woff2; s_woff[3] = woff3;
                 s_stat[S_MODE] = (double)(vmin + mi);
@@ -1143,29 +1184,36 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 #endif
         double acc[6] = {0, 0, 0, 0, 0, 0};
         auto central_outputs = [&](const double (&acc)[6]) {   // everything that depends only on the sums (single lane)
+            // Tolerance-class outputs: the quotients and roots go through reciprocal / reciprocal-square-root estimates with two
+            // Newton steps (1-2 ulp) and are shared -- 1/n, 1/(n-1), 1/sqrt(variance), 1/sqrt(M2), 1/sqrt(n) -- instead of ten
+            // IEEE divisions and five IEEE roots on one lane (which the whole wave waits for): ~90 instead of ~250 instructions.
             const double var = acc[1];                 // intensity.cpp:110-118
-            o[I_MEAN_ABSOLUTE_DEVIATION] = fdiv(acc[0], dn);
-            const double variance = dn > 1 ? fdiv(var, dn - 1) : 0.0;
-            const double variance_b = dn > 1 ? fdiv(var, dn) : 0.0;
-            const double sd = sqrt(variance);
+            const double inv_n = frcp(dn);
+            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] * inv_n;
+            const double variance = dn > 1 ? var * frcp(dn - 1) : 0.0;
+            const double variance_b = dn > 1 ? var * inv_n : 0.0;
+            const double rsd = variance > 0 ? frsq(variance) : 0.0;     // 1 / sd (0 stands for "sd == 0": every use below tests it)
+            const double sd = variance * rsd;
+            const double rs_n = frsq(dn);
             o[I_VARIANCE] = variance;
             o[I_VARIANCE_BIASED] = variance_b;
             o[I_STANDARD_DEVIATION] = sd;
-            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
-            o[I_COV] = sd / mean;
-            o[I_STANDARD_ERROR] = fdiv(sd, sqrt(dn));
+            o[I_STANDARD_DEVIATION_BIASED] = variance_b > 0 ? variance_b * frsq(variance_b) : 0.0;
+            o[I_COV] = sd / mean;                      // (IEEE: a zero mean must give the reference's inf / NaN)
+            o[I_STANDARD_ERROR] = sd * rs_n;
             if (!blank) {
                 const double M2 = acc[1], M3 = acc[2], M4 = acc[3]; // moments.h:79-109
                 if (M2 != 0.0) {
-                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / (M2 * sqrt(M2)) : 0.0;   // pow(M2, 1.5)
-                    o[I_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
-                    o[I_EXCESS_KURTOSIS] = n > 4 ? (dn * M4) / (M2 * M2) - 3 : 0.0;
+                    const double r = frsq(M2), r2 = r * r;           // 1 / sqrt(M2), 1 / M2
+                    const double kurt = n > 4 ? (dn * M4) * (r2 * r2) : 0.0;
+                    o[I_SKEWNESS] = n > 3 ? ((dn * rs_n) * M3) * (r2 * r) : 0.0;   // sqrt(n) M3 / pow(M2, 1.5)
+                    o[I_KURTOSIS] = kurt;
+                    o[I_EXCESS_KURTOSIS] = n > 4 ? kurt - 3 : 0.0;
                 }
-                const double sd2 = sd * sd;
-                double denom = dn * (sd2 * sd2 * sd);  // n * pow(sd, 5), intensity.cpp:186-191
-                o[I_HYPERSKEWNESS] = denom == 0. ? 0. : acc[4] / denom;
-                denom = dn * (sd2 * sd2 * sd2);
-                o[I_HYPERFLATNESS] = denom == 0. ? 0. : acc[5] / denom;
+                // n * pow(sd, 5), n * pow(sd, 6), intensity.cpp:186-191; a zero denominator gives 0
+                const double rsd2 = rsd * rsd, t5 = inv_n * (rsd2 * rsd2 * rsd);
+                o[I_HYPERSKEWNESS] = acc[4] * t5;
+                o[I_HYPERFLATNESS] = acc[5] * (t5 * rsd);
             }
         };
         if (!FUSED || blank) {
@@ -1195,15 +1243,32 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 const uint32_t b = is100 ? t : t - 100;
                 uint32_t lo;
                 if (use_count) {
-                    // smallest offset d in [0, range+1] whose bin index reaches b: start from the
-                    // real-valued boundary and settle with the exact (reference) bin function
-                    double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
-                    uint32_t d = edge >= (double)range + 1.0 ? range + 1 : (uint32_t)edge;
+                    // smallest offset d in [0, range+1] whose bin index reaches b
                     auto bin_of = [=](uint32_t dd) -> uint32_t {
                         return is100 ? (uint32_t)idx100(vmin + dd) : to_grayscale(vmin + dd, vmin, range, nb);
                     };
-                    while (d > 0 && bin_of(d - 1) >= b) d--;
-                    while (d <= range && bin_of(d) < b) d++;
+                    uint32_t d;
+                    if (range < 65536u) {
+                        // The real-valued boundary is P = b * (bin width).  Unless P lies within 1e-6 of an integer, the answer is
+                        // floor(P) + 1 with certainty: the reference's bin function (one or two fp64 roundings of a value below
+                        // 2^16) cannot move a value that is >= 1e-6 / range away from the boundary across it.  Next to an integer m
+                        // the exact bin function decides between m and m + 1 (m - 1 is a whole bin width / range away): one
+                        // evaluation, no search -- and a wave pays it only when one of its lanes is such a boundary.
+                        const double Wl = is100 ? binW100 : (double)range / (double)nb;
+                        const double P = (double)b * Wl;
+                        const uint32_t m = (uint32_t)(P + 0.5);
+                        d = (uint32_t)P + 1;
+                        if (b == 0)
+                            d = 0;
+                        else if (fabs(P - (double)m) < 1e-6)
+                            d = bin_of(m) >= b ? m : m + 1;
+                    } else {
+                        // wide ranges: start from the real-valued boundary and settle with the exact (reference) bin function
+                        double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
+                        d = edge >= (double)range + 1.0 ? range + 1 : (uint32_t)edge;
+                        while (d > 0 && bin_of(d - 1) >= b) d--;
+                        while (d <= range && bin_of(d) < b) d++;
+                    }
                     lo = d > 0 ? cum(d - 1) : 0u;
                 } else {
                     uint32_t hi = n;
@@ -1363,7 +1428,14 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 }
                 lox = (uint32_t)__builtin_amdgcn_readfirstlane((int)lox);
                 span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
+                const uint32_t hix = lox + span;
                 const uint32_t m2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((median - (double)vmin) * 2.0));
+                const uint32_t kmed = m2x >> 1;                 // floor(median) - vmin; the median is kmed or kmed + 1/2
+                // The in-range tests cost nothing per value: x is CLAMPED to [lox, hix] (one v_med3_u32) and summed as it is; the
+                // values below / above the range contribute lox / hix each, and how many there are is in the cumulative table:
+                //   sum over [p10, p90] of x  =  sum of clamp(x)  -  #below * lox  -  #above * hix.
+                // Likewise sum |x - median| = sum |x - kmed| (one v_sad_u32, accumulating) + the half-integer correction
+                //   (#(x <= kmed) - #(x > kmed)) / 2  when the median is kmed + 1/2.
                 uint32_t sx = 0, sad = 0;
                 const double meanx = mean - (double)vmin;       // deviations are taken in the offset domain: d = x - (mean - vmin)
                 auto px1 = [&](uint32_t x) {
@@ -1376,9 +1448,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     const double d4 = d2 * d2;
                     acc[4] = __builtin_fma(d4, d, acc[4]);
                     acc[5] = __builtin_fma(d4, d2, acc[5]);
-                    sx += (x - lox) <= span ? x : 0u;
-                    const uint32_t x2 = x << 1;
-                    sad += x2 > m2x ? x2 - m2x : m2x - x2;
+                    sx += med3_u32_ss(x, lox, hix);
+                    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(sad) : "v"(x), "s"(kmed));
                 };
                 // the trip count is wave-uniform (n / 256 full trips, then the lanes below n % 256 once more): the loop control
                 // runs on the scalar unit and costs no vector instruction per value
@@ -1409,9 +1480,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // every thread needs the in-range sum (sweep 2) and the population of [p10, p90] (read off the cumulative table);
                 // the other totals are read by the one lane that derives the outputs -- no barrier follows: the next exchange
                 // (sweep 2's) goes through its own scratch (the percentile bounds, dead by now)
-                const double Sx = (s_red[6] + s_red[8 + 6]) + (s_red[16 + 6] + s_red[24 + 6]);
-                const uint32_t K = span == 0 && lox == 0x80000000u ? 0u : cum(lox + span) - (lox ? cum(lox - 1) : 0u);
-                const double dK = (double)K;
+                const bool empty = span == 0 && lox == 0x80000000u;
+                const uint32_t n_below = (uint32_t)__builtin_amdgcn_readfirstlane((int)((empty || lox == 0) ? 0u : cum(lox - 1)));
+                const uint32_t n_upto = (uint32_t)__builtin_amdgcn_readfirstlane((int)(empty ? 0u : cum(hix)));
+                const uint32_t K = n_upto - n_below, n_above = n - n_upto;                 // (wave-uniform: the products below run on the scalar unit)
+                const uint32_t Sx_all = (uint32_t)((s_red[6] + s_red[8 + 6]) + (s_red[16 + 6] + s_red[24 + 6]));
+                const uint32_t Sxu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Sx_all - n_below * lox - n_above * hix));   // < 2^30
+                const double Sx = (double)Sxu, dK = (double)K;
                 if (tid == 0) {
                     double a6[6];
 #pragma unroll
@@ -1419,28 +1494,54 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         a6[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
                         asm volatile("" : "+v"(a6[k]) :: "memory");   // one total at a time: 28 reads in flight (or their adds sunk into the output code) would spill
                     }
-                    const double sadt = (s_red[7] + s_red[8 + 7]) + (s_red[16 + 7] + s_red[24 + 7]);
+                    // sum |2x - m2x| = 2 sum |x - kmed| + (2 #(x <= kmed) - n  when m2x is odd)
+                    const double sadk = (s_red[7] + s_red[8 + 7]) + (s_red[16 + 7] + s_red[24 + 7]);
+                    const double sadt = 2.0 * sadk + ((m2x & 1u) ? 2.0 * (double)cum(kmed) - dn : 0.0);
                     central_outputs(a6);
                     o[I_ROBUST_MEAN] = K ? (Sx + dK * (double)vmin) / dK : 0.0;   // exact integer sum / count, as the reference's
                     o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(sadt * 0.5, dn);
                 }
-                // sweep 2: robust MAD about mean1090 = S / K (histogram.h:102-112): sum |a - S/K| = sum |K x - Sx| / K, exact in integers
-                const uint32_t Ku = K, Sxu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Sx);
-                unsigned long long ad = 0;
-                auto px2 = [&](uint32_t x) {
-                    const uint32_t t = (uint32_t)__umul24(Ku, x);            // < 2^30
-                    uint32_t dlt;
-                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dlt) : "v"(t), "s"(Sxu));   // |t - Sx| in one instruction
-                    ad += (x - lox) <= span ? dlt : 0u;
-                };
-                for (uint32_t k = 0; k < n_full; k++)
-                    px2(pv[k * kBlock]);
-                if ((uint32_t)tid < n_rem)
-                    px2(pv[n_full * kBlock]);
-                double ad1[1] = {(double)ad};
+                // sweep 2: robust MAD about mean1090 = S / K (histogram.h:102-112): sum |a - S/K| = sum |K x - Sx| / K, exact in integers.
+                // The clamp again: sum over ALL values of |K clamp(x) - Sx|, minus what the values outside contribute
+                // (#below |K lox - Sx| + #above |K hix - Sx|) -- three instructions per value.  32-bit lane sums need
+                // trips * K * span < 2^32 (|K x - Sx| <= K span inside the range); otherwise the masked 64-bit form.
+                const uint32_t Ku = K;
+                const bool fast32 = (unsigned long long)(n_full + 1) * Ku * (span + 1ull) < (1ull << 32);
+                double ad1[1];
+                if (fast32) {
+                    uint32_t ad = 0;
+                    auto px2 = [&](uint32_t x) {
+                        const uint32_t t = mul_u24_su(med3_u32_ss(x, lox, hix), Ku);      // < 2^30
+                        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(ad) : "v"(t), "s"(Sxu));
+                    };
+                    for (uint32_t k = 0; k < n_full; k++)
+                        px2(pv[k * kBlock]);
+                    if ((uint32_t)tid < n_rem)
+                        px2(pv[n_full * kBlock]);
+                    ad1[0] = (double)ad;
+                } else {
+                    unsigned long long ad = 0;
+                    auto px2 = [&](uint32_t x) {
+                        const uint32_t t = (uint32_t)__umul24(Ku, x);            // < 2^30
+                        uint32_t dlt;
+                        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dlt) : "v"(t), "s"(Sxu));   // |t - Sx| in one instruction
+                        ad += (x - lox) <= span ? dlt : 0u;
+                    };
+                    for (uint32_t k = 0; k < n_full; k++)
+                        px2(pv[k * kBlock]);
+                    if ((uint32_t)tid < n_rem)
+                        px2(pv[n_full * kBlock]);
+                    ad1[0] = (double)ad;
+                }
                 block_sum<1, GS>(ad1, (double*)s_lb100, tid);
-                if (tid == 0)
-                    o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? fdiv(fdiv(ad1[0], dK), dK) : 0.0;
+                if (tid == 0) {
+                    double adin = ad1[0];
+                    if (fast32) {                      // (exact: every term is an integer below 2^53)
+                        const double klo = (double)Ku * (double)lox, khi = (double)Ku * (double)hix;
+                        adin -= (double)n_below * fabs(klo - Sx) + (double)n_above * fabs(khi - Sx);
+                    }
+                    o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? fdiv(fdiv(adin, dK), dK) : 0.0;
+                }
             } else {
             // sweep 1: sum and count inside [p10, p90], and the median absolute deviation (it only needs the median)
             double rb[3] = {0, 0, 0};
@@ -1703,17 +1804,39 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         char* const T3 = (char*)(s_P + (slot3 >= 0 ? slot3 : 0) * cells);
                         if (has0 && has1 && has2 && has3 && !sym) {
                             // the usual request -- four angles, asymmetric: nothing but the four adds per row
+                            auto pairs = [&](uint32_t c4, uint32_t n4) {
+                                const uint32_t nb_e = lane_plus1_z(c4), nb_se = lane_plus1_z(n4), nb_sw = lane_minus1_z(n4);
+                                if (c4 != 0) {        // skipped centres (a third of a disk's box) stay out: piled on one cell their adds serialise
+                                    const uint32_t rowb = mul_u24_su(c4, ng1);
+                                    atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
+                                    atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
+                                    atomicAdd((uint32_t*)(T2 + rowb + n4), 1u);
+                                    atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
+                                }
+                            };
+                            if (D8) {
+                                // 8-bit plane at LDS address 0 with 64 zero bytes behind its last row: a lane of the box walks its column
+                                // (stride w), a lane beyond the box keeps reading one of the zero bytes (stride 0), and the row below
+                                // the last row is the zero row -- the read needs no test at all
+                                uint32_t adr = in_col ? (uint32_t)(r_begin + 1) * w + (uint32_t)lane : area + (uint32_t)lane - w;
+                                const uint32_t stride = in_col ? w : 0u;
+                                if (r_begin >= r_end) cur4 = 0;
+                                int row = r_begin;
+                                for (; row + 1 < r_end; row += 2) {   // two rows per trip: the row below becomes the centre row without a move
+                                    const uint32_t n4a = (uint32_t)(*(const lds_u8_t*)adr) << 2;
+                                    pairs(cur4, n4a);
+                                    const uint32_t n4b = (uint32_t)(*(const lds_u8_t*)(adr + stride)) << 2;
+                                    pairs(n4a, n4b);
+                                    cur4 = n4b;
+                                    adr += 2 * stride;
+                                }
+                                if (row < r_end)
+                                    pairs(cur4, (uint32_t)(*(const lds_u8_t*)adr) << 2);
+                            } else
                             for (int row = r_begin; row < r_end; row++) {
                                 uint32_t nxt4 = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
                                 nxt4 <<= 2;
-                                const uint32_t nb_e = lane_plus1_z(cur4), nb_se = lane_plus1_z(nxt4), nb_sw = lane_minus1_z(nxt4);
-                                if (cur4 != 0) {      // skipped centres (a third of a disk's box) stay out: piled on one cell their adds serialise
-                                    const uint32_t rowb = mul_u24_su(cur4, ng1);
-                                    atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
-                                    atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
-                                    atomicAdd((uint32_t*)(T2 + rowb + nxt4), 1u);
-                                    atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
-                                }
+                                pairs(cur4, nxt4);
                                 cur4 = nxt4;
                             }
                         } else
@@ -1941,6 +2064,16 @@ size_t roi_features_max_lds()
 
 namespace {
 
+// The 8-bit plane is addressed by absolute LDS addresses (it opens the carve-out, and the carve-out is expected at LDS address 0):
+// true as long as the kernel owns no static LDS in front of its dynamic allocation.
+int no_static_lds(const void* f)
+{
+    hipFuncAttributes at;
+    if (hipError_t e = hipFuncGetAttributes(&at, f); e != hipSuccess)
+        return (int)e;
+    return at.sharedSizeBytes == 0 ? 0 : (int)hipErrorInvalidConfiguration;
+}
+
 template <bool C16, bool SPLIT, bool D8>
 int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
@@ -1953,6 +2086,8 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
                 return (int)e;
+            if (int src = no_static_lds(f))
+                return src;
         }
         return 0;
     }))
@@ -1992,7 +2127,11 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] features launch: g16 %u dense8 %u cnt16 %u ng_cap %u app %u total %u mask %u gd %d\n", a.L.g16, a.L.dense8, a.L.cnt16, a.L.ng_cap, a.L.app, a.L.total, a.mask, a.grey_depth);
     if (a.L.g16) {
         static DeviceOnce optin;
-        if (int orc = optin.run([]() -> int { return (int)hipFuncSetAttribute((const void*)roi_features_kernel_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); }))
+        if (int orc = optin.run([]() -> int {
+                if (hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); e != hipSuccess)
+                    return (int)e;
+                return no_static_lds((const void*)roi_features_kernel_g16);
+            }))
             return orc;
         hipLaunchKernelGGL(roi_features_kernel_g16, dim3(grid), dim3(kBlock), a.L.total, st, a);
         return (int)hipGetLastError();
