@@ -1019,7 +1019,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             sum = wave_sum_t<uint32_t>((uint32_t)sum);
         else
             sum = wave_sum_u64(sum);
-        sumsq = wave_sum_u64(sumsq);
+        if (C16) {   // n < 65536: a lane's sum of squares is below 2^41 -- two 32-bit DPP sums (bits 0..23, bits 24..) instead of a 64-bit one
+            const uint32_t lo24 = wave_sum_t<uint32_t>((uint32_t)sumsq & 0xFFFFFFu), hi = wave_sum_t<uint32_t>((uint32_t)(sumsq >> 24));
+            sumsq = ((unsigned long long)hi << 24) + lo24;
+        } else
+            sumsq = wave_sum_u64(sumsq);
         if (lane == 0) {
             s_red[wave * 8 + 0] = (double)sum;
             s_red[wave * 8 + 1] = (double)sumsq;
@@ -1034,6 +1038,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             }
             const double mean = tot / dn;              // the one IEEE division; every other thread reads the mean after the barrier
             s_stat[S_MEAN] = mean;
+            if (FAST)                                  // GLCM degenerate guard (glcm.cpp:27-95, on GLCM_GREYDEPTH): two binnings, once per ROI
+                s_stat[S_NG] = bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth) ? 1.0 : 0.0;
             o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
             o[I_MAX] = (double)vmax;
             o[I_RANGE] = (double)vmax - (double)vmin;
@@ -1361,6 +1367,23 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     o[I_INTERQUARTILE_RANGE] = pq[3] - pq[2];
                     s_stat[S_P10] = pq[1];
                     s_stat[S_P90] = pq[4];
+                    if (FUSED) {
+                        // bounds of the robust statistics in the offset domain and the populations around them (see the fused sweep):
+                        // derived once, here, instead of by every thread of the workgroup
+                        const double p10 = pq[1], p90 = pq[4];
+                        uint32_t lox = 0x80000000u, span = 0;                   // empty range unless the bounds say otherwise (NaN: empty)
+                        if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
+                            const double cl = ceil(p10), fl = floor(p90);
+                            const uint32_t lo_v = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_v = fl >= (double)vmax ? vmax : (uint32_t)fl;
+                            if (lo_v <= hi_v) { lox = lo_v - vmin; span = hi_v - lo_v; }
+                        }
+                        const bool empty = span == 0 && lox == 0x80000000u;
+                        uint32_t* const s_rob = (uint32_t*)(s_stat + 6);
+                        s_rob[0] = lox;
+                        s_rob[1] = span;
+                        s_rob[2] = (empty || lox == 0) ? 0u : cum(lox - 1);       // values below the range
+                        s_rob[3] = empty ? 0u : cum(lox + span);                  // values up to its upper end
+                    }
                 }
             } else if (wave == 1) {
                 // entropy / uniformity over the n+1 slots (histogram.h:145-151): slot n is empty
@@ -1407,6 +1430,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     o[I_MEDIAN] = median;
                     o[I_MODE] = s_stat[S_MODE];
                     s_stat[S_MEDIAN] = median;
+                    if (FUSED) {   // 2 (median - vmin) as an integer, and #(x <= floor(median)) for the half-integer correction of the MAD
+                        const uint32_t m2x = (uint32_t)((median - (double)vmin) * 2.0);
+                        uint32_t* const s_med = (uint32_t*)(s_stat + 10);
+                        s_med[0] = m2x;
+                        s_med[1] = (m2x & 1u) ? cum(m2x >> 1) : 0u;
+                    }
                 }
             }
             blk_sync<GS>();
@@ -1420,16 +1449,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 //   a >= p10 && a <= p90  <=>  lox <= x <= hix  with  lox = ceil(p10) - vmin, hix = floor(p90) - vmin  (a is an integer)
                 //   sum |a - median| = sum |2x - m2x| / 2,  m2x = 2 (median - vmin)  (an integer: the median is k or k + 1/2)
                 // Every partial sum fits 32 bits: n < 65536 and x < 16384 in a C16 launch.
-                uint32_t lox = 0x80000000u, span = 0;                       // empty range unless the bounds say otherwise (NaN: empty)
-                if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
-                    const double cl = ceil(p10), fl = floor(p90);
-                    const uint32_t lo_v = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_v = fl >= (double)vmax ? vmax : (uint32_t)fl;
-                    if (lo_v <= hi_v) { lox = lo_v - vmin; span = hi_v - lo_v; }
-                }
-                lox = (uint32_t)__builtin_amdgcn_readfirstlane((int)lox);
-                span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
+                const uint32_t* const s_rob = (const uint32_t*)(s_stat + 6);     // written by the percentile / median lanes above
+                const uint32_t lox = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[0]), span = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[1]);
                 const uint32_t hix = lox + span;
-                const uint32_t m2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((median - (double)vmin) * 2.0));
+                const uint32_t m2x = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t*)(s_stat + 10))[0]);
                 const uint32_t kmed = m2x >> 1;                 // floor(median) - vmin; the median is kmed or kmed + 1/2
                 // The in-range tests cost nothing per value: x is CLAMPED to [lox, hix] (one v_med3_u32) and summed as it is; the
                 // values below / above the range contribute lox / hix each, and how many there are is in the cumulative table:
@@ -1480,9 +1503,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // every thread needs the in-range sum (sweep 2) and the population of [p10, p90] (read off the cumulative table);
                 // the other totals are read by the one lane that derives the outputs -- no barrier follows: the next exchange
                 // (sweep 2's) goes through its own scratch (the percentile bounds, dead by now)
-                const bool empty = span == 0 && lox == 0x80000000u;
-                const uint32_t n_below = (uint32_t)__builtin_amdgcn_readfirstlane((int)((empty || lox == 0) ? 0u : cum(lox - 1)));
-                const uint32_t n_upto = (uint32_t)__builtin_amdgcn_readfirstlane((int)(empty ? 0u : cum(hix)));
+                const uint32_t n_below = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[2]);
+                const uint32_t n_upto = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[3]);
                 const uint32_t K = n_upto - n_below, n_above = n - n_upto;                 // (wave-uniform: the products below run on the scalar unit)
                 const uint32_t Sx_all = (uint32_t)((s_red[6] + s_red[8 + 6]) + (s_red[16 + 6] + s_red[24 + 6]));
                 const uint32_t Sxu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Sx_all - n_below * lox - n_above * hix));   // < 2^30
@@ -1496,7 +1518,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     }
                     // sum |2x - m2x| = 2 sum |x - kmed| + (2 #(x <= kmed) - n  when m2x is odd)
                     const double sadk = (s_red[7] + s_red[8 + 7]) + (s_red[16 + 7] + s_red[24 + 7]);
-                    const double sadt = 2.0 * sadk + ((m2x & 1u) ? 2.0 * (double)cum(kmed) - dn : 0.0);
+                    const double sadt = 2.0 * sadk + ((m2x & 1u) ? 2.0 * (double)((const uint32_t*)(s_stat + 10))[1] - dn : 0.0);
                     central_outputs(a6);
                     o[I_ROBUST_MEAN] = K ? (Sx + dK * (double)vmin) / dK : 0.0;   // exact integer sum / count, as the reference's
                     o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(sadt * 0.5, dn);
@@ -1578,6 +1600,140 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // =====================================================================================
     // GLCM
     // =====================================================================================
+    if (FAST) {
+        // ---- INTENSITY + GLCM under matlab binning with <= 16 levels, counts exported to glcm_features_kernel: the straight-line
+        // form of the general block below (one pass over all angles, matrix order = grey depth, 8-bit plane at LDS address 0,
+        // skip-column matrices).  Kept apart because the general block's loop structure and run-time cases cost this build
+        // ~60 scalar-register spills per wave (each a vector instruction).
+        double* o = out_row + A.col_glcm;
+        const int na = A.glcm_na;
+        const int Ng = greyInfo, NG1 = Ng + 1, NN = Ng * Ng, cells = NG1 * NG1;
+        const bool degenerate = s_stat[S_NG] != 0.0;
+        if (tid == 0)
+            A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
+        if (degenerate) {
+            for (int c = tid; c < kGlcmAngled * na + kGlcmAve; c += kBlock)
+                o[c] = A.soft_nan;
+            return;
+        }
+        const bool dpp = A.glcm_offset == 1 && w <= 64;
+        const bool symmetric = A.glcm_symmetric != 0;
+        blk_sync<GS>();
+        for (int i = tid; i < na * (dpp ? cells : NN); i += kBlock)
+            s_P[i] = 0;
+        blk_sync<GS>();
+        STAMP(10);
+        if (dpp) {
+            int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+            for (int q = 0; q < kMaxAngles; q++)
+                if (q < na) {
+                    const int ang = A.glcm_angles[q];
+                    if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                }
+            const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+            const int r_begin = wave * rows_per_wave;
+            const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+            const bool in_col = lane < (int)w;
+            const uint32_t ng1 = (uint32_t)NG1;
+            char* const T0 = (char*)(s_P + (slot0 >= 0 ? slot0 : 0) * cells);
+            char* const T1 = (char*)(s_P + (slot1 >= 0 ? slot1 : 0) * cells);
+            char* const T2 = (char*)(s_P + (slot2 >= 0 ? slot2 : 0) * cells);
+            char* const T3 = (char*)(s_P + (slot3 >= 0 ? slot3 : 0) * cells);
+            // a lane of the box walks its column of the plane (stride w), a lane beyond the box keeps reading one of the 64 zero
+            // bytes behind the last row (stride 0), and the row below the last row is that zero row: the read needs no test
+            uint32_t adr = in_col ? (uint32_t)r_begin * w + (uint32_t)lane : area + (uint32_t)lane - w;
+            const uint32_t stride = in_col ? w : 0u;
+            uint32_t cur4 = r_begin < r_end ? (uint32_t)(*(const lds_u8_t*)adr) << 2 : 0u;
+            adr += stride;
+            if (slot0 >= 0 && slot1 >= 0 && slot2 >= 0 && slot3 >= 0 && !symmetric) {
+                // the usual request -- four angles, asymmetric: nothing but the four adds per row
+                auto pairs = [&](uint32_t c4, uint32_t n4) {
+                    const uint32_t nb_e = lane_plus1_z(c4), nb_se = lane_plus1_z(n4), nb_sw = lane_minus1_z(n4);
+                    if (c4 != 0) {        // skipped centres (a third of a disk's box) stay out: piled on one cell their adds serialise
+                        const uint32_t rowb = mul_u24_su(c4, ng1);
+                        atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
+                        atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
+                        atomicAdd((uint32_t*)(T2 + rowb + n4), 1u);
+                        atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
+                    }
+                };
+                int row = r_begin;
+                for (; row + 1 < r_end; row += 2) {   // two rows per trip: the row below becomes the centre row without a move
+                    const uint32_t n4a = (uint32_t)(*(const lds_u8_t*)adr) << 2;
+                    pairs(cur4, n4a);
+                    const uint32_t n4b = (uint32_t)(*(const lds_u8_t*)(adr + stride)) << 2;
+                    pairs(n4a, n4b);
+                    cur4 = n4b;
+                    adr += 2 * stride;
+                }
+                if (row < r_end)
+                    pairs(cur4, (uint32_t)(*(const lds_u8_t*)adr) << 2);
+            } else {
+                const int has0 = slot0 >= 0, has1 = slot1 >= 0, has2 = slot2 >= 0, has3 = slot3 >= 0;
+                for (int row = r_begin; row < r_end; row++, adr += stride) {
+                    const uint32_t nxt4 = (uint32_t)(*(const lds_u8_t*)adr) << 2;
+                    const uint32_t nb_e = lane_plus1_z(cur4), nb_se = lane_plus1_z(nxt4), nb_sw = lane_minus1_z(nxt4);
+                    if (cur4 != 0) {
+                        const uint32_t rowb = mul_u24_su(cur4, ng1);
+                        if (has0) atomicAdd((uint32_t*)(T0 + rowb + nb_e), 1u);
+                        if (has1) atomicAdd((uint32_t*)(T1 + rowb + nb_se), 1u);
+                        if (has2) atomicAdd((uint32_t*)(T2 + rowb + nxt4), 1u);
+                        if (has3) atomicAdd((uint32_t*)(T3 + rowb + nb_sw), 1u);
+                        if (symmetric) {
+                            if (has0) atomicAdd((uint32_t*)(T0 + mul_u24_su(nb_e, ng1) + cur4), 1u);
+                            if (has1) atomicAdd((uint32_t*)(T1 + mul_u24_su(nb_se, ng1) + cur4), 1u);
+                            if (has2) atomicAdd((uint32_t*)(T2 + mul_u24_su(nxt4, ng1) + cur4), 1u);
+                            if (has3) atomicAdd((uint32_t*)(T3 + mul_u24_su(nb_sw, ng1) + cur4), 1u);
+                        }
+                    }
+                    cur4 = nxt4;
+                }
+            }
+        } else {
+            // any offset / boxes wider than a wave: rows dealt to waves, columns to lanes, plain Ng x Ng matrices (glcm.cpp:431-478)
+            for (int row = wave; row < (int)h; row += kWaves)
+                for (int col = lane; col < (int)w; col += 64) {
+                    const uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
+                    if (lb == 0)
+                        continue;
+#pragma unroll
+                    for (int q = 0; q < kMaxAngles; q++) {
+                        if (q >= na)
+                            break;
+                        const int ang = A.glcm_angles[q];                 // glcm.cpp:234-255
+                        const int dx = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset, dy = ang == 0 ? 0 : A.glcm_offset;
+                        const int r2 = row + dy, c2 = col + dx;
+                        if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
+                            continue;
+                        const uint32_t la = s_dense[(uint32_t)r2 * w + (uint32_t)c2];
+                        if (la == 0)
+                            continue;
+                        atomicAdd(&s_P[q * NN + ((int)lb - 1) * Ng + (int)la - 1], 1u);
+                        if (symmetric)
+                            atomicAdd(&s_P[q * NN + ((int)la - 1) * Ng + (int)lb - 1], 1u);
+                    }
+                }
+        }
+        blk_sync<GS>();
+        STAMP(11);
+        {
+            uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
+            if (dpp) {
+                // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
+                // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the error of the reciprocal.
+                const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);
+                for (int i = tid; i < na * NN; i += kBlock) {
+                    const int q = (int)(((float)i + 0.5f) * inv_nn), rem = i - q * NN;
+                    const int r = (int)(((float)rem + 0.5f) * inv_ng), c = rem - r * Ng;
+                    dst[i] = s_P[q * cells + (r + 1) * NG1 + c + 1];
+                }
+            } else
+                for (int i = tid; i < na * NN; i += kBlock)
+                    dst[i] = s_P[i];
+        }
+        STAMP(12);
+    } else
     if (do_glcm) {
         double* o = out_row + A.col_glcm;
         const int na = A.glcm_na;
@@ -1592,7 +1748,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         double* s_I = s_g;                       // [ng_cap] level values
         double* s_f = s_g + A.L.ng_cap;          // [kMaxAngles][32] per-angle features
         double* s_scr = s_f + kMaxAngles * 32;   // [kMaxAngles][6*ng_cap]
-        if (greyInfo > 0) {
+        if (FAST) {
+            // matlab binning: the matrix order is the grey depth itself -- nothing to agree on, no barrier
+        } else if (greyInfo > 0) {
             if (tid == 0)
                 s_stat[S_NG] = (double)greyInfo;
         } else {
@@ -1622,9 +1780,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 s_stat[S_NG] = (double)Ng;
             }
         }
-        blk_sync<GS>();
-        const int Ng = (int)s_stat[S_NG];
-        const bool too_big = (uint32_t)Ng > A.L.ng_cap;
+        if (!FAST) blk_sync<GS>();
+        const int Ng = FAST ? greyInfo : (int)s_stat[S_NG];
+        const bool too_big = !FAST && (uint32_t)Ng > A.L.ng_cap;      // (FAST: make_layout reserved exactly this order)
         if (too_big && tid == 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
         if (!SPLIT && greyInfo >= 0 && !too_big)
@@ -1739,7 +1897,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         } else {
             const int NN = Ng * Ng;
             const bool symmetric = A.glcm_symmetric || greyInfo <= 0; // glcm.cpp:475
-            const int app = (int)A.L.app;
+            const int app = FAST ? kMaxAngles : (int)A.L.app;         // (FAST launches hold every angle in one pass: build_args)
             for (int a0 = 0; a0 < na; a0 += app) {
                 const int na_pass = (na - a0) < app ? (na - a0) : app;
                 // Split launches on the lane-per-column path count into matrices of order Ng + 1 indexed by the level itself:
@@ -1923,7 +2081,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     if (trash) {
                         // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
                         // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the rounding of the product.
-                        const float inv_nn = 1.0f / (float)NN, inv_ng = 1.0f / (float)Ng;
+                        const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);   // (1 ulp: far inside the margin)
                         for (int i = tid; i < na_pass * NN; i += kBlock) {
                             const int q = (int)(((float)i + 0.5f) * inv_nn), rem = i - q * NN;
                             const int r = (int)(((float)rem + 0.5f) * inv_ng), c = rem - r * Ng;

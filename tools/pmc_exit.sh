@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 for lib in $PWD/gpurun_scratch/libexit_*.so; do
   OUT=$PWD/gpurun_out/pmc_exit/$(basename $lib .so)
   mkdir -p $OUT
-  NYXHIP_LIB=$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --tile-path-tiles 0 > $OUT/log.txt 2>&1
+  NYXHIP_LIB=$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extras --tile-path-tiles 0 > $OUT/log.txt 2>&1
   python3 - <<PY
 import csv,glob
 from collections import defaultdict
