@@ -277,6 +277,21 @@ __device__ __forceinline__ void for_each_cloud_pixel(const uint32_t* inten, cons
     }
 }
 
+// 24-bit multiplies (both factors below 2^24; the low 32 bits of the product): full rate, where v_mul_lo_u32 -- what the
+// compiler emits for a plain 32-bit product, and for __umul24 as well -- issues at a quarter of it
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ---- (row, column) of a linear index that advances by a fixed stride -----------------------------------------------
 // p = first, first + stride, ... over a plane of width w: one integer division per thread and loop instead of one per pixel
 // (a u32 division is ~25 instructions, two of them quarter-rate multiplies).
@@ -286,6 +301,15 @@ struct RowCol {
     {
         row = first / width; col = first - row * width;
         step_r = stride / width; step_c = stride - step_r * width;
+    }
+    // the same for small operands (first, stride < 2^16, width <= 64): the two quotients through a float reciprocal --
+    // (x + 1/2) / d is never closer than 1 / (2 d) to an integer, far beyond the rounding of the product
+    struct small_t {};
+    __device__ __forceinline__ RowCol(uint32_t first, uint32_t stride, uint32_t width, small_t) : w(width)
+    {
+        const float inv = __builtin_amdgcn_rcpf((float)width);
+        row = (uint32_t)(((float)first + 0.5f) * inv); col = first - mul24(row, width);
+        step_r = (uint32_t)(((float)stride + 0.5f) * inv); step_c = stride - mul24(step_r, width);
     }
     __device__ __forceinline__ void advance()
     {

@@ -380,30 +380,37 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     const int slot_raw = lane >> 4, l = lane & 15;
     const bool live = slot_raw < n_slots;
     const int slot = live ? slot_raw : 0;              // idle rows shadow slot 0 and never store
-    const uint32_t* P = Pslots + slot * NN;
-    double* pcol_s = scr_base + slot * scr_stride;     // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
+    const uint32_t* P = Pslots + mul24((uint32_t)slot, (uint32_t)NN);
+    double* pcol_s = scr_base + mul24((uint32_t)slot, (uint32_t)scr_stride);     // px[i] = sum_j xy(i,j)/sum_p   (glcm.cpp:523-525, :859-864)
     double* prow_s = pcol_s + Ng;                      // py[j] = sum_i xy(i,j)/sum_p
     double* Pxpy = pcol_s + 2 * Ng;                    // [2Ng]  glcm.cpp:503-508
     double* f = fslots + slot * 32;
     double* sm = sums + slot * 32;
 
     // ---- marginal counts: lane i < Ng owns column i, row i and the diagonal pair |x - y| = i ------------------------------
+    // (indices advance by additions, products are 24-bit -- full-rate instructions -- and the loops stay rolled: their control is
+    //  scalar or a mask update, while the unroller's prologue / remainder code is vector work)
     uint32_t cc = 0, rc = 0, dc = 0;
     if (l < Ng) {
-        for (int j = 0; j < Ng; j++) {
-            cc += P[j * Ng + l];
-            rc += P[l * Ng + j];
+        const uint32_t lN = mul24((uint32_t)l, (uint32_t)Ng);
+        uint32_t ic = (uint32_t)l;
+#pragma unroll 1
+        for (int j = 0; j < Ng; j++, ic += (uint32_t)Ng) {
+            cc += P[ic];                               // P[j * Ng + l]
+            rc += P[lN + (uint32_t)j];                 // P[l * Ng + j]
         }
-        for (int x = l; x < Ng; x++) {
-            dc += P[x * Ng + (x - l)];
+        uint32_t i1 = lN, i2 = (uint32_t)l;            // P[x * Ng + (x - l)], P[(x - l) * Ng + x] for x = l ..: both step by Ng + 1
+#pragma unroll 1
+        for (int x = l; x < Ng; x++, i1 += (uint32_t)Ng + 1u, i2 += (uint32_t)Ng + 1u) {
+            dc += P[i1];
             if (l > 0)
-                dc += P[(x - l) * Ng + x];
+                dc += P[i2];
         }
     }
     const uint32_t l1 = (uint32_t)l + 1u;
     const uint32_t csum = row16_sum(rc);               // sum_p (glcm.cpp:481-484)
-    const uint32_t Sr_i = row16_sum(rc * l1), Sc_i = row16_sum(cc * l1);          // f_corr mr :601, mc :608 (exact numerators)
-    const uint32_t con_i = row16_sum(dc * (uint32_t)(l * l)), dis_i = row16_sum(dc * (uint32_t)l);   // f_contrast :579, f_GLCM_DIS :1052
+    const uint32_t Sr_i = row16_sum(mul24(rc, l1)), Sc_i = row16_sum(mul24(cc, l1));          // f_corr mr :601, mc :608 (exact numerators)
+    const uint32_t con_i = row16_sum(mul24(dc, (uint32_t)(l * l))), dis_i = row16_sum(mul24(dc, (uint32_t)l));   // f_contrast :579, f_GLCM_DIS :1052
     const bool empty = csum == 0;                      // glcm.cpp:260-295 -> soft NaN for this angle
     const double sum_p = empty ? 1.0 : (double)csum;
     const double inv_sum_p = fdiv(1.0, sum_p);
@@ -413,8 +420,10 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     for (int k = l; k < 2 * Ng - 1; k += 16) {
         uint32_t c = 0;
         const int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
-        for (int x = x0; x <= x1; x++)
-            c += P[x * Ng + (k - x)];
+        uint32_t ix = mad24((uint32_t)x0, (uint32_t)Ng, (uint32_t)(k - x0));     // P[x * Ng + (k - x)]: steps by Ng - 1
+#pragma unroll 1
+        for (int x = x0; x <= x1; x++, ix += (uint32_t)Ng - 1u)
+            c += P[ix];
         if (live) Pxpy[k] = fdiv((double)c, sum_p);
     }
     wav_sync<false>();
@@ -426,13 +435,13 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     double ent = 0, hxy1 = 0, hxy2 = 0, asm_d = 0;
     uint32_t acor_i = 0, asm_i = 0, cmax = 0;
     const bool big = csum >= 65536u;                                   // (symmetric matrices of ROIs beyond 32767 pixels)
-    RowCol rcw((uint32_t)l, 16u, (uint32_t)Ng);
+    RowCol rcw((uint32_t)l, 16u, (uint32_t)Ng, RowCol::small_t{});
     for (int e = l; e < NN; e += 16, rcw.advance()) {
         const uint32_t r = rcw.row, c = rcw.col, cnt = P[e];
         const double p = (double)cnt * inv_sum_p;
         if (big) asm_d = __builtin_fma(p, p, asm_d);                 // f_asm :555 / f_energy :927-928
-        else asm_i += cnt * cnt;                                     //   (sum cnt^2 <= (sum cnt)^2 < 2^32 while sum_p < 65536)
-        acor_i += cnt * ((r + 1u) * (c + 1u));                       // f_GLCM_ACOR :961 (integer-exact)
+        else asm_i = mad24(cnt, cnt, asm_i);                         //   (sum cnt^2 <= (sum cnt)^2 < 2^32 while sum_p < 65536)
+        acor_i = mad24(cnt, mul24(r + 1u, c + 1u), acor_i);          // f_GLCM_ACOR :961 (integer-exact; a count is far below 2^24)
         cmax = cnt > cmax ? cnt : cmax;                              // f_GLCM_JMAX :1178-1179
         ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);       // f_entropy :734-735, JE :1160-1161, HXY :868
         const double pp = pcol_s[c] * prow_s[r];                     // px[i]*py[j], i = column, j = row (:869, :909)
@@ -1410,7 +1419,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         uint32_t lo = 0, span = range + 1;                  // the answer lies in [lo, lo + span)
                         while (span > 1) {
                             const uint32_t B = (span + 63) >> 6;
-                            uint32_t i = lo + ((uint32_t)lane + 1) * B - 1;   // last position of this lane's block
+                            uint32_t i = lo + mul24((uint32_t)lane + 1, B) - 1;   // last position of this lane's block
                             if (i > range) i = range;
                             const unsigned long long hit = __ballot(cum(i) > k);
                             const uint32_t first = hit ? (uint32_t)__builtin_ctzll(hit) : 63u;
@@ -1724,9 +1733,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the error of the reciprocal.
                 const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);
                 for (int i = tid; i < na * NN; i += kBlock) {
-                    const int q = (int)(((float)i + 0.5f) * inv_nn), rem = i - q * NN;
-                    const int r = (int)(((float)rem + 0.5f) * inv_ng), c = rem - r * Ng;
-                    dst[i] = s_P[q * cells + (r + 1) * NG1 + c + 1];
+                    const uint32_t q = (uint32_t)(((float)i + 0.5f) * inv_nn), rem = (uint32_t)i - mul24(q, (uint32_t)NN);
+                    const uint32_t r = (uint32_t)(((float)rem + 0.5f) * inv_ng), c = rem - mul24(r, (uint32_t)Ng);
+                    dst[i] = s_P[mad24(q, (uint32_t)cells, mad24(r + 1u, (uint32_t)NG1, c + 1u))];
                 }
             } else
                 for (int i = tid; i < na * NN; i += kBlock)
@@ -2083,9 +2092,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the rounding of the product.
                         const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);   // (1 ulp: far inside the margin)
                         for (int i = tid; i < na_pass * NN; i += kBlock) {
-                            const int q = (int)(((float)i + 0.5f) * inv_nn), rem = i - q * NN;
-                            const int r = (int)(((float)rem + 0.5f) * inv_ng), c = rem - r * Ng;
-                            dst[i] = s_P[q * cells + (r + 1) * NG1 + c + 1];
+                            const uint32_t q = (uint32_t)(((float)i + 0.5f) * inv_nn), rem = (uint32_t)i - mul24(q, (uint32_t)NN);
+                            const uint32_t r = (uint32_t)(((float)rem + 0.5f) * inv_ng), c = rem - mul24(r, (uint32_t)Ng);
+                            dst[i] = s_P[mad24(q, (uint32_t)cells, mad24(r + 1u, (uint32_t)NG1, c + 1u))];
                         }
                     } else
                     for (int i = tid; i < na_pass * NN; i += kBlock)
@@ -2184,7 +2193,15 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
     double* s_scr = (double*)(base + (((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15)) + ngc;
     double* s_f = s_scr + kMaxAngles * 6 * ngc;
     const uint32_t* src = A.glcm_ws + roi * A.glcm_ws_stride;
-    for (int i = lane; i < na * NN; i += 64) s_P[i] = src[i];
+    // the ROI's counts: 16 bytes per lane and trip (na * Ng^2 = 256 words for four 8 x 8 matrices: one load per lane)
+    const int nw = na * NN;
+    if (((nw | (int)A.glcm_ws_stride) & 3) == 0) {
+#pragma unroll 1
+        for (int i = lane; i < (nw >> 2); i += 64) ((uint4*)s_P)[i] = ((const uint4*)src)[i];
+    } else {
+#pragma unroll 1
+        for (int i = lane; i < nw; i += 64) s_P[i] = src[i];
+    }
     wav_sync<false>();
     glcm_features_wave16(s_P, na, Ng, s_scr, 6 * ngc, A.soft_nan, s_f, s_f + kMaxAngles * 32, lane);   // level values I[i] = i + 1 (glcm.cpp:400-408)
     wav_sync<false>();
@@ -2205,7 +2222,8 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
         }
         for (; a < na; a++)
             init = init + s_f[a * 32 + k];
-        o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+        // (dividing by 4, 2 or 1 is a multiplication by the exact reciprocal: the same rounding, a tenth of the instructions)
+        o[kGlcmAngled * na + j] = na == 4 ? init * 0.25 : na == 2 ? init * 0.5 : na ? init / (double)na : 0.0;
     }
 }
 
