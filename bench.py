@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--families", type=int, default=3, help="family bitmask (diagnostic; the metric is 3 = INTENSITY|GLCM)")
-    ap.add_argument("--tile-path-tiles", type=int, default=128, help="tiles for the informational fused tile-path measurement (0 = skip)")
+    ap.add_argument("--tile-path-tiles", type=int, default=1000, help="tiles for the informational fused tile-path measurement (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (grey depth 64, configs 4 and 5)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST HOOK (tests/test_bench_launcher.py): no GPU, gloo; every rank fills a rank-coded table on the CPU so that "
@@ -416,7 +416,8 @@ def main():
                                 "rois": int(nroi.value), "ms_per_call": 1e3 * dt,
                                 "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
-                                        "compaction, cloud assembly, then the same reduce kernels (one host sync inside for the ROI count)"}
+                                        "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
+                                        "(no materialised clouds; one host sync inside for the ROI count)"}
             # CPU baseline of THIS leg: the reference's in-memory workflow end to end (its two serial label scans with a hash-map
             # lookup per pixel + ROI buffers + the multithreaded reduce) on a bounded sample of the same tiles
             if not a.no_cpu_baseline:

@@ -931,6 +931,100 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         // the window; a label-only pre-pass counts each quarter's members so that a pixel's index in s_val is its rank in
         // window order: exactly the index it has in the cloud, so all that follows is bit-identical to the batch path.
         const uint32_t L = A.win.label[roi], x0 = A.win.x0[roi];
+        const uint64_t tile_px = (uint64_t)A.win.H * A.win.W;
+        const bool nz_w = vmin > 0;
+        // what one member pixel contributes (the body of `trip` above, with its cloud index i and its plane cell)
+        auto member = [&](uint32_t v, uint32_t i, uint32_t cell) {
+            if (do_int) {
+                if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
+                else s_val[i] = v;
+                sum += v;
+                sumsq += small_v ? mul24(v, v) : (uint32_t)(v * v);
+                if (use_count) {
+                    const uint32_t ci = v - vmin;
+                    if (C16) atomicAdd(cnt16_word(s_cnt, ci), 1u << (16 * (ci & 1u)));
+                    else atomicAdd(&s_cnt[ci], 1u);
+                }
+            }
+            if (do_glcm) {
+                uint32_t lvl = 0;
+                if (nz_w || v != 0) {
+                    if (FAST || G16) {
+                        const uint32_t sc = (uint32_t)(mslope * (double)v + 1.0);
+                        lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
+                    } else
+                    lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+                    if (greyInfo < 0) s_lvlmap[lvl] = 1;
+                    if (greyInfo <= 0) lvl_max = lvl > lvl_max ? lvl : lvl_max;
+                }
+                if (D8) *(lds_u8_t*)cell = (uint8_t)lvl;
+                else s_dense[cell] = (dense_t)(lvl > 0xFFFFu ? 0xFFFFu : lvl);
+            }
+        };
+        if (w <= 64 && tile_px * 4ull < (1ull << 31)) {
+            // ---- boxes up to a wave wide: a row of the window per step, lane = column, every wave a contiguous block of rows
+            // (window order = row-major order is kept: waves in order, rows in order, lanes in order).  The tile is read through
+            // raw buffer descriptors (32-bit lane offsets, the row advance in the scalar offset: no 64-bit address arithmetic),
+            // eight rows per trip (sixteen in the label-only pre-pass) with every load of the trip issued before the first use,
+            // where a row-at-a-time loop left the kernel waiting on ~30 dependent round trips per ROI (3.7 ms per 196 k ROIs
+            // against 2.0 ms from pre-assembled clouds).
+            constexpr int UP = 16, UW = 8;                                               // rows per trip: label-only pre-pass / main pass
+            const int dtl = A.win.dt_label, dti = A.win.dt_inten;
+            const uint32_t Wt = A.win.W;
+            const uint64_t tile0 = (uint64_t)A.win.tile[roi] * tile_px;
+            const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.win.lab + tile0 * (uint64_t)dtl), 0, (int)(tile_px * (uint64_t)dtl), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.win.inten + tile0 * (uint64_t)dti), 0, (int)(tile_px * (uint64_t)dti), 0x00020000);
+            auto ldb = [](const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff, int dt) -> uint32_t {   // element `voff + soff` (bytes) of a tile
+                return dt == 4 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0)
+                     : dt == 2 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0)
+                               : (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff, (int)soff, 0);
+            };
+            const uint32_t rows_pw = (h + kWaves - 1) / kWaves;
+            const uint32_t r_begin = (uint32_t)wave * rows_pw, r_end = r_begin + rows_pw < h ? r_begin + rows_pw : h;
+            const uint32_t e0 = (A.win.y0[roi] + r_begin) * Wt + x0;                      // element offset of this wave's first row (scalar)
+            const uint32_t vl = (uint32_t)lane * (uint32_t)dtl, vi = (uint32_t)lane * (uint32_t)dti;
+            uint32_t hits = 0;
+            if (lane < (int)w) {                                                         // (ballots below see the box's columns only)
+                for (uint32_t r = r_begin; r < r_end; r += UP) {
+                    uint32_t lb[UP];
+#pragma unroll
+                    for (int u = 0; u < UP; u++)
+                        if (r + u < r_end) lb[u] = ldb(rs_l, vl, (e0 + (r + u - r_begin) * Wt) * (uint32_t)dtl, dtl);
+#pragma unroll
+                    for (int u = 0; u < UP; u++)
+                        if (r + u < r_end) hits += (uint32_t)__popcll(__ballot(lb[u] == L));
+                }
+            }
+            hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hits);
+            uint32_t* const s_hits = (uint32_t*)(s_stat + 12);                          // (s_stat is free until the sums)
+            if (lane == 0) s_hits[wave] = hits;
+            blk_sync<GS>();
+            uint32_t rank0 = 0;
+            for (int wv = 0; wv < wave; wv++) rank0 += s_hits[wv];
+            rank0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank0);
+            if (lane < (int)w) {
+                for (uint32_t r = r_begin; r < r_end; r += UW) {
+                    uint32_t lb[UW], vv[UW];
+#pragma unroll
+                    for (int u = 0; u < UW; u++)
+                        if (r + u < r_end) {
+                            const uint32_t eo = e0 + (r + u - r_begin) * Wt;
+                            lb[u] = ldb(rs_l, vl, eo * (uint32_t)dtl, dtl);
+                            vv[u] = ldb(rs_i, vi, eo * (uint32_t)dti, dti);
+                        }
+#pragma unroll
+                    for (int u = 0; u < UW; u++)
+                        if (r + u < r_end) {
+                            const bool hit = lb[u] == L;
+                            const unsigned long long bal = __ballot(hit);
+                            const uint32_t i = rank0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                            rank0 += (uint32_t)__popcll(bal);
+                            if (hit && i < n)
+                                member(vv[u], i, (r + u) * w + (uint32_t)lane);
+                        }
+                }
+            }
+        } else {
         const uint64_t row0 = (uint64_t)A.win.tile[roi] * A.win.H + A.win.y0[roi];
         const uint64_t org = row0 * A.win.W + x0;
         const int dtl = A.win.dt_label, dti = A.win.dt_inten;
@@ -1002,6 +1096,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             }
             bx += step_x; by += step_y; o32 += step_o;
             if (bx >= w) { bx -= w; by++; o32 += wrap_o; }
+        }
         }
     } else {
         using T = std::true_type; using F = std::false_type;
