@@ -48,97 +48,141 @@ __device__ __forceinline__ double plog_tex(double p)
 // Always inlined: as a real call (shared by kernels built for different register budgets, reached with SGPRs spilled to VGPR
 // lanes) this function produced wrong GLRLM rows / faults in the global-workspace launches and a wrong GLSZM_ZP in the
 // 80-register build (tools/spill_probe.py, tests/test_parity_gpu.py::test_glrlm_alone_on_spilled_rois).
+// diagnostic builds (-DNYX_TEX_EXIT_AT=k, tools/tex_phases.sh): the kernel ends at phase k (results are wrong by design)
+#ifdef NYX_TEX_EXIT_AT
+#define TSTAMP(k) do { if ((k) == NYX_TEX_EXIT_AT) return; } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+
 template <bool GS>
 __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
                                     uint32_t Np, double* f, int lane)
 {
-    unsigned long long tot = 0;
-    for (int i = lane; i < Ng; i += 64) {
+    // The kernel is bound by vector-instruction issue, so this routine is organised around the instruction count:
+    //   * row sums by 16-lane groups (four levels at a time, a 4-step DPP sum each) instead of one lane walking a whole row;
+    //   * the fifteen wave totals through two transposed reductions (8 + 7 values: ~35 exchanges each) instead of fifteen
+    //     six-step butterflies, parked in the output slot `f` between the stages;
+    //   * every quotient by a per-lane or per-wave reciprocal (two Newton steps: 1-2 ulp; all of GLRLM is tolerance-class)
+    //     instead of an IEEE division per term, and 24-bit multiplies for the small integer products.
+    const int slot = lane >> 4, l = lane & 15;
+    uint32_t part = 0;
+    for (int i0 = 0; i0 < Ng; i0 += 4) {
+        const int i = i0 + slot;
         uint32_t sm = 0;
-        for (int j = 0; j < Nr; j++) sm += P[i * Nr + j];
-        ri[i] = sm;
-        tot += sm;
+        if (i < Ng) {
+            uint32_t idx = mul24((uint32_t)i, (uint32_t)Nr) + (uint32_t)l;
+            for (int j = l; j < Nr; j += 16, idx += 16) sm += P[idx];
+        }
+        part += sm;
+        sm = row16_sum(sm);
+        if (l == 0 && i < Ng) ri[i] = sm;
     }
     for (int j = lane; j < Nr; j += 64) {
-        uint32_t sm = 0;
-        for (int i = 0; i < Ng; i++) sm += P[i * Nr + j];
+        uint32_t sm = 0, idx = (uint32_t)j;
+        for (int i = 0; i < Ng; i++, idx += (uint32_t)Nr) sm += P[idx];
         rj[j] = sm;
     }
-    tot = wave_sum_u64(tot);
+    const uint32_t tot = wave_sum_t<uint32_t>(part);       // number of runs: at most the pixel count
     wav_sync<GS>();
     if (tot == 0) { // sum_p == 0 -> every feature 0.0 (glrlm.cpp:364-367 etc.)
         if (lane < 16) f[lane] = 0.0;
         wav_sync<GS>();
         return;
     }
-    const double sum_p = (double)tot;
+    const double sum_p = (double)tot, inv_p = frcp(sum_p);
     // level-only and length-only sums from the marginals
-    double gln = 0, mu_g = 0, lgl = 0, hgl = 0;
+    double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // gln, mu_g, lgl, hgl | sre, lre, rln, mu_r
     for (int i = lane; i < Ng; i += 64) {
-        double r = (double)ri[i];
-        uint32_t in2 = lv[i] * lv[i];                 // unsigned-int product as in the reference
-        gln += r * r;                                  // calc_GLN :431-461
-        mu_g += fdiv(r, sum_p) * (double)lv[i];        // calc_GLV mu :602-609
-        lgl += fdiv(r, (double)in2);                   // calc_LGLRE :712-741
-        hgl += r * (double)in2;                        // calc_HGLRE :744-773
-    }
-    double sre = 0, lre = 0, rln = 0, mu_r = 0;
-    for (int j = lane; j < Nr; j += 64) {
-        double c = (double)rj[j];
-        int jj = j + 1;
-        sre += fdiv(c, (double)(jj * jj));             // calc_SRE :378-385
-        lre += c * (double)jj * (double)jj;            // calc_LRE :411-418 (integer-exact)
-        rln += c * c;                                  // calc_RLN :499-529
-        mu_r += fdiv(c, sum_p) * (double)jj;           // calc_RV mu :649-655
-    }
-    gln = wave_sum(gln); mu_g = wave_sum(mu_g); lgl = wave_sum(lgl); hgl = wave_sum(hgl);
-    sre = wave_sum(sre); lre = wave_sum(lre); rln = wave_sum(rln); mu_r = wave_sum(mu_r);
-    double glv = 0, rv = 0;
-    for (int i = lane; i < Ng; i += 64) {
-        double d = (double)lv[i] - mu_g;
-        glv += fdiv((double)ri[i], sum_p) * (d * d);   // calc_GLV :611-620
+        const double r = (double)ri[i];
+        const uint32_t in2 = lv[i] * lv[i];                // unsigned-int product as in the reference (levels can be intensities: 32-bit wrap)
+        t8[0] += r * r;                                    // calc_GLN :431-461
+        t8[1] += (r * inv_p) * (double)lv[i];              // calc_GLV mu :602-609
+        t8[2] += r * frcp((double)in2);                    // calc_LGLRE :712-741
+        t8[3] += r * (double)in2;                          // calc_HGLRE :744-773
     }
     for (int j = lane; j < Nr; j += 64) {
-        double d = (double)(j + 1) - mu_r;
-        rv += fdiv((double)rj[j], sum_p) * (d * d);    // calc_RV :657-665
+        const double c = (double)rj[j], jd = (double)(j + 1), j2 = jd * jd;
+        t8[4] += c * frcp(j2);                             // calc_SRE :378-385
+        t8[5] += c * j2;                                   // calc_LRE :411-418 (integer-exact)
+        t8[6] += c * c;                                    // calc_RLN :499-529
+        t8[7] += (c * inv_p) * jd;                         // calc_RV mu :649-655
     }
-    glv = wave_sum(glv); rv = wave_sum(rv);
-    // cell-level sums
-    double re = 0, srl = 0, srh = 0, lrl = 0, lrh = 0;
-    const int NN = Ng * Nr;
-    RowCol rc((uint32_t)lane, 64u, (uint32_t)Nr);       // (level row, run length - 1) of the cell without a division per cell
-    for (int e = lane; e < NN; e += 64, rc.advance()) {
-        uint32_t c = P[e];
-        if (c == 0)
-            continue;                                  // zero cells add +-0 in the reference
-        const int i = (int)rc.row, jj = (int)rc.col + 1;
-        double cnt = (double)c;
-        uint32_t in2 = lv[i] * lv[i];
-        uint32_t j2 = (uint32_t)jj * (uint32_t)jj;
-        re += plog_tex(fdiv(cnt, sum_p));              // calc_RE :693-699
-        srl += cnt / (double)(uint32_t)(in2 * j2);     // calc_SRLGLE :790-797
-        srh += fdiv(cnt * (double)in2, (double)(jj * jj));  // calc_SRHGLE :822-829
-        lrl += fdiv(cnt * (double)(jj * jj), (double)in2);  // calc_LRLGLE :855-862
-        lrh += cnt * (double)(uint32_t)(in2 * j2);     // calc_LRHGLE :887-894
+    {
+        const double tt = wave_transpose_sum8(t8, lane);   // lane 8 k holds total k
+        if ((lane & 7) == 0) f[lane >> 3] = tt;
     }
-    re = wave_sum(re); srl = wave_sum(srl); srh = wave_sum(srh); lrl = wave_sum(lrl); lrh = wave_sum(lrh);
+    wav_sync<GS>();
+    const double mu_g = f[1], mu_r = f[7];
+    double s8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s8[k] = lane == 0 ? f[k] : 0.0;   // lane 0 keeps stage 1 (the slot is reused below)
+    wav_sync<GS>();
+    double u8[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // glv, rv, re, srl, srh, lrl, lrh
+    for (int i = lane; i < Ng; i += 64) {
+        const double d = (double)lv[i] - mu_g;
+        u8[0] += ((double)ri[i] * inv_p) * (d * d);        // calc_GLV :611-620
+    }
+    for (int j = lane; j < Nr; j += 64) {
+        const double d = (double)(j + 1) - mu_r;
+        u8[1] += ((double)rj[j] * inv_p) * (d * d);        // calc_RV :657-665
+    }
+    // cell-level sums: lane = run length (a per-lane 1 / j^2), rows in sequence (a per-wave 1 / i^2).  The reference multiplies the
+    // two squares as 32-bit unsigned integers; while (largest level)^2 * Nr^2 stays below 2^32 that product is exact and the
+    // quotients factor into the two reciprocals -- otherwise the wrapped product is formed and divided cell by cell.
+    const uint32_t lv_max = lv[Ng - 1];                    // (levels are sorted)
+    const bool exact = (unsigned long long)lv_max * lv_max * (unsigned long long)Nr * (unsigned long long)Nr < (1ull << 32);
+    for (int j0 = 0; j0 < Nr; j0 += 64) {
+        const int j = j0 + lane;
+        const bool live = j < Nr;
+        const double jd = (double)(j + 1), j2d = jd * jd, rj2 = frcp(j2d);
+        const uint32_t j2 = mul24((uint32_t)(j + 1), (uint32_t)(j + 1));
+        uint32_t idx = (uint32_t)j;
+        for (int i = 0; i < Ng; i++, idx += (uint32_t)Nr) {
+            const uint32_t c = live ? P[idx] : 0u;
+            if (c == 0)
+                continue;                                  // zero cells add +-0 in the reference
+            const double cnt = (double)c;
+            const uint32_t in2 = lv[i] * lv[i];
+            u8[2] += plog_tex(cnt * inv_p);                // calc_RE :693-699
+            if (exact) {
+                const double in2d = (double)in2, ri2 = frcp(in2d), a = cnt * rj2, b = cnt * j2d;
+                u8[3] = __builtin_fma(a, ri2, u8[3]);      // calc_SRLGLE :790-797
+                u8[4] = __builtin_fma(a, in2d, u8[4]);     // calc_SRHGLE :822-829
+                u8[5] = __builtin_fma(b, ri2, u8[5]);      // calc_LRLGLE :855-862
+                u8[6] = __builtin_fma(b, in2d, u8[6]);     // calc_LRHGLE :887-894
+            } else {
+                u8[3] += cnt / (double)(uint32_t)(in2 * j2);
+                u8[4] += fdiv(cnt * (double)in2, j2d);
+                u8[5] += fdiv(cnt * j2d, (double)in2);
+                u8[6] += cnt * (double)(uint32_t)(in2 * j2);
+            }
+        }
+    }
+    {
+        const double tt = wave_transpose_sum8(u8, lane);
+        if ((lane & 7) == 0) f[8 + (lane >> 3)] = tt;
+    }
+    wav_sync<GS>();
     if (lane == 0) {
-        f[R_SRE] = sre / sum_p;
-        f[R_LRE] = lre / sum_p;
-        f[R_GLN] = gln / sum_p;
-        f[R_GLNN] = gln / (sum_p * sum_p);
-        f[R_RLN] = rln / sum_p;
-        f[R_RLNN] = rln / (sum_p * sum_p);
-        f[R_RP] = sum_p / (double)(int)Np;             // calc_RP :569-585
+        const double glv = f[8], rv = f[9], re = f[10], srl = f[11], srh = f[12], lrl = f[13], lrh = f[14];
+        const double inv_p2 = inv_p * inv_p;
+        f[R_SRE] = s8[4] * inv_p;
+        f[R_LRE] = s8[5] * inv_p;
+        f[R_GLN] = s8[0] * inv_p;
+        f[R_GLNN] = s8[0] * inv_p2;
+        f[R_RLN] = s8[6] * inv_p;
+        f[R_RLNN] = s8[6] * inv_p2;
+        f[R_RP] = fdiv(sum_p, (double)(int)Np);             // calc_RP :569-585
         f[R_GLV] = glv;
         f[R_RV] = rv;
         f[R_RE] = -re;
-        f[R_LGLRE] = lgl / sum_p;
-        f[R_HGLRE] = hgl / sum_p;
-        f[R_SRLGLE] = srl / sum_p;
-        f[R_SRHGLE] = srh / sum_p;
-        f[R_LRLGLE] = lrl / sum_p;
-        f[R_LRHGLE] = lrh / sum_p;
+        f[R_LGLRE] = s8[2] * inv_p;
+        f[R_HGLRE] = s8[3] * inv_p;
+        f[R_SRLGLE] = srl * inv_p;
+        f[R_SRHGLE] = srh * inv_p;
+        f[R_LRLGLE] = lrl * inv_p;
+        f[R_LRHGLE] = lrh * inv_p;
     }
     wav_sync<GS>();
 }
@@ -199,6 +243,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             d32[i] = bg;
         for (uint32_t i = tid; i <= Lcap + 1; i += kBlock)
             s_lvlmap[i] = 0;
+        if (tid >= 1 && tid <= 8)                       // 840 / nd for nd = 1..8 (NGTDM stencil): 840 420 280 210 168 140 120 105
+            ((uint32_t*)(s_stat + 8))[tid] = (uint32_t)(840.0f / (float)tid + 0.5f);
     }
     blk_sync<GS>();
 
@@ -215,6 +261,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     lvl_over = wave_max_u32(lvl_over);
     if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
     blk_sync<GS>();
+    TSTAMP(0);
     // The two pixel counts are needed once each, much later: they wait in s_stat instead of occupying registers through
     // the whole kernel.
     bool over = false;
@@ -261,6 +308,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         s_stat[1] = (double)k;                               // Ngp = unique non-zero levels (ngtdm.cpp:150)
     }
     blk_sync<GS>();
+    TSTAMP(1);
     const int Ng = (int)s_stat[0];
     const int Nuniq = (int)s_stat[1];
     const bool blank = vmin == vmax;
@@ -331,6 +379,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         if (rv != 0) count_run(rv, rl);
                     }
                     wav_sync<GS>();
+                    TSTAMP(2);
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, lane);
                 }
             } else {
@@ -374,6 +423,46 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         blk_sync<GS>();
     }
 
+    TSTAMP(3);
+    // ---- NGTDM stencil for boxes up to a wave wide (used from two places: see the GLSZM sweep) ------------------------------
+    // IBSI: I = 0..max, row = level (ngtdm.cpp:56-61, :163-166); else rows = unique levels
+    const int NgT = greyInfo == 0 ? (Nuniq ? Ng + 1 : 0) : Nuniq;
+    const bool ngt_own = !GS && A.L.ngt_own != 0;
+    unsigned long long* const s_S = (unsigned long long*)(ngt_own ? lds + A.L.ngt_own : s_work);   // [NgT] sum |i - mean| in units of 1/840
+    uint32_t* const s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);                                           // [NgT]
+    // One lane per column, rows r_begin .. r_end - 1; the rows above / below travel in registers and the horizontal neighbours
+    // come through DPP lane shifts (level 0 = outside the box or not a pixel: skipped, like the bounds tests and the q != 0 test
+    // of the reference's stencil).  A level travels with a "present" flag in bit 24 (levels are 16-bit), so ONE sum over the eight
+    // neighbours yields both their level sum (bits 0..23) and their number (bits 24..27); |840 i - sum * (840 / nd)| is 32-bit
+    // arithmetic (24-bit multiplies, one v_sad_u32), 840 / nd comes from a nine-entry LDS table, and while a level's sum cannot
+    // reach 2^32 the accumulation is a 32-bit LDS atomic on the low word.  ~27 vector instructions per row (70 before).
+    auto ngtdm_rows = [&](int r_begin, int r_end) {
+        const bool in_col = (uint32_t)lane < w;
+        const uint32_t* const s_q = (const uint32_t*)(s_stat + 8);
+        const bool sum32 = (unsigned long long)area * 840ull * (unsigned long long)(greyInfo == 0 ? Ng + 1 : (int)s_lv[Ng > 0 ? Ng - 1 : 0]) < (1ull << 32);
+        auto load_row = [=](int r) -> uint32_t {
+            const uint32_t v = (in_col && r >= 0 && r < (int)h) ? (uint32_t)s_dense[(uint32_t)r * w + (uint32_t)lane] : 0u;
+            return v | (min(v, 1u) << 24);
+        };
+        uint32_t prv = load_row(r_begin - 1), cur = load_row(r_begin);
+        for (int row = r_begin; row < r_end; row++) {
+            const uint32_t nxt = load_row(row + 1);
+            const uint32_t pw = lane_minus1(prv, 0u), pe = lane_plus1(prv, 0u), cw = lane_minus1(cur, 0u), ce = lane_plus1(cur, 0u),
+                           nw = lane_minus1(nxt, 0u), ne = lane_plus1(nxt, 0u);
+            const uint32_t tot = ((pw + prv) + (pe + cw)) + ((ce + nw) + (nxt + ne));
+            if (cur != 0 && tot >= (1u << 24)) {
+                const uint32_t lvl = cur & 0xFFFFFFu, sum = tot & 0xFFFFFFu, nd = tot >> 24;
+                const uint32_t r = greyInfo == 0 ? lvl : (uint32_t)s_lvlmap[lvl] - 1u;
+                uint32_t d;                             // |840 i - sum * (840 / nd)|
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(mul24(lvl, 840u)), "v"(mul24(sum, s_q[nd])));
+                atomicAdd(&s_N[r], 1u);
+                if (sum32) atomicAdd((uint32_t*)&s_S[r], d);
+                else atomicAdd(&s_S[r], (unsigned long long)d);
+            }
+            prv = cur; cur = nxt;
+        }
+    };
+    bool ngt_stencil_done = false;
     // =====================================================================================
     // GLSZM
     // =====================================================================================
@@ -419,7 +508,20 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0; s_hval[i] = 0; }   // key 0 = empty (a size is >= 1)
             for (uint32_t i = tid; i < (uint32_t)Ng * S; i += kBlock) s_small[i] = 0;
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
+            // The row sweep below occupies ONE wave (a serial chain over the rows); with accumulators of its own the NGTDM stencil
+            // runs on the other three meanwhile instead of adding its time afterwards.
+            const bool ngt_here = ngt_own && do_ngt && NgT >= 2 && w <= 64;
+            if (ngt_here)
+                for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
             blk_sync<GS>();
+            if (ngt_here) {
+                ngt_stencil_done = true;
+                if (wave != solo) {
+                    const int k = (wave - solo - 1) & 3, per = ((int)h + 2) / 3;                 // k = 0, 1, 2
+                    const int rb = k * per, re = rb + per < (int)h ? rb + per : (int)h;
+                    ngtdm_rows(rb, re);
+                }
+            }
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
             // (the one-wave stretches of this kernel rotate over the four waves -- hence the four SIMDs -- by ROI: with six
             //  workgroups per CU a fixed wave 0 would pile all of them onto one SIMD)
@@ -506,6 +608,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 }
             }
             blk_sync<GS>();
+            TSTAMP(4);
             // zone sizes at the owners (the DPP sweep counted on the way)
             if (w > 64) {
                 for (uint32_t p = tid; p < area; p += kBlock)
@@ -547,6 +650,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             }
             nzone = (uint32_t)wave_sum_u64(nzone);
             blk_sync<GS>();
+            TSTAMP(5);
             if (lane == 0) s_red[wave * 8] = (double)nzone;
             // zones per size (sj): reuse s_count, keyed by size
             for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
@@ -560,6 +664,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     cnt_add(key & 0xFFFFFu, val);
             }
             blk_sync<GS>();
+            TSTAMP(6);
             if (sum_p == 0) {                                // glszm.cpp:229-233
                 for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
             } else {
@@ -590,6 +695,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
 #pragma unroll
                 for (int k = 0; k < 7; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
                 blk_sync<GS>();
+                TSTAMP(7);
                 const double mu_ZV = acc[5], mu_GLV = acc[6];
                 double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < n_cells; i += kBlock) {
@@ -646,51 +752,28 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         blk_sync<GS>();
     }
 
+    TSTAMP(8);
     // =====================================================================================
     // NGTDM
     // =====================================================================================
     if (do_ngt) {
         double* o = s_out + col;
         col += 5;
-        // IBSI: I = 0..max, row = level (ngtdm.cpp:56-61, :163-166); else rows = unique levels
-        const int NgT = greyInfo == 0 ? (Nuniq ? Ng + 1 : 0) : Nuniq;
-        unsigned long long* s_S = (unsigned long long*)s_work;   // [NgT] sum |i - mean| in units of 1/840
-        uint32_t* s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);        // [NgT]
-        double* s_P = (double*)(s_N + A.L.ng_cap + 2);            // [NgT]
+        double* s_P = (double*)((uint32_t*)((unsigned long long*)s_work + A.L.ng_cap + 2) + A.L.ng_cap + 2);   // [NgT] (behind the aliased S / N arrays)
         double* s_Sd = s_P + A.L.ng_cap + 2;                      // [NgT]
         if (NgT < 2) {                                            // ngtdm.cpp:70-78
             for (int c = tid; c < 5; c += kBlock) o[c] = A.soft_nan;
         } else {
-            for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
-            blk_sync<GS>();
-            if (w <= 64) {
-                // One lane per column, each wave a block of rows; the rows above / below travel in registers and the
-                // horizontal neighbours come through DPP lane shifts (level 0 = outside the box or not a pixel: skipped, like
-                // the bounds tests and the q != 0 test of the stencil below).  One LDS read per pixel instead of nine.
+            if (!ngt_stencil_done) {
+                for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
+                blk_sync<GS>();
+            }
+            if (ngt_stencil_done) {
+                // (the sums were taken during the GLSZM row sweep)
+            } else if (w <= 64) {
                 const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
                 const int r_begin = wave * rows_per_wave;
-                const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
-                const bool in_col = (uint32_t)lane < w;
-                auto load_row = [=](int r) -> uint32_t { return (in_col && r >= 0 && r < (int)h) ? (uint32_t)s_dense[(uint32_t)r * w + (uint32_t)lane] : 0u; };
-                uint32_t prv = load_row(r_begin - 1), cur = load_row(r_begin);
-                for (int row = r_begin; row < r_end; row++) {
-                    const uint32_t nxt = load_row(row + 1);
-                    const uint32_t pw = lane_minus1(prv, 0u), pe = lane_plus1(prv, 0u), cw = lane_minus1(cur, 0u), ce = lane_plus1(cur, 0u),
-                                   nw = lane_minus1(nxt, 0u), ne = lane_plus1(nxt, 0u);
-                    const uint32_t sum = ((pw + prv) + (pe + cw)) + ((ce + nw) + (nxt + ne));
-                    const uint32_t nd = (uint32_t)(pw != 0) + (uint32_t)(prv != 0) + (uint32_t)(pe != 0) + (uint32_t)(cw != 0) + (uint32_t)(ce != 0) +
-                                        (uint32_t)(nw != 0) + (uint32_t)(nxt != 0) + (uint32_t)(ne != 0);
-                    if (cur != 0 && nd > 0) {
-                        const int r = greyInfo == 0 ? (int)cur : (int)s_lvlmap[cur] - 1;
-                        // 840 / nd for nd = 1..8: 840 420 280 210 168 140 120 105 (ten bits each)
-                        const uint32_t q = nd <= 4 ? ((840u | (420u << 10) | (280u << 20)) >> (10u * (nd - 1u)) & 1023u) | (nd == 4 ? 210u : 0u)
-                                                   : (((168u | (140u << 10) | (120u << 20)) >> (10u * (nd - 5u))) & 1023u) | (nd == 8 ? 105u : 0u);
-                        const long long t = 840ll * (long long)cur - (long long)sum * (long long)q;
-                        atomicAdd(&s_N[r], 1u);
-                        atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
-                    }
-                    prv = cur; cur = nxt;
-                }
+                ngtdm_rows(r_begin, (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h);
             } else {
             RowCol rc((uint32_t)tid, kBlock, w);
             for (uint32_t p = tid; p < area; p += kBlock, rc.advance()) {
@@ -718,6 +801,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             }
             }
             blk_sync<GS>();
+            TSTAMP(9);
             // Nvc = Nvp = number of pixels with a neighbourhood (every mean is > 0), ngtdm.cpp:176-186
             uint32_t nvc_part = 0;
             for (int i = tid; i < NgT; i += kBlock) nvc_part += s_N[i];

@@ -1,0 +1,6 @@
+#!/bin/bash
+# cumulative time of the texture kernel's phases from early-exit builds in gpurun_scratch (libtex_<k>.so): tools/tex_phases.sh [families]
+FAM=${1:-28}
+for lib in $(ls $PWD/gpurun_scratch/libtex_*.so | sort -t_ -k2 -n); do
+  NYXHIP_LIB=$lib python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-extras --tile-path-tiles 0 --families $FAM 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $lib)', 'ms', round(d['ms_per_step'],3))"
+done
