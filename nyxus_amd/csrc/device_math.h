@@ -188,6 +188,19 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v)
     v += dpp_mov0<0x143, 0xC>(v);
     return v;
 }
+// inclusive prefix MINIMUM over the 64 lanes (lanes without a source in a step keep their own value)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_self(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ uint32_t wave_scan_min_u32(uint32_t v)
+{
+    v = min(v, dpp_self<0x111, 0xF>(v));
+    v = min(v, dpp_self<0x112, 0xF>(v));
+    v = min(v, dpp_self<0x114, 0xF>(v));
+    v = min(v, dpp_self<0x118, 0xF>(v));
+    v = min(v, dpp_self<0x142, 0xA>(v));
+    v = min(v, dpp_self<0x143, 0xC>(v));
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_t<double>(v); }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) { return wave_sum_t<unsigned long long>(v); }
 

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 {
                     uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
                     const bool in_col = (uint32_t)lane < w;
-                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&P[(uint32_t)(((int)s_lvlmap[rv] - 1) * Nr) + (rl - 1u)], 1u); };
+                    // cell (row of level rv, length rl) = P[(lvlmap - 1) * Nr + rl - 1]: the two "- 1" live in the base pointer and
+                    // the product is a 24-bit multiply-add (a plain 32-bit product issues at quarter rate)
+                    uint32_t* const Pm = P - (Nr + 1);
+                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
                     if (wave == 0) {
                         for (uint32_t row = 0; row < h; row++) {
                             const uint32_t v = in_col ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u;
@@ -530,7 +533,6 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 // through DPP lane shifts, the W chain is a segmented prefix-min in DPP steps -- no LDS on the critical path
                 uint32_t v_prev = 0, lab_prev = 0xFFFFFFFFu;
                 const bool in = (uint32_t)lane < w;
-                const uint32_t row_start = (uint32_t)lane & ~15u;
                 for (uint32_t row = 0; row < h; row++) {
                     const uint32_t p = row * w + (uint32_t)lane;
                     const uint32_t v = in ? (uint32_t)s_dense[p] : 0u;
@@ -546,28 +548,17 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     }
                     const uint32_t vl = lane_minus1(v, 0u);
                     const bool start = v == 0 || vl != v;       // run starts here (or not a zone pixel); lane 0: vl = 0 != v or v == 0
+                    // Segmented inclusive prefix-min along the W chain as a PLAIN prefix-min: a label (< 2^20) travels with
+                    // 63 - (index of its run) in bits 20..25, so whatever comes from an earlier run compares larger than anything
+                    // of the lane's own run -- six v_min_u32 DPP steps, no per-step segment tests.
                     const unsigned long long smask = __ballot(start);
-                    const uint32_t run0 = 63u - (uint32_t)__clzll((long long)(smask & ((2ull << lane) - 1ull)));
-                    // segmented inclusive prefix-min: inside the 16-lane DPP rows, then row to row
-#define NYX_SEG_STEP(D)                                                                                                         \
-                    {                                                                                                                   \
-                        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x110 + D, 0xF, 0xF, false); /* row_shr:D */ \
-                        if ((uint32_t)lane >= run0 + D && ((uint32_t)lane & 15u) >= D) lab = min(lab, o2);                            \
-                    }
-                    NYX_SEG_STEP(1u) NYX_SEG_STEP(2u) NYX_SEG_STEP(4u) NYX_SEG_STEP(8u)
-#undef NYX_SEG_STEP
-                    {
-                        uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x2, 0xF, false);             // row_bcast15 -> row 1
-                        if (run0 < row_start) lab = min(lab, o2);
-                        o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x4, 0xF, false);                      // -> row 2
-                        if (run0 < row_start) lab = min(lab, o2);
-                        o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)lab, (int)lab, 0x142, 0x8, 0xF, false);                      // -> row 3
-                        if (run0 < row_start) lab = min(lab, o2);
-                    }
-                    // zone sizes: one atomic per string of equal labels in the row
+                    const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u)) + (start ? 1u : 0u);
+                    lab = wave_scan_min_u32(((64u - ridx) << 20) | lab) & 0xFFFFFu;    // (ridx is 1..64; lanes beyond the box are runs of their own at the far end)
+                    // zone sizes: one atomic per string of equal labels in the row (a lane that is no zone pixel carries its own
+                    // index -- unique in the row -- so it never continues or starts a string)
                     const uint32_t ln = lane_plus1(lab, 0xFFFFFFFFu);
                     const bool zp = in && v != 0;
-                    const unsigned long long same = __ballot(zp && lane < 63 && ln == lab && lane_plus1(v, 0u) != 0);
+                    const unsigned long long same = __ballot(zp && (uint32_t)lane + 1u < w && ln == lab);
                     if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
                         cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
                     v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
