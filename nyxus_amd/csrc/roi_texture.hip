@@ -353,9 +353,15 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     // the product is a 24-bit multiply-add (a plain 32-bit product issues at quarter rate)
                     uint32_t* const Pm = P - (Nr + 1);
                     auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
+                    // (the plane row is read one step ahead and a run carries the matrix row of its level from the step it starts:
+                    //  no LDS round trip between a row's values and the decisions on them)
+                    auto load_row = [=](uint32_t row) -> uint32_t { return (in_col && row < h) ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u; };
+                    auto count_at = [=](uint32_t rm, uint32_t rl) { atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u); };
+                    uint32_t vn = load_row(0);
                     if (wave == 0) {
                         for (uint32_t row = 0; row < h; row++) {
-                            const uint32_t v = in_col ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u;
+                            const uint32_t v = vn;
+                            vn = load_row(row + 1);
                             const uint32_t nx = lane_plus1(v, 0u);
                             const unsigned long long same = __ballot((uint32_t)lane + 1 < w && v != 0 && v == nx);
                             if (v != 0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
@@ -363,23 +369,25 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         }
                     } else {
                         const int dx = wave == 1 ? 1 : wave == 2 ? 0 : -1;                   // glrlm.cpp:128-176
-                        uint32_t rv = 0, rl = 0;
+                        uint32_t rv = 0, rl = 0, rm = 0;                                      // run: level, length, matrix row + 1
                         for (uint32_t row = 0; row < h; row++) {
                             if (dx == 1) {
-                                if (w == 64 && lane == 63 && rv != 0) count_run(rv, rl);
-                                rv = lane_minus1(rv, 0u); rl = lane_minus1(rl, 0u);
+                                if (w == 64 && lane == 63 && rv != 0) count_at(rm, rl);
+                                rv = lane_minus1(rv, 0u); rl = lane_minus1(rl, 0u); rm = lane_minus1(rm, 0u);
                             } else if (dx == -1) {
-                                if (lane == 0 && rv != 0) count_run(rv, rl);
-                                rv = lane_plus1(rv, 0u); rl = lane_plus1(rl, 0u);
+                                if (lane == 0 && rv != 0) count_at(rm, rl);
+                                rv = lane_plus1(rv, 0u); rl = lane_plus1(rl, 0u); rm = lane_plus1(rm, 0u);
                             }
-                            const uint32_t v = in_col ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u;
+                            const uint32_t v = vn;
+                            vn = load_row(row + 1);
                             if (v != 0 && v == rv) rl++;
                             else {
-                                if (rv != 0) count_run(rv, rl);
+                                if (rv != 0) count_at(rm, rl);
                                 rv = v; rl = v != 0 ? 1u : 0u;
+                                rm = v != 0 ? (uint32_t)s_lvlmap[v] : 0u;
                             }
                         }
-                        if (rv != 0) count_run(rv, rl);
+                        if (rv != 0) count_at(rm, rl);
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
