@@ -491,16 +491,29 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         const double* raw = s_raw[var];
         const double* cen = s_cen[var];
         const double m00 = raw[0], w00 = s_wraw[var][0];
+        // x / pow(m, (p + q) / 2 + 1) for p + q = 0..6: the seven powers are m^(1 + j/2) = m^(1 + j div 2) * sqrt(m)^(j mod 2) -- one
+        // square root, a few products and seven divisions per normalising mass, where thirty pow() calls (a couple of hundred
+        // instructions each, on two lanes of one wave) were a tenth of the kernel.  Tolerance-class values; 1-2 ulp from pow().
+        double rm[7], rw[7];
+        {
+            const double sm = sqrt(m00), sw = sqrt(w00);
+            double pm = m00, pw = w00;
+#pragma unroll
+            for (int j = 0; j < 7; j += 2) {
+                rm[j] = 1.0 / pm; rw[j] = 1.0 / pw;
+                if (j + 1 < 7) { rm[j + 1] = 1.0 / (pm * sm); rw[j + 1] = 1.0 / (pw * sw); }
+                pm *= m00; pw *= w00;
+            }
+        }
         for (int k = 0; k < 13; k++) o[k] = raw[k];                                       // RM 00..23, 30
         for (int k = 0; k < 16; k++) o[13 + k] = cen[k];                                          // CM
-        for (int k = 0; k < 16; k++) {                                                             // NRM :204-209
-            const int p = k >> 2, q = k & 3;
-            o[29 + k] = raw[k] / pow(m00, (((double)p + (double)q) / 2.0) + 1.0);
-        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)                                                               // NRM :204-209
+            o[29 + k] = raw[k] * rm[(k >> 2) + (k & 3)];
         double nu[7], wn[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) {                                                              // NCM :212-217
-            nu[k] = cen[nc_p[k] * 4 + nc_q[k]] / pow(m00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
+            nu[k] = cen[nc_p[k] * 4 + nc_q[k]] * rm[nc_p[k] + nc_q[k]];
             o[45 + k] = nu[k];
         }
         hu7(nu[0], nu[1], nu[2], nu[3], nu[4], nu[5], nu[6], o + 52);
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         for (int k = 0; k < 7; k++) o[69 + k] = s_wcen[var][k];                                    // WCM
 #pragma unroll
         for (int k = 0; k < 7; k++) {                                                              // WNCM :220-225
-            wn[k] = s_wcen[var][k] / pow(w00, (((double)nc_p[k] + (double)nc_q[k]) / 2.0) + 1.0);
+            wn[k] = s_wcen[var][k] * rw[nc_p[k] + nc_q[k]];
             o[76 + k] = wn[k];
         }
         hu7(wn[0], wn[1], wn[2], wn[3], wn[4], wn[5], wn[6], o + 83);
