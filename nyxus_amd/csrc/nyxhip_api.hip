@@ -523,6 +523,14 @@ int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, 
     size_t need = (size_t)4 * 9 * (L.ng_cap + 1);                       // GLDM / NGLDM matrices
     if (mask & NYXHIP_FAM_GLDZM)                                     // union-find parents + matrix
         need = std::max<size_t>(need, 4ull * L.dense_cap + 4ull * (size_t)L.ng_cap * L.nd_cap + 64);
+    if (cap == roi_features_max_lds() && L.ng_cap <= 65 && !getenv("NYXHIP_DEP_SEQ")) {   // (NYXHIP_DEP_SEQ: A/B knob, sequential tails)
+        // small matrices: GLDM's and NGLDM's sit side by side at the start of `work` -- where GLDZM keeps its union-find parents,
+        // which are dead once its own matrix (behind them) is built -- so the three tails can run in parallel at the end without
+        // a byte of extra LDS (the carve-out of the benchmark ROI sits 400 B below the five-workgroups-per-CU line)
+        const size_t mat = ((size_t)4 * 9 * (L.ng_cap + 1) + 15) & ~(size_t)15;
+        L.par = 1; L.off_pdm = 0; L.off_m = (uint32_t)mat;
+        need = std::max<size_t>(need, 2 * mat);
+    }
     if (off + need > cap) { why = "ROI too large for the LDS-resident dependence / distance-zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     L.work_bytes = (uint32_t)need;
     off = align16(off + (uint32_t)need);

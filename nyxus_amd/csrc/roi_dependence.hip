@@ -149,6 +149,238 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     const int Ng = (int)s_stat[0];
     const int Ng2 = (int)s_stat[1];
 
+    // ---- feature tails: one wave each.  Organised around the instruction count (the kernel is bound by vector-instruction issue):
+    //   * a cell's quotients by level^2 / distance^2 through two reciprocals (1-2 ulp; tolerance-class sums) instead of up to
+    //     eight Newton divisions, the division by the zone count as a multiplication by its reciprocal;
+    //   * the wave totals through ONE transposed reduction (wave_transpose_sum16: ~60 exchanges for sixteen values) instead of
+    //     one six-step butterfly per value, parked in s_red-like scratch of the wave's own (`scr`, 16 doubles);
+    //   * row sums by 16-lane groups, cell indices without integer division.
+    const bool par = !GS && A.L.par != 0;
+    int Nd_dzm = 0, Nd_dm = 0, Nr_ng = 0;
+    double* const scr_all = s_red;                       // 4 x 8 doubles are not enough for three concurrent tails: see below
+    auto tail_totals16 = [&](double (&t)[16], double* scr) {   // every lane gets all sixteen totals back (through LDS)
+        const double tt = wave_transpose_sum16(t, lane);       // lane 4 k holds total k
+        if ((lane & 3) == 0) scr[lane >> 2] = tt;
+        wav_sync<GS>();
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = scr[k];
+        wav_sync<GS>();
+    };
+    auto dzm_tail = [&](const uint32_t* P, uint32_t ndmax, int Nd, double* o) {
+        double* const scr = (double*)(lds + A.L.stat);         // 16 doubles (s_stat is dead by now)
+        const int NN = Ng * Nd;
+        uint32_t ns_i = 0;
+        {
+            RowCol rc((uint32_t)lane, 64u, (uint32_t)Nd, RowCol::small_t{});
+            for (int e = lane; e < NN; e += 64, rc.advance()) ns_i += P[mad24(rc.row, ndmax, rc.col)];
+        }
+        const double Ns = (double)wave_sum_t<uint32_t>(ns_i), invNs = frcp(Ns);
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = 0.0;               // 0..6: SDLGLE SDHGLE LDLGLE LDHGLE GLM ZDM ZDE | 7..9: SDE LDE ZDNU | 10..12: LGLZE HGLZE GLNU
+        {
+            RowCol rc((uint32_t)lane, 64u, (uint32_t)Nd, RowCol::small_t{});
+            for (int e = lane; e < NN; e += 64, rc.advance()) {
+                const uint32_t pc = P[mad24(rc.row, ndmax, rc.col)];
+                if (pc == 0) continue;
+                const double p = (double)pc, g_ = (double)s_lv[rc.row], d_ = (double)(rc.col + 1);
+                const double g2 = g_ * g_, d2 = d_ * d_, rg2 = frcp(g2), rd2 = frcp(d2);    // (levels and distances are >= 1)
+                const double pg = p * rg2, pG = p * g2;
+                t[0] = __builtin_fma(pg, rd2, t[0]);
+                t[1] = __builtin_fma(pG, rd2, t[1]);
+                t[2] = __builtin_fma(pg, d2, t[2]);
+                t[3] = __builtin_fma(pG, d2, t[3]);
+                t[4] = __builtin_fma(g_, p, t[4]);
+                t[5] = __builtin_fma(d_, p, t[5]);
+                const double pn = p * invNs;
+                t[6] += pn * log2(pn + 2.2e-16);
+            }
+        }
+        for (int d = lane; d < Nd; d += 64) {
+            uint32_t m = 0, idx = (uint32_t)d;
+            for (int g = 0; g < Ng; g++, idx += ndmax) m += P[idx];
+            const double md = (double)m, dd = (double)(d + 1), d2 = dd * dd;
+            t[7] += md * frcp(d2); t[8] += d2 * md; t[9] += md * md;
+        }
+        {
+            const int slot = lane >> 4, l = lane & 15;
+            for (int g0 = 0; g0 < Ng; g0 += 4) {
+                const int g = g0 + slot;
+                uint32_t x = 0;
+                if (g < Ng) {
+                    uint32_t idx = mul24((uint32_t)g, ndmax) + (uint32_t)l;
+                    for (int d = l; d < Nd; d += 16, idx += 16) x += P[idx];
+                }
+                x = row16_sum(x);
+                if (l == 0 && g < Ng) {
+                    const double xd = (double)x, g_ = (double)s_lv[g], g2 = g_ * g_;
+                    t[10] += xd * frcp(g2); t[11] += g2 * xd; t[12] += xd * xd;
+                }
+            }
+        }
+        tail_totals16(t, scr);
+        const double GLM = t[4] * invNs, ZDM = t[5] * invNs;
+        double v4[4] = {0, 0, 0, 0};
+        {
+            RowCol rc((uint32_t)lane, 64u, (uint32_t)Nd, RowCol::small_t{});
+            for (int e = lane; e < NN; e += 64, rc.advance()) {
+                const double p = (double)P[mad24(rc.row, ndmax, rc.col)] * invNs;
+                double dif = (double)s_lv[rc.row] - GLM;
+                v4[0] += dif * dif * p;
+                dif = (double)(rc.col + 1) - ZDM;
+                v4[1] += dif * dif * p;
+            }
+        }
+        const double vt = wave_transpose_sum4(v4);             // lane 16 k holds total k
+        if (lane == 0 || lane == 16) scr[lane >> 4] = vt;
+        wav_sync<GS>();
+        if (lane == 0) {
+            const double glv = scr[0], zdv = scr[1];
+            const double zdnu = t[9] * invNs, glnu = t[12] * invNs;
+            o[0] = t[7] * invNs; o[1] = t[8] * invNs; o[2] = t[10] * invNs; o[3] = t[11] * invNs;
+            o[4] = t[0] * invNs; o[5] = t[1] * invNs; o[6] = t[2] * invNs; o[7] = t[3] * invNs;
+            o[8] = glnu; o[9] = glnu * invNs; o[10] = zdnu; o[11] = zdnu * invNs;
+            o[12] = fdiv(Ns, (double)n);                       // ZP = Ns / roi_area :399
+            o[13] = GLM; o[14] = glv; o[15] = ZDM; o[16] = zdv; o[17] = -t[6];
+        }
+    };
+    auto dm_tail = [&](const uint32_t* P, int Nd, double* o) {
+        double* const scr = s_red;                             // 32 doubles: [0..15] this tail, [16..31] the NGLDM tail
+        uint32_t nz_i = 0;
+        for (int e = lane; e < Ng * 9; e += 64) nz_i += P[e];
+        const uint32_t nz = wave_sum_t<uint32_t>(nz_i);
+        if (nz == 0) {
+            if (lane < kGldmCols) o[lane] = A.soft_nan;        // :216-234
+            return;
+        }
+        const double Nz = (double)nz, invNz = frcp(Nz);
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = 0.0;               // 0..8: SDE LDE mu_g mu_d DE SDLGLE SDHGLE LDLGLE LDHGLE | 9..11: GLN LGLE HGLE | 12: DN
+        {
+            RowCol rc((uint32_t)lane, 64u, 9u, RowCol::small_t{});
+            for (int e = lane; e < Ng * 9; e += 64, rc.advance()) {
+                const uint32_t ci = P[e];
+                const int j = (int)rc.col + 1;
+                if (ci == 0 || j > Nd) continue;
+                const double c = (double)ci, inten = (double)s_lv[rc.row], jj = (double)j;
+                const double i2 = inten * inten, j2 = jj * jj, ri2 = frcp(i2), rj2 = frcp(j2);   // (levels and dependence counts are >= 1)
+                const double cn = c * invNz, cj = c * rj2, cJ = c * j2;
+                t[0] += cj;
+                t[1] += cJ;
+                t[2] = __builtin_fma(cn, inten, t[2]);
+                t[3] = __builtin_fma(cn, jj, t[3]);
+                t[4] += plog_dep(cn);
+                t[5] = __builtin_fma(cj, ri2, t[5]);
+                t[6] = __builtin_fma(cj, i2, t[6]);
+                t[7] = __builtin_fma(cJ, ri2, t[7]);
+                t[8] = __builtin_fma(cJ, i2, t[8]);
+            }
+        }
+        for (int i = lane; i < Ng; i += 64) {
+            uint32_t si_i = 0;
+            for (int j = 0; j < Nd; j++) si_i += P[i * 9 + j];
+            const double si = (double)si_i, inten = (double)s_lv[i], i2 = inten * inten;
+            t[9] += si * si; t[10] += si * frcp(i2); t[11] += si * i2;
+        }
+        if (lane < Nd) {
+            uint32_t sj_i = 0;
+            for (int i = 0; i < Ng; i++) sj_i += P[i * 9 + lane];
+            const double sj = (double)sj_i;
+            t[12] = sj * sj;
+        }
+        tail_totals16(t, scr);
+        const double mu_g = t[2], mu_d = t[3];
+        double v4[4] = {0, 0, 0, 0};
+        {
+            RowCol rc((uint32_t)lane, 64u, 9u, RowCol::small_t{});
+            for (int e = lane; e < Ng * 9; e += 64, rc.advance()) {
+                const uint32_t ci = P[e];
+                const int j = (int)rc.col + 1;
+                if (ci == 0 || j > Nd) continue;
+                const double cn = (double)ci * invNz, dg = (double)s_lv[rc.row] - mu_g, dd = (double)j - mu_d;
+                v4[0] += cn * (dg * dg);
+                v4[1] += cn * (dd * dd);
+            }
+        }
+        const double vt = wave_transpose_sum4(v4);
+        if (lane == 0 || lane == 16) scr[lane >> 4] = vt;
+        wav_sync<GS>();
+        if (lane == 0) {
+            const double glv = scr[0], dv = scr[1];
+            o[0] = t[0] * invNz; o[1] = t[1] * invNz; o[2] = t[9] * invNz; o[3] = t[12] * invNz; o[4] = t[12] * invNz * invNz;
+            o[5] = glv; o[6] = dv; o[7] = -t[4]; o[8] = t[10] * invNz; o[9] = t[11] * invNz;
+            o[10] = t[5] * invNz; o[11] = t[6] * invNz; o[12] = t[7] * invNz; o[13] = t[8] * invNz;
+        }
+    };
+    auto ng_tail = [&](const uint32_t* M, int Nr, double* o) {
+        double* const scr = s_red + 16;
+        const double Ns = (double)n, invNs = frcp(Ns);         // every cloud pixel is counted once
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = 0.0;               // 0..11: LDE HDE LGLCE HGLCE LDLGLE LDHGLE HDLGLE HDHGLE GLM DCM DCENT DCENE | 12, 13: sum Sg^2, sum Sr^2
+        {
+            RowCol rc((uint32_t)lane, 64u, 9u, RowCol::small_t{});
+            for (int e = lane; e < Ng2 * 9; e += 64, rc.advance()) {
+                const uint32_t si = M[e];
+                const int j = (int)rc.col;
+                if (si == 0 || j >= Nr) continue;
+                const double sij = (double)si, gl = (double)s_lv2[rc.row], dc = (double)(j + 1), pij = sij * invNs;
+                const double d2 = dc * dc, g2 = gl * gl, rd2 = frcp(d2), sd = sij * rd2, sD = sij * d2;
+                t[0] += sd;
+                t[1] += sD;
+                if (gl != 0.0) {                               // (a zero level has no reciprocal: its terms are skipped, ngldm.cpp)
+                    const double rg2 = frcp(g2);
+                    t[2] = __builtin_fma(sij, rg2, t[2]);
+                    t[4] = __builtin_fma(sd, rg2, t[4]);
+                    t[6] = __builtin_fma(sD, rg2, t[6]);
+                }
+                t[3] = __builtin_fma(sij, g2, t[3]);
+                t[5] = __builtin_fma(sd, g2, t[5]);
+                t[7] = __builtin_fma(sD, g2, t[7]);
+                t[8] = __builtin_fma(gl, pij, t[8]);
+                t[9] = __builtin_fma(dc, pij, t[9]);
+                t[10] -= pij * (log(pij) * 1.4426950408889634);   // log2 through the natural log, as the reference's log(p) / log(2)
+                t[11] = __builtin_fma(pij, pij, t[11]);
+            }
+        }
+        for (int i = lane; i < Ng2; i += 64) {
+            uint32_t sg = 0;
+            for (int j = 0; j < Nr; j++) sg += M[i * 9 + j];
+            t[12] += (double)sg * (double)sg;
+        }
+        if (lane < Nr) {
+            uint32_t sr = 0;
+            for (int i = 0; i < Ng2; i++) sr += M[i * 9 + lane];
+            t[13] = (double)sr * (double)sr;
+        }
+        tail_totals16(t, scr);
+        const double GLM = t[8], DCM = t[9];
+        double v4[4] = {0, 0, 0, 0};
+        {
+            RowCol rc((uint32_t)lane, 64u, 9u, RowCol::small_t{});
+            for (int e = lane; e < Ng2 * 9; e += 64, rc.advance()) {
+                const uint32_t si = M[e];
+                const int j = (int)rc.col;
+                if (si == 0 || j >= Nr) continue;
+                const double gl = (double)s_lv2[rc.row], dc = (double)(j + 1), pij = (double)si * invNs;
+                v4[0] += (gl - GLM) * (gl - GLM) * pij;
+                v4[1] += (dc - DCM) * (dc - DCM) * pij;
+            }
+        }
+        const double vt = wave_transpose_sum4(v4);
+        if (lane == 0 || lane == 16) scr[lane >> 4] = vt;
+        wav_sync<GS>();
+        if (lane == 0) {
+            const double glv = scr[0], dcv = scr[1];
+            o[0] = t[0] * invNs; o[1] = t[1] * invNs; o[2] = t[2] * invNs; o[3] = t[3] * invNs; o[4] = t[4] * invNs; o[5] = t[5] * invNs;
+            o[6] = t[6] * invNs; o[7] = t[7] * invNs; o[8] = t[12] * invNs; o[9] = t[12] * invNs * invNs; o[10] = t[13] * invNs; o[11] = t[13] * invNs * invNs;
+            o[12] = 1.0;                                       // DCP :339
+            o[13] = GLM; o[14] = glv; o[15] = DCM; o[16] = dcv; o[17] = t[10]; o[18] = t[11];
+        }
+    };
+    (void)scr_all;
+
     // =====================================================================================================
     // GLDZM
     // =====================================================================================================
@@ -247,66 +479,12 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         int Nd = 0;
         for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
         blk_sync<GS>();
-        // features (calc_features :323-420); every level of the LUT is non-zero here
-        if (wave == solo) {
-            double Ns = 0;
-            for (int e = lane; e < Ng * Nd; e += 64) { const int g = e / Nd, d = e - g * Nd; Ns += (double)s_P[g * ndmax + d]; }
-            Ns = wave_sum(Ns);
-            double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // SDLGLE SDHGLE LDLGLE LDHGLE GLM ZDM ZDE | Mx2 Md2 placeholders
-            RowCol rcz((uint32_t)lane, 64u, (uint32_t)Nd);
-            for (int e = lane; e < Ng * Nd; e += 64, rcz.advance()) {
-                const int g = (int)rcz.row, d = (int)rcz.col;
-                const double p = (double)s_P[g * ndmax + d];
-                if (p == 0) continue;
-                const double g_ = (double)s_lv[g], d_ = (double)(d + 1);
-                // (the divisors of this tail -- level values, distances, Ns -- are all >= 1: fdiv's domain; tolerance-class sums)
-                a[0] += fdiv(fdiv(fdiv(fdiv(p, g_), g_), d_), d_);
-                a[1] += fdiv(fdiv(g_ * g_ * p, d_), d_);
-                a[2] += fdiv(fdiv(d_ * d_ * p, g_), g_);
-                a[3] += g_ * g_ * d_ * d_ * p;
-                a[4] += g_ * p;
-                a[5] += d_ * p;
-                const double pn = fdiv(p, Ns);
-                a[6] += pn * log2(pn + 2.2e-16);
-            }
-            double b[6] = {0, 0, 0, 0, 0, 0};             // SDE LDE ZDNU | LGLZE HGLZE GLNU
-            for (int d = lane; d < Nd; d += 64) {
-                double m = 0;
-                for (int g = 0; g < Ng; g++) m += (double)s_P[g * ndmax + d];
-                const double dd = (double)(d + 1);
-                b[0] += fdiv(fdiv(m, dd), dd); b[1] += dd * dd * m; b[2] += m * m;
-            }
-            for (int g = lane; g < Ng; g += 64) {
-                double x = 0;
-                for (int d = 0; d < Nd; d++) x += (double)s_P[g * ndmax + d];
-                const double g_ = (double)s_lv[g];
-                b[3] += fdiv(x, g_ * g_); b[4] += (g_ * g_) * x; b[5] += x * x;
-            }
-#pragma unroll
-            for (int k = 0; k < 7; k++) a[k] = wave_sum(a[k]);
-#pragma unroll
-            for (int k = 0; k < 6; k++) b[k] = wave_sum(b[k]);
-            const double GLM = fdiv(a[4], Ns), ZDM = fdiv(a[5], Ns);
-            double glv = 0, zdv = 0;
-            for (int e = lane; e < Ng * Nd; e += 64) {
-                const int g = e / Nd, d = e - g * Nd;
-                const double p = fdiv((double)s_P[g * ndmax + d], Ns);
-                double dif = (double)s_lv[g] - GLM;
-                glv += dif * dif * p;
-                dif = (double)(d + 1) - ZDM;
-                zdv += dif * dif * p;
-            }
-            glv = wave_sum(glv); zdv = wave_sum(zdv);
-            if (lane == 0) {
-                const double zdnu = fdiv(b[2], Ns), glnu = fdiv(b[5], Ns);
-                o[0] = fdiv(b[0], Ns); o[1] = fdiv(b[1], Ns); o[2] = fdiv(b[3], Ns); o[3] = fdiv(b[4], Ns);
-                o[4] = fdiv(a[0], Ns); o[5] = fdiv(a[1], Ns); o[6] = fdiv(a[2], Ns); o[7] = fdiv(a[3], Ns);
-                o[8] = glnu; o[9] = fdiv(glnu, Ns); o[10] = zdnu; o[11] = fdiv(zdnu, Ns);
-                o[12] = fdiv(Ns, (double)n);               // ZP = Ns / roi_area :399
-                o[13] = GLM; o[14] = glv; o[15] = ZDM; o[16] = zdv; o[17] = -a[6];
-            }
+        // features (calc_features :323-420): dzm_tail, on the solo wave now or next to the other tails at the end
+        Nd_dzm = Nd;
+        if (!par) {
+            if (wave == solo) dzm_tail(s_P, ndmax, Nd, o);
+            blk_sync<GS>();
         }
-        blk_sync<GS>();
     }
 
     // =====================================================================================================
@@ -314,7 +492,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     // =====================================================================================================
     if (do_dm) {
         double* o = row_out + A.col_gldm;
-        uint32_t* s_P = (uint32_t*)s_work;                           // [Ng][9]
+        uint32_t* s_P = (uint32_t*)(s_work + (par ? A.L.off_pdm : 0u));   // [Ng][9]
         for (int i = tid; i < Ng * 9; i += kBlk) s_P[i] = 0;
         blk_sync<GS>();
         uint32_t nd_loc = 0;
@@ -373,66 +551,11 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int wv = 0; wv < kBlk / 64; wv++) Nd = (int)s_red[wv * 8] > Nd ? (int)s_red[wv * 8] : Nd;
         if (greyInfo == 0) Nd = 9;                                   // gldm.cpp:173,208-209
         blk_sync<GS>();
-        if (wave == solo) {
-            unsigned long long nz = 0;
-            for (int e = lane; e < Ng * 9; e += 64) nz += s_P[e];
-            nz = wave_sum_u64(nz);
-            if (nz == 0) {
-                if (lane < kGldmCols) o[lane] = A.soft_nan;          // :216-234
-            } else {
-                const double Nz = (double)nz;
-                double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};           // SDE LDE mu_g mu_d DE SDLGLE SDHGLE LDLGLE LDHGLE
-                for (int e = lane; e < Ng * 9; e += 64) {
-                    const int i = e / 9, j = e - i * 9 + 1;
-                    const double c = (double)s_P[e];
-                    if (c == 0 || j > Nd) continue;
-                    const double inten = (double)s_lv[i], jj = (double)j;
-                    const double cn = fdiv(c, Nz);                    // (levels, dependence counts and Nz are >= 1: fdiv's domain)
-                    a[0] += fdiv(c, jj * jj);
-                    a[1] += c * (jj * jj);
-                    a[2] += cn * inten;
-                    a[3] += cn * jj;
-                    a[4] += plog_dep(cn);
-                    a[5] += fdiv(c, inten * inten * jj * jj);
-                    a[6] += fdiv(c * (inten * inten), (double)(j * j));
-                    a[7] += fdiv(c * (double)(j * j), inten * inten);
-                    a[8] += c * (inten * inten * jj * jj);
-                }
-                double b[4] = {0, 0, 0, 0};                          // GLN LGLE HGLE | DN
-                for (int i = lane; i < Ng; i += 64) {
-                    double si = 0;
-                    for (int j = 0; j < Nd; j++) si += (double)s_P[i * 9 + j];
-                    const double inten = (double)s_lv[i];
-                    b[0] += si * si; b[1] += fdiv(si, inten * inten); b[2] += si * inten * inten;
-                }
-                if (lane < Nd) {
-                    double sj = 0;
-                    for (int i = 0; i < Ng; i++) sj += (double)s_P[i * 9 + lane];
-                    b[3] = sj * sj;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) a[k] = wave_sum(a[k]);
-#pragma unroll
-                for (int k = 0; k < 4; k++) b[k] = wave_sum(b[k]);
-                const double mu_g = a[2], mu_d = a[3];
-                double glv = 0, dv = 0;
-                for (int e = lane; e < Ng * 9; e += 64) {
-                    const int i = e / 9, j = e - i * 9 + 1;
-                    const double c = (double)s_P[e];
-                    if (c == 0 || j > Nd) continue;
-                    const double dg = (double)s_lv[i] - mu_g, dd = (double)j - mu_d;
-                    glv += c / Nz * (dg * dg);
-                    dv += c / Nz * (dd * dd);
-                }
-                glv = wave_sum(glv); dv = wave_sum(dv);
-                if (lane == 0) {
-                    o[0] = a[0] / Nz; o[1] = a[1] / Nz; o[2] = b[0] / Nz; o[3] = b[3] / Nz; o[4] = b[3] / (Nz * Nz);
-                    o[5] = glv; o[6] = dv; o[7] = -a[4]; o[8] = b[1] / Nz; o[9] = b[2] / Nz;
-                    o[10] = a[5] / Nz; o[11] = a[6] / Nz; o[12] = a[7] / Nz; o[13] = a[8] / Nz;
-                }
-            }
+        Nd_dm = Nd;
+        if (!par) {
+            if (wave == solo) dm_tail(s_P, Nd, o);
+            blk_sync<GS>();
         }
-        blk_sync<GS>();
     }
 
     // =====================================================================================================
@@ -440,7 +563,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     // =====================================================================================================
     if (do_ng) {
         double* o = row_out + A.col_ngldm;
-        uint32_t* s_M = (uint32_t*)s_work;                           // [Ng2][9]
+        uint32_t* s_M = (uint32_t*)(s_work + (par ? A.L.off_m : 0u));    // [Ng2][9]
         for (int i = tid; i < Ng2 * 9; i += kBlk) s_M[i] = 0;
         blk_sync<GS>();
         uint32_t dep_loc = 0;
@@ -494,61 +617,21 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         for (int wv = 0; wv < kBlk / 64; wv++) Nr = (int)s_red[wv * 8] > Nr ? (int)s_red[wv * 8] : Nr;
         Nr += 1;                                                     // ngldm.cpp:142
         blk_sync<GS>();
-        if (wave == solo) {
-            double Ns = (double)n;                                   // every cloud pixel is counted once
-            double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // LDE HDE LGLCE HGLCE LDLGLE LDHGLE HDLGLE HDHGLE GLM DCM DCENT DCENE
-            for (int e = lane; e < Ng2 * 9; e += 64) {
-                const int i = e / 9, j = e - i * 9;
-                const double sij = (double)s_M[e];
-                if (sij == 0 || j >= Nr) continue;
-                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = fdiv(sij, Ns);   // (dc, Ns >= 1; gl is tested below)
-                a[0] += fdiv(fdiv(sij, dc), dc);
-                a[1] += sij * dc * dc;
-                if (gl != 0.0) {
-                    a[2] += fdiv(fdiv(sij, gl), gl);
-                    a[4] += fdiv(fdiv(fdiv(fdiv(sij, dc), dc), gl), gl);
-                    a[6] += fdiv(fdiv(sij * dc * dc, gl), gl);
-                }
-                a[3] += sij * gl * gl;
-                a[5] += fdiv(fdiv(sij * gl * gl, dc), dc);
-                a[7] += sij * dc * dc * gl * gl;
-                a[8] += gl * pij;
-                a[9] += dc * pij;
-                a[10] -= pij * log(pij) / log(2.0);
-                a[11] += pij * pij;
-            }
-            double b[2] = {0, 0};                                    // sum Sg^2, sum Sr^2
-            for (int i = lane; i < Ng2; i += 64) {
-                double sg = 0;
-                for (int j = 0; j < Nr; j++) sg += (double)s_M[i * 9 + j];
-                b[0] += sg * sg;
-            }
-            if (lane < Nr) {
-                double sr = 0;
-                for (int i = 0; i < Ng2; i++) sr += (double)s_M[i * 9 + lane];
-                b[1] = sr * sr;
-            }
-#pragma unroll
-            for (int k = 0; k < 12; k++) a[k] = wave_sum(a[k]);
-            b[0] = wave_sum(b[0]); b[1] = wave_sum(b[1]);
-            const double GLM = a[8], DCM = a[9];
-            double glv = 0, dcv = 0;
-            for (int e = lane; e < Ng2 * 9; e += 64) {
-                const int i = e / 9, j = e - i * 9;
-                const double sij = (double)s_M[e];
-                if (sij == 0 || j >= Nr) continue;
-                const double gl = (double)s_lv2[i], dc = (double)(j + 1), pij = fdiv(sij, Ns);
-                glv += (gl - GLM) * (gl - GLM) * pij;
-                dcv += (dc - DCM) * (dc - DCM) * pij;
-            }
-            glv = wave_sum(glv); dcv = wave_sum(dcv);
-            if (lane == 0) {
-                o[0] = a[0] / Ns; o[1] = a[1] / Ns; o[2] = a[2] / Ns; o[3] = a[3] / Ns; o[4] = a[4] / Ns; o[5] = a[5] / Ns;
-                o[6] = a[6] / Ns; o[7] = a[7] / Ns; o[8] = b[0] / Ns; o[9] = b[0] / (Ns * Ns); o[10] = b[1] / Ns; o[11] = b[1] / (Ns * Ns);
-                o[12] = 1.0;                                         // DCP :339
-                o[13] = GLM; o[14] = glv; o[15] = DCM; o[16] = dcv; o[17] = a[10]; o[18] = a[11];
-            }
+        Nr_ng = Nr;
+        if (!par) {
+            if (wave == solo) ng_tail(s_M, Nr, o);
         }
+    }
+    // ---- the three feature tails side by side: one wave each (they are short serial chains of one wave; run one after the other
+    //      they left three quarters of the workgroup waiting three times)
+    if (par) {
+        blk_sync<GS>();
+        if (do_dzm && wave == solo)
+            dzm_tail((const uint32_t*)s_work + A.L.dense_cap, ((w < h ? w : h) + 1) / 2 + 1, Nd_dzm, row_out + A.col_gldzm);
+        else if (do_dm && wave == ((solo + 1) & 3))
+            dm_tail((const uint32_t*)(s_work + A.L.off_pdm), Nd_dm, row_out + A.col_gldm);
+        else if (do_ng && wave == ((solo + 2) & 3))
+            ng_tail((const uint32_t*)(s_work + A.L.off_m), Nr_ng, row_out + A.col_ngldm);
     }
 }
 

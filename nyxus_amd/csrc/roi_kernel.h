@@ -157,6 +157,9 @@ struct DepLayout {
     uint32_t work;      // per-family scratch, families run one after the other
     uint32_t total;
     uint32_t dense_cap, side_cap, lvl_cap, ng_cap, nd_cap, work_bytes;
+    uint32_t par;       // 1: the GLDM / NGLDM matrices have places of their own inside `work` (off_pdm, off_m), so the three feature
+                        // tails run side by side on three waves at the end of the kernel instead of one after the other on one wave
+    uint32_t off_pdm, off_m;
 };
 
 struct DepArgs {
