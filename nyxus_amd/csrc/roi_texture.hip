@@ -667,29 +667,32 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             if (sum_p == 0) {                                // glszm.cpp:229-233
                 for (int c = tid; c < 16; c += kBlock) o[c] = A.soft_nan;
             } else {
-                // calc_sums_of_P :342-395 over the non-zero cells
-                double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+                // calc_sums_of_P :342-395 over the non-zero cells.  (Vector-instruction diet: reciprocals of i^2 / j^2 instead of a
+                // Newton division per quotient, p / sum_p as a product, wave totals through transposed reductions.)
+                const double inv_p = frcp(sum_p);
+                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < n_cells; i += kBlock) {
                     uint32_t key, val;
                     cell(i, key, val);
                     if (key == 0) continue;
-                    double p = (double)val;
-                    double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
-                    double i2 = inten * inten, j2 = jd * jd;
-                    acc[0] += p * i2 * j2;                   // f_LAHGLE
-                    const double pn = fdiv(p, sum_p);        // (levels, sizes and sum_p are >= 1: fdiv's domain)
-                    acc[1] += fdiv(p * j2, i2);              // f_LALGLE
-                    acc[2] += fdiv(p * i2, j2);              // f_SAHGLE
-                    acc[3] += fdiv(p, i2 * j2);              // f_SALGLE
+                    const double p = (double)val;
+                    const double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
+                    const double i2 = inten * inten, j2 = jd * jd, ri2 = frcp(i2), rj2 = frcp(j2);   // (levels and sizes are >= 1)
+                    const double pj = p * j2, pr = p * rj2;
+                    acc[0] = __builtin_fma(pj, i2, acc[0]);  // f_LAHGLE
+                    acc[1] = __builtin_fma(pj, ri2, acc[1]); // f_LALGLE
+                    acc[2] = __builtin_fma(pr, i2, acc[2]);  // f_SAHGLE
+                    acc[3] = __builtin_fma(pr, ri2, acc[3]); // f_SALGLE
+                    const double pn = p * inv_p;
                     acc[4] += plog_tex(pn);                  // f_ZE
-                    acc[5] += pn * jd;                       // mu_ZV
-                    acc[6] += pn * inten;                    // mu_GLV
+                    acc[5] = __builtin_fma(pn, jd, acc[5]);  // mu_ZV
+                    acc[6] = __builtin_fma(pn, inten, acc[6]); // mu_GLV
                 }
-                // block reduction (fixed order)
-#pragma unroll
-                for (int k = 0; k < 7; k++) acc[k] = wave_sum(acc[k]);
-                if (lane == 0)
-                    for (int k = 0; k < 7; k++) s_red[wave * 8 + k] = acc[k];
+                // block reduction (fixed order): transposed wave sum, lane 8 k holds total k
+                {
+                    const double tt = wave_transpose_sum8(acc, lane);
+                    if ((lane & 7) == 0) s_red[wave * 8 + (lane >> 3)] = tt;
+                }
                 blk_sync<GS>();
 #pragma unroll
                 for (int k = 0; k < 7; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
@@ -701,50 +704,58 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     uint32_t key, val;
                     cell(i, key, val);
                     if (key == 0) continue;
-                    double p = fdiv((double)val, sum_p);
-                    double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
+                    const double p = (double)val * inv_p;
+                    const double dg = (double)s_lv[key >> 20] - mu_GLV, dz = (double)(key & 0xFFFFFu) - mu_ZV;
                     b[0] += p * (dg * dg);                   // calc_GLV :497-510
                     b[1] += p * (dz * dz);                   // calc_ZV :512-524
                 }
                 for (uint32_t j = 1 + tid; j <= area; j += kBlock) {
-                    double sj = (double)cnt_get(j);
+                    const uint32_t sji = cnt_get(j);
                     // j * j is an int product in the reference: it wraps for j >= 46341 and is exactly 0 at multiples of
                     // 65536, where the empty column contributes 0.0 / 0 = NaN to SAE (Ns = bbox area, glszm.cpp:212)
-                    if (sj == 0 && (j & 0xFFFFu) != 0) continue;
-                    int jj = (int)(j * j);
-                    b[2] += sj / (double)jj;                 // calc_SAE :419-428
-                    b[3] += sj * (double)jj;                 // calc_LAE :430-439
+                    if (sji == 0 && (j & 0xFFFFu) != 0) continue;
+                    const double sj = (double)sji;
+                    if (j < 32768u) {                        // (the product is exact and positive: a reciprocal serves)
+                        const double jj = (double)mul24(j, j);
+                        b[2] += sj * frcp(jj);               // calc_SAE :419-428
+                        b[3] += sj * jj;                     // calc_LAE :430-439
+                    } else {
+                        const int jj = (int)(j * j);
+                        b[2] += sj / (double)jj;
+                        b[3] += sj * (double)jj;
+                    }
                     b[4] += sj * sj;                         // calc_SZN :464-474
                 }
                 for (int i = tid; i < Ng; i += kBlock) {
-                    double si = (double)s_si[i], inten = (double)s_lv[i];
+                    const double si = (double)s_si[i], inten = (double)s_lv[i], i2 = inten * inten;
                     b[5] += si * si;                         // calc_GLN :441-451
-                    b[6] += si / (inten * inten);            // calc_LGLZE :531-541
-                    b[7] += si * (inten * inten);            // calc_HGLZE :543-553
+                    b[6] += si * frcp(i2);                   // calc_LGLZE :531-541
+                    b[7] += si * i2;                         // calc_HGLZE :543-553
                 }
-#pragma unroll
-                for (int k = 0; k < 8; k++) b[k] = wave_sum(b[k]);
-                if (lane == 0)
-                    for (int k = 0; k < 8; k++) s_red[wave * 8 + k] = b[k];
+                {
+                    const double tt = wave_transpose_sum8(b, lane);
+                    if ((lane & 7) == 0) s_red[wave * 8 + (lane >> 3)] = tt;
+                }
                 blk_sync<GS>();
                 if (tid == 0) {
                     for (int k = 0; k < 8; k++) b[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
-                    o[Z_SAE] = b[2] / sum_p;
-                    o[Z_LAE] = b[3] / sum_p;
-                    o[Z_GLN] = b[5] / sum_p;
-                    o[Z_GLNN] = b[5] / (sum_p * sum_p);
-                    o[Z_SZN] = b[4] / sum_p;
-                    o[Z_SZNN] = b[4] / (sum_p * sum_p);
-                    o[Z_ZP] = sum_p / (double)(int)(uint32_t)s_stat[3];   // calc_ZP :491-495
+                    const double inv_p2 = inv_p * inv_p;
+                    o[Z_SAE] = b[2] * inv_p;
+                    o[Z_LAE] = b[3] * inv_p;
+                    o[Z_GLN] = b[5] * inv_p;
+                    o[Z_GLNN] = b[5] * inv_p2;
+                    o[Z_SZN] = b[4] * inv_p;
+                    o[Z_SZNN] = b[4] * inv_p2;
+                    o[Z_ZP] = fdiv(sum_p, (double)(int)(uint32_t)s_stat[3]);   // calc_ZP :491-495
                     o[Z_GLV] = b[0];
                     o[Z_ZV] = b[1];
                     o[Z_ZE] = -acc[4];
-                    o[Z_LGLZE] = b[6] / sum_p;
-                    o[Z_HGLZE] = b[7] / sum_p;
-                    o[Z_SALGLE] = acc[3] / sum_p;
-                    o[Z_SAHGLE] = acc[2] / sum_p;
-                    o[Z_LALGLE] = acc[1] / sum_p;
-                    o[Z_LAHGLE] = acc[0] / sum_p;
+                    o[Z_LGLZE] = b[6] * inv_p;
+                    o[Z_HGLZE] = b[7] * inv_p;
+                    o[Z_SALGLE] = acc[3] * inv_p;
+                    o[Z_SAHGLE] = acc[2] * inv_p;
+                    o[Z_LALGLE] = acc[1] * inv_p;
+                    o[Z_LAHGLE] = acc[0] * inv_p;
                 }
             }
         }
