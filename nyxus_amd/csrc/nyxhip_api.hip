@@ -36,6 +36,8 @@ struct nyxhip_ctx {
     size_t stage_bytes = 0;
     // split GLCM: exported co-occurrence counts + matrix orders (grow-only)
     uint32_t* d_glcm_ws = nullptr;
+    double* d_logtab = nullptr;      // moments: log(sqrt(d) + 0.001) per integer squared distance (roi_moments.hip)
+    uint32_t logtab_n = 0;
     size_t glcm_ws_bytes = 0;
     // contour + moments workspace (grow-only): contour points, contour lengths, per-pixel log distances
     void* d_mom = nullptr;
@@ -528,8 +530,11 @@ int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, 
         // which are dead once its own matrix (behind them) is built -- so the three tails can run in parallel at the end without
         // a byte of extra LDS (the carve-out of the benchmark ROI sits 400 B below the five-workgroups-per-CU line)
         const size_t mat = ((size_t)4 * 9 * (L.ng_cap + 1) + 15) & ~(size_t)15;
-        L.par = 1; L.off_pdm = 0; L.off_m = (uint32_t)mat;
-        need = std::max<size_t>(need, 2 * mat);
+        size_t base = 0;
+        if ((mask & NYXHIP_FAM_GLDZM) && 2 * mat > 4ull * L.dense_cap)       // small boxes, many levels: the pair would reach GLDZM's own
+            base = (4ull * L.dense_cap + 4ull * (size_t)L.ng_cap * L.nd_cap + 64 + 15) & ~15ull;   // matrix -- it goes behind it instead
+        L.par = 1; L.off_pdm = (uint32_t)base; L.off_m = (uint32_t)(base + mat);
+        need = std::max<size_t>(need, base + 2 * mat);
     }
     if (off + need > cap) { why = "ROI too large for the LDS-resident dependence / distance-zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     L.work_bytes = (uint32_t)need;
@@ -755,6 +760,13 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
     m.col_smoms = nyxhip_n_columns(mask & ~kMoments, s);
     m.col_imoms = m.col_smoms + ((mask & NYXHIP_FAM_SMOMS) ? kMomCols : 0);
     m.ws_contour = (uint32_t*)(base + o_k); m.n_contour = (uint32_t*)(base + o_n); m.ws_L = (double*)(base + o_l);
+    if (!ctx->d_logtab) {                                 // log(sqrt(d) + 0.001), d < 32768: boxes up to 128 x 128 never evaluate a logarithm
+        constexpr uint32_t kLogTab = 32768;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_logtab, 8ull * kLogTab));
+        if (launch_moments_logtab(ctx->d_logtab, kLogTab, st) != 0) return fail(ctx, NYXHIP_ERR_HIP, "moments log table: launch failed");
+        ctx->logtab_n = kLogTab;
+    }
+    m.log_tab = ctx->d_logtab; m.log_tab_n = ctx->logtab_n;
     const uint64_t full_plane = (uint64_t)max_area + 4ull * max_side + 4;      // (w + 2)(h + 2) <= area + 2(w + h) + 4
     const uint32_t grid = (uint32_t)b->n_roi;
     const uint32_t lds_cap = (uint32_t)roi_features_max_lds();
@@ -1069,6 +1081,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_mom) (void)hipFree(ctx->d_mom);
     if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
+    if (ctx->d_logtab) (void)hipFree(ctx->d_logtab);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);

@@ -207,6 +207,8 @@ struct MomArgs {
     uint32_t* ws_contour;     // [total pixels]  merged multicontour of every ROI at its CSR offset: x | y << 16, padded coordinates
     uint32_t* n_contour;      // [n_roi]         its length
     double* ws_L;             // [total pixels]  log(distance to contour + eps) per pixel (the contour kernel's walk stack before that)
+    const double* log_tab;    // [log_tab_n]     log(sqrt(d) + 0.001) for the integer squared distances d < log_tab_n (context-owned, built once
+    uint32_t log_tab_n;       //                 on the device by the same expression: bit-identical to evaluating it per pixel)
     uint32_t plane_cap;       // bytes of the padded flag plane one ROI may use
     SpillArgs sp;
 };
@@ -278,6 +280,7 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid);
 int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid);
 int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid);
 int launch_roi_moments(const MomArgs& a, void* stream, uint32_t grid);
+int launch_moments_logtab(double* tab, uint32_t n, void* stream);
 size_t roi_features_max_lds();
 
 } // namespace nyxhip

@@ -430,8 +430,11 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
 #pragma unroll
         for (int k = 0; k < 10; k++) { as[k] = 0; ai[k] = 0; }
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double lg = log(sqrt(small_xy ? min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
-                                                : min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)) + 0.001);
+            // (a squared distance between integer points is an integer: for the small ones the logarithm comes from a table
+            //  built once per context with this very expression -- ~100 vector instructions per pixel less)
+            const double dsq = small_xy ? min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
+                                        : min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
+            const double lg = (small_xy && dsq < (double)A.log_tab_n) ? A.log_tab[(uint32_t)dsq] : log(sqrt(dsq) + 0.001);
             L[i] = lg;
             const double X = (double)xi, Y = (double)yi;
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
@@ -544,6 +547,18 @@ int launch_roi_contour(const MomArgs& a, void* stream, uint32_t grid)
         hipLaunchKernelGGL(roi_contour_kernel<true>, dim3(wgs), dim3(64 * kContourWaves), 0, (hipStream_t)stream, b);
     else
         hipLaunchKernelGGL(roi_contour_kernel<false>, dim3(wgs), dim3(64 * kContourWaves), kContourWaves * ((a.plane_cap + 15u) & ~15u), (hipStream_t)stream, b);
+    return (int)hipGetLastError();
+}
+
+__global__ void moments_logtab_kernel(double* tab, uint32_t n)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n) tab[d] = log(sqrt((double)d) + 0.001);
+}
+
+int launch_moments_logtab(double* tab, uint32_t n, void* stream)
+{
+    hipLaunchKernelGGL(moments_logtab_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab, n);
     return (int)hipGetLastError();
 }
 
