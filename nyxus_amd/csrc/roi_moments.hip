@@ -268,12 +268,15 @@ __device__ __forceinline__ double min_sqdist_v2(int px, int py, const uint32_t* 
 {
     if (n == 0) return 0.0;
     using dist_t = typename std::conditional<SMALL, uint32_t, double>::type;
+    const uint32_t ppack = ((uint32_t)px & 0xFFFFu) | ((uint32_t)py << 16);
     auto sqd = [&](uint32_t i) -> dist_t {
         const uint32_t k = K[i];
         if (SMALL) {
-            const int dx = (int)(k & 0xFFFFu) - px, dy = (int)(k >> 16) - py;
-            return (dist_t)(__umul24((uint32_t)(dx < 0 ? -dx : dx), (uint32_t)(dx < 0 ? -dx : dx)) +
-                            __umul24((uint32_t)(dy < 0 ? -dy : dy), (uint32_t)(dy < 0 ? -dy : dy)));
+            // a contour point is x | y << 16 and both coordinates are below 2^15: the difference is one packed 16-bit subtraction,
+            // dx^2 + dy^2 one two-element dot product (v_pk_sub_i16 + v_dot2_i32_i16 instead of unpack / subtract / square / add)
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const s16x2 d = __builtin_bit_cast(s16x2, k) - __builtin_bit_cast(s16x2, ppack);
+            return (dist_t)(uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
         } else {
             const double dx = (double)(int)(k & 0xFFFFu) - (double)px, dy = (double)(int)(k >> 16) - (double)py;
             return (dist_t)(dx * dx + dy * dy);
@@ -432,8 +435,11 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             // (a squared distance between integer points is an integer: for the small ones the logarithm comes from a table
             //  built once per context with this very expression -- ~100 vector instructions per pixel less)
-            const double dsq = small_xy ? min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
-                                        : min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
+            // (the contour normally sits in LDS: passing the array itself -- not a pointer that may also be global -- turns the
+            //  descent's loads into ds_read instead of flat loads with 64-bit addresses)
+            const double dsq = !small_xy ? min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
+                             : K == s_K ? min_sqdist_v2<true>((int)xi, (int)yi, s_K, nK, step0, s_step, tab_n)
+                                        : min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
             const double lg = (small_xy && dsq < (double)A.log_tab_n) ? A.log_tab[(uint32_t)dsq] : log(sqrt(dsq) + 0.001);
             L[i] = lg;
             const double X = (double)xi, Y = (double)yi;
