@@ -186,7 +186,8 @@ struct DepArgs {
 // ---- contour + 2-D geometric moments (roi_moments.hip) -----------------------------------------
 constexpr int kMomCols = 90;              // per family: RM 13, CM 16, NRM 16, NCM 7, HU 7, WRM 10, WCM 7, WNCM 7, WHU 7
 constexpr int kMomStepTab = 2048;         // hill-descent step table (window width -> step)
-constexpr int kMomContourLds = 4096;      // contour points the moments kernel keeps in LDS (longer contours are read from HBM)
+constexpr int kMomContourLds = 2048;      // contour points the moments kernel keeps in LDS (longer contours are read from HBM)
+constexpr int kMomPxLds = 3072;           // ROI pixels (x | y << 16, intensity) the moments kernel keeps in LDS for its six sweeps
 
 constexpr int kContourWaves = 4;     // ROIs (waves) per workgroup of roi_contour_kernel
 

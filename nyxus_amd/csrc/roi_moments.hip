@@ -321,12 +321,19 @@ __device__ void hu7(double _02, double _03, double _11, double _12, double _20, 
 #ifndef NYX_MOM_OCC
 #define NYX_MOM_OCC 4
 #endif
+// diagnostic builds (-DNYX_MOM_EXIT_AT=k): the kernel ends after pass k (results are wrong by design)
+#ifdef NYX_MOM_EXIT_AT
+#define MSTAMP(k) do { if ((k) == NYX_MOM_EXIT_AT) return; } while (0)
+#else
+#define MSTAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const MomArgs A)
 {
     __shared__ double s_red[4 * 16];
     __shared__ double s_raw[2][16], s_cen[2][16], s_wraw[2][10], s_wcen[2][7];
     __shared__ uint32_t s_K[kMomContourLds];
     __shared__ uint16_t s_step[kMomStepTab];
+    __shared__ uint2 s_px[kMomPxLds];
     const int tid = threadIdx.x;
     const uint64_t roi = blockIdx.x;
     if (roi >= A.n_roi)
@@ -356,6 +363,25 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
     const int tab_n = min(kMomStepTab, 2 * step0 + 2);
     for (int m = 11 + tid; m < tab_n; m += kMB) s_step[m] = (uint16_t)(int)((double)m / log((double)m));
 
+    // The six sweeps below read the ROI's pixels again and again.  From HBM / L2 every sweep is a chain of dependent round
+    // trips (four waves per SIMD hide little of it: the sweeps took 3-4 ms each way); ROIs of up to kMomPxLds pixels are
+    // therefore staged in LDS once -- x | y << 16 and the intensity, 8 bytes per pixel -- and swept from there.
+    const bool staged = n <= (uint32_t)kMomPxLds;
+    if (staged)
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+            s_px[i] = make_uint2(xi | (yi << 16), vi);
+        });
+    __syncthreads();
+    auto sweep = [&](auto&& body) {                      // body(i, intensity, x, y) for this thread's pixels i = tid, tid + 256, ...
+        if (staged) {
+            for (uint32_t i = (uint32_t)tid; i < n; i += kMB) {
+                const uint2 q = s_px[i];
+                body(i, q.y, q.x & 0xFFFFu, q.x >> 16);
+            }
+        } else
+            for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, body);
+    };
+    MSTAMP(0);
     // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209);
     //      one sweep per variant (0 = shape, INTEN = 1; 1 = intensity): 16 accumulators stay in registers
     // (the kernel is bound by vector-instruction issue: a term I x^p y^q is (I x^p) -- four products per pixel -- times y^q,
@@ -367,7 +393,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
         if (var ? do_i : do_s)
-        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
+        sweep([&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double X = (double)xi, Y = (double)yi;
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
             if (var) {
@@ -391,6 +417,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         }
     }
     __syncthreads();
+    MSTAMP(1);
     // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316); each variant has its own origin
 #pragma unroll 1
     for (int var = 0; var < 2; var++) {
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[k] = 0;
         if (var ? do_i : do_s)
-        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
+        sweep([&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double dx = (double)xi - ox, dy = (double)yi - oy;
             const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
             if (var) {
@@ -423,6 +450,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         }
     }
     __syncthreads();
+    MSTAMP(2);
     // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
     constexpr int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
     constexpr int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
@@ -432,7 +460,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         double as[10], ai[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) { as[k] = 0; ai[k] = 0; }
-        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+        sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             // (a squared distance between integer points is an integer: for the small ones the logarithm comes from a table
             //  built once per context with this very expression -- ~100 vector instructions per pixel less)
             // (the contour normally sits in LDS: passing the array itself -- not a pointer that may also be global -- turns the
@@ -460,6 +488,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         }
     }
     __syncthreads();
+    MSTAMP(3);
     // ---- pass 4: weighted central moments about the weighted origin (:162-167, :318-327) -----------------------------------
     {
         const double oxs = s_wraw[0][4] / s_wraw[0][0], oys = s_wraw[0][1] / s_wraw[0][0];
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         double as[7], ai[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) { as[k] = 0; ai[k] = 0; }
-        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+        sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double X = (double)xi, Y = (double)yi, lg = L[i];
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             {
@@ -493,6 +522,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
         }
     }
     __syncthreads();
+    MSTAMP(4);
     // ---- derived values and output ------------------------------------------------------------------------------------------
     if (tid < 2 && (tid ? do_i : do_s)) {
         const int var = tid;
