@@ -466,7 +466,9 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         // distinct (level, size) pairs <= sqrt(2 * Ng * area) (sizes of one level sum to <= its area)
         double bound = sqrt(2.0 * (double)L.ng_cap * (double)L.dense_cap) + (double)L.ng_cap;
         uint32_t distinct = (uint32_t)std::min((double)L.dense_cap, bound) + 1;
-        L.hash_cap = pow2ceil(2 * distinct);
+        // (load <= 2/3 in the worst case; zones of up to 32 pixels bypass the hash altogether when the direct table exists.  With
+        //  2 * distinct the benchmark's carve-out was 4 KiB larger: six instead of seven workgroups per CU)
+        L.hash_cap = pow2ceil(distinct + distinct / 2 + 8);
         // zone sizes (16-bit entries, two per word, while a size fits), hash, zones per level; the owner-label plane only
         // exists for boxes wider than one wave (the DPP sweep of narrower boxes keeps labels in registers)
         L.szm_c16 = (!spill && L.dense_cap < 65535u) ? 1 : 0;

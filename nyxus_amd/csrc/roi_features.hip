@@ -577,8 +577,9 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     }
     const uint32_t l1 = (uint32_t)lane + 1u;
     const uint32_t csum = wave_sum_t<uint32_t>(rc);    // sum_p (glcm.cpp:481-484)
-    const uint32_t Sr_i = wave_sum_t<uint32_t>(rc * l1), Sc_i = wave_sum_t<uint32_t>(cc * l1);
-    const uint32_t con_i = wave_sum_t<uint32_t>(dc * (uint32_t)(lane * lane)), dis_i = wave_sum_t<uint32_t>(dc * (uint32_t)lane);
+    // (24-bit products: a plain 32-bit multiply issues at a quarter of the rate)
+    const uint32_t Sr_i = wave_sum_t<uint32_t>(mul24(rc, l1)), Sc_i = wave_sum_t<uint32_t>(mul24(cc, l1));
+    const uint32_t con_i = wave_sum_t<uint32_t>(mul24(dc, mul24((uint32_t)lane, (uint32_t)lane))), dis_i = wave_sum_t<uint32_t>(mul24(dc, (uint32_t)lane));
     const bool empty = csum == 0;
     const double sum_p = empty ? 1.0 : (double)csum;
     const double inv_sum_p = fdiv(1.0, sum_p);
@@ -618,8 +619,8 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
         const uint32_t cnt = act ? pcell[r * S] : 0u;
         const double pr = prow_s[r];
         rc1 += l1;                                                   // (r + 1) * (c + 1)
-        asm_i += cnt * cnt;                                          // f_asm :555 / f_energy :927-928
-        acor_i += cnt * rc1;                                         // f_GLCM_ACOR :961 (integer-exact)
+        asm_i = mad24(cnt, cnt, asm_i);                              // f_asm :555 / f_energy :927-928
+        acor_i = mad24(cnt, rc1, acor_i);                            // f_GLCM_ACOR :961 (integer-exact)
         cmax = cnt > cmax ? cnt : cmax;                              // f_GLCM_JMAX :1178-1179
         const double p = (double)cnt * inv_sum_p;
         double et = Tent[cnt < 15u ? cnt : 15u];
@@ -1931,21 +1932,28 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 const int r_begin = wave * rows_per_wave;
                 const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                 const bool in_col = lane < (int)w;
-                uint32_t cur = (in_col && r_begin < r_end) ? s_dense[(uint32_t)r_begin * w + lane] : 0u;
+                // (8-bit plane at LDS address 0 with 64 zero bytes behind its last row: a lane of the box walks its column, a lane
+                //  beyond the box keeps reading a zero byte, the row below the last row is the zero row -- no test per read;
+                //  24-bit products for the cell indices)
+                uint32_t adr = in_col ? (uint32_t)r_begin * w + (uint32_t)lane : area + (uint32_t)lane - w;
+                const uint32_t stride = in_col ? w : 0u;
+                uint32_t cur = r_begin < r_end ? (uint32_t)(*(const lds_u8_t*)adr) : 0u;
+                const uint32_t ng1 = (uint32_t)NG1;
                 for (int row = r_begin; row < r_end; row++) {
-                    const uint32_t nxt = (in_col && row + 1 < (int)h) ? s_dense[(uint32_t)(row + 1) * w + lane] : 0u;
+                    adr += stride;
+                    const uint32_t nxt = (uint32_t)(*(const lds_u8_t*)adr);
                     const uint32_t nb_e = lane_plus1_z(cur), nb_se = lane_plus1_z(nxt), nb_sw = lane_minus1_z(nxt);
                     if (cur != 0) {
-                        const uint32_t rowi = cur * (uint32_t)NG1;
+                        const uint32_t rowi = mul24(cur, ng1);
                         if (slot0 >= 0) bump16(s_P + slot0 * cellsw, rowi + nb_e);
                         if (slot1 >= 0) bump16(s_P + slot1 * cellsw, rowi + nb_se);
                         if (slot2 >= 0) bump16(s_P + slot2 * cellsw, rowi + nxt);
                         if (slot3 >= 0) bump16(s_P + slot3 * cellsw, rowi + nb_sw);
                         if (symmetric) {
-                            if (slot0 >= 0) bump16(s_P + slot0 * cellsw, nb_e * (uint32_t)NG1 + cur);
-                            if (slot1 >= 0) bump16(s_P + slot1 * cellsw, nb_se * (uint32_t)NG1 + cur);
-                            if (slot2 >= 0) bump16(s_P + slot2 * cellsw, nxt * (uint32_t)NG1 + cur);
-                            if (slot3 >= 0) bump16(s_P + slot3 * cellsw, nb_sw * (uint32_t)NG1 + cur);
+                            if (slot0 >= 0) bump16(s_P + slot0 * cellsw, mad24(nb_e, ng1, cur));
+                            if (slot1 >= 0) bump16(s_P + slot1 * cellsw, mad24(nb_se, ng1, cur));
+                            if (slot2 >= 0) bump16(s_P + slot2 * cellsw, mad24(nxt, ng1, cur));
+                            if (slot3 >= 0) bump16(s_P + slot3 * cellsw, mad24(nb_sw, ng1, cur));
                         }
                     }
                     cur = nxt;

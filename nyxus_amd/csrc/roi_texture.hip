@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
 
 static int tex_max_occ()   // diagnostic knob: NYXHIP_TEX_OCC=4 keeps the 106-register build
 {
-    static const int v = [] { const char* e = getenv("NYXHIP_TEX_OCC"); return e && *e ? atoi(e) : 6; }();
+    static const int v = [] { const char* e = getenv("NYXHIP_TEX_OCC"); return e && *e ? atoi(e) : 7; }();
     return v;
 }
 
@@ -876,6 +876,9 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)roi_features_max_lds());
         return (int)e;
     }))
         return orc;
@@ -883,6 +886,9 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
         return 0;
     if (a.sp.scratch)
         hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    // (LDS is handed out in 1280-byte granules: k workgroups share a CU when k rounded-up carve-outs fit)
+    else if (tex_max_occ() >= 7 && 7ull * (((size_t)a.L.total + 1279) / 1280 * 1280) <= roi_features_max_lds())
+        hipLaunchKernelGGL((roi_texture_kernel<false, 7>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     else if (tex_max_occ() >= 6 && 6ull * (a.L.total + 256) <= roi_features_max_lds())
         hipLaunchKernelGGL((roi_texture_kernel<false, 6>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     else
