@@ -449,9 +449,10 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     L.dense_cap = max_area ? max_area : 1;
     L.side_cap = max_side ? max_side : 1;
     if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    L.dense = off; off = align16(off + 2u * L.dense_cap + 4);
     L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
     if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the texture kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    L.dense8 = (!spill && L.lvl_cap <= 254) ? 1u : 0u;            // 8-bit plane (roi_texture_kernel<.., true>)
+    L.dense = off; off = align16(off + (L.dense8 ? 1u : 2u) * L.dense_cap + 4);
     L.ng_cap = L.lvl_cap + 1;
     L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
     L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));

@@ -190,7 +190,9 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
 // GS: scratch in the global workspace (large-ROI launches).  OCC: workgroups per CU the register budget is cut for -- the
 // serial stretches of this kernel (the GLSZM row sweep, the hash probes) are latency-bound, so when six carve-outs fit a
 // CU the 80-register build (a few spills) beats the 106-register one by 20-25 %.
-template <bool GS, int OCC>
+// D8: the binned plane holds 8-bit levels (grey depth <= 254, LDS launches): with it the benchmark's carve-out fits eight times
+// into a CU (the 64-register build).
+template <bool GS, int OCC, bool D8 = false>
 __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -202,7 +204,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     double* s_out = (double*)(lds + A.L.out);
     double* s_red = (double*)(lds + A.L.red);
     double* s_stat = (double*)(lds + A.L.stat);
-    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
+    using dense_t = typename std::conditional<D8, uint8_t, uint16_t>::type;
+    dense_t* s_dense = (dense_t*)(lds + A.L.dense);
     uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);   // level -> row index + 1
     uint32_t* s_lv = (uint32_t*)(lds + A.L.lv);           // row index -> level value
     unsigned char* s_work = lds + A.L.work;                // per-family scratch (aliased)
@@ -237,9 +240,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     for (int c = tid; c < A.n_cols; c += kBlock)
         s_out[c] = 0.0;
     {
-        const uint32_t bg = greyInfo > 0 ? 0x00010001u : 0u;
+        const uint32_t bg = greyInfo > 0 ? (D8 ? 0x01010101u : 0x00010001u) : 0u;
         uint32_t* d32 = (uint32_t*)s_dense;
-        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlock)
+        for (uint32_t i = tid; i < (D8 ? (area + 3) / 4 : (area + 1) / 2); i += kBlock)
             d32[i] = bg;
         for (uint32_t i = tid; i <= Lcap + 1; i += kBlock)
             s_lvlmap[i] = 0;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         nz_orig += v != 0;
         if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
         if (px < w && py < h)
-            s_dense[__umul24(py, w) + px] = (uint16_t)lvl;
+            s_dense[__umul24(py, w) + px] = (dense_t)lvl;
     });
     nz_orig = (uint32_t)wave_sum_u64(nz_orig);
     lvl_over = wave_max_u32(lvl_over);
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
 
 static int tex_max_occ()   // diagnostic knob: NYXHIP_TEX_OCC=4 keeps the 106-register build
 {
-    static const int v = [] { const char* e = getenv("NYXHIP_TEX_OCC"); return e && *e ? atoi(e) : 7; }();
+    static const int v = [] { const char* e = getenv("NYXHIP_TEX_OCC"); return e && *e ? atoi(e) : 8; }();
     return v;
 }
 
@@ -879,6 +882,12 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_texture_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)roi_features_max_lds());
         return (int)e;
     }))
         return orc;
@@ -887,6 +896,10 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
     if (a.sp.scratch)
         hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     // (LDS is handed out in 1280-byte granules: k workgroups share a CU when k rounded-up carve-outs fit)
+    else if (a.L.dense8 && tex_max_occ() >= 8 && 8ull * (((size_t)a.L.total + 1279) / 1280 * 1280) <= roi_features_max_lds())
+        hipLaunchKernelGGL((roi_texture_kernel<false, 8, true>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
+    else if (a.L.dense8)
+        hipLaunchKernelGGL((roi_texture_kernel<false, 7, true>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     else if (tex_max_occ() >= 7 && 7ull * (((size_t)a.L.total + 1279) / 1280 * 1280) <= roi_features_max_lds())
         hipLaunchKernelGGL((roi_texture_kernel<false, 7>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
     else if (tex_max_occ() >= 6 && 6ull * (a.L.total + 256) <= roi_features_max_lds())
