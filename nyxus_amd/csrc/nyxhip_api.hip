@@ -514,10 +514,11 @@ int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, 
     L.dense_cap = max_area ? max_area : 1;
     L.side_cap = max_side ? max_side : 1;
     if (4ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    L.dense = off; off = align16(off + 2u * L.dense_cap + 4);
-    L.aux = off; off = align16(off + 2u * L.dense_cap + 4);
     L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
     if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the dependence kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    L.planes8 = (cap == roi_features_max_lds() && L.lvl_cap <= 63) ? 1u : 0u;   // byte planes: level + two flags fit 8 bits
+    L.dense = off; off = align16(off + (L.planes8 ? 1u : 2u) * L.dense_cap + 4);
+    L.aux = off; off = align16(off + (L.planes8 ? 1u : 2u) * L.dense_cap + 4);
     L.ng_cap = L.lvl_cap + 1;
     L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
     L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));

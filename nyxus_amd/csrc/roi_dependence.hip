@@ -31,13 +31,18 @@ __device__ __forceinline__ double plog_dep(double p)   // p * fast_log10(p + EPS
     return p * (double)fast_log2f(p + 2.2e-16);
 }
 
-constexpr uint16_t kInCloud = 0x4000, kOrigNZ = 0x8000, kLvlMask = 0x0FFF;
+// flags and level field of the auxiliary plane; P8 = both planes hold bytes (levels <= 63: 6 bits + 2 flags)
+template <bool P8> struct AuxBits { static constexpr uint32_t kInCloud = 0x4000, kOrigNZ = 0x8000, kLvlMask = 0x0FFF; };
+template <> struct AuxBits<true> { static constexpr uint32_t kInCloud = 0x40, kOrigNZ = 0x80, kLvlMask = 0x3F; };
 
 } // namespace
 
-template <bool GS>
+// P8: 8-bit planes (grey depth <= 63, LDS launches): 7.4 KB less LDS for the benchmark ROI -- six workgroups per CU instead of five.
+template <bool GS, bool P8 = false>
 __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
 {
+    constexpr uint32_t kInCloud = AuxBits<P8>::kInCloud, kOrigNZ = AuxBits<P8>::kOrigNZ, kLvlMask = AuxBits<P8>::kLvlMask;
+    using plane_t = typename std::conditional<P8, uint8_t, uint16_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,8 +53,8 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         return;
     double* s_red = (double*)(lds + A.L.red);
     double* s_stat = (double*)(lds + A.L.stat);
-    uint16_t* s_dense = (uint16_t*)(lds + A.L.dense);
-    uint16_t* s_aux = (uint16_t*)(lds + A.L.aux);
+    plane_t* s_dense = (plane_t*)(lds + A.L.dense);
+    plane_t* s_aux = (plane_t*)(lds + A.L.aux);
     uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);    // binned level -> row + 1   (GLDM, GLDZM)
     uint32_t* s_lv = (uint32_t*)(lds + A.L.lv);            // row -> level
     uint16_t* s_lvlmap2 = (uint16_t*)(lds + A.L.lvlmap2);  // NGLDM level -> row + 1
@@ -87,10 +92,10 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
 
     // ---- phase 0: planes ------------------------------------------------------------------------------------
     {
-        const uint32_t bg = greyInfo > 0 ? 0x00010001u : 0u;   // matlab binning: background -> level 1 (texture_feature.h:150-154)
+        const uint32_t bg = greyInfo > 0 ? (P8 ? 0x01010101u : 0x00010001u) : 0u;   // matlab binning: background -> level 1 (texture_feature.h:150-154)
         uint32_t* d32 = (uint32_t*)s_dense;
         uint32_t* a32 = (uint32_t*)s_aux;
-        for (uint32_t i = tid; i < (area + 1) / 2; i += kBlk) { d32[i] = bg; a32[i] = 0; }
+        for (uint32_t i = tid; i < (P8 ? (area + 3) / 4 : (area + 1) / 2); i += kBlk) { d32[i] = bg; a32[i] = 0; }
         for (uint32_t i = tid; i <= Lcap + 1; i += kBlk) { s_lvlmap[i] = 0; s_lvlmap2[i] = 0; }
     }
     blk_sync<GS>();
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
         if (nl > Lcap || nl > kLvlMask) { if (do_ng) lvl_over = 1; nl = 0; }
         if (px < w && py < h) {
-            s_dense[py * w + px] = (uint16_t)lvl;
-            s_aux[py * w + px] = (uint16_t)(kInCloud | (v != 0 ? kOrigNZ : 0) | nl);
+            s_dense[py * w + px] = (plane_t)lvl;
+            s_aux[py * w + px] = (plane_t)(kInCloud | (v != 0 ? kOrigNZ : 0) | nl);
             s_lvlmap2[nl] = 1;
         }
     });
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 const uint32_t x = x0 + lane;
                 const bool in = x < w;
                 const uint32_t p = y * w + (in ? x : 0);
-                const uint16_t v = in ? s_dense[p] : (uint16_t)0;
+                const uint32_t v = in ? (uint32_t)s_dense[p] : 0u;
                 const bool starts = in && (x == 0 || s_dense[p - 1] != v);
                 const unsigned long long m = __ballot(starts);
                 const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
         RowCol rc_v(w + (uint32_t)tid, kBlk, w);
         for (uint32_t p = w + tid; p < area; p += kBlk, rc_v.advance()) {
             if (s_label[p] == kNone) continue;
-            const uint16_t v = s_dense[p];
+            const uint32_t v = s_dense[p];
             if (s_dense[p - w] != v) continue;
             const uint32_t x = rc_v.col;
             if (x > 0 && s_dense[p - 1] == v && s_dense[p - w - 1] == v) continue;
@@ -639,14 +644,20 @@ int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid)
 {
     static DeviceOnce optin;
     if (int orc = optin.run([]() -> int {
-        return (int)hipFuncSetAttribute((const void*)roi_dependence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)roi_features_max_lds());
+        hipError_t e = hipFuncSetAttribute((const void*)roi_dependence_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)roi_features_max_lds());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)roi_dependence_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)roi_features_max_lds());
+        return (int)e;
     }))
         return orc;
     if (grid == 0)
         return 0;
     if (a.sp.scratch)
         hipLaunchKernelGGL(roi_dependence_kernel<true>, dim3(grid), dim3(kBlk), 0, (hipStream_t)stream, a);
+    else if (a.L.planes8)
+        hipLaunchKernelGGL((roi_dependence_kernel<false, true>), dim3(grid), dim3(kBlk), a.L.total, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(roi_dependence_kernel<false>, dim3(grid), dim3(kBlk), a.L.total, (hipStream_t)stream, a);
     return (int)hipGetLastError();

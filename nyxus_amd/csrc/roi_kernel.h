@@ -161,6 +161,7 @@ struct DepLayout {
     uint32_t par;       // 1: the GLDM / NGLDM matrices have places of their own inside `work` (off_pdm, off_m), so the three feature
                         // tails run side by side on three waves at the end of the kernel instead of one after the other on one wave
     uint32_t off_pdm, off_m;
+    uint32_t planes8;   // 1: both planes hold bytes (grey depth <= 63, LDS launches): roi_dependence_kernel<false, true>
 };
 
 struct DepArgs {
