@@ -442,6 +442,24 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
                 a = old;                                                // somebody re-parented a first: retry from there
             }
         };
+        if (w <= 64) {
+            // boxes up to a wave wide: lane = column, a block of rows per wave, the row above in a register and the west pair
+            // through DPP lane shifts -- one plane read per pixel instead of a label read and up to four plane reads
+            // (a pixel has a label unless it is an IBSI zero: s_label[p] != kNone <=> greyInfo > 0 || v != 0)
+            const uint32_t rows_pw = (h + kBlk / 64 - 1) / (kBlk / 64);
+            const uint32_t r_begin = (uint32_t)wave * rows_pw > 1u ? (uint32_t)wave * rows_pw : 1u;
+            const uint32_t r_end = ((uint32_t)wave + 1u) * rows_pw < h ? ((uint32_t)wave + 1u) * rows_pw : h;
+            const bool in_col = (uint32_t)lane < w;
+            uint32_t up = (in_col && r_begin < r_end) ? (uint32_t)s_dense[(r_begin - 1) * w + (uint32_t)lane] : 0xFFFFFFFFu;
+            for (uint32_t y = r_begin; y < r_end; y++) {
+                const uint32_t p = y * w + (uint32_t)lane;
+                const uint32_t v = in_col ? (uint32_t)s_dense[p] : 0xFFFFFFFEu;
+                const uint32_t vw = lane_minus1(v, 0xFFFFFFFDu), upw = lane_minus1(up, 0xFFFFFFFCu);
+                if (in_col && (greyInfo > 0 || v != 0) && up == v && !(vw == v && upw == v))
+                    unite(p, p - w);
+                up = v;
+            }
+        } else {
         RowCol rc_v(w + (uint32_t)tid, kBlk, w);
         for (uint32_t p = w + tid; p < area; p += kBlk, rc_v.advance()) {
             if (s_label[p] == kNone) continue;
@@ -450,6 +468,7 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             const uint32_t x = rc_v.col;
             if (x > 0 && s_dense[p - 1] == v && s_dense[p - w - 1] == v) continue;
             unite(p, p - w);
+        }
         }
         blk_sync<GS>();
         for (uint32_t p = tid; p < area; p += kBlk)
