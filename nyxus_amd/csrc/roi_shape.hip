@@ -380,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     // moments carry a 1e-5 tolerance).  Everything that DECIDES something -- x, y, r and the unit-disc test -- keeps the
     // reference's exact divisions.
     const double inv_sum_pi = 1.0 / (sum * 3.14159265358979323846);
+    const double inv_rad = 1.0 / rad;
 
     double AR[kZL + 1][kZL + 1], AI[kZL + 1][kZL + 1];
 #pragma unroll
@@ -391,9 +392,17 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
         uint32_t xi, yi, vi;
         if (staged) { const uint32_t xy = s_xy[i]; xi = xy & 0xFFFFu; yi = xy >> 16; vi = s_v[i]; }
         else { xi = A.x[off + i]; yi = A.y[off + i]; vi = A.inten[off + i]; }
-        const double x = ((double)((int)xi + 1) - m10_m00) / rad;   // :254
-        const double y = ((double)((int)yi + 1) - m01_m00) / rad;   // :262
-        const double r2 = x * x + y * y, r = sqrt(r2);
+        // x, y, r (:254, :262) decide one thing: whether the pixel lies in the unit disc.  They are formed with a reciprocal of the
+        // radius and a reciprocal square root (1-2 ulp from the reference's two divisions and its sqrt; the moments carry a 1e-5
+        // tolerance); a pixel within 1e-12 of either edge of the test is redone with the reference's exact operations, so the
+        // decision -- the only discontinuous step -- is the reference's in every case.
+        const double dxp = (double)((int)xi + 1) - m10_m00, dyp = (double)((int)yi + 1) - m01_m00;
+        double x = dxp * inv_rad, y = dyp * inv_rad;
+        double r2 = x * x + y * y, inv_r = frsq(r2), r = r2 * inv_r;
+        if (!(r >= 1e-12) || fabs(r - 1.0) < 1e-12) {
+            x = dxp / rad; y = dyp / rad;
+            r2 = x * x + y * y; r = sqrt(r2); inv_r = 1.0 / r;
+        }
         if (r < 2.2204460492503131e-16 || r > 1.0)
             continue;
         double R[kZL + 1], COST[kZL + 1], SINT[kZL + 1];
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
         for (int n = 1; n <= kZL; n++) R[n] = r * R[n - 1];
         {   // from here on nothing decides anything: products feed sums directly (contraction allowed, 1e-5 tolerance)
 #pragma clang fp contract(fast)
-        const double inv_r = 1.0 / r, inv_r2 = inv_r * inv_r;
+        const double inv_r2 = inv_r * inv_r;
         const double a = x * inv_r, b = y * inv_r;
         COST[0] = a; SINT[0] = b;
 #pragma unroll
