@@ -512,24 +512,25 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     if (live && l == 0) {
         const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
         const double asm_t = big ? asm_d : (double)asm_i * inv_sum_p * inv_sum_p;
-        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
+        // (quotients by sum_p as products with its reciprocal; the correlation's sqrt(a) sqrt(b) denominator as one reciprocal root)
+        const double cov_t = ((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i) * (inv_sum_p * inv_sum_p);   // sum (r - mr)(c - mc) p, exact numerator
         f[G_ASM] = asm_t;
         f[G_ENERGY] = asm_t;
-        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
-        f[G_ACOR] = fdiv((double)acor_i, sum_p);
+        f[G_CONTRAST] = (double)con_i * inv_sum_p;
+        f[G_ACOR] = (double)acor_i * inv_sum_p;
         f[G_ENTROPY] = -ent_t;
         f[G_JE] = -ent_t;
-        f[G_DIS] = fdiv((double)dis_i, sum_p);
+        f[G_DIS] = (double)dis_i * inv_sum_p;
         f[G_JMAX] = (double)cmax * inv_sum_p;
         f[G_JAVE] = mr;
-        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
+        f[G_VARIANCE] = sm[8 + 2] * inv_sum_p;
         f[G_CLUPROM] = sm[8 + 13];
         f[G_CLUSHADE] = sm[8 + 14];
         f[G_CLUTEND] = sm[8 + 15];
         f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
         f[G_JVAR] = sm[8 + 3];
-        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
-        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
+        const double vv = sm[8 + 0] * sm[8 + 1];                      // f_corr tail, glcm.cpp:619-643: cov / (sqrt(var_r) sqrt(var_c))
+        f[G_CORRELATION] = !(sm[8 + 0] > 0.0 && sm[8 + 1] > 0.0) ? soft_nan : cov_t * frsq(vv);
         f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
         f[G_IDM] = sm[8 + 4];
         f[G_HOM2] = sm[8 + 4];                        // f_GLCM_HOM2 :1069 == f_idm over p_{x-y}
@@ -1170,8 +1171,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             return (realIdx != realIdx) ? 0 : (int)realIdx;
         };
 
-        // Q = entries of the counting table scanned per wave (multiple of 256)
-        const uint32_t Q = ((range + 1 + kWaves * 256 - 1) / (kWaves * 256)) * 256;
+        // Q = entries of the counting table scanned per wave (multiple of 512: the 16-bit scan takes eight entries per lane and step)
+        const uint32_t Q = ((range + 1 + kWaves * 512 - 1) / (kWaves * 512)) * 512;
         uint32_t* const s_woff = (uint32_t*)(s_stat + 8);   // [4] prefix offsets of the waves' table quarters (kept in LDS: as
                                                             // registers they were live across the whole intensity block and spilled)
         if (use_count) {
@@ -1187,32 +1188,39 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 //   A = x + (x << 16) = (c0, c0+c1),  B likewise for (c2, c3),  lane total T = (A + B) >> 16;
                 //   the scanned totals are replicated into both halves and added to A and B in one instruction each.
                 // Mode: key = count << 16 | (0xFFFF - index) -- the largest key is the largest count and, among equals, the smallest
-                // index (an index is < 16384 here).  Four running maxima, one per entry of the lane, share the lane's base index;
-                // the 1, 2, 3 they are off by are subtracted once after the loop.
-                uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-                uint32_t inv = 0xFFFFu - (base + 4u * (uint32_t)lane);
-                const uint2* src = (const uint2*)((const uint16_t*)s_cnt + base + 4u * (uint32_t)lane);
-                uint32_t i = base + 4u * (uint32_t)lane;
-                for (uint32_t t = 0; t < Q; t += 256, i += 256, inv -= 256, src += 64) {
-                    uint2 pk = make_uint2(0, 0);
+                // index (an index is < 16384 here).  Eight running maxima, one per entry of the lane, share the lane's base index;
+                // the 1 .. 7 they are off by are subtracted once after the loop.
+                // Eight entries (four words, one 16-byte access) per lane and step: the six-step wave scan and the loop bookkeeping
+                // are paid once per 512 entries.  Word k holds (c_2k, c_2k+1); A_k = w + (w << 16) = (c_2k, c_2k + c_2k+1); the
+                // lane total is the high half of A_0 + .. + A_3; output word k = A_k + (everything before it, in both halves),
+                // and "everything before word k" is the high half of output word k - 1, broadcast by one v_perm.
+                uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t inv = 0xFFFFu - (base + 8u * (uint32_t)lane);
+                uint4* src = (uint4*)((uint16_t*)s_cnt + base + 8u * (uint32_t)lane);
+                uint32_t i = base + 8u * (uint32_t)lane;
+                for (uint32_t t = 0; t < Q; t += 512, i += 512, inv -= 512, src += 64) {
+                    uint4 pk = make_uint4(0, 0, 0, 0);
                     const bool live = i <= range;
                     if (live) pk = *src;
-                    k0 = max(k0, (pk.x << 16) | inv);
-                    k1 = max(k1, (pk.x & 0xFFFF0000u) | inv);
-                    k2 = max(k2, (pk.y << 16) | inv);
-                    k3 = max(k3, (pk.y & 0xFFFF0000u) | inv);
-                    const uint32_t Apk = pk.x + (pk.x << 16), Bpk = pk.y + (pk.y << 16);
-                    const uint32_t T = (Apk + Bpk) >> 16;
+                    kk[0] = max(kk[0], (pk.x << 16) | inv); kk[1] = max(kk[1], (pk.x & 0xFFFF0000u) | inv);
+                    kk[2] = max(kk[2], (pk.y << 16) | inv); kk[3] = max(kk[3], (pk.y & 0xFFFF0000u) | inv);
+                    kk[4] = max(kk[4], (pk.z << 16) | inv); kk[5] = max(kk[5], (pk.z & 0xFFFF0000u) | inv);
+                    kk[6] = max(kk[6], (pk.w << 16) | inv); kk[7] = max(kk[7], (pk.w & 0xFFFF0000u) | inv);
+                    const uint32_t A0 = pk.x + (pk.x << 16), A1 = pk.y + (pk.y << 16), A2 = pk.z + (pk.z << 16), A3 = pk.w + (pk.w << 16);
+                    const uint32_t T = ((A0 + A1) + (A2 + A3)) >> 16;
                     const uint32_t sc = wave_scan_u32(T);
                     const uint32_t excl = carry + sc - T;
-                    const uint32_t E = excl | (excl << 16);
-                    const uint32_t Ah = __builtin_amdgcn_perm(Apk, Apk, 0x03020302u);     // (A.hi, A.hi)
+                    const uint32_t o0 = A0 + (excl | (excl << 16));
+                    const uint32_t o1 = A1 + __builtin_amdgcn_perm(o0, o0, 0x03020302u);
+                    const uint32_t o2 = A2 + __builtin_amdgcn_perm(o1, o1, 0x03020302u);
+                    const uint32_t o3 = A3 + __builtin_amdgcn_perm(o2, o2, 0x03020302u);
                     if (live)
-                        *(uint2*)src = make_uint2(Apk + E, Bpk + E + Ah);
+                        *src = make_uint4(o0, o1, o2, o3);
                     carry += readlane63(sc);
                 }
-                k1 -= 1; k2 -= 2; k3 -= 3;                 // (a key with count 0 never wins: the ROI has a pixel)
-                const uint32_t key = wave_max_u32(max(max(k0, k1), max(k2, k3)));
+#pragma unroll
+                for (int q = 1; q < 8; q++) kk[q] -= (uint32_t)q;      // (a key with count 0 never wins: the ROI has a pixel)
+                const uint32_t key = wave_max_u32(max(max(max(kk[0], kk[1]), max(kk[2], kk[3])), max(max(kk[4], kk[5]), max(kk[6], kk[7]))));
                 best_c = key >> 16;
                 best_i = 0xFFFFu - (key & 0xFFFFu);
             } else
@@ -1583,8 +1591,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // runs on the scalar unit and costs no vector instruction per value
                 const uint16_t* const pv = (const uint16_t*)s_val + tid;
                 const uint32_t n_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n / kBlock)), n_rem = n - n_full * kBlock;
-                for (uint32_t k = 0; k < n_full; k++)
-                    px1(pv[k * kBlock]);
+                {   // (two values per trip: the second read sits at an immediate offset of the first, one address update per pair)
+                    uint32_t k = 0;
+                    for (; k + 1 < n_full; k += 2) { px1(pv[k * kBlock]); px1(pv[(k + 1) * kBlock]); }
+                    if (k < n_full) px1(pv[k * kBlock]);
+                }
                 if ((uint32_t)tid < n_rem)
                     px1(pv[n_full * kBlock]);
                 // workgroup totals: the two integer sums through 32-bit DPP wave sums (slots 6, 7 of the exchange area), the six
@@ -1641,8 +1652,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         const uint32_t t = mul_u24_su(med3_u32_ss(x, lox, hix), Ku);      // < 2^30
                         asm("v_sad_u32 %0, %1, %2, %0" : "+v"(ad) : "v"(t), "s"(Sxu));
                     };
-                    for (uint32_t k = 0; k < n_full; k++)
-                        px2(pv[k * kBlock]);
+                    {
+                        uint32_t k = 0;
+                        for (; k + 1 < n_full; k += 2) { px2(pv[k * kBlock]); px2(pv[(k + 1) * kBlock]); }
+                        if (k < n_full) px2(pv[k * kBlock]);
+                    }
                     if ((uint32_t)tid < n_rem)
                         px2(pv[n_full * kBlock]);
                     ad1[0] = (double)ad;
