@@ -562,18 +562,38 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
 {
     const int S = Ng + 1;
     const bool act = lane < Ng;                        // lane l owns column l, row l and the diagonal pair |x - y| = l
+    // ---- marginal counts in ONE pass over the rows (lane = column): the column sums accumulate in place, and the two families of
+    // diagonals ride along in registers that move one lane per row -- W(lane) holds the partial sum of the diagonal through
+    // (r, lane) (index c - r, shifts right), X(lane) that of the anti-diagonal (index r + c, shifts left).  A diagonal is
+    // complete when it leaves the matrix: upper diagonals (c - r = d >= 0) end in lane Ng - 1 at row Ng - 1 - d, anti-diagonals
+    // k <= Ng - 2 end in lane 0 at row k; each is picked off with a v_readlane and a select into the lane that owns it.
+    // What is still travelling after the last row -- the lower diagonals in W, the anti-diagonals k >= Ng - 1 in X -- is fetched
+    // with one ds_bpermute each.  ~10 vector instructions per row instead of three per-lane walks over the matrix (1.3 k -> 0.8 k).
     uint32_t cc = 0, rc = 0, dc = 0;
-    if (act) {
-        const uint16_t* pc = P + S + lane + 1;         // (row 1, column lane + 1)
-        const uint16_t* pr = P + (lane + 1) * S + 1;   // (row lane + 1, column 1)
-        for (int j = 0; j < Ng; j++) {
-            cc += pc[j * S];
-            rc += pr[j];
+    uint32_t pxpy_c[2] = {0u, 0u};                     // counts of p_{x+y}: k = lane and k = lane + 64
+    {
+        uint32_t W = 0, X = 0, eup = 0, dlo = 0;
+        const uint16_t* pcol_cells = P + S + lane + 1; // (row 1, column lane + 1)
+        for (int r = 0; r < Ng; r++) {
+            const uint32_t cnt = act ? pcol_cells[r * S] : 0u;
+            cc += cnt;
+            if (r >= 1)                                // anti-diagonal r - 1 is complete in lane 0 (before this row's shift)
+                dlo = lane == r - 1 ? (uint32_t)__builtin_amdgcn_readlane((int)X, 0) : dlo;
+            X = lane_plus1_z(X) + cnt;
+            W = lane_minus1_z(W) + cnt;
+            eup = lane == Ng - 1 - r ? (uint32_t)__builtin_amdgcn_readlane((int)W, Ng - 1) : eup;                     // upper diagonal Ng - 1 - r
         }
-        for (int x = lane; x < Ng; x++) {
-            dc += P[(x + 1) * S + (x - lane) + 1];
-            if (lane > 0)
-                dc += P[(x - lane + 1) * S + x + 1];
+        // lower diagonal d (>= 1) waits in lane Ng - 1 - d of W; anti-diagonal k >= Ng - 1 in lane k - (Ng - 1) of X
+        const uint32_t wrev = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (Ng - 1 - lane), (int)W);
+        dc = act ? eup + (lane >= 1 ? wrev : 0u) : 0u;
+        const int k0 = lane, k1 = lane + 64;
+        const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (k0 - (Ng - 1)), (int)X);
+        const uint32_t xb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (k1 - (Ng - 1)), (int)X);
+        pxpy_c[0] = k0 < Ng - 1 ? dlo : (k0 <= 2 * Ng - 2 ? xa : 0u);
+        pxpy_c[1] = k1 <= 2 * Ng - 2 ? xb : 0u;       // (k1 >= 64 > Ng - 2: always in X)
+        if (act) {                                     // row sums: lane = row, a walk along the row
+            const uint16_t* pr = P + (lane + 1) * S + 1;
+            for (int j = 0; j < Ng; j++) rc += pr[j];
         }
     }
     const uint32_t l1 = (uint32_t)lane + 1u;
@@ -587,19 +607,11 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
     const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
     if (act) prow_s[lane] = prow;
-    // p_{x+y}: lane k owns k and k + 64 (k <= 2 Ng - 2)
+    // p_{x+y}: lane k owns k and k + 64 (k <= 2 Ng - 2); the counts were gathered by the pass above
     double pxpy[2] = {0.0, 0.0};
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int k = lane + 64 * u;
-        if (k < 2 * Ng - 1) {
-            uint32_t c = 0;
-            const int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
-            for (int x = x0; x <= x1; x++)
-                c += P[(x + 1) * S + (k - x) + 1];
-            pxpy[u] = fdiv((double)c, sum_p);
-        }
-    }
+    for (int u = 0; u < 2; u++)
+        if (lane + 64 * u < 2 * Ng - 1) pxpy[u] = fdiv((double)pxpy_c[u], sum_p);
     wav_sync<false>();
 
     // ---- the cell pass: lane = column, rows in sequence ------------------------------------------------------------------------
