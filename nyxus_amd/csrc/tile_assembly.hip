@@ -45,7 +45,13 @@ __device__ __forceinline__ uint32_t wave_max_u32_x(uint32_t v)
 // the statistics of its current label run in registers (ROIs are compact: a column crosses a ROI once).  Runs
 // are merged in an LDS hash table keyed by label, and only the table's few live entries go to the tile's global
 // table: ~7 global atomics per (ROI, block) instead of per (ROI, row segment).
-constexpr int kScanCols = 256, kScanRows = 32, kScanCap = 512, kScanProbes = 32;
+#ifndef NYX_SCAN_BATCH
+#define NYX_SCAN_BATCH 8
+#endif
+#ifndef NYX_SCAN_ROWS
+#define NYX_SCAN_ROWS 32
+#endif
+constexpr int kScanCols = 256, kScanRows = NYX_SCAN_ROWS, kScanCap = 512, kScanProbes = 32;
 
 template <typename TI, typename TL>
 __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const TI* __restrict__ inten, const TL* __restrict__ label, uint32_t W, uint32_t H,
@@ -102,17 +108,18 @@ __global__ __launch_bounds__(kScanCols) void tile_scan_kernel(const TI* __restri
     if (x < W) {
         const uint64_t col = ((uint64_t)tile * H) * W + x;
         uint32_t cur = 0, cnt = 0, mn = 0xFFFFFFFFu, mx = 0, y0 = 0, y1 = 0;
-        for (uint32_t yb = y_begin; yb < y_end; yb += 8) {
-            uint32_t l[8], v[8];
+        constexpr int kB = NYX_SCAN_BATCH;
+        for (uint32_t yb = y_begin; yb < y_end; yb += kB) {
+            uint32_t l[kB], v[kB];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {                // all loads of the batch in flight before first use
+            for (int k = 0; k < kB; k++) {               // all loads of the batch in flight before first use
                 const uint32_t y = yb + k;
                 const bool in = y < y_end;
                 l[k] = in ? (uint32_t)label[col + (uint64_t)y * W] : 0u;
                 v[k] = in ? (uint32_t)inten[col + (uint64_t)y * W] : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < kB; k++) {
                 const uint32_t y = yb + k;
                 if (l[k] != cur) {
                     if (cur) flush(cur, cnt, mn, mx, y0, y1);
