@@ -36,6 +36,12 @@ __device__ __forceinline__ int dial_pos(int dx, int dy)     // contour.cpp:218-2
 
 } // namespace
 
+// diagnostic builds (-DNYX_CON_EXIT_AT=k): the contour kernel ends after phase k (results are wrong by design)
+#ifdef NYX_CON_EXIT_AT
+#define CSTAMP(k) do { if ((k) == NYX_CON_EXIT_AT) return; } while (0)
+#else
+#define CSTAMP(k) do { } while (0)
+#endif
 template <bool GS>
 __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const MomArgs A)
 {
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
     });
     wav_sync<GS>();
 
+    CSTAMP(0);
     // ---- border image: raster scan with the inside / outside state + Moore trace (contour.cpp:395-493) ----------------
     // The scan's `inside` flag is false after every blank position, so it only lives inside a horizontal run of pixels:
     // at the run's first pixel the scan is outside; a border mark switches it inside for the rest of the run, an unmarked
@@ -120,8 +127,37 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
             wav_sync<GS>();
         }
     }
+    CSTAMP(1);
     // ---- candidates: border pixels with a border neighbour, bounds as written (:509-552) -----------------------------
-    uint32_t n_cand = 0;
+    uint32_t n_cand = 0, n_x = 0;
+    if (W2 <= 64) {
+        // planes up to a wave wide: a row per step, lane = padded column; the border flags of the rows above / below travel in
+        // registers and the horizontal neighbours come through DPP lane shifts (one plane read and one plane write per row
+        // instead of an integer division and up to eight reads per position).  The reference's bounds are kept as written:
+        // the neighbour tests use the UNPADDED sizes on padded coordinates (xx < w - 1, yy < h - 1).
+        const bool in_row = lane < W2;
+        const uint32_t gx0 = lane > 0 ? 1u : 0u, gx1 = lane < w - 1 ? 1u : 0u;
+        auto row_byte = [&](int yy) -> uint32_t { return (in_row && yy < H2) ? (uint32_t)img[(uint32_t)yy * (uint32_t)W2 + (uint32_t)lane] : 0u; };
+        uint32_t v_cur = row_byte(0), v_next = row_byte(1);
+        uint32_t b_prev = 0, b_cur = (v_cur >> 1) & 1u;                    // kBorder = 2
+        uint32_t c_prev2 = 0, c_prev = 0;                                 // candidate flags of rows yy - 2, yy - 1
+        for (int yy = 0; yy < H2; yy++) {
+            const uint32_t b_next = (v_next >> 1) & 1u;
+            const uint32_t gy0 = yy > 0 ? 1u : 0u, gy1 = yy < h - 1 ? 1u : 0u;
+            const uint32_t up = gy0 & b_prev, dn = gy1 & b_next;          // (a row guard applies to the whole row: folded into the row's flags)
+            const uint32_t has = (gx0 & (lane_minus1(b_cur, 0u) | lane_minus1(up, 0u) | lane_minus1(dn, 0u))) |
+                                 (gx1 & (lane_plus1(b_cur, 0u) | lane_plus1(up, 0u) | lane_plus1(dn, 0u))) | up | dn;
+            const uint32_t c_cur = b_cur & has;
+            if (c_cur) img[(uint32_t)yy * (uint32_t)W2 + (uint32_t)lane] = (uint8_t)(v_cur | kCand | kAlive);
+            n_cand += c_cur;
+            // X-crossing count (:566-585) of row yy - 1, whose three candidate rows are known now (rows 1 .. H2 - 2 qualify)
+            if (yy >= 2)
+                n_x += c_prev & c_prev2 & c_cur & lane_minus1(c_prev, 0u) & lane_plus1(c_prev, 0u);
+            c_prev2 = c_prev; c_prev = c_cur;
+            b_prev = b_cur; b_cur = b_next; v_cur = v_next; v_next = row_byte(yy + 2);
+        }
+        wav_sync<GS>();
+    } else {
     for (uint32_t p = lane; p < np; p += 64) {
         if (!(img[p] & kBorder)) continue;
         const int yy = (int)(p / (uint32_t)W2), xx = (int)(p - (uint32_t)yy * (uint32_t)W2);
@@ -138,12 +174,13 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         if (has) { img[p] |= (uint8_t)(kCand | kAlive); n_cand++; }
     }
     wav_sync<GS>();
+    CSTAMP(2);
     // ---- X-crossing fix (:566-585): a candidate whose N, S, W, E are all still in the list leaves it; raster order matters
-    uint32_t n_x = 0;
     for (uint32_t p = lane; p < np; p += 64)
         if ((img[p] & kCand) && p >= (uint32_t)W2 && p + (uint32_t)W2 < np && (img[p - W2] & kCand) && (img[p + W2] & kCand) && (img[p - 1] & kCand) &&
             (img[p + 1] & kCand))
             n_x++;
+    }
     n_cand = (uint32_t)wave_sum_u64(n_cand);
     n_x = (uint32_t)wave_sum_u64(n_x);
     n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_cand);
@@ -159,6 +196,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_u);
         wav_sync<GS>();
     }
+    CSTAMP(3);
     // ---- contour by contour (:587-619) with check_loop (:306-379) on the alive bits.  The walk state is wave-uniform;
     //      lanes 0-3 probe the straight neighbours and lanes 4-7 the diagonal ones, each group ordered by falling dial
     //      position (W 5, N 3, E 1, S -2; NW 4, NE 2, SE -1, SW -3), so prune_cands' winner is the lowest set lane.
