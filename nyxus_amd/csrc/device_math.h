@@ -452,6 +452,13 @@ __device__ __forceinline__ uint32_t mul_u24_su(uint32_t a, uint32_t b_uniform)
     return r;
 }
 
+__device__ __forceinline__ int mul_i24(int a, int b)      // signed 24-bit factors, full rate
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // clamp of a per-lane value to wave-uniform bounds lo <= hi: the median of the three, one instruction
 __device__ __forceinline__ uint32_t med3_u32_ss(uint32_t x, uint32_t lo_uniform, uint32_t hi_uniform)
 {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
     for (uint32_t i = lane; i < np; i += 64) img[i] = 0;
     wav_sync<GS>();
     for_each_cloud_pixel<64>(A.inten + off, A.x + off, A.y + off, n, lane, [&](uint32_t, uint32_t, uint32_t px, uint32_t py) {   // padded image, contour.cpp:661-666
-        if (px < (uint32_t)w && py < (uint32_t)h) img[(px + 1) + (py + 1) * (uint32_t)W2] = kPix;
+        if (px < (uint32_t)w && py < (uint32_t)h) img[mad24(py + 1, (uint32_t)W2, px + 1)] = kPix;
     });
     wav_sync<GS>();
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
                     int pos = (int)p0, loc = 1, counter = 0;
                     for (;;) {
                         const int d = (loc - 1 + lane) & 7;
-                        const int cpl = pos + ((int)((kDy >> (2 * d)) & 3u) - 1) * W2 + ((int)((kDx >> (2 * d)) & 3u) - 1);
+                        const int cpl = pos + mul_i24((int)((kDy >> (2 * d)) & 3u) - 1, W2) + ((int)((kDx >> (2 * d)) & 3u) - 1);   // (24-bit product: full rate)
                         const bool hit = lane < 8 && cpl >= 0 && (uint32_t)cpl < np && (img[cpl] & kPix);
                         const uint32_t hm = (uint32_t)__ballot(hit) & 0xFFu;
                         if (hm == 0) break;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
                             if (nloc == 1 || counter >= 3) { inside = true; break; }
                         }
                         loc = nloc; pos = cp;
-                        if (lane == 0) img[cp] |= kBorder;
+                        if (lane == 0) img[cp] = (uint8_t)(kPix | kBorder);     // (a hit is a pixel and no other flag exists yet: a plain store, no read on the chain)
                     }
                 }
             }
@@ -213,13 +213,15 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         const int ox = (int)(cursor % (uint32_t)W2), oy = (int)(cursor / (uint32_t)W2);
         uint32_t ns = 0, nP = 0;
         int looplen = 0, result = -1;
-        if (lane == 0) { K[nK] = (uint32_t)ox | ((uint32_t)oy << 16); img[cursor] &= (uint8_t)~kAlive; }
+        // (an alive position carries all four flags: clearing kAlive is a plain store of the other three -- no read-modify-write
+        //  on the walk's serial chain)
+        if (lane == 0) { K[nK] = (uint32_t)ox | ((uint32_t)oy << 16); img[cursor] = (uint8_t)(kPix | kBorder | kCand); }
         ns = 1; n_u--;
         int tx = ox, ty = oy;
         wav_sync<GS>();
         while (n_u != 0) {
             const int X = tx + pdx, Y = ty + pdy;                 // padded coordinates: every neighbour of a pixel is inside the plane
-            const bool alive = lane < 8 && X >= 0 && Y >= 0 && X < W2 && Y < H2 && (img[(uint32_t)X + (uint32_t)Y * (uint32_t)W2] & kAlive);
+            const bool alive = lane < 8 && X >= 0 && Y >= 0 && X < W2 && Y < H2 && (img[mad24((uint32_t)Y, (uint32_t)W2, (uint32_t)X)] & kAlive);
             const uint32_t m = (uint32_t)__ballot(alive);
             const uint32_t cands = (m & 0xFu) ? (m & 0xFu) : (m >> 4);   // find_cands :193-216: straight neighbours first
             const bool diag = (m & 0xFu) == 0;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
                 tx += bdx; ty += bdy;
                 if (lane == 0) {
                     K[nK + ns] = (uint32_t)tx | ((uint32_t)ty << 16);
-                    img[(uint32_t)tx + (uint32_t)ty * (uint32_t)W2] &= (uint8_t)~kAlive;
+                    img[mad24((uint32_t)ty, (uint32_t)W2, (uint32_t)tx)] = (uint8_t)(kPix | kBorder | kCand);
                 }
                 ns++; n_u--;
                 wav_sync<GS>();
