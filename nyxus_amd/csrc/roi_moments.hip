@@ -202,6 +202,7 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
     //      position (W 5, N 3, E 1, S -2; NW 4, NE 2, SE -1, SW -3), so prune_cands' winner is the lowest set lane.
     const int pdx = lane == 0 ? -1 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? -1 : lane == 5 ? 1 : lane == 6 ? 1 : -1;
     const int pdy = lane == 0 ? 0 : lane == 1 ? -1 : lane == 2 ? 0 : lane == 3 ? 1 : lane == 4 ? -1 : lane == 5 ? -1 : lane == 6 ? 1 : 1;
+    const int noff = pdx + pdy * W2;                              // this lane's neighbour as an offset in the plane
     uint32_t nK = 0, cursor = 0;
     while (n_u != 0) {
         for (;;) {                                                // U.front(): the raster-first unordered pixel
@@ -220,8 +221,9 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         int tx = ox, ty = oy;
         wav_sync<GS>();
         while (n_u != 0) {
-            const int X = tx + pdx, Y = ty + pdy;                 // padded coordinates: every neighbour of a pixel is inside the plane
-            const bool alive = lane < 8 && X >= 0 && Y >= 0 && X < W2 && Y < H2 && (img[mad24((uint32_t)Y, (uint32_t)W2, (uint32_t)X)] & kAlive);
+            // (padded coordinates: the walk stands on a pixel, so all eight neighbours lie inside the plane -- the probe is one add
+            //  on the position, which travels in a scalar register next to tx / ty)
+            const bool alive = lane < 8 && (img[(uint32_t)(ty * W2 + tx + noff)] & kAlive);
             const uint32_t m = (uint32_t)__ballot(alive);
             const uint32_t cands = (m & 0xFu) ? (m & 0xFu) : (m >> 4);   // find_cands :193-216: straight neighbours first
             const bool diag = (m & 0xFu) == 0;
