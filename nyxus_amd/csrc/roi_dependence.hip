@@ -162,7 +162,6 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     //   * row sums by 16-lane groups, cell indices without integer division.
     const bool par = !GS && A.L.par != 0;
     int Nd_dzm = 0, Nd_dm = 0, Nr_ng = 0;
-    double* const scr_all = s_red;                       // 4 x 8 doubles are not enough for three concurrent tails: see below
     auto tail_totals16 = [&](double (&t)[16], double* scr) {   // every lane gets all sixteen totals back (through LDS)
         const double tt = wave_transpose_sum16(t, lane);       // lane 4 k holds total k
         if ((lane & 3) == 0) scr[lane >> 2] = tt;
@@ -384,7 +383,6 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
             o[13] = GLM; o[14] = glv; o[15] = DCM; o[16] = dcv; o[17] = t[10]; o[18] = t[11];
         }
     };
-    (void)scr_all;
 
     // =====================================================================================================
     // GLDZM
