@@ -612,3 +612,54 @@ def test_default_grey_depth_variants(hip_ctx, gd, na, sym, offset, mask):
     s.glcm_symmetric = sym
     s.glcm_offset = offset
     _check(hip_ctx, _abi.batch_from_rois(rois), mask, s)
+
+
+# ---- round-2 code paths that the default settings do not reach ------------------------------------------------------------------
+TEX_ALL = _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+DEP_ALL = _abi.FAM_GLDZM | _abi.FAM_GLDM | _abi.FAM_NGLDM
+
+
+def test_texture_sixteen_bit_plane(hip_ctx):
+    """A grey depth above 254 keeps the texture kernel on its 16-bit plane (the 8-bit plane / eight-workgroup build serves <= 254)."""
+    rois = synth.random_rois(40, seed=21)
+    _check(hip_ctx, _abi.batch_from_rois(rois), TEX_ALL, _abi.default_settings(300), against_ref=False)
+
+
+@pytest.mark.parametrize("gd", [8, 63, 64])
+def test_dependence_tails_parallel_equals_sequential(hip_ctx, gd, monkeypatch):
+    """The three feature tails side by side on three waves (default) against one after the other (NYXHIP_DEP_SEQ=1): the same bits.
+    gd 63 is the last depth served by the byte planes, 64 the first on the 16-bit ones."""
+    b = _abi.batch_from_rois(synth.random_rois(60, seed=22))
+    s = _abi.default_settings(gd)
+    par = hip_ctx.featurize_host(b, DEP_ALL, s)
+    monkeypatch.setenv("NYXHIP_DEP_SEQ", "1")
+    seq = hip_ctx.featurize_host(b, DEP_ALL, s)
+    assert np.array_equal(par.view(np.uint64), seq.view(np.uint64))
+    monkeypatch.delenv("NYXHIP_DEP_SEQ")
+    O = po.oracle_featurize(b, DEP_ALL, s)
+    bad = parity.compare_tables(par, O, _lib.column_names(DEP_ALL, s))
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_grey_depth_64_split_launch_equals_fused(hip_ctx, monkeypatch):
+    """INTENSITY + GLCM at 17..64 levels run as two launches (intensity at eight workgroups per CU); NYXHIP_G16_FUSED=1 keeps the one
+    launch: the same bits either way."""
+    b = synth.tile_batch(2, irregular=True)
+    s = _abi.default_settings(64)
+    split = hip_ctx.featurize_host(b, MASK, s)
+    monkeypatch.setenv("NYXHIP_G16_FUSED", "1")
+    fused = hip_ctx.featurize_host(b, MASK, s)
+    assert np.array_equal(split.view(np.uint64), fused.view(np.uint64))
+
+
+def test_contour_wide_boxes_take_the_position_wise_pass(hip_ctx):
+    """Padded planes wider than a wave (w + 2 > 64) keep the position-wise candidate / X-crossing passes of the contour kernel."""
+    yy, xx = np.mgrid[0:50, 0:90]
+    m = ((xx - 45) / 44.0) ** 2 + ((yy - 25) / 24.0) ** 2 <= 1.0
+    m[20:30, 40:50] = False                                  # a hole: a second contour
+    ys, xs = np.nonzero(m)
+    rng = np.random.default_rng(5)
+    roi = {"x": xs.astype(np.int64), "y": ys.astype(np.int64), "inten": rng.integers(1, 4096, xs.size).astype(np.uint32)}
+    small = synth.random_rois(6, seed=23)
+    mask = _abi.FAM_SMOMS | _abi.FAM_IMOMS
+    _check(hip_ctx, _abi.batch_from_rois([roi] + small), mask, _abi.default_settings(8), against_ref=False)
