@@ -984,6 +984,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             // against 2.0 ms from pre-assembled clouds).
             constexpr int UP = 16, UW = 8;                                               // rows per trip: label-only pre-pass / main pass
             const int dtl = A.win.dt_label, dti = A.win.dt_inten;
+            // The element sizes are launch constants, but a test per load put two scalar branches between any two loads of a trip
+            // (1.6 k scalar instructions per wave, the loads trickling out behind taken branches): the loader body is instantiated
+            // for the usual pairs (u32 + u32, u16 intensities + u8 / u16 labels) with the sizes as compile-time facts, and once
+            // with run-time sizes for the rest.
+            auto window_load = [&](auto DTL_c, auto DTI_c) {
+            constexpr int DTLc = decltype(DTL_c)::value, DTIc = decltype(DTI_c)::value;   // 0: run-time size
+            const int dtl = DTLc ? DTLc : A.win.dt_label, dti = DTIc ? DTIc : A.win.dt_inten;
             const uint32_t Wt = A.win.W;
             const uint64_t tile0 = (uint64_t)A.win.tile[roi] * tile_px;
             const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.win.lab + tile0 * (uint64_t)dtl), 0, (int)(tile_px * (uint64_t)dtl), 0x00020000);
@@ -1038,6 +1045,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         }
                 }
             }
+            };   // window_load
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+            if (dtl == 4 && dti == 4) window_load(I4{}, I4{});
+            else if (dtl == 1 && dti == 2) window_load(I1{}, I2{});
+            else if (dtl == 2 && dti == 2) window_load(I2{}, I2{});
+            else window_load(I0{}, I0{});
         } else {
         const uint64_t row0 = (uint64_t)A.win.tile[roi] * A.win.H + A.win.y0[roi];
         const uint64_t org = row0 * A.win.W + x0;
