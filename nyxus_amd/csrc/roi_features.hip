@@ -768,11 +768,14 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
 // FAM: family set known at compile time -- 0: read A.mask; 1: INTENSITY + GLCM under matlab binning with <= 16 levels (what
 // make_layout's dense8 stands for); 2: INTENSITY alone.  The 64-VGPR tier is only launched for 1 and 2, so the run-time
 // switches are compile-time facts there and their branches disappear from the pixel loops.
+// WIN: where the pixels come from -- 0: a cloud (the window loader is compiled out), 1: the ROI's window of its tile (the cloud
+// loader is compiled out), 2: decided at run time from A.win.  With both loaders in one kernel the 64-VGPR build carried ~90
+// scalar-register spills through the whole body (every spill and reload a vector instruction: 1388 -> 1249 per wave without them).
 // TIER: occupancy tier of the calling kernel; it only tags the kernel's private copy of glcm_features_rows (kRowsTag), so
 // that caller and callee are always compiled for the same register budget.
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;     // a byte at an absolute LDS address
 
-template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false>
+template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false, int WIN = 2>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -938,7 +941,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
         if (TINY) { sum += s32; sumsq += q32; }
     };
-    if (!GS && A.win.inten != nullptr) {
+    bool from_window = false;
+    if constexpr (WIN != 0 && !GS) {
+    if (WIN == 1 || A.win.inten != nullptr) {
+        from_window = true;
         // ---- window mode (fused tile path): the ROI's pixels are read straight from the tile -- the bounding-box window in
         // row-major order, a pixel belongs to the ROI when its label matches -- instead of from a materialised cloud
         // (roi_cloud_kernel wrote 8 B per ROI pixel that this pass then read back).  Every wave takes a contiguous quarter of
@@ -1126,7 +1132,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             if (bx >= w) { bx -= w; by++; o32 += wrap_o; }
         }
         }
-    } else {
+    }
+    }
+    if constexpr (WIN != 1) {
+    if (!from_window) {
         using T = std::true_type; using F = std::false_type;
         const bool nz = vmin > 0, tiny = vmax < (1u << 15);
         uint32_t base = 0;
@@ -1136,6 +1145,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         } else {
             for (; base < n; base += kU * kBlock) trip(F{}, F{}, F{}, base);
         }
+    }
     }
 
     STAMP(1);
@@ -2302,16 +2312,17 @@ __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiA
 {
     roi_features_body<false, C16, SPLIT, D8, 0, 7>(A);
 }
-template <int FAM>
+template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 8>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM, 8, false, WIN>(A);
 }
 
 // the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
+template <int WIN>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiArgs A)
 {
-    roi_features_body<false, true, false, true, 0, 9, true>(A);
+    roi_features_body<false, true, false, true, 0, 9, true, WIN>(A);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
@@ -2398,9 +2409,10 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static DeviceOnce optin;
     if (int orc = optin.run([]() -> int {
-        const void* fns[6] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
+        const void* fns[8] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
                               (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
-                              (const void*)roi_features_kernel_occ8<1>, (const void*)roi_features_kernel_occ8<2>};
+                              (const void*)roi_features_kernel_occ8<1, 0>, (const void*)roi_features_kernel_occ8<2, 0>,
+                              (const void*)roi_features_kernel_occ8<1, 1>, (const void*)roi_features_kernel_occ8<2, 1>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -2421,8 +2433,11 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
     for (int o = (C16 && SPLIT && D8 && (int_only || int_glcm)) ? 8 : 7; o > 4; o--)
         if ((size_t)o * a.L.total <= lds) { occ = o; break; }
     if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
-    if (occ == 8 && int_only) hipLaunchKernelGGL(roi_features_kernel_occ8<2>, dim3(grid), dim3(kBlock), a.L.total, st, a);
-    else if (occ == 8) hipLaunchKernelGGL(roi_features_kernel_occ8<1>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+    const bool win = a.win.inten != nullptr;
+    if (occ == 8 && int_only && win) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 8 && int_only) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 8 && win) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (occ == 8) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
@@ -2447,12 +2462,17 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     if (a.L.g16) {
         static DeviceOnce optin;
         if (int orc = optin.run([]() -> int {
-                if (hipError_t e = hipFuncSetAttribute((const void*)roi_features_kernel_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); e != hipSuccess)
-                    return (int)e;
-                return no_static_lds((const void*)roi_features_kernel_g16);
+                for (const void* f : {(const void*)roi_features_kernel_g16<0>, (const void*)roi_features_kernel_g16<1>}) {
+                    if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); e != hipSuccess)
+                        return (int)e;
+                    if (int src = no_static_lds(f))
+                        return src;
+                }
+                return 0;
             }))
             return orc;
-        hipLaunchKernelGGL(roi_features_kernel_g16, dim3(grid), dim3(kBlock), a.L.total, st, a);
+        if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16<1>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+        else hipLaunchKernelGGL(roi_features_kernel_g16<0>, dim3(grid), dim3(kBlock), a.L.total, st, a);
         return (int)hipGetLastError();
     }
     const bool split = a.glcm_ws != nullptr;

@@ -7,7 +7,7 @@ txt = open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "summary.txt")).read(
 fetch = float(re.search(r"FETCH_SIZE: n=\d+ mean=([0-9.e+]+)", txt).group(1))
 write = float(re.search(r"WRITE_SIZE: n=\d+ mean=([0-9.e+]+)", txt).group(1))
 kern = re.search(r"launch group: roi_features_kernel ([0-9.]+) ms \+ glcm_features_kernel ([0-9.]+) ms", txt)
-rec = {"round": tag, "kernel": "roi_features_kernel_occ8<1>", "tiles": 1000, "gray_depth": 8,
+rec = {"round": tag, "kernel": "roi_features_kernel_occ8<1, 0>", "tiles": 1000, "gray_depth": 8,
        "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
        "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
