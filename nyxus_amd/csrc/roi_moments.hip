@@ -262,9 +262,11 @@ namespace {
 
 constexpr int kMB = 256;
 
-// Sum N doubles across the workgroup in a fixed order; every thread gets the totals.
+// Sum N doubles across the workgroup in a fixed order; total k lands in dst[k] (LDS), visible to every thread on return.
+// (Only the totals' consumers read them: when every thread formed all N totals itself -- 4 N LDS reads, 3 N adds and 2 N
+//  registers each -- the 128-register build spilled around every call: 14 GB of scratch writes per 196 k ROIs in the counters.)
 template <int N, bool GS>
-__device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int tid)
+__device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, double* dst, int tid)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (N > 8) {                                      // transposed wave sums (device_math.h): slot k's total lands in its lane group
@@ -288,8 +290,7 @@ __device__ __forceinline__ void mom_block_sum(double (&v)[N], double* s_red, int
             for (int k = 0; k < N; k++) s_red[wave * N + k] = v[k];
     }
     blk_sync<GS>();
-#pragma unroll
-    for (int k = 0; k < N; k++) v[k] = ((s_red[k] + s_red[N + k]) + s_red[2 * N + k]) + s_red[3 * N + k];
+    if (tid < N) dst[tid] = ((s_red[tid] + s_red[N + tid]) + s_red[2 * N + tid]) + s_red[3 * N + tid];
     blk_sync<GS>();
 }
 
@@ -452,11 +453,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
                     for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
             }
         });
-        mom_block_sum<16, false>(acc, s_red, tid);
-        if (tid == 0) {                                  // compile-time indices only: a run-time index would send the array to scratch
-#pragma unroll
-            for (int k = 0; k < 16; k++) s_raw[var][k] = acc[k];
-        }
+        mom_block_sum<16, false>(acc, s_red, s_raw[var], tid);
     }
     __syncthreads();
     MSTAMP(1);
@@ -485,11 +482,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
                     for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
             }
         });
-        mom_block_sum<16, false>(acc, s_red, tid);
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) s_cen[var][k] = acc[k];
-        }
+        mom_block_sum<16, false>(acc, s_red, s_cen[var], tid);
     }
     __syncthreads();
     MSTAMP(2);
@@ -522,12 +515,8 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
                 ai[k] = wr_q[k] ? __builtin_fma(ix[wr_p[k]], yp[wr_q[k]], ai[k]) : ai[k] + ix[wr_p[k]];
             }
         });
-        mom_block_sum<10, false>(as, s_red, tid);
-        mom_block_sum<10, false>(ai, s_red, tid);
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 10; k++) { s_wraw[0][k] = as[k]; s_wraw[1][k] = ai[k]; }
-        }
+        mom_block_sum<10, false>(as, s_red, s_wraw[0], tid);
+        mom_block_sum<10, false>(ai, s_red, s_wraw[1], tid);
     }
     __syncthreads();
     MSTAMP(3);
@@ -556,12 +545,8 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
                 for (int k = 0; k < 7; k++) ai[k] = nc_q[k] ? __builtin_fma(wx[nc_p[k]], yp[nc_q[k]], ai[k]) : ai[k] + wx[nc_p[k]];
             }
         });
-        mom_block_sum<7, false>(as, s_red, tid);
-        mom_block_sum<7, false>(ai, s_red, tid);
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 7; k++) { s_wcen[0][k] = as[k]; s_wcen[1][k] = ai[k]; }
-        }
+        mom_block_sum<7, false>(as, s_red, s_wcen[0], tid);
+        mom_block_sum<7, false>(ai, s_red, s_wcen[1], tid);
     }
     __syncthreads();
     MSTAMP(4);

@@ -57,7 +57,7 @@ __device__ __forceinline__ double plog_tex(double p)
 
 template <bool GS>
 __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
-                                    uint32_t Np, double* f, int lane)
+                                    uint32_t Np, double* f, double* park, int lane)
 {
     // The kernel is bound by vector-instruction issue, so this routine is organised around the instruction count:
     //   * row sums by 16-lane groups (four levels at a time, a 4-step DPP sum each) instead of one lane walking a whole row;
@@ -114,9 +114,10 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
     }
     wav_sync<GS>();
     const double mu_g = f[1], mu_r = f[7];
-    double s8[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) s8[k] = lane == 0 ? f[k] : 0.0;   // lane 0 keeps stage 1 (the slot is reused below)
+    // stage 1 waits in the wave's eight slots of the block exchange area (`park`; nobody else touches it while the waves are in
+    // here) instead of in sixteen registers of lane 0 that every lane carried through the cell loop below -- the 64-register
+    // build spilled them to scratch, which the counters showed as gigabytes of HBM writes per launch
+    if ((lane & 7) == 0) park[lane >> 3] = f[lane >> 3];
     wav_sync<GS>();
     double u8[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // glv, rv, re, srl, srh, lrl, lrh
     for (int i = lane; i < Ng; i += 64) {
@@ -167,6 +168,9 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
     if (lane == 0) {
         const double glv = f[8], rv = f[9], re = f[10], srl = f[11], srh = f[12], lrl = f[13], lrh = f[14];
         const double inv_p2 = inv_p * inv_p;
+        double s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s8[k] = park[k];
         f[R_SRE] = s8[4] * inv_p;
         f[R_LRE] = s8[5] * inv_p;
         f[R_GLN] = s8[0] * inv_p;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
                         }
                         wav_sync<GS>();
-                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, lane);
+                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, s_red + wave * 8, lane);
                     }
                 }
             }
@@ -697,11 +701,21 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     if ((lane & 7) == 0) s_red[wave * 8 + (lane >> 3)] = tt;
                 }
                 blk_sync<GS>();
+                // every thread needs the two means; the other five totals only feed outputs, which one thread writes right here
+                // (carried by all threads through the second sweep they cost ten registers -- scratch spills in the 64-register build)
+                const double mu_ZV = ((s_red[5] + s_red[8 + 5]) + s_red[16 + 5]) + s_red[24 + 5];
+                const double mu_GLV = ((s_red[6] + s_red[8 + 6]) + s_red[16 + 6]) + s_red[24 + 6];
+                if (tid == 0) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                    for (int k = 0; k < 5; k++) acc[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                    o[Z_ZE] = -acc[4];
+                    o[Z_SALGLE] = acc[3] * inv_p;
+                    o[Z_SAHGLE] = acc[2] * inv_p;
+                    o[Z_LALGLE] = acc[1] * inv_p;
+                    o[Z_LAHGLE] = acc[0] * inv_p;
+                }
                 blk_sync<GS>();
                 TSTAMP(7);
-                const double mu_ZV = acc[5], mu_GLV = acc[6];
                 double b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t i = tid; i < n_cells; i += kBlock) {
                     uint32_t key, val;
@@ -752,13 +766,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     o[Z_ZP] = fdiv(sum_p, (double)(int)(uint32_t)s_stat[3]);   // calc_ZP :491-495
                     o[Z_GLV] = b[0];
                     o[Z_ZV] = b[1];
-                    o[Z_ZE] = -acc[4];
                     o[Z_LGLZE] = b[6] * inv_p;
                     o[Z_HGLZE] = b[7] * inv_p;
-                    o[Z_SALGLE] = acc[3] * inv_p;
-                    o[Z_SAHGLE] = acc[2] * inv_p;
-                    o[Z_LALGLE] = acc[1] * inv_p;
-                    o[Z_LAHGLE] = acc[0] * inv_p;
                 }
             }
         }
