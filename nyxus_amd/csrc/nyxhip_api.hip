@@ -741,7 +741,7 @@ __global__ void classify_plane_kernel(uint64_t n_roi, const uint32_t* bw, const 
 // Contour + 2-D geometric moments (roi_moments.hip).  The contour of every ROI goes to a context-owned workspace at the
 // ROI's CSR offset (a contour never has more points than the ROI has pixels); the moments kernel reads it back.
 int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
-                   uint32_t max_area, uint32_t max_side)
+                   uint32_t max_px, uint32_t max_area, uint32_t max_side)
 {
     hipStream_t st = ctx->stream();
     uint64_t total_px = 0;
@@ -771,6 +771,11 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
         ctx->logtab_n = kLogTab;
     }
     m.log_tab = ctx->d_logtab; m.log_tab_n = ctx->logtab_n;
+    // LDS of the moments kernel from the batch extrema: every pixel of the largest ROI (up to kMomPxLds; larger ROIs sweep HBM),
+    // a contour of up to the bounding box's perimeter (what a convex ROI can have; longer ones are read from HBM), its step table
+    m.px_cap = std::min<uint32_t>((uint32_t)kMomPxLds, (std::max<uint32_t>(max_px ? max_px : max_area, 1u) + 7u) & ~7u);
+    m.k_cap = std::min<uint32_t>((uint32_t)kMomContourLds, std::max<uint32_t>(256u, (4u * std::min<uint32_t>(max_side, 65536u) + 63u) & ~63u));
+    m.step_cap = std::min<uint32_t>((uint32_t)kMomStepTab, m.k_cap);
     const uint64_t full_plane = (uint64_t)max_area + 4ull * max_side + 4;      // (w + 2)(h + 2) <= area + 2(w + h) + 4
     const uint32_t grid = (uint32_t)b->n_roi;
     const uint32_t lds_cap = (uint32_t)roi_features_max_lds();
@@ -913,7 +918,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     if (mask & kMoments)
-        if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_area, max_side))
+        if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_px, max_area, max_side))
             return mrc;
     if (feat_all_gs) {
         const size_t list_bytes = 4ull * b->n_roi + 256;

@@ -187,9 +187,9 @@ struct DepArgs {
 
 // ---- contour + 2-D geometric moments (roi_moments.hip) -----------------------------------------
 constexpr int kMomCols = 90;              // per family: RM 13, CM 16, NRM 16, NCM 7, HU 7, WRM 10, WCM 7, WNCM 7, WHU 7
-constexpr int kMomStepTab = 2048;         // hill-descent step table (window width -> step)
-constexpr int kMomContourLds = 2048;      // contour points the moments kernel keeps in LDS (longer contours are read from HBM)
-constexpr int kMomPxLds = 3072;           // ROI pixels (x | y << 16, intensity) the moments kernel keeps in LDS for its six sweeps
+constexpr int kMomStepTab = 2048;         // hill-descent step table (window width -> step): upper bound of MomArgs::step_cap
+constexpr int kMomContourLds = 2048;      // upper bound of MomArgs::k_cap, the contour points the moments kernel keeps in LDS (longer contours are read from HBM)
+constexpr int kMomPxLds = 3072;           // upper bound of MomArgs::px_cap, the ROI pixels (x | y << 16, intensity) the moments kernel keeps in LDS for its six sweeps
 
 constexpr int kContourWaves = 4;     // ROIs (waves) per workgroup of roi_contour_kernel
 
@@ -213,6 +213,7 @@ struct MomArgs {
     const double* log_tab;    // [log_tab_n]     log(sqrt(d) + 0.001) for the integer squared distances d < log_tab_n (context-owned, built once
     uint32_t log_tab_n;       //                 on the device by the same expression: bit-identical to evaluating it per pixel)
     uint32_t plane_cap;       // bytes of the padded flag plane one ROI may use
+    uint32_t px_cap, k_cap, step_cap;   // moments kernel: pixels / contour points / step-table entries its dynamic LDS holds
     SpillArgs sp;
 };
 

@@ -361,22 +361,26 @@ __device__ void hu7(double _02, double _03, double _11, double _12, double _20, 
 } // namespace
 
 // Column layout of one 90-wide block (Feature2D order): RM(13) CM(16) NRM(16) NCM(7) HU(7) WRM(10) WCM(7) WNCM(7) WHU(7)
-#ifndef NYX_MOM_OCC
-#define NYX_MOM_OCC 4
-#endif
 // diagnostic builds (-DNYX_MOM_EXIT_AT=k): the kernel ends after pass k (results are wrong by design)
 #ifdef NYX_MOM_EXIT_AT
 #define MSTAMP(k) do { if ((k) == NYX_MOM_EXIT_AT) return; } while (0)
 #else
 #define MSTAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const MomArgs A)
+// OCC: workgroups per CU the register budget is cut for (4: 128 registers, no spills; 6: 80 registers and ~30 spilled words
+// outside the pixel loops -- the hill descent is a chain of dependent LDS reads, so when six carve-outs fit a CU the extra
+// waves win: 11.7 -> 10.2 ms per 196 k benchmark ROIs).  The launcher picks by the launch's LDS bytes.
+template <int OCC>
+__global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
 {
     __shared__ double s_red[4 * 16];
     __shared__ double s_raw[2][16], s_cen[2][16], s_wraw[2][10], s_wcen[2][7];
-    __shared__ uint32_t s_K[kMomContourLds];
-    __shared__ uint16_t s_step[kMomStepTab];
-    __shared__ uint2 s_px[kMomPxLds];
+    // staged pixels | contour | step table: sized per launch from the batch extrema (launch_moments), so that small ROIs do not
+    // pay for the largest ROI the LDS path accepts -- the benchmark ROI needs 25 KB instead of the 38 KB the fixed arrays took
+    extern __shared__ __attribute__((aligned(16))) unsigned char mom_lds[];
+    uint2* const s_px = (uint2*)mom_lds;                                  // [A.px_cap]
+    uint32_t* const s_K = (uint32_t*)(mom_lds + 8u * A.px_cap);           // [A.k_cap]
+    uint16_t* const s_step = (uint16_t*)(s_K + A.k_cap);                  // [A.step_cap]
     const int tid = threadIdx.x;
     const uint64_t roi = blockIdx.x;
     if (roi >= A.n_roi)
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
     const int nK = (int)A.n_contour[roi];
     const bool small_xy = A.bbox_w[roi] + 2u < 32768u && A.bbox_h[roi] + 2u < 32768u;   // integer distances are exact (min_sqdist_v2)
     const uint32_t* K = A.ws_contour + off;
-    if (nK <= kMomContourLds) {
+    if (nK <= (int)A.k_cap) {
         for (int i = tid; i < nK; i += kMB) s_K[i] = K[i];
         K = s_K;
     }
@@ -403,13 +407,13 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
 
     // window width -> step of the hill descent (first step from n, later ones from windows of at most two steps)
     const int step0 = nK >= 2 ? (int)((double)nK / log((double)nK)) : 1;
-    const int tab_n = min(kMomStepTab, 2 * step0 + 2);
+    const int tab_n = min((int)A.step_cap, 2 * step0 + 2);
     for (int m = 11 + tid; m < tab_n; m += kMB) s_step[m] = (uint16_t)(int)((double)m / log((double)m));
 
     // The six sweeps below read the ROI's pixels again and again.  From HBM / L2 every sweep is a chain of dependent round
     // trips (four waves per SIMD hide little of it: the sweeps took 3-4 ms each way); ROIs of up to kMomPxLds pixels are
     // therefore staged in LDS once -- x | y << 16 and the intensity, 8 bytes per pixel -- and swept from there.
-    const bool staged = n <= (uint32_t)kMomPxLds;
+    const bool staged = n <= A.px_cap;
     if (staged)
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             s_px[i] = make_uint2(xi | (yi << 16), vi);
@@ -505,6 +509,11 @@ __global__ __launch_bounds__(kMB, NYX_MOM_OCC) void roi_moments_kernel(const Mom
                                         : min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
             const double lg = (small_xy && dsq < (double)A.log_tab_n) ? A.log_tab[(uint32_t)dsq] : log(sqrt(dsq) + 0.001);
             L[i] = lg;
+        });
+        // (the sums run as a sweep of their own over the weights just written -- every thread reads back its own stores: with
+        //  the twenty accumulators live across the hill descent the 80-register build spilled and reloaded them per pixel)
+        sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+            const double lg = L[i];
             const double X = (double)xi, Y = (double)yi;
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
@@ -629,7 +638,13 @@ int launch_roi_moments(const MomArgs& a, void* stream, uint32_t grid)
 {
     if (grid == 0)
         return 0;
-    hipLaunchKernelGGL(roi_moments_kernel, dim3(grid), dim3(kMB), 0, (hipStream_t)stream, a);
+    const uint32_t dyn = 8u * a.px_cap + 4u * a.k_cap + 2u * a.step_cap;
+    // static LDS of the kernel (exchange area + the four total blocks) is 1296 B; LDS is allocated in 1280-byte granules
+    const uint32_t granules = (dyn + 1296u + 1279u) / 1280u;
+    if (6u * granules * 1280u <= (uint32_t)roi_features_max_lds())
+        hipLaunchKernelGGL(roi_moments_kernel<6>, dim3(grid), dim3(kMB), dyn, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(roi_moments_kernel<4>, dim3(grid), dim3(kMB), dyn, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
