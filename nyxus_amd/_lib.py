@@ -5,8 +5,11 @@ present this module raises -- there is no CPU fallback on the product path.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -119,6 +122,23 @@ def column_names(mask: int, s: _abi.Settings) -> List[str]:
     return out
 
 
+# Contexts still open at interpreter exit are destroyed here, while the HIP runtime is certainly alive (Python's atexit handlers
+# run before the C library's): a context freed by the garbage collector during shutdown could reach hipFree / hipStreamDestroy
+# after the runtime's own exit handlers.
+_live_contexts = weakref.WeakSet()
+
+
+def _close_live_contexts():
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_contexts)
+
+
 class Context:
     """One ``nyxhip_ctx`` bound to one GPU (one per process rank)."""
 
@@ -130,6 +150,7 @@ class Context:
             raise NyxHipError(rc, (self._lib.nyxhip_last_error(None) or b"").decode())
         self._h = h
         self.device = device
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -137,6 +158,10 @@ class Context:
             self._h = None
 
     def __del__(self):
+        # a context that is still alive when the interpreter shuts down was closed by _close_live_contexts (atexit: before the
+        # HIP runtime's own exit handlers); one collected later than that must not call into a runtime that may be gone
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

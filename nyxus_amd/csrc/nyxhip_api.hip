@@ -29,6 +29,7 @@ struct nyxhip_ctx {
     // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
     double* d_bank = nullptr;
     std::vector<double> bank_key;
+    uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
     // grow-only device staging for host-memory batches
@@ -396,6 +397,18 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
     gabor_filter(bank.data(), s->gabor_f0lp, s->gabor_sig2lam, s->gabor_gamma, M_PI_2, 0, n);
     for (int f = 0; f < nF; f++)
         gabor_filter(bank.data() + (size_t)(f + 1) * n * n * 2, s->gabor_f0[f], s->gabor_sig2lam, s->gabor_gamma, s->gabor_theta[f], 0, n);
+    for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) ctx->bank_zero_rows[f] = 0;
+    if (n == 16)
+        for (int f = 0; f <= nF; f++)
+            for (int j = 0; j < n; j++) {
+                bool re0 = true, im0 = true;
+                for (int i = 0; i < n; i++) {
+                    const double* t = bank.data() + ((size_t)f * n * n + (size_t)j * n + i) * 2;
+                    re0 = re0 && t[0] == 0.0;             // (+0 and -0 alike; a NaN or a denormal is not zero)
+                    im0 = im0 && t[1] == 0.0;
+                }
+                ctx->bank_zero_rows[f] |= (re0 ? 1u << j : 0u) | (im0 ? 1u << (16 + j) : 0u);
+            }
     if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank, bank.size() * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_bank, bank.data(), bank.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -725,6 +738,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= 512 && E.area <= 1024) ? 1 : 0;
         g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+        for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
     }
     return NYXHIP_OK;
 }

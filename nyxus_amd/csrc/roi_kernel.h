@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/nyxhip.h"
 
 namespace nyxhip {
 
@@ -251,6 +252,11 @@ struct ShapeArgs {
     double soft_nan;
     const double* gabor_bank; // device: (F+1) filters (low-pass first), n*n complex taps each
     int32_t gabor_nf, gabor_n;
+    // 16 x 16 banks: per filter, bit j = every real part of tap row j is +-0, bit 16 + j = every imaginary part is.  Such a row adds
+    // +-0 to the running sums, which leaves them as they are (they start at +0 and no sum of the scan is -0): the tiled kernel
+    // skips that half of the row's arithmetic -- the reference's default bank has f0 = 0 in its first filter, i.e. sin(0) = 0
+    // in every imaginary part
+    uint32_t gabor_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1];
     double gabor_thr;
     int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
     SpillArgs sp;

@@ -182,7 +182,10 @@ typedef const double __attribute__((address_space(4))) * bank_ptr_t;
 // exact ties (flat blocks: thousands of pixels share one energy, and which of them is the strict minimum is decided by the
 // last bit) 0.6 % of the ROIs changed by up to 9 % (tools/gabor_fuzz.py).  The default therefore keeps the reference's
 // separate multiply and add, which is bit-identical on every input.
-template <int T, int NW, bool FUSED>
+// ZR: the bank has tap rows whose real or imaginary parts are all zero (ShapeArgs::gabor_zero_rows): those halves of the
+// row's arithmetic are skipped.  Banks without such rows run the build without the tests (the three copies of the tap block
+// cost the DSB-sized launches 6 %).
+template <int T, int NW, bool FUSED, bool ZR = false>
 __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArgs A)
 {
     constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
 
     for (int f = 0; f <= nF; f++) {
         const bank_ptr_t G = bank + (size_t)f * N * N * 2;
+        const uint32_t zero_rows = ZR ? A.gabor_zero_rows[f] : 0u;
         uint32_t sc = 0;
         for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
             const uint32_t b = tile / tpr, a0 = (tile - b * tpr) * T;
@@ -248,6 +252,10 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
             const uint32_t* row = s_plane + (b + 15) * pitch + a0;      // tap row j reads padded row b + 15 - j
 #pragma unroll 1
             for (int j = 0; j < N; j++, row -= pitch) {
+                // tap rows whose real (imaginary) parts are all +-0 leave re (im) as it is: see ShapeArgs::gabor_zero_rows
+                const bool re0 = (zero_rows >> j) & 1u, im0 = (zero_rows >> (16 + j)) & 1u;
+                if (re0 && im0)
+                    continue;
                 double win[T + 16];
 #pragma unroll
                 for (int q = 0; q < W4; q++) {
@@ -256,21 +264,28 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
                     win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
                 }
                 const bank_ptr_t Gj = G + j * N * 2;
+                auto taps = [&](auto do_re_c, auto do_im_c) {
+                    constexpr bool DO_RE = decltype(do_re_c)::value, DO_IM = decltype(do_im_c)::value;
 #pragma unroll
-                for (int i = 0; i < N; i++) {
-                    const double gr = Gj[2 * i], gi = Gj[2 * i + 1];
+                    for (int i = 0; i < N; i++) {
+                        const double gr = DO_RE ? Gj[2 * i] : 0.0, gi = DO_IM ? Gj[2 * i + 1] : 0.0;
 #pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        const double av = win[t + 16 - i];   // padded column a0 + t + 16 - i = image column a0 + t + 8 - i
-                        if (FUSED) {
-                            re[t] = __builtin_fma(av, gr, re[t]);
-                            im[t] = __builtin_fma(av, gi, im[t]);
-                        } else {
-                            re[t] += av * gr;                // C[ip]   += a * wr   (gabor.cpp:374)
-                            im[t] += av * gi;                // C[ip+1] += a * wi   (:377)
+                        for (int t = 0; t < T; t++) {
+                            const double av = win[t + 16 - i];   // padded column a0 + t + 16 - i = image column a0 + t + 8 - i
+                            if (FUSED) {
+                                if (DO_RE) re[t] = __builtin_fma(av, gr, re[t]);
+                                if (DO_IM) im[t] = __builtin_fma(av, gi, im[t]);
+                            } else {
+                                if (DO_RE) re[t] += av * gr;     // C[ip]   += a * wr   (gabor.cpp:374)
+                                if (DO_IM) im[t] += av * gi;     // C[ip+1] += a * wi   (:377)
+                            }
                         }
                     }
-                }
+                };
+                // (a row whose real parts alone vanish does not occur in a Gabor bank -- cos(x' f0) has no exact zeros on the tap
+                //  grid -- and takes the full block)
+                if (ZR && im0) taps(std::true_type{}, std::false_type{});
+                else taps(std::true_type{}, std::true_type{});
             }
 #pragma unroll
             for (int t = 0; t < T; t++) {
@@ -474,7 +489,9 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         const void* tiled[] = {(const void*)roi_gabor_tiled_kernel<8, 4, false>, (const void*)roi_gabor_tiled_kernel<4, 1, false>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, true>, (const void*)roi_gabor_tiled_kernel<4, 1, true>};
+                               (const void*)roi_gabor_tiled_kernel<8, 4, true>, (const void*)roi_gabor_tiled_kernel<4, 1, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, false, true>, (const void*)roi_gabor_tiled_kernel<4, 1, false, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, true, true>, (const void*)roi_gabor_tiled_kernel<4, 1, true, true>};
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -492,12 +509,27 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
     }
     if ((a.mask & NYXHIP_FAM_GABOR) && a.L.tiled) {
         static const bool fused = [] { const char* e = getenv("NYXHIP_GABOR_FUSED"); return e && *e && *e != '0'; }();
-        if (!fused) {
+        // worth its registers (the build with the row tests needs ~25 more: one wave per SIMD less) when at least 4 % of the
+        // bank's arithmetic falls away: the reference's default bank (f0 = 0 in its first filter) saves 10.6 %, the 8-orientation
+        // bank of BASELINE.json configs[4] one row in 288
+        int zero_halves = 0;
+        for (int f = 0; f <= a.gabor_nf && f <= NYXHIP_MAX_GABOR_FILTERS; f++) {
+            const uint32_t z = a.gabor_zero_rows[f], im = z >> 16, both = z & im & 0xFFFFu;
+            zero_halves += __builtin_popcount(im) + __builtin_popcount(both);
+        }
+        const bool zr = 25 * zero_halves >= 32 * (a.gabor_nf + 1);
+        if (!fused && !zr) {
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, false>), dim3(grid), dim3(64), a.L.total, st, a);
             else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, false>), dim3(grid), dim3(256), a.L.total, st, a);
-        } else {
+        } else if (!fused) {
+            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, false, true>), dim3(grid), dim3(64), a.L.total, st, a);
+            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, false, true>), dim3(grid), dim3(256), a.L.total, st, a);
+        } else if (!zr) {
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, true>), dim3(grid), dim3(64), a.L.total, st, a);
             else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, true>), dim3(grid), dim3(256), a.L.total, st, a);
+        } else {
+            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, true, true>), dim3(grid), dim3(64), a.L.total, st, a);
+            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, true, true>), dim3(grid), dim3(256), a.L.total, st, a);
         }
     } else if (a.mask & NYXHIP_FAM_GABOR) {
         if (small) hipLaunchKernelGGL((roi_gabor_kernel<1, false>), dim3(grid), dim3(64), a.L.total, st, a);
