@@ -30,6 +30,7 @@ struct nyxhip_ctx {
     double* d_bank = nullptr;
     std::vector<double> bank_key;
     uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
+    uint32_t bank_box_mask = 0;                                  // ShapeArgs::gabor_box_mask of the uploaded bank
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
     // grow-only device staging for host-memory batches
@@ -409,6 +410,16 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
                 }
                 ctx->bank_zero_rows[f] |= (re0 ? 1u << j : 0u) | (im0 ? 1u << (16 + j) : 0u);
             }
+    ctx->bank_box_mask = 0;
+    if (n == 16)
+        for (int f = 0; f <= nF; f++) {
+            const double* t = bank.data() + (size_t)f * n * n * 2;
+            int e = 0;
+            bool box = t[0] > 0.0 && std::frexp(t[0], &e) == 0.5 && t[0] >= 0x1p-64 && t[0] <= 1.0;   // a power of two (2^-8 in the default bank)
+            for (int k = 0; k < n * n && box; k++)
+                box = t[2 * k] == t[0] && t[2 * k + 1] == 0.0;
+            if (box) ctx->bank_box_mask |= 1u << f;
+        }
     if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank, bank.size() * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_bank, bank.data(), bank.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -739,6 +750,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.small_rois = (E.px <= 512 && E.area <= 1024) ? 1 : 0;
         g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
+        g.gabor_box_mask = ctx->bank_box_mask;
     }
     return NYXHIP_OK;
 }

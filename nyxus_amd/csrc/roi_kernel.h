@@ -257,6 +257,10 @@ struct ShapeArgs {
     // skips that half of the row's arithmetic -- the reference's default bank has f0 = 0 in its first filter, i.e. sin(0) = 0
     // in every imaginary part
     uint32_t gabor_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1];
+    // bit f: every tap of filter f is (c, +-0) with one power of two c -- a box filter, which the reference's default bank has
+    // as its first filter (f0 = 0: infinite envelope, cos 0 = 1, normalised by 256).  Its response is exact integer arithmetic
+    // (roi_gabor_tiled_kernel).
+    uint32_t gabor_box_mask;
     double gabor_thr;
     int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
     SpillArgs sp;

@@ -243,6 +243,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
     for (int f = 0; f <= nF; f++) {
         const bank_ptr_t G = bank + (size_t)f * N * N * 2;
         const uint32_t zero_rows = ZR ? A.gabor_zero_rows[f] : 0u;
+        const bool box = ZR && ((A.gabor_box_mask >> f) & 1u) && A.max_inten[roi] < (1u << 24);
+        const double box_c = box ? G[0] : 0.0;
         uint32_t sc = 0;
         for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
             const uint32_t b = tile / tpr, a0 = (tile - b * tpr) * T;
@@ -250,6 +252,33 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
 #pragma unroll
             for (int t = 0; t < T; t++) { re[t] = 0.0; im[t] = 0.0; }
             const uint32_t* row = s_plane + (b + 15) * pitch + a0;      // tap row j reads padded row b + 15 - j
+            if (ZR && box) {
+                // box filter (ShapeArgs::gabor_box_mask): every tap is (c, 0) with c a power of two.  Each product a * c and every
+                // partial sum of the reference's scan is then an exact multiple of c below 2^53 c -- no rounding anywhere, whatever
+                // the order -- so the response is c times the integer sum of the 16 x 16 window: a sliding sum over the row's
+                // words (two integer operations per output and tap row instead of sixteen multiplies and sixteen adds).  32-bit
+                // sums hold because this ROI's intensities are below 2^24 (checked above).
+                uint32_t S[T];
+#pragma unroll
+                for (int t = 0; t < T; t++) S[t] = 0;
+#pragma unroll 1
+                for (int j = 0; j < N; j++, row -= pitch) {
+                    uint32_t wd[T + 16];
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        const uint4 u = ((const uint4*)row)[q];
+                        wd[4 * q + 0] = u.x; wd[4 * q + 1] = u.y; wd[4 * q + 2] = u.z; wd[4 * q + 3] = u.w;
+                    }
+                    uint32_t sm = 0;                             // taps i = 0..15 of output t read words t + 16 - i = t + 1 .. t + 16
+#pragma unroll
+                    for (int k = 1; k <= 16; k++) sm += wd[k];
+                    S[0] += sm;
+#pragma unroll
+                    for (int t = 1; t < T; t++) { sm = sm + wd[t + 16] - wd[t]; S[t] += sm; }
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) re[t] = (double)S[t] * box_c;
+            } else
 #pragma unroll 1
             for (int j = 0; j < N; j++, row -= pitch) {
                 // tap rows whose real (imaginary) parts are all +-0 leave re (im) as it is: see ShapeArgs::gabor_zero_rows

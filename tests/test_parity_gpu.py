@@ -483,6 +483,32 @@ def test_gabor_tiled_kernel_edge_shapes_exact(hip_ctx):
             assert ((G == Rf) | (np.isnan(G) & np.isnan(Rf))).all()
 
 
+@pytest.mark.parametrize("top", [255, (1 << 24) - 1, 1 << 24, (1 << 32) - 1])
+def test_gabor_default_bank_box_filter_and_zero_rows_exact(hip_ctx, top):
+    """The default bank's first filter has f0 = 0 (gabor.cpp:19-25 consumed as :107-110): every tap is (2^-8, 0).  The tiled
+    kernel takes its response from exact integer window sums while the ROI's intensities stay below 2^24 and skips the
+    all-zero imaginary rows otherwise -- both must give the reference's count ratios bit for bit, on either side of the
+    boundary and for flat blocks (ties at the threshold)."""
+    rng = np.random.default_rng(top & 0xFFFF)
+    rois = []
+    for k, (w, h) in enumerate([(61, 61), (17, 9), (64, 30), (8, 40), (33, 33)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = ((xx - w / 2) ** 2 / (w / 2) ** 2 + (yy - h / 2) ** 2 / (h / 2) ** 2 <= 1.0) if k % 2 == 0 else np.ones((h, w), bool)
+        v = rng.integers(max(1, top // 2), top + 1, (h, w), dtype=np.uint64).astype(np.uint32)
+        if k == 4:
+            v[:, : w // 2] = top                      # a flat block: thousands of equal energies
+        v[0, 0] = top
+        rois.append(dict(x=xx[m].astype(np.uint16), y=yy[m].astype(np.uint16), inten=v[m]))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(8)
+    G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+    O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+    assert ((G == O) | (np.isnan(G) & np.isnan(O))).all()
+    if po.have_ref():
+        Rf = po.ref_featurize(b, _abi.FAM_GABOR, s, 2)
+        assert ((G == Rf) | (np.isnan(G) & np.isnan(Rf))).all()
+
+
 @pytest.mark.parametrize("n", [9, 20])
 def test_gabor_other_kernel_sizes_exact(hip_ctx, n):
     """Bank sizes other than 16 take the generic Gabor kernel."""
