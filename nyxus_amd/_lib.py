@@ -160,9 +160,9 @@ class Context:
     def __del__(self):
         # a context that is still alive when the interpreter shuts down was closed by _close_live_contexts (atexit: before the
         # HIP runtime's own exit handlers); one collected later than that must not call into a runtime that may be gone
-        if sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():    # (module globals may already be cleared at that point)
+                return
             self.close()
         except Exception:
             pass

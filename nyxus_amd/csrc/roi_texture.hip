@@ -400,6 +400,80 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     TSTAMP(2);
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
                 }
+            } else if (nslot >= 4 && w > 64 && w <= 128) {
+                // Boxes 65..128 wide: the same one-wave-per-direction row scans over TWO chunks of 64 columns (lane = column and
+                // column + 64).  E: a run that reaches column 63 continues with the second chunk's string of set bits.  SE / SW:
+                // the run state that leaves one chunk enters the other through v_readlane (wave-uniform), the state that leaves
+                // the box is counted before the shift.  (The per-pixel walk below made a 65-wide box 2.8 times as expensive as a
+                // 63-wide one.)
+                blk_sync<GS>();
+                for (uint32_t i = tid; i < 4u * slot_words; i += kBlock) s_mat[i] = 0;
+                blk_sync<GS>();
+                {
+                    uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
+                    const bool in1 = (uint32_t)lane + 64u < w;
+                    uint32_t* const Pm = P - (Nr + 1);
+                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
+                    auto count_at = [=](uint32_t rm, uint32_t rl) { atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u); };
+                    auto load0 = [=](uint32_t row) -> uint32_t { return row < h ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u; };
+                    auto load1 = [=](uint32_t row) -> uint32_t { return (in1 && row < h) ? (uint32_t)s_dense[row * w + 64u + (uint32_t)lane] : 0u; };
+                    uint32_t vn0 = load0(0), vn1 = load1(0);
+                    if (wave == 0) {
+                        for (uint32_t row = 0; row < h; row++) {
+                            const uint32_t v0 = vn0, v1 = vn1;
+                            vn0 = load0(row + 1); vn1 = load1(row + 1);
+                            const uint32_t v1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v1);
+                            const uint32_t nx0 = lane_plus1(v0, v1_0), nx1 = lane_plus1(v1, 0u);
+                            const unsigned long long same0 = __ballot(v0 != 0 && v0 == nx0);          // bit 63: column 63 continues in column 64
+                            const unsigned long long same1 = __ballot((uint32_t)lane + 65u < w && v1 != 0 && v1 == nx1);
+                            const uint32_t head1 = (uint32_t)__ffsll((long long)~same1) - 1u;          // ones at the start of the second chunk (< 64: its last column never continues)
+                            if (v0 != 0 && !(lane > 0 && ((same0 >> (lane - 1)) & 1ull))) {
+                                const unsigned long long rest = ~(same0 >> lane);                      // (the shift zero-fills from the top)
+                                const uint32_t t = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u; // set bits from this lane on (all 64 at lane 0: rest = 0)
+                                const bool through = t == 64u - (uint32_t)lane;                        // all of bits lane..63 set
+                                count_run(v0, through ? t + 1u + head1 : t + 1u);
+                            }
+                            const bool cont = lane > 0 ? ((same1 >> (lane - 1)) & 1ull) != 0 : (same0 >> 63) != 0;
+                            if (in1 && v1 != 0 && !cont)
+                                count_run(v1, (uint32_t)__ffsll((long long)~(same1 >> lane)));
+                        }
+                    } else {
+                        const int dx = wave == 1 ? 1 : wave == 2 ? 0 : -1;                   // glrlm.cpp:128-176
+                        uint32_t rv0 = 0, rl0 = 0, rm0 = 0, rv1 = 0, rl1 = 0, rm1 = 0;        // runs of the two chunks: level, length, matrix row + 1
+                        for (uint32_t row = 0; row < h; row++) {
+                            if (dx == 1) {
+                                if (w == 128 && lane == 63 && rv1 != 0) count_at(rm1, rl1);
+                                const uint32_t a = readlane63(rv0), bq = readlane63(rl0), c = readlane63(rm0);
+                                rv1 = lane_minus1(rv1, a); rl1 = lane_minus1(rl1, bq); rm1 = lane_minus1(rm1, c);
+                                rv0 = lane_minus1(rv0, 0u); rl0 = lane_minus1(rl0, 0u); rm0 = lane_minus1(rm0, 0u);
+                            } else if (dx == -1) {
+                                if (lane == 0 && rv0 != 0) count_at(rm0, rl0);
+                                const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv1), bq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl1),
+                                               c = (uint32_t)__builtin_amdgcn_readfirstlane((int)rm1);
+                                rv0 = lane_plus1(rv0, a); rl0 = lane_plus1(rl0, bq); rm0 = lane_plus1(rm0, c);
+                                rv1 = lane_plus1(rv1, 0u); rl1 = lane_plus1(rl1, 0u); rm1 = lane_plus1(rm1, 0u);
+                            }
+                            const uint32_t v0 = vn0, v1 = vn1;
+                            vn0 = load0(row + 1); vn1 = load1(row + 1);
+                            if (v0 != 0 && v0 == rv0) rl0++;
+                            else {
+                                if (rv0 != 0) count_at(rm0, rl0);
+                                rv0 = v0; rl0 = v0 != 0 ? 1u : 0u;
+                                rm0 = v0 != 0 ? (uint32_t)s_lvlmap[v0] : 0u;
+                            }
+                            if (v1 != 0 && v1 == rv1) rl1++;
+                            else {
+                                if (rv1 != 0) count_at(rm1, rl1);
+                                rv1 = v1; rl1 = v1 != 0 ? 1u : 0u;
+                                rm1 = v1 != 0 ? (uint32_t)s_lvlmap[v1] : 0u;
+                            }
+                        }
+                        if (rv0 != 0) count_at(rm0, rl0);
+                        if (rv1 != 0) count_at(rm1, rl1);
+                    }
+                    wav_sync<GS>();
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
+                }
             } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
                 for (int a0 = 0; a0 < 4; a0 += per) {
@@ -578,6 +652,67 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
                     v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
                 }
+            } else if (wave == solo && w <= 128) {
+                // bounding boxes 65..128 wide: the same register sweep over TWO chunks of 64 columns per row (lane = column and
+                // column + 64).  What crosses the chunk boundary is wave-uniform and travels through v_readlane: the NE
+                // predecessor of column 63 / the NW predecessor and the W chain of column 64.  A run that continues into the
+                // second chunk hands over its (already final) label before that chunk's scan; a string of equal labels is counted
+                // once per chunk.  (The chunked LDS sweep below made a 65-wide box 4.6 times as expensive as a 63-wide one.)
+                uint32_t vp0 = 0, vp1 = 0, lp0 = 0xFFFFFFFFu, lp1 = 0xFFFFFFFFu;
+                const bool in1 = (uint32_t)lane + 64u < w;
+                for (uint32_t row = 0; row < h; row++) {
+                    const uint32_t p0 = row * w + (uint32_t)lane, p1 = p0 + 64u;
+                    const uint32_t v0 = (uint32_t)s_dense[p0], v1 = in1 ? (uint32_t)s_dense[p1] : 0u;
+                    uint32_t lab0 = p0, lab1 = p1;
+                    {   // N, NW, NE predecessors (final labels of the previous row)
+                        const uint32_t vp0_63 = readlane63(vp0), lp0_63 = readlane63(lp0);
+                        const uint32_t vp1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vp1), lp1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lp1);
+                        const uint32_t vW0 = lane_minus1(vp0, 0u), lW0 = lane_minus1(lp0, 0xFFFFFFFFu);
+                        const uint32_t vE0 = lane_plus1(vp0, vp1_0), lE0 = lane_plus1(lp0, lp1_0);
+                        if (v0 != 0) {
+                            if (vp0 == v0) lab0 = min(lab0, lp0);
+                            if (vW0 == v0) lab0 = min(lab0, lW0);
+                            if (vE0 == v0) lab0 = min(lab0, lE0);
+                        }
+                        const uint32_t vW1 = lane_minus1(vp1, vp0_63), lW1 = lane_minus1(lp1, lp0_63);
+                        const uint32_t vE1 = lane_plus1(vp1, 0u), lE1 = lane_plus1(lp1, 0xFFFFFFFFu);
+                        if (v1 != 0) {
+                            if (vp1 == v1) lab1 = min(lab1, lp1);
+                            if (vW1 == v1) lab1 = min(lab1, lW1);
+                            if (vE1 == v1) lab1 = min(lab1, lE1);
+                        }
+                    }
+                    // W chain, first chunk
+                    const uint32_t vl0 = lane_minus1(v0, 0u);
+                    const bool start0 = v0 == 0 || vl0 != v0;
+                    const unsigned long long sm0 = __ballot(start0);
+                    const uint32_t ri0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm0, 0u)) + (start0 ? 1u : 0u);
+                    lab0 = wave_scan_min_u32(((64u - ri0) << 20) | lab0) & 0xFFFFFu;
+                    // second chunk: column 64 continues column 63's run when the values agree
+                    const uint32_t v0_63 = readlane63(v0), l0_63 = readlane63(lab0);
+                    const uint32_t vl1 = lane_minus1(v1, v0_63);
+                    const bool start1 = v1 == 0 || vl1 != v1;
+                    if (lane == 0 && !start1) lab1 = min(lab1, l0_63);
+                    const unsigned long long sm1 = __ballot(start1);
+                    const uint32_t ri1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm1, 0u)) + (start1 ? 1u : 0u);
+                    lab1 = wave_scan_min_u32(((64u - ri1) << 20) | lab1) & 0xFFFFFu;    // (lanes before the first start carry bias 64: seven bits)
+                    // zone sizes: one atomic per string of equal labels and chunk
+                    const bool zp0 = v0 != 0, zp1 = in1 && v1 != 0;
+                    {
+                        const uint32_t ln = lane_plus1(lab0, 0xFFFFFFFFu);
+                        const unsigned long long same = __ballot(zp0 && ln == lab0);       // (lane 63 reads the fill: never continues)
+                        if (zp0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                            cnt_add(lab0, (uint32_t)__ffsll((long long)~(same >> lane)));
+                    }
+                    {
+                        const uint32_t ln = lane_plus1(lab1, 0xFFFFFFFFu);
+                        const unsigned long long same = __ballot(zp1 && (uint32_t)lane + 65u < w && ln == lab1);
+                        if (zp1 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                            cnt_add(lab1, (uint32_t)__ffsll((long long)~(same >> lane)));
+                    }
+                    vp0 = v0; vp1 = v1;
+                    lp0 = zp0 ? lab0 : 0xFFFFFFFFu; lp1 = zp1 ? lab1 : 0xFFFFFFFFu;
+                }
             } else if (wave == solo) {
                 for (uint32_t row = 0; row < h; row++) {
                     uint32_t carry_v = 0, carry_l = 0;       // right-most pixel of the previous chunk
@@ -616,7 +751,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             blk_sync<GS>();
             TSTAMP(4);
             // zone sizes at the owners (the DPP sweep counted on the way)
-            if (w > 64) {
+            if (w > 128) {
                 for (uint32_t p = tid; p < area; p += kBlock)
                     if (s_dense[p] != 0)
                         cnt_add(s_label[p], 1u);

@@ -583,6 +583,41 @@ def test_texture_row_scans_at_edge_widths(hip_ctx, gd):
         assert not parity.compare_tables(G, po.ref_featurize(b, TEX, s, 2), _lib.column_names(TEX, s))
 
 
+@pytest.mark.parametrize("gd", [3, 8])
+def test_texture_row_scans_on_boxes_wider_than_a_wave(hip_ctx, gd):
+    """Boxes 65 .. 128 wide take the two-chunk register sweeps (GLSZM: labels and runs crossing column 63 | 64 through
+    v_readlane), 129 and up the chunked LDS sweep: widths on both sides of both boundaries, few grey levels (long runs and
+    large zones that straddle the chunk boundary), holes, a zone that snakes across the boundary several times."""
+    rng = np.random.default_rng(23)
+    rois = []
+    for (w, h) in [(65, 5), (65, 65), (66, 3), (96, 40), (127, 9), (128, 20), (128, 1), (129, 6), (70, 70), (100, 2), (30, 100), (128, 128)]:
+        m = np.ones((h, w), bool)
+        if h > 3:
+            m &= rng.random((h, w)) > 0.08
+            m[0, 0] = m[0, w - 1] = m[h - 1, 0] = m[h - 1, w - 1] = True
+        ys, xs = np.nonzero(m)
+        v = rng.integers(1, 4, len(xs)) * 1000
+        if h >= 9:                                               # a one-level snake over columns 60..68, rows 0..8
+            snake = (xs >= 60) & (xs <= 68) & (ys < 9) & (((ys % 2 == 0)) | ((ys % 4 == 1) & (xs == 68)) | ((ys % 4 == 3) & (xs == 60)))
+            v[snake] = 2000
+        if h == 20:                                              # whole rows of one level: runs of 128, 65, 64 across the boundary
+            v[ys == 3] = 3000
+            v[(ys == 5) & (xs <= 64)] = 3000
+            v[(ys == 7) & (xs >= 64)] = 3000
+            v[(ys == 9) & (xs <= 63)] = 3000
+        rois.append(dict(x=xs, y=ys, inten=v.astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd)
+    G = hip_ctx.featurize_host(b, TEX, s)
+    O = po.oracle_featurize(b, TEX, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(TEX, s))
+    if po.have_ref():
+        assert not parity.compare_tables(G, po.ref_featurize(b, TEX, s, 2), _lib.column_names(TEX, s))
+    for fam in (_abi.FAM_GLSZM, _abi.FAM_GLRLM, _abi.FAM_NGTDM):  # each family alone (its own launch layout)
+        G1 = hip_ctx.featurize_host(b, fam, s)
+        assert not parity.compare_tables(G1, po.oracle_featurize(b, fam, s), _lib.column_names(fam, s))
+
+
 def test_output_is_bit_reproducible(hip_ctx):
     """Twenty repeated calls of all twelve families: identical bits every time (the GLSZM cell table is an ordered hash, every
     other accumulation is integer or runs in a fixed order) -- a first-come hash made GLSZM_ZE / GLV / SALGLE move by 1-2 ulp."""
