@@ -1771,21 +1771,67 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 o[c] = A.soft_nan;
             return;
         }
-        const bool dpp = A.glcm_offset == 1 && w <= 64;
         const bool symmetric = A.glcm_symmetric != 0;
+        int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+        for (int q = 0; q < kMaxAngles; q++)
+            if (q < na) {
+                const int ang = A.glcm_angles[q];
+                if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+            }
+        const bool usual = slot0 >= 0 && slot1 >= 0 && slot2 >= 0 && slot3 >= 0 && !symmetric;   // four angles, asymmetric counts
+        // lane-per-column sweeps (skip-column matrices): boxes up to a wave wide, and -- for the usual request -- boxes up to
+        // two waves wide with two columns per lane
+        const bool dpp2 = A.glcm_offset == 1 && w > 64 && w <= 128 && usual;
+        const bool dpp = (A.glcm_offset == 1 && w <= 64) || dpp2;
         blk_sync<GS>();
         for (int i = tid; i < na * (dpp ? cells : NN); i += kBlock)
             s_P[i] = 0;
         blk_sync<GS>();
         STAMP(10);
-        if (dpp) {
-            int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
-#pragma unroll
-            for (int q = 0; q < kMaxAngles; q++)
-                if (q < na) {
-                    const int ang = A.glcm_angles[q];
-                    if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+        if (dpp2) {
+            // ---- boxes 65 .. 128 wide: lane = column and column + 64.  What crosses the boundary is wave-uniform (v_readlane):
+            // the E / SE neighbours of column 63 are column 64's, the SW neighbour of column 64 is column 63's.  Lanes whose second
+            // column lies beyond the box read a zero byte behind the plane (stride 0), like the lanes beyond a narrow box; the row
+            // below the last row is tested (the zero row behind the plane is 64 bytes, not 128).  (The per-pixel loop below
+            // made the co-occurrence sweep of a 65-wide box three times as expensive as a 63-wide one.)
+            const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+            const int r_begin = wave * rows_per_wave;
+            const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+            const uint32_t ng1 = (uint32_t)NG1;
+            char* const T0 = (char*)(s_P + slot0 * cells);
+            char* const T1 = (char*)(s_P + slot1 * cells);
+            char* const T2 = (char*)(s_P + slot2 * cells);
+            char* const T3 = (char*)(s_P + slot3 * cells);
+            const bool in1 = (uint32_t)lane + 64u < w;
+            uint32_t adr0 = (uint32_t)r_begin * w + (uint32_t)lane;
+            uint32_t adr1 = in1 ? adr0 + 64u : area + (uint32_t)lane;
+            const uint32_t stride1 = in1 ? w : 0u;
+            uint32_t c0 = 0, c1 = 0;
+            if (r_begin < r_end) { c0 = (uint32_t)(*(const lds_u8_t*)adr0) << 2; c1 = (uint32_t)(*(const lds_u8_t*)adr1) << 2; }
+            auto pairs2 = [&](uint32_t c4, uint32_t e, uint32_t se, uint32_t sth, uint32_t sw) {
+                if (c4 != 0) {
+                    const uint32_t rowb = mul_u24_su(c4, ng1);
+                    atomicAdd((uint32_t*)(T0 + rowb + e), 1u);
+                    atomicAdd((uint32_t*)(T1 + rowb + se), 1u);
+                    atomicAdd((uint32_t*)(T2 + rowb + sth), 1u);
+                    atomicAdd((uint32_t*)(T3 + rowb + sw), 1u);
                 }
+            };
+            for (int row = r_begin; row < r_end; row++) {
+                adr0 += w; adr1 += stride1;
+                const bool below = row + 1 < (int)h;                                   // (wave-uniform)
+                const uint32_t n0 = (uint32_t)(*(const lds_u8_t*)adr0) << 2;           // row h reads the zero row behind the plane
+                const uint32_t r1 = (uint32_t)(*(const lds_u8_t*)adr1) << 2;
+                const uint32_t n1 = below ? r1 : 0u;
+                const uint32_t c1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1), n1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+                const uint32_t n0_63 = readlane63(n0);
+                pairs2(c0, lane_plus1(c0, c1_0), lane_plus1(n0, n1_0), n0, lane_minus1_z(n0));
+                pairs2(c1, lane_plus1_z(c1), lane_plus1_z(n1), n1, lane_minus1(n1, n0_63));
+                c0 = n0; c1 = n1;
+            }
+        } else
+        if (dpp) {
             const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
             const int r_begin = wave * rows_per_wave;
             const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
@@ -1801,7 +1847,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             const uint32_t stride = in_col ? w : 0u;
             uint32_t cur4 = r_begin < r_end ? (uint32_t)(*(const lds_u8_t*)adr) << 2 : 0u;
             adr += stride;
-            if (slot0 >= 0 && slot1 >= 0 && slot2 >= 0 && slot3 >= 0 && !symmetric) {
+            if (usual) {
                 // the usual request -- four angles, asymmetric: nothing but the four adds per row
                 auto pairs = [&](uint32_t c4, uint32_t n4) {
                     const uint32_t nb_e = lane_plus1_z(c4), nb_se = lane_plus1_z(n4), nb_sw = lane_minus1_z(n4);
@@ -2317,6 +2363,19 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
 {
     roi_features_body<false, true, FAM == 1, true, FAM, 8, false, WIN>(A);
 }
+// The same compile-time family sets and loaders at seven and six workgroups per CU: batches whose largest ROI needs a bigger
+// carve-out than the benchmark's (mixed-size data: the launch is sized by its largest ROI) keep the specialised body instead of
+// falling back to the generic one with its run-time switches and scalar-register spills.
+template <int FAM, int WIN>
+__global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_fam7(const RoiArgs A)
+{
+    roi_features_body<false, true, FAM == 1, true, FAM, 7, false, WIN>(A);
+}
+template <int FAM, int WIN>
+__global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_fam6(const RoiArgs A)
+{
+    roi_features_body<false, true, FAM == 1, true, FAM, 6, false, WIN>(A);
+}
 
 // the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
 template <int WIN>
@@ -2409,10 +2468,14 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static DeviceOnce optin;
     if (int orc = optin.run([]() -> int {
-        const void* fns[8] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
-                              (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
-                              (const void*)roi_features_kernel_occ8<1, 0>, (const void*)roi_features_kernel_occ8<2, 0>,
-                              (const void*)roi_features_kernel_occ8<1, 1>, (const void*)roi_features_kernel_occ8<2, 1>};
+        const void* fns[16] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
+                               (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
+                               (const void*)roi_features_kernel_occ8<1, 0>, (const void*)roi_features_kernel_occ8<2, 0>,
+                               (const void*)roi_features_kernel_occ8<1, 1>, (const void*)roi_features_kernel_occ8<2, 1>,
+                               (const void*)roi_features_kernel_fam7<1, 0>, (const void*)roi_features_kernel_fam7<2, 0>,
+                               (const void*)roi_features_kernel_fam7<1, 1>, (const void*)roi_features_kernel_fam7<2, 1>,
+                               (const void*)roi_features_kernel_fam6<1, 0>, (const void*)roi_features_kernel_fam6<2, 0>,
+                               (const void*)roi_features_kernel_fam6<1, 1>, (const void*)roi_features_kernel_fam6<2, 1>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -2429,8 +2492,9 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
     const bool int_only = !(a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY);
     const bool int_glcm = (a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY) && a.L.dense8 && a.glcm_ws != nullptr && !a.ibsi &&
                           a.grey_depth > 0 && a.grey_depth <= 16;
+    const bool fam_ok = C16 && SPLIT && D8 && (int_only || int_glcm);   // a compile-time family set of the compact builds applies
     int occ = 4;
-    for (int o = (C16 && SPLIT && D8 && (int_only || int_glcm)) ? 8 : 7; o > 4; o--)
+    for (int o = fam_ok ? 8 : 7; o > 4; o--)
         if ((size_t)o * a.L.total <= lds) { occ = o; break; }
     if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
     const bool win = a.win.inten != nullptr;
@@ -2438,6 +2502,14 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
     else if (occ == 8 && int_only) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 8 && win) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 8) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 7 && int_only && win) hipLaunchKernelGGL((roi_features_kernel_fam7<2, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 7 && int_only) hipLaunchKernelGGL((roi_features_kernel_fam7<2, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 7 && win) hipLaunchKernelGGL((roi_features_kernel_fam7<1, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 7) hipLaunchKernelGGL((roi_features_kernel_fam7<1, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 6 && int_only && win) hipLaunchKernelGGL((roi_features_kernel_fam6<2, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 6 && int_only) hipLaunchKernelGGL((roi_features_kernel_fam6<2, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 6 && win) hipLaunchKernelGGL((roi_features_kernel_fam6<1, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    else if (fam_ok && occ == 6) hipLaunchKernelGGL((roi_features_kernel_fam6<1, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 7) hipLaunchKernelGGL((roi_features_kernel_occ7<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 6) hipLaunchKernelGGL((roi_features_kernel_occ6<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 5) hipLaunchKernelGGL((roi_features_kernel_occ5<C16, SPLIT, D8>), dim3(grid), dim3(kBlock), a.L.total, st, a);

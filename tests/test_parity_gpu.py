@@ -618,6 +618,33 @@ def test_texture_row_scans_on_boxes_wider_than_a_wave(hip_ctx, gd):
         assert not parity.compare_tables(G1, po.oracle_featurize(b, fam, s), _lib.column_names(fam, s))
 
 
+@pytest.mark.parametrize("gd", [8, 16, 64])
+def test_intensity_glcm_on_boxes_wider_than_a_wave(hip_ctx, gd):
+    """INTENSITY + GLCM on boxes 65 .. 129 wide: the co-occurrence sweep takes two columns per lane up to 128 (the E / SE / SW
+    pairs across column 63 | 64 through v_readlane) and the per-pixel loop beyond; pairs that straddle the boundary, zero
+    intensities (skipped by the scan) on both sides of it, last rows and last columns."""
+    rng = np.random.default_rng(29)
+    rois = []
+    for (w, h) in [(65, 4), (65, 65), (66, 1), (100, 30), (127, 9), (128, 16), (129, 6), (71, 71)]:
+        m = np.ones((h, w), bool)
+        if h > 3:
+            m &= rng.random((h, w)) > 0.05
+            m[0, 0] = m[0, w - 1] = m[h - 1, 0] = m[h - 1, w - 1] = True
+        ys, xs = np.nonzero(m)
+        v = rng.integers(0, 4096, len(xs))
+        v[(xs >= 62) & (xs <= 66) & (ys % 3 == 0)] = 0            # zero intensities around the chunk boundary
+        v[0] = 4095
+        rois.append(dict(x=xs, y=ys, inten=v.astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd)
+    mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s))
+    if po.have_ref():
+        assert not parity.compare_tables(G, po.ref_featurize(b, mask, s, 2), _lib.column_names(mask, s))
+
+
 def test_output_is_bit_reproducible(hip_ctx):
     """Twenty repeated calls of all twelve families: identical bits every time (the GLSZM cell table is an ordered hash, every
     other accumulation is integer or runs in a fixed order) -- a first-come hash made GLSZM_ZE / GLV / SALGLE move by 1-2 ulp."""
