@@ -418,6 +418,31 @@ def main():
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                         "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
                                         "(no materialised clouds; one host sync inside for the ROI count)"}
+            # SURVEY 8(d)'s second synthetic set on the same path: per-ROI radius in [8, 36), 10 % concave ROIs (mixed sizes: boxes
+            # on both sides of a wave's width, load imbalance, background inside the boxes); eight distinct label tiles, cycled
+            try:
+                nvar = 8
+                lab_i = torch.from_numpy(np.stack([synth.disk_label_tile(irregular=True, seed=k) for k in range(nvar)]).astype(np.int32)).to(dev)
+                labs_i = lab_i.repeat((nt + nvar - 1) // nvar, 1, 1)[:nt].contiguous()
+
+                def tile_step_i():
+                    rc = lib.nyxhip_featurize_tiles(ctx._h, tin.data_ptr(), labs_i.data_ptr(), 1024, 1024, nt, _abi.MEM_DEVICE, 196, mask,
+                                                    C.byref(s), t_lab.data_ptr(), t_idx.data_ptr(), cap, t_out.data_ptr(), ncol, C.byref(nroi))
+                    if rc != 0:
+                        raise RuntimeError(lib.nyxhip_last_error(ctx._h).decode())
+                tile_step_i()
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(reps):
+                    tile_step_i()
+                torch.cuda.synchronize()
+                dti = (time.perf_counter() - c0) / reps
+                rec["tile_path"]["irregular"] = {"value": nroi.value / dti, "unit": "ROIs/s", "tiles": nt, "rois": int(nroi.value), "ms_per_call": 1e3 * dti,
+                                                 "what": "the same call on SURVEY 8(d)'s irregular label tiles (radius 8..35 per ROI, 10 % concave): "
+                                                         "mixed ROI sizes, bounding boxes up to 71 wide"}
+                del labs_i, lab_i
+            except Exception as ei:             # informational leg: never costs the headline line
+                rec["tile_path"]["irregular"] = {"error": repr(ei)}
             # CPU baseline of THIS leg: the reference's in-memory workflow end to end (its two serial label scans with a hash-map
             # lookup per pixel + ROI buffers + the multithreaded reduce) on a bounded sample of the same tiles
             if not a.no_cpu_baseline:

@@ -2016,6 +2016,54 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             blk_sync<GS>();
             STAMP(10);
             auto bump16 = [&](uint32_t* M, uint32_t idx) { atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
+            if (A.glcm_offset == 1 && w > 64 && w <= 128) {
+                // boxes 65 .. 128 wide: lane = column and column + 64, the pairs across column 63 | 64 through v_readlane (see the
+                // <= 16-level block above); any angle subset, symmetric counts included
+                int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+                for (int q = 0; q < kMaxAngles; q++)
+                    if (q < na) {
+                        const int ang = A.glcm_angles[q];
+                        if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                    }
+                const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                const int r_begin = wave * rows_per_wave;
+                const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                const bool in1 = (uint32_t)lane + 64u < w;
+                uint32_t adr0 = (uint32_t)r_begin * w + (uint32_t)lane;
+                uint32_t adr1 = in1 ? adr0 + 64u : area + (uint32_t)lane;
+                const uint32_t stride1 = in1 ? w : 0u;
+                const uint32_t ng1 = (uint32_t)NG1;
+                uint32_t c0 = 0, c1 = 0;
+                if (r_begin < r_end) { c0 = (uint32_t)(*(const lds_u8_t*)adr0); c1 = (uint32_t)(*(const lds_u8_t*)adr1); }
+                auto pairs2 = [&](uint32_t cur, uint32_t e, uint32_t se, uint32_t sth, uint32_t sw) {
+                    if (cur != 0) {
+                        const uint32_t rowi = mul24(cur, ng1);
+                        if (slot0 >= 0) bump16(s_P + slot0 * cellsw, rowi + e);
+                        if (slot1 >= 0) bump16(s_P + slot1 * cellsw, rowi + se);
+                        if (slot2 >= 0) bump16(s_P + slot2 * cellsw, rowi + sth);
+                        if (slot3 >= 0) bump16(s_P + slot3 * cellsw, rowi + sw);
+                        if (symmetric) {
+                            if (slot0 >= 0) bump16(s_P + slot0 * cellsw, mad24(e, ng1, cur));
+                            if (slot1 >= 0) bump16(s_P + slot1 * cellsw, mad24(se, ng1, cur));
+                            if (slot2 >= 0) bump16(s_P + slot2 * cellsw, mad24(sth, ng1, cur));
+                            if (slot3 >= 0) bump16(s_P + slot3 * cellsw, mad24(sw, ng1, cur));
+                        }
+                    }
+                };
+                for (int row = r_begin; row < r_end; row++) {
+                    adr0 += w; adr1 += stride1;
+                    const bool below = row + 1 < (int)h;
+                    const uint32_t n0 = (uint32_t)(*(const lds_u8_t*)adr0);            // row h reads the zero row behind the plane
+                    const uint32_t r1 = (uint32_t)(*(const lds_u8_t*)adr1);
+                    const uint32_t n1 = below ? r1 : 0u;                                // (that zero row is 64 bytes, not 128)
+                    const uint32_t c1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1), n1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+                    const uint32_t n0_63 = readlane63(n0);
+                    pairs2(c0, lane_plus1(c0, c1_0), lane_plus1(n0, n1_0), n0, lane_minus1_z(n0));
+                    pairs2(c1, lane_plus1_z(c1), lane_plus1_z(n1), n1, lane_minus1(n1, n0_63));
+                    c0 = n0; c1 = n1;
+                }
+            } else
             if (A.glcm_offset == 1 && w <= 64) {
                 int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
 #pragma unroll
