@@ -505,7 +505,7 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         L.szm_small = L.ng_cap <= 33 ? 32u : 0u;
         L.szm_smalltab = (uint32_t)szm; szm += 4ull * L.ng_cap * L.szm_small;
         szm = (szm + 15) & ~15ull;
-        L.szm_label = (uint32_t)szm; if (L.side_cap > 128) szm += 4ull * L.dense_cap;   // (boxes up to 128 wide keep their labels in registers)
+        L.szm_label = (uint32_t)szm; if (L.side_cap > 256) szm += 4ull * L.dense_cap;   // (boxes up to 256 wide keep their labels in registers: kSzmChunks of roi_texture.hip)
         L.szm_ok = (off + szm <= cap) ? 1 : 0;
         if (!L.szm_ok) { why = "ROI too large for the LDS-resident GLSZM zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
         need = std::max(need, szm);

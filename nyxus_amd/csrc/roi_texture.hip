@@ -196,6 +196,8 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
 // CU the 80-register build (a few spills) beats the 106-register one by 20-25 %.
 // D8: the binned plane holds 8-bit levels (grey depth <= 254, LDS launches): with it the benchmark's carve-out fits eight times
 // into a CU (the 64-register build).
+constexpr int kSzmChunks = 4;      // GLSZM row sweep in registers: boxes up to 64 * kSzmChunks wide (TexLayout: owner labels in LDS only beyond that)
+
 template <bool GS, int OCC, bool D8 = false>
 __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs A)
 {
@@ -652,66 +654,70 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
                     v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
                 }
-            } else if (wave == solo && w <= 128) {
-                // bounding boxes 65..128 wide: the same register sweep over TWO chunks of 64 columns per row (lane = column and
-                // column + 64).  What crosses the chunk boundary is wave-uniform and travels through v_readlane: the NE
-                // predecessor of column 63 / the NW predecessor and the W chain of column 64.  A run that continues into the
-                // second chunk hands over its (already final) label before that chunk's scan; a string of equal labels is counted
-                // once per chunk.  (The chunked LDS sweep below made a 65-wide box 4.6 times as expensive as a 63-wide one.)
-                uint32_t vp0 = 0, vp1 = 0, lp0 = 0xFFFFFFFFu, lp1 = 0xFFFFFFFFu;
-                const bool in1 = (uint32_t)lane + 64u < w;
+            } else if (wave == solo && w <= 64u * kSzmChunks) {
+                // bounding boxes 65 .. 256 wide: the same register sweep over up to four chunks of 64 columns per row (lane = column
+                // + 64 c).  What crosses a chunk boundary is wave-uniform and travels through v_readlane: the NE predecessor of a
+                // chunk's column 63 / the NW predecessor and the W chain of the next chunk's column 0.  A run that continues into
+                // the next chunk hands over its (already final) label before that chunk's scan; a string of equal labels is
+                // counted once per chunk.  (The chunked LDS sweep below made a 65-wide box 4.6 times as expensive as a 63-wide one.)
+                const int nch = (int)((w + 63u) >> 6);           // 2 .. kSzmChunks, wave-uniform
+                uint32_t vp[kSzmChunks], lp[kSzmChunks];
+                bool inc[kSzmChunks];
+#pragma unroll
+                for (int c = 0; c < kSzmChunks; c++) { vp[c] = 0; lp[c] = 0xFFFFFFFFu; inc[c] = (uint32_t)lane + 64u * c < w; }
                 for (uint32_t row = 0; row < h; row++) {
-                    const uint32_t p0 = row * w + (uint32_t)lane, p1 = p0 + 64u;
-                    const uint32_t v0 = (uint32_t)s_dense[p0], v1 = in1 ? (uint32_t)s_dense[p1] : 0u;
-                    uint32_t lab0 = p0, lab1 = p1;
-                    {   // N, NW, NE predecessors (final labels of the previous row)
-                        const uint32_t vp0_63 = readlane63(vp0), lp0_63 = readlane63(lp0);
-                        const uint32_t vp1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vp1), lp1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lp1);
-                        const uint32_t vW0 = lane_minus1(vp0, 0u), lW0 = lane_minus1(lp0, 0xFFFFFFFFu);
-                        const uint32_t vE0 = lane_plus1(vp0, vp1_0), lE0 = lane_plus1(lp0, lp1_0);
-                        if (v0 != 0) {
-                            if (vp0 == v0) lab0 = min(lab0, lp0);
-                            if (vW0 == v0) lab0 = min(lab0, lW0);
-                            if (vE0 == v0) lab0 = min(lab0, lE0);
+                    uint32_t v[kSzmChunks], lab[kSzmChunks];
+#pragma unroll
+                    for (int c = 0; c < kSzmChunks; c++) {
+                        const uint32_t p = row * w + (uint32_t)lane + 64u * c;
+                        v[c] = (c < nch && inc[c]) ? (uint32_t)s_dense[p] : 0u;
+                        lab[c] = p;
+                    }
+#pragma unroll
+                    for (int c = 0; c < kSzmChunks; c++) {       // N, NW, NE predecessors (final labels of the previous row)
+                        if (c < nch) {
+                            uint32_t fvW = 0u, flW = 0xFFFFFFFFu, fvE = 0u, flE = 0xFFFFFFFFu;
+                            if (c > 0) { fvW = readlane63(vp[c > 0 ? c - 1 : 0]); flW = readlane63(lp[c > 0 ? c - 1 : 0]); }
+                            if (c + 1 < kSzmChunks && c + 1 < nch) {
+                                fvE = (uint32_t)__builtin_amdgcn_readfirstlane((int)vp[c + 1 < kSzmChunks ? c + 1 : c]);
+                                flE = (uint32_t)__builtin_amdgcn_readfirstlane((int)lp[c + 1 < kSzmChunks ? c + 1 : c]);
+                            }
+                            const uint32_t vW = lane_minus1(vp[c], fvW), lW = lane_minus1(lp[c], flW);
+                            const uint32_t vE = lane_plus1(vp[c], fvE), lE = lane_plus1(lp[c], flE);
+                            if (v[c] != 0) {
+                                if (vp[c] == v[c]) lab[c] = min(lab[c], lp[c]);
+                                if (vW == v[c]) lab[c] = min(lab[c], lW);
+                                if (vE == v[c]) lab[c] = min(lab[c], lE);
+                            }
                         }
-                        const uint32_t vW1 = lane_minus1(vp1, vp0_63), lW1 = lane_minus1(lp1, lp0_63);
-                        const uint32_t vE1 = lane_plus1(vp1, 0u), lE1 = lane_plus1(lp1, 0xFFFFFFFFu);
-                        if (v1 != 0) {
-                            if (vp1 == v1) lab1 = min(lab1, lp1);
-                            if (vW1 == v1) lab1 = min(lab1, lW1);
-                            if (vE1 == v1) lab1 = min(lab1, lE1);
+                    }
+#pragma unroll
+                    for (int c = 0; c < kSzmChunks; c++) {       // W chain, chunk after chunk
+                        if (c < nch) {
+                            const uint32_t carry_v = c > 0 ? readlane63(v[c > 0 ? c - 1 : 0]) : 0u;
+                            const uint32_t vl = lane_minus1(v[c], carry_v);
+                            const bool start = v[c] == 0 || vl != v[c];
+                            if (c > 0) {
+                                const uint32_t carry_l = readlane63(lab[c > 0 ? c - 1 : 0]);     // (final: the previous chunk is scanned)
+                                if (lane == 0 && !start) lab[c] = min(lab[c], carry_l);
+                            }
+                            const unsigned long long smk = __ballot(start);
+                            const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(smk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smk, 0u)) + (start ? 1u : 0u);
+                            lab[c] = wave_scan_min_u32(((64u - ri) << 20) | lab[c]) & 0xFFFFFu;   // (lanes before the first start carry bias 64: seven bits)
                         }
                     }
-                    // W chain, first chunk
-                    const uint32_t vl0 = lane_minus1(v0, 0u);
-                    const bool start0 = v0 == 0 || vl0 != v0;
-                    const unsigned long long sm0 = __ballot(start0);
-                    const uint32_t ri0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm0, 0u)) + (start0 ? 1u : 0u);
-                    lab0 = wave_scan_min_u32(((64u - ri0) << 20) | lab0) & 0xFFFFFu;
-                    // second chunk: column 64 continues column 63's run when the values agree
-                    const uint32_t v0_63 = readlane63(v0), l0_63 = readlane63(lab0);
-                    const uint32_t vl1 = lane_minus1(v1, v0_63);
-                    const bool start1 = v1 == 0 || vl1 != v1;
-                    if (lane == 0 && !start1) lab1 = min(lab1, l0_63);
-                    const unsigned long long sm1 = __ballot(start1);
-                    const uint32_t ri1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm1, 0u)) + (start1 ? 1u : 0u);
-                    lab1 = wave_scan_min_u32(((64u - ri1) << 20) | lab1) & 0xFFFFFu;    // (lanes before the first start carry bias 64: seven bits)
-                    // zone sizes: one atomic per string of equal labels and chunk
-                    const bool zp0 = v0 != 0, zp1 = in1 && v1 != 0;
-                    {
-                        const uint32_t ln = lane_plus1(lab0, 0xFFFFFFFFu);
-                        const unsigned long long same = __ballot(zp0 && ln == lab0);       // (lane 63 reads the fill: never continues)
-                        if (zp0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                            cnt_add(lab0, (uint32_t)__ffsll((long long)~(same >> lane)));
+#pragma unroll
+                    for (int c = 0; c < kSzmChunks; c++) {       // zone sizes: one atomic per string of equal labels and chunk
+                        if (c < nch) {
+                            const bool zp = inc[c] && v[c] != 0;
+                            const uint32_t ln = lane_plus1(lab[c], 0xFFFFFFFFu);                   // (lane 63 reads the fill: never continues)
+                            const unsigned long long same = __ballot(zp && (uint32_t)lane + 64u * c + 1u < w && ln == lab[c]);
+                            if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                                cnt_add(lab[c], (uint32_t)__ffsll((long long)~(same >> lane)));
+                            vp[c] = v[c];
+                            lp[c] = zp ? lab[c] : 0xFFFFFFFFu;
+                        }
                     }
-                    {
-                        const uint32_t ln = lane_plus1(lab1, 0xFFFFFFFFu);
-                        const unsigned long long same = __ballot(zp1 && (uint32_t)lane + 65u < w && ln == lab1);
-                        if (zp1 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                            cnt_add(lab1, (uint32_t)__ffsll((long long)~(same >> lane)));
-                    }
-                    vp0 = v0; vp1 = v1;
-                    lp0 = zp0 ? lab0 : 0xFFFFFFFFu; lp1 = zp1 ? lab1 : 0xFFFFFFFFu;
                 }
             } else if (wave == solo) {
                 for (uint32_t row = 0; row < h; row++) {
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             blk_sync<GS>();
             TSTAMP(4);
             // zone sizes at the owners (the DPP sweep counted on the way)
-            if (w > 128) {
+            if (w > 64u * kSzmChunks) {
                 for (uint32_t p = tid; p < area; p += kBlock)
                     if (s_dense[p] != 0)
                         cnt_add(s_label[p], 1u);

@@ -590,7 +590,8 @@ def test_texture_row_scans_on_boxes_wider_than_a_wave(hip_ctx, gd):
     large zones that straddle the chunk boundary), holes, a zone that snakes across the boundary several times."""
     rng = np.random.default_rng(23)
     rois = []
-    for (w, h) in [(65, 5), (65, 65), (66, 3), (96, 40), (127, 9), (128, 20), (128, 1), (129, 6), (70, 70), (100, 2), (30, 100), (128, 128)]:
+    for (w, h) in [(65, 5), (65, 65), (66, 3), (96, 40), (127, 9), (128, 20), (128, 1), (129, 6), (70, 70), (100, 2), (30, 100), (128, 128),
+                   (129, 20), (192, 9), (193, 12), (255, 7), (256, 20), (257, 5), (200, 60)]:
         m = np.ones((h, w), bool)
         if h > 3:
             m &= rng.random((h, w)) > 0.08
@@ -600,6 +601,12 @@ def test_texture_row_scans_on_boxes_wider_than_a_wave(hip_ctx, gd):
         if h >= 9:                                               # a one-level snake over columns 60..68, rows 0..8
             snake = (xs >= 60) & (xs <= 68) & (ys < 9) & (((ys % 2 == 0)) | ((ys % 4 == 1) & (xs == 68)) | ((ys % 4 == 3) & (xs == 60)))
             v[snake] = 2000
+        if h == 20 and w >= 200:                                 # one level across all four chunks, and runs that end / begin at each boundary
+            v[ys == 11] = 3000
+            for cb in (64, 128, 192):
+                v[(ys == 13) & (xs >= cb - 3) & (xs <= cb + 2)] = 2000
+                v[(ys == 15) & (xs == cb - 1)] = 1000
+                v[(ys == 15) & (xs == cb)] = 2000
         if h == 20:                                              # whole rows of one level: runs of 128, 65, 64 across the boundary
             v[ys == 3] = 3000
             v[(ys == 5) & (xs <= 64)] = 3000
