@@ -196,6 +196,7 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
 // CU the 80-register build (a few spills) beats the 106-register one by 20-25 %.
 // D8: the binned plane holds 8-bit levels (grey depth <= 254, LDS launches): with it the benchmark's carve-out fits eight times
 // into a CU (the 64-register build).
+constexpr int kRlmChunks = 4;      // GLRLM row scans in registers: boxes up to 64 * kRlmChunks wide
 constexpr int kSzmChunks = 4;      // GLSZM row sweep in registers: boxes up to 64 * kSzmChunks wide (TexLayout: owner labels in LDS only beyond that)
 
 template <bool GS, int OCC, bool D8 = false>
@@ -402,76 +403,113 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     TSTAMP(2);
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
                 }
-            } else if (nslot >= 4 && w > 64 && w <= 128) {
-                // Boxes 65..128 wide: the same one-wave-per-direction row scans over TWO chunks of 64 columns (lane = column and
-                // column + 64).  E: a run that reaches column 63 continues with the second chunk's string of set bits.  SE / SW:
-                // the run state that leaves one chunk enters the other through v_readlane (wave-uniform), the state that leaves
-                // the box is counted before the shift.  (The per-pixel walk below made a 65-wide box 2.8 times as expensive as a
-                // 63-wide one.)
+            } else if (nslot >= 4 && w > 64 && w <= 64u * kRlmChunks) {
+                // Boxes 65 .. 256 wide: the same one-wave-per-direction row scans over up to four chunks of 64 columns (lane =
+                // column + 64 c).  E: a run that reaches a chunk's column 63 continues with the following chunks' strings of set
+                // bits (their lengths are wave-uniform).  SE / SW: the run state that leaves one chunk enters the next through
+                // v_readlane, the state that leaves the box is counted before the shift.  (The per-pixel walk below made a 65-wide
+                // box 2.8 times as expensive as a 63-wide one.)
                 blk_sync<GS>();
                 for (uint32_t i = tid; i < 4u * slot_words; i += kBlock) s_mat[i] = 0;
                 blk_sync<GS>();
                 {
                     uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
-                    const bool in1 = (uint32_t)lane + 64u < w;
+                    const int nch = (int)((w + 63u) >> 6);           // 2 .. kRlmChunks, wave-uniform
+                    bool inc[kRlmChunks];
+#pragma unroll
+                    for (int c = 0; c < kRlmChunks; c++) inc[c] = (uint32_t)lane + 64u * c < w;
                     uint32_t* const Pm = P - (Nr + 1);
                     auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
                     auto count_at = [=](uint32_t rm, uint32_t rl) { atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u); };
-                    auto load0 = [=](uint32_t row) -> uint32_t { return row < h ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u; };
-                    auto load1 = [=](uint32_t row) -> uint32_t { return (in1 && row < h) ? (uint32_t)s_dense[row * w + 64u + (uint32_t)lane] : 0u; };
-                    uint32_t vn0 = load0(0), vn1 = load1(0);
+                    auto load = [=](uint32_t row, int c, bool in) -> uint32_t {
+                        return (in && row < h) ? (uint32_t)s_dense[row * w + 64u * (uint32_t)c + (uint32_t)lane] : 0u;
+                    };
+                    uint32_t vn[kRlmChunks];
+#pragma unroll
+                    for (int c = 0; c < kRlmChunks; c++) vn[c] = c < nch ? load(0, c, inc[c]) : 0u;
                     if (wave == 0) {
                         for (uint32_t row = 0; row < h; row++) {
-                            const uint32_t v0 = vn0, v1 = vn1;
-                            vn0 = load0(row + 1); vn1 = load1(row + 1);
-                            const uint32_t v1_0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v1);
-                            const uint32_t nx0 = lane_plus1(v0, v1_0), nx1 = lane_plus1(v1, 0u);
-                            const unsigned long long same0 = __ballot(v0 != 0 && v0 == nx0);          // bit 63: column 63 continues in column 64
-                            const unsigned long long same1 = __ballot((uint32_t)lane + 65u < w && v1 != 0 && v1 == nx1);
-                            const uint32_t head1 = (uint32_t)__ffsll((long long)~same1) - 1u;          // ones at the start of the second chunk (< 64: its last column never continues)
-                            if (v0 != 0 && !(lane > 0 && ((same0 >> (lane - 1)) & 1ull))) {
-                                const unsigned long long rest = ~(same0 >> lane);                      // (the shift zero-fills from the top)
-                                const uint32_t t = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u; // set bits from this lane on (all 64 at lane 0: rest = 0)
-                                const bool through = t == 64u - (uint32_t)lane;                        // all of bits lane..63 set
-                                count_run(v0, through ? t + 1u + head1 : t + 1u);
+                            uint32_t v[kRlmChunks];
+                            unsigned long long same[kRlmChunks];
+#pragma unroll
+                            for (int c = 0; c < kRlmChunks; c++) { v[c] = vn[c]; vn[c] = c < nch ? load(row + 1, c, inc[c]) : 0u; }
+#pragma unroll
+                            for (int c = 0; c < kRlmChunks; c++) {
+                                const uint32_t fill = (c + 1 < kRlmChunks && c + 1 < nch) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[c + 1 < kRlmChunks ? c + 1 : c]) : 0u;
+                                const uint32_t nx = lane_plus1(v[c], fill);
+                                same[c] = c < nch ? __ballot((uint32_t)lane + 64u * c + 1u < w && v[c] != 0 && v[c] == nx) : 0ull;   // bit 63: continues in the next chunk
                             }
-                            const bool cont = lane > 0 ? ((same1 >> (lane - 1)) & 1ull) != 0 : (same0 >> 63) != 0;
-                            if (in1 && v1 != 0 && !cont)
-                                count_run(v1, (uint32_t)__ffsll((long long)~(same1 >> lane)));
+                            // pixels a run gains beyond chunk c once it passes that chunk's column 63 (wave-uniform, last chunk first)
+                            uint32_t ext[kRlmChunks];
+#pragma unroll
+                            for (int c = kRlmChunks - 1; c >= 0; c--) {
+                                if (c + 1 < kRlmChunks) {
+                                    const unsigned long long nxt = same[c + 1 < kRlmChunks ? c + 1 : c];
+                                    const uint32_t head = ~nxt ? (uint32_t)__ffsll((long long)~nxt) - 1u : 64u;
+                                    ext[c] = head + (head == 64u ? ext[c + 1 < kRlmChunks ? c + 1 : c] : 0u);
+                                } else
+                                    ext[c] = 0u;
+                            }
+#pragma unroll
+                            for (int c = 0; c < kRlmChunks; c++) {
+                                if (c < nch) {
+                                    const bool cont = lane > 0 ? ((same[c] >> (lane - 1)) & 1ull) != 0 : (c > 0 ? (same[c > 0 ? c - 1 : 0] >> 63) != 0 : false);
+                                    if (inc[c] && v[c] != 0 && !cont) {
+                                        const unsigned long long rest = ~(same[c] >> lane);                 // (the shift zero-fills from the top)
+                                        const uint32_t t = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;   // set bits from this lane on
+                                        const bool through = t == 64u - (uint32_t)lane;                       // all of bits lane .. 63 set
+                                        count_run(v[c], through ? t + 1u + ext[c] : t + 1u);
+                                    }
+                                }
+                            }
                         }
                     } else {
                         const int dx = wave == 1 ? 1 : wave == 2 ? 0 : -1;                   // glrlm.cpp:128-176
-                        uint32_t rv0 = 0, rl0 = 0, rm0 = 0, rv1 = 0, rl1 = 0, rm1 = 0;        // runs of the two chunks: level, length, matrix row + 1
+                        uint32_t rv[kRlmChunks], rl[kRlmChunks], rm[kRlmChunks];              // runs of the chunks: level, length, matrix row + 1
+#pragma unroll
+                        for (int c = 0; c < kRlmChunks; c++) { rv[c] = 0; rl[c] = 0; rm[c] = 0; }
+                        const bool full_last = w == 64u * (uint32_t)nch;                      // the last chunk's lane 63 is a column of the box
                         for (uint32_t row = 0; row < h; row++) {
                             if (dx == 1) {
-                                if (w == 128 && lane == 63 && rv1 != 0) count_at(rm1, rl1);
-                                const uint32_t a = readlane63(rv0), bq = readlane63(rl0), c = readlane63(rm0);
-                                rv1 = lane_minus1(rv1, a); rl1 = lane_minus1(rl1, bq); rm1 = lane_minus1(rm1, c);
-                                rv0 = lane_minus1(rv0, 0u); rl0 = lane_minus1(rl0, 0u); rm0 = lane_minus1(rm0, 0u);
+#pragma unroll
+                                for (int c = kRlmChunks - 1; c >= 0; c--) {
+                                    if (c < nch) {
+                                        if (c == nch - 1 && full_last && lane == 63 && rv[c] != 0) count_at(rm[c], rl[c]);
+                                        const uint32_t a = c > 0 ? readlane63(rv[c > 0 ? c - 1 : 0]) : 0u, bq = c > 0 ? readlane63(rl[c > 0 ? c - 1 : 0]) : 0u,
+                                                       cq = c > 0 ? readlane63(rm[c > 0 ? c - 1 : 0]) : 0u;
+                                        rv[c] = lane_minus1(rv[c], a); rl[c] = lane_minus1(rl[c], bq); rm[c] = lane_minus1(rm[c], cq);
+                                    }
+                                }
                             } else if (dx == -1) {
-                                if (lane == 0 && rv0 != 0) count_at(rm0, rl0);
-                                const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv1), bq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl1),
-                                               c = (uint32_t)__builtin_amdgcn_readfirstlane((int)rm1);
-                                rv0 = lane_plus1(rv0, a); rl0 = lane_plus1(rl0, bq); rm0 = lane_plus1(rm0, c);
-                                rv1 = lane_plus1(rv1, 0u); rl1 = lane_plus1(rl1, 0u); rm1 = lane_plus1(rm1, 0u);
+                                if (lane == 0 && rv[0] != 0) count_at(rm[0], rl[0]);
+#pragma unroll
+                                for (int c = 0; c < kRlmChunks; c++) {
+                                    if (c < nch) {
+                                        const bool more = c + 1 < kRlmChunks && c + 1 < nch;
+                                        const uint32_t a = more ? (uint32_t)__builtin_amdgcn_readfirstlane((int)rv[c + 1 < kRlmChunks ? c + 1 : c]) : 0u,
+                                                       bq = more ? (uint32_t)__builtin_amdgcn_readfirstlane((int)rl[c + 1 < kRlmChunks ? c + 1 : c]) : 0u,
+                                                       cq = more ? (uint32_t)__builtin_amdgcn_readfirstlane((int)rm[c + 1 < kRlmChunks ? c + 1 : c]) : 0u;
+                                        rv[c] = lane_plus1(rv[c], a); rl[c] = lane_plus1(rl[c], bq); rm[c] = lane_plus1(rm[c], cq);
+                                    }
+                                }
                             }
-                            const uint32_t v0 = vn0, v1 = vn1;
-                            vn0 = load0(row + 1); vn1 = load1(row + 1);
-                            if (v0 != 0 && v0 == rv0) rl0++;
-                            else {
-                                if (rv0 != 0) count_at(rm0, rl0);
-                                rv0 = v0; rl0 = v0 != 0 ? 1u : 0u;
-                                rm0 = v0 != 0 ? (uint32_t)s_lvlmap[v0] : 0u;
-                            }
-                            if (v1 != 0 && v1 == rv1) rl1++;
-                            else {
-                                if (rv1 != 0) count_at(rm1, rl1);
-                                rv1 = v1; rl1 = v1 != 0 ? 1u : 0u;
-                                rm1 = v1 != 0 ? (uint32_t)s_lvlmap[v1] : 0u;
+#pragma unroll
+                            for (int c = 0; c < kRlmChunks; c++) {
+                                if (c < nch) {
+                                    const uint32_t v = vn[c];
+                                    vn[c] = load(row + 1, c, inc[c]);
+                                    if (v != 0 && v == rv[c]) rl[c]++;
+                                    else {
+                                        if (rv[c] != 0) count_at(rm[c], rl[c]);
+                                        rv[c] = v; rl[c] = v != 0 ? 1u : 0u;
+                                        rm[c] = v != 0 ? (uint32_t)s_lvlmap[v] : 0u;
+                                    }
+                                }
                             }
                         }
-                        if (rv0 != 0) count_at(rm0, rl0);
-                        if (rv1 != 0) count_at(rm1, rl1);
+#pragma unroll
+                        for (int c = 0; c < kRlmChunks; c++)
+                            if (c < nch && rv[c] != 0) count_at(rm[c], rl[c]);
                     }
                     wav_sync<GS>();
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
