@@ -568,19 +568,27 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     // neighbours yields both their level sum (bits 0..23) and their number (bits 24..27); |840 i - sum * (840 / nd)| is 32-bit
     // arithmetic (24-bit multiplies, one v_sad_u32), 840 / nd comes from a nine-entry LDS table, and while a level's sum cannot
     // reach 2^32 the accumulation is a 32-bit LDS atomic on the low word.  ~27 vector instructions per row (70 before).
-    auto ngtdm_rows = [&](int r_begin, int r_end) {
-        const bool in_col = (uint32_t)lane < w;
+    // (col0: first column of the 64-column chunk the wave's lanes stand for -- boxes wider than a wave take the stencil chunk by
+    //  chunk; the columns just outside a chunk are wave-uniform plane reads that fill the lane shifts' open ends)
+    auto ngtdm_rows = [&](int r_begin, int r_end, uint32_t col0 = 0u) {
+        const bool in_col = col0 + (uint32_t)lane < w;
         const uint32_t* const s_q = (const uint32_t*)(s_stat + 8);
         const bool sum32 = (unsigned long long)area * 840ull * (unsigned long long)(greyInfo == 0 ? Ng + 1 : (int)s_lv[Ng > 0 ? Ng - 1 : 0]) < (1ull << 32);
-        auto load_row = [=](int r) -> uint32_t {
-            const uint32_t v = (in_col && r >= 0 && r < (int)h) ? (uint32_t)s_dense[(uint32_t)r * w + (uint32_t)lane] : 0u;
+        auto code_at = [=](int r, uint32_t cl, bool ok) -> uint32_t {
+            const uint32_t v = (ok && r >= 0 && r < (int)h) ? (uint32_t)s_dense[(uint32_t)r * w + cl] : 0u;
             return v | (min(v, 1u) << 24);
         };
+        auto load_row = [=](int r) -> uint32_t { return code_at(r, col0 + (uint32_t)lane, in_col); };
+        const bool has_w = col0 > 0u, has_e = col0 + 64u < w;        // a column of the box to the chunk's left / right
+        auto west = [=](int r) -> uint32_t { return has_w ? code_at(r, col0 - 1u, true) : 0u; };
+        auto east = [=](int r) -> uint32_t { return has_e ? code_at(r, col0 + 64u, true) : 0u; };
         uint32_t prv = load_row(r_begin - 1), cur = load_row(r_begin);
+        uint32_t prv_w = west(r_begin - 1), cur_w = west(r_begin), prv_e = east(r_begin - 1), cur_e = east(r_begin);
         for (int row = r_begin; row < r_end; row++) {
             const uint32_t nxt = load_row(row + 1);
-            const uint32_t pw = lane_minus1(prv, 0u), pe = lane_plus1(prv, 0u), cw = lane_minus1(cur, 0u), ce = lane_plus1(cur, 0u),
-                           nw = lane_minus1(nxt, 0u), ne = lane_plus1(nxt, 0u);
+            const uint32_t nxt_w = west(row + 1), nxt_e = east(row + 1);
+            const uint32_t pw = lane_minus1(prv, prv_w), pe = lane_plus1(prv, prv_e), cw = lane_minus1(cur, cur_w), ce = lane_plus1(cur, cur_e),
+                           nw = lane_minus1(nxt, nxt_w), ne = lane_plus1(nxt, nxt_e);
             const uint32_t tot = ((pw + prv) + (pe + cw)) + ((ce + nw) + (nxt + ne));
             if (cur != 0 && tot >= (1u << 24)) {
                 const uint32_t lvl = cur & 0xFFFFFFu, sum = tot & 0xFFFFFFu, nd = tot >> 24;
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 else atomicAdd(&s_S[r], (unsigned long long)d);
             }
             prv = cur; cur = nxt;
+            prv_w = cur_w; cur_w = nxt_w; prv_e = cur_e; cur_e = nxt_e;
         }
     };
     bool ngt_stencil_done = false;
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
             // The row sweep below occupies ONE wave (a serial chain over the rows); with accumulators of its own the NGTDM stencil
             // runs on the other three meanwhile instead of adding its time afterwards.
-            const bool ngt_here = ngt_own && do_ngt && NgT >= 2 && w <= 64;
+            const bool ngt_here = ngt_own && do_ngt && NgT >= 2 && w <= 64u * kSzmChunks;   // (the widths the register sweep below takes)
             if (ngt_here)
                 for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
             blk_sync<GS>();
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 if (wave != solo) {
                     const int k = (wave - solo - 1) & 3, per = ((int)h + 2) / 3;                 // k = 0, 1, 2
                     const int rb = k * per, re = rb + per < (int)h ? rb + per : (int)h;
-                    ngtdm_rows(rb, re);
+                    for (uint32_t c0 = 0; c0 < w; c0 += 64u) ngtdm_rows(rb, re, c0);
                 }
             }
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
@@ -971,10 +980,11 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             }
             if (ngt_stencil_done) {
                 // (the sums were taken during the GLSZM row sweep)
-            } else if (w <= 64) {
+            } else if (w <= 64u * kSzmChunks) {
                 const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
                 const int r_begin = wave * rows_per_wave;
-                ngtdm_rows(r_begin, (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h);
+                for (uint32_t c0 = 0; c0 < w; c0 += 64u)
+                    ngtdm_rows(r_begin, (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h, c0);
             } else {
             RowCol rc((uint32_t)tid, kBlock, w);
             for (uint32_t p = tid; p < area; p += kBlock, rc.advance()) {
