@@ -289,6 +289,17 @@ int nyxhip_timing_enable(nyxhip_ctx* ctx, int on);
 int nyxhip_timing_reset(nyxhip_ctx* ctx);
 int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launches);
 
+/* The size classes of the LAST nyxhip_featurize_batch[_async] call on this context, as launched: a JSON array written to
+ * buf (NUL-terminated, truncated to buf_len), one object per launch group:
+ *   {"class": c, "size_class": 0..4, "wide_range": 0|1, "rois": n, "max_px": .., "max_bbox_area": .., "max_range": ..,
+ *    "max_side": .., "workspace": 0|1|2, "ms": t}
+ * "class" -1 = the whole batch in one launch group (batch extrema stated by the caller and small); "workspace" 0 = kernels
+ * with their state in LDS, 1 = INTENSITY + GLCM from the global workspace, 2 = every kernel group; "ms" = device time of the
+ * class's launches when nyxhip_timing_enable(ctx, 1) was in force for the call (waits for them), else null.  Counterpart in the
+ * reference: none -- its worker threads take ROIs of any size (parallel.h:23-42); here a launch is sized by its largest
+ * ROI, so a call is split by ROI size.  Returns the number of bytes the full text needs (excluding the NUL), or < 0. */
+int nyxhip_launch_report(nyxhip_ctx* ctx, char* buf, size_t buf_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "nyxhip_featurize_batch_async", "nyxhip_sync", "nyxhip_finalize_table", "nyxhip_featurize_tile", "nyxhip_featurize_tiles",
     "nyxhip_timing_enable", "nyxhip_timing_reset", "nyxhip_timing_get",
     "nyxhip_featurize_tiles_v2", "nyxhip_fetch_result", "nyxhip_featurize_tiles_sharded", "nyxhip_fetch_result_sharded",
+    "nyxhip_launch_report",
 ]
 
 
@@ -105,6 +106,8 @@ def load() -> C.CDLL:
     lib.nyxhip_timing_reset.restype = C.c_int
     lib.nyxhip_timing_get.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
     lib.nyxhip_timing_get.restype = C.c_int
+    lib.nyxhip_launch_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.nyxhip_launch_report.restype = C.c_int
     _lib = lib
     return lib
 
@@ -259,6 +262,15 @@ class Context:
 
     def timing_reset(self):
         self._check(self._lib.nyxhip_timing_reset(self._h))
+
+    def launch_report(self):
+        """The size classes of the last featurize_batch call as launched (list of dicts; nyxhip_launch_report)."""
+        import json
+        buf = C.create_string_buffer(1 << 14)
+        n = self._lib.nyxhip_launch_report(self._h, buf, len(buf))
+        if n < 0:
+            raise NyxHipError(-n, "launch report")
+        return json.loads(buf.value.decode())
 
     def timing_get(self):
         ms = C.c_double()

@@ -19,6 +19,15 @@
 
 using namespace nyxhip;
 
+struct Extrema { uint32_t px, area, range, side; };
+struct ClassRun {              // one size class of one call, as launched (nyxhip_launch_report)
+    int cls;                   // 2 * size class + (1: some ROI needs 32-bit tables); -1: the whole batch in one launch group
+    uint32_t count;            // members (0xFFFFFFFF: counted on the device only)
+    Extrema E;                 // extrema the carve-outs were sized for
+    int workspace;             // 0: LDS launches, 1: INTENSITY + GLCM from the global workspace, 2: every kernel group
+    hipEvent_t e0, e1;         // around the class's launches (timing enabled), else NULL
+};
+
 struct nyxhip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -67,6 +76,12 @@ struct nyxhip_ctx {
     double* res_table() const { return (double*)d_res; }
     uint32_t* res_label() const { return (uint32_t*)((char*)d_res + (((size_t)res_cap * res_cols * 8 + 255) & ~(size_t)255)); }
     uint32_t* res_tile() const { return res_label() + res_cap; }
+    // size classes of a call (launch_device_all): ROI indices grouped by class, class headers on the device and their pinned host copy
+    uint32_t* d_cls_list = nullptr;
+    size_t cls_list_bytes = 0;
+    uint32_t* d_cls_hdr = nullptr;
+    uint32_t* h_cls_hdr = nullptr;
+    std::vector<ClassRun> runs;         // the classes of the last call as launched (nyxhip_launch_report)
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -489,11 +504,10 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         need = std::max(need, (size_t)(L.ng_cap + 2) * (8 + 4 + 8 + 8) + 64);
     if (mask & NYXHIP_FAM_GLSZM) {
         // distinct (level, size) pairs <= sqrt(2 * Ng * area) (sizes of one level sum to <= its area)
-        double bound = sqrt(2.0 * (double)L.ng_cap * (double)L.dense_cap) + (double)L.ng_cap;
-        uint32_t distinct = (uint32_t)std::min((double)L.dense_cap, bound) + 1;
         // (load <= 2/3 in the worst case; zones of up to 32 pixels bypass the hash altogether when the direct table exists.  With
-        //  2 * distinct the benchmark's carve-out was 4 KiB larger: six instead of seven workgroups per CU)
-        L.hash_cap = pow2ceil(distinct + distinct / 2 + 8);
+        //  2 * distinct the benchmark's carve-out was 4 KiB larger: six instead of seven workgroups per CU.)  The kernel uses
+        // szm_hash_cap of each ROI's OWN box, which this carve-out -- the same monotone function of the largest box -- covers.
+        L.hash_cap = szm_hash_cap(L.ng_cap, L.dense_cap);
         // zone sizes (16-bit entries, two per word, while a size fits), hash, zones per level; the owner-label plane only
         // exists for boxes wider than one wave (the DPP sweep of narrower boxes keeps labels in registers)
         L.szm_c16 = (!spill && L.dense_cap < 65535u) ? 1 : 0;
@@ -571,33 +585,6 @@ int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, 
     return NYXHIP_OK;
 }
 
-__global__ void batch_extrema_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
-                                     const uint32_t* mn, const uint32_t* mx, uint32_t* out4)
-{
-    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint32_t n = 0, a = 0, r = 0, sd = 0;
-    if (i < n_roi) {
-        n = (uint32_t)(px_offset[i + 1] - px_offset[i]);
-        a = bw[i] * bh[i];
-        r = mx[i] - mn[i];
-        sd = bw[i] > bh[i] ? bw[i] : bh[i];
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t on = __shfl_down(n, off, 64), oa = __shfl_down(a, off, 64), orr = __shfl_down(r, off, 64),
-                 os = __shfl_down(sd, off, 64);
-        n = on > n ? on : n;
-        a = oa > a ? oa : a;
-        r = orr > r ? orr : r;
-        sd = os > sd ? os : sd;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&out4[0], n);
-        atomicMax(&out4[1], a);
-        atomicMax(&out4[2], r);
-        atomicMax(&out4[3], sd);
-    }
-}
-
 int ensure_stage(nyxhip_ctx* ctx, size_t bytes)
 {
     if (bytes <= ctx->stage_bytes)
@@ -628,21 +615,6 @@ int check_status(nyxhip_ctx* ctx)
     return NYXHIP_OK;
 }
 
-// Launch on device-resident arrays.
-// ROIs whose pixel count / bounding box exceed the LDS caps -> index list (order irrelevant: rows are
-// addressed by ROI index).  list[0..count) ; count in *n_out.
-__global__ void classify_large_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh,
-                                      uint32_t cap_px, uint32_t cap_area, uint32_t cap_side, uint32_t* list, uint32_t* n_out)
-{
-    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= n_roi) return;
-    uint64_t n = px_offset[i + 1] - px_offset[i];
-    uint64_t a = (uint64_t)bw[i] * bh[i];
-    uint32_t sd = bw[i] > bh[i] ? bw[i] : bh[i];
-    if (n > cap_px || a > cap_area || sd > cap_side)
-        list[atomicAdd(n_out, 1u)] = (uint32_t)i;
-}
-
 __global__ void iota_kernel(uint32_t n, uint32_t* out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,7 +627,6 @@ __global__ void add_offset_kernel(const uint32_t* in, uint32_t add, uint32_t n, 
     if (i < n) out[i] = in[i] + add;
 }
 
-struct Extrema { uint32_t px, area, range, side; };
 
 // Fills the three argument blocks for one set of extrema; `cap` = 0 -> LDS carve-outs, else spill layouts.
 int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
@@ -857,181 +828,299 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
     return NYXHIP_OK;
 }
 
-// Launch on device-resident arrays.  Normal case: one LDS-resident launch per kernel group.  When the batch
-// extrema do not fit the 160 KiB of a CU, the LDS launches run with capped carve-outs and skip the oversized
-// ROIs, which are then collected into an index list and re-run by the same kernels instantiated with their
-// scratch in a global workspace (slower, but any ROI the device memory can hold is served).
-int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                      size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+// ---- size classes ------------------------------------------------------------------------------------------------------------
+// The reference has no coupling between the ROIs of a batch: every worker thread takes ROIs of any size
+// (/root/reference/src/nyx/parallel.h:23-42, roi_cache.h:31-84).  Here a launch carves its LDS for the largest ROI it holds, so
+// a call is split into launches per SIZE CLASS: a classifier kernel sorts the ROI indices into five size classes x
+// {16-bit tables possible, not possible} by each ROI's OWN pixel count, box and intensity range (never by its companions), and
+// every class is launched over its index list with a carve-out -- hence kernel build and occupancy -- of its own.  Classes whose
+// carve-out does not fit a CU's LDS run the same kernels with their scratch in a global workspace.
+constexpr int kSizeClasses = 5, kClasses = 2 * kSizeClasses;
+constexpr uint32_t kClassPx[kSizeClasses - 1] = {256, 4096, 16384, 32768};      // class k: n_px <= kClassPx[k] and both box sides
+constexpr uint32_t kClassSide[kSizeClasses - 1] = {32, 64, 128, 256};           //          <= kClassSide[k]; the last class takes the rest
+enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_PAD, H_WORDS };   // header words per class
+
+__device__ __forceinline__ int roi_class(uint32_t n, uint32_t w, uint32_t h, uint32_t range)
+{
+    const uint32_t side = w > h ? w : h;
+    int sc = kSizeClasses - 1;
+#pragma unroll
+    for (int k = kSizeClasses - 2; k >= 0; k--)
+        if (n <= kClassPx[k] && side <= kClassSide[k]) sc = k;
+    const bool c16 = n < 65536u && range < 16384u;       // the 16-bit counting tables of roi_features.hip (LdsLayout::cnt16) can serve this ROI
+    return 2 * sc + (c16 ? 0 : 1);
+}
+
+// pass 1: members and extrema of every class (block-local in LDS first: ten hot words would serialise 5 n_roi global atomics)
+__global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
+                                   const uint32_t* mx, uint32_t* hdr)
+{
+    __shared__ uint32_t s_h[kClasses * H_WORDS];
+    for (int i = threadIdx.x; i < kClasses * H_WORDS; i += blockDim.x) s_h[i] = 0;
+    __syncthreads();
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n_roi) {
+        const uint64_t n64 = px_offset[i + 1] - px_offset[i];
+        const uint32_t n = n64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n64, w = bw[i], h = bh[i], r = mx[i] - mn[i];
+        const uint64_t a64 = (uint64_t)w * h;
+        uint32_t* c = s_h + roi_class(n, w, h, r) * H_WORDS;
+        atomicAdd(&c[H_COUNT], 1u);
+        atomicMax(&c[H_PX], n);
+        atomicMax(&c[H_AREA], a64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a64);
+        atomicMax(&c[H_RANGE], r);
+        atomicMax(&c[H_SIDE], w > h ? w : h);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kClasses * H_WORDS; k += blockDim.x) {
+        const int f = k % H_WORDS;
+        if (s_h[k] == 0) continue;
+        if (f == H_COUNT) atomicAdd(&hdr[k], s_h[k]);
+        else if (f >= H_PX && f <= H_SIDE) atomicMax(&hdr[k], s_h[k]);
+    }
+}
+
+// pass 2: ROI indices grouped by class (class c occupies list[offset_c .. offset_c + count_c), offsets = prefix of the counts);
+// blocks reserve their ranges in arrival order, so a class's list follows the batch order closely (neighbouring workgroups of a
+// launch read neighbouring clouds) without being a function of it -- rows are addressed by ROI index, the order is free.
+__global__ void class_scatter_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
+                                     const uint32_t* mx, uint32_t* hdr, uint32_t* list)
+{
+    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
+    if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    int c = -1;
+    uint32_t rank = 0;
+    if (i < n_roi) {
+        const uint64_t n64 = px_offset[i + 1] - px_offset[i];
+        c = roi_class(n64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n64, bw[i], bh[i], mx[i] - mn[i]);
+        rank = atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kClasses) {
+        uint32_t off = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++) off += hdr[k * H_WORDS + H_COUNT];
+        if (blockIdx.x == 0) hdr[threadIdx.x * H_WORDS + H_OFFSET] = off;
+        s_base[threadIdx.x] = off + (s_cnt[threadIdx.x] ? atomicAdd(&hdr[threadIdx.x * H_WORDS + H_CURSOR], s_cnt[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (c >= 0) list[s_base[c] + rank] = (uint32_t)i;
+}
+
+static void set_slots(SpillArgs& sp, const uint32_t* list, const uint32_t* hdr, uint32_t n_slots)
+{
+    sp.roi_index = list; sp.cls_hdr = hdr; sp.n_slots = n_slots;
+}
+
+// One class: LDS launches when the carve-outs of the class's extrema fit, else the same kernels over a global workspace.
+//   list / hdr / grid: exact launches pass the class's first list entry, hdr = NULL and grid = its member count; launches whose
+//   count is only known on the device pass the whole list, the class's header and an upper bound (no workspace fallback then:
+//   *needs_host is set instead and nothing is launched).  dry: build the argument blocks only (does this class fit LDS?).
+int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
+              const uint32_t* list, const uint32_t* hdr, uint32_t grid, bool dry, bool* needs_host, int* used_workspace)
 {
     std::string why;
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
-    if (mask3 & NYXHIP_FAM_GABOR)
-        if (int brc = ensure_gabor_bank(ctx, s))
-            return brc;
-    const Extrema full{max_px, max_area, max_range, max_side};
     RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
     uint32_t groups = 0xF;
-    bool feat_all_gs = false;
-    // Builds the LDS argument blocks for one set of extrema.  A GLCM grey depth whose matrix does not fit LDS next to any ROI
-    // sends the whole INTENSITY + GLCM group to the global workspace instead (slow, but every depth the matrices' 2 GiB
-    // offset range allows is served); the other groups keep their LDS launches.
-    auto try_build = [&](const Extrema& E) -> int {
-        int rc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
-        if (rc == NYXHIP_ERR_UNSUPPORTED && mask1 && !feat_all_gs) {
-            RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
-            std::string why2;
-            if (build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
-                feat_all_gs = true;
-                groups = 0xE;
-                rc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
-            }
+    bool feat_gs = false, all_gs = false;
+    if (used_workspace) *used_workspace = 0;
+    int lrc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+    if (lrc == NYXHIP_ERR_UNSUPPORTED && mask1) {
+        // a GLCM grey depth whose matrix does not fit LDS next to any ROI: the INTENSITY + GLCM group of this class runs from the
+        // global workspace (slow, but every depth the matrices' 2 GiB offset range allows is served); the other groups keep LDS
+        RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
+        std::string why2;
+        if (build_args(ctx, b, mask, s, d_out, ld, E, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
+            feat_gs = true;
+            groups = 0xE;
+            lrc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
         }
-        return rc;
-    };
-    int lrc = try_build(full);
-    bool need_spill = false;
-    Extrema capE = full;
-    if (lrc == NYXHIP_ERR_UNSUPPORTED)
-        return fail(ctx, lrc, why);
-    if (lrc == NYXHIP_ERR_ROI_TOO_LARGE) {
-        need_spill = true;
-        // LDS caps for the bulk of the batch: keep the carve-out small enough for two workgroups per CU
-        capE.px = std::min<uint32_t>(max_px, 8192);
-        capE.area = std::min<uint32_t>(max_area, 16384);
-        capE.side = std::min<uint32_t>(max_side, 256);
-        for (int tries = 0; tries < 8; tries++) {
-            lrc = try_build(capE);
-            if (lrc != NYXHIP_ERR_ROI_TOO_LARGE) break;
-            capE.px = std::max<uint32_t>(capE.px / 2, 64); capE.area = std::max<uint32_t>(capE.area / 2, 64); capE.side = std::max<uint32_t>(capE.side / 2, 8);
-        }
-        if (lrc) return fail(ctx, lrc, why);
-        a.sp.defer_large = t.sp.defer_large = g.sp.defer_large = d.sp.defer_large = 1;
-        g.small_rois = 0;                          // the one-wave shape kernels are sized for uniformly small batches
-    } else if (lrc)
-        return fail(ctx, lrc, why);
+    }
+    if (lrc == NYXHIP_ERR_UNSUPPORTED) return fail(ctx, lrc, why);
+    if (lrc == NYXHIP_ERR_ROI_TOO_LARGE) all_gs = true;
+    else if (lrc) return fail(ctx, lrc, why);
+    if ((feat_gs || all_gs) && hdr) { if (needs_host) *needs_host = true; return NYXHIP_OK; }
+    if (dry) return NYXHIP_OK;
+    if (used_workspace) *used_workspace = all_gs ? 2 : feat_gs ? 1 : 0;
 
     hipStream_t st = ctx->stream();
-    const uint32_t grid = (uint32_t)b->n_roi;
-    // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
-    // kernel holds 43 KB of LDS per workgroup (three per CU); the intensity block inside it ran at that occupancy, 2.9 ms per
-    // 196 k ROIs against 1.4 ms for the intensity-only build at eight workgroups per CU.  Each launch zeroes and fills its own
-    // block of columns.
-    auto launch_features_main = [&]() -> int {
-        const uint32_t both = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM;
-        if ((a.mask & both) == both && a.L.g16 && !getenv("NYXHIP_G16_FUSED")) {
-            const Extrema& E = need_spill ? capE : full;
-            RoiArgs ai = a, ag = a;
-            std::string w2;
-            const int ncol_g = a.n_cols - kIntensityCols;
-            if (make_layout(NYXHIP_FAM_INTENSITY, s, kIntensityCols, E.px, E.area, E.range, ai.L, w2) == NYXHIP_OK &&
-                make_layout(NYXHIP_FAM_GLCM, s, ncol_g, E.px, E.area, E.range, ag.L, w2) == NYXHIP_OK && ag.L.g16) {
-                ai.mask = NYXHIP_FAM_INTENSITY; ai.n_cols = kIntensityCols; ai.col_intensity = 0; ai.col_glcm = -1;
-                ag.mask = NYXHIP_FAM_GLCM; ag.n_cols = ncol_g; ag.col_glcm = 0; ag.col_intensity = -1; ag.out = a.out + kIntensityCols;
-                if (int r1 = launch_roi_features(ag, st, grid)) return r1;
-                return launch_roi_features(ai, st, grid);
+    int rc = 0;
+    if (!all_gs) {
+        set_slots(a.sp, list, hdr, grid); set_slots(t.sp, list, hdr, grid); set_slots(g.sp, list, hdr, grid); set_slots(d.sp, list, hdr, grid);
+        // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
+        // kernel holds 43 KB of LDS per workgroup (three per CU); the intensity block inside it ran at that occupancy, 2.9 ms per
+        // 196 k ROIs against 1.4 ms for the intensity-only build at eight workgroups per CU.  Each launch zeroes and fills its own
+        // block of columns.
+        auto launch_features_main = [&]() -> int {
+            const uint32_t both = NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM;
+            if ((a.mask & both) == both && a.L.g16 && !getenv("NYXHIP_G16_FUSED")) {
+                RoiArgs ai = a, ag = a;
+                std::string w2;
+                const int ncol_g = a.n_cols - kIntensityCols;
+                if (make_layout(NYXHIP_FAM_INTENSITY, s, kIntensityCols, E.px, E.area, E.range, ai.L, w2) == NYXHIP_OK &&
+                    make_layout(NYXHIP_FAM_GLCM, s, ncol_g, E.px, E.area, E.range, ag.L, w2) == NYXHIP_OK && ag.L.g16) {
+                    ai.mask = NYXHIP_FAM_INTENSITY; ai.n_cols = kIntensityCols; ai.col_intensity = 0; ai.col_glcm = -1;
+                    ag.mask = NYXHIP_FAM_GLCM; ag.n_cols = ncol_g; ag.col_glcm = 0; ag.col_intensity = -1; ag.out = a.out + kIntensityCols;
+                    if (int r1 = launch_roi_features(ag, st, grid)) return r1;
+                    return launch_roi_features(ai, st, grid);
+                }
             }
-        }
-        return launch_roi_features(a, st, grid);
-    };
-    int rc = (mask1 && !feat_all_gs) ? launch_features_main() : 0;
-    if (rc == 0 && mask2)
-        rc = launch_roi_texture(t, st, grid);
-    if (rc == 0 && mask4)
-        rc = launch_roi_dependence(d, st, grid);
-    if (rc == 0 && mask3)
-        rc = launch_roi_shape(g, st, grid);
-    if (rc != 0)
-        return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-    if (mask & kMoments)
-        if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_px, max_area, max_side))
-            return mrc;
-    if (feat_all_gs) {
-        const size_t list_bytes = 4ull * b->n_roi + 256;
-        if (list_bytes > ctx->spill_list_bytes) {
-            if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
-            ctx->spill_list_bytes = list_bytes;
-        }
-        uint32_t* d_list = ctx->d_spill_list + 64;
-        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, (uint32_t)b->n_roi, d_list);
-        RoiArgs a3; TexArgs t3; ShapeArgs g3; DepArgs d3;
-        lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a3, t3, g3, d3, why, 1);
-        if (lrc) return fail(ctx, lrc, "global workspace: " + why);
-        const size_t stride3 = ((size_t)a3.L.total + 255) & ~(size_t)255;
-        const uint32_t chunk3 = (uint32_t)std::max<size_t>(1, std::min<size_t>(b->n_roi, ((size_t)4 << 30) / stride3));
-        if (stride3 * chunk3 > ctx->spill_bytes) {
-            if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, stride3 * chunk3));
-            ctx->spill_bytes = stride3 * chunk3;
-        }
-        a3.sp.scratch = ctx->d_spill; a3.sp.stride = stride3;
-        for (uint32_t o = 0; o < (uint32_t)b->n_roi; o += chunk3) {
-            a3.sp.roi_index = d_list + o;
-            rc = launch_roi_features(a3, st, std::min(chunk3, (uint32_t)b->n_roi - o));
-            if (rc != 0)
-                return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-        }
+            return launch_roi_features(a, st, grid);
+        };
+        rc = (mask1 && !feat_gs) ? launch_features_main() : 0;
+        if (rc == 0 && mask2) rc = launch_roi_texture(t, st, grid);
+        if (rc == 0 && mask4) rc = launch_roi_dependence(d, st, grid);
+        if (rc == 0 && mask3) rc = launch_roi_shape(g, st, grid);
+        if (rc != 0)
+            return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
-    if (!need_spill)
+    if (!feat_gs && !all_gs)
         return NYXHIP_OK;
 
-    // ---- spill pass ------------------------------------------------------------------------------------
-    const size_t list_bytes = 4ull * b->n_roi + 256;
-    if (list_bytes > ctx->spill_list_bytes) {
-        if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
-        ctx->spill_list_bytes = list_bytes;
-    }
-    uint32_t* d_cnt = ctx->d_spill_list;           // word 0 = count, list from word 64
-    uint32_t* d_list = ctx->d_spill_list + 64;
-    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st));
-    hipLaunchKernelGGL(classify_large_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w,
-                       b->bbox_h, capE.px, capE.area, capE.side, d_list, d_cnt);
-    uint32_t n_large = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_large, d_cnt, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (n_large == 0)
-        return NYXHIP_OK;
+    // ---- global-workspace pass of this class: the feature group alone (feat_gs) or every group (all_gs) ---------------------
+    const uint32_t gs_groups = all_gs ? 0xFu : 1u;
     RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
-    lrc = build_args(ctx, b, mask, s, d_out, ld, full, (size_t)1 << 31, a2, t2, g2, d2, why, groups);
+    lrc = build_args(ctx, b, mask, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs_groups);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
     size_t stride = 0;
-    if (mask1 && !feat_all_gs) stride = std::max<size_t>(stride, a2.L.total);
-    if (mask2) stride = std::max<size_t>(stride, t2.L.total);
-    if (mask3 & NYXHIP_FAM_GABOR) stride = std::max<size_t>(stride, g2.L.total);
-    if (mask4) stride = std::max<size_t>(stride, d2.L.total);
+    if (mask1) stride = std::max<size_t>(stride, a2.L.total);
+    if (all_gs && mask2) stride = std::max<size_t>(stride, t2.L.total);
+    if (all_gs && (mask3 & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
+    if (all_gs && mask4) stride = std::max<size_t>(stride, d2.L.total);
     stride = (stride + 255) & ~(size_t)255;
     const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, budget / std::max<size_t>(stride, 1)));
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(stride, 1)));
     const size_t need = stride * chunk;
     if (need > ctx->spill_bytes) {
-        if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+        if (ctx->d_spill) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, need));
         ctx->spill_bytes = need;
     }
-    for (uint32_t o = 0; o < n_large; o += chunk) {
-        const uint32_t nb = std::min(chunk, n_large - o);
-        a2.sp.roi_index = t2.sp.roi_index = g2.sp.roi_index = d2.sp.roi_index = d_list + o;
+    if (all_gs && (mask3 & NYXHIP_FAM_ZERNIKE)) {   // Zernike keeps no ROI-sized state in LDS: one launch over the class, whatever its size
+        ShapeArgs gz = g2;
+        gz.mask = NYXHIP_FAM_ZERNIKE; gz.sp.scratch = nullptr; gz.small_rois = 0;
+        set_slots(gz.sp, list, nullptr, grid);
+        rc = launch_roi_shape(gz, st, grid);
+        if (rc != 0) return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    for (uint32_t o = 0; o < grid; o += chunk) {
+        const uint32_t nb = std::min(chunk, grid - o);
+        set_slots(a2.sp, list + o, nullptr, nb); set_slots(t2.sp, list + o, nullptr, nb); set_slots(g2.sp, list + o, nullptr, nb); set_slots(d2.sp, list + o, nullptr, nb);
         a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
         a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
-        rc = (mask1 && !feat_all_gs) ? launch_roi_features(a2, st, nb) : 0;
-        if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
-        if (rc == 0 && mask4) rc = launch_roi_dependence(d2, st, nb);
-        if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
+        rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
+        if (all_gs) {
+            if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
+            if (rc == 0 && mask4) rc = launch_roi_dependence(d2, st, nb);
+            if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
+        }
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
     return NYXHIP_OK;
 }
 
+static void clear_runs(nyxhip_ctx* ctx)
+{
+    for (ClassRun& r : ctx->runs) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    ctx->runs.clear();
+}
+
+// Launch on device-resident arrays: one launch group per non-empty size class (see above).
+//   hinted: the extrema are the caller's statement about the batch (or exact, computed by the caller of this function).  When
+//   they say that every ROI belongs to the two smallest size classes -- one carve-out then serves all of them at the top
+//   occupancy -- the whole batch is one launch group sized by those extrema and nothing waits for anything: a stream of
+//   back-to-back calls stays back to back (the metric configuration).  Otherwise the classifier runs, its class headers come
+//   to the host once (two small kernels + one 320-byte copy), and every class gets an exact grid and a carve-out of its own.
+int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
+                      size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side, bool hinted)
+{
+    if (mask & NYXHIP_FAM_GABOR)
+        if (int brc = ensure_gabor_bank(ctx, s))
+            return brc;
+    hipStream_t st = ctx->stream();
+    const uint32_t n_roi = (uint32_t)b->n_roi;
+    clear_runs(ctx);
+    auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, const uint32_t* hp, uint32_t grid) -> int {
+        ClassRun r{cls, count, E, 0, nullptr, nullptr};
+        if (ctx->timing) {
+            HIP_TRY(ctx, hipEventCreate(&r.e0));
+            HIP_TRY(ctx, hipEventCreate(&r.e1));
+            HIP_TRY(ctx, hipEventRecord(r.e0, st));
+        }
+        const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, hp, grid, false, nullptr, &r.workspace);
+        if (ctx->timing && rc == 0) HIP_TRY(ctx, hipEventRecord(r.e1, st));
+        ctx->runs.push_back(r);
+        return rc;
+    };
+    if ((mask & ~kMoments) || !hinted) {               // (a batch without stated extrema gets them from the class headers)
+        bool done = false;
+        static const bool force_classes = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
+        if (hinted && !force_classes && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
+            const Extrema E{max_px, max_area, max_range, max_side};
+            RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d; std::string why;
+            if (build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, 0xF) == NYXHIP_OK) {   // (else: the exact path, whose workspace chunks need member counts)
+                if (int rc = timed_class(-1, n_roi, E, nullptr, nullptr, n_roi)) return rc;
+                done = true;
+            }
+        }
+        if (!done) {
+            // ---- classify ---------------------------------------------------------------------------------------------------
+            const size_t list_bytes = 4ull * n_roi + 256;
+            if (list_bytes > ctx->cls_list_bytes) {
+                if (ctx->d_cls_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_cls_list)); ctx->d_cls_list = nullptr; ctx->cls_list_bytes = 0; }
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cls_list, list_bytes + list_bytes / 4));
+                ctx->cls_list_bytes = list_bytes + list_bytes / 4;
+            }
+            if (!ctx->d_cls_hdr) {
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cls_hdr, sizeof(uint32_t) * kClasses * H_WORDS));
+                HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_cls_hdr, sizeof(uint32_t) * kClasses * H_WORDS, hipHostMallocDefault));
+            }
+            uint32_t* const hdr = ctx->d_cls_hdr;
+            uint32_t* const list = ctx->d_cls_list;
+            HIP_TRY(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * kClasses * H_WORDS, st));
+            const unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
+            hipLaunchKernelGGL(class_count_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr);
+            hipLaunchKernelGGL(class_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr, list);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                return fail(ctx, NYXHIP_ERR_HIP, std::string("classifier launch failed: ") + hipGetErrorString(e));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cls_hdr, hdr, sizeof(uint32_t) * kClasses * H_WORDS, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            const uint32_t* H = ctx->h_cls_hdr;
+            if (!hinted) {
+                max_px = max_area = max_range = max_side = 0;
+                for (int cls = 0; cls < kClasses; cls++) {
+                    const uint32_t* h = H + cls * H_WORDS;
+                    max_px = std::max(max_px, h[H_PX]); max_area = std::max(max_area, h[H_AREA]);
+                    max_range = std::max(max_range, h[H_RANGE]); max_side = std::max(max_side, h[H_SIDE]);
+                }
+            }
+            for (int cls = kClasses - 1; cls >= 0 && (mask & ~kMoments); cls--) {   // largest ROIs first: their long workgroups start early
+                const uint32_t* h = H + cls * H_WORDS;
+                if (h[H_COUNT] == 0) continue;
+                const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE]};
+                if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], nullptr, h[H_COUNT]))
+                    return rc;
+            }
+        }
+    }
+    if (mask & kMoments)
+        if (int mrc = launch_moments(ctx, b, mask, s, d_out, ld, max_px, max_area, max_side))
+            return mrc;
+    return NYXHIP_OK;
+}
+
 // launch_device_all between two events on the launch stream: the timing hooks of include/nyxhip.h cover EVERY kernel the call
 // enqueues (the LDS launch groups, the moments pair, the global-workspace and large-ROI passes), on every return path.
 int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
-                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side)
+                  size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side, bool hinted = true)
 {
     if (!ctx->timing)
-        return launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side);
+        return launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side, hinted);
     hipStream_t st = ctx->stream();
     if (ctx->ev_used == ctx->ev.size()) {
         hipEvent_t x, y;
@@ -1041,7 +1130,7 @@ int launch_device(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const n
     }
     hipEvent_t e0 = ctx->ev[ctx->ev_used].first, e1 = ctx->ev[ctx->ev_used].second;
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    const int rc = launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side);
+    const int rc = launch_device_all(ctx, b, mask, s, d_out, ld, max_px, max_area, max_range, max_side, hinted);
     HIP_TRY(ctx, hipEventRecord(e1, st));
     ctx->ev_used++;
     return rc;
@@ -1139,6 +1228,10 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
     if (ctx->d_logtab) (void)hipFree(ctx->d_logtab);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
+    clear_runs(ctx);
+    if (ctx->d_cls_list) (void)hipFree(ctx->d_cls_list);
+    if (ctx->d_cls_hdr) (void)hipFree(ctx->d_cls_hdr);
+    if (ctx->h_cls_hdr) (void)hipHostFree(ctx->h_cls_hdr);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);
@@ -1210,22 +1303,10 @@ int nyxhip_featurize_batch_async(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_
         return fail(ctx, NYXHIP_ERR_INVALID_ARG, "the async form takes device-resident batches only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->n_roi == 0) return NYXHIP_OK;
-    uint32_t max_px = b->max_px, max_area = b->max_bbox_area, max_range = b->max_inten_range, max_side = b->max_bbox_side;
-    if (max_px == 0 || max_area == 0 || max_side == 0) {
-        hipStream_t st = ctx->stream();
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_extrema, 0, 4 * sizeof(uint32_t), st));
-        unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
-        hipLaunchKernelGGL(batch_extrema_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h,
-                           b->min_inten, b->max_inten, ctx->d_extrema);
-        uint32_t h[4];
-        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_extrema, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        max_px = h[0];
-        max_area = h[1];
-        max_range = h[2];
-        max_side = h[3];
-    }
-    return launch_device(ctx, b, mask, s, out, ld, max_px, max_area, max_range, max_side);
+    // batch extrema: the caller's statement when given (all of max_px / max_bbox_area / max_bbox_side non-zero), else the size
+    // classifier of launch_device_all derives them on the device
+    const bool hinted = b->max_px != 0 && b->max_bbox_area != 0 && b->max_bbox_side != 0;
+    return launch_device(ctx, b, mask, s, out, ld, b->max_px, b->max_bbox_area, b->max_inten_range, b->max_bbox_side, hinted);
 }
 
 int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s,
@@ -1780,6 +1861,33 @@ int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launch
     if (avg_kernel_ms) *avg_kernel_ms = ctx->ev_used ? tot / (double)ctx->ev_used : 0.0;
     if (n_launches) *n_launches = ctx->ev_used;
     return NYXHIP_OK;
+}
+
+int nyxhip_launch_report(nyxhip_ctx* ctx, char* buf, size_t buf_len)
+{
+    if (!ctx) return -NYXHIP_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::string js = "[";
+    for (size_t i = 0; i < ctx->runs.size(); i++) {
+        const ClassRun& r = ctx->runs[i];
+        char ms[48] = "null";
+        if (r.e0 && r.e1 && hipEventSynchronize(r.e1) == hipSuccess) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) snprintf(ms, sizeof(ms), "%.6f", (double)t);
+        }
+        char one[384];
+        snprintf(one, sizeof(one), "%s{\"class\": %d, \"size_class\": %d, \"wide_range\": %d, \"rois\": %u, \"max_px\": %u, \"max_bbox_area\": %u, "
+                 "\"max_range\": %u, \"max_side\": %u, \"workspace\": %d, \"ms\": %s}", i ? ", " : "", r.cls, r.cls < 0 ? -1 : r.cls / 2, r.cls < 0 ? -1 : r.cls & 1,
+                 r.count, r.E.px, r.E.area, r.E.range, r.E.side, r.workspace, ms);
+        js += one;
+    }
+    js += "]";
+    if (buf && buf_len) {
+        const size_t n = std::min(js.size(), buf_len - 1);
+        memcpy(buf, js.data(), n);
+        buf[n] = 0;
+    }
+    return (int)js.size();
 }
 
 } // extern "C"

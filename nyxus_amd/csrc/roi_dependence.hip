@@ -47,10 +47,10 @@ __global__ __launch_bounds__(kBlk) void roi_dependence_kernel(const DepArgs A)
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
-    const int solo = (int)(roi & 3u);    // the wave that runs this ROI's single-wave stretches (spreads them over the four SIMDs)
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
+    const int solo = (int)(roi & 3u);    // the wave that runs this ROI's single-wave stretches (spreads them over the four SIMDs)
     double* s_red = (double*)(lds + A.L.red);
     double* s_stat = (double*)(lds + A.L.stat);
     plane_t* s_dense = (plane_t*)(lds + A.L.dense);

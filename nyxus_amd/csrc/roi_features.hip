@@ -781,8 +781,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
 
     double* s_red = (double*)(lds + A.L.red);
@@ -2440,8 +2440,8 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t roi = (uint64_t)blockIdx.x * kWaves + wave;
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, (uint64_t)blockIdx.x * kWaves + wave, A.n_roi, roi))
         return;
     const int Ng = (int)A.glcm_ng[roi];
     if (Ng == 0)

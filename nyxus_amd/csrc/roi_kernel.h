@@ -20,7 +20,26 @@ struct SpillArgs {
     unsigned char* scratch;      // global scratch, `stride` bytes per workgroup (spill launches only)
     uint64_t stride;
     int32_t defer_large;         // LDS launch: silently skip ROIs beyond the caps (a spill launch follows)
+    // size-class launches whose member count is only known on the device (the host launched an upper-bound grid without waiting
+    // for the classifier): {count, first entry of the class inside roi_index}.  NULL: the grid is exact, roi_index points at the
+    // class's first entry (or is NULL: slot = ROI).
+    const uint32_t* cls_hdr;
+    uint32_t n_slots;            // entries of roi_index this launch may use (exact-grid list launches; wave-per-ROI kernels round their grids up)
 };
+
+// slot of a launch (workgroup, or wave of a wave-per-ROI launch) -> ROI; false: nothing to do for this slot
+__device__ __forceinline__ bool roi_of_slot(const SpillArgs& sp, uint64_t slot, uint64_t n_roi, uint64_t& roi)
+{
+    if (sp.cls_hdr) {
+        if (slot >= sp.cls_hdr[0]) return false;
+        roi = sp.roi_index[sp.cls_hdr[1] + slot];
+    } else if (sp.roi_index) {
+        if (slot >= sp.n_slots) return false;
+        roi = sp.roi_index[slot];
+    } else
+        roi = slot;
+    return roi < n_roi;
+}
 
 // Byte offsets of the regions carved out of the workgroup's dynamic LDS; computed
 // on the host per launch (size classes differ per batch).
@@ -117,6 +136,24 @@ struct TexLayout {
     uint32_t ngt_own;   // NGTDM accumulators (u64 S[ng_cap+2], u32 N[ng_cap+2]) outside `work`, 0 = none: lets the NGTDM stencil run on the
                         // three waves that would otherwise wait for the one-wave GLSZM row sweep
 };
+
+// Slots of the GLSZM (level, size) hash for a bounding box of `area` pixels at `ng` level rows: the distinct pairs number at most
+// sqrt(2 ng area) + ng (the sizes of one level sum to <= area), kept at a load <= 2/3.  A function of the ROI and the settings
+// alone: the kernel sizes the table of every ROI with it (the launch's carve-out, TexLayout::hash_cap, is the same function of
+// the launch's largest box), so the slot order -- and with it the order of the floating-point sums over the cells -- does not
+// depend on which other ROIs share the launch.  Integer arithmetic only: host and device agree on every value.
+__host__ __device__ inline uint32_t szm_hash_cap(uint32_t ng, uint32_t area)
+{
+    const unsigned long long t = 2ull * ng * area;
+    unsigned long long r = (unsigned long long)__builtin_sqrt((double)t);
+    while (r * r > t) r--;
+    while ((r + 1) * (r + 1) <= t) r++;                          // r = floor(sqrt(t)) whatever the rounding of the estimate
+    const unsigned long long bound = r + 1 + ng;
+    const uint32_t distinct = (uint32_t)(bound < area ? bound : area) + 1;
+    uint32_t want = distinct + distinct / 2 + 8, p = 1;
+    while (p < want) p <<= 1;
+    return p;
+}
 
 struct TexArgs {
     uint64_t n_roi;

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
     double* s_red = (double*)(lds + A.L.red);
     double* s_plane = (double*)(lds + A.L.plane);   // [area] original intensities as double, 0 = background
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
     constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
     double* s_red = (double*)(lds_raw + A.L.red);
     uint32_t* s_plane = (uint32_t*)(lds_raw + A.L.plane);   // [(h + 15)][pitch] original intensities, zero padding
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     uint32_t* const s_xy = (uint32_t*)lds_raw;                 // [zern_px_cap] x | y << 16 of the staged cloud
     uint32_t* const s_v = s_xy + A.L.zern_px_cap;              // [zern_px_cap] intensities
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t roi = blockIdx.x;   // no size limit: always part of the first (non-spill) launch
-    if (roi >= A.n_roi)
+    uint64_t roi;                      // (no LDS-resident state that limits the ROI: never part of a workspace launch)
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
     const uint64_t off = A.px_offset[roi];
     const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);

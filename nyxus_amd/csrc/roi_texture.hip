@@ -205,8 +205,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: lets the line / row bookkeeping run on the scalar unit
-    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;
-    if (roi >= A.n_roi)
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
     double* s_out = (double*)(lds + A.L.out);
     double* s_red = (double*)(lds + A.L.red);
@@ -615,7 +615,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         uint32_t* s_hval = s_hkey + A.L.hash_cap;            // [hcap] multiplicity P(i,j)
         uint32_t* s_si = s_hval + A.L.hash_cap;              // [Ng] zones per level
         uint32_t* s_label = (uint32_t*)(s_work + A.L.szm_label);   // [area] owner index of each pixel (boxes wider than 64 only)
-        const uint32_t hcap = A.L.hash_cap;
+        // the ROI's own table size (<= A.L.hash_cap, the same function of the launch's largest box): slot order, hence the order of
+        // the floating-point sums over the cells, is a property of the ROI -- not of the batch it travels in
+        const uint32_t hcap = szm_hash_cap(A.L.ng_cap, area);
         // P(i,j) cells: sizes <= S sit in a direct [level][size] table (one atomic per zone), larger ones in the ordered hash.
         // Every pass over the cells walks hash slots first, then the table: a fixed order on every launch.
         const uint32_t S = A.L.szm_small;                     // 0 or 32

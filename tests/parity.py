@@ -1,6 +1,8 @@
 """Comparison policy shared by the parity tests (north_star):
-bit-exact for label/count features, <= 1e-5 relative otherwise, with an absolute floor
-of 1e-9 x (feature scale) for features that cross zero through cancellation."""
+bit-exact for label/count features, <= 1e-5 relative otherwise.  The only absolute allowance a column gets by default is
+1e-12 of the column's own scale (its largest |value| in the expected table); columns that are sums with cancellation
+(central / normalised central / Hu moments) get per-row floors DERIVED from the size of the cancelling terms (moment_atol),
+never a floor tied to 1.0 -- so a column whose values are 1e-30 is still checked at 1e-5 of ITS values."""
 from __future__ import annotations
 
 import numpy as np
@@ -12,11 +14,15 @@ EXACT_COLUMNS = {"MIN", "MAX", "RANGE", "MODE", "MEDIAN", "INTEGRATED_INTENSITY"
                  "UNIFORMITY_PIU", "COVERED_IMAGE_INTENSITY_RANGE", "ROBUST_MEAN"}
 
 
-def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=EXACT_COLUMNS, atol=None):
+def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=EXACT_COLUMNS, atol=None, batch=None):
     """Returns a list of human-readable mismatches (empty = parity).
     atol: optional {column name: per-row absolute tolerance} for columns that are zero up to cancellation noise by
-    construction (first-order central moments), where neither a relative bound nor the column scale means anything."""
+    construction (central moments and what is derived from them), where neither a relative bound nor the column scale means
+    anything.  batch: the HostBatch the table was computed from -- the floors of the moment columns are then derived here
+    (moment_atol) when the table holds any."""
     assert got.shape == want.shape, (got.shape, want.shape)
+    if atol is None and batch is not None and any(n.startswith(("CENTRAL_MOMENT_", "IMOM_CM_")) for n in names):
+        atol = moment_atol(batch, want, names)
     bad = []
     for j, name in enumerate(names):
         g, w = got[:, j], want[:, j]
@@ -30,7 +36,7 @@ def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=
         if base not in exact:
             scale = np.nanmax(np.abs(np.where(np.isfinite(w), w, 0.0))) if len(w) else 0.0
             with np.errstate(invalid="ignore"):
-                ok |= np.abs(g - w) <= rel * np.abs(w) + 1e-9 * max(scale, 1.0) * 0 + 1e-12 * max(scale, 1.0)
+                ok |= np.abs(g - w) <= rel * np.abs(w) + 1e-12 * scale
         if base in ("GLCM_INFOMEAS2", "GLCM_INFOMEAS2_AVE"):
             # sqrt(|1 - exp(-2 (HXY2 - HXY))|): when the matrix is (numerically) a product of its marginals the argument is
             # +-1 ulp of cancellation noise and the value is 0 or sqrt(2^-52 .. 2^-50) = 1.5e-8 .. 3e-8 on either side
@@ -45,7 +51,61 @@ def compare_tables(got: np.ndarray, want: np.ndarray, names, rel=REL_TOL, exact=
     return bad
 
 
-def moment_atol(b):
+def tolerance_of(name, w, rel=REL_TOL, exact=EXACT_COLUMNS, atol=None):
+    """The per-row tolerance compare_tables grants column `name` with expected values w (0 for exact columns): for margin reports."""
+    base = name
+    for suf in ("_0", "_45", "_90", "_135"):
+        if base.endswith(suf):
+            base = base[: -len(suf)]
+    if base in exact:
+        return np.zeros(len(w))
+    scale = np.nanmax(np.abs(np.where(np.isfinite(w), w, 0.0))) if len(w) else 0.0
+    tol = rel * np.abs(np.where(np.isfinite(w), w, 0.0)) + 1e-12 * scale
+    if base in ("GLCM_INFOMEAS2", "GLCM_INFOMEAS2_AVE"):
+        tol = np.maximum(tol, 1e-7)
+    if atol is not None and name in atol:
+        tol = np.maximum(tol, np.asarray(atol[name]))
+    return tol
+
+
+_NC = ("02", "03", "11", "12", "20", "21", "30")
+
+
+def _hu7(e):
+    """calcHu_imp (/root/reference/src/nyx/features/2d_geomoments_basic.cpp:231-253) on arrays; e: dict pq -> eta_pq."""
+    _02, _03, _11, _12, _20, _21, _30 = (e[k] for k in _NC)
+    a, b = _30 + _12, _21 + _03
+    return [_20 + _02,
+            (_20 - _02) ** 2 + 4 * _11 ** 2,
+            (_30 - 3 * _12) ** 2 + (3 * _21 - _03) ** 2,
+            a ** 2 + b ** 2,
+            (_30 - 3 * _12) * a * (a ** 2 - 3 * b ** 2) + (3 * _21 - _03) * b * (3 * a ** 2 - b ** 2),
+            (_20 - _02) * (a ** 2 - b ** 2) + 4 * _11 * a * b,
+            (3 * _21 - _03) * a * (a ** 2 - 3 * b ** 2) - (_30 - 3 * _12) * b * (3 * a ** 2 - b ** 2)]
+
+
+def _hu_floor(eta, d_eta):
+    """First-order propagation of the allowance d_eta on the seven normalised central moments through the Hu polynomials
+    (sum over inputs of |H(eta + d e_k) - H(eta)|), plus 1e-13 of the magnitude the polynomial's terms reach when every
+    eta is replaced by |eta| (rounding of the evaluation itself)."""
+    h0 = _hu7(eta)
+    out = [np.zeros_like(h0[0]) for _ in range(7)]
+    for k in _NC:
+        e2 = dict(eta)
+        e2[k] = eta[k] + d_eta[k]
+        for i, (hp, hb) in enumerate(zip(_hu7(e2), h0)):
+            out[i] = out[i] + np.abs(hp - hb)
+    # magnitude of the terms: evaluate with |eta| and every subtraction turned into an addition
+    A = {k: np.abs(v) for k, v in eta.items()}
+    a, b = A["30"] + A["12"], A["21"] + A["03"]
+    mag = [A["20"] + A["02"], (A["20"] + A["02"]) ** 2 + 4 * A["11"] ** 2, (A["30"] + 3 * A["12"]) ** 2 + (3 * A["21"] + A["03"]) ** 2,
+           a ** 2 + b ** 2, (A["30"] + 3 * A["12"]) * a * (a ** 2 + 3 * b ** 2) + (3 * A["21"] + A["03"]) * b * (3 * a ** 2 + b ** 2),
+           (A["20"] + A["02"]) * (a ** 2 + b ** 2) + 4 * A["11"] * a * b,
+           (3 * A["21"] + A["03"]) * a * (a ** 2 + 3 * b ** 2) + (A["30"] + 3 * A["12"]) * b * (3 * a ** 2 + b ** 2)]
+    return [o + 1e-13 * m for o, m in zip(out, mag)]
+
+
+def moment_atol(b, want=None, names=None):
     """Per-row absolute tolerances for the first-order central moments of a HostBatch: they vanish identically
     (sum I (x - m10/m00)); what is left is rounding noise of magnitude eps * sum I |x - cx|.  Bound: 1e-9 * m00 * side."""
     off = np.asarray(b.px_offset).astype(np.int64)
@@ -64,4 +124,39 @@ def moment_atol(b):
             scale = 1e-13 * (side / 2.0) ** (p + q)
             tol["CENTRAL_MOMENT_%d%d" % (p, q)] = scale * m00_s
             tol["IMOM_CM_%d%d" % (p, q)] = scale * m00_i
-    return tol
+    if want is None:
+        return tol
+    # ---- columns derived from the central moments: their floors follow from the floors above -------------------------------
+    # (names / want: the expected table, from which the normalising masses and the eta_pq are read)
+    col = {n: want[:, j] for j, n in enumerate(names)}
+    IN_REL = 1e-9                                     # allowance on an eta beyond its own cancellation floor
+    fam = [("CENTRAL_MOMENT_", "NORM_CENTRAL_MOMENT_", "HU_M", "SPAT_MOMENT_00", "WEIGHTED_SPAT_MOMENT_", "WEIGHTED_CENTRAL_MOMENT_", "WT_NORM_CTR_MOM_", "WEIGHTED_HU_M", m00_s),
+           ("IMOM_CM_", "IMOM_NCM_", "IMOM_HU", "IMOM_RM_00", "IMOM_WRM_", "IMOM_WCM_", "IMOM_WNCM_", "IMOM_WHU", m00_i)]
+    for cm, ncm, hu, m00n, wrm, wcm, wncm, whu, mass in fam:
+        if m00n not in col:
+            continue
+        m00 = np.abs(col[m00n])
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            eta, d_eta = {}, {}
+            for k in _NC:                                                   # normCentralMom :212-217: CM_pq / m00^((p+q)/2 + 1)
+                t = (int(k[0]) + int(k[1])) / 2.0 + 1.0
+                tol[ncm + k] = tol[cm + k] / m00 ** t
+                eta[k] = col[ncm + k]
+                d_eta[k] = IN_REL * np.abs(eta[k]) + tol[ncm + k]
+            for i, f in enumerate(_hu_floor(eta, d_eta)):
+                tol[hu + str(i + 1)] = f
+            # weighted set: weights I log(d + 0.001), |log| <= 7 for boxes below 1000 px (contour pixels: log(0.001) = -6.9); the
+            # weighted origin (w10 / w00, w01 / w00) may lie far outside the box when the weighted mass nearly cancels
+            w00 = np.abs(col[wrm + "00"])
+            ox, oy = np.abs(col[wrm + "10"]) / w00, np.abs(col[wrm + "01"]) / w00
+            reach = side + ox + oy
+            weta, d_weta = {}, {}
+            for k in _NC:
+                pq = int(k[0]) + int(k[1])
+                tol[wcm + k] = 1e-13 * 7.0 * mass * reach ** pq
+                tol[wncm + k] = tol[wcm + k] / w00 ** (pq / 2.0 + 1.0)
+                weta[k] = col[wncm + k]
+                d_weta[k] = IN_REL * np.abs(weta[k]) + tol[wncm + k]
+            for i, f in enumerate(_hu_floor(weta, d_weta)):
+                tol[whu + str(i + 1)] = f
+    return {k: np.where(np.isfinite(v), v, np.inf) for k, v in tol.items()}

@@ -20,12 +20,11 @@ def _check(ctx, b, mask, s, against_ref=True):
     names = _lib.column_names(mask, s)
     G = ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
-    atol = _moment_atol(b) if mask & (_abi.FAM_SMOMS | _abi.FAM_IMOMS) else None
-    bad = parity.compare_tables(G, O, names, atol=atol)
+    bad = parity.compare_tables(G, O, names, batch=b)
     assert not bad, "\n".join(bad[:20])
     if against_ref and po.have_ref():
         R = po.ref_featurize(b, mask, s, n_threads=2)
-        bad = parity.compare_tables(G, R, names, atol=atol)
+        bad = parity.compare_tables(G, R, names, batch=b)
         assert not bad, "vs reference classes:\n" + "\n".join(bad[:20])
     return G
 
@@ -190,7 +189,7 @@ def test_rois_beyond_lds_use_global_workspace(hip_ctx, gd):
     b = _abi.batch_from_rois(rois)
     G = hip_ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
-    assert not parity.compare_tables(G, O, _lib.column_names(mask, s), atol=_moment_atol(b))
+    assert not parity.compare_tables(G, O, _lib.column_names(mask, s), batch=b)
 
 
 def test_large_roi_gabor_is_exact(hip_ctx):
@@ -359,11 +358,10 @@ def _check_moments(ctx, b, mask=MOM, against_ref=True):
     names = _lib.column_names(mask, s)
     G = ctx.featurize_host(b, mask, s)
     O = po.oracle_featurize(b, mask, s)
-    atol = _moment_atol(b)
-    bad = parity.compare_tables(G, O, names, atol=atol)
+    bad = parity.compare_tables(G, O, names, batch=b)
     assert not bad, "\n".join(bad[:20])
     if against_ref and po.have_ref():
-        bad = parity.compare_tables(G, po.ref_featurize(b, mask, s, n_threads=2), names, atol=atol)
+        bad = parity.compare_tables(G, po.ref_featurize(b, mask, s, n_threads=2), names, batch=b)
         assert not bad, "vs reference classes:\n" + "\n".join(bad[:20])
     return G, names
 
@@ -439,7 +437,7 @@ def test_geomoments_adversarial_masks(hip_ctx):
     ok = (np.abs(O[:, names.index("WEIGHTED_SPAT_MOMENT_00")]) >= 0.05 * O[:, names.index("SPAT_MOMENT_00")]) & \
          (np.abs(O[:, names.index("IMOM_WRM_00")]) >= 0.05 * O[:, names.index("IMOM_RM_00")])
     assert ok.sum() > 200
-    atol = {k: v[ok] for k, v in parity.moment_atol(b).items()}
+    atol = {k: v[ok] for k, v in parity.moment_atol(b, O, names).items()}
     bad = parity.compare_tables(G[ok], O[ok], names, atol=atol)
     assert not bad, "\n".join(bad[:20])
 

@@ -1,0 +1,79 @@
+"""GPU tests of the size-class launches (nyxhip_api.hip: launch_device_all / run_class).
+
+The reference has no coupling between the ROIs of a batch -- every worker thread takes ROIs of any size
+(/root/reference/src/nyx/parallel.h:23-42, roi_cache.h:31-84).  Here a launch is sized by its largest ROI, so a call is split into
+launches per size class; these tests pin (1) parity of a heavy-tailed batch against the oracle, (2) that an ROI's row does not
+depend on which other ROIs share its call, (3) what the call reports about its classes."""
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi, _lib
+from oracle import pyoracle as po
+from tests import parity, synth
+
+pytestmark = pytest.mark.gpu
+
+MASK = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+CONFIG4 = MASK | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+
+
+def ellipse_roi(a, b, rng, hi=4096, lo=1, holes=0.0):
+    yy, xx = np.mgrid[-b:b + 1, -a:a + 1]
+    m = (xx * xx) * (b * b) + (yy * yy) * (a * a) <= (a * a) * (b * b)
+    if holes:
+        m &= rng.random(m.shape) >= holes
+        m[b, a] = True
+    y, x = np.nonzero(m)
+    o = np.lexsort((y, x))
+    return dict(x=x[o], y=y[o], inten=rng.integers(lo, hi, len(x)).astype(np.uint32))
+
+
+def mixed_rois(seed=1, n=90, big=2):
+    """Log-normal radii 2..150 (median 10) + `big` ellipses with 300..400-px boxes + a few wide-range and degenerate ROIs."""
+    rng = np.random.default_rng(seed)
+    rois = []
+    for k in range(n):
+        r = int(np.clip(np.rint(np.exp(rng.normal(np.log(10.0), 0.8))), 2, 150))
+        hi = 70000 if k % 17 == 5 else 300 if k % 7 == 3 else 4096       # some ranges beyond the 16-bit tables
+        rois.append(ellipse_roi(r, max(2, int(r * rng.uniform(0.6, 1.0))), rng, hi=hi, lo=0 if k % 9 == 0 else 1, holes=0.1 if k % 4 == 0 else 0.0))
+    for _ in range(big):
+        rois.insert(int(rng.integers(0, len(rois))), ellipse_roi(int(rng.integers(150, 200)), int(rng.integers(150, 200)), rng, holes=0.02))
+    rois.insert(7, dict(x=[0], y=[0], inten=[9]))                      # single pixel
+    rois.insert(11, dict(x=np.arange(40), y=np.zeros(40, int), inten=np.full(40, 5, np.uint32)))   # constant row
+    return rois
+
+
+@pytest.mark.parametrize("mask,gd", [(MASK, 8), (CONFIG4, 8), (MASK, 64), (_abi.FAM_ALL & ~_abi.FAM_GABOR & ~_abi.FAM_SMOMS & ~_abi.FAM_IMOMS, 16)])
+def test_mixed_size_batch_matches_oracle(hip_ctx, mask, gd):
+    b = _abi.batch_from_rois(mixed_rois())
+    s = _abi.default_settings(gd)
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    bad = parity.compare_tables(G, O, _lib.column_names(mask, s), batch=b)
+    assert not bad, "\n".join(bad[:20])
+    rep = hip_ctx.launch_report()
+    assert sum(r["rois"] for r in rep) == b.n_roi and len(rep) >= 5, rep          # several classes, every ROI in exactly one
+    assert any(r["wide_range"] == 1 for r in rep) and any(r["size_class"] == 4 for r in rep), rep
+
+
+def test_a_row_does_not_depend_on_its_companions(hip_ctx):
+    """The same ROIs alone, and in a call that also holds large, huge and wide-range ROIs: their rows are equal bit for bit
+    (class membership, table sizes and summation orders are functions of the ROI and the settings alone)."""
+    rng = np.random.default_rng(4)
+    small = [ellipse_roi(int(r), int(max(2, r - k % 3)), rng, holes=0.05 * (k % 3)) for k, r in enumerate(rng.integers(2, 31, 40))]
+    others = [ellipse_roi(100, 80, rng), ellipse_roi(180, 160, rng), ellipse_roi(12, 12, rng, hi=200000), ellipse_roi(60, 50, rng)]
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_ALL & ~_abi.FAM_GABOR
+    alone = hip_ctx.featurize_host(_abi.batch_from_rois(small), mask, s)
+    mixed = hip_ctx.featurize_host(_abi.batch_from_rois(others[:2] + small + others[2:]), mask, s)[2:2 + len(small)]
+    names = _lib.column_names(mask, s)
+    diff = [(names[j], i) for i, j in zip(*np.nonzero(~((alone == mixed) | (np.isnan(alone) & np.isnan(mixed)))))]
+    assert not diff, diff[:10]
+
+
+def test_launch_report_of_a_homogeneous_hinted_batch_is_one_group(hip_ctx):
+    b = synth.tile_batch(1)
+    s = _abi.default_settings(8)
+    hip_ctx.featurize_host(b, MASK, s)
+    rep = hip_ctx.launch_report()
+    assert len(rep) == 1 and rep[0]["class"] == -1 and rep[0]["rois"] == 196 and rep[0]["workspace"] == 0, rep

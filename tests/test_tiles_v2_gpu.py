@@ -122,6 +122,42 @@ def test_two_contexts_share_a_stack(hip_ctx):
         other.close(); third.close()
 
 
+def _varied_stack(seed=16, nt=12):
+    """Tiles whose ROI sizes differ from tile to tile (radius 4 .. 26, one tile with a single 120-px-wide blob): chunks and shards of
+    this stack have different extrema, hence different carve-outs and size classes."""
+    rng = np.random.default_rng(seed)
+    I = rng.integers(0, 4096, (nt, 128, 128)).astype(np.uint16)
+    M = np.zeros((nt, 128, 128), np.uint32)
+    for k in range(nt):
+        if k == nt // 2:
+            yy, xx = np.mgrid[0:128, 0:128]
+            M[k][(xx - 64) ** 2 + (yy - 64) ** 2 <= 60 * 60] = 7
+        else:
+            r = 4 + (k * 7) % 23
+            M[k] = synth.disk_label_tile(size=128, pitch=max(2 * r + 3, 16), radius=r) * (1 + k % 3)
+    return I, M
+
+
+def test_chunking_and_sharding_are_invisible_for_every_family(hip_ctx):
+    """ADVICE r2 (GLSZM bits followed the launch extrema): with ROI sizes that differ between tiles, the rows of every family
+    -- texture, dependence, shape and moment families included -- are the same bits whatever the chunk size or context count."""
+    I, M = _varied_stack()
+    s = _abi.default_settings(8)
+    mask = _abi.FAM_ALL
+    one = hip_ctx.featurize_tiles_host(I, M, mask, s, max_device_bytes=1 << 34)
+    many = hip_ctx.featurize_tiles_host(I, M, mask, s, max_device_bytes=3 << 20)
+    other = _lib.Context(0)
+    try:
+        shared = hip_ctx.featurize_tiles_host(I, M, mask, s, contexts=[other])
+    finally:
+        other.close()
+    names = _lib.column_names(mask, s)
+    for tag, alt in (("chunked", many), ("two contexts", shared)):
+        assert np.array_equal(one[0], alt[0]) and np.array_equal(one[1], alt[1])
+        ne = ~((one[2] == alt[2]) | (np.isnan(one[2]) & np.isnan(alt[2])))
+        assert not ne.any(), (tag, sorted({names[j] for j in np.nonzero(ne)[1]})[:12])
+
+
 def test_label_confetti_grows_the_tile_table(hip_ctx):
     rng = np.random.default_rng(16)
     s = _abi.default_settings(8)
