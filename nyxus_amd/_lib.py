@@ -106,8 +106,9 @@ def load() -> C.CDLL:
     lib.nyxhip_timing_reset.restype = C.c_int
     lib.nyxhip_timing_get.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
     lib.nyxhip_timing_get.restype = C.c_int
-    lib.nyxhip_launch_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
-    lib.nyxhip_launch_report.restype = C.c_int
+    if hasattr(lib, "nyxhip_launch_report"):     # (absent from older builds of the ABI selected through NYXHIP_LIB for A/B runs)
+        lib.nyxhip_launch_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.nyxhip_launch_report.restype = C.c_int
     _lib = lib
     return lib
 

@@ -47,6 +47,8 @@ struct nyxhip_ctx {
     size_t stage_bytes = 0;
     // split GLCM: exported co-occurrence counts + matrix orders (grow-only)
     uint32_t* d_glcm_ws = nullptr;
+    uint32_t* d_glcm_ng = nullptr;   // [n_roi] matrix order of every ROI whose counts were exported in the CURRENT call (0: none) -- cleared per call
+    size_t glcm_ng_bytes = 0;
     double* d_logtab = nullptr;      // moments: log(sqrt(d) + 0.001) per integer squared distance (roi_moments.hip)
     uint32_t logtab_n = 0;
     size_t glcm_ws_bytes = 0;
@@ -667,18 +669,18 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         const int gi = s->ibsi ? 0 : s->grey_depth;
         if ((mask1 & NYXHIP_FAM_GLCM) && cap == 0 && gi >= 0 && a.L.ng_cap <= 16 && (int)a.L.app >= s->glcm_n_angles && s->glcm_n_angles > 0) {
             const size_t stride = (size_t)s->glcm_n_angles * a.L.ng_cap * a.L.ng_cap;
-            const size_t need = 4 * (stride + 1) * (size_t)b->n_roi + 256;
+            const size_t need = 4 * stride * (size_t)b->n_roi + 256;
             if (need > ctx->glcm_ws_bytes) {
                 if (ctx->d_glcm_ws) { (void)hipFree(ctx->d_glcm_ws); ctx->d_glcm_ws = nullptr; ctx->glcm_ws_bytes = 0; }
                 if (hipMalloc((void**)&ctx->d_glcm_ws, need) == hipSuccess) ctx->glcm_ws_bytes = need;
             }
-            if (!(ctx->d_glcm_ws && ctx->glcm_ws_bytes >= need)) {
+            if (!(ctx->d_glcm_ws && ctx->glcm_ws_bytes >= need) || !ctx->d_glcm_ng) {   // (d_glcm_ng: sized and cleared once per call by launch_device_all)
                 why = "out of device memory for the GLCM count workspace";
                 return NYXHIP_ERR_HIP;
             }
             {
-                a.glcm_ng = ctx->d_glcm_ws;
-                a.glcm_ws = ctx->d_glcm_ws + ((b->n_roi + 63) & ~(uint64_t)63);
+                a.glcm_ng = ctx->d_glcm_ng;
+                a.glcm_ws = ctx->d_glcm_ws;
                 a.glcm_ws_stride = (uint32_t)stride;
             }
         }
@@ -718,7 +720,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.col_gabor = n_cols1 + n_cols2 + n_cols4;
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
-        g.small_rois = (E.px <= 512 && E.area <= 1024) ? 1 : 0;
+        g.small_rois = (E.px <= kClassPx[0] && E.side <= kClassSide[0]) ? 1 : 0;   // the smallest size class (a function of the ROI: roi_class)
         g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
@@ -835,21 +837,7 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
 // {16-bit tables possible, not possible} by each ROI's OWN pixel count, box and intensity range (never by its companions), and
 // every class is launched over its index list with a carve-out -- hence kernel build and occupancy -- of its own.  Classes whose
 // carve-out does not fit a CU's LDS run the same kernels with their scratch in a global workspace.
-constexpr int kSizeClasses = 5, kClasses = 2 * kSizeClasses;
-constexpr uint32_t kClassPx[kSizeClasses - 1] = {256, 4096, 16384, 32768};      // class k: n_px <= kClassPx[k] and both box sides
-constexpr uint32_t kClassSide[kSizeClasses - 1] = {32, 64, 128, 256};           //          <= kClassSide[k]; the last class takes the rest
 enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_PAD, H_WORDS };   // header words per class
-
-__device__ __forceinline__ int roi_class(uint32_t n, uint32_t w, uint32_t h, uint32_t range)
-{
-    const uint32_t side = w > h ? w : h;
-    int sc = kSizeClasses - 1;
-#pragma unroll
-    for (int k = kSizeClasses - 2; k >= 0; k--)
-        if (n <= kClassPx[k] && side <= kClassSide[k]) sc = k;
-    const bool c16 = n < 65536u && range < 16384u;       // the 16-bit counting tables of roi_features.hip (LdsLayout::cnt16) can serve this ROI
-    return 2 * sc + (c16 ? 0 : 1);
-}
 
 // pass 1: members and extrema of every class (block-local in LDS first: ten hot words would serialise 5 n_roi global atomics)
 __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
@@ -907,47 +895,56 @@ __global__ void class_scatter_kernel(uint64_t n_roi, const uint64_t* px_offset, 
     if (c >= 0) list[s_base[c] + rank] = (uint32_t)i;
 }
 
-static void set_slots(SpillArgs& sp, const uint32_t* list, const uint32_t* hdr, uint32_t n_slots)
+static void set_slots(SpillArgs& sp, const uint32_t* list, uint32_t n_slots)
 {
-    sp.roi_index = list; sp.cls_hdr = hdr; sp.n_slots = n_slots;
+    sp.roi_index = list; sp.n_slots = n_slots;
 }
 
-// One class: LDS launches when the carve-outs of the class's extrema fit, else the same kernels over a global workspace.
-//   list / hdr / grid: exact launches pass the class's first list entry, hdr = NULL and grid = its member count; launches whose
-//   count is only known on the device pass the whole list, the class's header and an upper bound (no workspace fallback then:
-//   *needs_host is set instead and nothing is launched).  dry: build the argument blocks only (does this class fit LDS?).
+// One launch group: LDS launches when the carve-outs for the extrema E fit, else the same kernels over a global workspace.
+//   list != NULL: the members of one class, `grid` of them (exact launches).
+//   list == NULL: the whole batch (slot = ROI, grid = n_roi); class_mask != 0 then restricts the launch to the classes of the
+//   mask (SpillArgs::class_mask: everybody else returns at once) -- used when the host launches without knowing the member
+//   counts; such a launch cannot fall back to the workspace (its chunks are sized by member counts): *needs_host is set instead
+//   and nothing is launched.  dry: build the argument blocks only (do the carve-outs fit?).
+//   group_sel: kernel groups to launch (bit 0 features, 1 texture, 2 shape, 3 dependence).
 int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
-              const uint32_t* list, const uint32_t* hdr, uint32_t grid, bool dry, bool* needs_host, int* used_workspace)
+              const uint32_t* list, uint32_t grid, bool dry, bool* needs_host, int* used_workspace, uint32_t class_mask = 0, uint32_t group_sel = 0xF)
 {
     std::string why;
+    const uint32_t full = mask;                          // column positions follow the call's full mask: build_args always gets it
+    if (!(group_sel & 1)) mask &= ~(uint32_t)(NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM);
+    if (!(group_sel & 2)) mask &= ~kTexture;
+    if (!(group_sel & 4)) mask &= ~kShape;
+    if (!(group_sel & 8)) mask &= ~kDependence;
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
-    RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
-    uint32_t groups = 0xF;
-    bool feat_gs = false, all_gs = false;
     if (used_workspace) *used_workspace = 0;
-    int lrc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+    if (!(mask1 | mask2 | mask3 | mask4)) return NYXHIP_OK;
+    RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
+    uint32_t groups = group_sel & 0xF;
+    bool feat_gs = false, all_gs = false;
+    int lrc = build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, groups);
     if (lrc == NYXHIP_ERR_UNSUPPORTED && mask1) {
         // a GLCM grey depth whose matrix does not fit LDS next to any ROI: the INTENSITY + GLCM group of this class runs from the
         // global workspace (slow, but every depth the matrices' 2 GiB offset range allows is served); the other groups keep LDS
         RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
         std::string why2;
-        if (build_args(ctx, b, mask, s, d_out, ld, E, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
+        if (build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
             feat_gs = true;
-            groups = 0xE;
-            lrc = build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+            groups &= 0xE;
+            lrc = build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, groups);
         }
     }
     if (lrc == NYXHIP_ERR_UNSUPPORTED) return fail(ctx, lrc, why);
     if (lrc == NYXHIP_ERR_ROI_TOO_LARGE) all_gs = true;
     else if (lrc) return fail(ctx, lrc, why);
-    if ((feat_gs || all_gs) && hdr) { if (needs_host) *needs_host = true; return NYXHIP_OK; }
+    if ((feat_gs || all_gs) && needs_host) { *needs_host = true; return NYXHIP_OK; }
     if (dry) return NYXHIP_OK;
     if (used_workspace) *used_workspace = all_gs ? 2 : feat_gs ? 1 : 0;
 
     hipStream_t st = ctx->stream();
     int rc = 0;
     if (!all_gs) {
-        set_slots(a.sp, list, hdr, grid); set_slots(t.sp, list, hdr, grid); set_slots(g.sp, list, hdr, grid); set_slots(d.sp, list, hdr, grid);
+        for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
         // kernel holds 43 KB of LDS per workgroup (three per CU); the intensity block inside it ran at that occupancy, 2.9 ms per
         // 196 k ROIs against 1.4 ms for the intensity-only build at eight workgroups per CU.  Each launch zeroes and fills its own
@@ -979,9 +976,9 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         return NYXHIP_OK;
 
     // ---- global-workspace pass of this class: the feature group alone (feat_gs) or every group (all_gs) ---------------------
-    const uint32_t gs_groups = all_gs ? 0xFu : 1u;
+    const uint32_t gs_groups = all_gs ? (group_sel & 0xFu) : 1u;
     RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
-    lrc = build_args(ctx, b, mask, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs_groups);
+    lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs_groups);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
     size_t stride = 0;
     if (mask1) stride = std::max<size_t>(stride, a2.L.total);
@@ -1000,13 +997,13 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     if (all_gs && (mask3 & NYXHIP_FAM_ZERNIKE)) {   // Zernike keeps no ROI-sized state in LDS: one launch over the class, whatever its size
         ShapeArgs gz = g2;
         gz.mask = NYXHIP_FAM_ZERNIKE; gz.sp.scratch = nullptr; gz.small_rois = 0;
-        set_slots(gz.sp, list, nullptr, grid);
+        set_slots(gz.sp, list, grid);
         rc = launch_roi_shape(gz, st, grid);
         if (rc != 0) return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
     for (uint32_t o = 0; o < grid; o += chunk) {
         const uint32_t nb = std::min(chunk, grid - o);
-        set_slots(a2.sp, list + o, nullptr, nb); set_slots(t2.sp, list + o, nullptr, nb); set_slots(g2.sp, list + o, nullptr, nb); set_slots(d2.sp, list + o, nullptr, nb);
+        set_slots(a2.sp, list + o, nb); set_slots(t2.sp, list + o, nb); set_slots(g2.sp, list + o, nb); set_slots(d2.sp, list + o, nb);
         a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
         a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
         rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
@@ -1030,12 +1027,15 @@ static void clear_runs(nyxhip_ctx* ctx)
     ctx->runs.clear();
 }
 
-// Launch on device-resident arrays: one launch group per non-empty size class (see above).
+// Launch on device-resident arrays.
 //   hinted: the extrema are the caller's statement about the batch (or exact, computed by the caller of this function).  When
-//   they say that every ROI belongs to the two smallest size classes -- one carve-out then serves all of them at the top
-//   occupancy -- the whole batch is one launch group sized by those extrema and nothing waits for anything: a stream of
-//   back-to-back calls stays back to back (the metric configuration).  Otherwise the classifier runs, its class headers come
-//   to the host once (two small kernels + one 320-byte copy), and every class gets an exact grid and a carve-out of its own.
+//   they rule out everything but the two smallest size classes, nothing has to be counted: the kernel builds of those classes
+//   differ only in whether the 16-bit tables apply (feature kernels) and in the one-wave shape kernels of the smallest class, so
+//   the call enqueues whole-batch launches -- filtered by class where the build follows the class -- and returns without a
+//   host round trip (the metric configuration: a stream of back-to-back calls stays back to back).  Otherwise the classifier
+//   runs, its class headers come to the host once (two small kernels + one 320-byte copy), and every class gets an exact
+//   grid and a carve-out of its own extrema.  Either way the kernel build an ROI runs through follows from ITS class and the
+//   settings, not from its companions.
 int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out,
                       size_t ld, uint32_t max_px, uint32_t max_area, uint32_t max_range, uint32_t max_side, bool hinted)
 {
@@ -1045,31 +1045,71 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
     hipStream_t st = ctx->stream();
     const uint32_t n_roi = (uint32_t)b->n_roi;
     clear_runs(ctx);
-    auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, const uint32_t* hp, uint32_t grid) -> int {
+    if (mask & NYXHIP_FAM_GLCM) {
+        // matrix orders of the split GLCM launches (RoiArgs::glcm_ng).  A table of its own: the count workspace may be re-allocated
+        // between the launch groups of a call.
+        const size_t need = 4ull * n_roi + 256;
+        if (need > ctx->glcm_ng_bytes) {
+            if (ctx->d_glcm_ng) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_glcm_ng)); ctx->d_glcm_ng = nullptr; ctx->glcm_ng_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_glcm_ng, need + need / 4));
+            ctx->glcm_ng_bytes = need + need / 4;
+        }
+    }
+    auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, uint32_t grid, uint32_t class_mask = 0, uint32_t group_sel = 0xF) -> int {
         ClassRun r{cls, count, E, 0, nullptr, nullptr};
         if (ctx->timing) {
             HIP_TRY(ctx, hipEventCreate(&r.e0));
             HIP_TRY(ctx, hipEventCreate(&r.e1));
             HIP_TRY(ctx, hipEventRecord(r.e0, st));
         }
-        const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, hp, grid, false, nullptr, &r.workspace);
+        const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, grid, false, nullptr, &r.workspace, class_mask, group_sel);
         if (ctx->timing && rc == 0) HIP_TRY(ctx, hipEventRecord(r.e1, st));
         ctx->runs.push_back(r);
         return rc;
     };
     if ((mask & ~kMoments) || !hinted) {               // (a batch without stated extrema gets them from the class headers)
         bool done = false;
-        static const bool force_classes = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
-        if (hinted && !force_classes && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
-            const Extrema E{max_px, max_area, max_range, max_side};
-            RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d; std::string why;
-            if (build_args(ctx, b, mask, s, d_out, ld, E, 0, a, t, g, d, why, 0xF) == NYXHIP_OK) {   // (else: the exact path, whose workspace chunks need member counts)
-                if (int rc = timed_class(-1, n_roi, E, nullptr, nullptr, n_roi)) return rc;
+        static const bool force_exact = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
+        if (hinted && !force_exact && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
+            // ---- whole-batch launches, nothing counted -----------------------------------------------------------------------
+            const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]), has_wide = max_range >= 16384u;
+            const Extrema Eall{max_px, max_area, max_range, max_side};
+            struct Group { int cls; Extrema E; uint32_t class_mask, group_sel; };
+            std::vector<Group> groups;
+            // texture / dependence kernels: one build for both classes
+            if (mask & (kTexture | kDependence)) groups.push_back({-1, Eall, 0u, 2u | 8u});
+            // feature kernels: the 16-bit-table build for the ROIs it can serve, the 32-bit build for the others (when the statement
+            // allows any); without wide ranges the one launch needs no filter (a contradicting ROI raises the error flag in the kernel)
+            if (mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) {
+                if (!has_wide) groups.push_back({-2, Eall, 0u, 1u});
+                else {
+                    groups.push_back({-2, Extrema{max_px, max_area, 16383u, max_side}, 0x5u, 1u});      // classes 0 and 2
+                    groups.push_back({-3, Eall, 0xAu, 1u});                                            // classes 1 and 3
+                }
+            }
+            // shape kernels: one-wave builds for the smallest size class, four-wave builds for the other
+            if (mask & kShape) {
+                const uint32_t sd0 = std::min(max_side, kClassSide[0]);
+                if (!has_m1) groups.push_back({-4, Eall, 0u, 4u});
+                else {
+                    groups.push_back({-4, Extrema{std::min(max_px, kClassPx[0]), std::min(max_area, sd0 * sd0), max_range, sd0}, 0x3u, 4u});
+                    groups.push_back({-5, Eall, 0xCu, 4u});
+                }
+            }
+            bool needs_host = false;
+            for (const Group& g : groups)
+                if (int rc = run_class(ctx, b, mask, s, d_out, ld, g.E, nullptr, n_roi, true, &needs_host, nullptr, g.class_mask, g.group_sel)) return rc;
+            if (!needs_host) {                             // (else: the exact path, whose workspace chunks need member counts)
+                // two feature launches share the table of matrix orders, and the glcm_features launch of each walks the whole batch:
+                // what the other one has not exported yet must read "nothing to derive", not a previous call's entry
+                if (has_wide && (mask & NYXHIP_FAM_GLCM)) HIP_TRY(ctx, hipMemsetAsync(ctx->d_glcm_ng, 0, 4ull * n_roi, st));
+                for (const Group& g : groups)
+                    if (int rc = timed_class(g.cls, n_roi, g.E, nullptr, n_roi, g.class_mask, g.group_sel)) return rc;
                 done = true;
             }
         }
         if (!done) {
-            // ---- classify ---------------------------------------------------------------------------------------------------
+            // ---- classify, class headers to the host, one exact launch group per class ------------------------------------------
             const size_t list_bytes = 4ull * n_roi + 256;
             if (list_bytes > ctx->cls_list_bytes) {
                 if (ctx->d_cls_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_cls_list)); ctx->d_cls_list = nullptr; ctx->cls_list_bytes = 0; }
@@ -1103,7 +1143,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
                 const uint32_t* h = H + cls * H_WORDS;
                 if (h[H_COUNT] == 0) continue;
                 const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE]};
-                if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], nullptr, h[H_COUNT]))
+                if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], h[H_COUNT]))
                     return rc;
             }
         }
@@ -1226,6 +1266,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_mom) (void)hipFree(ctx->d_mom);
     if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
+    if (ctx->d_glcm_ng) (void)hipFree(ctx->d_glcm_ng);
     if (ctx->d_logtab) (void)hipFree(ctx->d_logtab);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
     clear_runs(ctx);

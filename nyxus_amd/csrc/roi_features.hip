@@ -25,6 +25,7 @@
 // Built with -ffp-contract=off (see device_math.h).
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <algorithm>
 #include <cstdlib>
 #include <cstdio>
 #include "device_math.h"
@@ -67,7 +68,23 @@ enum { S_MEAN = 0, S_P10, S_P90, S_MEDIAN, S_MODE, S_NG };
 
 // Sum N doubles across the workgroup in a fixed order (deterministic): wave shuffle
 // tree, then the four wave partials in wave order.  All threads get the totals.
-template <int N, bool GS>
+template <bool GS, int NW>
+__device__ __forceinline__ void grp_sync()      // the waves of one ROI meet: a workgroup barrier, or -- one wave per ROI -- nothing but ordering
+{
+    if (NW == 1) wav_sync<GS>(); else blk_sync<GS>();   // (NW == 1: see roi_features_body)
+}
+
+// totals of slot k of the cross-wave exchange area (eight doubles per wave), in the two fixed orders the body uses
+template <int NW> __device__ __forceinline__ double xw_chain(const double* s_red, int k)
+{
+    return NW == 1 ? s_red[k] : ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+}
+template <int NW> __device__ __forceinline__ double xw_pairs(const double* s_red, int k)
+{
+    return NW == 1 ? s_red[k] : (s_red[k] + s_red[8 + k]) + (s_red[16 + k] + s_red[24 + k]);
+}
+
+template <int N, bool GS, int NW = 4>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,25 +112,25 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* s_red, int tid
                 s_red[wave * 8 + k] = v[k];
         }
     }
-    blk_sync<GS>();
+    grp_sync<GS, NW>();
 #pragma unroll
     for (int k = 0; k < N; k++) {
         double t = s_red[k];
 #pragma unroll
-        for (int w = 1; w < kWaves; w++)
+        for (int w = 1; w < NW; w++)
             t += s_red[w * 8 + k];
         v[k] = t;
     }
-    blk_sync<GS>();
+    grp_sync<GS, NW>();
 }
 
 // In-place ascending bitonic sort of s[0..P), P a power of two.
-template <bool GS>
+template <bool GS, int NW = 4>
 __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 {
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += kBlock) {
+            for (uint32_t t = tid; t < (P >> 1); t += NW * 64) {
                 uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 uint32_t l = i | j;
                 uint32_t a = s[i], b = s[l];
@@ -123,7 +140,7 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
                     s[l] = a;
                 }
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
         }
     }
 }
@@ -775,14 +792,20 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
 // that caller and callee are always compiled for the same register budget.
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;     // a byte at an absolute LDS address
 
-template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false, int WIN = 2>
-__device__ __forceinline__ void roi_features_body(const RoiArgs& A)
+template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false, int WIN = 2, int NW = 4>
+__device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64_t slot)
 {
+    // NW = waves per ROI.  Only 4 (one workgroup per ROI) is built.  A one-wave build -- four ROIs per workgroup, for the smallest
+    // size class -- was measured and dropped: at 12 KB of LDS per wave (16-bit counting table) or 77 .. 120 VGPRs (sort engine) it
+    // keeps 12 .. 24 ROIs in flight per CU against 8 here, but every ROI's chain of dependent LDS / HBM round trips gets longer:
+    // 49-pixel ROIs 8.4 -> 7.3 ns, 253-pixel ROIs 8.7 -> 8.9 ns per ROI.
+    static_assert(NW == 4 && NW == kMaxAngles, "one workgroup of four waves per ROI (and a wave per GLCM angle)");
+    constexpr int BS = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t roi;
-    if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
+    if (!roi_of_slot(A.sp, slot, A.n_roi, roi))
         return;
 
     double* s_red = (double*)(lds + A.L.red);
@@ -801,6 +824,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
     const uint32_t area = w * h;
     const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
+    if (!roi_in_launch(A.sp, n, w, h, vmax - vmin))
+        return;                                       // another launch of this call serves the ROI's size class
     constexpr bool FAST = FAM == 1;
     constexpr int kRowsTag = 16 + TIER * 4 + (C16 ? 2 : 0) + (D8 ? 1 : 0);
     const bool do_int = FAM != 0 || (A.mask & NYXHIP_FAM_INTENSITY) != 0;
@@ -813,6 +838,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
     // order-statistics engine for this ROI: counting table when [vmin, vmax] fits
     const uint32_t range = vmax - vmin;
     const bool use_count = C16 ? do_int : (do_int && A.L.count_cap != 0 && range < A.L.count_cap);   // C16: every ROI of the launch counts
+    if (C16 && do_int && range >= A.L.count_cap) {    // (a range beyond the table: the caller's statement about the batch was wrong)
+        if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+        return;
+    }
     uint32_t* s_cnt = (uint32_t*)(lds + A.L.cnt);
     // smallest power of two >= n (sort length of the fallback engine)
     uint32_t P2 = 1;
@@ -825,7 +854,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             return;                                   // handled by the spill launch that follows
         if (tid == 0 && n != 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
-        for (int c = tid; c < A.n_cols; c += kBlock)
+        for (int c = tid; c < A.n_cols; c += BS)
             out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
@@ -838,32 +867,32 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 
     // ---- phase 0: clear LDS state; the output row is written in place (zeros first: features that are skipped stay 0; every
     //      later store to the row is separated from these by a workgroup barrier) ----------------------------------------
-    for (int c = tid; c < A.n_cols; c += kBlock)
+    for (int c = tid; c < A.n_cols; c += BS)
         out_row[c] = 0.0;
     if (do_glcm) {
         uint32_t* d32 = (uint32_t*)s_dense;       // region is 16-byte aligned and padded
         // (8-bit planes: 64 more zero bytes behind the last row -- the "row below" of the last row and the cell every lane beyond the
         //  box reads in the co-occurrence sweep; the cell that takes out-of-box coordinates lies behind them)
-        for (uint32_t i = tid; i < (D8 ? (area + 64 + 3) / 4 : (area + 1) / 2); i += kBlock)
+        for (uint32_t i = tid; i < (D8 ? (area + 64 + 3) / 4 : (area + 1) / 2); i += BS)
             d32[i] = 0;
         if (greyInfo < 0)
-            for (uint32_t i = tid; i <= A.L.lvl_cap; i += kBlock)
+            for (uint32_t i = tid; i <= A.L.lvl_cap; i += BS)
                 s_lvlmap[i] = 0;
     }
     if (do_int) {
         if (use_count) {
             uint4* c4 = (uint4*)s_cnt;             // count_cap is a multiple of 64 entries
             const uint32_t n16 = C16 ? (range + 8) / 8 : (range + 4) / 4;   // 16-byte stores
-            for (uint32_t i = tid; i < n16; i += kBlock)
+            for (uint32_t i = tid; i < n16; i += BS)
                 c4[i] = make_uint4(0, 0, 0, 0);
         } else {
-            for (uint32_t i = n + tid; i < P2; i += kBlock)
+            for (uint32_t i = n + tid; i < P2; i += BS)
                 s_val[i] = 0xFFFFFFFFu;
         }
     }
     if (tid < 16)
         s_stat[tid] = 0.0;
-    blk_sync<GS>();
+    grp_sync<GS, NW>();
 
     STAMP(0);
     // ---- phase 1: the only pass over HBM ------------------------------------------------
@@ -889,7 +918,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         uint32_t v[kU], px[kU], py[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            const uint32_t i = base + u * kBlock + tid;
+            const uint32_t i = base + u * BS + tid;
             v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_v, (int)(i * 4u), 0, 0);
             px[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_x, (int)(i * 2u), 0, 0) : 0u;
             py[u] = do_glcm ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_y, (int)(i * 2u), 0, 0) : 0u;
@@ -899,11 +928,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         uint16_t* const val16 = (uint16_t*)s_val + i0;
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            if (!FULL && i0 + u * kBlock >= n)
+            if (!FULL && i0 + u * BS >= n)
                 continue;
             if (do_int) {
-                if (C16) val16[u * kBlock] = (uint16_t)(v[u] - vmin);       // C16 launches: every ROI counts, range < 16384
-                else s_val[i0 + u * kBlock] = v[u];
+                if (C16) val16[u * BS] = (uint16_t)(v[u] - vmin);       // C16 launches: every ROI counts, range < 16384
+                else s_val[i0 + u * BS] = v[u];
                 // unsigned-int product, wraps (intensity.cpp:90).  v_mul_lo_u32 issues at quarter rate; below 2^24 the 24-bit
                 // multiply returns the same low 32 bits at full rate (uniform choice per ROI).
                 const uint32_t sq = (TINY || small_v) ? (uint32_t)__umul24(v[u], v[u]) : (uint32_t)(v[u] * v[u]);
@@ -1006,7 +1035,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                      : dt == 2 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0)
                                : (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff, (int)soff, 0);
             };
-            const uint32_t rows_pw = (h + kWaves - 1) / kWaves;
+            const uint32_t rows_pw = (h + NW - 1) / NW;
             const uint32_t r_begin = (uint32_t)wave * rows_pw, r_end = r_begin + rows_pw < h ? r_begin + rows_pw : h;
             const uint32_t e0 = (A.win.y0[roi] + r_begin) * Wt + x0;                      // element offset of this wave's first row (scalar)
             const uint32_t vl = (uint32_t)lane * (uint32_t)dtl, vi = (uint32_t)lane * (uint32_t)dti;
@@ -1025,7 +1054,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hits);
             uint32_t* const s_hits = (uint32_t*)(s_stat + 12);                          // (s_stat is free until the sums)
             if (lane == 0) s_hits[wave] = hits;
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             uint32_t rank0 = 0;
             for (int wv = 0; wv < wave; wv++) rank0 += s_hits[wv];
             rank0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank0);
@@ -1070,7 +1099,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             return dt == 4 ? ((const uint32_t*)p)[i] : dt == 2 ? (uint32_t)((const uint16_t*)p)[i] : (uint32_t)((const uint8_t*)p)[i];
         };
         const uint32_t Wt = A.win.W;
-        const uint32_t cw = ((area + kBlock - 1) / kBlock) * 64u;               // pixels per wave (a multiple of 64)
+        const uint32_t cw = ((area + BS - 1) / BS) * 64u;               // pixels per wave (a multiple of 64)
         const uint32_t p_begin = (uint32_t)wave * cw, p_end = p_begin + cw < area ? p_begin + cw : area;
         const uint32_t step_y = 64u / w, step_x = 64u - step_y * w;
         const uint32_t step_o = step_y * Wt + step_x, wrap_o = Wt - w;          // offset advance per 64 pixels, extra when the column wraps
@@ -1089,7 +1118,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         }
         uint32_t* const s_hits = (uint32_t*)(s_stat + 12);                      // (s_stat is free until the sums)
         if (lane == 0) s_hits[wave] = hits;
-        blk_sync<GS>();
+        grp_sync<GS, NW>();
         uint32_t rank0 = 0;
         for (int wv = 0; wv < wave; wv++) rank0 += s_hits[wv];
         const bool nz = vmin > 0;
@@ -1140,10 +1169,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         const bool nz = vmin > 0, tiny = vmax < (1u << 15);
         uint32_t base = 0;
         if (nz && tiny) {
-            for (; base + kU * kBlock <= n; base += kU * kBlock) trip(T{}, T{}, T{}, base);
+            for (; base + kU * BS <= n; base += kU * BS) trip(T{}, T{}, T{}, base);
             if (base < n) trip(F{}, T{}, T{}, base);
         } else {
-            for (; base < n; base += kU * kBlock) trip(F{}, F{}, F{}, base);
+            for (; base < n; base += kU * BS) trip(F{}, F{}, F{}, base);
         }
     }
     }
@@ -1170,11 +1199,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             s_red[wave * 8 + 0] = (double)sum;
             s_red[wave * 8 + 1] = (double)sumsq;
         }
-        blk_sync<GS>(); // also: every s_val / s_cnt write of phase 1 is visible
+        grp_sync<GS, NW>(); // also: every s_val / s_cnt write of phase 1 is visible
         const bool blank = (vmin == 0 && vmax == 0); // intensity.cpp:121-122
         if (tid == 0) {                                // the sums' own outputs leave the registers right away
             double tot = 0, totsq = 0;
-            for (int wv = 0; wv < kWaves; wv++) {
+            for (int wv = 0; wv < NW; wv++) {
                 tot += s_red[wv * 8 + 0];
                 totsq += s_red[wv * 8 + 1];
             }
@@ -1194,7 +1223,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             if (!blank)
                 o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0; // :162
         }
-        blk_sync<GS>();
+        grp_sync<GS, NW>();
         const double mean = s_stat[S_MEAN];
         STAMP(2);
 
@@ -1208,7 +1237,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         };
 
         // Q = entries of the counting table scanned per wave (multiple of 512: the 16-bit scan takes eight entries per lane and step)
-        const uint32_t Q = ((range + 1 + kWaves * 512 - 1) / (kWaves * 512)) * 512;
+        const uint32_t Q = ((range + 1 + NW * 512 - 1) / (NW * 512)) * 512;
         uint32_t* const s_woff = (uint32_t*)(s_stat + 8);   // [4] prefix offsets of the waves' table quarters (kept in LDS: as
                                                             // registers they were live across the whole intensity block and spilled)
         if (use_count) {
@@ -1307,20 +1336,20 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 s_red[wave * 8 + 1] = (double)best_c;
                 s_red[wave * 8 + 2] = (double)best_i;
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             if (tid == 0) {
                 uint32_t mc = 0, mi = 0;
-                for (int wv = 0; wv < kWaves; wv++) {
+                for (int wv = 0; wv < NW; wv++) {
                     uint32_t c = (uint32_t)s_red[wv * 8 + 1], i = (uint32_t)s_red[wv * 8 + 2];
                     if (c > mc) { mc = c; mi = i; } // waves cover ascending value ranges
                 }
-                const uint32_t woff1 = (uint32_t)s_red[0], woff2 = woff1 + (uint32_t)s_red[8], woff3 = woff2 + (uint32_t)s_red[16];
+                const uint32_t woff1 = (uint32_t)s_red[0], woff2 = woff1 + (NW > 1 ? (uint32_t)s_red[8] : 0u), woff3 = woff2 + (NW > 1 ? (uint32_t)s_red[16] : 0u);
                 s_woff[0] = 0; s_woff[1] = woff1; s_woff[2] = woff2; s_woff[3] = woff3;
                 s_stat[S_MODE] = (double)(vmin + mi);
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
         } else {
-            bitonic_sort<GS>(s_val, P2, tid);
+            bitonic_sort<GS, NW>(s_val, P2, tid);
         }
         STAMP(3);
         // C(i) = number of values <= vmin + i (counting engine)
@@ -1373,7 +1402,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         };
         if (!FUSED || blank) {
             if (!blank) {
-                for (uint32_t i = tid; i < n; i += kBlock) {
+                for (uint32_t i = tid; i < n; i += BS) {
                     double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]) - mean;
                     double d2 = d * d;
                     acc[0] += fabs(d);
@@ -1383,7 +1412,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     acc[4] += d2 * d2 * d;
                     acc[5] += d2 * d2 * d2;
                 }
-                block_sum<6, GS>(acc, s_red, tid);
+                block_sum<6, GS, NW>(acc, s_red, tid);
             }
             if (tid == 0)
                 central_outputs(acc);
@@ -1393,7 +1422,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         if (!blank) {
             // histogram bin boundaries: lower bounds found by binary search, over the value
             // domain (counting engine) or over the sorted array (sort engine)
-            for (uint32_t t = tid; t < 100 + nb; t += kBlock) {
+            for (uint32_t t = tid; t < 100 + nb; t += BS) {
                 const bool is100 = t < 100;
                 const uint32_t b = is100 ? t : t - 100;
                 uint32_t lo;
@@ -1442,7 +1471,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // mode on the sorted array: longest run, smallest value on ties; every thread
                 // keeps its best run, then a wave / block reduction
                 uint32_t best_c = 0, best_v = 0;
-                for (uint32_t i = tid; i < n; i += kBlock) {
+                for (uint32_t i = tid; i < n; i += BS) {
                     uint32_t v = s_val[i];
                     if (i == n - 1 || s_val[i + 1] != v) {
                         uint32_t lo = 0, hi = i;
@@ -1463,21 +1492,21 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     s_red[wave * 8 + 0] = (double)best_c;
                     s_red[wave * 8 + 1] = (double)best_v;
                 }
-                blk_sync<GS>();
+                grp_sync<GS, NW>();
                 if (tid == 0) {
                     uint32_t mc = 0, mv = 0;
-                    for (int wv = 0; wv < kWaves; wv++) {
+                    for (int wv = 0; wv < NW; wv++) {
                         uint32_t c = (uint32_t)s_red[wv * 8 + 0], v = (uint32_t)s_red[wv * 8 + 1];
                         if (c > mc || (c == mc && v < mv)) { mc = c; mv = v; }
                     }
                     s_stat[S_MODE] = (double)mv;
                 }
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(6);
 
             // three independent reductions run on three different waves
-            if (wave == 0) {
+            if (NW == 1 || wave == 0) {
                 // percentiles P01,P10,P25,P75,P90,P99 (histogram.h:214-243): the LAST bin i with
                 // runSum_i <= cnt <= runSum_i + bins_i wins (every matching bin overwrites);
                 // runSum_i is exactly the lower bound of bin i.  Lanes test bins i and i+64.
@@ -1534,7 +1563,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         s_rob[3] = empty ? 0u : cum(lox + span);                  // values up to its upper end
                     }
                 }
-            } else if (wave == 1) {
+            }
+            if (NW == 1 || wave == 1) {
                 // entropy / uniformity over the n+1 slots (histogram.h:145-151): slot n is empty
                 double e = 0, u = 0;
                 for (uint32_t k = lane; k < nb; k += 64) {
@@ -1549,7 +1579,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     o[I_ENTROPY] = -e;
                     o[I_UNIFORMITY] = u;
                 }
-            } else if (wave == 2) {
+            }
+            if (NW == 1 || wave == 2) {
                 // median (histogram.h:268-287): order statistics n/2 and n/2-1
                 uint32_t hi_v, lo_v;
                 if (use_count) {
@@ -1587,7 +1618,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     }
                 }
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(7);
 
             // robust mean over p10..p90 (intensity.cpp:139-149 == histogram.h:90-101)
@@ -1626,14 +1657,14 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // the trip count is wave-uniform (n / 256 full trips, then the lanes below n % 256 once more): the loop control
                 // runs on the scalar unit and costs no vector instruction per value
                 const uint16_t* const pv = (const uint16_t*)s_val + tid;
-                const uint32_t n_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n / kBlock)), n_rem = n - n_full * kBlock;
+                const uint32_t n_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n / BS)), n_rem = n - n_full * BS;
                 {   // (two values per trip: the second read sits at an immediate offset of the first, one address update per pair)
                     uint32_t k = 0;
-                    for (; k + 1 < n_full; k += 2) { px1(pv[k * kBlock]); px1(pv[(k + 1) * kBlock]); }
-                    if (k < n_full) px1(pv[k * kBlock]);
+                    for (; k + 1 < n_full; k += 2) { px1(pv[k * BS]); px1(pv[(k + 1) * BS]); }
+                    if (k < n_full) px1(pv[k * BS]);
                 }
                 if ((uint32_t)tid < n_rem)
-                    px1(pv[n_full * kBlock]);
+                    px1(pv[n_full * BS]);
                 // workgroup totals: the two integer sums through 32-bit DPP wave sums (slots 6, 7 of the exchange area), the six
                 // fp64 sums through the transposed wave sum (slots 0..5); one barrier pair for all eight
                 {
@@ -1651,25 +1682,25 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     if ((lane & 7) == 0 && (lane >> 3) < 6)
                         s_red[wave * 8 + (lane >> 3)] = tot;
                 }
-                blk_sync<GS>();
+                grp_sync<GS, NW>();
                 // every thread needs the in-range sum (sweep 2) and the population of [p10, p90] (read off the cumulative table);
                 // the other totals are read by the one lane that derives the outputs -- no barrier follows: the next exchange
                 // (sweep 2's) goes through its own scratch (the percentile bounds, dead by now)
                 const uint32_t n_below = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[2]);
                 const uint32_t n_upto = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rob[3]);
                 const uint32_t K = n_upto - n_below, n_above = n - n_upto;                 // (wave-uniform: the products below run on the scalar unit)
-                const uint32_t Sx_all = (uint32_t)((s_red[6] + s_red[8 + 6]) + (s_red[16 + 6] + s_red[24 + 6]));
+                const uint32_t Sx_all = (uint32_t)xw_pairs<NW>(s_red, 6);
                 const uint32_t Sxu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Sx_all - n_below * lox - n_above * hix));   // < 2^30
                 const double Sx = (double)Sxu, dK = (double)K;
                 if (tid == 0) {
                     double a6[6];
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        a6[k] = ((s_red[k] + s_red[8 + k]) + s_red[16 + k]) + s_red[24 + k];
+                        a6[k] = xw_chain<NW>(s_red, k);
                         asm volatile("" : "+v"(a6[k]) :: "memory");   // one total at a time: 28 reads in flight (or their adds sunk into the output code) would spill
                     }
                     // sum |2x - m2x| = 2 sum |x - kmed| + (2 #(x <= kmed) - n  when m2x is odd)
-                    const double sadk = (s_red[7] + s_red[8 + 7]) + (s_red[16 + 7] + s_red[24 + 7]);
+                    const double sadk = xw_pairs<NW>(s_red, 7);
                     const double sadt = 2.0 * sadk + ((m2x & 1u) ? 2.0 * (double)((const uint32_t*)(s_stat + 10))[1] - dn : 0.0);
                     central_outputs(a6);
                     o[I_ROBUST_MEAN] = K ? (Sx + dK * (double)vmin) / dK : 0.0;   // exact integer sum / count, as the reference's
@@ -1690,11 +1721,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     };
                     {
                         uint32_t k = 0;
-                        for (; k + 1 < n_full; k += 2) { px2(pv[k * kBlock]); px2(pv[(k + 1) * kBlock]); }
-                        if (k < n_full) px2(pv[k * kBlock]);
+                        for (; k + 1 < n_full; k += 2) { px2(pv[k * BS]); px2(pv[(k + 1) * BS]); }
+                        if (k < n_full) px2(pv[k * BS]);
                     }
                     if ((uint32_t)tid < n_rem)
-                        px2(pv[n_full * kBlock]);
+                        px2(pv[n_full * BS]);
                     ad1[0] = (double)ad;
                 } else {
                     unsigned long long ad = 0;
@@ -1705,12 +1736,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         ad += (x - lox) <= span ? dlt : 0u;
                     };
                     for (uint32_t k = 0; k < n_full; k++)
-                        px2(pv[k * kBlock]);
+                        px2(pv[k * BS]);
                     if ((uint32_t)tid < n_rem)
-                        px2(pv[n_full * kBlock]);
+                        px2(pv[n_full * BS]);
                     ad1[0] = (double)ad;
                 }
-                block_sum<1, GS>(ad1, (double*)s_lb100, tid);
+                block_sum<1, GS, NW>(ad1, (double*)s_lb100, tid);
                 if (tid == 0) {
                     double adin = ad1[0];
                     if (fast32) {                      // (exact: every term is an integer below 2^53)
@@ -1722,7 +1753,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             } else {
             // sweep 1: sum and count inside [p10, p90], and the median absolute deviation (it only needs the median)
             double rb[3] = {0, 0, 0};
-            for (uint32_t i = tid; i < n; i += kBlock) {
+            for (uint32_t i = tid; i < n; i += BS) {
                 double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90) {
                     rb[0] += a;
@@ -1730,16 +1761,16 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 }
                 rb[2] += fabs(a - median);
             }
-            block_sum<3, GS>(rb, s_red, tid);
+            block_sum<3, GS, NW>(rb, s_red, tid);
             const double mean1090 = rb[1] > 0 ? rb[0] / rb[1] : 0.0;
             // sweep 2: robust MAD about that mean (histogram.h:102-112)
             double ad[1] = {0};
-            for (uint32_t i = tid; i < n; i += kBlock) {
+            for (uint32_t i = tid; i < n; i += BS) {
                 double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
                 if (a >= p10 && a <= p90)
                     ad[0] += fabs(a - mean1090);
             }
-            block_sum<1, GS>(ad, s_red, tid);
+            block_sum<1, GS, NW>(ad, s_red, tid);
             if (tid == 0) {
                 o[I_ROBUST_MEAN] = mean1090;
                 o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = rb[1] > 0 ? ad[0] / rb[1] : 0.0;
@@ -1767,7 +1798,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         if (tid == 0)
             A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
         if (degenerate) {
-            for (int c = tid; c < kGlcmAngled * na + kGlcmAve; c += kBlock)
+            for (int c = tid; c < kGlcmAngled * na + kGlcmAve; c += BS)
                 o[c] = A.soft_nan;
             return;
         }
@@ -1784,10 +1815,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
         // two waves wide with two columns per lane
         const bool dpp2 = A.glcm_offset == 1 && w > 64 && w <= 128 && usual;
         const bool dpp = (A.glcm_offset == 1 && w <= 64) || dpp2;
-        blk_sync<GS>();
-        for (int i = tid; i < na * (dpp ? cells : NN); i += kBlock)
+        grp_sync<GS, NW>();
+        for (int i = tid; i < na * (dpp ? cells : NN); i += BS)
             s_P[i] = 0;
-        blk_sync<GS>();
+        grp_sync<GS, NW>();
         STAMP(10);
         if (dpp2) {
             // ---- boxes 65 .. 128 wide: lane = column and column + 64.  What crosses the boundary is wave-uniform (v_readlane):
@@ -1795,7 +1826,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             // column lies beyond the box read a zero byte behind the plane (stride 0), like the lanes beyond a narrow box; the row
             // below the last row is tested (the zero row behind the plane is 64 bytes, not 128).  (The per-pixel loop below
             // made the co-occurrence sweep of a 65-wide box three times as expensive as a 63-wide one.)
-            const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+            const int rows_per_wave = ((int)h + NW - 1) / NW;
             const int r_begin = wave * rows_per_wave;
             const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
             const uint32_t ng1 = (uint32_t)NG1;
@@ -1832,7 +1863,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             }
         } else
         if (dpp) {
-            const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+            const int rows_per_wave = ((int)h + NW - 1) / NW;
             const int r_begin = wave * rows_per_wave;
             const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
             const bool in_col = lane < (int)w;
@@ -1893,7 +1924,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             }
         } else {
             // any offset / boxes wider than a wave: rows dealt to waves, columns to lanes, plain Ng x Ng matrices (glcm.cpp:431-478)
-            for (int row = wave; row < (int)h; row += kWaves)
+            for (int row = wave; row < (int)h; row += NW)
                 for (int col = lane; col < (int)w; col += 64) {
                     const uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
                     if (lb == 0)
@@ -1916,7 +1947,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     }
                 }
         }
-        blk_sync<GS>();
+        grp_sync<GS, NW>();
         STAMP(11);
         {
             uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
@@ -1924,13 +1955,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
                 // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the error of the reciprocal.
                 const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);
-                for (int i = tid; i < na * NN; i += kBlock) {
+                for (int i = tid; i < na * NN; i += BS) {
                     const uint32_t q = (uint32_t)(((float)i + 0.5f) * inv_nn), rem = (uint32_t)i - mul24(q, (uint32_t)NN);
                     const uint32_t r = (uint32_t)(((float)rem + 0.5f) * inv_ng), c = rem - mul24(r, (uint32_t)Ng);
                     dst[i] = s_P[mad24(q, (uint32_t)cells, mad24(r + 1u, (uint32_t)NG1, c + 1u))];
                 }
             } else
-                for (int i = tid; i < na * NN; i += kBlock)
+                for (int i = tid; i < na * NN; i += BS)
                     dst[i] = s_P[i];
         }
         STAMP(12);
@@ -1958,12 +1989,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             lvl_max = wave_max_u32(lvl_max);
             if (lane == 0)
                 s_red[wave * 8] = (double)lvl_max;
-            blk_sync<GS>(); // also orders the s_lvlmap writes of phase 1
+            grp_sync<GS, NW>(); // also orders the s_lvlmap writes of phase 1
             if (tid == 0) {
                 int Ng;
                 if (greyInfo == 0) {
                     double m = 0;
-                    for (int wv = 0; wv < kWaves; wv++)
+                    for (int wv = 0; wv < NW; wv++)
                         m = s_red[wv * 8] > m ? s_red[wv * 8] : m;
                     Ng = (int)m;
                 } else {
@@ -1981,23 +2012,23 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 s_stat[S_NG] = (double)Ng;
             }
         }
-        if (!FAST) blk_sync<GS>();
+        if (!FAST) grp_sync<GS, NW>();
         const int Ng = FAST ? greyInfo : (int)s_stat[S_NG];
         const bool too_big = !FAST && (uint32_t)Ng > A.L.ng_cap;      // (FAST: make_layout reserved exactly this order)
         if (too_big && tid == 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
         if (!SPLIT && greyInfo >= 0 && !too_big)
-            for (int i = tid; i < Ng; i += kBlock)
+            for (int i = tid; i < Ng; i += BS)
                 s_I[i] = (double)(i + 1);
 
         const bool split = SPLIT && !degenerate && !too_big;
         if (SPLIT && tid == 0)
             A.glcm_ng[roi] = split ? (uint32_t)Ng : 0u;
         if (degenerate) {
-            for (int c = tid; c < ncol_g; c += kBlock)
+            for (int c = tid; c < ncol_g; c += BS)
                 o[c] = A.soft_nan;
         } else if (too_big) {
-            for (int c = tid; c < ncol_g; c += kBlock)
+            for (int c = tid; c < ncol_g; c += BS)
                 o[c] = __longlong_as_double(0x7ff8000000000000LL);
         } else if (G16) {
             // ---- the reference's default grey depth (17..64 matlab levels) --------------------------------------------------------
@@ -2010,10 +2041,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
             const bool symmetric = A.glcm_symmetric != 0;
             double* s_sum = s_f + kMaxAngles * 32;
             double* s_prow = s_sum + kMaxAngles * 32;                 // [kMaxAngles][Ng]
-            blk_sync<GS>();
-            for (int i = tid; i < na * cellsw; i += kBlock)
+            grp_sync<GS, NW>();
+            for (int i = tid; i < na * cellsw; i += BS)
                 s_P[i] = 0;
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(10);
             auto bump16 = [&](uint32_t* M, uint32_t idx) { atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
             if (A.glcm_offset == 1 && w > 64 && w <= 128) {
@@ -2026,7 +2057,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         const int ang = A.glcm_angles[q];
                         if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                     }
-                const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                const int rows_per_wave = ((int)h + NW - 1) / NW;
                 const int r_begin = wave * rows_per_wave;
                 const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                 const bool in1 = (uint32_t)lane + 64u < w;
@@ -2072,7 +2103,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         const int ang = A.glcm_angles[q];
                         if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                     }
-                const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                const int rows_per_wave = ((int)h + NW - 1) / NW;
                 const int r_begin = wave * rows_per_wave;
                 const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                 const bool in_col = lane < (int)w;
@@ -2103,7 +2134,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     cur = nxt;
                 }
             } else {
-                for (int row = wave; row < (int)h; row += kWaves)
+                for (int row = wave; row < (int)h; row += NW)
                     for (int col = lane; col < (int)w; col += 64) {
                         const uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
                         if (lb == 0)
@@ -2126,18 +2157,18 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         }
                     }
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(11);
-            if (wave < na)
+            if (wave < na)                               // (NW = 4 = kMaxAngles: a wave per angle)
                 glcm_features_wave64_u16((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_prow + (size_t)wave * Ng, A.soft_nan, s_f + wave * 32,
                                          s_sum + wave * 32, lane);
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(12);
-            for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
+            for (int c = tid; c < kGlcmAngled * na; c += BS) {
                 int k = c / na, a = c - k * na;
                 o[c] = s_f[a * 32 + k];
             }
-            for (int j = tid; j < kGlcmAve; j += kBlock) {               // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+            for (int j = tid; j < kGlcmAve; j += BS) {               // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
                 int k = c_glcm_ave_order[j];
                 double init = 0.0;
                 int a = 0;
@@ -2165,10 +2196,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                 const bool dpp = A.glcm_offset == 1 && w <= 64;
                 const bool trash = SPLIT && dpp;
                 const int NG1 = Ng + 1, cells = trash ? NG1 * NG1 : NN;
-                blk_sync<GS>();
-                for (int i = tid; i < na_pass * cells; i += kBlock)
+                grp_sync<GS, NW>();
+                for (int i = tid; i < na_pass * cells; i += BS)
                     s_P[i] = 0;
-                blk_sync<GS>();
+                grp_sync<GS, NW>();
                 STAMP(10);
                 // co-occurrence scan (glcm.cpp:431-478): LDS atomics, all angles of the pass.
                 // Rows are dealt to waves, columns to lanes (no integer division per pixel).
@@ -2191,7 +2222,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                             int ang = A.glcm_angles[a0 + q];
                             if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                         }
-                    const int rows_per_wave = ((int)h + kWaves - 1) / kWaves;
+                    const int rows_per_wave = ((int)h + NW - 1) / NW;
                     const int r_begin = wave * rows_per_wave;
                     const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
                     const bool in_col = lane < (int)w;
@@ -2307,7 +2338,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                     }
                     }
                 } else
-                for (int row = wave; row < (int)h; row += kWaves) {
+                for (int row = wave; row < (int)h; row += NW) {
                     for (int col = lane; col < (int)w; col += 64) {
                         uint32_t lb = s_dense[(uint32_t)row * w + (uint32_t)col];
                         if (lb == 0)
@@ -2330,7 +2361,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         }
                     }
                 }
-                blk_sync<GS>();
+                grp_sync<GS, NW>();
                 STAMP(11);
                 if (SPLIT) {                         // the host sets this up only when every angle fits one pass
                     uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
@@ -2338,32 +2369,32 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
                         // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
                         // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the rounding of the product.
                         const float inv_nn = __builtin_amdgcn_rcpf((float)NN), inv_ng = __builtin_amdgcn_rcpf((float)Ng);   // (1 ulp: far inside the margin)
-                        for (int i = tid; i < na_pass * NN; i += kBlock) {
+                        for (int i = tid; i < na_pass * NN; i += BS) {
                             const uint32_t q = (uint32_t)(((float)i + 0.5f) * inv_nn), rem = (uint32_t)i - mul24(q, (uint32_t)NN);
                             const uint32_t r = (uint32_t)(((float)rem + 0.5f) * inv_ng), c = rem - mul24(r, (uint32_t)Ng);
                             dst[i] = s_P[mad24(q, (uint32_t)cells, mad24(r + 1u, (uint32_t)NG1, c + 1u))];
                         }
                     } else
-                    for (int i = tid; i < na_pass * NN; i += kBlock)
+                    for (int i = tid; i < na_pass * NN; i += BS)
                         dst[i] = s_P[i];
                 } else if (SPLIT) {
                 } else if (Ng <= 16) {               // small matrices: the four angles share one wave's instruction stream
                     if (wave == 0)
                         glcm_features_rows<GS, 16, kRowsTag>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
-                } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells
+                } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells (NW = 4 = kMaxAngles)
                     glcm_features_rows<GS, 64, kRowsTag>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * A.L.ng_cap, 6 * (int)A.L.ng_cap,
                                                A.soft_nan, s_f + (a0 + wave) * 32, lane);
             }
-            blk_sync<GS>();
+            grp_sync<GS, NW>();
             STAMP(12);
             // lay out: feature-major, angle-minor (output_2_buffer.cpp:336-346), then _AVE
             if (!SPLIT)
-            for (int c = tid; c < kGlcmAngled * na; c += kBlock) {
+            for (int c = tid; c < kGlcmAngled * na; c += BS) {
                 int k = c / na, a = c - k * na;
                 o[c] = s_f[a * 32 + k];
             }
             if (!SPLIT)
-            for (int j = tid; j < kGlcmAve; j += kBlock) {
+            for (int j = tid; j < kGlcmAve; j += BS) {
                 // calc_ave (glcm.cpp:1205-1214): libstdc++ std::reduce folds four at a time
                 int k = c_glcm_ave_order[j];
                 double init = 0.0;
@@ -2387,29 +2418,29 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A)
 template <bool GS, bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel(const RoiArgs A)
 {
-    roi_features_body<GS, C16, SPLIT, D8>(A);
+    roi_features_body<GS, C16, SPLIT, D8>(A, blockIdx.x);
 }
 
 // the same body under tighter VGPR budgets (96 / 80): five or six workgroups per CU when their LDS fits (16-bit tables)
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 5) void roi_features_kernel_occ5(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8, 0, 5>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 5>(A, blockIdx.x);
 }
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_occ6(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8, 0, 6>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 6>(A, blockIdx.x);
 }
 template <bool C16, bool SPLIT, bool D8>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiArgs A)
 {
-    roi_features_body<false, C16, SPLIT, D8, 0, 7>(A);
+    roi_features_body<false, C16, SPLIT, D8, 0, 7>(A, blockIdx.x);
 }
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 8, false, WIN>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM, 8, false, WIN>(A, blockIdx.x);
 }
 // The same compile-time family sets and loaders at seven and six workgroups per CU: batches whose largest ROI needs a bigger
 // carve-out than the benchmark's (mixed-size data: the launch is sized by its largest ROI) keep the specialised body instead of
@@ -2417,19 +2448,19 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_fam7(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 7, false, WIN>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM, 7, false, WIN>(A, blockIdx.x);
 }
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_fam6(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 6, false, WIN>(A);
+    roi_features_body<false, true, FAM == 1, true, FAM, 6, false, WIN>(A, blockIdx.x);
 }
 
 // the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
 template <int WIN>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiArgs A)
 {
-    roi_features_body<false, true, false, true, 0, 9, true, WIN>(A);
+    roi_features_body<false, true, false, true, 0, 9, true, WIN>(A, blockIdx.x);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------

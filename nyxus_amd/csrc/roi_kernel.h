@@ -13,6 +13,22 @@ constexpr int kGlcmAngled = 30;      // Feature2D GLCM_ASM..GLCM_VARIANCE (featu
 constexpr int kGlcmAve = 29;         // Feature2D GLCM_ASM_AVE..GLCM_SUMVARIANCE_AVE (:205-233)
 constexpr int kMaxAngles = 4;
 
+// ---- size classes (launch_device_all of nyxhip_api.hip) -------------------------------------------------------------------------
+// Class of an ROI = 2 * size class + (1: its pixel count or intensity range rules the 16-bit tables out).  Size class k of
+// 0 .. 3: n_px <= kClassPx[k] and both box sides <= kClassSide[k]; 4: everything larger.  A function of the ROI alone.
+constexpr int kSizeClasses = 5, kClasses = 2 * kSizeClasses;
+constexpr uint32_t kClassPx[kSizeClasses - 1] = {256, 4096, 16384, 32768};
+constexpr uint32_t kClassSide[kSizeClasses - 1] = {32, 64, 128, 256};
+__host__ __device__ inline int roi_class(uint32_t n, uint32_t w, uint32_t h, uint32_t range)
+{
+    const uint32_t side = w > h ? w : h;
+    const int sc = (n <= 256u && side <= 32u) ? 0 : (n <= 4096u && side <= 64u) ? 1 : (n <= 16384u && side <= 128u) ? 2 : (n <= 32768u && side <= 256u) ? 3 : 4;
+    const bool c16 = n < 65536u && range < 16384u;       // the 16-bit counting tables of roi_features.hip (LdsLayout::cnt16) can serve this ROI
+    return 2 * sc + (c16 ? 0 : 1);
+}
+static_assert(kClassPx[0] == 256 && kClassPx[1] == 4096 && kClassPx[2] == 16384 && kClassPx[3] == 32768 && kClassSide[0] == 32 &&
+              kClassSide[1] == 64 && kClassSide[2] == 128 && kClassSide[3] == 256, "roi_class spells the bounds out");
+
 // Large-ROI ("spill") launches: the same kernels instantiated with their per-workgroup scratch in a global
 // workspace instead of LDS, run over an index list of the ROIs that do not fit the LDS carve-out.
 struct SpillArgs {
@@ -20,20 +36,21 @@ struct SpillArgs {
     unsigned char* scratch;      // global scratch, `stride` bytes per workgroup (spill launches only)
     uint64_t stride;
     int32_t defer_large;         // LDS launch: silently skip ROIs beyond the caps (a spill launch follows)
-    // size-class launches whose member count is only known on the device (the host launched an upper-bound grid without waiting
-    // for the classifier): {count, first entry of the class inside roi_index}.  NULL: the grid is exact, roi_index points at the
-    // class's first entry (or is NULL: slot = ROI).
-    const uint32_t* cls_hdr;
-    uint32_t n_slots;            // entries of roi_index this launch may use (exact-grid list launches; wave-per-ROI kernels round their grids up)
+    uint32_t n_slots;            // entries of roi_index this launch may use (list launches; kernels that pack several ROIs per workgroup round their grids up)
+    // launches over the whole batch (slot = ROI) that serve some classes only: bit c set = ROIs of class c are this launch's,
+    // everybody else returns at once (the kernel derives the class from what it loads anyway: no list, no dependent load in
+    // front of the ROI's own data).  0 = no filter.
+    uint32_t class_mask;
 };
+__device__ __forceinline__ bool roi_in_launch(const SpillArgs& sp, uint32_t n, uint32_t w, uint32_t h, uint32_t range)
+{
+    return sp.class_mask == 0 || ((sp.class_mask >> roi_class(n, w, h, range)) & 1u) != 0;
+}
 
 // slot of a launch (workgroup, or wave of a wave-per-ROI launch) -> ROI; false: nothing to do for this slot
 __device__ __forceinline__ bool roi_of_slot(const SpillArgs& sp, uint64_t slot, uint64_t n_roi, uint64_t& roi)
 {
-    if (sp.cls_hdr) {
-        if (slot >= sp.cls_hdr[0]) return false;
-        roi = sp.roi_index[sp.cls_hdr[1] + slot];
-    } else if (sp.roi_index) {
+    if (sp.roi_index) {
         if (slot >= sp.n_slots) return false;
         roi = sp.roi_index[slot];
     } else

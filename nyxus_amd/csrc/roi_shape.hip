@@ -71,6 +71,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
     const uint32_t area = w * h;
     const int nF = A.gabor_nf, n = A.gabor_n;
     double* const o = A.out + roi * A.ld + A.col_gabor;
+    if (!roi_in_launch(A.sp, npx, w, h, A.max_inten[roi] - A.min_inten[roi]))
+        return;                                       // another launch of this call serves the ROI's size class
     if (npx == 0 || area > A.L.area_cap) {
         if (npx != 0 && A.sp.defer_large)
             return;                                   // handled by the spill launch that follows
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
     const uint32_t area = w * h;
     const int nF = A.gabor_nf;
     double* const o = A.out + roi * A.ld + A.col_gabor;
+    if (!roi_in_launch(A.sp, npx, w, h, A.max_inten[roi] - A.min_inten[roi]))
+        return;                                       // another launch of this call serves the ROI's size class
     if (npx == 0 || area > A.L.area_cap || (w > h ? w : h) > A.L.side_cap) {
         if (npx != 0 && A.sp.defer_large)
             return;                                   // handled by the spill launch that follows
@@ -395,6 +399,8 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);
     const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
     double* const o = A.out + roi * A.ld + A.col_zernike;
+    if (!roi_in_launch(A.sp, npx, w, h, A.max_inten[roi] - A.min_inten[roi]))
+        return;                                       // another launch of this call serves the ROI's size class
     if (npx == 0 || A.max_inten[roi] == A.min_inten[roi]) {   // zernike.cpp:348-356
         for (int c = tid; c < 30; c += kBlk)
             o[c] = npx == 0 ? __longlong_as_double(0x7ff8000000000000LL) : A.soft_nan;

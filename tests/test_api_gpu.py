@@ -13,6 +13,27 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_featurize.json")))
 
 
+def _moment_floors(images, masks, want, cols):
+    """Central moments and what is derived from them (normalised, Hu) are sums with cancellation: floors derived from the size of
+    the cancelling terms (tests/parity.py: moment_atol), per ROI, from the same pixels the call saw.  None without such columns."""
+    if not any(c.startswith(("CENTRAL_MOMENT_", "IMOM_CM_")) for c in cols):
+        return None
+    from nyxus_amd import roi_assembly
+    r0, atol = 0, {}
+    for it, sg in zip(images, masks):
+        it = np.asarray(it).astype(np.float64)
+        if it.min() < 0:
+            it = it - it.min()                                      # the package's shift of negative intensities (nyxus.py:480-489)
+        b = roi_assembly.assemble(it.astype(np.uint32), np.asarray(sg).astype(np.uint32), 1.7976931348623157e308, -1.7976931348623157e308)
+        if b is None:
+            continue
+        for k, v in parity.moment_atol(b, want[r0:r0 + b.n_roi], cols).items():
+            atol.setdefault(k, []).append(v)
+        r0 += b.n_roi
+    assert r0 == want.shape[0]
+    return {k: np.concatenate(v) for k, v in atol.items()}
+
+
 @pytest.mark.parametrize("case", sorted(GOLD))
 def test_featurize_matches_reference_dataframe(case):
     g = GOLD[case]
@@ -32,12 +53,8 @@ def test_featurize_matches_reference_dataframe(case):
     got = df[g["numeric_columns"]].values.astype(float)
     want = np.array(g["numeric"], dtype=float)
     exact = parity.EXACT_COLUMNS | {"ROI_label", "t_index"} | {c for c in g["numeric_columns"] if c.startswith("GABOR_")}
-    # first-order central moments are zero up to cancellation noise: bound them by 1e-9 * m00 * image side
-    atol = {}
     cols = g["numeric_columns"]
-    for cm, m00 in (("CENTRAL_MOMENT_01", "SPAT_MOMENT_00"), ("CENTRAL_MOMENT_10", "SPAT_MOMENT_00"), ("IMOM_CM_01", "IMOM_RM_00"), ("IMOM_CM_10", "IMOM_RM_00")):
-        if cm in cols and m00 in cols:
-            atol[cm] = 1e-9 * np.abs(want[:, cols.index(m00)]) * max(seg.shape[-2:])
+    atol = _moment_floors(inten if inten.ndim == 3 else inten[None], seg if seg.ndim == 3 else seg[None], want, cols)
     bad = parity.compare_tables(got, want, cols, exact=exact, atol=atol)
     assert not bad, "\n".join(bad[:20])
 
@@ -79,8 +96,10 @@ def test_featurize_directory_matches_reference(case):
     want = np.array(g["numeric"], dtype=float)
     assert got.shape == want.shape == (139, len(g["numeric_columns"]))
     cols = g["numeric_columns"]
-    atol = {cm: 1e-9 * np.abs(want[:, cols.index(m00)]) * 1024 for cm, m00 in (("CENTRAL_MOMENT_01", "SPAT_MOMENT_00"), ("CENTRAL_MOMENT_10", "SPAT_MOMENT_00"))
-            if cm in cols and m00 in cols}
+    from nyxus_amd import tiff_ingest
+    names = g["files"] if "files" in g else sorted(os.listdir(os.path.join(root, "int")))
+    atol = _moment_floors([tiff_ingest.read_tiff(os.path.join(root, "int", f)) for f in names],
+                          [tiff_ingest.read_tiff(os.path.join(root, "seg", f)) for f in names], want, cols)
     bad = parity.compare_tables(got, want, cols, exact=parity.EXACT_COLUMNS | {"ROI_label", "t_index"}, atol=atol)
     assert not bad, "\n".join(bad[:20])
 

@@ -71,9 +71,44 @@ def test_a_row_does_not_depend_on_its_companions(hip_ctx):
     assert not diff, diff[:10]
 
 
-def test_launch_report_of_a_homogeneous_hinted_batch_is_one_group(hip_ctx):
+def test_launch_report_of_a_hinted_batch_of_small_rois(hip_ctx):
+    """Stated extrema within the two smallest size classes: whole-batch launches, nothing counted, no host round trip."""
     b = synth.tile_batch(1)
     s = _abi.default_settings(8)
     hip_ctx.featurize_host(b, MASK, s)
     rep = hip_ctx.launch_report()
-    assert len(rep) == 1 and rep[0]["class"] == -1 and rep[0]["rois"] == 196 and rep[0]["workspace"] == 0, rep
+    assert len(rep) == 1 and rep[0]["class"] == -2 and rep[0]["rois"] == 196 and rep[0]["workspace"] == 0, rep
+    rois = synth.random_rois(40, seed=3, rmax=20)                     # value modes up to 2^32 - 1: both table widths, both shape builds
+    hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK | _abi.FAM_ZERNIKE | _abi.FAM_GLSZM, s)
+    assert sorted(r["class"] for r in hip_ctx.launch_report()) == [-5, -4, -3, -2, -1]
+
+
+def test_a_wrong_statement_about_the_batch_is_an_error(hip_ctx):
+    """max_px / max_bbox_side stated smaller than an ROI of the batch: the call fails (error flag raised by the classifier) instead of
+    missing the ROI or overrunning a carve-out."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(2)
+    b = _abi.batch_from_rois([ellipse_roi(5, 5, rng), ellipse_roi(40, 30, rng), ellipse_roi(7, 6, rng)])
+    s = _abi.default_settings(8)
+    dev = torch.device("cuda", 0)
+    keep = {k: torch.from_numpy(getattr(b, k).view({2: np.int16, 4: np.int32, 8: np.int64}[getattr(b, k).dtype.itemsize])).to(dev)
+            for k in ("px_offset", "x", "y", "inten", "bbox_w", "bbox_h", "min_inten", "max_inten")}
+    cb = b.c_struct()
+    for k, t in keep.items():
+        setattr(cb, k, t.data_ptr())
+    cb.slide_min = None; cb.slide_max = None; cb.memory = _abi.MEM_DEVICE
+    ncol = hip_ctx.n_columns(MASK, s)
+    out = torch.empty((b.n_roi, ncol), dtype=torch.float64, device=dev)
+    hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)          # the true extrema: fine
+    hip_ctx.sync()
+    cb.max_px = 200; cb.max_bbox_area = 400; cb.max_bbox_side = 20                # a wrong statement
+    hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)
+    with pytest.raises(_lib.NyxHipError) as ei:
+        hip_ctx.sync()
+    assert ei.value.code == 5
+    cb.max_px = cb.max_bbox_area = cb.max_bbox_side = 0                           # no statement: the classifier derives everything
+    hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)
+    hip_ctx.sync()
+    want = po.oracle_featurize(b, MASK, s)
+    assert not parity.compare_tables(out.cpu().numpy(), want, _lib.column_names(MASK, s))
