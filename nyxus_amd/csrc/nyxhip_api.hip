@@ -365,6 +365,34 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         L.out += dsz; L.red += dsz; L.stat += dsz; L.lb100 += dsz; L.lbc += dsz;
         L.dense = 0;
     }
+    if (spill) {
+        // ---- workspace launches: the ROI-sized buffers (values, binned plane) live in global memory, but everything small and
+        // atomics-heavy stays in LDS when it fits 60 KiB -- the fixed scratch always, then the co-occurrence matrices with their
+        // feature scratch, the counting table, the level map.  (With all of it in the workspace a 96 k-pixel ROI spent two thirds of
+        // its 4 ms in the global atomics of the co-occurrence sweep and the load pass.)  LDS-resident regions are exactly those at
+        // offsets below L.gs_lds_bytes; nothing aliases.
+        const uint32_t esz = L.cnt16 ? 2u : 4u;
+        const uint64_t sz_val = align16(esz * L.sort_cap + 16), sz_cnt = do_int ? (uint64_t)esz * L.count_cap + 32 : 0;
+        const uint64_t sz_dense = 2ull * L.dense_cap + 24, sz_lvl = do_glcm ? 2ull * (L.lvl_cap + 8) + 16 : 0;
+        const uint64_t ngc = L.ng_cap, sz_P = do_glcm ? 4ull * L.app * (ngc <= 16 ? (ngc + 1) * (ngc + 1) : ngc * ngc) + 16 : 0;
+        const uint64_t sz_g = do_glcm ? 8ull * (25ull * ngc + 128) + 16 : 0;
+        const uint64_t kLdsMax = 60 * 1024;
+        uint64_t o = fixed;
+        const bool p_lds = do_glcm && o + sz_P + sz_g <= kLdsMax;
+        if (p_lds) { L.P = (uint32_t)o; o = (o + sz_P + 15) & ~15ull; L.gscr = (uint32_t)o; o = (o + sz_g + 15) & ~15ull; }
+        const bool c_lds = do_int && o + sz_cnt <= kLdsMax;
+        if (c_lds) { L.cnt = (uint32_t)o; o = (o + sz_cnt + 15) & ~15ull; }
+        const bool l_lds = do_glcm && o + sz_lvl <= kLdsMax;
+        if (l_lds) { L.lvlmap = (uint32_t)o; o = (o + sz_lvl + 15) & ~15ull; }
+        L.gs_lds_bytes = (uint32_t)o;
+        if (do_glcm && !l_lds) { L.lvlmap = (uint32_t)o; o = (o + sz_lvl + 15) & ~15ull; }
+        L.dense = (uint32_t)o; o = (o + sz_dense + 15) & ~15ull;
+        L.val = (uint32_t)o; o = (o + sz_val + 15) & ~15ull;
+        if (do_int && !c_lds) { L.cnt = (uint32_t)o; o = (o + sz_cnt + 15) & ~15ull; }
+        if (do_glcm && !p_lds) { L.P = (uint32_t)o; o = (o + sz_P + 15) & ~15ull; L.gscr = (uint32_t)o; o = (o + sz_g + 15) & ~15ull; }
+        if (o > cap) { why = "ROI too large for the global workspace (2 GiB of offsets per workgroup)"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+        off = (uint32_t)o;
+    }
     L.total = off;
     if (L.total > cap) {
         why = "ROI too large for the LDS-resident path (" + std::to_string(L.total) + " B of LDS needed; max_px=" +

@@ -808,16 +808,18 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     if (!roi_of_slot(A.sp, slot, A.n_roi, roi))
         return;
 
-    double* s_red = (double*)(lds + A.L.red);
-    double* s_stat = (double*)(lds + A.L.stat);
-    uint32_t* s_lb100 = (uint32_t*)(lds + A.L.lb100);
-    uint32_t* s_lbc = (uint32_t*)(lds + A.L.lbc);
+    // (workspace launches: regions below A.L.gs_lds_bytes live in the workgroup's LDS, the ROI-sized ones in the workspace)
+    auto reg = [&](uint32_t o) -> unsigned char* { return (GS && o < A.L.gs_lds_bytes) ? lds_raw + o : lds + o; };
+    double* s_red = (double*)reg(A.L.red);
+    double* s_stat = (double*)reg(A.L.stat);
+    uint32_t* s_lb100 = (uint32_t*)reg(A.L.lb100);
+    uint32_t* s_lbc = (uint32_t*)reg(A.L.lbc);
     uint32_t* s_val = (uint32_t*)(lds + A.L.val);
     using dense_t = typename std::conditional<D8, uint8_t, uint16_t>::type;
     dense_t* s_dense = (dense_t*)(lds + (D8 ? 0u : A.L.dense));     // 8-bit plane launches: the plane opens the carve-out (make_layout)
-    uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);
-    uint32_t* s_P = (uint32_t*)(lds + A.L.P);
-    double* s_g = (double*)(lds + A.L.gscr);
+    uint16_t* s_lvlmap = (uint16_t*)reg(A.L.lvlmap);
+    uint32_t* s_P = (uint32_t*)reg(A.L.P);
+    double* s_g = (double*)reg(A.L.gscr);
 
     const uint64_t off = A.px_offset[roi];
     const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
@@ -842,7 +844,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         return;
     }
-    uint32_t* s_cnt = (uint32_t*)(lds + A.L.cnt);
+    uint32_t* s_cnt = (uint32_t*)reg(A.L.cnt);
     // smallest power of two >= n (sort length of the fallback engine)
     uint32_t P2 = 1;
     while (P2 < n)
@@ -2133,6 +2135,44 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     }
                     cur = nxt;
                 }
+            } else if (A.glcm_offset == 1) {
+                // boxes wider than two waves: column strips of 62 centre columns between two halo lanes (see the general block below)
+                int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+                for (int q = 0; q < kMaxAngles; q++)
+                    if (q < na) {
+                        const int ang = A.glcm_angles[q];
+                        if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                    }
+                const int rows_per_wave = ((int)h + NW - 1) / NW;
+                const int r_begin = wave * rows_per_wave;
+                const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                const uint32_t ng1 = (uint32_t)NG1;
+                for (uint32_t c0 = 0; c0 < w; c0 += 62) {
+                    const int c = (int)c0 - 1 + lane;
+                    const bool in_col = c >= 0 && c < (int)w;
+                    const bool centre = in_col && lane >= 1 && lane <= 62;
+                    auto lvl = [&](int row) -> uint32_t { return (in_col && row < (int)h) ? (uint32_t)s_dense[(uint32_t)row * w + (uint32_t)c] : 0u; };
+                    uint32_t cur = r_begin < r_end ? lvl(r_begin) : 0u;
+                    for (int row = r_begin; row < r_end; row++) {
+                        const uint32_t nxt = lvl(row + 1);
+                        const uint32_t nb_e = lane_plus1(cur, 0), nb_se = lane_plus1(nxt, 0), nb_sw = lane_minus1(nxt, 0);
+                        if (centre && cur != 0) {
+                            const uint32_t rowi = mul24(cur, ng1);
+                            if (slot0 >= 0) bump16(s_P + slot0 * cellsw, rowi + nb_e);
+                            if (slot1 >= 0) bump16(s_P + slot1 * cellsw, rowi + nb_se);
+                            if (slot2 >= 0) bump16(s_P + slot2 * cellsw, rowi + nxt);
+                            if (slot3 >= 0) bump16(s_P + slot3 * cellsw, rowi + nb_sw);
+                            if (symmetric) {
+                                if (slot0 >= 0) bump16(s_P + slot0 * cellsw, mad24(nb_e, ng1, cur));
+                                if (slot1 >= 0) bump16(s_P + slot1 * cellsw, mad24(nb_se, ng1, cur));
+                                if (slot2 >= 0) bump16(s_P + slot2 * cellsw, mad24(nxt, ng1, cur));
+                                if (slot3 >= 0) bump16(s_P + slot3 * cellsw, mad24(nb_sw, ng1, cur));
+                            }
+                        }
+                        cur = nxt;
+                    }
+                }
             } else {
                 for (int row = wave; row < (int)h; row += NW)
                     for (int col = lane; col < (int)w; col += 64) {
@@ -2336,6 +2376,57 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                         pair_row(cur4, nxt4);
                         cur4 = nxt4;
                     }
+                    }
+                } else if (A.glcm_offset == 1) {
+                    // ---- boxes wider than a wave: column strips.  Lane L of a strip holds column c0 - 1 + L; lanes 1 .. 62 are the
+                    // centres, lanes 0 and 63 only lend their values as the west / east neighbours of the strip's edge columns (a
+                    // strip advances by 62 columns), so every neighbour is a DPP lane shift away as in the narrow-box sweep -- where
+                    // the per-pixel loop below pays four bounds tests, four plane reads and the index arithmetic per pixel (two
+                    // thirds of the kernel's time on 205-wide boxes).  Plain Ng x Ng matrices.
+                    int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
+#pragma unroll
+                    for (int q = 0; q < kMaxAngles; q++)
+                        if (q < na_pass) {
+                            int ang = A.glcm_angles[a0 + q];
+                            if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
+                        }
+                    const int rows_per_wave = ((int)h + NW - 1) / NW;
+                    const int r_begin = wave * rows_per_wave;
+                    const int r_end = (r_begin + rows_per_wave) < (int)h ? (r_begin + rows_per_wave) : (int)h;
+                    const bool remap = greyInfo < 0;
+                    char* const B0 = slot0 >= 0 ? (char*)(s_P + slot0 * NN) - 4 : nullptr;
+                    char* const B1 = slot1 >= 0 ? (char*)(s_P + slot1 * NN) - 4 : nullptr;
+                    char* const B2 = slot2 >= 0 ? (char*)(s_P + slot2 * NN) - 4 : nullptr;
+                    char* const B3 = slot3 >= 0 ? (char*)(s_P + slot3 * NN) - 4 : nullptr;
+                    auto bump = [=](char* Bq, uint32_t rowb, uint32_t c4, uint32_t nb4) {
+                        if (Bq != nullptr && nb4 != 0) {
+                            atomicAdd((uint32_t*)(Bq + rowb + nb4), 1u);
+                            if (symmetric)
+                                atomicAdd((uint32_t*)(Bq + __umul24(nb4 - 4, (uint32_t)Ng) + c4), 1u);
+                        }
+                    };
+                    for (uint32_t c0 = 0; c0 < w; c0 += 62) {
+                        const int c = (int)c0 - 1 + lane;
+                        const bool in_col = c >= 0 && c < (int)w;
+                        const bool centre = in_col && lane >= 1 && lane <= 62;
+                        auto lvl4 = [&](int row) -> uint32_t {      // level of (row, c) as a byte offset into a matrix row, 0 = skip
+                            uint32_t v = (in_col && row < (int)h) ? (uint32_t)s_dense[(uint32_t)row * w + (uint32_t)c] : 0u;
+                            if (remap && v) v = s_lvlmap[v];        // compact index + 1
+                            return v << 2;
+                        };
+                        uint32_t cur4 = r_begin < r_end ? lvl4(r_begin) : 0u;
+                        for (int row = r_begin; row < r_end; row++) {
+                            const uint32_t nxt4 = lvl4(row + 1);
+                            const uint32_t nb_e = lane_plus1(cur4, 0), nb_se = lane_plus1(nxt4, 0), nb_sw = lane_minus1(nxt4, 0);
+                            if (centre && cur4 != 0) {
+                                const uint32_t rowb = __umul24(cur4 - 4, (uint32_t)Ng);
+                                bump(B0, rowb, cur4, nb_e);
+                                bump(B1, rowb, cur4, nb_se);
+                                bump(B2, rowb, cur4, nxt4);
+                                bump(B3, rowb, cur4, nb_sw);
+                            }
+                            cur4 = nxt4;
+                        }
                     }
                 } else
                 for (int row = wave; row < (int)h; row += NW) {
@@ -2605,8 +2696,8 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = a.L.cnt16 != 0;
     if (a.sp.scratch) {
-        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((roi_features_kernel<true, false, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (c16) hipLaunchKernelGGL((roi_features_kernel<true, true, false, false>), dim3(grid), dim3(kBlock), a.L.gs_lds_bytes, st, a);
+        else hipLaunchKernelGGL((roi_features_kernel<true, false, false, false>), dim3(grid), dim3(kBlock), a.L.gs_lds_bytes, st, a);
         return (int)hipGetLastError();
     }
     if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] features launch: g16 %u dense8 %u cnt16 %u ng_cap %u app %u total %u mask %u gd %d\n", a.L.g16, a.L.dense8, a.L.cnt16, a.L.ng_cap, a.L.app, a.L.total, a.mask, a.grey_depth);

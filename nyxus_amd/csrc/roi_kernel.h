@@ -82,6 +82,10 @@ struct LdsLayout {
     uint32_t lvl_cap;    // number of radiomics bins
     uint32_t app;        // angles per co-occurrence pass (4, 2 or 1)
     uint32_t g16;        // 1: matlab binning with 17..64 levels, 16-bit co-occurrence cells, marginal-based features (roi_features_kernel_g16)
+    // workspace launches (state in global memory): regions whose offset lies below this bound still live in the workgroup's LDS
+    // -- the small, atomics-heavy ones: reduction scratch, histogram bounds, co-occurrence matrices, the counting table when it
+    // fits -- and only the ROI-sized buffers (values, binned plane) in the workspace
+    uint32_t gs_lds_bytes;
 };
 
 // Window source of the fused tile path: when `inten` is set the feature kernel reads an ROI's pixels from its bounding-box
