@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_PEAK_TF = 78.6    # AMD Instinct MI355X data sheet: peak fp64 vector = fp64 matrix, 78.6 TFLOP/s (the guide has no fp64 row)
 
 
 def parse():
@@ -56,9 +57,21 @@ def parse():
     return ap.parse_args()
 
 
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into this process, which initialises the GPU before main() runs (with --pmc it
+    certainly does): starting child ranks from here would be an exec out of a GPU-initialised process -- forbidden on this pool."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return any(t in pre for t in ("rocprof", "roctracer", "rocprofiler")) or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+
+
 def launch(a) -> int:
     """`--gpus N` without a rendezvous in the environment: start N ranks of this script, one per GPU.
-    The launcher itself never initialises HIP (children are fresh processes, nothing is exec'ed over a GPU process)."""
+    The launcher itself never initialises HIP (children are fresh processes, nothing is exec'ed over a GPU process) -- which
+    does not hold under a profiler preload: profiling is single-rank only."""
+    if under_profiler():
+        print("bench.py: --gpus > 1 cannot be launched from a profiled process (the profiler has initialised the GPU here); "
+              "profile one rank (--gpus 1)", file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -107,6 +120,11 @@ def run_stub(a, world, rank):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    mine = {"rank": rank, "device": "cpu-stub", "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(rows.shape[0])}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     g = TableGather(ncol, dst=0)
     g.start(last)
     full = g.finish()
@@ -114,7 +132,7 @@ def run_stub(a, world, rank):
         want = [t * 1000.0 + r for t in range(a.tiles * world) for r in range(rois_per_tile)]
         ok = full.shape[0] == len(want) and bool((full[:, 0].floor() == torch.tensor(want, dtype=torch.float64)).all())
         print(json.dumps({"metric": "stub", "stub": True, "value": None, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(full.shape[0]), "row_order_ok": ok}))
+                          "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(full.shape[0]), "row_order_ok": ok, "per_rank": per_rank}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -128,6 +146,36 @@ def disk_cloud(radius=30):
     y, x = np.nonzero(m)
     o = np.lexsort((y, x))
     return x[o].astype(np.uint16), y[o].astype(np.uint16), 2 * r + 1
+
+
+def host_rows(dev_arrays, idx):
+    """HostBatch of the ROIs `idx` of a device-resident batch (dict of torch tensors: px_offset, x, y, inten, bbox_w, bbox_h,
+    min_inten, max_inten) -- what the oracle is given in the parity gates."""
+    from nyxus_amd import _abi
+    off = dev_arrays["px_offset"].cpu().numpy().astype(np.int64)
+    idx = np.asarray(idx, np.int64)
+    segs = [np.arange(off[i], off[i + 1]) for i in idx]
+    cat = np.concatenate(segs)
+    sel = lambda k, dt: dev_arrays[k].cpu().numpy().view(dt)
+    import torch
+    ct = torch.from_numpy(cat).to(dev_arrays["x"].device)
+    g = lambda k, dt: dev_arrays[k][ct].cpu().numpy().view(dt)
+    no = np.concatenate([[0], np.cumsum([len(s_) for s_ in segs])]).astype(np.uint64)
+    return _abi.HostBatch(np.asarray(idx + 1, np.uint32), no, g("x", np.uint16), g("y", np.uint16), g("inten", np.uint32), sel("bbox_w", np.uint32)[idx],
+                          sel("bbox_h", np.uint32)[idx], sel("min_inten", np.uint32)[idx], sel("max_inten", np.uint32)[idx])
+
+
+def gate(table_rows, hb, mask, s):
+    """Parity gate of a timed leg (a timed configuration counts only if its features match): rows of the
+    table the leg produced vs the CPU oracle on the same ROIs.  Returns "ok" or the mismatch count (details on stderr)."""
+    from nyxus_amd import _lib
+    from oracle import pyoracle as po
+    from tests import parity
+    want = po.oracle_featurize(hb, mask, s)
+    bad = parity.compare_tables(np.asarray(table_rows), want, _lib.column_names(mask, s), batch=hb)
+    if bad:
+        print("\n".join(bad[:10]), file=sys.stderr)
+    return "ok" if not bad else f"{len(bad)} MISMATCHES"
 
 
 def main():
@@ -220,6 +268,24 @@ def main():
     kern_ms, n_launch = ctx.timing_get()
     ctx.timing(False)
 
+    # per-rank detail for the one line the driver keeps: which physical device each rank ran on (PCI bus id -- two ranks on one
+    # device would still print a plausible aggregate), its own time and kernel time, its rows
+    props = torch.cuda.get_device_properties(local_rank)
+    pci = getattr(props, "pci_bus_id", None)
+    try:
+        dev_uuid = str(props.uuid)
+    except Exception:
+        dev_uuid = None
+    mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name, "pci_bus_id": pci, "uuid": dev_uuid,
+            "ms_per_step": 1e3 * (t1 - t0) / max(a.steps, 1), "kernel_ms": kern_ms, "rows": n_roi}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    same_device = None
+    ids = [(r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in per_rank]
+    if len(set(ids)) != len(ids):
+        same_device = f"ranks share a device: {ids}"
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -277,25 +343,38 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
 
+        rec["per_rank"] = per_rank
+        if same_device:
+            rec["error"] = same_device
         if gather_ms is not None or gather_err is not None:
             gb = n_roi * world * ncol * 8 / 1e9
             rec["table_gather"] = {"ms": gather_ms, "GB": gb, "GBps": (gb / (gather_ms * 1e-3)) if gather_ms else None, "error": gather_err,
                                    "what": "one RCCL gather of the last step's table (all ranks -> rank 0), outside the timed region"}
-        # ---- parity spot check of what was timed (first tile of the last step) -----------------
+        # ---- parity gate of what was timed: first, middle and LAST tile of the last step vs the oracle, and every row of the
+        #      table against exact reductions of the same device arrays (a defect at large ROI indices cannot hide) -----------------
+        dev_arrays = {"px_offset": off, "x": x, "y": y, "inten": inten, "bbox_w": bw, "bbox_h": bh, "min_inten": mn, "max_inten": mx}
+        gates = {}
         if not a.no_check:
-            from oracle import pyoracle as po
-            from tests import parity
             k = rois_per_tile
-            hb = _abi.HostBatch(labels[:k].cpu().numpy().astype(np.uint32), off[:k + 1].cpu().numpy().astype(np.uint64),
-                                x[:k * n_px_roi].cpu().numpy().view(np.uint16), y[:k * n_px_roi].cpu().numpy().view(np.uint16),
-                                inten[:k * n_px_roi].cpu().numpy().view(np.uint32), bw[:k].cpu().numpy().view(np.uint32),
-                                bh[:k].cpu().numpy().view(np.uint32), mn[:k].cpu().numpy().view(np.uint32),
-                                mx[:k].cpu().numpy().view(np.uint32))
-            want = po.oracle_featurize(hb, mask, s)
-            bad = parity.compare_tables(last[:k].cpu().numpy(), want, _lib.column_names(mask, s))
-            rec["config"]["parity_check"] = "first tile of the last timed step vs oracle: " + ("ok" if not bad else f"{len(bad)} MISMATCHES")
-            if bad:
-                print("\n".join(bad[:10]), file=sys.stderr)
+            res = []
+            for t in sorted({0, a.tiles // 2, a.tiles - 1}):
+                idx = np.arange(t * k, (t + 1) * k)
+                res.append(gate(last[idx[0]:idx[-1] + 1].cpu().numpy(), host_rows(dev_arrays, idx), mask, s))
+            cols = _lib.column_names(mask, s)
+            inv = "n/a"
+            if "MIN" in cols:
+                iv64 = inten.view(n_roi, n_px_roi).to(torch.int64)
+                tot = iv64.sum(dim=1).to(torch.float64)
+                # (tensor / tensor: a Python-scalar divisor makes torch multiply by the reciprocal, which rounds differently from the division)
+                exact = {"MIN": mn.to(torch.float64), "MAX": mx.to(torch.float64), "INTEGRATED_INTENSITY": tot,
+                         "MEAN": torch.div(tot, torch.full_like(tot, float(n_px_roi))), "RANGE": (mx - mn).to(torch.float64)}
+                wrong = {c: int((last[:, cols.index(c)] != v).sum().item()) for c, v in exact.items()}
+                inv = "ok" if not any(wrong.values()) else "MISMATCHES " + json.dumps({c: k for c, k in wrong.items() if k})
+                del iv64, tot
+            ok = all(r == "ok" for r in res) and inv in ("ok", "n/a")
+            gates["headline"] = "ok" if ok else "FAILED"
+            rec["config"]["parity_check"] = (f"tiles 0, {a.tiles // 2}, {a.tiles - 1} of the last timed step vs oracle: " + "/".join(res)
+                                             + f"; all {n_roi} rows, MIN/MAX/RANGE/MEAN/INTEGRATED_INTENSITY vs exact device reductions: {inv}")
 
         # ---- CPU baseline: the reference's own multithreaded reduce on host cores ---------------
         if world == 1 and not a.no_cpu_baseline:
@@ -327,7 +406,8 @@ def main():
                 "host_cpus": cores}
         # ---- informational legs on the same resident batch: the reference's DEFAULT grey depth, BASELINE.json configs[3] and [4] ----
         if world == 1 and not a.no_extras and mask == 3:
-            def timed(msk, st, cbatch, n_rows, reps=3):
+            def timed(msk, st, cbatch, n_rows, reps=3, check_rows=None, arrays=None):
+                """One leg: warm-up call, `reps` timed calls; the parity gate (rows `check_rows` of the table vs the oracle) on what it left."""
                 nc = ctx.n_columns(msk, st)
                 o = torch.empty((n_rows, nc), dtype=torch.float64, device=dev)
                 ctx.featurize_device_async(cbatch, msk, st, o.data_ptr(), nc)
@@ -337,15 +417,34 @@ def main():
                     ctx.featurize_device_async(cbatch, msk, st, o.data_ptr(), nc)
                 torch.cuda.synchronize()
                 ctx.sync()
-                return (time.perf_counter() - c0) / reps, nc
+                dt_ = (time.perf_counter() - c0) / reps
+                par = None
+                if check_rows is not None and not a.no_check:
+                    ct = torch.from_numpy(np.asarray(check_rows, np.int64)).to(dev)
+                    par = gate(o[ct].cpu().numpy(), host_rows(arrays, check_rows), msk, st)
+                return dt_, nc, par
+            last_tile = np.arange((a.tiles - 1) * rois_per_tile, a.tiles * rois_per_tile)
+            # BASELINE.json configs[1] and [2] alone: *ALL_INTENSITY* at the default 64 histogram bins, *ALL_GLCM* at 8 grey levels
             s64 = _abi.default_settings(64)
-            dt64, _ = timed(mask, s64, cb, n_roi)
-            rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64,
+            dt2, nc2, par2 = timed(_abi.FAM_INTENSITY, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            b2 = n_px * 4 + n_roi * nc2 * 8                      # intensities only: 4 B per ROI pixel in
+            rec["config2"] = {"value": n_roi / dt2, "unit": "ROIs/s", "ms_per_step": 1e3 * dt2, "n_columns": nc2, "parity_check": par2,
+                              "roofline": {"bound": "hbm", "achieved": b2 / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / dt2 / 1e9 / HBM_PEAK_GBS,
+                                           "algorithmic_bytes_per_launch": b2},
+                              "what": "BASELINE.json configs[1]: *ALL_INTENSITY* alone (36 columns, 64 histogram bins = the default coarse_gray_depth) on the same 1000 tiles"}
+            dt3, nc3, par3 = timed(_abi.FAM_GLCM, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            b3 = n_px * 8 + n_roi * nc3 * 8
+            rec["config3"] = {"value": n_roi / dt3, "unit": "ROIs/s", "ms_per_step": 1e3 * dt3, "n_columns": nc3, "parity_check": par3,
+                              "roofline": {"bound": "hbm", "achieved": b3 / dt3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b3 / dt3 / 1e9 / HBM_PEAK_GBS,
+                                           "algorithmic_bytes_per_launch": b3},
+                              "what": "BASELINE.json configs[2]: *ALL_GLCM* alone (8 grey levels, 4 angles, d = 1; 149 columns) on the same 1000 tiles"}
+            dt64, _, par64 = timed(mask, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64, "parity_check": par64,
                                     "what": "the metric workload at the reference's default coarse_gray_depth=64 (64 x 64 co-occurrence matrices, 64 histogram bins)"}
             m4 = _abi.FAM_INTENSITY | _abi.FAM_GLCM | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
-            dt4, nc4 = timed(m4, s, cb, n_roi)
+            dt4, nc4, par4 = timed(m4, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
             b4 = n_px * 8 + n_roi * nc4 * 8
-            rec["config4"] = {"value": n_roi / dt4, "unit": "ROIs/s", "ms_per_step": 1e3 * dt4, "n_columns": nc4,
+            rec["config4"] = {"value": n_roi / dt4, "unit": "ROIs/s", "ms_per_step": 1e3 * dt4, "n_columns": nc4, "parity_check": par4,
                               "roofline": {"bound": "hbm", "achieved": b4 / dt4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b4 / dt4 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b4},
                               "what": "BASELINE.json configs[3] per GPU: *ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY* (gd 8) on the same 1000 tiles"}
@@ -373,17 +472,42 @@ def main():
                     setattr(cb5, k5, t5.data_ptr())
                 cb5.slide_min = None; cb5.slide_max = None; cb5.memory = _abi.MEM_DEVICE
                 m5k = _abi.FAM_GABOR | _abi.FAM_ZERNIKE
-                dt5, _ = timed(m5k, s5, cb5, hb5.n_roi)
+                chk5 = np.concatenate([np.arange(64), np.arange(hb5.n_roi - 64, hb5.n_roi)])       # first and last ROIs of the batch
+                dt5, _, par5 = timed(m5k, s5, cb5, hb5.n_roi, check_rows=chk5, arrays=keep5)
                 # Gabor 2*2*w*h*n^2 flops per filter (complex MAC on a real image; 8 filters + the low-pass), Zernike 2*55 per pixel
                 fl5 = float(np.sum(9.0 * 4.0 * hb5.bbox_w.astype(np.float64) * hb5.bbox_h * 256.0) + 110.0 * hb5.n_px)
                 rec["config5"] = {"value": hb5.n_roi / dt5, "unit": "ROIs/s", "ms_per_step": 1e3 * dt5, "rois": int(hb5.n_roi), "mean_px": hb5.n_px / hb5.n_roi,
-                                  "roofline": {"bound": "fp64 vector", "achieved": fl5 / dt5 / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl5 / dt5 / 1e12 / 78.6,
+                                  "parity_check": par5,
+                                  "roofline": {"bound": "fp64 vector", "achieved": fl5 / dt5 / 1e12, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": fl5 / dt5 / 1e12 / FP64_PEAK_TF,
                                                "algorithmic_flops_per_launch": fl5,
-                                               "note": "fp64 matrix peak = fp64 vector peak on MI355X (MI355X_MICROARCH.md); the direct convolution is bit-exact with the reference, DESIGN 4.3"},
+                                               "note": "peak = AMD's MI355X data sheet (fp64 vector = fp64 matrix, 78.6 TFLOP/s; MI355X_MICROARCH.md lists no fp64 row); "
+                                                       "the direct convolution is bit-exact with the reference, DESIGN 4.3"},
                                   "what": "BASELINE.json configs[4]: GABOR (8-filter bank, 16x16) + ZERNIKE2D on DSB2018-shaped ROIs (fixture shapes replicated with seeded noise)"}
                 del keep5
             except Exception as e5:           # informational leg: never costs the headline line
                 rec["config5"] = {"error": repr(e5)}
+            # ---- ROI size: homogeneous batches at six sizes, and one heavy-tailed batch (log-normal radii 4..150 + 1 % of 300..400-px
+            #      boxes) in ONE call -- the reference's workers take ROIs of any size (parallel.h:23-42); here a call is split into
+            #      launches per size class (nyxhip_launch_report) -----------------------------------------------------------------------
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import size_legs as sl
+                rec["size_sweep"] = {"rows": sl.size_sweep(ctx, dev, mask, s),
+                                     "what": "ns per ROI of homogeneous batches of disks (radius 4, 9, 18, 30, 51, 102), *ALL_GLCM*+*ALL_INTENSITY*, gd 8"}
+
+                def chk_mixed(bm, om, mk=mask):
+                    rng = np.random.default_rng(1)
+                    pick = np.unique(np.concatenate([rng.choice(bm.n_roi, 96, replace=False), [int(np.argmax(bm.n_px_roi))], [int(np.argmin(bm.n_px_roi))], [bm.n_roi - 1]]))
+                    ct = torch.from_numpy(pick).to(dev)
+                    return gate(om[ct].cpu().numpy(), bm.host_rows(pick), mk, s)
+                mrec, bm, om = sl.mixed_sizes(ctx, dev, mask, s, check=None if a.no_check else chk_mixed)
+                del om
+                m4rec, _, _ = sl.mixed_sizes(ctx, dev, m4, s, check=None if a.no_check else (lambda b_, o_: chk_mixed(b_, o_, m4)))
+                mrec["config4_set"] = {k_: m4rec[k_] for k_ in ("ms_per_call", "rois_per_s", "GBps", "classes", "parity_check") if k_ in m4rec}
+                rec["mixed_sizes"] = mrec
+                del bm
+            except Exception as es:
+                rec["mixed_sizes"] = {"error": repr(es)}
         # ---- informational: the fused tile path (label scan + ROI assembly + reduce from tiles in HBM) -------
         if world == 1 and a.tile_path_tiles > 0:
             from tests import synth
@@ -403,6 +527,17 @@ def main():
                                                 C.byref(s), t_lab.data_ptr(), t_idx.data_ptr(), cap, t_out.data_ptr(), ncol, C.byref(nroi))
                 if rc != 0:
                     raise RuntimeError(lib.nyxhip_last_error(ctx._h).decode())
+            def tile_gate(label_stack):
+                """Parity gate of a tile-path leg: the rows of the LAST tile of the stack vs host ROI assembly + oracle."""
+                if a.no_check:
+                    return None
+                from nyxus_amd import roi_assembly
+                n_ = int(nroi.value)
+                sel = torch.nonzero(t_idx[:n_] == nt - 1).flatten()
+                hbt = roi_assembly.assemble(tin[nt - 1].cpu().numpy().view(np.uint32), label_stack[nt - 1].cpu().numpy().view(np.uint32), 1.7976931348623157e308, -1.7976931348623157e308)
+                if hbt is None or hbt.n_roi != len(sel) or not np.array_equal(t_lab[:n_][sel].cpu().numpy().view(np.uint32), hbt.roi_label):
+                    return "ROW MISMATCH (labels of the last tile)"
+                return gate(t_out[:n_][sel].cpu().numpy(), hbt, mask, s)
             tile_step()
             torch.cuda.synchronize()
             c0 = time.perf_counter()
@@ -411,9 +546,10 @@ def main():
                 tile_step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - c0) / reps
+            par_t = tile_gate(labs)
             tile_bytes = nt * (8 * 1024 * 1024 + 196 * ncol * 8)     # 8.68 MB per tile
             rec["tile_path"] = {"value": nroi.value / dt, "unit": "ROIs/s", "tiles_per_s": nt / dt, "tiles": nt,
-                                "rois": int(nroi.value), "ms_per_call": 1e3 * dt,
+                                "rois": int(nroi.value), "ms_per_call": 1e3 * dt, "parity_check": par_t,
                                 "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                         "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
@@ -438,6 +574,7 @@ def main():
                 torch.cuda.synchronize()
                 dti = (time.perf_counter() - c0) / reps
                 rec["tile_path"]["irregular"] = {"value": nroi.value / dti, "unit": "ROIs/s", "tiles": nt, "rois": int(nroi.value), "ms_per_call": 1e3 * dti,
+                                                 "parity_check": tile_gate(labs_i),
                                                  "what": "the same call on SURVEY 8(d)'s irregular label tiles (radius 8..35 per ROI, 10 % concave): "
                                                          "mixed ROI sizes, bounding boxes up to 71 wide"}
                 del labs_i, lab_i
@@ -482,6 +619,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if same_device or gather_err:
+        sys.exit(3)                          # the line is printed, but a job whose ranks shared a device (or whose gather failed) did not measure N GPUs
 
 
 if __name__ == "__main__":

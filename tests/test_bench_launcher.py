@@ -22,6 +22,16 @@ def test_gpus_flag_spawns_that_many_ranks():
     rec = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--tiles", "5", "--stub"])
     assert rec["stub"] is True and rec["n_gpus"] == 2 and rec["steps"] == 3
     assert rec["rows"] == 2 * 5 * 3 and rec["row_order_ok"]       # weak scaling: 5 tiles per rank, rows in (tile, label) order
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1] and all(r["rows"] == 15 for r in rec["per_rank"])   # per-rank detail in the one line
+
+
+def test_launcher_refuses_to_start_ranks_from_a_profiled_process():
+    """rocprofv3 preloads its tool into the process (the GPU is initialised before main() runs); child ranks started from there
+    would be an exec out of a GPU-initialised process.  The launcher refuses: profiling is single-rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ROCPROFILER_REGISTER_FORCE_LOAD"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--tiles", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "profiled process" in p.stderr
 
 
 def test_single_rank_needs_no_launcher():

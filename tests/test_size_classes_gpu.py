@@ -112,3 +112,36 @@ def test_a_wrong_statement_about_the_batch_is_an_error(hip_ctx):
     hip_ctx.sync()
     want = po.oracle_featurize(b, MASK, s)
     assert not parity.compare_tables(out.cpu().numpy(), want, _lib.column_names(MASK, s))
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise them)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
+def test_two_gpus_bench_and_sharded_api_agree_with_one():
+    """The moment two devices exist: `bench.py --gpus 2` over RCCL (per-rank devices distinct, table gathered, parity gate ok) and
+    Nyxus(gpu_devices=[0, 1]) equal to the single-device result bit for bit.  (The driver's 8-GPU SCALE run is the same code.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import nyxus_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiles", "16", "--steps", "2", "--warmup", "1", "--no-extras",
+                        "--tile-path-tiles", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and len(rec["per_rank"]) == 2 and "error" not in rec
+    assert len({r["uuid"] or r["pci_bus_id"] for r in rec["per_rank"]}) == 2
+    assert rec["table_gather"]["error"] is None and "ok" in rec["config"]["parity_check"] and "MISMATCH" not in rec["config"]["parity_check"]
+    rng = np.random.default_rng(8)
+    I = rng.integers(1, 4096, (6, 128, 128)).astype(np.uint16)
+    M = np.stack([synth.disk_label_tile(size=128, pitch=32, radius=6 + 2 * k) * (k + 1) for k in range(6)]).astype(np.uint32)
+    feats = ["*ALL_INTENSITY*", "*ALL_GLCM*", "*ALL_GLSZM*"]
+    one = nyxus_amd.Nyxus(feats, coarse_gray_depth=8).featurize(I, M)
+    two = nyxus_amd.Nyxus(feats, coarse_gray_depth=8, gpu_devices=[0, 1]).featurize(I, M)
+    assert one.equals(two)
