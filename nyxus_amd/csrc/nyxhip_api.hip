@@ -13,13 +13,14 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <atomic>
 
 #include "../../include/nyxhip.h"
 #include "roi_kernel.h"
 
 using namespace nyxhip;
 
-struct Extrema { uint32_t px, area, range, side; };
+struct Extrema { uint32_t px, area, range, side; uint32_t vmax = 0; };   // vmax: largest intensity (0: not known -- stated extrema carry none)
 struct ClassRun {              // one size class of one call, as launched (nyxhip_launch_report)
     int cls;                   // 2 * size class + (1: some ROI needs 32-bit tables); -1: the whole batch in one launch group
     uint32_t count;            // members (0xFFFFFFFF: counted on the device only)
@@ -94,6 +95,7 @@ struct nyxhip_ctx {
 namespace {
 
 thread_local std::string g_init_error;
+std::atomic<int> g_ctx_on_device[64];          // live contexts per device (default memory budgets are shared among them)
 
 int fail(nyxhip_ctx* ctx, int code, const std::string& msg)
 {
@@ -263,7 +265,7 @@ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 // NYXHIP_ERR_UNSUPPORTED when the grey depth alone cannot be held in LDS, or
 // NYXHIP_ERR_ROI_TOO_LARGE when the batch extrema do not fit the 160 KiB of a CU.
 int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
-                uint32_t max_range, LdsLayout& L, std::string& why, size_t cap = 0)
+                uint32_t max_range, LdsLayout& L, std::string& why, size_t cap = 0, uint32_t vmax = 0)
 {
     memset(&L, 0, sizeof(L));
     const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
@@ -344,10 +346,20 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
                 return NYXHIP_ERR_UNSUPPORTED;
             }
         } else {
-            // IBSI: matrix order = max intensity (glcm.cpp:412-419), unknown before the scan;
-            // reserve the largest order that fits next to this batch's ROIs, up to 128.
-            ng = 128;
-            while (ng > 8 && shared0 + glcm_bytes(ng, 1) > cap) ng >>= 1;
+            // IBSI: matrix order = the ROI's largest intensity (glcm.cpp:400-419: the reference allocates max x max).  Known
+            // (exact launch groups: the class header carries it): exactly that order -- and if it does not fit LDS next to the
+            // ROIs the group goes to the global workspace like any grey depth beyond LDS.  Not known (stated extrema): the
+            // largest order that fits next to this batch's ROIs, up to 128; a larger ROI raises the error flag.
+            if (vmax != 0) {
+                ng = vmax < 8 ? 8 : vmax;
+                if (shared0 + glcm_bytes(ng, 1) > cap) {
+                    why = "IBSI GLCM matrix order " + std::to_string(ng) + " too large for the LDS-resident co-occurrence matrix";
+                    return NYXHIP_ERR_UNSUPPORTED;
+                }
+            } else {
+                ng = 128;
+                while (ng > 8 && shared0 + glcm_bytes(ng, 1) > cap) ng >>= 1;
+            }
         }
         uint32_t app = 4;
         while (app > 1 && ((!spill && 4ull * app * ng * ng > 64 * 1024) || shared0 + glcm_bytes(ng, app) > cap)) app >>= 1;
@@ -673,7 +685,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
     int c_glszm = c_gldzm + ((mask & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0), c_gldm = c_glszm + ((mask & NYXHIP_FAM_GLSZM) ? kGlszmCols : 0);
     int c_ngldm = c_gldm + ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0);
     if (mask1 && (groups & 1)) {
-        if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap))
+        if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap, E.vmax))
             return lrc;
         a.n_roi = b->n_roi;
         a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
@@ -865,7 +877,7 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
 // {16-bit tables possible, not possible} by each ROI's OWN pixel count, box and intensity range (never by its companions), and
 // every class is launched over its index list with a carve-out -- hence kernel build and occupancy -- of its own.  Classes whose
 // carve-out does not fit a CU's LDS run the same kernels with their scratch in a global workspace.
-enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_PAD, H_WORDS };   // header words per class
+enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_VMAX, H_WORDS };   // header words per class
 
 // pass 1: members and extrema of every class (block-local in LDS first: ten hot words would serialise 5 n_roi global atomics)
 __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
@@ -885,13 +897,14 @@ __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, co
         atomicMax(&c[H_AREA], a64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a64);
         atomicMax(&c[H_RANGE], r);
         atomicMax(&c[H_SIDE], w > h ? w : h);
+        atomicMax(&c[H_VMAX], mx[i]);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < kClasses * H_WORDS; k += blockDim.x) {
         const int f = k % H_WORDS;
         if (s_h[k] == 0) continue;
         if (f == H_COUNT) atomicAdd(&hdr[k], s_h[k]);
-        else if (f >= H_PX && f <= H_SIDE) atomicMax(&hdr[k], s_h[k]);
+        else if ((f >= H_PX && f <= H_SIDE) || f == H_VMAX) atomicMax(&hdr[k], s_h[k]);
     }
 }
 
@@ -1098,7 +1111,9 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
     if ((mask & ~kMoments) || !hinted) {               // (a batch without stated extrema gets them from the class headers)
         bool done = false;
         static const bool force_exact = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
-        if (hinted && !force_exact && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
+        // (IBSI co-occurrence matrices are as large as the largest intensity, which a statement about the batch does not carry)
+        const bool need_vmax = s->ibsi && (mask & NYXHIP_FAM_GLCM);
+        if (hinted && !force_exact && !need_vmax && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
             // ---- whole-batch launches, nothing counted -----------------------------------------------------------------------
             const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]), has_wide = max_range >= 16384u;
             const Extrema Eall{max_px, max_area, max_range, max_side};
@@ -1170,7 +1185,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             for (int cls = kClasses - 1; cls >= 0 && (mask & ~kMoments); cls--) {   // largest ROIs first: their long workgroups start early
                 const uint32_t* h = H + cls * H_WORDS;
                 if (h[H_COUNT] == 0) continue;
-                const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE]};
+                const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE], h[H_VMAX]};
                 if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], h[H_COUNT]))
                     return rc;
             }
@@ -1271,6 +1286,7 @@ int nyxhip_init(int device, nyxhip_ctx** out_ctx)
         if (hipMalloc((void**)&ctx->d_stamps, 32 * sizeof(unsigned long long)) == hipSuccess)
             (void)hipMemset(ctx->d_stamps, 0, 32 * sizeof(unsigned long long));
     }
+    g_ctx_on_device[device & 63].fetch_add(1);
     *out_ctx = ctx;
     return NYXHIP_OK;
 }
@@ -1278,6 +1294,7 @@ int nyxhip_init(int device, nyxhip_ctx** out_ctx)
 void nyxhip_destroy(nyxhip_ctx* ctx)
 {
     if (!ctx) return;
+    g_ctx_on_device[ctx->device & 63].fetch_sub(1);
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -1482,7 +1499,9 @@ static uint32_t first_tile_cap(uint64_t tile_px)
 static size_t chunk_table_bytes(uint32_t nt, uint32_t cap)
 {
     const size_t ent = (size_t)nt * cap;
-    return ent * 32 + ent * (12 * 4 + 8 + 16) + (size_t)nt * 16 + (ent / 1024 + 2) * 12 + (1 << 16);
+    // per slot: 8 table words + 10 + 10 row words (unsorted / sorted rows) + three 8-byte arrays (CSR offsets, slide min / max) -- the
+    // carve-out of tiles_chunk, kept in step with it; per 1024 slots: block sums; per tile: row / pixel starts and given slide extrema
+    return ent * (28 * 4 + 3 * 8) + (ent / 1024 + 2) * 12 + (size_t)nt * (12 + 16) + 24 * 256 + (1 << 16);
 }
 
 // One chunk of tiles resident on the device -> rows in d_lab / d_til / d_out (device).  *n_roi_out rows are produced; more than
@@ -1664,7 +1683,10 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
     if (budget == 0) {
         size_t fr = 0, tot = 0;
         HIP_TRY(ctx, hipMemGetInfo(&fr, &tot));
-        budget = (fr + ctx->tile_bytes + ctx->cloud_bytes + ctx->slot_bytes[0] + ctx->slot_bytes[1]) / 2;
+        // half of what is free, shared with the other contexts living on this device (gpu_devices=[0, 0], two sharded contexts
+        // on one GPU: each taking half of the free memory for itself would together claim all of it)
+        const int sharers = std::max(1, g_ctx_on_device[ctx->device & 63].load());
+        budget = (fr + ctx->tile_bytes + ctx->cloud_bytes + ctx->slot_bytes[0] + ctx->slot_bytes[1]) / 2 / (size_t)sharers;
     }
     const uint32_t cap0 = ctx->tile_cap_hint ? ctx->tile_cap_hint : first_tile_cap(tile_px);
     const size_t per_tile = chunk_table_bytes(1, cap0) + 8 * (size_t)tile_px + (size_t)cap0 * 8 * n_cols / 8 + (host ? 2 * tile_in_bytes : 0);
@@ -1673,12 +1695,24 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
     if (chunk > t->n_tiles) chunk = t->n_tiles;
     if (host && t->n_tiles >= 4 && chunk > (t->n_tiles + 1) / 2) chunk = (t->n_tiles + 1) / 2;                 // at least two chunks to overlap
     while ((uint64_t)chunk * cap0 > (1ull << 30) && chunk > 1) chunk /= 2;
+    if (chunk > 65535) chunk = 65535;                      // the scan kernel spends grid.z on the tiles of a chunk (HIP: z <= 65535)
+    // the per-tile table may grow while the stack is processed (a tile with more labels than slots: x 4 and rescan); the chunks
+    // after that are sized for the table that is then in force
+    auto rechunk = [&](uint64_t cur) -> uint64_t {
+        const uint32_t capn = ctx->tile_cap_hint ? ctx->tile_cap_hint : cap0;
+        if (capn <= cap0) return cur;
+        const size_t pt = chunk_table_bytes(1, capn) + 8 * (size_t)tile_px + (size_t)capn * 8 * n_cols / 8 + (host ? 2 * tile_in_bytes : 0);
+        uint64_t c2 = std::max<uint64_t>(1, budget / std::max<size_t>(pt, 1));
+        while ((uint64_t)c2 * capn > (1ull << 30) && c2 > 1) c2 /= 2;
+        return std::min(cur, c2);
+    };
 
     if (keep) ctx->res_rows = 0;
     uint64_t rows_done = 0;
     bool short_out = false;
     if (!host) {
         for (uint64_t t0 = 0; t0 < t->n_tiles; t0 += chunk) {
+            chunk = rechunk(chunk);
             const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
             const char* di = (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype;
             const char* dl = (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype;
@@ -1735,6 +1769,12 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         if (hipHostRegister((void*)t->inten, bi, hipHostRegisterDefault) == hipSuccess) pin.p[0] = (void*)t->inten; else (void)hipGetLastError();
         if (hipHostRegister((void*)t->label, bl, hipHostRegisterDefault) == hipSuccess) pin.p[1] = (void*)t->label; else (void)hipGetLastError();
     }
+    // every exit below -- the error returns included -- first waits for the copies and kernels still in flight: the pin guard above
+    // unregisters the caller's arrays, and the caller may free them the moment this function returns
+    struct Drain {
+        hipStream_t a, b;
+        ~Drain() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
+    } drain{ctx->copy_stream, st};
     if (int urc = upload(0)) return urc;
     for (uint64_t c = 0; c < n_chunks; c++) {
         const int k = (int)(c & 1);

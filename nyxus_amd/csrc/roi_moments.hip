@@ -414,13 +414,32 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     // trips (four waves per SIMD hide little of it: the sweeps took 3-4 ms each way); ROIs of up to kMomPxLds pixels are
     // therefore staged in LDS once -- x | y << 16 and the intensity, 8 bytes per pixel -- and swept from there.
     const bool staged = n <= A.px_cap;
-    if (staged)
+    // Compact staging (boxes up to 256 x 256 whose squared diagonal stays inside the logarithm table -- every staged ROI of usual
+    // data): intensity u32 | x, y as two bytes | a 16-bit slot per pixel for the squared distance to the contour pass 3 finds --
+    // the same 8 bytes per pixel as the general staging, and the per-pixel weight never travels to HBM: the two sweeps that
+    // need it look the logarithm up again in the (L2-resident) table.  The weights written as doubles and read back twice were
+    // 13 of the kernel's 16 GB of traffic per 196 k benchmark ROIs (the reference keeps them as vector<float> realintens, pixel.h:8).
+    const uint32_t bw_ = A.bbox_w[roi], bh_ = A.bbox_h[roi];
+    const bool compact = staged && small_xy && bw_ <= 256u && bh_ <= 256u && (bw_ + 2u) * (bw_ + 2u) + (bh_ + 2u) * (bh_ + 2u) < A.log_tab_n;
+    uint32_t* const s_v = (uint32_t*)mom_lds;                             // [A.px_cap]   (compact staging)
+    uint16_t* const s_xy8 = (uint16_t*)(s_v + A.px_cap);                  // [A.px_cap]   x | y << 8
+    uint16_t* const s_d2 = s_xy8 + A.px_cap;                              // [A.px_cap]   squared distance to the contour
+    if (compact)
+        for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
+            s_v[i] = vi; s_xy8[i] = (uint16_t)(xi | (yi << 8));
+        });
+    else if (staged)
         for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             s_px[i] = make_uint2(xi | (yi << 16), vi);
         });
     __syncthreads();
     auto sweep = [&](auto&& body) {                      // body(i, intensity, x, y) for this thread's pixels i = tid, tid + 256, ...
-        if (staged) {
+        if (compact) {
+            for (uint32_t i = (uint32_t)tid; i < n; i += kMB) {
+                const uint32_t xy = s_xy8[i];
+                body(i, s_v[i], xy & 0xFFu, xy >> 8);
+            }
+        } else if (staged) {
             for (uint32_t i = (uint32_t)tid; i < n; i += kMB) {
                 const uint2 q = s_px[i];
                 body(i, q.y, q.x & 0xFFFFu, q.x >> 16);
@@ -507,13 +526,14 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             const double dsq = !small_xy ? min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
                              : K == s_K ? min_sqdist_v2<true>((int)xi, (int)yi, s_K, nK, step0, s_step, tab_n)
                                         : min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
+            if (compact) { s_d2[i] = (uint16_t)(uint32_t)dsq; return; }       // (dsq <= the box's squared diagonal < log_tab_n <= 65536)
             const double lg = (small_xy && dsq < (double)A.log_tab_n) ? A.log_tab[(uint32_t)dsq] : log(sqrt(dsq) + 0.001);
             L[i] = lg;
         });
         // (the sums run as a sweep of their own over the weights just written -- every thread reads back its own stores: with
         //  the twenty accumulators live across the hill descent the 80-register build spilled and reloaded them per pixel)
         sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double lg = L[i];
+            const double lg = compact ? A.log_tab[s_d2[i]] : L[i];
             const double X = (double)xi, Y = (double)yi;
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
@@ -537,7 +557,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
 #pragma unroll
         for (int k = 0; k < 7; k++) { as[k] = 0; ai[k] = 0; }
         sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double X = (double)xi, Y = (double)yi, lg = L[i];
+            const double X = (double)xi, Y = (double)yi, lg = compact ? A.log_tab[s_d2[i]] : L[i];
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             {
                 const double dx = X - oxs, dy = Y - oys;

@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256) void tile_rank_kernel(TileRows U, const uint32
     const uint32_t tile = blockIdx.x;
     const uint32_t b = tile_row_begin[tile], e = tile_row_begin[tile + 1];
     const uint32_t n_t = (e > max_rows ? max_rows : e) - (b > max_rows ? max_rows : b);
-    if (blockIdx.y * 256u >= n_t)
-        return;
-    const uint32_t i = blockIdx.y * 256u + tid;
+    // (a tile with more than 65535 x 256 rows: the blocks of grid.y stride over its row blocks -- the grid's y extent is capped)
+    for (uint32_t yb = blockIdx.y; yb * 256ull < n_t; yb += gridDim.y) {
+    const uint32_t i = yb * 256u + tid;
     const bool mine = i < n_t;
     const uint32_t my_l = mine ? U.label[b + i] : 0xFFFFFFFFu;
     uint32_t rank = 0, mn = 0xFFFFFFFFu, mx = 0;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void tile_rank_kernel(TileRows U, const uint32
         }
     }
     if (!mine)
-        return;
+        continue;
     const uint32_t src = b + i, row = b + rank;
     R.tile[row] = tile; R.label[row] = my_l; R.area[row] = U.area[src];
     R.px_offset[row] = tile_px_begin[tile] + off;
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void tile_rank_kernel(TileRows U, const uint32
     R.slide_max[row] = slide_mode == 0 ? -DBL_MAX_ : slide_mode == 1 ? (double)mx : smax_in[tile];
     if (row + 1 == tile_row_begin[gridDim.x])           // last row of the stack closes the CSR offsets
         R.px_offset[row + 1] = tile_px_begin[gridDim.x];
+    }
 }
 
 // One workgroup per ROI: bbox window of the tile -> SoA cloud in row-major order (deterministic).
@@ -394,7 +395,8 @@ int launch_tile_assembly_scan(const void* inten, int dt_inten, const void* label
 int launch_tile_rank(TileRows U, const uint32_t* tile_row_begin, const unsigned long long* tile_px_begin, TileRows R, uint32_t max_rows, uint32_t n_tiles,
                      uint32_t max_rows_per_tile, int slide_mode, const double* smin, const double* smax, void* stream)
 {
-    const unsigned gy = (max_rows_per_tile + 255) / 256;
+    unsigned gy = (max_rows_per_tile + 255) / 256;
+    if (gy > 65535u) gy = 65535u;                          // HIP's limit on grid.y; the kernel strides
     hipLaunchKernelGGL(tile_rank_kernel, dim3(n_tiles, gy ? gy : 1), dim3(256), 0, (hipStream_t)stream, U, tile_row_begin, tile_px_begin, R, max_rows,
                        slide_mode, smin, smax);
     return (int)hipGetLastError();

@@ -452,6 +452,25 @@ def test_glcm_grey_depth_beyond_lds_runs_from_the_global_workspace(hip_ctx, gd):
     _check(hip_ctx, b, MASK | _abi.FAM_GLRLM | _abi.FAM_NGTDM, s, against_ref=False)
 
 
+@pytest.mark.parametrize("vmax", [200, 255, 1000])
+def test_ibsi_glcm_of_order_beyond_128(hip_ctx, vmax):
+    """ibsi=True on an 8-bit image (and a 10-bit one): the co-occurrence matrix has the order of the largest intensity
+    (/root/reference/src/nyx/features/glcm.cpp:400-419 allocates max x max).  Orders that do not fit LDS run from the global
+    workspace, like a matlab grey depth of 256 does."""
+    rng = np.random.default_rng(vmax)
+    rois = []
+    for k in range(20):
+        r = synth.random_rois(1, seed=100 + k, rmax=18)[0]
+        v = rng.integers(0 if k % 4 == 0 else 1, vmax + 1, len(r["inten"])).astype(np.uint32)
+        if k == 3:
+            v[0] = vmax
+        rois.append(dict(r, inten=v))
+    s = _abi.default_settings(64, True)
+    b = _abi.batch_from_rois(rois)
+    _check(hip_ctx, b, MASK, s)
+    _check(hip_ctx, b, _abi.FAM_GLCM, s, against_ref=False)
+
+
 def _edge_shape_rois(seed=31):
     rng = np.random.default_rng(seed)
     rois = []
