@@ -500,6 +500,17 @@ def main():
                     pick = np.unique(np.concatenate([rng.choice(bm.n_roi, 96, replace=False), [int(np.argmax(bm.n_px_roi))], [int(np.argmin(bm.n_px_roi))], [bm.n_roi - 1]]))
                     ct = torch.from_numpy(pick).to(dev)
                     return gate(om[ct].cpu().numpy(), bm.host_rows(pick), mk, s)
+                # ---- intensity range: the metric ROI (disk r = 30) with 8-bit and 16-bit intensities.  The order-statistics engine
+                #      follows the range: 16-bit counting table up to 16383 (the metric's 12-bit data), radix sort beyond -----------
+                rng_rows = []
+                for hi_ in (256, 4096, 65536):
+                    bb = sl.DeviceBatch([(30, 30)] * 50_000, dev, seed=11, hi=hi_)
+                    ob = torch.empty((bb.n_roi, ncol), dtype=torch.float64, device=dev)
+                    dtb = sl.time_call(ctx, bb, mask, s, ob)
+                    parb = None if a.no_check else gate(ob[:64].cpu().numpy(), bb.host_rows(np.arange(64)), mask, s)
+                    rng_rows.append({"intensities": f"U[1, {hi_ - 1}]", "ns_per_roi": 1e9 * dtb / bb.n_roi, "rois_per_s": bb.n_roi / dtb, "parity_check": parb})
+                    del bb, ob
+                rec["intensity_range"] = {"rows": rng_rows, "what": "50 000 metric ROIs (disk r = 30, 2821 px), *ALL_GLCM*+*ALL_INTENSITY*, gd 8, at three intensity depths"}
                 mrec, bm, om = sl.mixed_sizes(ctx, dev, mask, s, check=None if a.no_check else chk_mixed)
                 del om
                 m4rec, _, _ = sl.mixed_sizes(ctx, dev, m4, s, check=None if a.no_check else (lambda b_, o_: chk_mixed(b_, o_, m4)))

@@ -20,7 +20,11 @@
 
 using namespace nyxhip;
 
-struct Extrema { uint32_t px, area, range, side; uint32_t vmax = 0; };   // vmax: largest intensity (0: not known -- stated extrema carry none)
+struct Extrema {
+    uint32_t px, area, range, side;
+    uint32_t vmax = 0;           // largest intensity (0: not known -- stated extrema carry none)
+    bool wide_only = false;      // every ROI of the group has an intensity range beyond the counting tables (a wide-range size class)
+};
 struct ClassRun {              // one size class of one call, as launched (nyxhip_launch_report)
     int cls;                   // 2 * size class + (1: some ROI needs 32-bit tables); -1: the whole batch in one launch group
     uint32_t count;            // members (0xFFFFFFFF: counted on the device only)
@@ -265,7 +269,7 @@ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 // NYXHIP_ERR_UNSUPPORTED when the grey depth alone cannot be held in LDS, or
 // NYXHIP_ERR_ROI_TOO_LARGE when the batch extrema do not fit the 160 KiB of a CU.
 int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_px, uint32_t max_area,
-                uint32_t max_range, LdsLayout& L, std::string& why, size_t cap = 0, uint32_t vmax = 0)
+                uint32_t max_range, LdsLayout& L, std::string& why, size_t cap = 0, uint32_t vmax = 0, bool wide_only = false)
 {
     memset(&L, 0, sizeof(L));
     const bool do_int = mask & NYXHIP_FAM_INTENSITY, do_glcm = mask & NYXHIP_FAM_GLCM;
@@ -284,7 +288,11 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     // value buffer needs no power-of-two padding; otherwise ROIs with a small range still
     // count (table of kCountCapMixed) and the rest bitonic-sort a padded buffer.
     const uint32_t kCountCapMax = spill ? (1u << 22) : 16384u, kCountCapMixed = 4096;
-    if (do_int) {
+    const bool radix = do_int && wide_only && !spill;   // every ROI sorts: LSD radix sort (roi_features.hip: radix_sort), no table, no padding
+    if (radix) {
+        L.count_cap = 0;
+        L.sort_cap = max_px ? max_px : 1;
+    } else if (do_int) {
         if ((uint64_t)max_range + 1 <= kCountCapMax) {
             L.count_cap = (max_range + 1 + 63u) & ~63u;
             L.sort_cap = max_px ? max_px : 1;
@@ -326,6 +334,10 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     if ((L.cnt16 ? 2ull : 4ull) * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
     off = align16(off + (L.cnt16 ? 2u : 4u) * L.sort_cap + 16);
     L.cnt = off; off = align16(off + (L.cnt16 ? 2u : 4u) * L.count_cap + 16);
+    if (radix) {                                          // second key buffer + [4][256] digit counts + the four wave totals
+        if (8ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident sort buffers"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+        L.radix = off; off = align16(off + 4u * L.sort_cap + 4u * (kWaves * 256 + kWaves) + 16);
+    }
     if (do_glcm && L.g16) {
         const uint32_t ng = (uint32_t)s->grey_depth, cellsw = ((ng + 1) * (ng + 1) + 1) / 2;
         L.ng_cap = ng; L.app = 4;
@@ -685,7 +697,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
     int c_glszm = c_gldzm + ((mask & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0), c_gldm = c_glszm + ((mask & NYXHIP_FAM_GLSZM) ? kGlszmCols : 0);
     int c_ngldm = c_gldm + ((mask & NYXHIP_FAM_GLDM) ? kGldmCols : 0);
     if (mask1 && (groups & 1)) {
-        if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap, E.vmax))
+        if (int lrc = make_layout(mask1, s, n_cols1, E.px, E.area, E.range, a.L, why, cap, E.vmax, E.wide_only))
             return lrc;
         a.n_roi = b->n_roi;
         a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
@@ -1127,7 +1139,9 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
                 if (!has_wide) groups.push_back({-2, Eall, 0u, 1u});
                 else {
                     groups.push_back({-2, Extrema{max_px, max_area, 16383u, max_side}, 0x5u, 1u});      // classes 0 and 2
-                    groups.push_back({-3, Eall, 0xAu, 1u});                                            // classes 1 and 3
+                    Extrema Ew = Eall;
+                    Ew.wide_only = true;
+                    groups.push_back({-3, Ew, 0xAu, 1u});                                              // classes 1 and 3
                 }
             }
             // shape kernels: one-wave builds for the smallest size class, four-wave builds for the other
@@ -1185,7 +1199,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             for (int cls = kClasses - 1; cls >= 0 && (mask & ~kMoments); cls--) {   // largest ROIs first: their long workgroups start early
                 const uint32_t* h = H + cls * H_WORDS;
                 if (h[H_COUNT] == 0) continue;
-                const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE], h[H_VMAX]};
+                const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE], h[H_VMAX], (cls & 1) != 0 && cls / 2 < kSizeClasses - 1};
                 if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], h[H_COUNT]))
                     return rc;
             }

@@ -145,6 +145,74 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
     }
 }
 
+// In-place ascending LSD radix sort of the n keys of `a` (8-bit digits of key - kmin, as many passes as the range has bytes),
+// ping-ponging with `b`; returns the buffer that holds the result.  hist: [NW][256] words.
+// For ROIs whose intensity range rules the counting table out -- 16-bit microscopy data -- the bitonic sort above costs 78
+// barrier-separated stages over the padded array (134 ns per 2821-pixel ROI against 12.7 ns through the counting table).  A pass
+// here: every wave counts the digits of ITS contiguous chunk, one thread per digit turns the [digit][wave] counts into
+// offsets, and every wave scatters its chunk in order -- a key's rank among the equal digits of its 64-key step comes from
+// eight ballots (lanes with my digit = AND over the digit's bits of ballot-or-its-complement), so the pass is stable and needs
+// no atomics in the scatter.
+template <bool GS, int NW>
+__device__ __forceinline__ uint32_t* radix_sort(uint32_t* a, uint32_t* b, uint32_t* hist, uint32_t n, uint32_t kmin, uint32_t range, int tid)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t chunk = ((n + NW * 64 - 1) / (NW * 64)) * 64;           // keys per wave (a multiple of 64)
+    const uint32_t c_begin = (uint32_t)wave * chunk, c_end = c_begin + chunk < n ? c_begin + chunk : n;
+    uint32_t* const myh = hist + wave * 256;
+    for (uint32_t shift = 0; shift < 32 && (range >> shift) != 0; shift += 8) {
+        for (int i = tid; i < NW * 256; i += NW * 64) hist[i] = 0;
+        grp_sync<GS, NW>();
+        for (uint32_t i = c_begin + (uint32_t)lane; i < c_end; i += 64)
+            atomicAdd(&myh[((a[i] - kmin) >> shift) & 255u], 1u);
+        grp_sync<GS, NW>();
+        {   // thread d < 256 owns digit d: offsets of (d, wave) = keys with a smaller digit + keys of digit d in earlier waves
+            uint32_t cnt[NW], tot = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < NW; w++) { cnt[w] = hist[w * 256 + tid]; tot += cnt[w]; }
+            }
+            const uint32_t inc = wave_scan_u32(tid < 256 ? tot : 0u);
+            // cross-wave carry through the table's own spare row is not available: the four wave totals go through four words behind it
+            uint32_t* const wtot = hist + NW * 256;
+            if (lane == 63 && tid < 256) wtot[wave] = inc;
+            grp_sync<GS, NW>();
+            if (tid < 256) {
+                uint32_t base = inc - tot;
+                for (int w = 0; w < wave; w++) base += wtot[w];
+#pragma unroll
+                for (int w = 0; w < NW; w++) { hist[w * 256 + tid] = base; base += cnt[w]; }
+            }
+        }
+        grp_sync<GS, NW>();
+        for (uint32_t i0 = c_begin; i0 < c_end; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool live = i < c_end;
+            const uint32_t key = live ? a[i] : 0u;
+            const uint32_t d = ((key - kmin) >> shift) & 255u;
+            unsigned long long same = __ballot(live);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const bool one = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(live && one);
+                same &= one ? bal : ~bal;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+            uint32_t pos = 0;
+            if (live) pos = myh[d] + rank;
+            wav_sync<GS>();                                               // every lane has read its digit's offset before the leaders advance it
+            if (live) {
+                b[pos] = key;
+                if (rank == 0) myh[d] = pos + (uint32_t)__popcll(same);   // the step's first key of digit d moves the offset past the step's keys
+            }
+            wav_sync<GS>();
+        }
+        grp_sync<GS, NW>();
+        uint32_t* t = a; a = b; b = t;
+    }
+    return a;
+}
+
 // ---- GLCM features: one wave, one DPP row (16 lanes) per angle ------------------------------
 // The four 16-lane rows of the wave work on four angles at once; every reduction is a 4-step butterfly
 // inside the row (row16_sum), so the instruction stream is issued once for all angles.
@@ -849,7 +917,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     uint32_t P2 = 1;
     while (P2 < n)
         P2 <<= 1;
-    if (n == 0 || (do_int && (use_count ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
+    const bool radix = !C16 && A.L.radix != 0;        // launches whose ROIs all sort (wide intensity ranges): radix sort, no padding
+    if (n == 0 || (do_int && ((use_count || radix) ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
         if (SPLIT && A.glcm_ng && tid == 0)
             A.glcm_ng[roi] = 0;                       // nothing for glcm_features_kernel (a deferred ROI gets its features in the spill launch)
         if (n != 0 && A.sp.defer_large)
@@ -887,7 +956,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             const uint32_t n16 = C16 ? (range + 8) / 8 : (range + 4) / 4;   // 16-byte stores
             for (uint32_t i = tid; i < n16; i += BS)
                 c4[i] = make_uint4(0, 0, 0, 0);
-        } else {
+        } else if (!radix) {
             for (uint32_t i = n + tid; i < P2; i += BS)
                 s_val[i] = 0xFFFFFFFFu;
         }
@@ -1016,10 +1085,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // ---- boxes up to a wave wide: a row of the window per step, lane = column, every wave a contiguous block of rows
             // (window order = row-major order is kept: waves in order, rows in order, lanes in order).  The tile is read through
             // raw buffer descriptors (32-bit lane offsets, the row advance in the scalar offset: no 64-bit address arithmetic),
-            // eight rows per trip (sixteen in the label-only pre-pass) with every load of the trip issued before the first use,
-            // where a row-at-a-time loop left the kernel waiting on ~30 dependent round trips per ROI (3.7 ms per 196 k ROIs
-            // against 2.0 ms from pre-assembled clouds).
-            constexpr int UP = 16, UW = 8;                                               // rows per trip: label-only pre-pass / main pass
+            // eight rows per wave and trip with every load of the trip issued before the first use, where a row-at-a-time loop left
+            // the kernel waiting on ~30 dependent round trips per ROI (3.7 ms per 196 k ROIs against 2.0 ms from pre-assembled clouds).
+            constexpr int UW = 8;                                                        // rows per wave and trip
             const int dtl = A.win.dt_label, dti = A.win.dt_inten;
             // The element sizes are launch constants, but a test per load put two scalar branches between any two loads of a trip
             // (1.6 k scalar instructions per wave, the loads trickling out behind taken branches): the loader body is instantiated
@@ -1037,51 +1105,49 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                      : dt == 2 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0)
                                : (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff, (int)soff, 0);
             };
-            const uint32_t rows_pw = (h + NW - 1) / NW;
-            const uint32_t r_begin = (uint32_t)wave * rows_pw, r_end = r_begin + rows_pw < h ? r_begin + rows_pw : h;
-            const uint32_t e0 = (A.win.y0[roi] + r_begin) * Wt + x0;                      // element offset of this wave's first row (scalar)
+            // Rows are dealt to the waves round-robin (row r to wave r & 3), eight rows per wave and trip, every load of the trip issued
+            // before the first use.  A member's index in s_val is its rank in window order; the ranks of a trip come from ONE
+            // exchange of its 32 row populations through LDS (lanes 0 .. 31 pick them up in row order, a wave scan turns them into
+            // offsets) -- where a label-only pre-pass over the whole window used to count each wave's block of rows first: a third
+            // of the window's bytes, read twice.
+            const uint32_t e0 = (A.win.y0[roi] + (uint32_t)wave) * Wt + x0;               // element offset of this wave's first row (scalar)
             const uint32_t vl = (uint32_t)lane * (uint32_t)dtl, vi = (uint32_t)lane * (uint32_t)dti;
-            uint32_t hits = 0;
-            if (lane < (int)w) {                                                         // (ballots below see the box's columns only)
-                for (uint32_t r = r_begin; r < r_end; r += UP) {
-                    uint32_t lb[UP];
-#pragma unroll
-                    for (int u = 0; u < UP; u++)
-                        if (r + u < r_end) lb[u] = ldb(rs_l, vl, (e0 + (r + u - r_begin) * Wt) * (uint32_t)dtl, dtl);
-#pragma unroll
-                    for (int u = 0; u < UP; u++)
-                        if (r + u < r_end) hits += (uint32_t)__popcll(__ballot(lb[u] == L));
-                }
-            }
-            hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hits);
-            uint32_t* const s_hits = (uint32_t*)(s_stat + 12);                          // (s_stat is free until the sums)
-            if (lane == 0) s_hits[wave] = hits;
-            grp_sync<GS, NW>();
-            uint32_t rank0 = 0;
-            for (int wv = 0; wv < wave; wv++) rank0 += s_hits[wv];
-            rank0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank0);
-            if (lane < (int)w) {
-                for (uint32_t r = r_begin; r < r_end; r += UW) {
-                    uint32_t lb[UW], vv[UW];
+            const bool incol = lane < (int)w;
+            uint32_t* const s_rc = (uint32_t*)s_red;                                     // [2][32] row populations of a trip, double-buffered
+            uint32_t base = 0, trip_i = 0;                                               // members in the rows of earlier trips (wave-uniform)
+            for (uint32_t r0 = 0; r0 < h; r0 += NW * UW, trip_i++) {
+                uint32_t lb[UW], vv[UW];
+                if (incol) {
 #pragma unroll
                     for (int u = 0; u < UW; u++)
-                        if (r + u < r_end) {
-                            const uint32_t eo = e0 + (r + u - r_begin) * Wt;
+                        if (r0 + (uint32_t)(u * NW) + (uint32_t)wave < h) {
+                            const uint32_t eo = e0 + (r0 + (uint32_t)(u * NW)) * Wt;
                             lb[u] = ldb(rs_l, vl, eo * (uint32_t)dtl, dtl);
                             vv[u] = ldb(rs_i, vi, eo * (uint32_t)dti, dti);
                         }
-#pragma unroll
-                    for (int u = 0; u < UW; u++)
-                        if (r + u < r_end) {
-                            const bool hit = lb[u] == L;
-                            const unsigned long long bal = __ballot(hit);
-                            const uint32_t i = rank0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                            rank0 += (uint32_t)__popcll(bal);
-                            if (hit && i < n)
-                                member(vv[u], i, (r + u) * w + (uint32_t)lane);
-                        }
                 }
+                unsigned long long bal[UW];
+#pragma unroll
+                for (int u = 0; u < UW; u++)
+                    bal[u] = __ballot(incol && r0 + (uint32_t)(u * NW) + (uint32_t)wave < h && lb[u] == L);
+                uint32_t* const rc = s_rc + (trip_i & 1u) * 32u;
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < UW; u++) rc[u * NW + wave] = (uint32_t)__popcll(bal[u]);
+                }
+                grp_sync<GS, NW>();
+                const uint32_t inc = wave_scan_u32(lane < 32 ? rc[lane & 31] : 0u);       // inclusive prefix over the trip's rows in row order
+#pragma unroll
+                for (int u = 0; u < UW; u++) {
+                    const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)inc, u * NW + wave);
+                    const uint32_t i = base + upto - (uint32_t)__popcll(bal[u])
+                                     + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+                    if (((bal[u] >> lane) & 1ull) && i < n)
+                        member(vv[u], i, (r0 + (uint32_t)(u * NW) + (uint32_t)wave) * w + (uint32_t)lane);
+                }
+                base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
             }
+            grp_sync<GS, NW>();                                                          // (the exchange words are the reduction scratch of what follows)
             };   // window_load
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
@@ -1350,6 +1416,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 s_stat[S_MODE] = (double)(vmin + mi);
             }
             grp_sync<GS, NW>();
+        } else if (radix) {
+            uint32_t* const s_rdx = (uint32_t*)reg(A.L.radix);         // [sort_cap] second key buffer | [NW * 256 + NW] digit counts
+            s_val = radix_sort<GS, NW>(s_val, s_rdx, s_rdx + A.L.sort_cap, n, vmin, range, tid);
         } else {
             bitonic_sort<GS, NW>(s_val, P2, tid);
         }
@@ -1476,10 +1545,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 for (uint32_t i = tid; i < n; i += BS) {
                     uint32_t v = s_val[i];
                     if (i == n - 1 || s_val[i + 1] != v) {
-                        uint32_t lo = 0, hi = i;
-                        while (lo < hi) {
-                            uint32_t mid = (lo + hi) >> 1;
-                            if (s_val[mid] < v) lo = mid + 1; else hi = mid;
+                        uint32_t lo = i, hi = i;
+                        if (i > 0 && s_val[i - 1] == v) {      // (a run of one -- nearly every run of 16-bit data -- needs no search)
+                            lo = 0;
+                            while (lo < hi) {
+                                uint32_t mid = (lo + hi) >> 1;
+                                if (s_val[mid] < v) lo = mid + 1; else hi = mid;
+                            }
                         }
                         uint32_t c = i - lo + 1;
                         if (c > best_c || (c == best_c && v < best_v)) { best_c = c; best_v = v; }

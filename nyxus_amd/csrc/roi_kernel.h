@@ -86,6 +86,8 @@ struct LdsLayout {
     // -- the small, atomics-heavy ones: reduction scratch, histogram bounds, co-occurrence matrices, the counting table when it
     // fits -- and only the ROI-sized buffers (values, binned plane) in the workspace
     uint32_t gs_lds_bytes;
+    uint32_t radix;      // != 0: every ROI of the launch sorts (its size class is the wide-range one): offset of the radix sort's second key
+                         // buffer [sort_cap] and digit counts [4 * 256 + 4]; no counting table, no power-of-two padding of the values
 };
 
 // Window source of the fused tile path: when `inten` is set the feature kernel reads an ROI's pixels from its bounding-box
