@@ -513,6 +513,7 @@ int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area
         const uint64_t words = (uint64_t)L.area_cap + 38ull * L.side_cap + 345;
         if (4ull * words + off > cap) { why = "ROI bounding box too large for the LDS-resident Gabor plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
         L.plane = off; off = align16(off + 4u * (uint32_t)words);
+        L.redo = off; off = align16(off + 4u * (512u + 4u));     // kGaborRedoCap of roi_shape.hip
         L.total = off;
         return NYXHIP_OK;
     }

@@ -292,6 +292,7 @@ struct ShapeLayout {
     uint32_t side_cap;  // tiled layout only
     uint32_t tiled;     // 1: `plane` is the zero-padded u32 plane of roi_gabor_tiled_kernel (16 x 16 kernels, LDS launches);
                         //    no energy plane and no bank copy
+    uint32_t redo;      // tiled layout: [1 + kGaborRedoCap] words -- the pixels whose decision the fused taps cannot make
 };
 
 struct ShapeArgs {

@@ -187,8 +187,36 @@ typedef const double __attribute__((address_space(4))) * bank_ptr_t;
 // ZR: the bank has tap rows whose real or imaginary parts are all zero (ShapeArgs::gabor_zero_rows): those halves of the
 // row's arithmetic are skipped.  Banks without such rows run the build without the tests (the three copies of the tap block
 // cost the DSB-sized launches 6 %).
-template <int T, int NW, bool FUSED, bool ZR = false>
-__global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArgs A)
+// MODE 2 (the default since round 3): fused taps WITH the reference's decisions.  A feature is a count of pixels whose energy
+// ratio e / max exceeds the threshold (gabor.cpp:117); the fused response differs from the reference's by a rigorously bounded
+// amount -- both are 256-term recursive sums of the same products, each within gamma_257 sum |a w| of the exact sum, and the
+// bank is L1-normalised (sum |w| = 1, gabor.cpp:427-448), so |d re|, |d im| <= 2 gamma_257 a_max = 1.15e-13 a_max -- and a pixel
+// whose ratio lies farther than that bound from the threshold is decided as the reference decides it.  The others (none on
+// ordinary data, thousands on flat fields whose common energy sits on the threshold) go to a list and are recomputed with the
+// reference's separate multiplies and adds in its (j, i) order.  The low-pass filter, whose strict minimum and maximum the
+// baseline hangs on, always runs the reference's arithmetic (the default bank's is a box filter: exact integers).
+constexpr int kGaborRedoCap = 512;
+// The response of one pixel with the reference's arithmetic: separate multiply and add, taps in (j, i) order (gabor.cpp:333-390; a
+// zero tap adds +-0, which leaves a sum that started at +0 as it is: the same bits as the scans that skip zero rows).  Not inlined:
+// it runs for a handful of pixels, and inlined into the unrolled output loop it cost the kernel 50 registers (two waves per SIMD
+// instead of four).
+__device__ __attribute__((noinline)) double gabor_exact_energy(const uint32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G)
+{
+    double re = 0.0, im = 0.0;
+    const uint32_t* rp = s_plane + (b + 15) * pitch + a + 16;
+#pragma unroll 1
+    for (int j = 0; j < 16; j++, rp -= pitch)
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const double av = (double)rp[-i];
+            re += av * G[(j * 16 + i) * 2];
+            im += av * G[(j * 16 + i) * 2 + 1];
+        }
+    return sqrt(re * re + im * im);
+}
+
+template <int T, int NW, int MODE, bool ZR = false>
+__global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_kernel(const ShapeArgs A)   // (MODE 2: held to 128 registers, four waves per SIMD like the other two)
 {
     constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -198,6 +226,7 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
         return;
     double* s_red = (double*)(lds_raw + A.L.red);
     uint32_t* s_plane = (uint32_t*)(lds_raw + A.L.plane);   // [(h + 15)][pitch] original intensities, zero padding
+    uint32_t* s_redo = (uint32_t*)(lds_raw + A.L.redo);     // MODE 2: [0] pixels to recompute, [1 ..] their indices b * w + a
 
     const uint64_t off = A.px_offset[roi];
     const uint32_t npx = (uint32_t)(A.px_offset[roi + 1] - off);
@@ -244,12 +273,24 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
     double tmax = -1.0, tmin = 1.7976931348623157e308;
     uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
 
-    for (int f = 0; f <= nF; f++) {
+    auto exact_energy = [&](uint32_t a, uint32_t b, const bank_ptr_t G) -> double { return gabor_exact_energy(s_plane, pitch, a, b, G); };
+    const double amax = (double)A.max_inten[roi];
+
+    // One filter over the whole box.  FUSE is a compile-time fact of the copy (the low-pass filter runs the copy with the
+    // reference's arithmetic, the others -- MODE 1 / 2 -- the fused one): with both tap blocks behind a run-time flag in ONE tile
+    // loop the MODE 2 build needed 164 registers against 120 for either alone.  Returns false when the ROI is finished.
+    auto run_filter = [&](const int f, auto fuse_c) -> bool {
+        constexpr bool fuse = decltype(fuse_c)::value;
         const bank_ptr_t G = bank + (size_t)f * N * N * 2;
         const uint32_t zero_rows = ZR ? A.gabor_zero_rows[f] : 0u;
         const bool box = ZR && ((A.gabor_box_mask >> f) & 1u) && A.max_inten[roi] < (1u << 24);
         const double box_c = box ? G[0] : 0.0;
+        const double thr_max = A.gabor_thr * maxval, thr_slack = __builtin_fma(2.5e-13, amax, 1e-15 * thr_max);
         uint32_t sc = 0;
+        if (MODE == 2 && fuse) {
+            if (tid == 0) s_redo[0] = 0;
+            __syncthreads();
+        }
         for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
             const uint32_t b = tile / tpr, a0 = (tile - b * tpr) * T;
             double re[T], im[T];
@@ -297,8 +338,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
                     win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
                 }
                 const bank_ptr_t Gj = G + j * N * 2;
-                auto taps = [&](auto do_re_c, auto do_im_c) {
-                    constexpr bool DO_RE = decltype(do_re_c)::value, DO_IM = decltype(do_im_c)::value;
+                auto taps = [&](auto do_re_c, auto do_im_c, auto fuse_c) {
+                    constexpr bool DO_RE = decltype(do_re_c)::value, DO_IM = decltype(do_im_c)::value, FUSED = decltype(fuse_c)::value;
 #pragma unroll
                     for (int i = 0; i < N; i++) {
                         const double gr = DO_RE ? Gj[2 * i] : 0.0, gi = DO_IM ? Gj[2 * i + 1] : 0.0;
@@ -317,8 +358,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
                 };
                 // (a row whose real parts alone vanish does not occur in a Gabor bank -- cos(x' f0) has no exact zeros on the tap
                 //  grid -- and takes the full block)
-                if (ZR && im0) taps(std::true_type{}, std::false_type{});
-                else taps(std::true_type{}, std::true_type{});
+                if (ZR && im0) taps(std::true_type{}, std::false_type{}, fuse_c);
+                else taps(std::true_type{}, std::true_type{}, fuse_c);
             }
 #pragma unroll
             for (int t = 0; t < T; t++) {
@@ -329,9 +370,39 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
                     tmax = e > tmax ? e : tmax;
                     if (e < tmin) { tmin = e; n_min = 1; }
                     else if (e == tmin) n_min++;
+                } else if (MODE == 2 && fuse) {
+                    // The reference decides fl(e / max) > thr (:117).  With T = thr * max: an e above T (1 + 4 u) gives a quotient above
+                    // thr, one below T (1 - 4 u) a quotient below it, whatever the rounding of the division; and the fused e is within
+                    // |d re| + |d im| + 4 u e <= 0.9e-13 a_max + 4 u e of the reference's (see the kernel's header).  So outside
+                    // |e - T| <= 2.5e-13 a_max + 1e-15 (e + T) the comparison of the fused e with T IS the reference's decision -- no
+                    // division per pixel -- and inside it the pixel is recomputed.
+                    const double dlt = e - thr_max;
+                    if (fabs(dlt) <= __builtin_fma(1e-15, e, thr_slack)) {
+                        const uint32_t k = atomicAdd(&s_redo[0], 1u);
+                        if (k < (uint32_t)kGaborRedoCap) s_redo[1 + k] = b * w + a0 + (uint32_t)t;
+                    } else if (dlt > 0.0)
+                        sc++;
                 } else if (e / maxval > A.gabor_thr)                    // :117
                     sc++;
             }
+        }
+        if (MODE == 2 && fuse) {                           // the pixels too close to the threshold, with the reference's arithmetic
+            __syncthreads();
+            const uint32_t nr = s_redo[0];
+            if (nr > (uint32_t)kGaborRedoCap) {
+                // more of them than the list holds (a flat field whose common energy IS the threshold): every pixel of the box is
+                // decided by the reference's arithmetic -- slow, rare, and the same answer
+                sc = 0;
+                for (uint32_t p = tid; p < area; p += kBlk) {
+                    const uint32_t b = p / w, a = p - b * w;
+                    if (exact_energy(a, b, G) / maxval > A.gabor_thr) sc++;
+                }
+            } else
+                for (uint32_t k = tid; k < nr; k += kBlk) {
+                    const uint32_t p = s_redo[1 + k], b = p / w, a = p - b * w;
+                    if (exact_energy(a, b, G) / maxval > A.gabor_thr) sc++;
+                }
+            __syncthreads();
         }
         if (f == 0) {
             tmax = wave_max_d(tmax);
@@ -351,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
             if (mx == mn) {                               // gabor.cpp:91-96
                 for (int c = tid; c < nF; c += kBlk)
                     o[c] = A.soft_nan;
-                return;
+                return false;
             }
             maxval = mx;
             n_min = area - at_min;                        // baseline score, :99-102: pixels with e > min
@@ -359,6 +430,14 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_tiled_kernel(const ShapeArg
             const uint32_t tot = (uint32_t)wave_sum_u64(sc);
             if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + f - 1] = (double)tot;   // [wave][filter]; read after the final barrier
         }
+        return true;
+    };
+    for (int f = 0; f <= nF; f++) {
+        bool go;
+        if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
+        else if constexpr (MODE == 1) go = run_filter(f, std::true_type{});
+        else go = f == 0 ? run_filter(f, std::false_type{}) : run_filter(f, std::true_type{});
+        if (!go) return;
     }
     const double baseline = (double)n_min;
     __syncthreads();
@@ -523,10 +602,12 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         hipError_t e = hipFuncSetAttribute((const void*)roi_gabor_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)roi_gabor_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
-        const void* tiled[] = {(const void*)roi_gabor_tiled_kernel<8, 4, false>, (const void*)roi_gabor_tiled_kernel<4, 1, false>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, true>, (const void*)roi_gabor_tiled_kernel<4, 1, true>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, false, true>, (const void*)roi_gabor_tiled_kernel<4, 1, false, true>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, true, true>, (const void*)roi_gabor_tiled_kernel<4, 1, true, true>};
+        const void* tiled[] = {(const void*)roi_gabor_tiled_kernel<8, 4, 0, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 0, false>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 0, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 0, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 1, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 1, false>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 1, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 1, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 2, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, false>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 2, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, true>};
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -543,7 +624,14 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
         return (int)hipGetLastError();
     }
     if ((a.mask & NYXHIP_FAM_GABOR) && a.L.tiled) {
-        static const bool fused = [] { const char* e = getenv("NYXHIP_GABOR_FUSED"); return e && *e && *e != '0'; }();
+        // 2 (default): fused taps with the reference's decisions; NYXHIP_GABOR_EXACT=1 -> 0: the reference's arithmetic throughout (A/B);
+        // NYXHIP_GABOR_FUSED=1 -> 1: fused taps, decisions unchecked (changes results on tie-laden inputs: INTEGRATION.md)
+        static const int mode = [] {
+            const char* e = getenv("NYXHIP_GABOR_FUSED");
+            if (e && *e && *e != '0') return 1;
+            e = getenv("NYXHIP_GABOR_EXACT");
+            return (e && *e && *e != '0') ? 0 : 2;
+        }();
         // worth its registers (the build with the row tests needs ~25 more: one wave per SIMD less) when at least 4 % of the
         // bank's arithmetic falls away: the reference's default bank (f0 = 0 in its first filter) saves 10.6 %, the 8-orientation
         // bank of BASELINE.json configs[4] one row in 288
@@ -553,19 +641,15 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             zero_halves += __builtin_popcount(im) + __builtin_popcount(both);
         }
         const bool zr = 25 * zero_halves >= 32 * (a.gabor_nf + 1);
-        if (!fused && !zr) {
-            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, false>), dim3(grid), dim3(64), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, false>), dim3(grid), dim3(256), a.L.total, st, a);
-        } else if (!fused) {
-            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, false, true>), dim3(grid), dim3(64), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, false, true>), dim3(grid), dim3(256), a.L.total, st, a);
-        } else if (!zr) {
-            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, true>), dim3(grid), dim3(64), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, true>), dim3(grid), dim3(256), a.L.total, st, a);
-        } else {
-            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, true, true>), dim3(grid), dim3(64), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, true, true>), dim3(grid), dim3(256), a.L.total, st, a);
-        }
+#define NYX_GABOR_LAUNCH(M, Z)                                                                                                         \
+        do {                                                                                                                           \
+            if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, M, Z>), dim3(grid), dim3(64), a.L.total, st, a);               \
+            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, M, Z>), dim3(grid), dim3(256), a.L.total, st, a);                    \
+        } while (0)
+        if (mode == 2) { if (zr) NYX_GABOR_LAUNCH(2, true); else NYX_GABOR_LAUNCH(2, false); }
+        else if (mode == 1) { if (zr) NYX_GABOR_LAUNCH(1, true); else NYX_GABOR_LAUNCH(1, false); }
+        else { if (zr) NYX_GABOR_LAUNCH(0, true); else NYX_GABOR_LAUNCH(0, false); }
+#undef NYX_GABOR_LAUNCH
     } else if (a.mask & NYXHIP_FAM_GABOR) {
         if (small) hipLaunchKernelGGL((roi_gabor_kernel<1, false>), dim3(grid), dim3(64), a.L.total, st, a);
         else hipLaunchKernelGGL((roi_gabor_kernel<4, false>), dim3(grid), dim3(256), a.L.total, st, a);
