@@ -530,7 +530,7 @@ int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area
 
 // LDS carve-out of the texture kernel (roi_texture.hip)
 int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t max_area, uint32_t max_side,
-                    TexLayout& L, std::string& why, size_t cap = 0)
+                    TexLayout& L, std::string& why, size_t cap = 0, uint32_t vmax = 0)
 {
     memset(&L, 0, sizeof(L));
     const bool spill = cap != 0;
@@ -543,8 +543,10 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     L.dense_cap = max_area ? max_area : 1;
     L.side_cap = max_side ? max_side : 1;
     if (2ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
-    if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the texture kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    // IBSI: levels are the intensities themselves -- up to the group's largest intensity when the class header gave it (exact launch
+    // groups), else the 8-bit range
+    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : (vmax ? vmax : 255u);
+    if (L.lvl_cap > 4094) { why = "grey depth (or IBSI intensity) above 4094 is not supported by the texture kernel"; return NYXHIP_ERR_UNSUPPORTED; }
     L.dense8 = (!spill && L.lvl_cap <= 254) ? 1u : 0u;            // 8-bit plane (roi_texture_kernel<.., true>)
     L.dense = off; off = align16(off + (L.dense8 ? 1u : 2u) * L.dense_cap + 4);
     L.ng_cap = L.lvl_cap + 1;
@@ -596,7 +598,8 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
 }
 
 // Carve-out of roi_dependence_kernel (GLDZM + GLDM + NGLDM).
-int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, uint32_t max_side, DepLayout& L, std::string& why, size_t cap = 0)
+int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, uint32_t max_side, DepLayout& L, std::string& why, size_t cap = 0,
+                    uint32_t vmax = 0)
 {
     memset(&L, 0, sizeof(L));
     if (cap == 0) cap = roi_features_max_lds();
@@ -607,8 +610,8 @@ int make_dep_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area, 
     L.dense_cap = max_area ? max_area : 1;
     L.side_cap = max_side ? max_side : 1;
     if (4ull * L.dense_cap > cap) { why = "ROI bounding box of " + std::to_string(max_area) + " px exceeds the LDS-resident planes"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : 255u;   // IBSI: levels are the intensities themselves
-    if (L.lvl_cap > 4094) { why = "grey depth above 4094 is not supported by the dependence kernel"; return NYXHIP_ERR_UNSUPPORTED; }
+    L.lvl_cap = greyInfo != 0 ? (uint32_t)abs(greyInfo) : (vmax ? vmax : 255u);   // IBSI: levels are the intensities themselves
+    if (L.lvl_cap > 4094) { why = "grey depth (or IBSI intensity) above 4094 is not supported by the dependence kernel"; return NYXHIP_ERR_UNSUPPORTED; }
     L.planes8 = (cap == roi_features_max_lds() && L.lvl_cap <= 63) ? 1u : 0u;   // byte planes: level + two flags fit 8 bits
     L.dense = off; off = align16(off + (L.planes8 ? 1u : 2u) * L.dense_cap + 4);
     L.aux = off; off = align16(off + (L.planes8 ? 1u : 2u) * L.dense_cap + 4);
@@ -739,7 +742,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         }
     }
     if (mask2 && (groups & 2)) {
-        if (int lrc = make_tex_layout(mask2, s, n_cols2, E.area, E.side, t.L, why, cap))
+        if (int lrc = make_tex_layout(mask2, s, n_cols2, E.area, E.side, t.L, why, cap, E.vmax))
             return lrc;
         t.n_roi = b->n_roi;
         t.px_offset = b->px_offset; t.x = b->x; t.y = b->y; t.inten = b->inten;
@@ -751,7 +754,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         t.soft_nan = s->soft_nan; t.grey_depth = s->grey_depth; t.ibsi = s->ibsi;
     }
     if (mask4 && (groups & 8)) {
-        if (int lrc = make_dep_layout(mask4, s, E.area, E.side, d.L, why, cap))
+        if (int lrc = make_dep_layout(mask4, s, E.area, E.side, d.L, why, cap, E.vmax))
             return lrc;
         d.n_roi = b->n_roi;
         d.px_offset = b->px_offset; d.x = b->x; d.y = b->y; d.inten = b->inten;
@@ -1125,7 +1128,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
         bool done = false;
         static const bool force_exact = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
         // (IBSI co-occurrence matrices are as large as the largest intensity, which a statement about the batch does not carry)
-        const bool need_vmax = s->ibsi && (mask & NYXHIP_FAM_GLCM);
+        const bool need_vmax = s->ibsi && (mask & (NYXHIP_FAM_GLCM | kTexture | kDependence));
         if (hinted && !force_exact && !need_vmax && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
             // ---- whole-batch launches, nothing counted -----------------------------------------------------------------------
             const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]), has_wide = max_range >= 16384u;

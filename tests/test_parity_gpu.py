@@ -471,6 +471,20 @@ def test_ibsi_glcm_of_order_beyond_128(hip_ctx, vmax):
     _check(hip_ctx, b, _abi.FAM_GLCM, s, against_ref=False)
 
 
+def test_ibsi_texture_levels_beyond_255(hip_ctx):
+    """ibsi=True on 10-bit intensities: the texture and dependence families take the intensities themselves as levels (no binning);
+    the group's largest intensity comes with the class header and sizes the level tables (LDS when they fit, else the workspace)."""
+    rng = np.random.default_rng(12)
+    rois = []
+    for k in range(16):
+        r = synth.random_rois(1, seed=300 + k, rmax=10)[0]
+        rois.append(dict(r, inten=rng.integers(1, 1001 if k % 2 else 301, len(r["inten"])).astype(np.uint32)))
+    s = _abi.default_settings(64, True)
+    b = _abi.batch_from_rois(rois)
+    mask = _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM | _abi.FAM_GLDM | _abi.FAM_NGLDM | _abi.FAM_GLDZM
+    _check(hip_ctx, b, mask, s, against_ref=False)
+
+
 def _edge_shape_rois(seed=31):
     rng = np.random.default_rng(seed)
     rois = []
