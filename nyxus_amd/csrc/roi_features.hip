@@ -710,25 +710,41 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
         Tent[lane] = pk * (double)fast_log2f(pk + 0.000000001);
     }
     wav_sync<false>();
-    double ent = 0, hxy1 = 0, hxy2 = 0;
-    uint32_t acor_i = 0, asm_i = 0, cmax = 0, rc1 = 0;
+    double ent = 0, hxy1c = 0, hxy2 = 0;
+    uint32_t acor_i = 0, asm_i = 0, cmax = 0;
     const uint16_t* pcell = P + S + lane + 1;
-    for (int r = 0; r < Ng; r++) {
-        const uint32_t cnt = act ? pcell[r * S] : 0u;
-        const double pr = prow_s[r];
-        rc1 += l1;                                                   // (r + 1) * (c + 1)
-        asm_i = mad24(cnt, cnt, asm_i);                              // f_asm :555 / f_energy :927-928
-        acor_i = mad24(cnt, rc1, acor_i);                            // f_GLCM_ACOR :961 (integer-exact)
-        cmax = cnt > cmax ? cnt : cmax;                              // f_GLCM_JMAX :1178-1179
-        const double p = (double)cnt * inv_sum_p;
-        double et = Tent[cnt < 15u ? cnt : 15u];
-        if (cnt >= 15u) et = p * (double)fast_log2f(p + 0.000000001);
-        ent += et;                                                   // f_entropy :734-735, JE :1160-1161, HXY :868
+    // Rows are visited in GROUPS of equal row marginal: the float log of p_x(i) p_y(j) + eps -- the reference's quadratic, 19 of a
+    // cell's 45 instructions with its conversions -- depends on the row only through its marginal count, and the 64 rows of a
+    // textured ROI share ~25 distinct counts (Poisson around n / 64).  One log per group and column; HXY2 takes the group's
+    // multiplicity, HXY1 the cells' counts against the group's log (scaled by 1 / sum_p once at the end).  Rows with an empty
+    // marginal hold no pair and are skipped (narrow histograms: most of the 64 levels of real images).  The group loop runs on
+    // the scalar unit (ballot, s_ff1, bit clears).
+    unsigned long long rem = __ballot(act && rc != 0u);
+    while (rem) {
+        const int r0 = (int)__builtin_ctzll(rem);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)rc, r0);
+        const unsigned long long pbits = (unsigned long long)__double_as_longlong(prow);
+        const double pr = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), r0) << 32) |
+                                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, r0)));
+        unsigned long long grp = __ballot(act && rc == v);
+        rem &= ~grp;
         const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
         const double lg = (double)fast_log2f(pp + 0.000000001);
-        hxy1 = __builtin_fma(p, lg, hxy1);
-        hxy2 = __builtin_fma(pp, lg, hxy2);
+        hxy2 = __builtin_fma(pp * (double)(uint32_t)__popcll(grp), lg, hxy2);
+        while (grp) {
+            const int r = (int)__builtin_ctzll(grp);
+            grp &= grp - 1ull;
+            const uint32_t cnt = act ? pcell[r * S] : 0u;
+            asm_i = mad24(cnt, cnt, asm_i);                          // f_asm :555 / f_energy :927-928
+            acor_i = mad24(cnt, mul24(l1, (uint32_t)(r + 1)), acor_i);   // f_GLCM_ACOR :961 (integer-exact): (r + 1) * (c + 1)
+            cmax = cnt > cmax ? cnt : cmax;                          // f_GLCM_JMAX :1178-1179
+            double et = Tent[cnt < 15u ? cnt : 15u];
+            if (cnt >= 15u) { const double p = (double)cnt * inv_sum_p; et = p * (double)fast_log2f(p + 0.000000001); }
+            ent += et;                                               // f_entropy :734-735, JE :1160-1161, HXY :868
+            hxy1c = __builtin_fma((double)cnt, lg, hxy1c);
+        }
     }
+    const double hxy1 = hxy1c * inv_sum_p;
     const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
     wav_sync<false>();                                               // the table is dead: sm[16..23] belong to batch 2 from here on
     {
@@ -2091,7 +2107,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         const bool too_big = !FAST && (uint32_t)Ng > A.L.ng_cap;      // (FAST: make_layout reserved exactly this order)
         if (too_big && tid == 0)
             atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
-        if (!SPLIT && greyInfo >= 0 && !too_big)
+        if (!SPLIT && !G16 && greyInfo >= 0 && !too_big)   // (G16: level values are i + 1 by construction, and its scratch lies over the live plane)
             for (int i = tid; i < Ng; i += BS)
                 s_I[i] = (double)(i + 1);
 
