@@ -39,7 +39,6 @@ struct nyxhip_ctx {
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
     int* d_status = nullptr;
-    uint32_t* d_extrema = nullptr; // [4]
     // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
     double* d_bank = nullptr;
     std::vector<double> bank_key;
@@ -60,7 +59,7 @@ struct nyxhip_ctx {
     // contour + moments workspace (grow-only): contour points, contour lengths, per-pixel log distances
     void* d_mom = nullptr;
     size_t mom_bytes = 0;
-    // large-ROI (spill) pass: index list and per-workgroup global scratch
+    // contour planes beyond LDS: index list (launch_moments); per-workgroup global scratch of every workspace launch
     uint32_t* d_spill_list = nullptr;
     size_t spill_list_bytes = 0;
     unsigned char* d_spill = nullptr;
@@ -680,12 +679,6 @@ int check_status(nyxhip_ctx* ctx)
     return NYXHIP_OK;
 }
 
-__global__ void iota_kernel(uint32_t n, uint32_t* out)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
-}
-
 __global__ void add_offset_kernel(const uint32_t* in, uint32_t add, uint32_t n, uint32_t* out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1302,8 +1295,7 @@ int nyxhip_init(int device, nyxhip_ctx** out_ctx)
     nyxhip_ctx* ctx = new nyxhip_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_extrema, 4 * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, NYXHIP_ERR_HIP, "failed to create the device context");
     }
@@ -1344,7 +1336,6 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_cls_hdr) (void)hipFree(ctx->d_cls_hdr);
     if (ctx->h_cls_hdr) (void)hipHostFree(ctx->h_cls_hdr);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    if (ctx->d_extrema) (void)hipFree(ctx->d_extrema);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);
     if (ctx->d_stamps) {
         unsigned long long h[32];

@@ -35,7 +35,9 @@ struct SpillArgs {
     const uint32_t* roi_index;   // NULL: workgroup b handles ROI b; else ROI roi_index[b]
     unsigned char* scratch;      // global scratch, `stride` bytes per workgroup (spill launches only)
     uint64_t stride;
-    int32_t defer_large;         // LDS launch: silently skip ROIs beyond the caps (a spill launch follows)
+    int32_t defer_large;         // LDS launch: silently skip ROIs beyond the caps, a workspace launch over them follows.  Set by the
+                                 // contour launch of launch_moments only: the other kernels are launched per size class with
+                                 // carve-outs of the class's own extrema and never meet an ROI beyond them
     uint32_t n_slots;            // entries of roi_index this launch may use (list launches; kernels that pack several ROIs per workgroup round their grids up)
     // launches over the whole batch (slot = ROI) that serve some classes only: bit c set = ROIs of class c are this launch's,
     // everybody else returns at once (the kernel derives the class from what it loads anyway: no list, no dependent load in
