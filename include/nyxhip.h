@@ -294,8 +294,8 @@ int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launch
  *   {"class": c, "size_class": 0..4, "wide_range": 0|1, "rois": n, "max_px": .., "max_bbox_area": .., "max_range": ..,
  *    "max_side": .., "workspace": 0|1|2, "ms": t}
  * "class" < 0 = a launch over the whole batch, enqueued without counting anything because the stated batch extrema rule out
- * all but the two smallest size classes (-1: texture + dependence kernels, -2 / -3: feature kernels with 16-bit / 32-bit
- * tables, -4 / -5: one-wave / four-wave shape kernels; "rois" is then the batch size); "workspace" 0 = kernels
+ * all but the two smallest size classes and wide intensity ranges (-1: texture + dependence kernels, -2: feature kernels,
+ * -4 / -5: one-wave / four-wave shape kernels; "rois" is then the batch size); "workspace" 0 = kernels
  * with their state in LDS, 1 = INTENSITY + GLCM from the global workspace, 2 = every kernel group; "ms" = device time of the
  * class's launches when nyxhip_timing_enable(ctx, 1) was in force for the call (waits for them), else null.  Counterpart in the
  * reference: none -- its worker threads take ROIs of any size (parallel.h:23-42); here a launch is sized by its largest

@@ -336,12 +336,14 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     // 16-bit tables: every ROI of the launch counts (range below the table) and has fewer than 65536 pixels, so counts,
     // per-wave prefix sums and the values' offsets from the ROI minimum all fit 16 bits
     L.cnt16 = (do_int && max_px < 65536u && (uint64_t)max_range + 1 <= kCountCapMax && max_range < 65536u) ? 1u : 0u;
+    L.radix_k16 = (radix && max_range < 65536u) ? 1u : 0u;
     if ((L.cnt16 ? 2ull : 4ull) * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident value buffer"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-    off = align16(off + (L.cnt16 ? 2u : 4u) * L.sort_cap + 16);
+    if (L.radix_k16) off = align16(off + 2u * 2u * ((L.sort_cap + 7u) & ~7u) + 16);      // two 16-bit key buffers
+    else off = align16(off + (L.cnt16 ? 2u : 4u) * L.sort_cap + 16);
     L.cnt = off; off = align16(off + (L.cnt16 ? 2u : 4u) * L.count_cap + 16);
-    if (radix) {                                          // second key buffer + [4][256] digit counts + the four wave totals
+    if (radix) {                                          // (second 32-bit key buffer +) [4][256] digit counts + the four wave totals
         if (8ull * L.sort_cap > cap) { why = "ROI pixel count " + std::to_string(max_px) + " exceeds the LDS-resident sort buffers"; return NYXHIP_ERR_ROI_TOO_LARGE; }
-        L.radix = off; off = align16(off + 4u * L.sort_cap + 4u * (kWaves * 256 + kWaves) + 16);
+        L.radix = off; off = align16(off + (L.radix_k16 ? 0u : 4u * L.sort_cap) + 4u * (kWaves * 256 + kWaves) + 16);
     }
     if (do_glcm && L.g16) {
         const uint32_t ng = (uint32_t)s->grey_depth, cellsw = ((ng + 1) * (ng + 1) + 1) / 2;
@@ -1129,25 +1131,20 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
         static const bool force_exact = [] { const char* e = getenv("NYXHIP_CLASS_SYNC"); return e && *e && *e != '0'; }();   // A/B knob
         // (IBSI co-occurrence matrices are as large as the largest intensity, which a statement about the batch does not carry)
         const bool need_vmax = s->ibsi && (mask & (NYXHIP_FAM_GLCM | kTexture | kDependence));
-        if (hinted && !force_exact && !need_vmax && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
+        // (a stated range that allows wide-range ROIs takes the exact path as well: a whole-batch launch per table width would
+        //  carve 43 KB for a class that 16-bit data leaves empty -- 100 k workgroups that only return, three per CU)
+        const bool wide_possible = max_range >= 16384u && (mask & NYXHIP_FAM_INTENSITY);
+        if (hinted && !force_exact && !need_vmax && !wide_possible && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
             // ---- whole-batch launches, nothing counted -----------------------------------------------------------------------
-            const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]), has_wide = max_range >= 16384u;
+            const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]);
             const Extrema Eall{max_px, max_area, max_range, max_side};
             struct Group { int cls; Extrema E; uint32_t class_mask, group_sel; };
             std::vector<Group> groups;
             // texture / dependence kernels: one build for both classes
             if (mask & (kTexture | kDependence)) groups.push_back({-1, Eall, 0u, 2u | 8u});
-            // feature kernels: the 16-bit-table build for the ROIs it can serve, the 32-bit build for the others (when the statement
-            // allows any); without wide ranges the one launch needs no filter (a contradicting ROI raises the error flag in the kernel)
-            if (mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) {
-                if (!has_wide) groups.push_back({-2, Eall, 0u, 1u});
-                else {
-                    groups.push_back({-2, Extrema{max_px, max_area, 16383u, max_side}, 0x5u, 1u});      // classes 0 and 2
-                    Extrema Ew = Eall;
-                    Ew.wide_only = true;
-                    groups.push_back({-3, Ew, 0xAu, 1u});                                              // classes 1 and 3
-                }
-            }
+            // feature kernels: one launch, no filter (both size classes run the same build; a contradicting ROI raises the error flag
+            // in the kernel)
+            if (mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) groups.push_back({-2, Eall, 0u, 1u});
             // shape kernels: one-wave builds for the smallest size class, four-wave builds for the other
             if (mask & kShape) {
                 const uint32_t sd0 = std::min(max_side, kClassSide[0]);
@@ -1161,9 +1158,6 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             for (const Group& g : groups)
                 if (int rc = run_class(ctx, b, mask, s, d_out, ld, g.E, nullptr, n_roi, true, &needs_host, nullptr, g.class_mask, g.group_sel)) return rc;
             if (!needs_host) {                             // (else: the exact path, whose workspace chunks need member counts)
-                // two feature launches share the table of matrix orders, and the glcm_features launch of each walks the whole batch:
-                // what the other one has not exported yet must read "nothing to derive", not a previous call's entry
-                if (has_wide && (mask & NYXHIP_FAM_GLCM)) HIP_TRY(ctx, hipMemsetAsync(ctx->d_glcm_ng, 0, 4ull * n_roi, st));
                 for (const Group& g : groups)
                     if (int rc = timed_class(g.cls, n_roi, g.E, nullptr, n_roi, g.class_mask, g.group_sel)) return rc;
                 done = true;

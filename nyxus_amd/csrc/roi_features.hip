@@ -153,8 +153,8 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* s, uint32_t P, int tid)
 // offsets, and every wave scatters its chunk in order -- a key's rank among the equal digits of its 64-key step comes from
 // eight ballots (lanes with my digit = AND over the digit's bits of ballot-or-its-complement), so the pass is stable and needs
 // no atomics in the scatter.
-template <bool GS, int NW>
-__device__ __forceinline__ uint32_t* radix_sort(uint32_t* a, uint32_t* b, uint32_t* hist, uint32_t n, uint32_t kmin, uint32_t range, int tid)
+template <bool GS, int NW, typename KEY>
+__device__ __forceinline__ KEY* radix_sort(KEY* a, KEY* b, uint32_t* hist, uint32_t n, uint32_t kmin, uint32_t range, int tid)
 {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk = ((n + NW * 64 - 1) / (NW * 64)) * 64;           // keys per wave (a multiple of 64)
@@ -164,7 +164,7 @@ __device__ __forceinline__ uint32_t* radix_sort(uint32_t* a, uint32_t* b, uint32
         for (int i = tid; i < NW * 256; i += NW * 64) hist[i] = 0;
         grp_sync<GS, NW>();
         for (uint32_t i = c_begin + (uint32_t)lane; i < c_end; i += 64)
-            atomicAdd(&myh[((a[i] - kmin) >> shift) & 255u], 1u);
+            atomicAdd(&myh[(((uint32_t)a[i] - kmin) >> shift) & 255u], 1u);
         grp_sync<GS, NW>();
         {   // thread d < 256 owns digit d: offsets of (d, wave) = keys with a smaller digit + keys of digit d in earlier waves
             uint32_t cnt[NW], tot = 0;
@@ -188,7 +188,7 @@ __device__ __forceinline__ uint32_t* radix_sort(uint32_t* a, uint32_t* b, uint32
         for (uint32_t i0 = c_begin; i0 < c_end; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool live = i < c_end;
-            const uint32_t key = live ? a[i] : 0u;
+            const uint32_t key = live ? (uint32_t)a[i] : 0u;
             const uint32_t d = ((key - kmin) >> shift) & 255u;
             unsigned long long same = __ballot(live);
 #pragma unroll
@@ -202,13 +202,13 @@ __device__ __forceinline__ uint32_t* radix_sort(uint32_t* a, uint32_t* b, uint32
             if (live) pos = myh[d] + rank;
             wav_sync<GS>();                                               // every lane has read its digit's offset before the leaders advance it
             if (live) {
-                b[pos] = key;
+                b[pos] = (KEY)key;
                 if (rank == 0) myh[d] = pos + (uint32_t)__popcll(same);   // the step's first key of digit d moves the offset past the step's keys
             }
             wav_sync<GS>();
         }
         grp_sync<GS, NW>();
-        uint32_t* t = a; a = b; b = t;
+        KEY* t = a; a = b; b = t;
     }
     return a;
 }
@@ -934,6 +934,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     while (P2 < n)
         P2 <<= 1;
     const bool radix = !C16 && A.L.radix != 0;        // launches whose ROIs all sort (wide intensity ranges): radix sort, no padding
+    // ... on 16-bit keys (value - minimum, two bytes per pixel in both key buffers) when every range of the launch fits them: the
+    // sorted values are then read as vmin + key (SV below) and the 32-bit value buffer does not exist
+    const bool k16 = radix && A.L.radix_k16 != 0;
     if (n == 0 || (do_int && ((use_count || radix) ? n : P2) > A.L.sort_cap) || (do_glcm && area > A.L.dense_cap)) {
         if (SPLIT && A.glcm_ng && tid == 0)
             A.glcm_ng[roi] = 0;                       // nothing for glcm_features_kernel (a deferred ROI gets its features in the spill launch)
@@ -1019,6 +1022,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 continue;
             if (do_int) {
                 if (C16) val16[u * BS] = (uint16_t)(v[u] - vmin);       // C16 launches: every ROI counts, range < 16384
+                else if (k16) ((uint16_t*)s_val)[i0 + u * BS] = (uint16_t)(v[u] - vmin);
                 else s_val[i0 + u * BS] = v[u];
                 // unsigned-int product, wraps (intensity.cpp:90).  v_mul_lo_u32 issues at quarter rate; below 2^24 the 24-bit
                 // multiply returns the same low 32 bits at full rate (uniform choice per ROI).
@@ -1072,7 +1076,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         // what one member pixel contributes (the body of `trip` above, with its cloud index i and its plane cell)
         auto member = [&](uint32_t v, uint32_t i, uint32_t cell) {
             if (do_int) {
-                if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
+                if (C16 || k16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
                 else s_val[i] = v;
                 sum += v;
                 sumsq += small_v ? mul24(v, v) : (uint32_t)(v * v);
@@ -1217,7 +1221,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             rank0 += (uint32_t)__popcll(bal);
             if (hit && i < n) {
                 if (do_int) {
-                    if (C16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
+                    if (C16 || k16) ((uint16_t*)s_val)[i] = (uint16_t)(v - vmin);
                     else s_val[i] = v;
                     sum += v;
                     sumsq += small_v ? (uint32_t)__umul24(v, v) : (uint32_t)(v * v);
@@ -1433,12 +1437,20 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             }
             grp_sync<GS, NW>();
         } else if (radix) {
-            uint32_t* const s_rdx = (uint32_t*)reg(A.L.radix);         // [sort_cap] second key buffer | [NW * 256 + NW] digit counts
-            s_val = radix_sort<GS, NW>(s_val, s_rdx, s_rdx + A.L.sort_cap, n, vmin, range, tid);
+            // second key buffer [sort_cap] | digit counts [NW * 256 + NW]
+            if (k16) {                                               // (both key buffers in the value region, the counts in A.L.radix)
+                uint16_t* const kb = (uint16_t*)s_val + ((A.L.sort_cap + 7u) & ~7u);
+                s_val = (uint32_t*)radix_sort<GS, NW, uint16_t>((uint16_t*)s_val, kb, (uint32_t*)reg(A.L.radix), n, 0u, range, tid);
+            } else {
+                uint32_t* const s_rdx = (uint32_t*)reg(A.L.radix);
+                s_val = radix_sort<GS, NW, uint32_t>(s_val, s_rdx, s_rdx + A.L.sort_cap, n, vmin, range, tid);
+            }
         } else {
             bitonic_sort<GS, NW>(s_val, P2, tid);
         }
         STAMP(3);
+        // sorted value i of the sort engines (16-bit radix keys are offsets from the minimum)
+        auto SV = [=](uint32_t i) -> uint32_t { return k16 ? vmin + (uint32_t)((const uint16_t*)s_val)[i] : s_val[i]; };
         // C(i) = number of values <= vmin + i (counting engine)
         auto cum = [=](uint32_t i) -> uint32_t {
             const uint32_t wq = (uint32_t)(i >= Q) + (uint32_t)(i >= 2 * Q) + (uint32_t)(i >= 3 * Q);   // i / Q without the division
@@ -1490,7 +1502,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         if (!FUSED || blank) {
             if (!blank) {
                 for (uint32_t i = tid; i < n; i += BS) {
-                    double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]) - mean;
+                    double d = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : SV(i)) - mean;
                     double d2 = d * d;
                     acc[0] += fabs(d);
                     acc[1] += d2;
@@ -1546,7 +1558,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     lo = 0;
                     while (lo < hi) {
                         uint32_t mid = (lo + hi) >> 1;
-                        uint32_t v = s_val[mid];
+                        uint32_t v = SV(mid);
                         uint32_t idx = is100 ? (uint32_t)idx100(v) : to_grayscale(v, vmin, range, nb);
                         if (idx < b) lo = mid + 1; else hi = mid;
                     }
@@ -1559,14 +1571,14 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 // keeps its best run, then a wave / block reduction
                 uint32_t best_c = 0, best_v = 0;
                 for (uint32_t i = tid; i < n; i += BS) {
-                    uint32_t v = s_val[i];
-                    if (i == n - 1 || s_val[i + 1] != v) {
+                    uint32_t v = SV(i);
+                    if (i == n - 1 || SV(i + 1) != v) {
                         uint32_t lo = i, hi = i;
-                        if (i > 0 && s_val[i - 1] == v) {      // (a run of one -- nearly every run of 16-bit data -- needs no search)
+                        if (i > 0 && SV(i - 1) == v) {         // (a run of one -- nearly every run of 16-bit data -- needs no search)
                             lo = 0;
                             while (lo < hi) {
                                 uint32_t mid = (lo + hi) >> 1;
-                                if (s_val[mid] < v) lo = mid + 1; else hi = mid;
+                                if (SV(mid) < v) lo = mid + 1; else hi = mid;
                             }
                         }
                         uint32_t c = i - lo + 1;
@@ -1692,8 +1704,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     hi_v = vmin + kth(n / 2);
                     lo_v = vmin + kth(n / 2 ? n / 2 - 1 : 0);
                 } else {
-                    hi_v = s_val[n / 2];
-                    lo_v = s_val[n / 2 ? n / 2 - 1 : 0];
+                    hi_v = SV(n / 2);
+                    lo_v = SV(n / 2 ? n / 2 - 1 : 0);
                 }
                 if (lane == 0) {
                     double median = (n & 1) ? (double)hi_v : (double)(uint32_t)(hi_v + lo_v) / 2.0;
@@ -1844,7 +1856,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // sweep 1: sum and count inside [p10, p90], and the median absolute deviation (it only needs the median)
             double rb[3] = {0, 0, 0};
             for (uint32_t i = tid; i < n; i += BS) {
-                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
+                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : SV(i));
                 if (a >= p10 && a <= p90) {
                     rb[0] += a;
                     rb[1] += 1.0;
@@ -1856,7 +1868,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // sweep 2: robust MAD about that mean (histogram.h:102-112)
             double ad[1] = {0};
             for (uint32_t i = tid; i < n; i += BS) {
-                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : s_val[i]);
+                double a = (double)(C16 ? vmin + ((const uint16_t*)s_val)[i] : SV(i));
                 if (a >= p10 && a <= p90)
                     ad[0] += fabs(a - mean1090);
             }

@@ -90,6 +90,8 @@ struct LdsLayout {
     uint32_t gs_lds_bytes;
     uint32_t radix;      // != 0: every ROI of the launch sorts (its size class is the wide-range one): offset of the radix sort's second key
                          // buffer [sort_cap] and digit counts [4 * 256 + 4]; no counting table, no power-of-two padding of the values
+    uint32_t radix_k16;  // 1: every range of the launch fits 16 bits -- the keys are 16-bit offsets from the ROI minimum, BOTH key buffers
+                         // live in the value region ([2][sort_cap rounded up to 8] u16) and `radix` holds the digit counts only
 };
 
 // Window source of the fused tile path: when `inten` is set the feature kernel reads an ROI's pixels from its bounding-box
