@@ -189,8 +189,10 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v)
     return v;
 }
 // inclusive prefix MINIMUM over the 64 lanes (lanes without a source in a step keep their own value)
+// (lanes without a source read the identity of the minimum: the compiler then folds the move into v_min_u32_dpp -- one
+//  instruction per step instead of copy + move + minimum)
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_self(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ uint32_t dpp_self(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xF, false); }
 __device__ __forceinline__ uint32_t wave_scan_min_u32(uint32_t v)
 {
     v = min(v, dpp_self<0x111, 0xF>(v));
@@ -477,6 +479,9 @@ __device__ __forceinline__ uint32_t* cnt16_word(uint32_t* tab, uint32_t ci)
     return (uint32_t*)((char*)tab + (t << 1));
 }
 
+// rotations of the wave by one lane (DPP wave_rol:1 / wave_ror:1): every lane has a source
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xF, 0xF, true); }   // value of lane + 1; lane 63 reads lane 0
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, true); }   // value of lane - 1; lane 0 reads lane 63
 __device__ __forceinline__ uint32_t lane_plus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_minus1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 

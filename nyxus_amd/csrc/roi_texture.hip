@@ -357,47 +357,68 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 for (uint32_t i = tid; i < 4u * slot_words; i += kBlock) s_mat[i] = 0;
                 blk_sync<GS>();
                 {
+                    // A run travels as ONE number, its cell S = m * Nr + rl of the matrix (m = row + 1 of its level, rl = length so far;
+                    // Pm = P - (Nr + 1) makes Pm[S] that cell): with c = m' * Nr + 1 the cell a run of the pixel's level m' starts in,
+                    // "same level" is S - c < Nr (unsigned), "continue" is S + 1, "a run is open" is S > Nr.  Level 0 (outside the ROI /
+                    // the box) counts as row 0: its S stays <= Nr (a line has at most Nr pixels) and is never written.  Lanes beyond
+                    // the box read a zero of the level map through a pointer with stride 0 -- no per-row bounds arithmetic.
+                    // ~11 vector instructions per row and direction (28 before: value, length and row travelled separately).
                     uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
-                    const bool in_col = (uint32_t)lane < w;
-                    // cell (row of level rv, length rl) = P[(lvlmap - 1) * Nr + rl - 1]: the two "- 1" live in the base pointer and
-                    // the product is a 24-bit multiply-add (a plain 32-bit product issues at quarter rate)
                     uint32_t* const Pm = P - (Nr + 1);
-                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
-                    // (the plane row is read one step ahead and a run carries the matrix row of its level from the step it starts:
-                    //  no LDS round trip between a row's values and the decisions on them)
-                    auto load_row = [=](uint32_t row) -> uint32_t { return (in_col && row < h) ? (uint32_t)s_dense[row * w + (uint32_t)lane] : 0u; };
-                    auto count_at = [=](uint32_t rm, uint32_t rl) { atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u); };
-                    uint32_t vn = load_row(0);
+                    const uint32_t nr = (uint32_t)Nr;
+                    const bool in_col = (uint32_t)lane < w;
+                    // Two loads ahead: the level of row + 2 and the level-map entry of row + 1.  (The reads of the last two trips land
+                    // up to two rows behind the plane -- in the regions that follow it, never used.  What a trip carries over is made
+                    // of 32-bit results, the map address and the cell c, not of the loaded bytes: no re-extension per trip.)
+                    const dense_t* ptr = in_col ? s_dense + lane : (const dense_t*)s_lvlmap;                  // (s_lvlmap[0] == 0)
+                    const uint32_t col_stride = in_col ? w : 0u;
+                    uint32_t c = mad24((uint32_t)s_lvlmap[*ptr], nr, 1u);                                     // row 0: the cell a run of the pixel's level starts in
+                    ptr += col_stride;
+                    const uint16_t* map_at = s_lvlmap + *ptr;                                                 // row 1
+                    ptr += col_stride;
                     if (wave == 0) {
+                        // E: a run starts on a lane whose level differs from its left neighbour's; the mask of such lanes also says where
+                        // it ends.
                         for (uint32_t row = 0; row < h; row++) {
-                            const uint32_t v = vn;
-                            vn = load_row(row + 1);
-                            const uint32_t nx = lane_plus1(v, 0u);
-                            const unsigned long long same = __ballot((uint32_t)lane + 1 < w && v != 0 && v == nx);
-                            if (v != 0 && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                                count_run(v, (uint32_t)__ffsll((long long)~(same >> lane)));   // 1 + trailing ones of same >> lane
+                            const uint32_t m_next = *map_at;
+                            const uint32_t v_next2 = *ptr;
+                            ptr += col_stride;
+                            const bool differs = lane_minus1(c, 0u) != c;             // (lane 0 compares with the 0 fill)
+                            const unsigned long long nz = __builtin_amdgcn_ballot_w64(c != 1u);
+                            const unsigned long long ends = (__builtin_amdgcn_ballot_w64(differs) >> 1) | ~nz | (1ull << 63);   // a run ends before the next lane that differs from its left neighbour
+                            if (c != 1u && differs)
+                                atomicAdd(&Pm[c + (uint32_t)__builtin_ctzll(ends >> lane)], 1u);
+                            c = mad24(m_next, nr, 1u);
+                            map_at = s_lvlmap + v_next2;
                         }
                     } else {
-                        const int dx = wave == 1 ? 1 : wave == 2 ? 0 : -1;                   // glrlm.cpp:128-176
-                        uint32_t rv = 0, rl = 0, rm = 0;                                      // run: level, length, matrix row + 1
-                        for (uint32_t row = 0; row < h; row++) {
-                            if (dx == 1) {
-                                if (w == 64 && lane == 63 && rv != 0) count_at(rm, rl);
-                                rv = lane_minus1(rv, 0u); rl = lane_minus1(rl, 0u); rm = lane_minus1(rm, 0u);
-                            } else if (dx == -1) {
-                                if (lane == 0 && rv != 0) count_at(rm, rl);
-                                rv = lane_plus1(rv, 0u); rl = lane_plus1(rl, 0u); rm = lane_plus1(rm, 0u);
+                        // SE, S, SW: the run that ends on a lane's line in the previous row; along the diagonals it moves one lane per
+                        // row (a rotation: what leaves the box lands on a lane that reads level 0 and is written there; a 64-wide box
+                        // has no such lane, its leaving run is written before the move).
+                        auto scan = [&](auto dxc) {
+                            constexpr int dx = decltype(dxc)::value;                         // glrlm.cpp:128-176
+                            uint32_t S = 0;
+                            for (uint32_t row = 0; row < h; row++) {
+                                const uint32_t m_next = *map_at;
+                                const uint32_t v_next2 = *ptr;
+                                ptr += col_stride;
+                                if (dx != 0) {
+                                    if (w == 64u) {
+                                        if ((uint32_t)lane == (dx == 1 ? 63u : 0u)) { if (S > nr) atomicAdd(&Pm[S], 1u); S = 0; }
+                                    }
+                                    S = dx == 1 ? wave_ror1(S) : wave_rol1(S);
+                                }
+                                const bool cont = S - c < nr;
+                                if (!cont && S > nr) atomicAdd(&Pm[S], 1u);
+                                S = cont ? S + 1u : c;
+                                c = mad24(m_next, nr, 1u);
+                                map_at = s_lvlmap + v_next2;
                             }
-                            const uint32_t v = vn;
-                            vn = load_row(row + 1);
-                            if (v != 0 && v == rv) rl++;
-                            else {
-                                if (rv != 0) count_at(rm, rl);
-                                rv = v; rl = v != 0 ? 1u : 0u;
-                                rm = v != 0 ? (uint32_t)s_lvlmap[v] : 0u;
-                            }
-                        }
-                        if (rv != 0) count_at(rm, rl);
+                            if (S > nr) atomicAdd(&Pm[S], 1u);
+                        };
+                        if (wave == 1) scan(std::integral_constant<int, 1>());
+                        else if (wave == 2) scan(std::integral_constant<int, 0>());
+                        else scan(std::integral_constant<int, -1>());
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
@@ -668,9 +689,46 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
             // (the one-wave stretches of this kernel rotate over the four waves -- hence the four SIMDs -- by ROI: with six
             //  workgroups per CU a fixed wave 0 would pile all of them onto one SIMD)
-            if (wave == solo && w <= 64) {
-                // bounding boxes up to 64 wide: the previous row's values / labels stay in registers, neighbours come
-                // through DPP lane shifts, the W chain is a segmented prefix-min in DPP steps -- no LDS on the critical path
+            if (D8 && wave == solo && w <= 64) {
+                // bounding boxes up to 64 wide, 8-bit levels: the previous row stays in registers, neighbours come through DPP lane
+                // shifts, the W chain is a prefix-min in DPP steps -- no LDS on the critical path.  A pixel travels as
+                // X = level << 20 | owner label (all ones: no zone pixel), so ONE lane shift fetches a predecessor and "same level ?
+                // its label : nothing" is X' - (level << 20): a label (< 2^20) on a match, something >= 2^20 otherwise (unsigned
+                // wrap) -- three subtractions and three minima for N / NW / NE.  Lanes beyond the box read a zero of the level map
+                // through a pointer with stride 0.  ~40 vector instructions per row (75 in the general sweep below).
+                const bool in = (uint32_t)lane < w;
+                const dense_t* const col_ptr = in ? s_dense + lane : (const dense_t*)s_lvlmap;       // (s_lvlmap[0] == 0)
+                const uint32_t col_stride = in ? w : 0u, p0 = in ? (uint32_t)lane : 0u;
+                uint32_t Xp = 0xFFFFFFFFu;
+                uint32_t vn = (uint32_t)col_ptr[0];
+                for (uint32_t row = 0; row < h; row++) {
+                    const uint32_t v = vn;
+                    vn = (uint32_t)col_ptr[mul_u24_su(col_stride, row + 1u < h ? row + 1u : row)];
+                    const uint32_t p = p0 + mul_u24_su(col_stride, row), V20 = v << 20;
+                    // N, NW, NE predecessors (final labels of the previous row).  (A lane without a source reads 0: on a zone pixel
+                    // 0 - V20 wraps beyond 2^20; on any other lane the label is never used.)
+                    uint32_t lab = min(min(p, Xp - V20), min(lane_minus1(Xp, 0u) - V20, lane_plus1(Xp, 0u) - V20));
+                    // W chain: inclusive prefix-min over runs of equal level as a PLAIN prefix-min -- a label travels with 63 - (index
+                    // of its run) in bits 20..25, so whatever comes from an earlier run compares larger than anything of the lane's own.
+                    const bool zp = v != 0;
+                    const unsigned long long nz = __builtin_amdgcn_ballot_w64(zp);
+                    const unsigned long long smask = ~nz | __builtin_amdgcn_ballot_w64(lane_minus1(v, 0u) != v);   // run starts; a lane that is no zone pixel is a run of its own
+                    const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 33), __builtin_amdgcn_mbcnt_lo((uint32_t)(smask >> 1), 0u));   // starts in lanes 1 .. lane
+                    uint32_t key;
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(key) : "v"(ridx), "s"(-(1 << 20)), "v"(63 << 20));
+                    key = wave_scan_min_u32((lab & 0xFFFFFu) | key);
+                    lab = key & 0xFFFFFu;
+                    const uint32_t X = zp ? (V20 | lab) : 0xFFFFFFFFu;
+                    // zone sizes: one atomic per string of equal X in the row, by the string's first lane (lane 0 compares with the 0
+                    // fill: always first); the string ends before the next lane that differs from its left neighbour
+                    const bool differs = lane_minus1(X, 0u) != X;
+                    const unsigned long long ends = (__builtin_amdgcn_ballot_w64(differs) >> 1) | ~nz | (1ull << 63);
+                    if (zp && differs)
+                        cnt_add(lab, 1u + (uint32_t)__builtin_ctzll(ends >> lane));
+                    Xp = X;
+                }
+            } else if (wave == solo && w <= 64) {
+                // the same sweep for 16-bit levels (value and label travel separately)
                 uint32_t v_prev = 0, lab_prev = 0xFFFFFFFFu;
                 const bool in = (uint32_t)lane < w;
                 for (uint32_t row = 0; row < h; row++) {
@@ -688,9 +746,6 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     }
                     const uint32_t vl = lane_minus1(v, 0u);
                     const bool start = v == 0 || vl != v;       // run starts here (or not a zone pixel); lane 0: vl = 0 != v or v == 0
-                    // Segmented inclusive prefix-min along the W chain as a PLAIN prefix-min: a label (< 2^20) travels with
-                    // 63 - (index of its run) in bits 20..25, so whatever comes from an earlier run compares larger than anything
-                    // of the lane's own run -- six v_min_u32 DPP steps, no per-step segment tests.
                     const unsigned long long smask = __ballot(start);
                     const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u)) + (start ? 1u : 0u);
                     lab = wave_scan_min_u32(((64u - ridx) << 20) | lab) & 0xFFFFFu;    // (ridx is 1..64; lanes beyond the box are runs of their own at the far end)

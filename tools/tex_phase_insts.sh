@@ -1,0 +1,21 @@
+#!/bin/bash
+# cumulative vector-instruction count of the texture kernel's phases: the early-exit builds gpurun_scratch/libtex_<k>.so
+# (-DNYX_TEX_EXIT_AT=k) under the SQ counters, then the shipped library: tools/tex_phase_insts.sh [families]
+export TMPDIR=/tmp
+FAM=${1:-28}
+for lib in $(ls $PWD/gpurun_scratch/libtex_*.so | sort -t_ -k2 -n) $PWD/nyxus_amd/libnyxhip.so; do
+  export NYXHIP_LIB=$lib
+  OUT=$PWD/gpurun_out/pmc_tex; rm -rf $OUT; mkdir -p $OUT
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d $OUT -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-extras --tile-path-tiles 0 --families $FAM > $OUT/log.txt 2>&1
+  python3 - <<PY
+import csv,glob
+from collections import defaultdict
+acc=defaultdict(list)
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "roi_texture" in r.get('Kernel_Name',''): acc[r['Counter_Name']].append(float(r['Counter_Value']))
+m={k: sum(v)/len(v) for k,v in acc.items()}
+w=m.get('SQ_WAVES',1)
+print("$(basename $lib)", {k: round(v/w,1) for k,v in sorted(m.items())})
+PY
+done
