@@ -560,6 +560,7 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     L.ng_cap = L.lvl_cap + 1;
     L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
     L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));
+    if (L.ng_cap <= 256 && (mask & (NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM))) { L.lvf = off; off = align16(off + 16u * (L.ng_cap + 2)); }
     if ((mask & NYXHIP_FAM_NGTDM) && (mask & NYXHIP_FAM_GLSZM) && !spill && L.ng_cap <= 64) {
         L.ngt_own = off; off = align16(off + (L.ng_cap + 2) * 12u + 16u);    // NGTDM sums of its own: the stencil overlaps the GLSZM sweep
     }

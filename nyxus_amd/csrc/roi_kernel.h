@@ -153,6 +153,7 @@ struct TexLayout {
     uint32_t dense;     // uint16[dense_cap]   binned bounding-box plane (background = level 1 under matlab binning)
     uint32_t lvlmap;    // uint16[lvl_cap+2]   level -> row index + 1
     uint32_t lv;        // uint32[ng_cap+2]    row index -> level value
+    uint32_t lvf;       // double[2][ng_cap+2] row index -> (level^2, 1 / level^2) for the feature passes, 0 = none (more than 256 levels)
     uint32_t work;      // per-family scratch, families run one after the other
     uint32_t total;
     uint32_t dense_cap, side_cap, lvl_cap, ng_cap, hash_cap, work_bytes, szm_ok;

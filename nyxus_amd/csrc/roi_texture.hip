@@ -55,10 +55,15 @@ __device__ __forceinline__ double plog_tex(double p)
 #define TSTAMP(k) do { } while (0)
 #endif
 
+// lvf: per level row (i^2, 1 / i^2) as doubles (TexLayout::lvf), or null (many levels: formed on the spot)
 template <bool GS>
-__device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, uint32_t* ri, uint32_t* rj,
+__device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, int Nr, const uint32_t* lv, const double* lvf, uint32_t* ri, uint32_t* rj,
                                     uint32_t Np, double* f, double* park, int lane)
 {
+    auto sq_of = [=](int i, double& in2d, double& ri2) {
+        if (lvf) { in2d = lvf[2 * i]; ri2 = lvf[2 * i + 1]; }
+        else { in2d = (double)(uint32_t)(lv[i] * lv[i]); ri2 = frcp(in2d); }   // unsigned-int product as in the reference (levels can be intensities: 32-bit wrap)
+    };
     // The kernel is bound by vector-instruction issue, so this routine is organised around the instruction count:
     //   * row sums by 16-lane groups (four levels at a time, a 4-step DPP sum each) instead of one lane walking a whole row;
     //   * the fifteen wave totals through two transposed reductions (8 + 7 values: ~35 exchanges each) instead of fifteen
@@ -95,11 +100,12 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
     double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // gln, mu_g, lgl, hgl | sre, lre, rln, mu_r
     for (int i = lane; i < Ng; i += 64) {
         const double r = (double)ri[i];
-        const uint32_t in2 = lv[i] * lv[i];                // unsigned-int product as in the reference (levels can be intensities: 32-bit wrap)
+        double in2d, ri2;
+        sq_of(i, in2d, ri2);
         t8[0] += r * r;                                    // calc_GLN :431-461
         t8[1] += (r * inv_p) * (double)lv[i];              // calc_GLV mu :602-609
-        t8[2] += r * frcp((double)in2);                    // calc_LGLRE :712-741
-        t8[3] += r * (double)in2;                          // calc_HGLRE :744-773
+        t8[2] += r * ri2;                                  // calc_LGLRE :712-741
+        t8[3] += r * in2d;                                 // calc_HGLRE :744-773
     }
     for (int j = lane; j < Nr; j += 64) {
         const double c = (double)rj[j], jd = (double)(j + 1), j2 = jd * jd;
@@ -133,30 +139,55 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
     // quotients factor into the two reciprocals -- otherwise the wrapped product is formed and divided cell by cell.
     const uint32_t lv_max = lv[Ng - 1];                    // (levels are sorted)
     const bool exact = (unsigned long long)lv_max * lv_max * (unsigned long long)Nr * (unsigned long long)Nr < (1ull << 32);
-    for (int j0 = 0; j0 < Nr; j0 += 64) {
-        const int j = j0 + lane;
-        const bool live = j < Nr;
-        const double jd = (double)(j + 1), j2d = jd * jd, rj2 = frcp(j2d);
-        const uint32_t j2 = mul24((uint32_t)(j + 1), (uint32_t)(j + 1));
-        uint32_t idx = (uint32_t)j;
-        for (int i = 0; i < Ng; i++, idx += (uint32_t)Nr) {
-            const uint32_t c = live ? P[idx] : 0u;
-            if (c == 0)
-                continue;                                  // zero cells add +-0 in the reference
-            const double cnt = (double)c;
-            const uint32_t in2 = lv[i] * lv[i];
-            u8[2] += plog_tex(cnt * inv_p);                // calc_RE :693-699
-            if (exact) {
-                const double in2d = (double)in2, ri2 = frcp(in2d), a = cnt * rj2, b = cnt * j2d;
+    // The entropy term of a cell is a function of its count alone, and counts are small: lane k holds the term of count k, a cell
+    // fetches it through ds_bpermute (all lanes take part: a zero cell reads lane 0's -0.0, which adds nothing, like the +-0 the
+    // reference adds for it) -- 64 evaluations of the float log per wave instead of one per cell.
+    const double ptab = plog_tex((double)lane * inv_p);
+    // (two loops, one per arithmetic: with the choice inside one loop the compiler shuffled all eight accumulators through copies
+    //  on every trip -- sixteen 64-bit moves per cell)
+    auto entropy_of = [=](uint32_t c, double cnt) -> double {
+        double e = __shfl(ptab, (int)(c & 63u), 64);
+        if (__builtin_amdgcn_ballot_w64(c >= 64u))
+            e = c >= 64u ? plog_tex(cnt * inv_p) : e;
+        return e;
+    };
+    if (exact) {
+        for (int j0 = 0; j0 < Nr; j0 += 64) {
+            const int j = j0 + lane;
+            const bool live = j < Nr;
+            const double jd = (double)(j + 1), j2d = jd * jd, rj2 = frcp(j2d);
+            uint32_t idx = (uint32_t)j;
+            for (int i = 0; i < Ng; i++, idx += (uint32_t)Nr) {
+                const uint32_t c = live ? P[idx] : 0u;
+                const double cnt = (double)c;
+                u8[2] += entropy_of(c, cnt);               // calc_RE :693-699
+                double in2d, ri2;
+                sq_of(i, in2d, ri2);
+                const double a = cnt * rj2, b = cnt * j2d; // (a zero cell adds +0 to every sum)
                 u8[3] = __builtin_fma(a, ri2, u8[3]);      // calc_SRLGLE :790-797
                 u8[4] = __builtin_fma(a, in2d, u8[4]);     // calc_SRHGLE :822-829
                 u8[5] = __builtin_fma(b, ri2, u8[5]);      // calc_LRLGLE :855-862
                 u8[6] = __builtin_fma(b, in2d, u8[6]);     // calc_LRHGLE :887-894
-            } else {
-                u8[3] += cnt / (double)(uint32_t)(in2 * j2);
-                u8[4] += fdiv(cnt * (double)in2, j2d);
-                u8[5] += fdiv(cnt * j2d, (double)in2);
-                u8[6] += cnt * (double)(uint32_t)(in2 * j2);
+            }
+        }
+    } else {
+        for (int j0 = 0; j0 < Nr; j0 += 64) {
+            const int j = j0 + lane;
+            const bool live = j < Nr;
+            const double jd = (double)(j + 1), j2d = jd * jd;
+            const uint32_t j2 = mul24((uint32_t)(j + 1), (uint32_t)(j + 1));
+            uint32_t idx = (uint32_t)j;
+            for (int i = 0; i < Ng; i++, idx += (uint32_t)Nr) {
+                const uint32_t c = live ? P[idx] : 0u;
+                const double cnt = (double)c;
+                u8[2] += entropy_of(c, cnt);
+                if (c != 0) {
+                    const uint32_t in2 = lv[i] * lv[i];
+                    u8[3] += cnt / (double)(uint32_t)(in2 * j2);
+                    u8[4] += fdiv(cnt * (double)in2, j2d);
+                    u8[5] += fdiv(cnt * j2d, (double)in2);
+                    u8[6] += cnt * (double)(uint32_t)(in2 * j2);
+                }
             }
         }
     }
@@ -216,6 +247,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     uint16_t* s_lvlmap = (uint16_t*)(lds + A.L.lvlmap);   // level -> row index + 1
     uint32_t* s_lv = (uint32_t*)(lds + A.L.lv);           // row index -> level value
     unsigned char* s_work = lds + A.L.work;                // per-family scratch (aliased)
+    const double* const s_lvf = A.L.lvf ? (const double*)(lds + A.L.lvf) : nullptr;   // row index -> (level^2, 1 / level^2)
 
     const uint64_t off = A.px_offset[roi];
     const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
@@ -259,17 +291,29 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     blk_sync<GS>();
 
     // ---- phase 1: cloud -> binned plane -----------------------------------------------------------
-    uint32_t nz_orig = 0, lvl_over = 0;
+    // The levels present and the number of non-zero binned pixels are taken on the way (a pixel list holds a position once): the
+    // plane is not read again for them.  Under matlab binning the background is level 1 -- present when the box has a pixel
+    // outside the list -- and every pixel of the box is non-zero.
+    uint32_t nz_orig = 0, lvl_over = 0, nz_bin = 0;
+    if (tid == 0 && greyInfo > 0 && n < area) s_lvlmap[1] = 1;
     for_each_cloud_pixel<kBlock>(A.inten + off, A.x + off, A.y + off, n, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
-        uint32_t lvl = greyInfo > 0 ? bin_matlab(v, mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
+        uint32_t lvl;
+        if (greyInfo > 0) {     // bin_matlab: a non-zero value gives floor(slope v + 1) >= 1, and the conversion truncates (floor of a positive value)
+            const uint32_t sc = (uint32_t)(mslope * (double)v + 1.0);         // (0 -> 1 as well)
+            lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
+        } else
+            lvl = greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
         nz_orig += v != 0;
         if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
-        if (px < w && py < h)
+        if (px < w && py < h) {
             s_dense[__umul24(py, w) + px] = (dense_t)lvl;
+            if (lvl != 0) { s_lvlmap[lvl] = 1; nz_bin++; }
+        }
     });
-    nz_orig = (uint32_t)wave_sum_u64(nz_orig);
+    nz_orig = wave_sum_t<uint32_t>(nz_orig);
+    nz_bin = wave_sum_t<uint32_t>(nz_bin);
     lvl_over = wave_max_u32(lvl_over);
-    if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; }
+    if (lane == 0) { s_red[wave * 8] = (double)nz_orig; s_red[wave * 8 + 1] = (double)lvl_over; s_red[wave * 8 + 2] = (double)nz_bin; }
     blk_sync<GS>();
     TSTAMP(0);
     // The two pixel counts are needed once each, much later: they wait in s_stat instead of occupying registers through
@@ -277,29 +321,15 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     bool over = false;
     {
         uint32_t Np_orig = 0;   // non-zero ORIGINAL pixels (glrlm.cpp:197-204)
-        for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; }
-        if (tid == 0) s_stat[2] = (double)Np_orig;
+        uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
+        for (int wv = 0; wv < kWaves; wv++) { Np_orig += (uint32_t)s_red[wv * 8]; over |= s_red[wv * 8 + 1] != 0; Np_bin += (uint32_t)s_red[wv * 8 + 2]; }
+        if (tid == 0) { s_stat[2] = (double)Np_orig; s_stat[3] = (double)(greyInfo > 0 ? area : Np_bin); }
     }
     if (over) { // IBSI level beyond the LDS-resident capacity
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
         for (int c = tid; c < A.n_cols; c += kBlock)
             out_row[gcol(c)] = __longlong_as_double(0x7ff8000000000000LL);
         return;
-    }
-    // levels present in the plane (background included)
-    uint32_t nz_bin = 0;
-    for (uint32_t p = tid; p < area; p += kBlock) {
-        uint32_t l = s_dense[p];
-        if (l) { s_lvlmap[l] = 1; nz_bin++; }
-    }
-    nz_bin = (uint32_t)wave_sum_u64(nz_bin);
-    blk_sync<GS>();
-    if (lane == 0) s_red[wave * 8] = (double)nz_bin;
-    blk_sync<GS>();
-    if (tid == 0) {
-        uint32_t Np_bin = 0;    // non-zero BINNED pixels (glszm.cpp:193-199)
-        for (int wv = 0; wv < kWaves; wv++) Np_bin += (uint32_t)s_red[wv * 8];
-        s_stat[3] = (double)Np_bin;
     }
     // sorted unique non-zero levels (glrlm.cpp:101-105, glszm.cpp:97-101, ngtdm.cpp:53-67);
     // IBSI: I = 1..max (GLRLM/GLSZM) and 0..max (NGTDM)
@@ -318,8 +348,16 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         s_stat[1] = (double)k;                               // Ngp = unique non-zero levels (ngtdm.cpp:150)
     }
     blk_sync<GS>();
-    TSTAMP(1);
     const int Ng = (int)s_stat[0];
+    if (A.L.lvf) {
+        for (int i = tid; i < Ng; i += kBlock) {
+            const double in2d = (double)(uint32_t)(s_lv[i] * s_lv[i]);       // (levels <= 4094: the unsigned product of glrlm.cpp and the double product of glszm.cpp are the same number)
+            double* t = (double*)(lds + A.L.lvf) + 2 * i;
+            t[0] = in2d; t[1] = frcp(in2d);
+        }
+        blk_sync<GS>();
+    }
+    TSTAMP(1);
     const int Nuniq = (int)s_stat[1];
     const bool blank = vmin == vmax;
     int col = 0;
@@ -422,7 +460,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else if (nslot >= 4 && w > 64 && w <= 64u * kRlmChunks) {
                 // Boxes 65 .. 256 wide: the same one-wave-per-direction row scans over up to four chunks of 64 columns (lane =
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             if (c < nch && rv[c] != 0) count_at(rm[c], rl[c]);
                     }
                     wav_sync<GS>();
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
@@ -559,7 +597,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
                         }
                         wav_sync<GS>();
-                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, s_red + wave * 8, lane);
+                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, s_red + wave * 8, lane);
                     }
                 }
             }
@@ -608,9 +646,12 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         for (int row = r_begin; row < r_end; row++) {
             const uint32_t nxt = load_row(row + 1);
             const uint32_t nxt_w = west(row + 1), nxt_e = east(row + 1);
-            const uint32_t pw = lane_minus1(prv, prv_w), pe = lane_plus1(prv, prv_e), cw = lane_minus1(cur, cur_w), ce = lane_plus1(cur, cur_e),
-                           nw = lane_minus1(nxt, nxt_w), ne = lane_plus1(nxt, nxt_e);
-            const uint32_t tot = ((pw + prv) + (pe + cw)) + ((ce + nw) + (nxt + ne));
+            // the eight neighbours = the three-row sums of the columns to the left and right + this column's without the centre
+            // (integer sums: any order) -- two lane shifts per row instead of six
+            const uint32_t col3 = prv + cur + nxt;
+            uint32_t tot;
+            if (!has_w && !has_e) tot = lane_minus1(col3, 0u) + lane_plus1(col3, 0u) + (prv + nxt);
+            else tot = lane_minus1(col3, prv_w + cur_w + nxt_w) + lane_plus1(col3, prv_e + cur_e + nxt_e) + (prv + nxt);
             if (cur != 0 && tot >= (1u << 24)) {
                 const uint32_t lvl = cur & 0xFFFFFFu, sum = tot & 0xFFFFFFu, nd = tot >> 24;
                 const uint32_t r = greyInfo == 0 ? lvl : (uint32_t)s_lvlmap[lvl] - 1u;
@@ -672,6 +713,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (uint32_t i = tid; i < hcap; i += kBlock) { s_hkey[i] = 0; s_hval[i] = 0; }   // key 0 = empty (a size is >= 1)
             for (uint32_t i = tid; i < (uint32_t)Ng * S; i += kBlock) s_small[i] = 0;
             for (int i = tid; i < Ng; i += kBlock) s_si[i] = 0;
+            uint32_t* const s_any_hashed = (uint32_t*)(s_stat + 5);   // a zone went to the hash (else its second sweep has nothing to do)
+            if (tid == 0) *s_any_hashed = 0;
             // The row sweep below occupies ONE wave (a serial chain over the rows); with accumulators of its own the NGTDM stencil
             // runs on the other three meanwhile instead of adding its time afterwards.
             const bool ngt_here = ngt_own && do_ngt && NgT >= 2 && w <= 64u * kSzmChunks;   // (the widths the register sweep below takes)
@@ -689,13 +732,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             // owner labels and zone sizes: wave 0 sweeps the rows, lanes own columns
             // (the one-wave stretches of this kernel rotate over the four waves -- hence the four SIMDs -- by ROI: with six
             //  workgroups per CU a fixed wave 0 would pile all of them onto one SIMD)
-            if (D8 && wave == solo && w <= 64) {
-                // bounding boxes up to 64 wide, 8-bit levels: the previous row stays in registers, neighbours come through DPP lane
+            if (wave == solo && w <= 64) {
+                // bounding boxes up to 64 wide: the previous row stays in registers, neighbours come through DPP lane
                 // shifts, the W chain is a prefix-min in DPP steps -- no LDS on the critical path.  A pixel travels as
-                // X = level << 20 | owner label (all ones: no zone pixel), so ONE lane shift fetches a predecessor and "same level ?
+                // X = level << 20 | owner label (levels <= 4094, labels < 2^20; all ones: no zone pixel), so ONE lane shift fetches a predecessor and "same level ?
                 // its label : nothing" is X' - (level << 20): a label (< 2^20) on a match, something >= 2^20 otherwise (unsigned
                 // wrap) -- three subtractions and three minima for N / NW / NE.  Lanes beyond the box read a zero of the level map
-                // through a pointer with stride 0.  ~40 vector instructions per row (75 in the general sweep below).
+                // through a pointer with stride 0.  ~40 vector instructions per row (75 before: value and label travelled separately).
                 const bool in = (uint32_t)lane < w;
                 const dense_t* const col_ptr = in ? s_dense + lane : (const dense_t*)s_lvlmap;       // (s_lvlmap[0] == 0)
                 const uint32_t col_stride = in ? w : 0u, p0 = in ? (uint32_t)lane : 0u;
@@ -726,37 +769,6 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     if (zp && differs)
                         cnt_add(lab, 1u + (uint32_t)__builtin_ctzll(ends >> lane));
                     Xp = X;
-                }
-            } else if (wave == solo && w <= 64) {
-                // the same sweep for 16-bit levels (value and label travel separately)
-                uint32_t v_prev = 0, lab_prev = 0xFFFFFFFFu;
-                const bool in = (uint32_t)lane < w;
-                for (uint32_t row = 0; row < h; row++) {
-                    const uint32_t p = row * w + (uint32_t)lane;
-                    const uint32_t v = in ? (uint32_t)s_dense[p] : 0u;
-                    uint32_t lab = p;
-                    {   // N, NW, NE predecessors (final labels of the previous row; v_prev = 0 on the first row)
-                        const uint32_t vW = lane_minus1(v_prev, 0u), lW = lane_minus1(lab_prev, 0xFFFFFFFFu);
-                        const uint32_t vE = lane_plus1(v_prev, 0u), lE = lane_plus1(lab_prev, 0xFFFFFFFFu);
-                        if (v != 0) {
-                            if (v_prev == v) lab = min(lab, lab_prev);
-                            if (vW == v) lab = min(lab, lW);
-                            if (vE == v) lab = min(lab, lE);
-                        }
-                    }
-                    const uint32_t vl = lane_minus1(v, 0u);
-                    const bool start = v == 0 || vl != v;       // run starts here (or not a zone pixel); lane 0: vl = 0 != v or v == 0
-                    const unsigned long long smask = __ballot(start);
-                    const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u)) + (start ? 1u : 0u);
-                    lab = wave_scan_min_u32(((64u - ridx) << 20) | lab) & 0xFFFFFu;    // (ridx is 1..64; lanes beyond the box are runs of their own at the far end)
-                    // zone sizes: one atomic per string of equal labels in the row (a lane that is no zone pixel carries its own
-                    // index -- unique in the row -- so it never continues or starts a string)
-                    const uint32_t ln = lane_plus1(lab, 0xFFFFFFFFu);
-                    const bool zp = in && v != 0;
-                    const unsigned long long same = __ballot(zp && (uint32_t)lane + 1u < w && ln == lab);
-                    if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                        cnt_add(lab, (uint32_t)__ffsll((long long)~(same >> lane)));
-                    v_prev = v; lab_prev = zp ? lab : 0xFFFFFFFFu;
                 }
             } else if (wave == solo && w <= 64u * kSzmChunks) {
                 // bounding boxes 65 .. 256 wide: the same register sweep over up to four chunks of 64 columns per row (lane = column
@@ -880,6 +892,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
                 atomicAdd(&s_si[rowi], 1u);
                 if (sz <= S) { atomicAdd(&s_small[rowi * 32u + (sz - 1u)], 1u); continue; }
+                *s_any_hashed = 1u;
                 uint32_t k = (rowi << 20) | sz;
                 uint32_t hsl = (k * 2654435761u) & (hcap - 1);
                 for (;;) {
@@ -890,6 +903,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 }
             }
             blk_sync<GS>();
+            if (*s_any_hashed)
             for (uint32_t p = tid; p < area; p += kBlock) {
                 uint32_t sz = cnt_get(p);
                 if (sz <= S) continue;                   // no zone here, or counted in the direct table
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     hsl = (hsl + 1) & (hcap - 1);
                 atomicAdd(&s_hval[hsl], 1u);
             }
-            nzone = (uint32_t)wave_sum_u64(nzone);
+            nzone = wave_sum_t<uint32_t>(nzone);
             blk_sync<GS>();
             TSTAMP(5);
             if (lane == 0) s_red[wave * 8] = (double)nzone;
@@ -923,20 +937,30 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 // Newton division per quotient, p / sum_p as a product, wave totals through transposed reductions.)
                 const double inv_p = frcp(sum_p);
                 double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t i = tid; i < n_cells; i += kBlock) {
-                    uint32_t key, val;
-                    cell(i, key, val);
+                // (the entropy term of a cell is a function of its multiplicity, a small number: lane k holds the term of
+                //  multiplicity k and a cell fetches it through ds_bpermute -- whole waves, so the loop runs in block-sized steps)
+                const double ztab = plog_tex((double)lane * inv_p);
+                for (uint32_t i0 = 0; i0 < n_cells; i0 += kBlock) {
+                    const uint32_t i = i0 + (uint32_t)tid;
+                    uint32_t key = 0, val = 0;
+                    if (i < n_cells) cell(i, key, val);
+                    double ze = __shfl(ztab, (int)(val & 63u), 64);
+                    if (__builtin_amdgcn_ballot_w64(val >= 64u))
+                        ze = val >= 64u ? plog_tex((double)val * inv_p) : ze;
                     if (key == 0) continue;
                     const double p = (double)val;
                     const double inten = (double)s_lv[key >> 20], jd = (double)(key & 0xFFFFFu);
-                    const double i2 = inten * inten, j2 = jd * jd, ri2 = frcp(i2), rj2 = frcp(j2);   // (levels and sizes are >= 1)
+                    double i2, ri2;
+                    if (s_lvf) { i2 = s_lvf[2 * (key >> 20)]; ri2 = s_lvf[2 * (key >> 20) + 1]; }
+                    else { i2 = inten * inten; ri2 = frcp(i2); }
+                    const double j2 = jd * jd, rj2 = frcp(j2);   // (levels and sizes are >= 1)
                     const double pj = p * j2, pr = p * rj2;
                     acc[0] = __builtin_fma(pj, i2, acc[0]);  // f_LAHGLE
                     acc[1] = __builtin_fma(pj, ri2, acc[1]); // f_LALGLE
                     acc[2] = __builtin_fma(pr, i2, acc[2]);  // f_SAHGLE
                     acc[3] = __builtin_fma(pr, ri2, acc[3]); // f_SALGLE
                     const double pn = p * inv_p;
-                    acc[4] += plog_tex(pn);                  // f_ZE
+                    acc[4] += ze;                            // f_ZE
                     acc[5] = __builtin_fma(pn, jd, acc[5]);  // mu_ZV
                     acc[6] = __builtin_fma(pn, inten, acc[6]); // mu_GLV
                 }
@@ -989,9 +1013,12 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     b[4] += sj * sj;                         // calc_SZN :464-474
                 }
                 for (int i = tid; i < Ng; i += kBlock) {
-                    const double si = (double)s_si[i], inten = (double)s_lv[i], i2 = inten * inten;
+                    const double si = (double)s_si[i], inten = (double)s_lv[i];
+                    double i2, ri2;
+                    if (s_lvf) { i2 = s_lvf[2 * i]; ri2 = s_lvf[2 * i + 1]; }
+                    else { i2 = inten * inten; ri2 = frcp(i2); }
                     b[5] += si * si;                         // calc_GLN :441-451
-                    b[6] += si * frcp(i2);                   // calc_LGLZE :531-541
+                    b[6] += si * ri2;                        // calc_LGLZE :531-541
                     b[7] += si * i2;                         // calc_HGLZE :543-553
                 }
                 {
@@ -1073,7 +1100,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             // Nvc = Nvp = number of pixels with a neighbourhood (every mean is > 0), ngtdm.cpp:176-186
             uint32_t nvc_part = 0;
             for (int i = tid; i < NgT; i += kBlock) nvc_part += s_N[i];
-            nvc_part = (uint32_t)wave_sum_u64(nvc_part);
+            nvc_part = wave_sum_t<uint32_t>(nvc_part);
             if (lane == 0) s_red[wave * 8] = (double)nvc_part;
             blk_sync<GS>();
             const double Nvc = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
