@@ -884,13 +884,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             // final layout is a function of the key SET, not of the order in which the lanes win their atomics -- the
             // floating-point sums over the table below then run in the same order on every launch (bit-reproducible output).
             // Keys first (atomicMax carries a displaced key onward), multiplicities in a second sweep once the layout is final.
-            uint32_t nzone = 0;
+            uint32_t nzone = 0, sz_max = 0;
             for (uint32_t p = tid; p < area; p += kBlock) {
                 uint32_t sz = cnt_get(p);
                 if (sz == 0) continue;
                 nzone++;
+                sz_max = sz > sz_max ? sz : sz_max;
                 uint32_t rowi = (uint32_t)s_lvlmap[s_dense[p]] - 1;
-                atomicAdd(&s_si[rowi], 1u);
                 if (sz <= S) { atomicAdd(&s_small[rowi * 32u + (sz - 1u)], 1u); continue; }
                 *s_any_hashed = 1u;
                 uint32_t k = (rowi << 20) | sz;
@@ -914,19 +914,25 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 atomicAdd(&s_hval[hsl], 1u);
             }
             nzone = wave_sum_t<uint32_t>(nzone);
+            sz_max = wave_max_u32(sz_max);
             blk_sync<GS>();
             TSTAMP(5);
-            if (lane == 0) s_red[wave * 8] = (double)nzone;
-            // zones per size (sj): reuse s_count, keyed by size
-            for (uint32_t i = tid; i < cnt_words; i += kBlock) s_count[i] = 0;
+            if (lane == 0) { s_red[wave * 8] = (double)nzone; s_red[wave * 8 + 1] = (double)sz_max; }
             blk_sync<GS>();
             double sum_p = 0;
-            for (int wv = 0; wv < kWaves; wv++) sum_p += s_red[wv * 8];
+            for (int wv = 0; wv < kWaves; wv++) { sum_p += s_red[wv * 8]; const uint32_t m = (uint32_t)s_red[wv * 8 + 1]; sz_max = wv == 0 || m > sz_max ? m : sz_max; }
+            // zones per size (sj): reuse s_count, keyed by size -- only the sizes that occur (<= sz_max) are cleared and read back;
+            // boxes of 65536 pixels and more keep the full range (their empty columns at multiples of 65536 matter, see below)
+            const uint32_t j_max = area >= 65536u ? area : sz_max;
+            for (uint32_t i = tid; i < (c16 ? (j_max + 2) / 2 : j_max + 1); i += kBlock) s_count[i] = 0;
+            blk_sync<GS>();
             for (uint32_t i = tid; i < n_cells; i += kBlock) {
                 uint32_t key, val;
                 cell(i, key, val);
-                if (key != 0)
+                if (key != 0) {
                     cnt_add(key & 0xFFFFFu, val);
+                    atomicAdd(&s_si[key >> 20], val);    // zones per level, from the (few) cells instead of one atomic per zone on Ng hot addresses
+                }
             }
             blk_sync<GS>();
             TSTAMP(6);
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     b[0] += p * (dg * dg);                   // calc_GLV :497-510
                     b[1] += p * (dz * dz);                   // calc_ZV :512-524
                 }
-                for (uint32_t j = 1 + tid; j <= area; j += kBlock) {
+                for (uint32_t j = 1 + tid; j <= j_max; j += kBlock) {
                     const uint32_t sji = cnt_get(j);
                     // j * j is an int product in the reference: it wraps for j >= 46341 and is exactly 0 at multiples of
                     // 65536, where the empty column contributes 0.0 / 0 = NaN to SAE (Ns = bbox area, glszm.cpp:212)
