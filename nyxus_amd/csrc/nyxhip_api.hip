@@ -562,7 +562,11 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));
     if (L.ng_cap <= 256 && (mask & (NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM))) { L.lvf = off; off = align16(off + 16u * (L.ng_cap + 2)); }
     if ((mask & NYXHIP_FAM_NGTDM) && (mask & NYXHIP_FAM_GLSZM) && !spill && L.ng_cap <= 64) {
-        L.ngt_own = off; off = align16(off + (L.ng_cap + 2) * 12u + 16u);    // NGTDM sums of its own: the stencil overlaps the GLSZM sweep
+        // NGTDM sums of its own: the stencil overlaps the GLSZM sweep.  Few levels mean few addresses under 64-lane atomics: replicas
+        // (lane % R picks one) keep the lanes per address near one; 40 + 2 k dwords apart so that the replicas start in different banks
+        L.ngt_rep = L.ng_cap <= 16 ? 8u : L.ng_cap <= 32 ? 4u : 2u;
+        L.ngt_stride = (((L.ng_cap + 2) * 12u + 16u + 7u) & ~7u) | 8u;
+        L.ngt_own = off; off = align16(off + L.ngt_rep * L.ngt_stride);
     }
     L.work = off;
     size_t need = 0;

@@ -21,6 +21,7 @@
 // HBM traffic: the ROI cloud in (8 B/px), 101 doubles out; everything else is LDS.
 // Built with -ffp-contract=off (device_math.h).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
@@ -621,6 +622,10 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     const bool ngt_own = !GS && A.L.ngt_own != 0;
     unsigned long long* const s_S = (unsigned long long*)(ngt_own ? lds + A.L.ngt_own : s_work);   // [NgT] sum |i - mean| in units of 1/840
     uint32_t* const s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);                                           // [NgT]
+    // Replicas of the accumulators (own carve-out only): a lane adds into replica lane % R, so that the 64 lanes of an atomic
+    // spread over R times as many addresses -- with eight levels every atomic of the stencil had eight lanes per address, and LDS
+    // serialises those (the counters showed half of the kernel's LDS cycles as conflicts).  Replica 0 collects the others later.
+    const uint32_t ngt_rep = ngt_own ? A.L.ngt_rep : 1u, ngt_words = A.L.ngt_stride / 4u;              // (stride in bytes, a multiple of 8)
     // One lane per column, rows r_begin .. r_end - 1; the rows above / below travel in registers and the horizontal neighbours
     // come through DPP lane shifts (level 0 = outside the box or not a pixel: skipped, like the bounds tests and the q != 0 test
     // of the reference's stencil).  A level travels with a "present" flag in bit 24 (levels are 16-bit), so ONE sum over the eight
@@ -639,6 +644,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         };
         auto load_row = [=](int r) -> uint32_t { return code_at(r, col0 + (uint32_t)lane, in_col); };
         const bool has_w = col0 > 0u, has_e = col0 + 64u < w;        // a column of the box to the chunk's left / right
+        const uint32_t rep_off = mul24((uint32_t)lane & (ngt_rep - 1u), ngt_words);
+        uint32_t* const r_N = s_N + rep_off;
+        unsigned long long* const r_S = s_S + (rep_off >> 1);
         auto west = [=](int r) -> uint32_t { return has_w ? code_at(r, col0 - 1u, true) : 0u; };
         auto east = [=](int r) -> uint32_t { return has_e ? code_at(r, col0 + 64u, true) : 0u; };
         uint32_t prv = load_row(r_begin - 1), cur = load_row(r_begin);
@@ -657,9 +665,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 const uint32_t r = greyInfo == 0 ? lvl : (uint32_t)s_lvlmap[lvl] - 1u;
                 uint32_t d;                             // |840 i - sum * (840 / nd)|
                 asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(mul24(lvl, 840u)), "v"(mul24(sum, s_q[nd])));
-                atomicAdd(&s_N[r], 1u);
-                if (sum32) atomicAdd((uint32_t*)&s_S[r], d);
-                else atomicAdd(&s_S[r], (unsigned long long)d);
+                atomicAdd(&r_N[r], 1u);
+                if (sum32) atomicAdd((uint32_t*)&r_S[r], d);
+                else atomicAdd(&r_S[r], (unsigned long long)d);
             }
             prv = cur; cur = nxt;
             prv_w = cur_w; cur_w = nxt_w; prv_e = cur_e; cur_e = nxt_e;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             // runs on the other three meanwhile instead of adding its time afterwards.
             const bool ngt_here = ngt_own && do_ngt && NgT >= 2 && w <= 64u * kSzmChunks;   // (the widths the register sweep below takes)
             if (ngt_here)
-                for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
+                for (uint32_t i = tid; i < ngt_rep * ngt_words; i += kBlock) ((uint32_t*)s_S)[i] = 0;
             blk_sync<GS>();
             if (ngt_here) {
                 ngt_stencil_done = true;
@@ -1065,7 +1073,10 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             for (int c = tid; c < 5; c += kBlock) o[c] = A.soft_nan;
         } else {
             if (!ngt_stencil_done) {
-                for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
+                if (ngt_rep > 1u)
+                    for (uint32_t i = tid; i < ngt_rep * ngt_words; i += kBlock) ((uint32_t*)s_S)[i] = 0;
+                else
+                    for (int i = tid; i < NgT; i += kBlock) { s_S[i] = 0; s_N[i] = 0; }
                 blk_sync<GS>();
             }
             if (ngt_stencil_done) {
@@ -1100,6 +1111,15 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     atomicAdd(&s_S[r], (unsigned long long)(t < 0 ? -t : t));
                 }
             }
+            }
+            if (ngt_rep > 1u) {                                   // replica 0 collects the others
+                blk_sync<GS>();
+                for (int i = tid; i < NgT; i += kBlock) {
+                    unsigned long long sS = s_S[i];
+                    uint32_t sN = s_N[i];
+                    for (uint32_t r = 1; r < ngt_rep; r++) { sS += s_S[(size_t)r * (ngt_words >> 1) + i]; sN += s_N[r * ngt_words + i]; }
+                    s_S[i] = sS; s_N[i] = sN;
+                }
             }
             blk_sync<GS>();
             TSTAMP(9);
@@ -1181,6 +1201,7 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
         return orc;
     if (grid == 0)
         return 0;
+    if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] texture launch: dense8 %u ng_cap %u total %u work %u ngt_rep %u mask %u\n", a.L.dense8, a.L.ng_cap, a.L.total, a.L.work_bytes, a.L.ngt_rep, a.mask);
     if (a.sp.scratch)
         hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     // (LDS is handed out in 1280-byte granules: k workgroups share a CU when k rounded-up carve-outs fit)
