@@ -561,17 +561,24 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     L.lvlmap = off; off = align16(off + 2u * (L.lvl_cap + 4));
     L.lv = off; off = align16(off + 4u * (L.ng_cap + 4));
     if (L.ng_cap <= 256 && (mask & (NYXHIP_FAM_GLRLM | NYXHIP_FAM_GLSZM))) { L.lvf = off; off = align16(off + 16u * (L.ng_cap + 2)); }
-    if ((mask & NYXHIP_FAM_NGTDM) && (mask & NYXHIP_FAM_GLSZM) && !spill && L.ng_cap <= 64) {
-        // NGTDM sums of its own: the stencil overlaps the GLSZM sweep.  Few levels mean few addresses under 64-lane atomics: replicas
-        // (lane % R picks one) keep the lanes per address near one; 40 + 2 k dwords apart so that the replicas start in different banks
+    // NGTDM accumulators (u64 S[ng_cap + 2], u32 N[ng_cap + 2]).  Few levels mean few addresses under 64-lane atomics, which LDS
+    // serialises: R replicas (lane % R picks one) keep the lanes per address near one; an odd multiple of 8 bytes apart so that the
+    // replicas start in different banks.
+    L.ngt_rep = 1; L.ngt_stride = ((L.ng_cap + 2) * 12u + 7u) & ~7u;
+    if ((mask & NYXHIP_FAM_NGTDM) && !spill && L.ng_cap <= 64) {
         L.ngt_rep = L.ng_cap <= 16 ? 8u : L.ng_cap <= 32 ? 4u : 2u;
         L.ngt_stride = (((L.ng_cap + 2) * 12u + 16u + 7u) & ~7u) | 8u;
+    }
+    if ((mask & NYXHIP_FAM_NGTDM) && (mask & NYXHIP_FAM_GLSZM) && !spill && L.ng_cap <= 64) {
+        // accumulators of its own: the stencil overlaps the GLSZM sweep
         L.ngt_own = off; off = align16(off + L.ngt_rep * L.ngt_stride);
     }
     L.work = off;
     size_t need = 0;
-    if (mask & NYXHIP_FAM_NGTDM)
-        need = std::max(need, (size_t)(L.ng_cap + 2) * (8 + 4 + 8 + 8) + 64);
+    if (mask & NYXHIP_FAM_NGTDM) {
+        L.ngt_p = L.ngt_own ? 0u : (L.ngt_rep * L.ngt_stride + 15u) & ~15u;      // P[ng_cap + 2], S / 840 [ng_cap + 2] as doubles, behind the aliased accumulators
+        need = std::max(need, (size_t)L.ngt_p + (size_t)(L.ng_cap + 2) * 16 + 64);
+    }
     if (mask & NYXHIP_FAM_GLSZM) {
         // distinct (level, size) pairs <= sqrt(2 * Ng * area) (sizes of one level sum to <= its area)
         // (load <= 2/3 in the worst case; zones of up to 32 pixels bypass the hash altogether when the direct table exists.  With

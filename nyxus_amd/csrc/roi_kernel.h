@@ -161,7 +161,8 @@ struct TexLayout {
     uint32_t szm_small, szm_smalltab;   // GLSZM: zones of size <= szm_small (0 or 32) are counted in a direct [level][size] table at this offset of `work`
     uint32_t szm_count, szm_hkey, szm_label;   // offsets inside `work`: sizes, hash keys (values follow), owner labels (only when side_cap > 256)
     uint32_t dense8;    // 1: the binned plane holds 8-bit levels (LDS launches with a grey depth <= 254)
-    uint32_t ngt_rep, ngt_stride;   // ngt_own holds ngt_rep (a power of two) replicas of the accumulators, ngt_stride bytes apart
+    uint32_t ngt_rep, ngt_stride;   // ngt_rep (a power of two) replicas of the NGTDM accumulators, ngt_stride bytes apart, at ngt_own or at the start of `work`
+    uint32_t ngt_p;     // offset inside `work` of the NGTDM feature pass's double arrays
     uint32_t ngt_own;   // NGTDM accumulators (u64 S[ng_cap+2], u32 N[ng_cap+2]) outside `work`, 0 = none: lets the NGTDM stencil run on the
                         // three waves that would otherwise wait for the one-wave GLSZM row sweep
 };

@@ -622,10 +622,10 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     const bool ngt_own = !GS && A.L.ngt_own != 0;
     unsigned long long* const s_S = (unsigned long long*)(ngt_own ? lds + A.L.ngt_own : s_work);   // [NgT] sum |i - mean| in units of 1/840
     uint32_t* const s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);                                           // [NgT]
-    // Replicas of the accumulators (own carve-out only): a lane adds into replica lane % R, so that the 64 lanes of an atomic
+    // Replicas of the accumulators (LDS launches with few levels): a lane adds into replica lane % R, so that the 64 lanes of an atomic
     // spread over R times as many addresses -- with eight levels every atomic of the stencil had eight lanes per address, and LDS
     // serialises those (the counters showed half of the kernel's LDS cycles as conflicts).  Replica 0 collects the others later.
-    const uint32_t ngt_rep = ngt_own ? A.L.ngt_rep : 1u, ngt_words = A.L.ngt_stride / 4u;              // (stride in bytes, a multiple of 8)
+    const uint32_t ngt_rep = A.L.ngt_rep, ngt_words = A.L.ngt_stride / 4u;                             // (stride in bytes, a multiple of 8)
     // One lane per column, rows r_begin .. r_end - 1; the rows above / below travel in registers and the horizontal neighbours
     // come through DPP lane shifts (level 0 = outside the box or not a pixel: skipped, like the bounds tests and the q != 0 test
     // of the reference's stencil).  A level travels with a "present" flag in bit 24 (levels are 16-bit), so ONE sum over the eight
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     if (do_ngt) {
         double* o = s_out + col;
         col += 5;
-        double* s_P = (double*)((uint32_t*)((unsigned long long*)s_work + A.L.ng_cap + 2) + A.L.ng_cap + 2);   // [NgT] (behind the aliased S / N arrays)
+        double* s_P = (double*)(s_work + A.L.ngt_p);               // [NgT] (behind the S / N arrays when those are aliased)
         double* s_Sd = s_P + A.L.ng_cap + 2;                      // [NgT]
         if (NgT < 2) {                                            // ngtdm.cpp:70-78
             for (int c = tid; c < 5; c += kBlock) o[c] = A.soft_nan;
