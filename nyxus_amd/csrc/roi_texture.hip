@@ -411,24 +411,38 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     // of 32-bit results, the map address and the cell c, not of the loaded bytes: no re-extension per trip.)
                     const dense_t* ptr = in_col ? s_dense + lane : (const dense_t*)s_lvlmap;                  // (s_lvlmap[0] == 0)
                     const uint32_t col_stride = in_col ? w : 0u;
+                    // (LDS launches form the map address as a 32-bit LDS address right behind the byte load and pin it there: sunk
+                    //  into the block of its use, the byte costs a re-extension per trip)
+                    typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+                    using map_h = typename std::conditional<GS, const uint16_t*, uint32_t>::type;
+                    const uint32_t map0 = GS ? 0u : (uint32_t)(uintptr_t)(const lds_u16_t*)s_lvlmap;
+                    auto map_of = [=](uint32_t v) -> map_h {
+                        if constexpr (GS) return s_lvlmap + v;
+                        else { uint32_t a = map0 + 2u * v; asm volatile("" : "+v"(a)); return a; }
+                    };
+                    auto map_read = [=](map_h hd) -> uint32_t {
+                        if constexpr (GS) return (uint32_t)*hd;
+                        else return (uint32_t)*(const lds_u16_t*)hd;
+                    };
                     uint32_t c = mad24((uint32_t)s_lvlmap[*ptr], nr, 1u);                                     // row 0: the cell a run of the pixel's level starts in
                     ptr += col_stride;
-                    const uint16_t* map_at = s_lvlmap + *ptr;                                                 // row 1
+                    map_h map_at = map_of((uint32_t)*ptr);                                                    // row 1
                     ptr += col_stride;
                     if (wave == 0) {
                         // E: a run starts on a lane whose level differs from its left neighbour's; the mask of such lanes also says where
                         // it ends.
                         for (uint32_t row = 0; row < h; row++) {
-                            const uint32_t m_next = *map_at;
-                            const uint32_t v_next2 = *ptr;
+                            // (both loads are turned into their 32-bit results right here, in the block that issues them: carried
+                            //  across the branch below as bytes they cost a re-extension each per trip)
+                            const uint32_t c_next = mad24(map_read(map_at), nr, 1u);
+                            map_at = map_of((uint32_t)*ptr);
                             ptr += col_stride;
                             const bool differs = lane_minus1(c, 0u) != c;             // (lane 0 compares with the 0 fill)
                             const unsigned long long nz = __builtin_amdgcn_ballot_w64(c != 1u);
                             const unsigned long long ends = (__builtin_amdgcn_ballot_w64(differs) >> 1) | ~nz | (1ull << 63);   // a run ends before the next lane that differs from its left neighbour
                             if (c != 1u && differs)
                                 atomicAdd(&Pm[c + (uint32_t)__builtin_ctzll(ends >> lane)], 1u);
-                            c = mad24(m_next, nr, 1u);
-                            map_at = s_lvlmap + v_next2;
+                            c = c_next;
                         }
                     } else {
                         // SE, S, SW: the run that ends on a lane's line in the previous row; along the diagonals it moves one lane per
@@ -438,8 +452,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             constexpr int dx = decltype(dxc)::value;                         // glrlm.cpp:128-176
                             uint32_t S = 0;
                             for (uint32_t row = 0; row < h; row++) {
-                                const uint32_t m_next = *map_at;
-                                const uint32_t v_next2 = *ptr;
+                                const uint32_t c_next = mad24(map_read(map_at), nr, 1u);
+                                map_at = map_of((uint32_t)*ptr);
                                 ptr += col_stride;
                                 if (dx != 0) {
                                     if (w == 64u) {
@@ -450,8 +464,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                                 const bool cont = S - c < nr;
                                 if (!cont && S > nr) atomicAdd(&Pm[S], 1u);
                                 S = cont ? S + 1u : c;
-                                c = mad24(m_next, nr, 1u);
-                                map_at = s_lvlmap + v_next2;
+                                c = c_next;
                             }
                             if (S > nr) atomicAdd(&Pm[S], 1u);
                         };

@@ -6,7 +6,7 @@ FAM=${1:-28}
 for lib in $(ls $PWD/gpurun_scratch/libtex_*.so | sort -t_ -k2 -n) $PWD/nyxus_amd/libnyxhip.so; do
   export NYXHIP_LIB=$lib
   OUT=$PWD/gpurun_out/pmc_tex; rm -rf $OUT; mkdir -p $OUT
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d $OUT -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-extras --tile-path-tiles 0 --families $FAM > $OUT/log.txt 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-extras --tile-path-tiles 0 --families $FAM > $OUT/log.txt 2>&1
   python3 - <<PY
 import csv,glob
 from collections import defaultdict
