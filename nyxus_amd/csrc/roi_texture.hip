@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         s_stat[1] = (double)k;                               // Ngp = unique non-zero levels (ngtdm.cpp:150)
     }
     blk_sync<GS>();
-    const int Ng = (int)s_stat[0];
+    const int Ng = __builtin_amdgcn_readfirstlane((int)s_stat[0]);    // (wave-uniform numbers go to scalar registers at once: kept as the doubles
+                                                                      //  they were read as, two of them sat in scratch across the GLRLM section)
     if (A.L.lvf) {
         for (int i = tid; i < Ng; i += kBlock) {
             const double in2d = (double)(uint32_t)(s_lv[i] * s_lv[i]);       // (levels <= 4094: the unsigned product of glrlm.cpp and the double product of glszm.cpp are the same number)
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         blk_sync<GS>();
     }
     TSTAMP(1);
-    const int Nuniq = (int)s_stat[1];
+    const int Nuniq = __builtin_amdgcn_readfirstlane((int)s_stat[1]);
     const bool blank = vmin == vmax;
     int col = 0;
 
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_stat[2]), s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else if (nslot >= 4 && w > 64 && w <= 64u * kRlmChunks) {
                 // Boxes 65 .. 256 wide: the same one-wave-per-direction row scans over up to four chunks of 64 columns (lane =
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             if (c < nch && rv[c] != 0) count_at(rm[c], rl[c]);
                     }
                     wav_sync<GS>();
-                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + wave * 16, s_red + wave * 8, lane);
+                    glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_stat[2]), s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else {
             const int per = nslot >= 4 ? 4 : nslot;          // angles handled concurrently (one wave each)
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             atomicAdd(&P[((int)s_lvlmap[v] - 1) * Nr + (len - 1)], 1u);
                         }
                         wav_sync<GS>();
-                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)s_stat[2], s_f + ai * 16, s_red + wave * 8, lane);
+                        glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_stat[2]), s_f + ai * 16, s_red + wave * 8, lane);
                     }
                 }
             }
