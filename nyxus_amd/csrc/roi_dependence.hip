@@ -15,6 +15,8 @@
 // Matrix sums are formed lane-strided by one wave and combined in a fixed order (deterministic); the reference's
 // serial sums differ from these at the 1e-15 level.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "launch_util.h"
@@ -671,6 +673,7 @@ int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid)
         return orc;
     if (grid == 0)
         return 0;
+    if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] dependence launch: mask %u planes8 %u total %u work %u par %u\n", a.mask, a.L.planes8, a.L.total, a.L.work_bytes, a.L.par);
     if (a.sp.scratch)
         hipLaunchKernelGGL(roi_dependence_kernel<true>, dim3(grid), dim3(kBlk), 0, (hipStream_t)stream, a);
     else if (a.L.planes8)
