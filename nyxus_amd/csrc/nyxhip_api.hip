@@ -596,7 +596,7 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
         L.szm_small = L.ng_cap <= 33 ? 32u : 0u;
         L.szm_smalltab = (uint32_t)szm; szm += 4ull * L.ng_cap * L.szm_small;
         szm = (szm + 15) & ~15ull;
-        L.szm_label = (uint32_t)szm; if (L.side_cap > 256) szm += 4ull * L.dense_cap;   // (boxes up to 256 wide keep their labels in registers: kSzmChunks of roi_texture.hip)
+        L.szm_label = (uint32_t)szm; if (L.side_cap > (spill ? 512u : 256u)) szm += 4ull * L.dense_cap;   // (boxes up to 256 wide keep their labels in registers: kSzmChunks of roi_texture.hip)
         L.szm_ok = (off + szm <= cap) ? 1 : 0;
         if (!L.szm_ok) { why = "ROI too large for the LDS-resident GLSZM zone tables"; return NYXHIP_ERR_ROI_TOO_LARGE; }
         need = std::max(need, szm);
@@ -614,6 +614,20 @@ int make_tex_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_
     off = align16(off + (uint32_t)need);
     L.total = off;
     if (L.total > cap) { why = "ROI too large for the LDS-resident texture path"; return NYXHIP_ERR_ROI_TOO_LARGE; }
+    if (spill) {
+        // what a workspace launch keeps in LDS all the same: the atomics-heavy small state (64 lanes adding into a handful of
+        // addresses are 64 serialised L2 atomics in global memory)
+        uint32_t o = 0;
+        if ((mask & NYXHIP_FAM_NGTDM) && L.ng_cap <= 1024) {
+            L.ngt_rep = L.ng_cap <= 16 ? 8u : L.ng_cap <= 32 ? 4u : L.ng_cap <= 64 ? 2u : 1u;
+            L.ngt_stride = (((L.ng_cap + 2) * 12u + 16u + 7u) & ~7u) | 8u;
+            L.gs_ngt = o; L.gs_ngt_ok = 1; o = align16(o + L.ngt_rep * L.ngt_stride);
+        }
+        if ((mask & NYXHIP_FAM_GLRLM) && 16ull * L.ng_cap * kRlmLdsCols <= 32768) {
+            L.gs_rlm = o; L.gs_rlm_ok = 1; o = align16(o + 16u * L.ng_cap * kRlmLdsCols);
+        }
+        L.gs_lds_bytes = o;
+    }
     return NYXHIP_OK;
 }
 

@@ -146,6 +146,7 @@ constexpr int kGlrlmCols = 16 * 4 + 16;   // Feature2D GLRLM_SRE..GLRLM_LRHGLE x
 constexpr int kGlszmCols = 16;            // Feature2D GLSZM_SAE..GLSZM_LAHGLE (featureset.h:291-306)
 constexpr int kNgtdmCols = 5;             // Feature2D NGTDM_COARSENESS..NGTDM_STRENGTH (featureset.h:346-350)
 
+constexpr int kRlmLdsCols = 16;           // GLRLM run lengths counted in LDS by the global-workspace launches (TexLayout::gs_rlm)
 struct TexLayout {
     uint32_t out;       // double[n_cols]
     uint32_t red;       // double[kWaves*8]
@@ -163,6 +164,10 @@ struct TexLayout {
     uint32_t dense8;    // 1: the binned plane holds 8-bit levels (LDS launches with a grey depth <= 254)
     uint32_t ngt_rep, ngt_stride;   // ngt_rep (a power of two) replicas of the NGTDM accumulators, ngt_stride bytes apart, at ngt_own or at the start of `work`
     uint32_t ngt_p;     // offset inside `work` of the NGTDM feature pass's double arrays
+    // global-workspace launches: what stays in LDS all the same (small, atomics-heavy), offsets into the kernel's dynamic LDS
+    uint32_t gs_lds_bytes;
+    uint32_t gs_ngt, gs_ngt_ok;   // NGTDM accumulators (ngt_rep replicas, ngt_stride apart)
+    uint32_t gs_rlm, gs_rlm_ok;   // GLRLM: columns 1 .. kRlmLdsCols of the four matrices, [4][ng_cap][kRlmLdsCols] u32
     uint32_t ngt_own;   // NGTDM accumulators (u64 S[ng_cap+2], u32 N[ng_cap+2]) outside `work`, 0 = none: lets the NGTDM stencil run on the
                         // three waves that would otherwise wait for the one-wave GLSZM row sweep
 };

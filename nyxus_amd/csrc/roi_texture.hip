@@ -228,13 +228,17 @@ __device__ __forceinline__ void glrlm_features_wave(const uint32_t* P, int Ng, i
 // CU the 80-register build (a few spills) beats the 106-register one by 20-25 %.
 // D8: the binned plane holds 8-bit levels (grey depth <= 254, LDS launches): with it the benchmark's carve-out fits eight times
 // into a CU (the 64-register build).
-constexpr int kRlmChunks = 4;      // GLRLM row scans in registers: boxes up to 64 * kRlmChunks wide
-constexpr int kSzmChunks = 4;      // GLSZM row sweep in registers: boxes up to 64 * kSzmChunks wide (TexLayout: owner labels in LDS only beyond that)
+// Row scans / sweeps in registers take boxes up to 64 * chunks wide: four chunks in the LDS builds (a wider box rarely fits LDS), eight in
+// the global-workspace build -- the 300..400-px boxes of a heavy-tailed batch fell to the per-pixel walks there, dependent round trips
+// to global memory: 17.5 ms for one 361 x 341 ROI (GLRLM 6.9, GLSZM sweep 4.5, NGTDM stencil 2.9 ms).
+template <bool GS> struct TexChunks { static constexpr int value = GS ? 8 : 4; };
 
 template <bool GS, int OCC, bool D8 = false>
 __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int kRlmChunks = TexChunks<GS>::value;      // GLRLM row scans in registers: boxes up to 64 * kRlmChunks wide
+    constexpr int kSzmChunks = TexChunks<GS>::value;      // GLSZM row sweep (and the NGTDM stencil): boxes up to 64 * kSzmChunks wide (TexLayout: owner labels only beyond that)
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: lets the line / row bookkeeping run on the scalar unit
     uint64_t roi;
@@ -493,8 +497,21 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
 #pragma unroll
                     for (int c = 0; c < kRlmChunks; c++) inc[c] = (uint32_t)lane + 64u * c < w;
                     uint32_t* const Pm = P - (Nr + 1);
-                    auto count_run = [=](uint32_t rv, uint32_t rl) { atomicAdd(&Pm[mad24((uint32_t)s_lvlmap[rv], (uint32_t)Nr, rl)], 1u); };
-                    auto count_at = [=](uint32_t rm, uint32_t rl) { atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u); };
+                    // Workspace build: the matrix lives in global memory, where 64 lanes adding into the handful of (level, short run)
+                    // cells are 64 serialised L2 atomics (4.1 ms of a 361 x 341 ROI's GLRLM).  Runs of up to kRlmLdsCols pixels -- nearly
+                    // all of them on a textured image -- are counted in an LDS copy of those columns and added to the matrix before
+                    // the feature pass.
+                    const bool lds_cols = GS && A.L.gs_rlm_ok != 0;
+                    uint32_t* const Lp = (uint32_t*)(lds_raw + A.L.gs_rlm) + (uint32_t)wave * (uint32_t)Ng * kRlmLdsCols;   // cell (m, rl) = Lp[(m - 1) * kRlmLdsCols + rl - 1]
+                    if (lds_cols) {
+                        for (uint32_t i = lane; i < (uint32_t)Ng * kRlmLdsCols; i += 64) Lp[i] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    }
+                    auto count_at = [=](uint32_t rm, uint32_t rl) {
+                        if (lds_cols && rl <= (uint32_t)kRlmLdsCols) atomicAdd(&Lp[mad24(rm, (uint32_t)kRlmLdsCols, rl) - (uint32_t)(kRlmLdsCols + 1)], 1u);
+                        else atomicAdd(&Pm[mad24(rm, (uint32_t)Nr, rl)], 1u);
+                    };
+                    auto count_run = [=](uint32_t rv, uint32_t rl) { count_at((uint32_t)s_lvlmap[rv], rl); };
                     auto load = [=](uint32_t row, int c, bool in) -> uint32_t {
                         return (in && row < h) ? (uint32_t)s_dense[row * w + 64u * (uint32_t)c + (uint32_t)lane] : 0u;
                     };
@@ -586,6 +603,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                             if (c < nch && rv[c] != 0) count_at(rm[c], rl[c]);
                     }
                     wav_sync<GS>();
+                    if (lds_cols) {                              // the short runs join the matrix (this wave's own: plain adds)
+                        for (uint32_t i = lane; i < (uint32_t)Ng * kRlmLdsCols; i += 64) {
+                            const uint32_t m0 = i / kRlmLdsCols, j = i - m0 * kRlmLdsCols, cnt = Lp[i];
+                            if (cnt != 0 && j < (uint32_t)Nr) P[m0 * (uint32_t)Nr + j] += cnt;
+                        }
+                        wav_sync<GS>();
+                    }
                     glrlm_features_wave<GS>(P, Ng, Nr, s_lv, s_lvf, P + Ng * Nr, P + Ng * Nr + Ng, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_stat[2]), s_f + wave * 16, s_red + wave * 8, lane);
                 }
             } else {
@@ -634,7 +658,9 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
     // IBSI: I = 0..max, row = level (ngtdm.cpp:56-61, :163-166); else rows = unique levels
     const int NgT = greyInfo == 0 ? (Nuniq ? Ng + 1 : 0) : Nuniq;
     const bool ngt_own = !GS && A.L.ngt_own != 0;
-    unsigned long long* const s_S = (unsigned long long*)(ngt_own ? lds + A.L.ngt_own : s_work);   // [NgT] sum |i - mean| in units of 1/840
+    // (workspace build: the accumulators sit in LDS all the same when they fit -- two atomics per pixel on Ng addresses of global
+    //  memory were 1.6 ms of a 361 x 341 ROI)
+    unsigned long long* const s_S = (unsigned long long*)((GS && A.L.gs_ngt_ok) ? lds_raw + A.L.gs_ngt : ngt_own ? lds + A.L.ngt_own : s_work);   // [NgT] sum |i - mean| in units of 1/840
     uint32_t* const s_N = (uint32_t*)(s_S + A.L.ng_cap + 2);                                           // [NgT]
     // Replicas of the accumulators (LDS launches with few levels): a lane adds into replica lane % R, so that the 64 lanes of an atomic
     // spread over R times as many addresses -- with eight levels every atomic of the stencil had eight lanes per address, and LDS
@@ -1217,7 +1243,7 @@ int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid)
         return 0;
     if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] texture launch: dense8 %u ng_cap %u total %u work %u ngt_rep %u mask %u\n", a.L.dense8, a.L.ng_cap, a.L.total, a.L.work_bytes, a.L.ngt_rep, a.mask);
     if (a.sp.scratch)
-        hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((roi_texture_kernel<true, 2>), dim3(grid), dim3(kBlock), a.L.gs_lds_bytes, (hipStream_t)stream, a);
     // (LDS is handed out in 1280-byte granules: k workgroups share a CU when k rounded-up carve-outs fit)
     else if (a.L.dense8 && tex_max_occ() >= 8 && 8ull * (((size_t)a.L.total + 1279) / 1280 * 1280) <= roi_features_max_lds())
         hipLaunchKernelGGL((roi_texture_kernel<false, 8, true>), dim3(grid), dim3(kBlock), a.L.total, (hipStream_t)stream, a);
