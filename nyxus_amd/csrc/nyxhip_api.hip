@@ -518,7 +518,7 @@ int make_shape_layout(uint32_t mask, const nyxhip_settings* s, uint32_t max_area
         L.red = off; off = align16(off + 8u * kWaves * NYXHIP_MAX_GABOR_FILTERS);
         L.area_cap = max_area ? max_area : 1;
         L.side_cap = max_side ? max_side : 1;
-        const uint64_t words = (uint64_t)L.area_cap + 38ull * L.side_cap + 345;
+        const uint64_t words = (uint64_t)L.area_cap + 42ull * L.side_cap + 405;   // (w + 27) (h + 15): tiles + padding, pitch made an odd number of 16-byte units
         if (4ull * words + off > cap) { why = "ROI bounding box too large for the LDS-resident Gabor plane"; return NYXHIP_ERR_ROI_TOO_LARGE; }
         L.plane = off; off = align16(off + 4u * (uint32_t)words);
         L.redo = off; off = align16(off + 4u * (512u + 4u));     // kGaborRedoCap of roi_shape.hip

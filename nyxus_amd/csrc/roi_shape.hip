@@ -253,7 +253,10 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
     // tap (j, i) of output (a, b) reads image (a + 8 - i, b + 8 - j): 7 padding rows above, 8 below, 8 padding columns
     // left, >= 8 right; padded column = image column + 8, padded row = image row + 7
     const uint32_t tpr = (w + T - 1) / T;             // tiles per row
-    const uint32_t pitch = tpr * T + 16;              // multiple of 4 words
+    // (an ODD number of 16-byte units: a wave's 16-byte window reads then fall on different banks for lanes one row apart --
+    //  with an even number the eight tiles of a row and those of the next row hit the same eight units of the 256-byte bank
+    //  period, and the counters showed the LDS pipe 96 % busy at 28 cycles per read instead of 8)
+    const uint32_t pitch = (tpr * T + 16) | 4u;       // multiple of 4 words
     const uint32_t words = pitch * (h + 15);
     {
         uint4* p4 = (uint4*)s_plane;
