@@ -1170,29 +1170,40 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
             if (lane == 0) s_red[wave * 8] = (double)nvc_part;
             blk_sync<GS>();
             const double Nvc = ((s_red[0] + s_red[8]) + s_red[16]) + s_red[24];
-            for (int i = tid; i < NgT; i += kBlock) {
-                s_P[i] = (double)s_N[i] / Nvc;
-                s_Sd[i] = (double)s_S[i] / 840.0;
+            {   // (quotients through reciprocals: every NGTDM value is tolerance-class, and this block runs on all four waves)
+                const double inv_nvc = frcp(Nvc);
+                for (int i = tid; i < NgT; i += kBlock) {
+                    s_P[i] = (double)s_N[i] * inv_nvc;
+                    s_Sd[i] = (double)s_S[i] * (1.0 / 840.0);
+                }
             }
             blk_sync<GS>();
             if (wave == solo) {
                 auto Iof = [=](int i) -> double { return greyInfo == 0 ? (double)i : (double)s_lv[i]; };
-                double ps = 0, ssum = 0;
-                for (int i = lane; i < NgT; i += 64) { ps += s_P[i] * s_Sd[i]; ssum += s_Sd[i]; }
-                ps = wave_sum(ps); ssum = wave_sum(ssum);
-                double c_sum = 0, b_sum = 0, x_sum = 0, s_sum = 0;
+                // (one wave: the cell's (i, j) from a float reciprocal while Ng^2 stays small, the quotient of the complexity term by a
+                //  reciprocal, the six totals through one transposed reduction)
+                double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // ps, ssum, contrast, busyness, complexity, strength
+                for (int i = lane; i < NgT; i += 64) { t8[0] += s_P[i] * s_Sd[i]; t8[1] += s_Sd[i]; }
+                const bool small_ng = NgT <= 256;
+                const float inv_ng = 1.0f / (float)NgT;
                 for (int e = lane; e < NgT * NgT; e += 64) {
-                    int i = e / NgT, j = e - i * NgT;
+                    int i = small_ng ? (int)(((float)e + 0.5f) * inv_ng) : e / NgT;   // (e < 2^16: the product is off by < 1e-2 from (e + 0.5) / Ng, never across an integer)
+                    const int j = e - i * NgT;
                     double pi_ = s_P[i], pj = s_P[j], iv = Iof(i), jv = Iof(j);
                     double d = iv - jv;
-                    c_sum += pi_ * pj * d * d;                                  // calc_Contrast :245-247
+                    t8[2] += pi_ * pj * d * d;                                  // calc_Contrast :245-247
                     if (pi_ != 0 && pj != 0) {
-                        b_sum += fabs(pi_ * iv - pj * jv);                       // calc_Busyness :280-283
-                        x_sum += fabs(d) * (pi_ * s_Sd[i] + pj * s_Sd[j]) / (pi_ + pj); // calc_Complexity :305
-                        s_sum += (pi_ + pj) * d * d;                             // calc_Strength :326
+                        t8[3] += fabs(pi_ * iv - pj * jv);                       // calc_Busyness :280-283
+                        t8[4] += fdiv(fabs(d) * (pi_ * s_Sd[i] + pj * s_Sd[j]), pi_ + pj); // calc_Complexity :305
+                        t8[5] += (pi_ + pj) * d * d;                             // calc_Strength :326
                     }
                 }
-                c_sum = wave_sum(c_sum); b_sum = wave_sum(b_sum); x_sum = wave_sum(x_sum); s_sum = wave_sum(s_sum);
+                {
+                    const double tt = wave_transpose_sum8(t8, lane);             // lane 8 k holds total k
+                    if ((lane & 7) == 0) s_red[lane >> 3] = tt;
+                }
+                wav_sync<GS>();
+                const double ps = s_red[0], ssum = s_red[1], c_sum = s_red[2], b_sum = s_red[3], x_sum = s_red[4], s_sum = s_red[5];
                 if (lane == 0) {
                     int Ngp = Nuniq;
                     int Ngp_p2 = Ngp > 1 ? Ngp * (Ngp - 1) : Ngp;
