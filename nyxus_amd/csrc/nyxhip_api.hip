@@ -1697,9 +1697,31 @@ static int res_reserve(nyxhip_ctx* ctx, size_t rows, size_t n_cols, hipStream_t 
     return NYXHIP_OK;
 }
 
-// The whole stack in chunks.  label_limit: v1's max_label (validated only).
+// Pins a caller's host arrays for the duration of a call (hipHostRegister): a pinned source makes the chunk copies true DMA
+// transfers that overlap the kernels (50-57 GB/s measured); left pageable, an asynchronous copy goes through the runtime's staging
+// path at 8-20 GB/s.  The runtime keeps the pinning cached across calls on the same buffer (first call ~22 us/MB, later ones
+// ~0.01 ms).  Only arrays of at least kPinMinBytes are pinned: below that the staging path costs nothing measurable, and a small
+// array lives in the allocator's heap, sharing its first and last page with unrelated objects -- registering and unregistering such
+// pages call after call ended one full run of the GPU test suite in six with "Memory access fault by GPU ... on address <a page
+// of the host heap>" inside a later call's copy (never with the tile tests alone; large arrays are mapped regions of their own).
+// One guard per ARRAY: the sharded entry pins the whole stack once, before its threads copy their shares -- per-share
+// registrations would overlap in the pages that hold a share boundary and be released at different times.
+struct HostPin {
+    void* p[2] = {nullptr, nullptr};
+    static constexpr size_t kPinMinBytes = (size_t)8 << 20;
+    void pin(int k, const void* ptr, size_t bytes)
+    {
+        static const bool no_pin = [] { const char* e = getenv("NYXHIP_NO_PIN"); return e && *e && *e != '0'; }();   // A/B knob
+        if (no_pin || bytes < kPinMinBytes || !ptr) return;
+        if (hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p[k] = (void*)ptr; else (void)hipGetLastError();
+    }
+    ~HostPin() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
+};
+
+// The whole stack in chunks.  label_limit: v1's max_label (validated only).  prepinned: the caller has pinned the arrays.
 static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint32_t* out_labels, uint32_t* out_tile_index,
-                     uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit, uint32_t tile_index_base = 0)
+                     uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit, uint32_t tile_index_base = 0,
+                     bool prepinned = false)
 {
     if (int vrc = tiles_validate(ctx, t, family_mask, s, n_roi_out)) return vrc;
     const int n_cols = nyxhip_n_columns(family_mask, s);
@@ -1793,17 +1815,10 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
         return NYXHIP_OK;
     };
-    // Pin the caller's arrays for the call: a pinned source makes the chunk copies true DMA transfers that overlap the kernels
-    // (50-57 GB/s measured); left pageable, an asynchronous copy goes through the runtime's staging path at 8-20 GB/s.  The
-    // runtime keeps the pinning cached across calls on the same buffer (first call ~22 us/MB, later ones ~0.01 ms).
-    struct Pin {
-        void* p[2] = {nullptr, nullptr};
-        ~Pin() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
-    } pin;
-    {
-        const size_t bi = (size_t)t->n_tiles * tile_px * t->inten_dtype, bl = (size_t)t->n_tiles * tile_px * t->label_dtype;
-        if (hipHostRegister((void*)t->inten, bi, hipHostRegisterDefault) == hipSuccess) pin.p[0] = (void*)t->inten; else (void)hipGetLastError();
-        if (hipHostRegister((void*)t->label, bl, hipHostRegisterDefault) == hipSuccess) pin.p[1] = (void*)t->label; else (void)hipGetLastError();
+    HostPin pin;                                        // (see HostPin: arrays of at least 8 MiB, unless the caller pinned the stack)
+    if (!prepinned) {
+        pin.pin(0, t->inten, (size_t)t->n_tiles * tile_px * t->inten_dtype);
+        pin.pin(1, t->label, (size_t)t->n_tiles * tile_px * t->label_dtype);
     }
     // every exit below -- the error returns included -- first waits for the copies and kernels still in flight: the pin guard above
     // unregisters the caller's arrays, and the caller may free them the moment this function returns
@@ -1914,6 +1929,11 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
     for (int g = 0; g < G; g++) lo[g + 1] = lo[g] + q + ((uint64_t)g < r ? 1 : 0);
     const uint64_t tile_px = (uint64_t)tiles->width * tiles->height;
     for (int g = 0; g < n_ctx; g++) ctxs[g]->res_rows = 0;
+    HostPin pin;                                        // the whole stack, once: released after every share's copies have drained (join below)
+    if (hipSetDevice(c0->device) == hipSuccess) {
+        pin.pin(0, tiles->inten, (size_t)tiles->n_tiles * tile_px * tiles->inten_dtype);
+        pin.pin(1, tiles->label, (size_t)tiles->n_tiles * tile_px * tiles->label_dtype);
+    } else (void)hipGetLastError();
     std::vector<std::thread> th;
     for (int g = 0; g < G; g++)
         th.emplace_back([&, g]() {
@@ -1924,7 +1944,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
             if (tiles->slide_min) part.slide_min = tiles->slide_min + lo[g];
             if (tiles->slide_max) part.slide_max = tiles->slide_max + lo[g];
             if (part.n_tiles == 0) { rcs[g] = 0; return; }
-            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu, (uint32_t)lo[g]);   // tile indices of the whole stack
+            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu, (uint32_t)lo[g], true);   // tile indices of the whole stack
         });
     for (auto& t : th) t.join();
     for (int g = 0; g < G; g++)

@@ -20,6 +20,7 @@
 //
 // Built with -ffp-contract=off (device_math.h).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include "device_math.h"
 #include "roi_kernel.h"
@@ -193,8 +194,12 @@ typedef const double __attribute__((address_space(4))) * bank_ptr_t;
 // bank is L1-normalised (sum |w| = 1, gabor.cpp:427-448), so |d re|, |d im| <= 2 gamma_257 a_max = 1.15e-13 a_max -- and a pixel
 // whose ratio lies farther than that bound from the threshold is decided as the reference decides it.  The others (none on
 // ordinary data, thousands on flat fields whose common energy sits on the threshold) go to a list and are recomputed with the
-// reference's separate multiplies and adds in its (j, i) order.  The low-pass filter, whose strict minimum and maximum the
-// baseline hangs on, always runs the reference's arithmetic (the default bank's is a box filter: exact integers).
+// reference's separate multiplies and adds in its (j, i) order.  The low-pass filter, whose strict minimum and maximum (and the
+// number of pixels AT the minimum) the baseline hangs on, runs fused too in the 256-thread kernel: the true extrema are found
+// among candidates -- pixels whose fused energy lies within the bound of a sampled lower bound of the maximum / upper bound of the
+// minimum -- which are recomputed with the reference's arithmetic; a list overflow (ties on a flat field) runs the filter again
+// unfused.  (A filter whose taps are one real constant is a box filter: exact integer sums, nothing to check.  The one-wave
+// kernel of small ROIs keeps the unfused low-pass: two recomputation calls cost more than it saves there.)
 constexpr int kGaborRedoCap = 512;
 // The response of one pixel with the reference's arithmetic: separate multiply and add, taps in (j, i) order (gabor.cpp:333-390; a
 // zero tap adds +-0, which leaves a sum that started at +0 as it is: the same bits as the scans that skip zero rows).  Not inlined:
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
     uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
 
     auto exact_energy = [&](uint32_t a, uint32_t b, const bank_ptr_t G) -> double { return gabor_exact_energy(s_plane, pitch, a, b, G); };
+    bool lp_overflow = false;                          // MODE 2: the fused low-pass pass found more candidates than its list holds
     const double amax = (double)A.max_inten[roi];
 
     // One filter over the whole box.  FUSE is a compile-time fact of the copy (the low-pass filter runs the copy with the
@@ -290,8 +296,26 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
         const double box_c = box ? G[0] : 0.0;
         const double thr_max = A.gabor_thr * maxval, thr_slack = __builtin_fma(2.5e-13, amax, 1e-15 * thr_max);
         uint32_t sc = 0;
+        // MODE 2, low-pass filter with fused taps: its strict maximum and minimum (and the number of pixels AT the minimum) carry
+        // every feature, so they are the reference's -- found among CANDIDATES.  One pixel per thread, spread over the box, is
+        // evaluated with the reference's arithmetic first: the largest of these energies, Bs, is a lower bound of the true maximum
+        // (the smallest, bs, an upper bound of the true minimum), so the pixel that attains the true maximum has a fused energy of at
+        // least Bs minus the error bound, and only such pixels go to the list (on a continuous field ~ area / 256 of them; a flat
+        // field, where thousands tie, overflows the list and the filter runs again with the reference's arithmetic throughout).
+        double Bs = 0.0, bs = 0.0;
+        const bool lp_cand = MODE == 2 && fuse && f == 0 && !box;     // (a box filter's sums are exact integers: nothing to check)
         if (MODE == 2 && fuse) {
             if (tid == 0) s_redo[0] = 0;
+            if (lp_cand) {
+                if (wave == 0) {                          // (64 samples: one wave's worth of the reference's arithmetic)
+                    const uint32_t p = (uint32_t)(((unsigned long long)(uint32_t)lane * area) / 64u), pb = p / w, pa = p - pb * w;
+                    const double es = exact_energy(pa, pb, G);
+                    const double wmx = wave_max_d(es), wmn = wave_min_d(es);
+                    if (lane == 0) { s_red[0] = wmx; s_red[1] = wmn; }
+                }
+                __syncthreads();
+                Bs = s_red[0]; bs = s_red[1];
+            }
             __syncthreads();
         }
         for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
@@ -369,7 +393,14 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                 if (a0 + t >= w)
                     continue;
                 const double e = sqrt(re[t] * re[t] + im[t] * im[t]);   // :505
-                if (f == 0) {
+                if (lp_cand) {
+                    // (the same bound as below, against Bs and bs instead of the threshold)
+                    const double m0 = __builtin_fma(1e-15, e, 2.5e-13 * amax);
+                    if (e >= Bs - __builtin_fma(1e-15, Bs, m0) || e <= bs + __builtin_fma(1e-15, bs, m0)) {
+                        const uint32_t k = atomicAdd(&s_redo[0], 1u);
+                        if (k < (uint32_t)kGaborRedoCap) s_redo[1 + k] = b * w + a0 + (uint32_t)t;
+                    }
+                } else if (f == 0) {
                     tmax = e > tmax ? e : tmax;
                     if (e < tmin) { tmin = e; n_min = 1; }
                     else if (e == tmin) n_min++;
@@ -389,7 +420,22 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                     sc++;
             }
         }
-        if (MODE == 2 && fuse) {                           // the pixels too close to the threshold, with the reference's arithmetic
+        if (lp_cand) {                                    // the candidates for maximum / minimum, with the reference's arithmetic
+            __syncthreads();
+            const uint32_t nr = s_redo[0];
+            lp_overflow = nr > (uint32_t)kGaborRedoCap;
+            if (!lp_overflow)
+                for (uint32_t k = tid; k < nr; k += kBlk) {
+                    const uint32_t p = s_redo[1 + k], b = p / w, a = p - b * w;
+                    const double e = exact_energy(a, b, G);
+                    tmax = e > tmax ? e : tmax;
+                    if (e < tmin) { tmin = e; n_min = 1; }
+                    else if (e == tmin) n_min++;
+                }
+            __syncthreads();
+            if (lp_overflow) return true;                 // (block-uniform) the caller runs the filter again, unfused
+        } else
+        if (MODE == 2 && fuse && f != 0) {                 // the pixels too close to the threshold, with the reference's arithmetic
             __syncthreads();
             const uint32_t nr = s_redo[0];
             if (nr > (uint32_t)kGaborRedoCap) {
@@ -439,7 +485,14 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
         bool go;
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
         else if constexpr (MODE == 1) go = run_filter(f, std::true_type{});
-        else go = f == 0 ? run_filter(f, std::false_type{}) : run_filter(f, std::true_type{});
+        else if (f == 0 && NW == 1) go = run_filter(0, std::false_type{});   // one-wave launches (small ROIs): two recomputation calls cost more than the unfused low-pass
+        else {
+            go = run_filter(f, std::true_type{});
+            if (f == 0 && lp_overflow) {                  // too many candidates (ties): the low-pass filter again, the reference's arithmetic throughout
+                tmax = -1.0; tmin = 1.7976931348623157e308; n_min = 0;
+                go = run_filter(0, std::false_type{});
+            }
+        }
         if (!go) return;
     }
     const double baseline = (double)n_min;
@@ -644,6 +697,7 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             zero_halves += __builtin_popcount(im) + __builtin_popcount(both);
         }
         const bool zr = 25 * zero_halves >= 32 * (a.gabor_nf + 1);
+        if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] gabor launch: nf %d box_mask %x zero_halves %d zr %d mode %d total %u small %d\n", a.gabor_nf, a.gabor_box_mask, zero_halves, (int)zr, mode, a.L.total, (int)small);
 #define NYX_GABOR_LAUNCH(M, Z)                                                                                                         \
         do {                                                                                                                           \
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, M, Z>), dim3(grid), dim3(64), a.L.total, st, a);               \
