@@ -614,6 +614,35 @@ def test_texture_row_scans_at_edge_widths(hip_ctx, gd):
         assert not parity.compare_tables(G, po.ref_featurize(b, TEX, s, 2), _lib.column_names(TEX, s))
 
 
+@pytest.mark.parametrize("gd", [3, 8, 40])
+def test_texture_families_on_workspace_rois_wider_than_four_chunks(hip_ctx, gd):
+    """ROIs beyond LDS run from the global workspace, whose build keeps the register sweeps for boxes up to 512 wide (eight
+    64-column chunks), counts runs of up to 16 pixels in an LDS copy of the matrix columns and keeps the NGTDM accumulators in
+    LDS: widths on both sides of 256 and 512, few grey levels, whole rows of one level (runs longer than the LDS columns and
+    longer than four chunks), a level that appears once."""
+    rng = np.random.default_rng(31)
+    rois = []
+    for (w, h) in [(300, 280), (257, 260), (512, 140), (513, 130), (448, 150)]:
+        m = rng.random((h, w)) > 0.05
+        m[0, 0] = m[0, w - 1] = m[h - 1, 0] = m[h - 1, w - 1] = True
+        ys, xs = np.nonzero(m)
+        v = rng.integers(1, 5, len(xs)) * 900
+        v[ys == 7] = 2700                                        # a run across every chunk of the row
+        v[(ys == 9) & (xs >= 250) & (xs < 270)] = 1800           # 20 pixels: beyond the LDS columns, across the 256 boundary
+        v[(ys == 11) & (xs < 17)] = 900                          # 17 pixels at the left edge
+        v[(ys % 50 == 20) & (xs % 64 == 63)] = 3600              # single pixels on chunk ends
+        v[len(v) // 2] = 4000                                    # a level of its own
+        rois.append(dict(x=xs, y=ys, inten=v.astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    s = _abi.default_settings(gd)
+    G = hip_ctx.featurize_host(b, TEX, s)
+    assert any(r["workspace"] for r in hip_ctx.launch_report())
+    assert not parity.compare_tables(G, po.oracle_featurize(b, TEX, s), _lib.column_names(TEX, s))
+    for fam in (_abi.FAM_GLRLM, _abi.FAM_NGTDM):                 # alone: other LDS offsets of the hybrid state
+        G1 = hip_ctx.featurize_host(b, fam, s)
+        assert not parity.compare_tables(G1, po.oracle_featurize(b, fam, s), _lib.column_names(fam, s))
+
+
 @pytest.mark.parametrize("gd", [3, 8])
 def test_texture_row_scans_on_boxes_wider_than_a_wave(hip_ctx, gd):
     """Boxes 65 .. 128 wide take the two-chunk register sweeps (GLSZM: labels and runs crossing column 63 | 64 through
