@@ -736,7 +736,6 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
             grp &= grp - 1ull;
             const uint32_t cnt = act ? pcell[r * S] : 0u;
             asm_i = mad24(cnt, cnt, asm_i);                          // f_asm :555 / f_energy :927-928
-            acor_i = mad24(cnt, mul24(l1, (uint32_t)(r + 1)), acor_i);   // f_GLCM_ACOR :961 (integer-exact): (r + 1) * (c + 1)
             cmax = cnt > cmax ? cnt : cmax;                          // f_GLCM_JMAX :1178-1179
             double et = Tent[cnt < 15u ? cnt : 15u];
             if (cnt >= 15u) { const double p = (double)cnt * inv_sum_p; et = p * (double)fast_log2f(p + 0.000000001); }
@@ -752,7 +751,13 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
         const double tot = wave_transpose_sum4(t4);                  // lane L holds the total of slot (L >> 4) & 3
         if ((lane & 15) == 0) sm[1 + (lane >> 4)] = tot;             // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
     }
-    acor_i = wave_sum_t<uint32_t>(acor_i);
+    // f_GLCM_ACOR :961 = sum (r + 1)(c + 1) cnt, integer-exact, from the two families of diagonals instead of two multiplies per
+    // cell: I J = ((I + J)^2 - (I - J)^2) / 4, so 4 ACOR = sum_k (k + 2)^2 n_{x+y}(k) - sum_d d^2 n_{x-y}(d) (the second sum is the
+    // contrast numerator; sum_p < 65536 and k + 2 <= 130 keep everything inside 32 bits)
+    {
+        const uint32_t k0 = (uint32_t)lane + 2u, k1 = (uint32_t)lane + 66u;
+        acor_i = (wave_sum_t<uint32_t>(mad24(pxpy_c[1], mul24(k1, k1), mul24(pxpy_c[0], mul24(k0, k0)))) - con_i) >> 2;
+    }
     asm_i = wave_sum_t<uint32_t>(asm_i);
     cmax = wave_max_u32(cmax);
 
