@@ -309,10 +309,17 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
         } else
             lvl = greyInfo < 0 ? bin_radiomix(v, vmin, vmax, -greyInfo) : v;
         nz_orig += v != 0;
-        if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
-        if (px < w && py < h) {
-            s_dense[__umul24(py, w) + px] = (dense_t)lvl;
-            if (lvl != 0) { s_lvlmap[lvl] = 1; nz_bin++; }
+        if (greyInfo > 0) {                             // (matlab binning: 1 <= level <= grey depth <= Lcap, and every pixel of the box counts as non-zero)
+            if (px < w && py < h) {
+                s_dense[__umul24(py, w) + px] = (dense_t)lvl;
+                s_lvlmap[lvl] = 1;
+            }
+        } else {
+            if (lvl > Lcap) { lvl_over = 1; lvl = Lcap; }
+            if (px < w && py < h) {
+                s_dense[__umul24(py, w) + px] = (dense_t)lvl;
+                if (lvl != 0) { s_lvlmap[lvl] = 1; nz_bin++; }
+            }
         }
     });
     nz_orig = wave_sum_t<uint32_t>(nz_orig);
@@ -456,8 +463,10 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                         auto scan = [&](auto dxc) {
                             constexpr int dx = decltype(dxc)::value;                         // glrlm.cpp:128-176
                             uint32_t S = 0;
-                            for (uint32_t row = 0; row < h; row++) {
-                                const uint32_t c_next = mad24(map_read(map_at), nr, 1u);
+                            // one row: the pixel's cell `cur`, the cell of the row after it into `nxt` (rows in pairs below: the two
+                            // change roles instead of a copy per row)
+                            auto step = [&](const uint32_t cur, uint32_t& nxt) {
+                                nxt = mad24(map_read(map_at), nr, 1u);
                                 map_at = map_of((uint32_t)*ptr);
                                 ptr += col_stride;
                                 if (dx != 0) {
@@ -466,11 +475,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                                     }
                                     S = dx == 1 ? wave_ror1(S) : wave_rol1(S);
                                 }
-                                const bool cont = S - c < nr;
+                                const bool cont = S - cur < nr;
                                 if (!cont && S > nr) atomicAdd(&Pm[S], 1u);
-                                S = cont ? S + 1u : c;
-                                c = c_next;
-                            }
+                                S = cont ? S + 1u : cur;
+                            };
+                            uint32_t c2 = 0, row = 0;
+                            for (; row + 1u < h; row += 2u) { step(c, c2); step(c2, c); }
+                            if (row < h) step(c, c2);
                             if (S > nr) atomicAdd(&Pm[S], 1u);
                         };
                         if (wave == 1) scan(std::integral_constant<int, 1>());
