@@ -417,12 +417,17 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     uint32_t* const P = s_mat + (uint32_t)wave * slot_words;
                     uint32_t* const Pm = P - (Nr + 1);
                     const uint32_t nr = (uint32_t)Nr;
-                    const bool in_col = (uint32_t)lane < w;
+                    // The E direction runs the same machine TRANSPOSED: its lanes are rows and its steps are columns, so the state never
+                    // moves between lanes (the ballot formulation -- run starts and ends read off a mask -- cost 16 instructions per row
+                    // against 10; byte reads a row pitch apart share banks only for pitches of 32 and 64, 8 and 16 lanes per bank).
+                    const bool trans = wave == 0;
+                    const bool in_col = (uint32_t)lane < (trans ? h : w);
+                    const uint32_t n_steps = trans ? w : h;
                     // Two loads ahead: the level of row + 2 and the level-map entry of row + 1.  (The reads of the last two trips land
                     // up to two rows behind the plane -- in the regions that follow it, never used.  What a trip carries over is made
                     // of 32-bit results, the map address and the cell c, not of the loaded bytes: no re-extension per trip.)
-                    const dense_t* ptr = in_col ? s_dense + lane : (const dense_t*)s_lvlmap;                  // (s_lvlmap[0] == 0)
-                    const uint32_t col_stride = in_col ? w : 0u;
+                    const dense_t* ptr = in_col ? s_dense + (trans ? mul24((uint32_t)lane, w) : (uint32_t)lane) : (const dense_t*)s_lvlmap;   // (s_lvlmap[0] == 0)
+                    const uint32_t col_stride = in_col ? (trans ? 1u : w) : 0u;
                     // (LDS launches form the map address as a 32-bit LDS address right behind the byte load and pin it there: sunk
                     //  into the block of its use, the byte costs a re-extension per trip)
                     typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
@@ -440,24 +445,8 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                     ptr += col_stride;
                     map_h map_at = map_of((uint32_t)*ptr);                                                    // row 1
                     ptr += col_stride;
-                    if (wave == 0) {
-                        // E: a run starts on a lane whose level differs from its left neighbour's; the mask of such lanes also says where
-                        // it ends.
-                        for (uint32_t row = 0; row < h; row++) {
-                            // (both loads are turned into their 32-bit results right here, in the block that issues them: carried
-                            //  across the branch below as bytes they cost a re-extension each per trip)
-                            const uint32_t c_next = mad24(map_read(map_at), nr, 1u);
-                            map_at = map_of((uint32_t)*ptr);
-                            ptr += col_stride;
-                            const bool differs = lane_minus1(c, 0u) != c;             // (lane 0 compares with the 0 fill)
-                            const unsigned long long nz = __builtin_amdgcn_ballot_w64(c != 1u);
-                            const unsigned long long ends = (__builtin_amdgcn_ballot_w64(differs) >> 1) | ~nz | (1ull << 63);   // a run ends before the next lane that differs from its left neighbour
-                            if (c != 1u && differs)
-                                atomicAdd(&Pm[c + (uint32_t)__builtin_ctzll(ends >> lane)], 1u);
-                            c = c_next;
-                        }
-                    } else {
-                        // SE, S, SW: the run that ends on a lane's line in the previous row; along the diagonals it moves one lane per
+                    {
+                        // E (transposed), SE, S, SW: the run that ends on a lane's line in the previous step; along the diagonals it moves one lane per
                         // row (a rotation: what leaves the box lands on a lane that reads level 0 and is written there; a 64-wide box
                         // has no such lane, its leaving run is written before the move).
                         auto scan = [&](auto dxc) {
@@ -480,13 +469,13 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                                 S = cont ? S + 1u : cur;
                             };
                             uint32_t c2 = 0, row = 0;
-                            for (; row + 1u < h; row += 2u) { step(c, c2); step(c2, c); }
-                            if (row < h) step(c, c2);
+                            for (; row + 1u < n_steps; row += 2u) { step(c, c2); step(c2, c); }
+                            if (row < n_steps) step(c, c2);
                             if (S > nr) atomicAdd(&Pm[S], 1u);
                         };
                         if (wave == 1) scan(std::integral_constant<int, 1>());
-                        else if (wave == 2) scan(std::integral_constant<int, 0>());
-                        else scan(std::integral_constant<int, -1>());
+                        else if (wave == 3) scan(std::integral_constant<int, -1>());
+                        else scan(std::integral_constant<int, 0>());                 // wave 2: S; wave 0: E, transposed
                     }
                     wav_sync<GS>();
                     TSTAMP(2);
