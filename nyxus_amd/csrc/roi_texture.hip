@@ -829,12 +829,17 @@ __global__ __launch_bounds__(kBlock, OCC) void roi_texture_kernel(const TexArgs 
                 bool inc[kSzmChunks];
 #pragma unroll
                 for (int c = 0; c < kSzmChunks; c++) { vp[c] = 0; lp[c] = 0xFFFFFFFFu; inc[c] = (uint32_t)lane + 64u * c < w; }
+                // (the plane row is read one row ahead: in the workspace build it comes from global memory, a round trip per row)
+                uint32_t vn[kSzmChunks];
+#pragma unroll
+                for (int c = 0; c < kSzmChunks; c++) vn[c] = (c < nch && inc[c]) ? (uint32_t)s_dense[(uint32_t)lane + 64u * c] : 0u;
                 for (uint32_t row = 0; row < h; row++) {
                     uint32_t v[kSzmChunks], lab[kSzmChunks];
 #pragma unroll
                     for (int c = 0; c < kSzmChunks; c++) {
                         const uint32_t p = row * w + (uint32_t)lane + 64u * c;
-                        v[c] = (c < nch && inc[c]) ? (uint32_t)s_dense[p] : 0u;
+                        v[c] = vn[c];
+                        vn[c] = (c < nch && inc[c] && row + 1u < h) ? (uint32_t)s_dense[p + w] : 0u;
                         lab[c] = p;
                     }
 #pragma unroll
