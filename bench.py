@@ -128,14 +128,25 @@ def run_stub(a, world, rank):
     g = TableGather(ncol, dst=0)
     g.start(last)
     full = g.finish()
+    gate_rc = 0
     if rank == 0:
         want = [t * 1000.0 + r for t in range(a.tiles * world) for r in range(rois_per_tile)]
+        if os.environ.get("NYX_BENCH_BREAK_GATE") and full.shape[0]:     # TEST HOOK: a wrong table must cost the value and the exit code
+            full[0, 0] += 1.0
         ok = full.shape[0] == len(want) and bool((full[:, 0].floor() == torch.tensor(want, dtype=torch.float64)).all())
-        print(json.dumps({"metric": "stub", "stub": True, "value": None, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(full.shape[0]), "row_order_ok": ok, "per_rank": per_rank}))
+        rec = {"metric": "stub", "stub": True, "value": float(full.shape[0]), "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1e3 * float(el.item()) / max(a.steps, 1), "rows": int(full.shape[0]), "row_order_ok": ok, "per_rank": per_rank,
+               "config": {"workload": "stub", "parity_check": "ok" if ok else "1 MISMATCHES (stub rows)"}}
+        gate_rc = apply_gates(rec)                   # the same gate the real line goes through
+        print(json.dumps(rec))
     if world > 1:
+        grc = torch.tensor([gate_rc], dtype=torch.int32)
+        dist.broadcast(grc, src=0)
+        gate_rc = int(grc.item())
         dist.barrier()
         dist.destroy_process_group()
+    if gate_rc:
+        sys.exit(gate_rc)
 
 
 def disk_cloud(radius=30):
@@ -165,17 +176,72 @@ def host_rows(dev_arrays, idx):
                           sel("bbox_h", np.uint32)[idx], sel("min_inten", np.uint32)[idx], sel("max_inten", np.uint32)[idx])
 
 
-def gate(table_rows, hb, mask, s):
+def margins(got, want, names):
+    """SURVEY.md 8(d) metric row: max relative error vs the CPU path per feature column.  Returns the five largest
+    {column: max over rows of |got - want| / |want|} (rows where both are finite and want != 0) and how many columns are equal bit for bit."""
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    n_exact = int(same.all(axis=0).sum())
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.where(same | ~np.isfinite(got) | ~np.isfinite(want) | (want == 0), 0.0, np.abs(got - want) / np.abs(want))
+    col = rel.max(axis=0) if rel.shape[0] else np.zeros(rel.shape[1])
+    top = np.argsort(-col)[:5]
+    return {"top5": {names[j]: float(col[j]) for j in top if col[j] > 0}, "exact_columns": n_exact, "columns": int(got.shape[1]), "rows": int(got.shape[0])}
+
+
+def gate(table_rows, hb, mask, s, marg=None):
     """Parity gate of a timed leg (a timed configuration counts only if its features match): rows of the
-    table the leg produced vs the CPU oracle on the same ROIs.  Returns "ok" or the mismatch count (details on stderr)."""
+    table the leg produced vs the CPU oracle on the same ROIs.  Returns "ok" or the mismatch count (details on stderr);
+    marg (a dict) receives the leg's per-column error margins."""
     from nyxus_amd import _lib
     from oracle import pyoracle as po
     from tests import parity
     want = po.oracle_featurize(hb, mask, s)
-    bad = parity.compare_tables(np.asarray(table_rows), want, _lib.column_names(mask, s), batch=hb)
+    names = _lib.column_names(mask, s)
+    got = np.asarray(table_rows)
+    if os.environ.get("NYX_BENCH_BREAK_GATE"):       # TEST HOOK: a deliberately wrong table must fail the bench
+        got = got.copy(); got[0, 0] += 1.0
+    bad = parity.compare_tables(got, want, names, batch=hb)
+    if marg is not None:
+        marg.update(margins(got, want, names))
     if bad:
         print("\n".join(bad[:10]), file=sys.stderr)
     return "ok" if not bad else f"{len(bad)} MISMATCHES"
+
+
+def gate_ok(v) -> bool:
+    """A leg's parity_check string (or None: not checked) says the leg counts."""
+    return v is None or (isinstance(v, str) and "ok" in v and "MISMATCH" not in v and "FAILED" not in v)
+
+
+def apply_gates(rec) -> int:
+    """a timed configuration counts only if its features match.  Every object of the line that carries a
+    `parity_check` which is not ok loses its `value` (null) and the process exits with code 4 after printing the line.
+    Returns the exit code (0 or 4)."""
+    failed = []
+
+    def walk(obj, path):
+        if isinstance(obj, dict):
+            pc = obj.get("parity_check", "absent")
+            if pc != "absent" and not gate_ok(pc):
+                failed.append(path or "headline")
+                for k in ("value", "rois_per_s", "ns_per_roi", "ms_per_call", "ms_per_step"):
+                    if k in obj:
+                        obj[k] = None
+            for k, v in obj.items():
+                walk(v, f"{path}.{k}" if path else k)
+        elif isinstance(obj, list):
+            for i, v in enumerate(obj):
+                walk(v, f"{path}[{i}]")
+    cfg = rec.get("config", {})
+    if "parity_check" in cfg and not gate_ok(cfg["parity_check"]):
+        failed.append("headline")
+        rec["value"] = None
+    walk({k: v for k, v in rec.items() if k != "config"}, "")
+    if failed:
+        rec["error"] = (rec.get("error", "") + "; " if rec.get("error") else "") + "parity gate failed: " + ", ".join(sorted(set(failed)))
+        return 4
+    return 0
 
 
 def main():
@@ -305,6 +371,7 @@ def main():
         except Exception as e:               # the bench line is still printed; the failure is part of it
             gather_err = repr(e)
 
+    gate_rc = 0
     if rank == 0:
         total_rois = n_roi * world * a.steps
         value = total_rois / elapsed
@@ -353,27 +420,35 @@ def main():
         # ---- parity gate of what was timed: first, middle and LAST tile of the last step vs the oracle, and every row of the
         #      table against exact reductions of the same device arrays (a defect at large ROI indices cannot hide) -----------------
         dev_arrays = {"px_offset": off, "x": x, "y": y, "inten": inten, "bbox_w": bw, "bbox_h": bh, "min_inten": mn, "max_inten": mx}
-        gates = {}
-        if not a.no_check:
-            k = rois_per_tile
-            res = []
-            for t in sorted({0, a.tiles // 2, a.tiles - 1}):
-                idx = np.arange(t * k, (t + 1) * k)
-                res.append(gate(last[idx[0]:idx[-1] + 1].cpu().numpy(), host_rows(dev_arrays, idx), mask, s))
-            cols = _lib.column_names(mask, s)
-            inv = "n/a"
-            if "MIN" in cols:
+        exact_cache = {}
+
+        def all_rows_invariant(table, msk, st):
+            """EVERY row of a table computed from the resident batch against exact device reductions of the same arrays
+            (MIN / MAX / RANGE / MEAN / INTEGRATED_INTENSITY are integer-exact columns): a defect at large ROI indices cannot hide
+            behind the three tiles the oracle sees."""
+            cols = _lib.column_names(msk, st)
+            if "MIN" not in cols:
+                return "n/a"
+            if not exact_cache:
                 iv64 = inten.view(n_roi, n_px_roi).to(torch.int64)
                 tot = iv64.sum(dim=1).to(torch.float64)
                 # (tensor / tensor: a Python-scalar divisor makes torch multiply by the reciprocal, which rounds differently from the division)
-                exact = {"MIN": mn.to(torch.float64), "MAX": mx.to(torch.float64), "INTEGRATED_INTENSITY": tot,
-                         "MEAN": torch.div(tot, torch.full_like(tot, float(n_px_roi))), "RANGE": (mx - mn).to(torch.float64)}
-                wrong = {c: int((last[:, cols.index(c)] != v).sum().item()) for c, v in exact.items()}
-                inv = "ok" if not any(wrong.values()) else "MISMATCHES " + json.dumps({c: k for c, k in wrong.items() if k})
-                del iv64, tot
+                exact_cache.update({"MIN": mn.to(torch.float64), "MAX": mx.to(torch.float64), "INTEGRATED_INTENSITY": tot,
+                                    "MEAN": torch.div(tot, torch.full_like(tot, float(n_px_roi))), "RANGE": (mx - mn).to(torch.float64)})
+                del iv64
+            wrong = {c: int((table[:, cols.index(c)] != v).sum().item()) for c, v in exact_cache.items()}
+            return "ok" if not any(wrong.values()) else "MISMATCHES " + json.dumps({c: k for c, k in wrong.items() if k})
+        if not a.no_check:
+            k = rois_per_tile
+            res = []
+            marg_h = {}
+            for t in sorted({0, a.tiles // 2, a.tiles - 1}):
+                idx = np.arange(t * k, (t + 1) * k)
+                res.append(gate(last[idx[0]:idx[-1] + 1].cpu().numpy(), host_rows(dev_arrays, idx), mask, s, marg=marg_h))
+            rec["config"]["max_rel_err"] = marg_h          # (of the last tile checked)
+            inv = all_rows_invariant(last, mask, s)
             ok = all(r == "ok" for r in res) and inv in ("ok", "n/a")
-            gates["headline"] = "ok" if ok else "FAILED"
-            rec["config"]["parity_check"] = (f"tiles 0, {a.tiles // 2}, {a.tiles - 1} of the last timed step vs oracle: " + "/".join(res)
+            rec["config"]["parity_check"] = (("" if ok else "FAILED: ") + f"tiles 0, {a.tiles // 2}, {a.tiles - 1} of the last timed step vs oracle: " + "/".join(res)
                                              + f"; all {n_roi} rows, MIN/MAX/RANGE/MEAN/INTEGRATED_INTENSITY vs exact device reductions: {inv}")
 
         # ---- CPU baseline: the reference's own multithreaded reduce on host cores ---------------
@@ -406,7 +481,7 @@ def main():
                 "host_cpus": cores}
         # ---- informational legs on the same resident batch: the reference's DEFAULT grey depth, BASELINE.json configs[3] and [4] ----
         if world == 1 and not a.no_extras and mask == 3:
-            def timed(msk, st, cbatch, n_rows, reps=3, check_rows=None, arrays=None):
+            def timed(msk, st, cbatch, n_rows, reps=3, check_rows=None, arrays=None, all_rows=False):
                 """One leg: warm-up call, `reps` timed calls; the parity gate (rows `check_rows` of the table vs the oracle) on what it left."""
                 nc = ctx.n_columns(msk, st)
                 o = torch.empty((n_rows, nc), dtype=torch.float64, device=dev)
@@ -419,32 +494,43 @@ def main():
                 ctx.sync()
                 dt_ = (time.perf_counter() - c0) / reps
                 par = None
+                timed.margin = {}
                 if check_rows is not None and not a.no_check:
                     ct = torch.from_numpy(np.asarray(check_rows, np.int64)).to(dev)
-                    par = gate(o[ct].cpu().numpy(), host_rows(arrays, check_rows), msk, st)
+                    par = gate(o[ct].cpu().numpy(), host_rows(arrays, check_rows), msk, st, marg=timed.margin)
+                    if all_rows and par == "ok":
+                        inv_ = all_rows_invariant(o, msk, st)
+                        if inv_ == "ok":
+                            par = f"ok (rows of the last tile vs oracle; all {n_rows} rows, MIN/MAX/RANGE/MEAN/INTEGRATED_INTENSITY vs exact device reductions)"
+                        elif inv_ != "n/a":
+                            par = f"all {n_rows} rows vs exact device reductions: {inv_}"
                 return dt_, nc, par
             last_tile = np.arange((a.tiles - 1) * rois_per_tile, a.tiles * rois_per_tile)
             # BASELINE.json configs[1] and [2] alone: *ALL_INTENSITY* at the default 64 histogram bins, *ALL_GLCM* at 8 grey levels
             s64 = _abi.default_settings(64)
-            dt2, nc2, par2 = timed(_abi.FAM_INTENSITY, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            dt2, nc2, par2 = timed(_abi.FAM_INTENSITY, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays, all_rows=True)
+            mg2 = timed.margin
             b2 = n_px * 4 + n_roi * nc2 * 8                      # intensities only: 4 B per ROI pixel in
-            rec["config2"] = {"value": n_roi / dt2, "unit": "ROIs/s", "ms_per_step": 1e3 * dt2, "n_columns": nc2, "parity_check": par2,
+            rec["config2"] = {"value": n_roi / dt2, "unit": "ROIs/s", "ms_per_step": 1e3 * dt2, "n_columns": nc2, "parity_check": par2, "max_rel_err": mg2,
                               "roofline": {"bound": "hbm", "achieved": b2 / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / dt2 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b2},
                               "what": "BASELINE.json configs[1]: *ALL_INTENSITY* alone (36 columns, 64 histogram bins = the default coarse_gray_depth) on the same 1000 tiles"}
             dt3, nc3, par3 = timed(_abi.FAM_GLCM, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            mg3 = timed.margin
             b3 = n_px * 8 + n_roi * nc3 * 8
-            rec["config3"] = {"value": n_roi / dt3, "unit": "ROIs/s", "ms_per_step": 1e3 * dt3, "n_columns": nc3, "parity_check": par3,
+            rec["config3"] = {"value": n_roi / dt3, "unit": "ROIs/s", "ms_per_step": 1e3 * dt3, "n_columns": nc3, "parity_check": par3, "max_rel_err": mg3,
                               "roofline": {"bound": "hbm", "achieved": b3 / dt3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b3 / dt3 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b3},
                               "what": "BASELINE.json configs[2]: *ALL_GLCM* alone (8 grey levels, 4 angles, d = 1; 149 columns) on the same 1000 tiles"}
-            dt64, _, par64 = timed(mask, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
-            rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64, "parity_check": par64,
+            dt64, _, par64 = timed(mask, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays, all_rows=True)
+            mg64 = timed.margin
+            rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64, "parity_check": par64, "max_rel_err": mg64,
                                     "what": "the metric workload at the reference's default coarse_gray_depth=64 (64 x 64 co-occurrence matrices, 64 histogram bins)"}
             m4 = _abi.FAM_INTENSITY | _abi.FAM_GLCM | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
-            dt4, nc4, par4 = timed(m4, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
+            dt4, nc4, par4 = timed(m4, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays, all_rows=True)
+            mg4 = timed.margin
             b4 = n_px * 8 + n_roi * nc4 * 8
-            rec["config4"] = {"value": n_roi / dt4, "unit": "ROIs/s", "ms_per_step": 1e3 * dt4, "n_columns": nc4, "parity_check": par4,
+            rec["config4"] = {"value": n_roi / dt4, "unit": "ROIs/s", "ms_per_step": 1e3 * dt4, "n_columns": nc4, "parity_check": par4, "max_rel_err": mg4,
                               "roofline": {"bound": "hbm", "achieved": b4 / dt4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b4 / dt4 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b4},
                               "what": "BASELINE.json configs[3] per GPU: *ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY* (gd 8) on the same 1000 tiles"}
@@ -474,10 +560,11 @@ def main():
                 m5k = _abi.FAM_GABOR | _abi.FAM_ZERNIKE
                 chk5 = np.concatenate([np.arange(64), np.arange(hb5.n_roi - 64, hb5.n_roi)])       # first and last ROIs of the batch
                 dt5, _, par5 = timed(m5k, s5, cb5, hb5.n_roi, check_rows=chk5, arrays=keep5)
+                mg5 = timed.margin
                 # Gabor 2*2*w*h*n^2 flops per filter (complex MAC on a real image; 8 filters + the low-pass), Zernike 2*55 per pixel
                 fl5 = float(np.sum(9.0 * 4.0 * hb5.bbox_w.astype(np.float64) * hb5.bbox_h * 256.0) + 110.0 * hb5.n_px)
                 rec["config5"] = {"value": hb5.n_roi / dt5, "unit": "ROIs/s", "ms_per_step": 1e3 * dt5, "rois": int(hb5.n_roi), "mean_px": hb5.n_px / hb5.n_roi,
-                                  "parity_check": par5,
+                                  "parity_check": par5, "max_rel_err": mg5,
                                   "roofline": {"bound": "fp64 vector", "achieved": fl5 / dt5 / 1e12, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": fl5 / dt5 / 1e12 / FP64_PEAK_TF,
                                                "algorithmic_flops_per_launch": fl5,
                                                "note": "peak = AMD's MI355X data sheet (fp64 vector = fp64 matrix, 78.6 TFLOP/s; MI355X_MICROARCH.md lists no fp64 row); "
@@ -548,7 +635,37 @@ def main():
                 hbt = roi_assembly.assemble(tin[nt - 1].cpu().numpy().view(np.uint32), label_stack[nt - 1].cpu().numpy().view(np.uint32), 1.7976931348623157e308, -1.7976931348623157e308)
                 if hbt is None or hbt.n_roi != len(sel) or not np.array_equal(t_lab[:n_][sel].cpu().numpy().view(np.uint32), hbt.roi_label):
                     return "ROW MISMATCH (labels of the last tile)"
-                return gate(t_out[:n_][sel].cpu().numpy(), hbt, mask, s)
+                tile_gate.margin = {}
+                par = gate(t_out[:n_][sel].cpu().numpy(), hbt, mask, s, marg=tile_gate.margin)
+                cols = _lib.column_names(mask, s)
+                if par != "ok" or "MIN" not in cols:
+                    return par
+                # every row of the call against exact device reductions of its (tile, label) pixels
+                K = int(label_stack.max().item()) + 1
+                big = torch.iinfo(torch.int64).max
+                key_r = t_idx[:n_].to(torch.int64) * K + t_lab[:n_].to(torch.int64)
+                wrong = {c: 0 for c in ("MIN", "MAX", "RANGE", "MEAN", "INTEGRATED_INTENSITY")}
+                for t0_ in range(0, nt, 16):
+                    t1_ = min(nt, t0_ + 16)
+                    Lk = label_stack[t0_:t1_].reshape(t1_ - t0_, -1).to(torch.int64) + K * torch.arange(t1_ - t0_, device=dev, dtype=torch.int64)[:, None]
+                    Vk = tin[t0_:t1_].reshape(t1_ - t0_, -1).to(torch.int64)
+                    Lk = Lk.reshape(-1); Vk = Vk.reshape(-1)
+                    sz = (t1_ - t0_) * K
+                    sm = torch.zeros(sz, dtype=torch.int64, device=dev).scatter_add_(0, Lk, Vk)
+                    cn = torch.zeros(sz, dtype=torch.int64, device=dev).scatter_add_(0, Lk, torch.ones_like(Vk))
+                    lo_ = torch.full((sz,), big, dtype=torch.int64, device=dev).scatter_reduce_(0, Lk, Vk, "amin")
+                    hi_ = torch.zeros(sz, dtype=torch.int64, device=dev).scatter_reduce_(0, Lk, Vk, "amax")
+                    rows_ = torch.nonzero((t_idx[:n_] >= t0_) & (t_idx[:n_] < t1_)).flatten()
+                    kk = key_r[rows_] - t0_ * K
+                    tot_ = sm[kk].to(torch.float64)
+                    exact = {"MIN": lo_[kk].to(torch.float64), "MAX": hi_[kk].to(torch.float64), "RANGE": (hi_[kk] - lo_[kk]).to(torch.float64),
+                             "INTEGRATED_INTENSITY": tot_, "MEAN": torch.div(tot_, cn[kk].to(torch.float64))}
+                    for c_, v_ in exact.items():
+                        wrong[c_] += int((t_out[:n_][rows_, cols.index(c_)] != v_).sum().item())
+                    del Lk, Vk, sm, cn, lo_, hi_
+                if any(wrong.values()):
+                    return f"all {n_} rows vs exact device reductions: MISMATCHES " + json.dumps({c: k for c, k in wrong.items() if k})
+                return f"ok (rows of the last tile vs oracle; all {n_} rows, MIN/MAX/RANGE/MEAN/INTEGRATED_INTENSITY vs exact device reductions of the tiles)"
             tile_step()
             torch.cuda.synchronize()
             c0 = time.perf_counter()
@@ -560,7 +677,7 @@ def main():
             par_t = tile_gate(labs)
             tile_bytes = nt * (8 * 1024 * 1024 + 196 * ncol * 8)     # 8.68 MB per tile
             rec["tile_path"] = {"value": nroi.value / dt, "unit": "ROIs/s", "tiles_per_s": nt / dt, "tiles": nt,
-                                "rois": int(nroi.value), "ms_per_call": 1e3 * dt, "parity_check": par_t,
+                                "rois": int(nroi.value), "ms_per_call": 1e3 * dt, "parity_check": par_t, "max_rel_err": getattr(tile_gate, "margin", None),
                                 "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                 "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                         "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
@@ -625,13 +742,19 @@ def main():
                 rec["tile_path"][tag] = {"value": len(hl_out) / dth, "unit": "ROIs/s", "tiles": nh, "ms_per_call": 1e3 * dth,
                                          "host_GBps": (hi.nbytes + hl.nbytes) / dth / 1e9,
                                          "what": "pageable host tiles (" + str(hi.dtype) + " intensity, " + str(hl.dtype) + " labels) in, host table out"}
+        gate_rc = apply_gates(rec)           # a leg whose features do not match loses its value; exit code 4 below
         print(json.dumps(rec))
     if world > 1:
+        grc = torch.tensor([gate_rc], dtype=torch.int32, device=dev)
+        dist.broadcast(grc, src=0)
+        gate_rc = int(grc.item())
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
     if same_device or gather_err:
         sys.exit(3)                          # the line is printed, but a job whose ranks shared a device (or whose gather failed) did not measure N GPUs
+    if gate_rc:
+        sys.exit(gate_rc)                    # a timed configuration counts only if its features match
 
 
 if __name__ == "__main__":

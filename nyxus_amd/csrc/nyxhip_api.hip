@@ -29,9 +29,14 @@ struct ClassRun {              // one size class of one call, as launched (nyxhi
     int cls;                   // 2 * size class + (1: some ROI needs 32-bit tables); -1: the whole batch in one launch group
     uint32_t count;            // members (0xFFFFFFFF: counted on the device only)
     Extrema E;                 // extrema the carve-outs were sized for
-    int workspace;             // 0: LDS launches, 1: INTENSITY + GLCM from the global workspace, 2: every kernel group
+    int workspace;             // kernel groups that ran from a global workspace instead of LDS: bit 0 INTENSITY + GLCM, 1 texture, 2 shape, 3 dependence
     hipEvent_t e0, e1;         // around the class's launches (timing enabled), else NULL
+    int cooperative = 0;       // 1: INTENSITY + GLCM by the several-workgroups-per-ROI kernels of roi_large.hip
 };
+struct ClassTotals {           // sums over the members of a class (class header): what the large-ROI path sizes its workspace from
+    uint64_t px, area, range1; // pixels, bounding-box cells, histogram entries (range + 1 of the members whose range the path serves)
+};
+constexpr int NYXHIP_INTERNAL_NEEDS_CLOUDS = -1000;   // run_class: a launch group of a window-mode call needs the materialised clouds
 
 struct nyxhip_ctx {
     int device = 0;
@@ -88,6 +93,11 @@ struct nyxhip_ctx {
     uint32_t* d_cls_hdr = nullptr;
     uint32_t* h_cls_hdr = nullptr;
     std::vector<ClassRun> runs;         // the classes of the last call as launched (nyxhip_launch_report)
+    // large-ROI path (roi_large.hip): per-ROI blocks of histogram / plane / matrices, and the work maps + offsets + counters
+    void* d_large = nullptr;
+    size_t large_bytes = 0;
+    void* d_large_aux = nullptr;
+    size_t large_aux_bytes = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -921,13 +931,15 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
 // {16-bit tables possible, not possible} by each ROI's OWN pixel count, box and intensity range (never by its companions), and
 // every class is launched over its index list with a carve-out -- hence kernel build and occupancy -- of its own.  Classes whose
 // carve-out does not fit a CU's LDS run the same kernels with their scratch in a global workspace.
-enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_VMAX, H_WORDS };   // header words per class
+enum { H_COUNT = 0, H_OFFSET, H_PX, H_AREA, H_RANGE, H_SIDE, H_CURSOR, H_VMAX,
+       H_SUMPX, H_SUMPX_HI, H_SUMAREA, H_SUMAREA_HI, H_SUMRANGE, H_SUMRANGE_HI, H_WORDS };   // header words per class (the three sums: 64 bits, even offsets)
 
 // pass 1: members and extrema of every class (block-local in LDS first: ten hot words would serialise 5 n_roi global atomics)
+// lvl_on: IBSI levels matter to the call (a texture family under IBSI): an ROI's largest intensity is its level count (roi_class)
 __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
-                                   const uint32_t* mx, uint32_t* hdr)
+                                   const uint32_t* mx, uint32_t* hdr, uint32_t lvl_on)
 {
-    __shared__ uint32_t s_h[kClasses * H_WORDS];
+    __shared__ __attribute__((aligned(8))) uint32_t s_h[kClasses * H_WORDS];
     for (int i = threadIdx.x; i < kClasses * H_WORDS; i += blockDim.x) s_h[i] = 0;
     __syncthreads();
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -935,8 +947,11 @@ __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, co
         const uint64_t n64 = px_offset[i + 1] - px_offset[i];
         const uint32_t n = n64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n64, w = bw[i], h = bh[i], r = mx[i] - mn[i];
         const uint64_t a64 = (uint64_t)w * h;
-        uint32_t* c = s_h + roi_class(n, w, h, r) * H_WORDS;
+        uint32_t* c = s_h + roi_class(n, w, h, r, lvl_on ? mx[i] : 0u) * H_WORDS;
         atomicAdd(&c[H_COUNT], 1u);
+        atomicAdd((unsigned long long*)&c[H_SUMPX], (unsigned long long)n);
+        atomicAdd((unsigned long long*)&c[H_SUMAREA], (unsigned long long)a64);
+        if (r < kLargeRangeMax) atomicAdd((unsigned long long*)&c[H_SUMRANGE], (unsigned long long)r + 1ull);
         atomicMax(&c[H_PX], n);
         atomicMax(&c[H_AREA], a64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a64);
         atomicMax(&c[H_RANGE], r);
@@ -946,6 +961,11 @@ __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, co
     __syncthreads();
     for (int k = threadIdx.x; k < kClasses * H_WORDS; k += blockDim.x) {
         const int f = k % H_WORDS;
+        if (f == H_SUMPX || f == H_SUMAREA || f == H_SUMRANGE) {
+            const unsigned long long v = *(const unsigned long long*)&s_h[k];
+            if (v) atomicAdd((unsigned long long*)&hdr[k], v);
+            continue;
+        }
         if (s_h[k] == 0) continue;
         if (f == H_COUNT) atomicAdd(&hdr[k], s_h[k]);
         else if ((f >= H_PX && f <= H_SIDE) || f == H_VMAX) atomicMax(&hdr[k], s_h[k]);
@@ -956,7 +976,7 @@ __global__ void class_count_kernel(uint64_t n_roi, const uint64_t* px_offset, co
 // blocks reserve their ranges in arrival order, so a class's list follows the batch order closely (neighbouring workgroups of a
 // launch read neighbouring clouds) without being a function of it -- rows are addressed by ROI index, the order is free.
 __global__ void class_scatter_kernel(uint64_t n_roi, const uint64_t* px_offset, const uint32_t* bw, const uint32_t* bh, const uint32_t* mn,
-                                     const uint32_t* mx, uint32_t* hdr, uint32_t* list)
+                                     const uint32_t* mx, uint32_t* hdr, uint32_t* list, uint32_t lvl_on)
 {
     __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
     if (threadIdx.x < kClasses) s_cnt[threadIdx.x] = 0;
@@ -966,7 +986,7 @@ __global__ void class_scatter_kernel(uint64_t n_roi, const uint64_t* px_offset, 
     uint32_t rank = 0;
     if (i < n_roi) {
         const uint64_t n64 = px_offset[i + 1] - px_offset[i];
-        c = roi_class(n64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n64, bw[i], bh[i], mx[i] - mn[i]);
+        c = roi_class(n64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n64, bw[i], bh[i], mx[i] - mn[i], lvl_on ? mx[i] : 0u);
         rank = atomicAdd(&s_cnt[c], 1u);
     }
     __syncthreads();
@@ -985,15 +1005,120 @@ static void set_slots(SpillArgs& sp, const uint32_t* list, uint32_t n_slots)
     sp.roi_index = list; sp.n_slots = n_slots;
 }
 
-// One launch group: LDS launches when the carve-outs for the extrema E fit, else the same kernels over a global workspace.
-//   list != NULL: the members of one class, `grid` of them (exact launches).
+// Extrema every member of size class cls / 2 stays below (roi_class): what "does this class run from LDS?" is decided on, so that
+// the answer is a function of the class -- i.e. of the ROI -- and the settings, never of the members a call happens to hold.
+static Extrema class_bounds(int cls, const nyxhip_settings* s)
+{
+    const int sc = cls / 2;
+    Extrema E{};
+    E.px = kClassPx[sc]; E.side = kClassSide[sc]; E.area = kClassSide[sc] * kClassSide[sc];
+    E.range = (cls & 1) ? (sc == 2 ? 65535u : 0xFFFFFFFFu) : 16383u;
+    E.vmax = s->ibsi ? kLdsLevels : 0u;
+    E.wide_only = (cls & 1) != 0;
+    return E;
+}
+
+// INTENSITY + GLCM of one class by the several-workgroups-per-ROI kernels of roi_large.hip.  Members whose intensity range the
+// histogram workspace does not hold (kLargeRangeMax) are left to the caller (the one-workgroup sort path).
+static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
+                     const ClassTotals& tot, const uint32_t* list, uint32_t count)
+{
+    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM);
+    if (!mask1 || !count) return NYXHIP_OK;
+    hipStream_t st = ctx->stream();
+    LargeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_roi = b->n_roi;
+    a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
+    a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
+    a.slide_min = b->slide_min; a.slide_max = b->slide_max;
+    a.out = d_out; a.ld = ld; a.status = ctx->d_status;
+    a.mask = mask1; a.n_cols = nyxhip_n_columns(mask1, s);
+    a.col_intensity = (mask1 & NYXHIP_FAM_INTENSITY) ? 0 : -1;
+    a.col_glcm = (mask1 & NYXHIP_FAM_GLCM) ? ((mask1 & NYXHIP_FAM_INTENSITY) ? kIntensityCols : 0) : -1;
+    a.soft_nan = s->soft_nan;
+    a.grey_depth = s->grey_depth; a.ibsi = s->ibsi; a.glcm_grey_depth = s->glcm_grey_depth;
+    a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
+    for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
+    a.n_hist = abs(s->grey_depth);
+    const bool do_int = mask1 & NYXHIP_FAM_INTENSITY, do_glcm = mask1 & NYXHIP_FAM_GLCM;
+    const int greyInfo = s->ibsi ? 0 : s->grey_depth;
+    const uint32_t ng_max = greyInfo != 0 ? (uint32_t)abs(greyInfo) : E.vmax;       // largest matrix order of the class
+    const uint32_t lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0u;
+    const uint32_t na = (uint32_t)s->glcm_n_angles;
+    a.plane16 = ng_max > 255 ? 1u : 0u;
+    // load kernel: histogram counted in LDS with 16-bit counters (a slab holds < 65536 pixels); up to 16384 entries at 256 threads and
+    // 8192 pixels per slab, up to 65536 entries (128 KiB) at 1024 threads and 32768 pixels per slab (16-bit data: the flush of the
+    // table -- one atomic add per non-empty entry -- must not outweigh the slab's pixels)
+    const uint32_t r_max = std::min(E.range, kLargeRangeMax - 1);
+    if (!do_int) { a.tab_lds = 0; a.px_per_wg = 8192; }
+    else if (r_max < 16384u) { a.tab_lds = (r_max + 1 + 63u) & ~63u; a.px_per_wg = 8192; }
+    else { a.tab_lds = 65536; a.px_per_wg = 32768; }
+    a.lds_P_bytes = do_glcm ? (uint32_t)std::min<uint64_t>(96 * 1024, ((4ull * na * ng_max * ng_max + 15) & ~15ull) + ((2ull * (lvl_cap + 2) + 15) & ~15ull)) : 0u;
+    // ---- workspace: the members' blocks back to back (offsets handed out by the prep kernel) when the class fits the budget, else
+    // chunks of the list with room for the class's largest block each
+    const char* const be = getenv("NYXHIP_LARGE_BUDGET_MB");                  // (tests: a small budget sends a class through the chunked form)
+    const size_t budget = be && atoll(be) > 0 ? (size_t)atoll(be) << 20 : (size_t)8 << 30;
+    const LargeWs Lmax = large_ws_layout(r_max, E.area, ng_max, lvl_cap, na, a.plane16 != 0, do_int, do_glcm);
+    const LargeWs Lfix = large_ws_layout(0, 0, ng_max, lvl_cap, na, a.plane16 != 0, do_int, do_glcm);   // what every block holds whatever its ROI
+    const uint64_t all_bytes = (uint64_t)count * (Lfix.total + 1024) + (do_int ? 4ull * tot.range1 : 0ull) + (do_glcm ? (a.plane16 ? 2ull : 1ull) * tot.area : 0ull);
+    uint32_t chunk = count;
+    uint64_t ws_need = all_bytes;
+    if (all_bytes > budget) {
+        if (Lmax.total > budget) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "an ROI's workspace block (" + std::to_string(Lmax.total >> 20) + " MiB) exceeds the large-ROI budget");
+        chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, budget / Lmax.total));
+        ws_need = (uint64_t)chunk * Lmax.total;
+    }
+    const uint64_t slabs_max = (E.px + a.px_per_wg - 1) / a.px_per_wg, strips_max = 2ull * E.area / kLargeCells + 1;
+    uint64_t cap_load = chunk == count ? tot.px / a.px_per_wg + count : (uint64_t)chunk * slabs_max;
+    uint64_t cap_cooc = do_glcm ? (chunk == count ? 2 * tot.area / kLargeCells + count : (uint64_t)chunk * strips_max) : 0;
+    if (cap_load > 0x7FFFFFFFull || cap_cooc > 0x7FFFFFFFull) {          // (grid limit: smaller chunks)
+        const uint64_t per = std::max(slabs_max, strips_max);
+        chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk, 0x7FFFFFFFull / per));
+        cap_load = (uint64_t)chunk * slabs_max; cap_cooc = do_glcm ? (uint64_t)chunk * strips_max : 0;
+        ws_need = std::min<uint64_t>(ws_need, (uint64_t)chunk * Lmax.total);
+        if (slabs_max > 0x7FFFFFFFull || strips_max > 0x7FFFFFFFull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "ROI too large for the large-ROI launch grid");
+    }
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ctr = 0, o_off = 256, o_ml = al(o_off + 8ull * chunk), o_mc = al(o_ml + 8ull * cap_load), aux_need = al(o_mc + 8ull * cap_cooc);
+    if (ws_need > ctx->large_bytes) {
+        if (ctx->d_large) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_large)); ctx->d_large = nullptr; ctx->large_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_large, ws_need));
+        ctx->large_bytes = ws_need;
+    }
+    if (aux_need > ctx->large_aux_bytes) {
+        if (ctx->d_large_aux) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_large_aux)); ctx->d_large_aux = nullptr; ctx->large_aux_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_large_aux, aux_need + aux_need / 4));
+        ctx->large_aux_bytes = aux_need + aux_need / 4;
+    }
+    char* const aux = (char*)ctx->d_large_aux;
+    a.ws = (unsigned char*)ctx->d_large; a.ws_bytes = ws_need;
+    a.ctr = (uint32_t*)(aux + o_ctr); a.ws_off = (uint64_t*)(aux + o_off);
+    a.map_load = (uint2*)(aux + o_ml); a.map_cooc = (uint2*)(aux + o_mc);
+    a.cap_load = (uint32_t)cap_load; a.cap_cooc = (uint32_t)cap_cooc;
+    for (uint32_t o = 0; o < count; o += chunk) {
+        a.list = list + o; a.n_list = std::min(chunk, count - o);
+        HIP_TRY(ctx, hipMemsetAsync(a.ws, 0, ws_need, st));
+        HIP_TRY(ctx, hipMemsetAsync(a.ctr, 0, 256, st));
+        if (int rc = launch_large_features(a, st))
+            return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    return NYXHIP_OK;
+}
+
+// One launch group.
+//   list != NULL: the members of one class (cls), `grid` of them (exact launches).  Which kernel groups of the class run from LDS is
+//   decided on the class BOUNDS (class_bounds); the carve-outs then follow the class's extrema E.  A group that does not fit runs
+//   from a global workspace: INTENSITY + GLCM by the several-workgroups-per-ROI path (run_large), the others with one workgroup
+//   per ROI.
 //   list == NULL: the whole batch (slot = ROI, grid = n_roi); class_mask != 0 then restricts the launch to the classes of the
 //   mask (SpillArgs::class_mask: everybody else returns at once) -- used when the host launches without knowing the member
 //   counts; such a launch cannot fall back to the workspace (its chunks are sized by member counts): *needs_host is set instead
 //   and nothing is launched.  dry: build the argument blocks only (do the carve-outs fit?).
 //   group_sel: kernel groups to launch (bit 0 features, 1 texture, 2 shape, 3 dependence).
 int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
-              const uint32_t* list, uint32_t grid, bool dry, bool* needs_host, int* used_workspace, uint32_t class_mask = 0, uint32_t group_sel = 0xF)
+              const uint32_t* list, uint32_t grid, bool dry, bool* needs_host, ClassRun* report, uint32_t class_mask = 0, uint32_t group_sel = 0xF,
+              int cls = -1, const ClassTotals* tot = nullptr)
 {
     std::string why;
     const uint32_t full = mask;                          // column positions follow the call's full mask: build_args always gets it
@@ -1001,34 +1126,45 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     if (!(group_sel & 2)) mask &= ~kTexture;
     if (!(group_sel & 4)) mask &= ~kShape;
     if (!(group_sel & 8)) mask &= ~kDependence;
-    const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), mask2 = mask & kTexture, mask3 = mask & kShape, mask4 = mask & kDependence;
-    if (used_workspace) *used_workspace = 0;
-    if (!(mask1 | mask2 | mask3 | mask4)) return NYXHIP_OK;
+    const uint32_t fam_of_group[4] = {NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM, kTexture, kShape, kDependence};
+    uint32_t want = 0;                                   // kernel groups this call has work for
+    for (int k = 0; k < 4; k++) if (mask & fam_of_group[k]) want |= 1u << k;
+    if (!want) return NYXHIP_OK;
     RoiArgs a; TexArgs t; ShapeArgs g; DepArgs d;
-    uint32_t groups = group_sel & 0xF;
-    bool feat_gs = false, all_gs = false;
-    int lrc = build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, groups);
-    if (lrc == NYXHIP_ERR_UNSUPPORTED && mask1) {
-        // a GLCM grey depth whose matrix does not fit LDS next to any ROI: the INTENSITY + GLCM group of this class runs from the
-        // global workspace (slow, but every depth the matrices' 2 GiB offset range allows is served); the other groups keep LDS
-        RoiArgs aa; TexArgs tt; ShapeArgs gg; DepArgs dd;
-        std::string why2;
-        if (build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, aa, tt, gg, dd, why2, 1) == NYXHIP_OK) {
-            feat_gs = true;
-            groups &= 0xE;
-            lrc = build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, groups);
+    uint32_t gs = 0;                                     // groups that run from a global workspace
+    if (list) {
+        const Extrema Eb = class_bounds(cls, s);
+        for (int k = 0; k < 4; k++) {
+            if (!(want & (1u << k))) continue;
+            if (cls / 2 >= kFirstLargeSizeClass) { gs |= 1u << k; continue; }
+            const int lrc = build_args(ctx, b, full, s, d_out, ld, Eb, 0, a, t, g, d, why, 1u << k);
+            if (lrc == NYXHIP_ERR_ROI_TOO_LARGE || lrc == NYXHIP_ERR_UNSUPPORTED) gs |= 1u << k;
+            else if (lrc) return fail(ctx, lrc, why);
         }
     }
-    if (lrc == NYXHIP_ERR_UNSUPPORTED) return fail(ctx, lrc, why);
-    if (lrc == NYXHIP_ERR_ROI_TOO_LARGE) all_gs = true;
-    else if (lrc) return fail(ctx, lrc, why);
-    if ((feat_gs || all_gs) && needs_host) { *needs_host = true; return NYXHIP_OK; }
+    uint32_t lds = want & ~gs;
+    if (lds) {
+        int lrc = build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, lds);
+        if (lrc == NYXHIP_ERR_UNSUPPORTED && (lds & 1) && list == nullptr) {
+            // whole-batch launches: a GLCM grey depth whose matrix does not fit LDS next to any ROI sends the feature group to the workspace
+            gs |= 1; lds &= ~1u;
+            lrc = lds ? build_args(ctx, b, full, s, d_out, ld, E, 0, a, t, g, d, why, lds) : NYXHIP_OK;
+        }
+        if (lrc == NYXHIP_ERR_UNSUPPORTED || lrc == NYXHIP_ERR_ROI_TOO_LARGE) {
+            if (list == nullptr && lrc == NYXHIP_ERR_UNSUPPORTED) return fail(ctx, lrc, why);
+            gs |= lds; lds = 0;                          // (exact launches: cannot happen -- the bounds fitted; served from the workspace all the same)
+        } else if (lrc) return fail(ctx, lrc, why);
+    }
+    if (gs && needs_host) { *needs_host = true; return NYXHIP_OK; }
+    if (gs && !list) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "ROI too large for the LDS-resident path: " + why);
     if (dry) return NYXHIP_OK;
-    if (used_workspace) *used_workspace = all_gs ? 2 : feat_gs ? 1 : 0;
+    if (gs && ctx->win_next.inten && !b->inten)          // window-mode call (no clouds materialised): the caller builds them and comes back
+        return NYXHIP_INTERNAL_NEEDS_CLOUDS;
+    if (report) report->workspace = (int)gs;
 
     hipStream_t st = ctx->stream();
     int rc = 0;
-    if (!all_gs) {
+    if (lds) {
         for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
         // kernel holds 43 KB of LDS per workgroup (three per CU); the intensity block inside it ran at that occupancy, 2.9 ms per
@@ -1050,26 +1186,37 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             }
             return launch_roi_features(a, st, grid);
         };
-        rc = (mask1 && !feat_gs) ? launch_features_main() : 0;
-        if (rc == 0 && mask2) rc = launch_roi_texture(t, st, grid);
-        if (rc == 0 && mask4) rc = launch_roi_dependence(d, st, grid);
-        if (rc == 0 && mask3) rc = launch_roi_shape(g, st, grid);
+        if (lds & 1) rc = launch_features_main();
+        if (rc == 0 && (lds & 2)) rc = launch_roi_texture(t, st, grid);
+        if (rc == 0 && (lds & 8)) rc = launch_roi_dependence(d, st, grid);
+        if (rc == 0 && (lds & 4)) rc = launch_roi_shape(g, st, grid);
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
-    if (!feat_gs && !all_gs)
+    if (!gs)
         return NYXHIP_OK;
 
-    // ---- global-workspace pass of this class: the feature group alone (feat_gs) or every group (all_gs) ---------------------
-    const uint32_t gs_groups = all_gs ? (group_sel & 0xFu) : 1u;
+    // ---- INTENSITY + GLCM of the class by several workgroups per ROI (every member whose intensity range the histogram holds) ------
+    static const bool no_coop = [] { const char* e = getenv("NYXHIP_NO_COOP"); return e && *e && *e != '0'; }();   // A/B knob: the one-workgroup path
+    bool coop = false;
+    if ((gs & 1) && tot && !no_coop) {
+        if (int lrc = run_large(ctx, b, full, s, d_out, ld, E, *tot, list, grid)) return lrc;
+        coop = true;
+        if (report) report->cooperative = 1;
+        if (E.range < kLargeRangeMax) gs &= ~1u;         // nobody left for the sort path below
+        if (!gs) return NYXHIP_OK;
+    }
+
+    // ---- one workgroup per ROI over a global workspace: the groups of `gs` ------------------------------------------------------
     RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
-    lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs_groups);
+    int lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
+    if (coop) a2.sp.min_range = kLargeRangeMax;          // the histogram path served everybody below
     size_t stride = 0;
-    if (mask1) stride = std::max<size_t>(stride, a2.L.total);
-    if (all_gs && mask2) stride = std::max<size_t>(stride, t2.L.total);
-    if (all_gs && (mask3 & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
-    if (all_gs && mask4) stride = std::max<size_t>(stride, d2.L.total);
+    if (gs & 1) stride = std::max<size_t>(stride, a2.L.total);
+    if (gs & 2) stride = std::max<size_t>(stride, t2.L.total);
+    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
+    if (gs & 8) stride = std::max<size_t>(stride, d2.L.total);
     stride = (stride + 255) & ~(size_t)255;
     const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(stride, 1)));
@@ -1079,7 +1226,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, need));
         ctx->spill_bytes = need;
     }
-    if (all_gs && (mask3 & NYXHIP_FAM_ZERNIKE)) {   // Zernike keeps no ROI-sized state in LDS: one launch over the class, whatever its size
+    if ((gs & 4) && (mask & NYXHIP_FAM_ZERNIKE)) {   // Zernike keeps no ROI-sized state in LDS: one launch over the class, whatever its size
         ShapeArgs gz = g2;
         gz.mask = NYXHIP_FAM_ZERNIKE; gz.sp.scratch = nullptr; gz.small_rois = 0;
         set_slots(gz.sp, list, grid);
@@ -1091,12 +1238,10 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         set_slots(a2.sp, list + o, nb); set_slots(t2.sp, list + o, nb); set_slots(g2.sp, list + o, nb); set_slots(d2.sp, list + o, nb);
         a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
         a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
-        rc = mask1 ? launch_roi_features(a2, st, nb) : 0;
-        if (all_gs) {
-            if (rc == 0 && mask2) rc = launch_roi_texture(t2, st, nb);
-            if (rc == 0 && mask4) rc = launch_roi_dependence(d2, st, nb);
-            if (rc == 0 && (mask3 & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
-        }
+        rc = (gs & 1) ? launch_roi_features(a2, st, nb) : 0;
+        if (rc == 0 && (gs & 2)) rc = launch_roi_texture(t2, st, nb);
+        if (rc == 0 && (gs & 8)) rc = launch_roi_dependence(d2, st, nb);
+        if (rc == 0 && (gs & 4) && (mask & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
@@ -1139,15 +1284,19 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_glcm_ng, need + need / 4));
             ctx->glcm_ng_bytes = need + need / 4;
         }
+        // 0 = "nothing to derive": an ROI whose feature kernel returns before it states its matrix order (error paths) must not leave
+        // glcm_features_kernel a stale order from an earlier call
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_glcm_ng, 0, 4ull * n_roi, st));
     }
-    auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, uint32_t grid, uint32_t class_mask = 0, uint32_t group_sel = 0xF) -> int {
+    auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, uint32_t grid, uint32_t class_mask = 0, uint32_t group_sel = 0xF,
+                           const ClassTotals* tot = nullptr) -> int {
         ClassRun r{cls, count, E, 0, nullptr, nullptr};
         if (ctx->timing) {
             HIP_TRY(ctx, hipEventCreate(&r.e0));
             HIP_TRY(ctx, hipEventCreate(&r.e1));
             HIP_TRY(ctx, hipEventRecord(r.e0, st));
         }
-        const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, grid, false, nullptr, &r.workspace, class_mask, group_sel);
+        const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, grid, false, nullptr, &r, class_mask, group_sel, cls, tot);
         if (ctx->timing && rc == 0) HIP_TRY(ctx, hipEventRecord(r.e1, st));
         ctx->runs.push_back(r);
         return rc;
@@ -1177,7 +1326,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
                 if (!has_m1) groups.push_back({-4, Eall, 0u, 4u});
                 else {
                     groups.push_back({-4, Extrema{std::min(max_px, kClassPx[0]), std::min(max_area, sd0 * sd0), max_range, sd0}, 0x3u, 4u});
-                    groups.push_back({-5, Eall, 0xCu, 4u});
+                    groups.push_back({-5, Eall, 0x3FCu, 4u});   // (every other class: an ROI beyond the stated extrema meets the kernel's cap check and raises the error flag)
                 }
             }
             bool needs_host = false;
@@ -1205,8 +1354,9 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             uint32_t* const list = ctx->d_cls_list;
             HIP_TRY(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * kClasses * H_WORDS, st));
             const unsigned blocks = (unsigned)((b->n_roi + 255) / 256);
-            hipLaunchKernelGGL(class_count_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr);
-            hipLaunchKernelGGL(class_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr, list);
+            const uint32_t lvl_on = need_vmax ? 1u : 0u;
+            hipLaunchKernelGGL(class_count_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr, lvl_on);
+            hipLaunchKernelGGL(class_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->n_roi, b->px_offset, b->bbox_w, b->bbox_h, b->min_inten, b->max_inten, hdr, list, lvl_on);
             if (hipError_t e = hipGetLastError(); e != hipSuccess)
                 return fail(ctx, NYXHIP_ERR_HIP, std::string("classifier launch failed: ") + hipGetErrorString(e));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cls_hdr, hdr, sizeof(uint32_t) * kClasses * H_WORDS, hipMemcpyDeviceToHost, st));
@@ -1224,7 +1374,9 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
                 const uint32_t* h = H + cls * H_WORDS;
                 if (h[H_COUNT] == 0) continue;
                 const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE], h[H_VMAX], (cls & 1) != 0 && cls / 2 < kSizeClasses - 1};
-                if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], h[H_COUNT]))
+                const ClassTotals tot{((uint64_t)h[H_SUMPX_HI] << 32) | h[H_SUMPX], ((uint64_t)h[H_SUMAREA_HI] << 32) | h[H_SUMAREA],
+                                      ((uint64_t)h[H_SUMRANGE_HI] << 32) | h[H_SUMRANGE]};
+                if (int rc = timed_class(cls, h[H_COUNT], E, list + h[H_OFFSET], h[H_COUNT], 0, 0xF, &tot))
                     return rc;
             }
         }
@@ -1351,6 +1503,8 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_glcm_ng) (void)hipFree(ctx->d_glcm_ng);
     if (ctx->d_logtab) (void)hipFree(ctx->d_logtab);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
+    if (ctx->d_large) (void)hipFree(ctx->d_large);
+    if (ctx->d_large_aux) (void)hipFree(ctx->d_large_aux);
     clear_runs(ctx);
     if (ctx->d_cls_list) (void)hipFree(ctx->d_cls_list);
     if (ctx->d_cls_hdr) (void)hipFree(ctx->d_cls_hdr);
@@ -1628,30 +1782,37 @@ static int tiles_chunk(nyxhip_ctx* ctx, const void* d_inten, int dtI, const void
     const size_t o_cx = c; c = al(c + 2 * npx);
     const size_t o_cy = c; c = al(c + 2 * npx);
     const size_t o_cv = c; c = al(c + 4 * npx);
-    char* cb = nullptr;
-    int rc = 0;
-    if (!window) {
+    nyxhip_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
+    b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
+    b.slide_min = R.slide_min; b.slide_max = R.slide_max;
+    b.memory = NYXHIP_MEM_DEVICE;
+    auto make_clouds = [&]() -> int {
         if (int grc = grow(ctx, &ctx->d_cloud, &ctx->cloud_bytes, c, st)) return grc;
-        cb = (char*)ctx->d_cloud;
-        rc = launch_tile_clouds(d_inten, dtI, d_label, dtL, W, H, R, (uint32_t)n_roi, (uint16_t*)(cb + o_cx), (uint16_t*)(cb + o_cy), (uint32_t*)(cb + o_cv), st);
+        char* const cb = (char*)ctx->d_cloud;
+        const int rc = launch_tile_clouds(d_inten, dtI, d_label, dtL, W, H, R, (uint32_t)n_roi, (uint16_t*)(cb + o_cx), (uint16_t*)(cb + o_cy), (uint32_t*)(cb + o_cv), st);
         if (rc) return fail(ctx, NYXHIP_ERR_HIP, std::string("cloud kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
-    }
+        b.x = (const uint16_t*)(cb + o_cx); b.y = (const uint16_t*)(cb + o_cy); b.inten = (const uint32_t*)(cb + o_cv);
+        return NYXHIP_OK;
+    };
+    if (!window)
+        if (int crc = make_clouds()) return crc;
     HIP_TRY(ctx, hipMemcpyAsync(d_lab, R.label, 4 * n_roi, hipMemcpyDeviceToDevice, st));
     if (d_til) {
         if (tile_base == 0) HIP_TRY(ctx, hipMemcpyAsync(d_til, R.tile, 4 * n_roi, hipMemcpyDeviceToDevice, st));
         else hipLaunchKernelGGL(add_offset_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.tile, tile_base, (uint32_t)n_roi, d_til);
     }
-    nyxhip_batch b;
-    memset(&b, 0, sizeof(b));
-    b.n_roi = n_roi; b.roi_label = R.label; b.px_offset = R.px_offset;
-    if (!window) { b.x = (const uint16_t*)(cb + o_cx); b.y = (const uint16_t*)(cb + o_cy); b.inten = (const uint32_t*)(cb + o_cv); }
-    b.bbox_w = R.bbox_w; b.bbox_h = R.bbox_h; b.min_inten = R.vmin; b.max_inten = R.vmax;
-    b.slide_min = R.slide_min; b.slide_max = R.slide_max;
-    b.memory = NYXHIP_MEM_DEVICE;
     if (window)
         ctx->win_next = WindowSrc{d_inten, d_label, dtI, dtL, W, H, R.tile, R.label, R.bbox_x0, R.bbox_y0};
-    const int lrc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+    int lrc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
     ctx->win_next = WindowSrc{};
+    if (lrc == NYXHIP_INTERNAL_NEEDS_CLOUDS) {
+        // a size class of this chunk does not run from LDS under these settings (the whole-chunk extrema above could not tell: classes
+        // get layouts of their own -- IBSI matrix orders, radix sort buffers of the wide-range classes): the workspace paths read clouds
+        if (int crc = make_clouds()) return crc;
+        lrc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
+    }
     return lrc;
 }
 
@@ -2042,8 +2203,8 @@ int nyxhip_launch_report(nyxhip_ctx* ctx, char* buf, size_t buf_len)
         }
         char one[384];
         snprintf(one, sizeof(one), "%s{\"class\": %d, \"size_class\": %d, \"wide_range\": %d, \"rois\": %u, \"max_px\": %u, \"max_bbox_area\": %u, "
-                 "\"max_range\": %u, \"max_side\": %u, \"workspace\": %d, \"ms\": %s}", i ? ", " : "", r.cls, r.cls < 0 ? -1 : r.cls / 2, r.cls < 0 ? -1 : r.cls & 1,
-                 r.count, r.E.px, r.E.area, r.E.range, r.E.side, r.workspace, ms);
+                 "\"max_range\": %u, \"max_side\": %u, \"workspace\": %d, \"cooperative\": %d, \"ms\": %s}", i ? ", " : "", r.cls, r.cls < 0 ? -1 : r.cls / 2, r.cls < 0 ? -1 : r.cls & 1,
+                 r.count, r.E.px, r.E.area, r.E.range, r.E.side, r.workspace, r.cooperative, ms);
         js += one;
     }
     js += "]";

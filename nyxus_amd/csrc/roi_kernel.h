@@ -16,13 +16,23 @@ constexpr int kMaxAngles = 4;
 // ---- size classes (launch_device_all of nyxhip_api.hip) -------------------------------------------------------------------------
 // Class of an ROI = 2 * size class + (1: its pixel count or intensity range rules the 16-bit tables out).  Size class k of
 // 0 .. 3: n_px <= kClassPx[k] and both box sides <= kClassSide[k]; 4: everything larger.  A function of the ROI alone.
+// Size classes 0 .. 2 run from LDS (their carve-outs at the CLASS BOUNDS fit a CU for every setting the LDS kernels serve -- checked
+// per call on the host, run_class), classes 3 and 4 take the large-ROI path (roi_large.hip: several workgroups per ROI).  So that
+// "LDS or large" is a function of the ROI and the settings alone -- never of the ROIs that share its call -- an ROI of size
+// class 2 whose intensity range needs 32-bit sort keys (range >= 65536: two key buffers of 4 B per pixel do not fit next to a
+// 128 x 128 plane) counts as size class 3, and so does any ROI whose IBSI level count (lvl = its largest intensity under IBSI, 0
+// otherwise) exceeds kLdsLevels: the co-occurrence matrix of such an ROI is sized by its own intensities.
 constexpr int kSizeClasses = 5, kClasses = 2 * kSizeClasses;
 constexpr uint32_t kClassPx[kSizeClasses - 1] = {256, 4096, 16384, 32768};
 constexpr uint32_t kClassSide[kSizeClasses - 1] = {32, 64, 128, 256};
-__host__ __device__ inline int roi_class(uint32_t n, uint32_t w, uint32_t h, uint32_t range)
+constexpr uint32_t kLdsLevels = 128;          // largest IBSI matrix order the LDS launches of size classes 0 .. 2 are sized for
+constexpr int kFirstLargeSizeClass = 3;
+__host__ __device__ inline int roi_class(uint32_t n, uint32_t w, uint32_t h, uint32_t range, uint32_t lvl = 0)
 {
     const uint32_t side = w > h ? w : h;
-    const int sc = (n <= 256u && side <= 32u) ? 0 : (n <= 4096u && side <= 64u) ? 1 : (n <= 16384u && side <= 128u) ? 2 : (n <= 32768u && side <= 256u) ? 3 : 4;
+    int sc = (n <= 256u && side <= 32u) ? 0 : (n <= 4096u && side <= 64u) ? 1 : (n <= 16384u && side <= 128u) ? 2 : (n <= 32768u && side <= 256u) ? 3 : 4;
+    if (sc == 2 && range >= 65536u) sc = 3;
+    if (sc < 3 && lvl > kLdsLevels) sc = 3;
     const bool c16 = n < 65536u && range < 16384u;       // the 16-bit counting tables of roi_features.hip (LdsLayout::cnt16) can serve this ROI
     return 2 * sc + (c16 ? 0 : 1);
 }
@@ -43,6 +53,8 @@ struct SpillArgs {
     // everybody else returns at once (the kernel derives the class from what it loads anyway: no list, no dependent load in
     // front of the ROI's own data).  0 = no filter.
     uint32_t class_mask;
+    uint32_t min_range;          // workspace launches of the feature kernel: serve only ROIs whose intensity range reaches this (0: all) -- the
+                                 // rest of the class went through the histogram path of roi_large.hip
 };
 __device__ __forceinline__ bool roi_in_launch(const SpillArgs& sp, uint32_t n, uint32_t w, uint32_t h, uint32_t range)
 {
@@ -359,6 +371,70 @@ int launch_tile_rank(TileRows U, const uint32_t* tile_row_begin, const unsigned 
                      uint32_t max_rows_per_tile, int slide_mode, const double* smin, const double* smax, void* stream);
 int launch_tile_clouds(const void* inten, int dt_inten, const void* label, int dt_label, uint32_t W, uint32_t H, TileRows R, uint32_t n_roi,
                        uint16_t* cx, uint16_t* cy, uint32_t* cv, void* stream);
+
+// ---- large-ROI path: INTENSITY + GLCM of an ROI by several workgroups (roi_large.hip) ---------------------------------------------
+// The reference gives any ROI to any worker (/root/reference/src/nyx/parallel.h:23-42); here an ROI beyond the LDS classes is cut
+// into slabs of its pixel cloud (load pass) and strips of its bounding-box plane (co-occurrence pass), every slab / strip a
+// workgroup of its own, and everything the slabs exchange is an INTEGER added with atomics into the ROI's block of a global
+// workspace -- the intensity histogram over [min, max], the two exact sums, the co-occurrence counts -- so the result does not
+// depend on how many workgroups shared the ROI or in which order they arrived.  A last kernel (one workgroup per ROI) derives the
+// 36 + 30 n_angles + 29 columns from that state: every first-order feature is a function of the histogram alone.
+constexpr uint32_t kLargeRangeMax = 1u << 22;     // histogram entries per ROI (wider ranges: the one-workgroup sort path of roi_features.hip)
+constexpr uint32_t kLargeCells = 8192;            // plane cells per co-occurrence workgroup (whole rows)
+struct LargeWs {                                  // byte offsets inside an ROI's workspace block
+    uint64_t tab, lvl, plane, P, scr, total;
+};
+constexpr uint32_t kLargeScratchLds = 48 * 1024;  // GLCM feature scratch of the finishing kernel: in LDS up to this size, else in the ROI's block
+__host__ __device__ inline uint64_t large_glcm_scratch_bytes(uint32_t ng) { return 8ull * ((uint64_t)ng + kMaxAngles * 32ull + kMaxAngles * 6ull * ng); }
+// ng: bound of the ROI's matrix order (grey depth, or its largest intensity under IBSI); lvl_cap: radiomics bin count (0: none)
+__host__ __device__ inline LargeWs large_ws_layout(uint32_t range, uint64_t area, uint32_t ng, uint32_t lvl_cap, uint32_t na, bool plane16, bool do_int, bool do_glcm)
+{
+    LargeWs L;
+    uint64_t o = 256;                                                        // header: u64 sum, u64 sum of squares (mod 2^32 each)
+    L.tab = o; if (do_int) o += (4ull * ((uint64_t)range + 1) + 255) & ~255ull;
+    L.lvl = o; if (do_glcm && lvl_cap) o += (2ull * (lvl_cap + 8) + 255) & ~255ull;
+    L.plane = o; if (do_glcm) o += ((plane16 ? 2ull : 1ull) * area + 64 + 255) & ~255ull;
+    L.P = o; if (do_glcm) o += (4ull * na * ng * ng + 255) & ~255ull;
+    L.scr = o; if (do_glcm && large_glcm_scratch_bytes(ng) > kLargeScratchLds) o += (large_glcm_scratch_bytes(ng) + 255) & ~255ull;
+    L.total = o;
+    return L;
+}
+struct LargeArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    const double* slide_min;
+    const double* slide_max;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;                 // subset of INTENSITY | GLCM
+    int32_t n_cols, col_intensity, col_glcm;
+    double soft_nan;
+    int32_t grey_depth, ibsi, glcm_grey_depth, glcm_offset, glcm_na, glcm_symmetric;
+    int32_t glcm_angles[kMaxAngles];
+    int32_t n_hist;
+    const uint32_t* list;          // the members of this launch group (ROI indices)
+    uint32_t n_list;
+    unsigned char* ws;             // workspace of the group, zeroed before the prep kernel
+    uint64_t ws_bytes;
+    uint64_t* ws_off;              // [n_list] byte offset of a member's block (prep kernel); ~0: not served by this path
+    uint32_t* ctr;                 // [8] zeroed: 0-1 u64 cursor of workspace bytes, 2 load workgroups, 3 co-occurrence workgroups
+    uint2* map_load;               // [cap_load] (member, slab) of a load workgroup
+    uint2* map_cooc;               // [cap_cooc] (member, strip) of a co-occurrence workgroup
+    uint32_t cap_load, cap_cooc;
+    uint32_t px_per_wg;            // pixels of a slab
+    uint32_t tab_lds;              // histogram entries the load kernel counts in LDS (16-bit counters): ROIs with range < tab_lds
+    uint32_t plane16;              // 1: the plane holds 16-bit levels
+    uint32_t lds_P_bytes;          // LDS the co-occurrence kernel may use for its matrices
+};
+int launch_large_features(const LargeArgs& a, void* stream);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);

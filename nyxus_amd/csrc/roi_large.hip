@@ -1,0 +1,643 @@
+// roi_large.hip -- INTENSITY + GLCM of ROIs beyond the LDS size classes, several workgroups per ROI (gfx950).
+//
+// The reference hands any ROI to any worker thread (/root/reference/src/nyx/parallel.h:23-42, roi_cache.h:31-84); the LDS
+// kernels of roi_features.hip give an ROI one workgroup, which leaves a 120 k-pixel ROI walking its cloud with 256 threads
+// while the rest of the chip idles.  Here such an ROI is cut up:
+//
+//   large_prep_kernel    one wave per ROI: its block of the workspace, its slabs / strips in the two work maps
+//   large_load_kernel    one workgroup per SLAB of the pixel cloud (the only pass over HBM: 8 B per pixel): exact sums, the
+//                        intensity histogram over [min, max] (counted in LDS, flushed with contiguous atomic adds), the binned
+//                        bounding-box plane (features/texture_feature.h binning) scattered to the workspace
+//   large_cooc_kernel    one workgroup per STRIP of plane rows: co-occurrence counts of all angles (features/glcm.cpp:343-485)
+//                        in LDS, flushed with atomic adds
+//   large_finish_kernel  one workgroup per ROI: every first-order feature is a function of the histogram
+//                        (features/intensity.cpp:57-192, histogram.h:27-309, moments.h:48-109), the Haralick features of the
+//                        matrices (glcm_rows.h)
+//
+// Everything that crosses a workgroup is an integer added with atomics, so the result is independent of the cut and of the
+// arrival order; the floating-point sums of the last kernel run in a fixed order.  Kernel boundaries are the only
+// synchronisation (no tickets, no fences).
+//
+// Built with -ffp-contract=off (device_math.h).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "launch_util.h"
+#include "glcm_rows.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+
+namespace {
+
+// what the kernels agree on for one ROI
+struct LargeRoi {
+    uint64_t roi, off;
+    uint32_t n, w, h, vmin, vmax, range;
+    uint64_t area;
+    uint32_t ng_bound, lvl_cap;
+    LargeWs L;
+    unsigned char* base;
+};
+
+__device__ __forceinline__ bool large_roi(const LargeArgs& A, uint32_t j, LargeRoi& R, bool need_block)
+{
+    R.roi = A.list[j];
+    R.off = A.px_offset[R.roi];
+    R.n = (uint32_t)(A.px_offset[R.roi + 1] - R.off);
+    R.w = A.bbox_w[R.roi]; R.h = A.bbox_h[R.roi];
+    R.vmin = A.min_inten[R.roi]; R.vmax = A.max_inten[R.roi];
+    R.range = R.vmax - R.vmin;
+    R.area = (uint64_t)R.w * R.h;
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    R.ng_bound = greyInfo > 0 ? (uint32_t)greyInfo : greyInfo < 0 ? (uint32_t)(-greyInfo) : R.vmax;
+    R.lvl_cap = greyInfo < 0 ? (uint32_t)(-greyInfo) : 0u;
+    R.L = large_ws_layout(R.range, R.area, R.ng_bound, R.lvl_cap, (uint32_t)A.glcm_na, A.plane16 != 0, (A.mask & NYXHIP_FAM_INTENSITY) != 0,
+                          (A.mask & NYXHIP_FAM_GLCM) != 0);
+    R.base = nullptr;
+    if (need_block) {
+        const uint64_t o = A.ws_off[j];
+        if (o == ~0ull) return false;
+        R.base = A.ws + o;
+    }
+    return true;
+}
+
+// served here: a non-empty ROI whose histogram the workspace can hold (wider ranges take the sort path of roi_features.hip)
+__device__ __forceinline__ bool large_served(const LargeRoi& R) { return R.n != 0 && R.range < kLargeRangeMax; }
+
+__device__ __forceinline__ uint32_t rows_per_strip(uint32_t w) { const uint32_t r = kLargeCells / (w ? w : 1u); return r ? r : 1u; }
+
+// ---- prep: one wave per member -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void large_prep_kernel(const LargeArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= A.n_list) return;
+    LargeRoi R;
+    large_roi(A, j, R, false);
+    if (!large_served(R)) {
+        if (lane == 0) A.ws_off[j] = ~0ull;
+        return;
+    }
+    const uint32_t g_load = (R.n + A.px_per_wg - 1) / A.px_per_wg;
+    const uint32_t rps = rows_per_strip(R.w);
+    const uint32_t g_cooc = (A.mask & NYXHIP_FAM_GLCM) ? (R.h + rps - 1) / rps : 0u;
+    unsigned long long off = 0;
+    uint32_t b_load = 0, b_cooc = 0;
+    if (lane == 0) {
+        off = atomicAdd((unsigned long long*)A.ctr, (unsigned long long)R.L.total);
+        b_load = atomicAdd(&A.ctr[2], g_load);
+        b_cooc = g_cooc ? atomicAdd(&A.ctr[3], g_cooc) : 0u;
+    }
+    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+    b_load = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_load);
+    b_cooc = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_cooc);
+    const bool fits = off + R.L.total <= A.ws_bytes && (uint64_t)b_load + g_load <= A.cap_load && (uint64_t)b_cooc + g_cooc <= A.cap_cooc;
+    if (!fits) {                                        // (the host sized all three from the class totals: cannot happen)
+        if (lane == 0) { A.ws_off[j] = ~0ull; atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE); }
+        return;
+    }
+    if (lane == 0) A.ws_off[j] = off;
+    for (uint32_t s = lane; s < g_load; s += 64) A.map_load[b_load + s] = make_uint2(j, s);
+    for (uint32_t s = lane; s < g_cooc; s += 64) A.map_cooc[b_cooc + s] = make_uint2(j, s);
+}
+
+// ---- load: one workgroup per slab of the cloud --------------------------------------------------------------------------------
+template <bool P16>
+__global__ __launch_bounds__(1024) void large_load_kernel(const LargeArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= A.ctr[2]) return;
+    const uint2 job = A.map_load[blockIdx.x];
+    LargeRoi R;
+    if (!large_roi(A, job.x, R, true)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, BS = blockDim.x, NWV = BS >> 6;
+    const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0, do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
+    uint32_t* const s_tab = (uint32_t*)lds_raw;                              // [tab_lds / 2] words of two 16-bit counters
+    unsigned long long* const s_red = (unsigned long long*)(lds_raw + 2ull * A.tab_lds);   // [2 * 16]
+    unsigned long long* const hdr = (unsigned long long*)R.base;
+    uint32_t* const T = (uint32_t*)(R.base + R.L.tab);
+    uint16_t* const flags = (uint16_t*)(R.base + R.L.lvl);
+    using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
+    plane_t* const plane = (plane_t*)(R.base + R.L.plane);
+    const bool tab_in_lds = do_int && R.range < A.tab_lds;                   // (a slab has < 65536 pixels: 16-bit counters never carry)
+    if (tab_in_lds) {
+        for (uint32_t i = tid; i < (R.range + 2) / 2; i += BS) s_tab[i] = 0;
+        __syncthreads();
+    }
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)R.vmax - 0.) : 0.0;
+    const uint32_t p0 = job.y * A.px_per_wg, p1 = p0 + A.px_per_wg < R.n ? p0 + A.px_per_wg : R.n;
+    const uint32_t* const gv = A.inten + R.off;
+    const uint16_t* const gx = A.x + R.off;
+    const uint16_t* const gy = A.y + R.off;
+    unsigned long long sum = 0, sumsq = 0;
+    constexpr int kU = 4;
+    for (uint32_t base = p0; base < p1; base += kU * BS) {
+        uint32_t v[kU], px[kU], py[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {                                        // every load of the trip before the first use
+            const uint32_t i = base + u * BS + tid;
+            const bool in = i < p1;
+            v[u] = in ? gv[i] : 0u;
+            px[u] = (in && do_glcm) ? gx[i] : 0u;
+            py[u] = (in && do_glcm) ? gy[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            if (base + u * BS + tid >= p1) continue;
+            sum += v[u];
+            sumsq += (uint32_t)(v[u] * v[u]);                                 // unsigned-int product, wraps (intensity.cpp:90)
+            if (do_int) {
+                const uint32_t ci = v[u] - R.vmin;
+                if (tab_in_lds) atomicAdd(&s_tab[ci >> 1], 1u << (16 * (ci & 1u)));
+                else if (ci <= R.range) atomicAdd(&T[ci], 1u);
+            }
+            if (do_glcm) {
+                uint32_t lvl = 0;
+                if (v[u] != 0) {                                               // original intensity 0 is skipped by the scan (glcm.cpp:445)
+                    lvl = greyInfo > 0 ? bin_matlab(v[u], mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v[u], R.vmin, R.vmax, -greyInfo) : v[u];
+                    if (greyInfo < 0 && lvl <= R.lvl_cap) flags[lvl] = 1;
+                }
+                const uint64_t cell = (uint64_t)py[u] * R.w + px[u];
+                if (px[u] < R.w && cell < R.area)
+                    plane[cell] = (plane_t)(lvl > (P16 ? 0xFFFFu : 0xFFu) ? (P16 ? 0xFFFFu : 0xFFu) : lvl);
+            }
+        }
+    }
+    sum = wave_sum_u64(sum);
+    sumsq = wave_sum_u64(sumsq);
+    if (lane == 0) { s_red[wave] = sum; s_red[16 + wave] = sumsq; }
+    __syncthreads();                                                          // (also: every LDS count of the slab is in)
+    if (tid == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int wv = 0; wv < NWV; wv++) { a += s_red[wv]; b += s_red[16 + wv]; }
+        atomicAdd(&hdr[0], a);
+        atomicAdd(&hdr[1], b);
+    }
+    if (tab_in_lds) {
+        const uint16_t* const t16 = (const uint16_t*)s_tab;
+        for (uint32_t i = tid; i <= R.range; i += BS) {                       // contiguous adds: a wave covers 256 bytes of the table
+            const uint32_t c = t16[i];
+            if (c) atomicAdd(&T[i], c);
+        }
+    }
+}
+
+// ---- co-occurrence: one workgroup per strip of plane rows ---------------------------------------------------------------------
+// matrix order and level -> matrix index of an ROI (glcm.cpp:388-420): s_map[level] = index + 1 (0 = skip) under radiomics binning
+template <typename MAP>
+__device__ __forceinline__ int large_matrix_order(const LargeArgs& A, const LargeRoi& R, MAP* s_map, double* s_I, int tid, int BS)
+{
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    if (greyInfo > 0) return greyInfo;
+    if (greyInfo == 0) return (int)R.vmax;                                   // IBSI: the largest level is the largest intensity
+    const uint16_t* const flags = (const uint16_t*)(R.base + R.L.lvl);
+    __shared__ int s_ng;
+    if (tid == 0) {
+        int k = 0;
+        for (uint32_t l = 1; l <= R.lvl_cap; l++) {
+            const bool on = flags[l] != 0;
+            if (s_map) s_map[l] = on ? (MAP)(k + 1) : (MAP)0;
+            if (on) { if (s_I) s_I[k] = (double)l; k++; }
+        }
+        s_ng = k;
+    }
+    __syncthreads();
+    return s_ng;
+}
+
+template <bool P16>
+__global__ __launch_bounds__(256) void large_cooc_kernel(const LargeArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= A.ctr[3]) return;
+    const uint2 job = A.map_cooc[blockIdx.x];
+    LargeRoi R;
+    if (!large_roi(A, job.x, R, true)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int BS = 256, NW = 4;
+    // degenerate guard (glcm.cpp:27-95, on GLCM_GREYDEPTH): nothing to count
+    if (bin_pixel(R.vmin, R.vmin, R.vmax, A.glcm_grey_depth) == bin_pixel(R.vmax, R.vmin, R.vmax, A.glcm_grey_depth)) return;
+    const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+    uint16_t* const s_map = (uint16_t*)lds_raw;                               // [lvl_cap + 2] (radiomics only)
+    const uint32_t map_bytes = greyInfo < 0 ? ((2u * (R.lvl_cap + 2) + 15u) & ~15u) : 0u;
+    uint32_t* const s_P = (uint32_t*)(lds_raw + map_bytes);
+    const int Ng = large_matrix_order<uint16_t>(A, R, greyInfo < 0 ? s_map : nullptr, (double*)nullptr, tid, BS);
+    if (Ng <= 0) return;
+    const int na = A.glcm_na;
+    const uint64_t NN = (uint64_t)Ng * Ng;
+    uint32_t* const gP = (uint32_t*)(R.base + R.L.P);
+    const bool in_lds = 4ull * na * NN + map_bytes <= A.lds_P_bytes;
+    uint32_t* const P = in_lds ? s_P : gP;
+    if (in_lds) {
+        for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) s_P[i] = 0;
+        __syncthreads();
+    }
+    const bool symmetric = A.glcm_symmetric || greyInfo <= 0;                 // glcm.cpp:475
+    int ddx[kMaxAngles], ddy[kMaxAngles];
+#pragma unroll
+    for (int q = 0; q < kMaxAngles; q++) {
+        const int ang = A.glcm_angles[q < na ? q : 0];                        // glcm.cpp:234-255
+        ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
+        ddy[q] = ang == 0 ? 0 : A.glcm_offset;
+    }
+    using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
+    const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
+    const uint32_t rps = rows_per_strip(R.w);
+    const uint32_t r0 = job.y * rps, r1 = r0 + rps < R.h ? r0 + rps : R.h;
+    const int w = (int)R.w, h = (int)R.h;
+    for (uint32_t row = r0 + wave; row < r1; row += NW) {
+        const plane_t* const prow = plane + (uint64_t)row * R.w;
+        for (int col = lane; col < w; col += 64) {
+            const uint32_t lb = prow[col];
+            if (lb == 0) continue;
+            const int ib = greyInfo < 0 ? (int)s_map[lb] - 1 : (int)lb - 1;
+#pragma unroll
+            for (int q = 0; q < kMaxAngles; q++) {
+                if (q >= na) break;
+                const int r2 = (int)row + ddy[q], c2 = col + ddx[q];
+                if (r2 < 0 || r2 >= h || c2 < 0 || c2 >= w) continue;
+                const uint32_t la = plane[(uint64_t)r2 * R.w + (uint32_t)c2];
+                if (la == 0) continue;
+                const int ia = greyInfo < 0 ? (int)s_map[la] - 1 : (int)la - 1;
+                atomicAdd(&P[q * NN + (uint64_t)ib * Ng + ia], 1u);
+                if (symmetric) atomicAdd(&P[q * NN + (uint64_t)ia * Ng + ib], 1u);
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) {
+            const uint32_t c = s_P[i];
+            if (c) atomicAdd(&gP[i], c);
+        }
+    }
+}
+
+// ---- finish: one workgroup per ROI ----------------------------------------------------------------------------------------------
+// fixed-order workgroup sums (wave DPP tree, then the four wave partials in wave order); every thread gets the totals
+template <int N>
+__device__ __forceinline__ void wg_sum(double (&v)[N], double* s_x, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; k++) s_x[wave * 8 + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = ((s_x[k] + s_x[8 + k]) + s_x[16 + k]) + s_x[24 + k];
+}
+__device__ __forceinline__ unsigned long long wg_sum_u64(unsigned long long v, unsigned long long* s_x, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    v = wave_sum_u64(v);
+    __syncthreads();
+    if (lane == 0) s_x[wave] = v;
+    __syncthreads();
+    return s_x[0] + s_x[1] + s_x[2] + s_x[3];
+}
+
+__global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    LargeRoi R;
+    if (blockIdx.x >= A.n_list || !large_roi(A, blockIdx.x, R, true)) return;
+    constexpr int BS = 256, NW = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0, do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
+    double* const out_row = A.out + R.roi * A.ld;
+    for (int c = tid; c < A.n_cols; c += BS) out_row[c] = 0.0;               // skipped features stay 0 (class members default to 0)
+    __shared__ double s_x[32];
+    __shared__ unsigned long long s_u[8];
+    __shared__ double s_stat[8];
+    __shared__ double s_pq[8];
+    __shared__ uint32_t s_w[16];
+    const uint32_t n = R.n, vmin = R.vmin, vmax = R.vmax, range = R.range;
+    const double dn = (double)n;
+    __syncthreads();
+
+    if (do_int) {
+        double* const o = out_row + A.col_intensity;
+        const unsigned long long* const hdr = (const unsigned long long*)R.base;
+        uint32_t* const T = (uint32_t*)(R.base + R.L.tab);                    // counts, then (in place) inclusive prefix sums
+        const double tot = (double)hdr[0], totsq = (double)hdr[1];
+        const double mean = tot / dn;
+        const bool blank = vmin == 0 && vmax == 0;                            // intensity.cpp:121-122
+        if (tid == 0) {
+            o[I_MIN] = (double)vmin;                                           // intensity.cpp:67-69
+            o[I_MAX] = (double)vmax;
+            o[I_RANGE] = (double)vmax - (double)vmin;
+            if (A.slide_min && A.slide_max)                                    // intensity.cpp:72-77
+                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[R.roi] - A.slide_min[R.roi]);
+            o[I_MEAN] = mean;                                                  // intensity.cpp:95-99
+            o[I_ENERGY] = totsq;
+            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
+            o[I_INTEGRATED_INTENSITY] = tot;
+            if (!blank)
+                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0;   // :162
+        }
+        // ---- sweep 1 over the histogram: central sums (intensity.cpp:102-109, :177-183; M2..M4 of moments.h:53-74 equal the plain
+        // central sums), the mode (largest count, smallest value on ties: histogram.h:289-309), inclusive prefix sums in place
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t best_c = 0, best_i = 0, carry = 0;
+        for (uint32_t i0 = 0; i0 <= range; i0 += BS * 4) {
+            const uint32_t i = i0 + 4u * (uint32_t)tid;
+            uint32_t c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = i + k <= range ? T[i + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (c[k] > best_c) { best_c = c[k]; best_i = i + k; }
+                if (c[k] && !blank) {
+                    const double cd = (double)c[k], d = (double)(vmin + i + k) - mean, d2 = d * d;
+                    acc[0] += cd * fabs(d);
+                    acc[1] += cd * d2;
+                    acc[2] += cd * (d2 * d);
+                    acc[3] += cd * (d2 * d2);
+                    acc[4] += cd * (d2 * d2 * d);
+                    acc[5] += cd * (d2 * d2 * d2);
+                }
+            }
+            c[1] += c[0]; c[2] += c[1]; c[3] += c[2];
+            const uint32_t sc = wave_scan_u32(c[3]);
+            __syncthreads();
+            if (lane == 63) s_w[wave] = sc;
+            __syncthreads();
+            uint32_t excl = carry + sc - c[3];
+            for (int wv = 0; wv < wave; wv++) excl += s_w[wv];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k <= range) T[i + k] = c[k] + excl;
+            carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        }
+        {   // mode: (count desc, index asc) over the workgroup
+            const uint32_t mc_w = wave_max_u32(best_c);
+            const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
+            const uint32_t bi_w = ~wave_max_u32(~cand);
+            __syncthreads();
+            if (lane == 0) { s_w[4 + wave] = mc_w; s_w[8 + wave] = bi_w; }
+        }
+        wg_sum<6>(acc, s_x, tid);                                             // (its barriers also publish the mode words and the prefix sums)
+        __threadfence_block();
+        auto cum = [=](uint32_t i) -> uint32_t { return T[i]; };              // number of values <= vmin + i
+        if (tid == 0) {
+            uint32_t mc = 0, mi = 0;
+            for (int wv = 0; wv < NW; wv++) {
+                const uint32_t c = s_w[4 + wv], i = s_w[8 + wv];
+                if (c > mc || (c == mc && i < mi)) { mc = c; mi = i; }
+            }
+            if (!blank) o[I_MODE] = (double)(vmin + mi);
+            // everything that depends only on the central sums (intensity.cpp:110-118, :166-191)
+            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
+            const double variance = dn > 1 ? acc[1] / (dn - 1) : 0.0, variance_b = dn > 1 ? acc[1] / dn : 0.0;
+            const double sd = sqrt(variance);
+            o[I_VARIANCE] = variance;
+            o[I_VARIANCE_BIASED] = variance_b;
+            o[I_STANDARD_DEVIATION] = sd;
+            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
+            o[I_COV] = sd / mean;
+            o[I_STANDARD_ERROR] = sd / sqrt(dn);
+            if (!blank) {
+                const double M2 = acc[1], M3 = acc[2], M4 = acc[3];           // moments.h:79-109
+                if (M2 != 0.0) {
+                    const double kurt = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
+                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / (M2 * sqrt(M2)) : 0.0;
+                    o[I_KURTOSIS] = kurt;
+                    o[I_EXCESS_KURTOSIS] = n > 4 ? kurt - 3 : 0.0;
+                }
+                const double sd2 = sd * sd, d5 = dn * (sd2 * sd2 * sd), d6 = dn * (sd2 * sd2 * sd2);   // intensity.cpp:186-191
+                o[I_HYPERSKEWNESS] = d5 == 0. ? 0. : acc[4] / d5;
+                o[I_HYPERFLATNESS] = d6 == 0. ? 0. : acc[5] / d6;
+            }
+        }
+        if (!blank) {
+            // ---- histogram bin populations (histogram.h:55-78): lower bounds of the 100 percentile bins and the n custom bins over
+            // the value domain -- the bin index is monotone in the value, so a bin's population is a difference of prefix sums
+            const uint32_t nb = (uint32_t)A.n_hist;
+            uint32_t* const s_lb100 = (uint32_t*)lds_raw;                     // [104]
+            uint32_t* const s_lbc = s_lb100 + 104;                            // [nb + 8]
+            const double binW100 = (double)range / 100.;
+            for (uint32_t t = tid; t < 100 + nb; t += BS) {
+                const bool is100 = t < 100;
+                const uint32_t b = is100 ? t : t - 100;
+                auto bin_of = [=](uint32_t dd) -> uint32_t {
+                    if (is100) {
+                        const double realIdx = (double)dd / binW100;          // (h - minVal) / binW100, histogram.h:57-60
+                        return (realIdx != realIdx) ? 0u : (uint32_t)(int)realIdx;
+                    }
+                    return to_grayscale(vmin + dd, vmin, range, nb);
+                };
+                // smallest offset d in [0, range + 1] whose bin index reaches b: start from the real-valued boundary and settle with
+                // the exact (reference) bin function
+                const double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
+                uint32_t d = !(edge < (double)range + 1.0) ? range + 1 : (uint32_t)edge;
+                while (d > 0 && bin_of(d - 1) >= b) d--;
+                while (d <= range && bin_of(d) < b) d++;
+                const uint32_t lo = d > 0 ? cum(d - 1) : 0u;
+                if (is100) s_lb100[b] = lo; else s_lbc[b] = lo;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // percentiles P01, P10, P25, P75, P90, P99 (histogram.h:214-243): the LAST bin i with runSum_i <= cnt <= runSum_i + bins_i
+                // wins (every matching bin overwrites); runSum_i is the lower bound of bin i.  Lanes test bins i and i + 64.
+                const int i0 = lane, i1 = lane + 64;
+                const uint32_t r0 = s_lb100[i0], e0 = (i0 < 99 ? s_lb100[i0 + 1] : n);
+                const uint32_t r1 = i1 < 100 ? s_lb100[i1] : 0u, e1 = i1 < 100 ? (i1 < 99 ? s_lb100[i1 + 1] : n) : 0u;
+                int mywin = -1;
+                double mycnt = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double frac = q == 0 ? 0.01 : q == 1 ? 0.1 : q == 2 ? 0.25 : q == 3 ? 0.75 : q == 4 ? 0.9 : 0.99;
+                    const double cnt_p = dn * frac;
+                    const bool m0 = (double)r0 <= cnt_p && cnt_p <= (double)e0;
+                    const bool m1 = i1 < 100 && (double)r1 <= cnt_p && cnt_p <= (double)e1;
+                    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+                    const int win = b1 ? 64 + (63 - __clzll((long long)b1)) : (b0 ? 63 - __clzll((long long)b0) : -1);
+                    if (lane == q) { mywin = win; mycnt = cnt_p; }
+                }
+                double pv = 0;
+                if (mywin >= 0) {
+                    const uint32_t rs = s_lb100[mywin], bi = (mywin < 99 ? s_lb100[mywin + 1] : n) - rs;
+                    pv = (mycnt - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)mywin;
+                }
+                if (lane < 6) s_pq[lane] = pv;
+                wav_sync<false>();
+                if (lane == 0) {
+                    const double* const pq = s_pq;
+                    o[I_P01] = pq[0]; o[I_P10] = pq[1]; o[I_P25] = pq[2]; o[I_P75] = pq[3]; o[I_P90] = pq[4]; o[I_P99] = pq[5];
+                    o[I_QCOD] = (pq[3] - pq[2]) / (pq[3] + pq[2]);
+                    o[I_INTERQUARTILE_RANGE] = pq[3] - pq[2];
+                    s_stat[0] = pq[1];
+                    s_stat[1] = pq[4];
+                }
+            }
+            if (wave == 2) {
+                // median (histogram.h:268-287): order statistics n/2 and n/2 - 1 = smallest i with cum(i) > k, by a 64-way search
+                auto kth = [&](uint32_t k) -> uint32_t {
+                    uint32_t lo = 0, span = range + 1;                       // the answer lies in [lo, lo + span)
+                    while (span > 1) {
+                        const uint32_t B = (span + 63) >> 6;
+                        uint64_t i64 = (uint64_t)lo + (uint64_t)((uint32_t)lane + 1) * B - 1;   // last position of this lane's block
+                        const uint32_t i = i64 > range ? range : (uint32_t)i64;
+                        const unsigned long long hit = __ballot(cum(i) > k);
+                        const uint32_t first = hit ? (uint32_t)__builtin_ctzll(hit) : 63u;
+                        lo += first * B;
+                        span = (uint64_t)lo + B > (uint64_t)range + 1 ? range + 1 - lo : B;
+                    }
+                    return lo;
+                };
+                const uint32_t hi_v = vmin + kth(n / 2), lo_v = vmin + kth(n / 2 ? n / 2 - 1 : 0);
+                if (lane == 0) {
+                    const double median = (n & 1) ? (double)hi_v : (double)(uint32_t)(hi_v + lo_v) / 2.0;
+                    o[I_MEDIAN] = median;
+                    s_stat[2] = median;
+                }
+            }
+            if (wave == 1) {
+                // entropy / uniformity over the n + 1 slots (histogram.h:145-151): slot n is empty
+                double e = 0, u = 0;
+                for (uint32_t k = lane; k < nb; k += 64) {
+                    const uint32_t ck = (k < nb - 1 ? s_lbc[k + 1] : n) - s_lbc[k];
+                    const double p = (double)ck / dn;
+                    e += p * log2(p + 2.2e-16);
+                    u += p * p;
+                }
+                e = wave_sum(e);
+                u = wave_sum(u);
+                if (lane == 0) { o[I_ENTROPY] = -e; o[I_UNIFORMITY] = u; }
+            }
+            __syncthreads();
+            // ---- robust statistics over [p10, p90] (intensity.cpp:139-149, histogram.h:90-112) and the median deviation (:156-159)
+            const double p10 = s_stat[0], p90 = s_stat[1], median = s_stat[2];
+            uint32_t lox = 1, hix = 0;                                         // empty unless the bounds say otherwise (NaN: empty)
+            if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
+                const double cl = ceil(p10), fl = floor(p90);
+                const uint32_t lo_v = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_v = fl >= (double)vmax ? vmax : (uint32_t)fl;
+                if (lo_v <= hi_v) { lox = lo_v - vmin; hix = hi_v - vmin; }
+            }
+            const bool some = lox <= hix;
+            const uint32_t K = some ? cum(hix) - (lox ? cum(lox - 1) : 0u) : 0u;
+            auto count_at = [=](uint32_t i) -> uint32_t { return cum(i) - (i ? cum(i - 1) : 0u); };
+            unsigned long long sx = 0;                                         // exact integer sum of the values inside the bounds
+            double medad[1] = {0};
+            for (uint32_t i = tid; i <= range; i += BS) {
+                const uint32_t c = count_at(i);
+                if (!c) continue;
+                if (some && i >= lox && i <= hix) sx += (unsigned long long)c * (vmin + i);
+                medad[0] += (double)c * fabs((double)(vmin + i) - median);
+            }
+            sx = wg_sum_u64(sx, s_u, tid);
+            wg_sum<1>(medad, s_x, tid);
+            const double mean1090 = K ? (double)sx / (double)K : 0.0;
+            double ad[1] = {0};
+            if (K)
+                for (uint32_t i = lox + tid; i <= hix; i += BS) {
+                    const uint32_t c = count_at(i);
+                    if (c) ad[0] += (double)c * fabs((double)(vmin + i) - mean1090);
+                }
+            wg_sum<1>(ad, s_x, tid);
+            if (tid == 0) {
+                o[I_ROBUST_MEAN] = mean1090;
+                o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? ad[0] / (double)K : 0.0;
+                o[I_MEDIAN_ABSOLUTE_DEVIATION] = medad[0] / dn;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (do_glcm) {
+        double* const o = out_row + A.col_glcm;
+        const int na = A.glcm_na, ncol_g = kGlcmAngled * na + kGlcmAve;
+        const int greyInfo = A.ibsi ? 0 : A.grey_depth;
+        if (bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth)) {   // glcm.cpp:27-95
+            for (int c = tid; c < ncol_g; c += BS) o[c] = A.soft_nan;
+            return;
+        }
+        // level values | per-angle features | per-angle marginals: in LDS up to ~240 levels, else in the ROI's block (IBSI on wide data)
+        const uint32_t ngb = R.ng_bound;
+        double* const scratch = large_glcm_scratch_bytes(ngb) > kLargeScratchLds ? (double*)(R.base + R.L.scr) : (double*)lds_raw;
+        double* const s_I = scratch;
+        double* const s_f = s_I + ngb;
+        double* const s_scr = s_f + kMaxAngles * 32;
+        const int Ng = large_matrix_order<uint16_t>(A, R, (uint16_t*)nullptr, greyInfo < 0 ? s_I : (double*)nullptr, tid, BS);
+        if (greyInfo >= 0)
+            for (int i = tid; i < Ng; i += BS) s_I[i] = (double)(i + 1);
+        __syncthreads();
+        __threadfence();
+        const uint32_t* const gP = (const uint32_t*)(R.base + R.L.P);
+        const uint64_t NN = (uint64_t)Ng * Ng;
+        if (Ng <= 0) {
+            for (int c = tid; c < ncol_g; c += BS) o[c] = A.soft_nan;
+            return;
+        }
+        if (Ng <= 16) {                                   // small matrices: the angles share one wave's instruction stream
+            if (wave == 0)
+                glcm_features_rows<true, 16, 900>(gP, na, Ng, s_I, s_scr, 6 * (int)ngb, A.soft_nan, s_f, lane);
+        } else
+            for (int a0 = 0; a0 < na; a0 += NW)          // a wave per angle, 64 lanes over the cells
+                if (a0 + wave < na)
+                    glcm_features_rows<true, 64, 901>(gP + (size_t)(a0 + wave) * NN, 1, Ng, s_I, s_scr + (size_t)(a0 + wave) * 6 * ngb, 6 * (int)ngb, A.soft_nan,
+                                                      s_f + (a0 + wave) * 32, lane);
+        __syncthreads();
+        __threadfence();
+        for (int c = tid; c < kGlcmAngled * na; c += BS) {   // feature-major, angle-minor (output_2_buffer.cpp:336-346)
+            const int k = c / na, a = c - k * na;
+            o[c] = s_f[a * 32 + k];
+        }
+        for (int j = tid; j < kGlcmAve; j += BS) {           // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+            const int k = c_glcm_ave_order[j];
+            double init = 0.0;
+            int a = 0;
+            for (; na - a >= 4; a += 4) {
+                const double v1 = s_f[a * 32 + k] + s_f[(a + 1) * 32 + k];
+                const double v2 = s_f[(a + 2) * 32 + k] + s_f[(a + 3) * 32 + k];
+                init = init + (v1 + v2);
+            }
+            for (; a < na; a++) init = init + s_f[a * 32 + k];
+            o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+        }
+    }
+}
+
+} // namespace
+
+// Launches the four kernels of one group.  The caller has zeroed a.ws[0 .. ws_bytes) and a.ctr on the stream.
+int launch_large_features(const LargeArgs& a, void* stream)
+{
+    if (a.n_list == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static DeviceOnce optin;
+    if (int orc = optin.run([]() -> int {
+            // (dynamic LDS beyond 64 KiB is an opt-in per kernel; the static words of a kernel count against the CU's 160 KiB too)
+            const struct { const void* f; int bytes; } k[] = {
+                {(const void*)large_load_kernel<false>, 136 * 1024}, {(const void*)large_load_kernel<true>, 136 * 1024},
+                {(const void*)large_cooc_kernel<false>, 104 * 1024}, {(const void*)large_cooc_kernel<true>, 104 * 1024},
+                {(const void*)large_finish_kernel, 64 * 1024}};
+            for (const auto& e : k)
+                if (hipError_t rc = hipFuncSetAttribute(e.f, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes); rc != hipSuccess) return (int)rc;
+            return 0;
+        }))
+        return orc;
+    hipLaunchKernelGGL(large_prep_kernel, dim3((a.n_list + 3) / 4), dim3(256), 0, st, a);
+    const size_t lds_load = 2ull * a.tab_lds + 2 * 16 * 8;
+    const uint32_t bs_load = a.px_per_wg > 8192 ? 1024u : 256u;
+    if (a.plane16) hipLaunchKernelGGL(large_load_kernel<true>, dim3(a.cap_load), dim3(bs_load), lds_load, st, a);
+    else hipLaunchKernelGGL(large_load_kernel<false>, dim3(a.cap_load), dim3(bs_load), lds_load, st, a);
+    if (a.mask & NYXHIP_FAM_GLCM) {
+        if (a.plane16) hipLaunchKernelGGL(large_cooc_kernel<true>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes, st, a);
+        else hipLaunchKernelGGL(large_cooc_kernel<false>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes, st, a);
+    }
+    size_t lds_fin = 4ull * (104 + (size_t)a.n_hist + 8);
+    if (a.mask & NYXHIP_FAM_GLCM) lds_fin = std::max<size_t>(lds_fin, kLargeScratchLds);   // (larger scratch lives in the ROI's block)
+    hipLaunchKernelGGL(large_finish_kernel, dim3(a.n_list), dim3(256), lds_fin, st, a);
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

@@ -1,0 +1,145 @@
+"""GPU tests of the large-ROI path (nyxus_amd/csrc/roi_large.hip): ROIs beyond the LDS size classes are cut into slabs and strips,
+several workgroups per ROI, and everything the workgroups exchange is an integer added with atomics.
+
+The reference gives any ROI to any worker thread (/root/reference/src/nyx/parallel.h:23-42); what these tests pin is that the cut is
+invisible: parity with the oracle at 20 k / 100 k / 400 k pixels under every binning mode and table width, and rows that do not
+depend on the companions, the workspace budget or the chunking."""
+import os
+
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi, _lib
+from oracle import pyoracle as po
+from tests import parity
+from tests.test_size_classes_gpu import ellipse_roi
+
+pytestmark = pytest.mark.gpu
+
+MASK = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+CONFIG4 = MASK | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+
+
+def large_rois(seed=3, hi=4096):
+    """~20 k, ~100 k and ~400 k pixels, plus the awkward ones: zero intensities, holes, a constant ROI, an all-zero ROI, a thin
+    2000 x 12 strip (size class 4 by its side alone), and a 17 k-pixel ROI just above the class boundary."""
+    rng = np.random.default_rng(seed)
+    rois = [ellipse_roi(90, 72, rng, hi=hi),                        # 20 k
+            ellipse_roi(200, 160, rng, hi=hi, lo=0, holes=0.03),    # 100 k, zeros and holes
+            ellipse_roi(400, 320, rng, hi=hi),                      # 400 k
+            ellipse_roi(80, 68, rng, hi=hi)]                        # 17 k
+    c = ellipse_roi(100, 70, rng)
+    c["inten"][:] = 77
+    rois.append(c)                                                  # constant
+    z = ellipse_roi(95, 75, rng)
+    z["inten"][:] = 0
+    rois.append(z)                                                  # blank
+    yy, xx = np.mgrid[0:12, 0:2000]
+    o = np.lexsort((yy.ravel(), xx.ravel()))
+    rois.append(dict(x=xx.ravel()[o], y=yy.ravel()[o], inten=rng.integers(1, hi, xx.size).astype(np.uint32)))
+    return rois
+
+
+def check(ctx, rois, mask, s, expect_coop=True):
+    b = _abi.batch_from_rois(rois)
+    G = ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    bad = parity.compare_tables(G, O, _lib.column_names(mask, s), batch=b)
+    assert not bad, "\n".join(bad[:20])
+    rep = ctx.launch_report()
+    if expect_coop:
+        assert any(r["cooperative"] for r in rep), rep
+    return G
+
+
+@pytest.mark.parametrize("gd,ibsi", [(8, 0), (64, 0), (-16, 0), (100, 0), (8, 1)])
+def test_large_rois_match_oracle(hip_ctx, gd, ibsi):
+    s = _abi.default_settings(gd)
+    s.ibsi = ibsi
+    check(hip_ctx, large_rois(hi=200 if ibsi else 4096), MASK, s)
+
+
+@pytest.mark.parametrize("hi", [256, 65536, 70000, 3000000])
+def test_large_rois_of_every_table_width(hip_ctx, hi):
+    """8-bit data (256 histogram entries shared by 100 k pixels), 16-bit data (the 128-KiB LDS table of the load kernel), ranges
+    beyond 16 bits (global atomics) -- all below kLargeRangeMax."""
+    check(hip_ctx, large_rois(seed=5, hi=hi)[:4], MASK, _abi.default_settings(8))
+
+
+def test_ranges_beyond_the_histogram_take_the_sort_path(hip_ctx):
+    rng = np.random.default_rng(7)
+    rois = [ellipse_roi(90, 72, rng, hi=2 ** 31), ellipse_roi(100, 80, rng, hi=4096), ellipse_roi(85, 70, rng, hi=2 ** 23)]
+    check(hip_ctx, rois, MASK, _abi.default_settings(8))
+
+
+def test_intensity_alone_and_glcm_alone(hip_ctx):
+    rois = large_rois(seed=9)[:3]
+    s = _abi.default_settings(8)
+    check(hip_ctx, rois, _abi.FAM_INTENSITY, s)
+    check(hip_ctx, rois, _abi.FAM_GLCM, s)
+    s2 = _abi.default_settings(8)
+    s2.glcm_n_angles = 2
+    s2.glcm_angles[0] = 45
+    s2.glcm_angles[1] = 135
+    s2.glcm_offset = 3
+    s2.glcm_symmetric = 1
+    check(hip_ctx, rois, _abi.FAM_GLCM, s2)
+
+
+def test_config4_on_large_rois(hip_ctx):
+    check(hip_ctx, large_rois(seed=11)[:3], CONFIG4, _abi.default_settings(8))
+
+
+def test_large_rows_do_not_depend_on_companions_budget_or_chunking(hip_ctx, monkeypatch):
+    """20 k / 100 k / 400 k-pixel ROIs alone, among small and other large ROIs, and with a workspace budget that forces the class
+    through chunks of one or two ROIs: equal bit for bit, every family the path touches and the ones beside it (Gabor included)."""
+    rng = np.random.default_rng(13)
+    big = [ellipse_roi(90, 72, rng), ellipse_roi(200, 160, rng, lo=0, holes=0.02), ellipse_roi(400, 320, rng), ellipse_roi(70, 60, rng, hi=60000)]
+    small = [ellipse_roi(int(r), int(max(2, r - 2)), rng) for r in rng.integers(3, 40, 30)]
+    others = [ellipse_roi(150, 150, rng, hi=300), ellipse_roi(260, 100, rng, hi=70000)]
+    s = _abi.default_settings(8)
+    mask = MASK | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM | _abi.FAM_GABOR | _abi.FAM_ZERNIKE
+    alone = hip_ctx.featurize_host(_abi.batch_from_rois(big), mask, s)
+    pos = [0, 9, 17, 30]
+    mixed_list = list(small) + others
+    for p, r in zip(pos, big):
+        mixed_list.insert(p, r)
+    idx = [[i for i, q in enumerate(mixed_list) if q is r][0] for r in big]
+    mixed = hip_ctx.featurize_host(_abi.batch_from_rois(mixed_list), mask, s)[idx]
+    names = _lib.column_names(mask, s)
+
+    def diff(a, c):
+        return [(names[j], i) for i, j in zip(*np.nonzero(~((a == c) | (np.isnan(a) & np.isnan(c)))))]
+    assert not diff(alone, mixed), diff(alone, mixed)[:10]
+    monkeypatch.setenv("NYXHIP_LARGE_BUDGET_MB", "2")       # a 400 k-pixel ROI's block is ~0.7 MiB: chunks of a few ROIs
+    tight = hip_ctx.featurize_host(_abi.batch_from_rois(mixed_list), mask, s)[idx]
+    assert not diff(alone, tight), diff(alone, tight)[:10]
+    monkeypatch.delenv("NYXHIP_LARGE_BUDGET_MB")
+
+
+def test_many_large_rois_in_one_call(hip_ctx):
+    """Sixty ROIs of 17 k .. 60 k pixels: the work maps hold hundreds of slabs and strips in arrival order; every row matches."""
+    rng = np.random.default_rng(17)
+    rois = [ellipse_roi(int(a), int(b), rng, hi=4096 if k % 3 else 40000) for k, (a, b) in enumerate(zip(rng.integers(80, 150, 60), rng.integers(70, 130, 60)))]
+    check(hip_ctx, rois, MASK, _abi.default_settings(8))
+
+
+def test_tile_path_with_a_large_roi_falls_back_to_clouds(hip_ctx):
+    """A tile whose largest ROI is beyond the LDS classes (window mode does not apply to it): the chunk is served from clouds and
+    equals the batch path."""
+    rng = np.random.default_rng(19)
+    H = W = 512
+    lab = np.zeros((H, W), np.uint32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab[(yy - 200) ** 2 + (xx - 200) ** 2 <= 150 ** 2] = 5             # 70 k pixels
+    lab[(yy - 450) ** 2 + (xx - 450) ** 2 <= 30 ** 2] = 9
+    lab[(yy - 60) ** 2 + (xx - 440) ** 2 <= 20 ** 2] = 2
+    inten = rng.integers(1, 4096, (H, W)).astype(np.uint32)
+    s = _abi.default_settings(8)
+    _tiles, labels, T = hip_ctx.featurize_tiles_host(inten[None], lab[None], MASK, s)
+    from tests import synth
+    b = _abi.batch_from_rois(synth.rois_from_tile(inten, lab))
+    O = po.oracle_featurize(b, MASK, s)
+    assert list(labels) == [2, 5, 9]
+    bad = parity.compare_tables(T, O, _lib.column_names(MASK, s), batch=b)
+    assert not bad, "\n".join(bad[:20])
