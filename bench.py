@@ -629,7 +629,7 @@ def main():
                 """Parity gate of a tile-path leg: the rows of the LAST tile of the stack vs host ROI assembly + oracle."""
                 if a.no_check:
                     return None
-                from nyxus_amd import roi_assembly
+                from tests import roi_assembly
                 n_ = int(nroi.value)
                 sel = torch.nonzero(t_idx[:n_] == nt - 1).flatten()
                 hbt = roi_assembly.assemble(tin[nt - 1].cpu().numpy().view(np.uint32), label_stack[nt - 1].cpu().numpy().view(np.uint32), 1.7976931348623157e308, -1.7976931348623157e308)

@@ -487,22 +487,46 @@ __device__ __forceinline__ uint32_t lane_minus1_z(uint32_t v) { return (uint32_t
 
 // ---- synchronisation that also works when the "LDS" of a workgroup lives in the global workspace ----------
 // GS = false: plain workgroup barrier / wave-level compiler fence (LDS instructions of a wave run in issue order).
-// GS = true (large-ROI launches): the scratch is global memory; atomics execute in L2 while plain loads may hit
-// a stale line of the CU's vector L1, so every exchange point writes back and invalidates at agent scope.
+// GS = true (workspace launches): the scratch is global memory, exchanged between the waves of ONE workgroup -- one CU, one
+// vector L1 (write-through), one XCD's L2.  An exchange point waits for the wave's outstanding memory operations, passes the
+// barrier, and invalidates the CU's L1 (acquire at agent scope, `buffer_inv sc1`: atomics are performed in L2, and a plain load
+// must not meet a line cached before one).  Nothing is RELEASED at agent scope: that is `buffer_wbl2 sc1`, the write-back of the
+// XCD's dirty L2 lines, which no other CU waits for here.  Rounds 1-3 did (seq_cst agent fences on both sides of every
+// exchange): with hundreds of workspace workgroups in flight, each passing dozens of exchange points, the write-backs were a
+// third of the workspace kernels' time (the 400 largest ROIs of the mixed batch with the config-4 families: 8.1 -> 5.1 ms).
+// Builds for A/B runs: NYX_GS_FULL_FENCE (the old form), NYX_GS_WG_ONLY (workgroup scope only, no L1 invalidate: the AMDGPU
+// memory model's rule for a workgroup on one CU; measured equal to the default within 1 %, suite and fuzzers green).
 template <bool GS>
 __device__ __forceinline__ void blk_sync()
 {
+#ifdef NYX_GS_FULL_FENCE
     if (GS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     __syncthreads();
     if (GS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#elif defined(NYX_GS_WG_ONLY)
+    __syncthreads();                                   // workgroup-scope release + acquire: s_waitcnt vmcnt(0) lgkmcnt(0), s_barrier
+#else
+    __syncthreads();
+    if (GS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 }
 template <bool GS>
 __device__ __forceinline__ void wav_sync()
 {
     if (GS) {
+#ifdef NYX_GS_FULL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#elif defined(NYX_GS_WG_ONLY)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (the stores have reached L2 before the wave goes on: s_waitcnt vmcnt(0))
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

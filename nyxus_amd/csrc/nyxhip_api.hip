@@ -30,7 +30,8 @@ struct ClassRun {              // one size class of one call, as launched (nyxhi
     uint32_t count;            // members (0xFFFFFFFF: counted on the device only)
     Extrema E;                 // extrema the carve-outs were sized for
     int workspace;             // kernel groups that ran from a global workspace instead of LDS: bit 0 INTENSITY + GLCM, 1 texture, 2 shape, 3 dependence
-    hipEvent_t e0, e1;         // around the class's launches (timing enabled), else NULL
+    hipEvent_t e0, e1;         // around the class's launches on the main stream (timing enabled), else NULL
+    hipEvent_t e2 = nullptr;   // ... and the end of its launches on its workspace lane
     int cooperative = 0;       // 1: INTENSITY + GLCM by the several-workgroups-per-ROI kernels of roi_large.hip
 };
 struct ClassTotals {           // sums over the members of a class (class header): what the large-ROI path sizes its workspace from
@@ -94,6 +95,17 @@ struct nyxhip_ctx {
     uint32_t* h_cls_hdr = nullptr;
     std::vector<ClassRun> runs;         // the classes of the last call as launched (nyxhip_launch_report)
     // large-ROI path (roi_large.hip): per-ROI blocks of histogram / plane / matrices, and the work maps + offsets + counters
+    // Workspace lanes: the one-workgroup-per-ROI launches of a large class are a chain of dependent passes per ROI (milliseconds)
+    // by a few hundred workgroups at most -- a fraction of the chip.  Each large class runs them on a stream of its own beside the
+    // main stream (which goes on with the several-workgroups-per-ROI kernels and the LDS classes), with scratch of its own; the
+    // lanes are forked from the main stream at the start of a call and joined into it at its end.
+    static constexpr int kLanes = 4;
+    hipStream_t lane_stream[kLanes] = {};
+    hipEvent_t lane_done[kLanes] = {};
+    hipEvent_t lane_fork = nullptr;
+    unsigned char* lane_buf[kLanes] = {};
+    size_t lane_bytes[kLanes] = {};
+    bool lane_used[kLanes] = {};
     void* d_large = nullptr;
     size_t large_bytes = 0;
     void* d_large_aux = nullptr;
@@ -1041,6 +1053,8 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
     a.glcm_offset = s->glcm_offset; a.glcm_na = s->glcm_n_angles; a.glcm_symmetric = s->glcm_symmetric;
     for (int i = 0; i < kMaxAngles; i++) a.glcm_angles[i] = s->glcm_angles[i];
     a.n_hist = abs(s->grey_depth);
+    if (const char* e = getenv("NYXHIP_LARGE_DBG")) a.dbg = (uint32_t)atoi(e);
+    a.vec_ok = (((uintptr_t)b->inten & 15u) == 0 && ((uintptr_t)b->x & 7u) == 0 && ((uintptr_t)b->y & 7u) == 0) ? 1u : 0u;
     const bool do_int = mask1 & NYXHIP_FAM_INTENSITY, do_glcm = mask1 & NYXHIP_FAM_GLCM;
     const int greyInfo = s->ibsi ? 0 : s->grey_depth;
     const uint32_t ng_max = greyInfo != 0 ? (uint32_t)abs(greyInfo) : E.vmax;       // largest matrix order of the class
@@ -1051,10 +1065,25 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
     // 8192 pixels per slab, up to 65536 entries (128 KiB) at 1024 threads and 32768 pixels per slab (16-bit data: the flush of the
     // table -- one atomic add per non-empty entry -- must not outweigh the slab's pixels)
     const uint32_t r_max = std::min(E.range, kLargeRangeMax - 1);
-    if (!do_int) { a.tab_lds = 0; a.px_per_wg = 8192; }
-    else if (r_max < 16384u) { a.tab_lds = (r_max + 1 + 63u) & ~63u; a.px_per_wg = 8192; }
+    // Slab size: 32 pixels per thread at 256 / 512 / 1024 threads.  Large slabs flush the table less often (the flush of a 12-bit
+    // table is 16 KB of atomic traffic per slab -- at 8192 pixels a quarter of what the slab reads); small slabs fill the chip when
+    // the class holds few pixels: as large as leaves ~2000 workgroups.
+    a.px_per_wg = tot.px / 2048 >= 32768 ? 32768u : tot.px / 2048 >= 16384 ? 16384u : 8192u;
+    if (!do_int) a.tab_lds = 0;
+    else if (r_max < 16384u) a.tab_lds = (r_max + 1 + 63u) & ~63u;
     else { a.tab_lds = 65536; a.px_per_wg = 32768; }
-    a.lds_P_bytes = do_glcm ? (uint32_t)std::min<uint64_t>(96 * 1024, ((4ull * na * ng_max * ng_max + 15) & ~15ull) + ((2ull * (lvl_cap + 2) + 15) & ~15ull)) : 0u;
+    a.lds_P_bytes = do_glcm ? (uint32_t)std::min<uint64_t>(72 * 1024, ((4ull * na * (ng_max + 1ull) * (ng_max + 1ull) + 15) & ~15ull) + ((2ull * (lvl_cap + 2) + 15) & ~15ull)) : 0u;
+    // ... plus the strip of plane rows with its halo rows: kLargeCells cells + 2 * offset rows of the class's widest plane
+    a.lds_strip_bytes = do_glcm ? (uint32_t)std::min<uint64_t>(40 * 1024, (a.plane16 ? 2ull : 1ull) * (kLargeCells + 2ull * (uint64_t)std::max(s->glcm_offset, 0) * std::min<uint32_t>(E.side, kLargeCells)) + 64) : 0u;
+    // finishing kernel: histogram bin bounds, then (over the same bytes) the GLCM feature scratch and the matrices themselves
+    {
+        // (an ROI keeps its scratch in LDS when it needs at most kLargeScratchLds -- its own matrix order decides, roi_large.hip)
+        const uint64_t scr = do_glcm ? ((std::min<uint64_t>(large_glcm_scratch_bytes(ng_max), kLargeScratchLds) + 15) & ~15ull) : 0ull;
+        const uint64_t pm = 4ull * na * ng_max * ng_max;
+        a.fin_P_bytes = (do_glcm && pm <= 32 * 1024) ? (uint32_t)pm : 0u;
+        a.fin_tab_bytes = do_int ? (uint32_t)((4ull * (std::min<uint32_t>(r_max, 8191u) + 1) + 15) & ~15ull) : 0u;   // up to 32 KiB of histogram
+        a.lds_fin_bytes = (uint32_t)std::max<uint64_t>(a.fin_tab_bytes + 4ull * (112 + (uint64_t)abs(s->grey_depth)), scr + a.fin_P_bytes + 16);
+    }
     // ---- workspace: the members' blocks back to back (offsets handed out by the prep kernel) when the class fits the budget, else
     // chunks of the list with room for the class's largest block each
     const char* const be = getenv("NYXHIP_LARGE_BUDGET_MB");                  // (tests: a small budget sends a class through the chunked form)
@@ -1069,8 +1098,8 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
         chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, budget / Lmax.total));
         ws_need = (uint64_t)chunk * Lmax.total;
     }
-    const uint64_t slabs_max = (E.px + a.px_per_wg - 1) / a.px_per_wg, strips_max = 2ull * E.area / kLargeCells + 1;
-    uint64_t cap_load = chunk == count ? tot.px / a.px_per_wg + count : (uint64_t)chunk * slabs_max;
+    const uint64_t slabs_max = ((uint64_t)E.px + 3 + a.px_per_wg - 1) / a.px_per_wg, strips_max = 2ull * E.area / kLargeCells + 1;
+    uint64_t cap_load = chunk == count ? tot.px / a.px_per_wg + 2ull * count : (uint64_t)chunk * slabs_max;   // (a slab more per ROI: slabs start at a multiple of four pixels)
     uint64_t cap_cooc = do_glcm ? (chunk == count ? 2 * tot.area / kLargeCells + count : (uint64_t)chunk * strips_max) : 0;
     if (cap_load > 0x7FFFFFFFull || cap_cooc > 0x7FFFFFFFull) {          // (grid limit: smaller chunks)
         const uint64_t per = std::max(slabs_max, strips_max);
@@ -1221,10 +1250,26 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(stride, 1)));
     const size_t need = stride * chunk;
-    if (need > ctx->spill_bytes) {
-        if (ctx->d_spill) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, need));
-        ctx->spill_bytes = need;
+    // the lane of this class (nyxhip_ctx::lane_stream): large classes only -- the workspace fallback of an LDS class stays on the main stream
+    static const bool no_lanes = [] { const char* e = getenv("NYXHIP_NO_LANES"); return e && *e && *e != '0'; }();   // A/B knob
+    const int lane = (!no_lanes && cls / 2 >= kFirstLargeSizeClass) ? (cls - 2 * kFirstLargeSizeClass) % nyxhip_ctx::kLanes : -1;
+    unsigned char** const bufp = lane >= 0 ? &ctx->lane_buf[lane] : &ctx->d_spill;
+    size_t* const bytesp = lane >= 0 ? &ctx->lane_bytes[lane] : &ctx->spill_bytes;
+    if (lane >= 0) {
+        if (!ctx->lane_stream[lane]) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+        }
+        if (!ctx->lane_used[lane]) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork, 0));   // the batch and the class lists are complete on the main stream
+            ctx->lane_used[lane] = true;
+        }
+        st = ctx->lane_stream[lane];
+    }
+    if (need > *bytesp) {
+        if (*bufp) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(*bufp)); *bufp = nullptr; *bytesp = 0; }
+        HIP_TRY(ctx, hipMalloc((void**)bufp, need));
+        *bytesp = need;
     }
     if ((gs & 4) && (mask & NYXHIP_FAM_ZERNIKE)) {   // Zernike keeps no ROI-sized state in LDS: one launch over the class, whatever its size
         ShapeArgs gz = g2;
@@ -1236,7 +1281,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     for (uint32_t o = 0; o < grid; o += chunk) {
         const uint32_t nb = std::min(chunk, grid - o);
         set_slots(a2.sp, list + o, nb); set_slots(t2.sp, list + o, nb); set_slots(g2.sp, list + o, nb); set_slots(d2.sp, list + o, nb);
-        a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = ctx->d_spill;
+        a2.sp.scratch = t2.sp.scratch = g2.sp.scratch = d2.sp.scratch = *bufp;
         a2.sp.stride = t2.sp.stride = g2.sp.stride = d2.sp.stride = stride;
         rc = (gs & 1) ? launch_roi_features(a2, st, nb) : 0;
         if (rc == 0 && (gs & 2)) rc = launch_roi_texture(t2, st, nb);
@@ -1244,6 +1289,10 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         if (rc == 0 && (gs & 4) && (mask & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    if (lane >= 0 && report && ctx->timing) {
+        HIP_TRY(ctx, hipEventCreate(&report->e2));
+        HIP_TRY(ctx, hipEventRecord(report->e2, st));
     }
     return NYXHIP_OK;
 }
@@ -1253,6 +1302,7 @@ static void clear_runs(nyxhip_ctx* ctx)
     for (ClassRun& r : ctx->runs) {
         if (r.e0) (void)hipEventDestroy(r.e0);
         if (r.e1) (void)hipEventDestroy(r.e1);
+        if (r.e2) (void)hipEventDestroy(r.e2);
     }
     ctx->runs.clear();
 }
@@ -1275,6 +1325,20 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
     hipStream_t st = ctx->stream();
     const uint32_t n_roi = (uint32_t)b->n_roi;
     clear_runs(ctx);
+    // workspace lanes (run_class): forked from here, joined into the main stream on every way out
+    if (!ctx->lane_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->lane_fork, st));
+    struct LaneJoin {
+        nyxhip_ctx* c; hipStream_t st;
+        ~LaneJoin() {
+            for (int k = 0; k < nyxhip_ctx::kLanes; k++)
+                if (c->lane_used[k]) {
+                    (void)hipEventRecord(c->lane_done[k], c->lane_stream[k]);
+                    (void)hipStreamWaitEvent(st, c->lane_done[k], 0);
+                    c->lane_used[k] = false;
+                }
+        }
+    } lane_join{ctx, st};
     if (mask & NYXHIP_FAM_GLCM) {
         // matrix orders of the split GLCM launches (RoiArgs::glcm_ng).  A table of its own: the count workspace may be re-allocated
         // between the launch groups of a call.
@@ -1503,6 +1567,12 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_glcm_ng) (void)hipFree(ctx->d_glcm_ng);
     if (ctx->d_logtab) (void)hipFree(ctx->d_logtab);
     if (ctx->d_spill_list) (void)hipFree(ctx->d_spill_list);
+    for (int k = 0; k < nyxhip_ctx::kLanes; k++) {
+        if (ctx->lane_stream[k]) { (void)hipStreamSynchronize(ctx->lane_stream[k]); (void)hipStreamDestroy(ctx->lane_stream[k]); }
+        if (ctx->lane_done[k]) (void)hipEventDestroy(ctx->lane_done[k]);
+        if (ctx->lane_buf[k]) (void)hipFree(ctx->lane_buf[k]);
+    }
+    if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
     if (ctx->d_large) (void)hipFree(ctx->d_large);
     if (ctx->d_large_aux) (void)hipFree(ctx->d_large_aux);
     clear_runs(ctx);
@@ -2201,10 +2271,15 @@ int nyxhip_launch_report(nyxhip_ctx* ctx, char* buf, size_t buf_len)
             float t = 0;
             if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) snprintf(ms, sizeof(ms), "%.6f", (double)t);
         }
-        char one[384];
+        char lane_ms[48] = "null";                      // from the class's start on the main stream to the end of its workspace lane
+        if (r.e0 && r.e2 && hipEventSynchronize(r.e2) == hipSuccess) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, r.e0, r.e2) == hipSuccess) snprintf(lane_ms, sizeof(lane_ms), "%.6f", (double)t);
+        }
+        char one[448];
         snprintf(one, sizeof(one), "%s{\"class\": %d, \"size_class\": %d, \"wide_range\": %d, \"rois\": %u, \"max_px\": %u, \"max_bbox_area\": %u, "
-                 "\"max_range\": %u, \"max_side\": %u, \"workspace\": %d, \"cooperative\": %d, \"ms\": %s}", i ? ", " : "", r.cls, r.cls < 0 ? -1 : r.cls / 2, r.cls < 0 ? -1 : r.cls & 1,
-                 r.count, r.E.px, r.E.area, r.E.range, r.E.side, r.workspace, r.cooperative, ms);
+                 "\"max_range\": %u, \"max_side\": %u, \"workspace\": %d, \"cooperative\": %d, \"ms\": %s, \"lane_ms\": %s}", i ? ", " : "", r.cls, r.cls < 0 ? -1 : r.cls / 2, r.cls < 0 ? -1 : r.cls & 1,
+                 r.count, r.E.px, r.E.area, r.E.range, r.E.side, r.workspace, r.cooperative, ms, lane_ms);
         js += one;
     }
     js += "]";

@@ -432,7 +432,13 @@ struct LargeArgs {
     uint32_t px_per_wg;            // pixels of a slab
     uint32_t tab_lds;              // histogram entries the load kernel counts in LDS (16-bit counters): ROIs with range < tab_lds
     uint32_t plane16;              // 1: the plane holds 16-bit levels
-    uint32_t lds_P_bytes;          // LDS the co-occurrence kernel may use for its matrices
+    uint32_t lds_P_bytes;          // LDS the co-occurrence kernel may use for its matrices (+ the radiomics level map)
+    uint32_t lds_strip_bytes;      // ... and for the staged strip of plane rows
+    uint32_t lds_fin_bytes;        // dynamic LDS of the finishing kernel
+    uint32_t fin_tab_bytes;        // ... of which the histogram may take this much (16-byte multiple; ROIs whose table fits are finished from LDS)
+    uint32_t fin_P_bytes;          // ... of which the matrices may take this much (staged from the workspace; 0: read in place)
+    uint32_t vec_ok;               // 1: inten is 16-byte and x / y are 8-byte aligned (groups of four pixels load as vectors)
+    uint32_t dbg;                  // timing experiments only (NYXHIP_LARGE_DBG): 1 no plane stores, 2 no histogram counts, 4 no table flush, 8 no sums
 };
 int launch_large_features(const LargeArgs& a, void* stream);
 

@@ -4,7 +4,7 @@
 // kernels of roi_features.hip give an ROI one workgroup, which leaves a 120 k-pixel ROI walking its cloud with 256 threads
 // while the rest of the chip idles.  Here such an ROI is cut up:
 //
-//   large_prep_kernel    one wave per ROI: its block of the workspace, its slabs / strips in the two work maps
+//   large_prep_kernel    one thread per ROI: its block of the workspace, its slabs / strips in the two work maps
 //   large_load_kernel    one workgroup per SLAB of the pixel cloud (the only pass over HBM: 8 B per pixel): exact sums, the
 //                        intensity histogram over [min, max] (counted in LDS, flushed with contiguous atomic adds), the binned
 //                        bounding-box plane (features/texture_feature.h binning) scattered to the workspace
@@ -40,7 +40,16 @@ struct LargeRoi {
     uint32_t ng_bound, lvl_cap;
     LargeWs L;
     unsigned char* base;
+    // The plane is laid out along the cloud: a cloud in column-major scan order (the in-memory workflow, phase2_2d.cpp:655-656)
+    // gets a column-major plane (tr = 1: cell = x * h + y), any other order a row-major one -- consecutive pixels of a slab then
+    // store consecutive bytes (scattered one byte per cache line, the stores were more than half of the load kernel's time).
+    // pw x ph: the plane as the co-occurrence kernel walks it (rows of pw cells).
+    uint32_t tr, pw, ph;
 };
+__device__ __forceinline__ void large_set_orientation(LargeRoi& R, uint32_t tr)
+{
+    R.tr = tr; R.pw = tr ? R.h : R.w; R.ph = tr ? R.w : R.h;
+}
 
 __device__ __forceinline__ bool large_roi(const LargeArgs& A, uint32_t j, LargeRoi& R, bool need_block)
 {
@@ -57,10 +66,12 @@ __device__ __forceinline__ bool large_roi(const LargeArgs& A, uint32_t j, LargeR
     R.L = large_ws_layout(R.range, R.area, R.ng_bound, R.lvl_cap, (uint32_t)A.glcm_na, A.plane16 != 0, (A.mask & NYXHIP_FAM_INTENSITY) != 0,
                           (A.mask & NYXHIP_FAM_GLCM) != 0);
     R.base = nullptr;
+    large_set_orientation(R, 0);
     if (need_block) {
         const uint64_t o = A.ws_off[j];
         if (o == ~0ull) return false;
-        R.base = A.ws + o;
+        R.base = A.ws + (o & ~255ull);                                       // (blocks are 256-byte aligned: bit 0 carries the orientation)
+        large_set_orientation(R, (uint32_t)(o & 1ull));
     }
     return true;
 }
@@ -70,39 +81,58 @@ __device__ __forceinline__ bool large_served(const LargeRoi& R) { return R.n != 
 
 __device__ __forceinline__ uint32_t rows_per_strip(uint32_t w) { const uint32_t r = kLargeCells / (w ? w : 1u); return r ? r : 1u; }
 
-// ---- prep: one wave per member -------------------------------------------------------------------------------------------------
+// ---- prep: one thread per member, one set of cursor adds per block -------------------------------------------------------------
+// (one wave per member with its own three adds on the shared cursors cost 11 ns per add: 130 us for 3700 members)
 __global__ __launch_bounds__(256) void large_prep_kernel(const LargeArgs A)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (j >= A.n_list) return;
+    __shared__ unsigned long long s_bytes[256];
+    __shared__ uint32_t s_load[256], s_cooc[256];
+    __shared__ unsigned long long s_base_bytes;
+    __shared__ uint32_t s_base_load, s_base_cooc;
+    const int tid = threadIdx.x;
+    const uint32_t j = blockIdx.x * 256u + (uint32_t)tid;
     LargeRoi R;
-    large_roi(A, j, R, false);
-    if (!large_served(R)) {
-        if (lane == 0) A.ws_off[j] = ~0ull;
-        return;
+    bool served = false;
+    uint32_t g_load = 0, g_cooc = 0;
+    if (j < A.n_list) {
+        large_roi(A, j, R, false);
+        served = large_served(R);
+        if (served) {
+            g_load = (uint32_t)(((R.off & 3ull) + R.n + A.px_per_wg - 1) / A.px_per_wg);   // slabs start at the group of four that holds the first pixel
+            // scan order of the cloud, read off a pair of pixels in its middle (the first column of a disk is a single pixel)
+            const uint64_t m = R.off + (R.n >= 2 ? R.n / 2 - 1 : 0);
+            large_set_orientation(R, (R.n >= 2 && A.x[m + 1] == A.x[m] && (uint32_t)A.y[m + 1] == (uint32_t)A.y[m] + 1u) ? 1u : 0u);
+            const uint32_t rps = rows_per_strip(R.pw);
+            g_cooc = (A.mask & NYXHIP_FAM_GLCM) ? (R.ph + rps - 1) / rps : 0u;
+        }
     }
-    const uint32_t g_load = (R.n + A.px_per_wg - 1) / A.px_per_wg;
-    const uint32_t rps = rows_per_strip(R.w);
-    const uint32_t g_cooc = (A.mask & NYXHIP_FAM_GLCM) ? (R.h + rps - 1) / rps : 0u;
-    unsigned long long off = 0;
-    uint32_t b_load = 0, b_cooc = 0;
-    if (lane == 0) {
-        off = atomicAdd((unsigned long long*)A.ctr, (unsigned long long)R.L.total);
-        b_load = atomicAdd(&A.ctr[2], g_load);
-        b_cooc = g_cooc ? atomicAdd(&A.ctr[3], g_cooc) : 0u;
+    s_bytes[tid] = served ? R.L.total : 0ull; s_load[tid] = g_load; s_cooc[tid] = g_cooc;
+    __syncthreads();
+    if (tid == 0) {                                         // exclusive prefixes over the block's members (256 short adds), then the cursors
+        unsigned long long b = 0; uint32_t l = 0, c = 0;
+        for (int k = 0; k < 256; k++) {
+            const unsigned long long tb = s_bytes[k]; const uint32_t tl = s_load[k], tc = s_cooc[k];
+            s_bytes[k] = b; s_load[k] = l; s_cooc[k] = c;
+            b += tb; l += tl; c += tc;
+        }
+        s_base_bytes = b ? atomicAdd((unsigned long long*)A.ctr, b) : 0ull;
+        s_base_load = l ? atomicAdd(&A.ctr[2], l) : 0u;
+        s_base_cooc = c ? atomicAdd(&A.ctr[3], c) : 0u;
     }
-    off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
-    b_load = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_load);
-    b_cooc = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_cooc);
+    __syncthreads();
+    if (j >= A.n_list) return;
+    if (!served) { A.ws_off[j] = ~0ull; return; }
+    const unsigned long long off = s_base_bytes + s_bytes[tid];
+    const uint32_t b_load = s_base_load + s_load[tid], b_cooc = s_base_cooc + s_cooc[tid];
     const bool fits = off + R.L.total <= A.ws_bytes && (uint64_t)b_load + g_load <= A.cap_load && (uint64_t)b_cooc + g_cooc <= A.cap_cooc;
-    if (!fits) {                                        // (the host sized all three from the class totals: cannot happen)
-        if (lane == 0) { A.ws_off[j] = ~0ull; atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE); }
+    if (!fits) {                                            // (the host sized all three from the class totals: cannot happen)
+        A.ws_off[j] = ~0ull;
+        atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         return;
     }
-    if (lane == 0) A.ws_off[j] = off;
-    for (uint32_t s = lane; s < g_load; s += 64) A.map_load[b_load + s] = make_uint2(j, s);
-    for (uint32_t s = lane; s < g_cooc; s += 64) A.map_cooc[b_cooc + s] = make_uint2(j, s);
+    A.ws_off[j] = off | R.tr;
+    for (uint32_t s = 0; s < g_load; s++) A.map_load[b_load + s] = make_uint2(j, s);
+    for (uint32_t s = 0; s < g_cooc; s++) A.map_cooc[b_cooc + s] = make_uint2(j, s);
 }
 
 // ---- load: one workgroup per slab of the cloud --------------------------------------------------------------------------------
@@ -130,41 +160,63 @@ __global__ __launch_bounds__(1024) void large_load_kernel(const LargeArgs A)
     }
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
     const double mslope = greyInfo > 0 ? (double)greyInfo / ((double)R.vmax - 0.) : 0.0;
-    const uint32_t p0 = job.y * A.px_per_wg, p1 = p0 + A.px_per_wg < R.n ? p0 + A.px_per_wg : R.n;
-    const uint32_t* const gv = A.inten + R.off;
-    const uint16_t* const gx = A.x + R.off;
-    const uint16_t* const gy = A.y + R.off;
+    // Slabs are cut in the batch's GLOBAL pixel index, at multiples of four from the group of four that holds the ROI's first pixel:
+    // a thread takes four consecutive pixels -- one 16-byte load of intensities, one 8-byte load each of x and y (the arrays of a
+    // batch are 16 / 8-byte aligned: vec_ok) -- where a pixel per lane cost three loads per pixel.  The ROI's first and last group
+    // (partly another ROI's pixels, or past the end of the arrays) go element by element.
+    const uint64_t roi_lo = R.off, roi_hi = R.off + R.n;
+    const uint64_t gs = (R.off & ~3ull) + (uint64_t)job.y * A.px_per_wg;      // first global index of the slab (a multiple of four)
+    const uint64_t ge = gs + A.px_per_wg < roi_hi ? gs + A.px_per_wg : roi_hi;
     unsigned long long sum = 0, sumsq = 0;
+    const uint32_t lvl_clip = P16 ? 0xFFFFu : 0xFFu;
+    const uint32_t pw_ = R.tr ? R.h : R.w;                                    // cell = major * pw_ + minor: below 2^32 (box sides are 16-bit)
+    auto pixel = [&](uint32_t v, uint32_t px, uint32_t py) {
+        sum += v;
+        sumsq += (uint32_t)(v * v);                                           // unsigned-int product, wraps (intensity.cpp:90)
+        if (do_int && !(A.dbg & 2)) {
+            const uint32_t ci = v - R.vmin;
+            if (tab_in_lds) atomicAdd(&s_tab[ci >> 1], 1u << (16 * (ci & 1u)));
+            else if (ci <= R.range) atomicAdd(&T[ci], 1u);
+        }
+        if (do_glcm) {
+            uint32_t lvl = 0;
+            if (v != 0) {                                                      // original intensity 0 is skipped by the scan (glcm.cpp:445)
+                if (greyInfo > 0) {   // matlab binning of a non-zero value: floor(slope v + 1) >= 1 already (the conversion truncates a positive value)
+                    const uint32_t sc = (uint32_t)(mslope * (double)v + 1.0);
+                    lvl = sc > (uint32_t)greyInfo ? (uint32_t)greyInfo : sc;
+                } else
+                    lvl = greyInfo < 0 ? bin_radiomix(v, R.vmin, R.vmax, -greyInfo) : v;
+                if (greyInfo < 0 && lvl <= R.lvl_cap) flags[lvl] = 1;
+            }
+            if (px < R.w && py < R.h && !(A.dbg & 1))
+                plane[(R.tr ? px : py) * pw_ + (R.tr ? py : px)] = (plane_t)(lvl > lvl_clip ? lvl_clip : lvl);
+        }
+    };
     constexpr int kU = 4;
-    for (uint32_t base = p0; base < p1; base += kU * BS) {
-        uint32_t v[kU], px[kU], py[kU];
+    for (uint64_t gb = gs; gb < ge; gb += 4ull * kU * BS) {
+        uint4 v4[kU]; uint2 x2[kU], y2[kU];
+        bool whole[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {                                        // every load of the trip before the first use
-            const uint32_t i = base + u * BS + tid;
-            const bool in = i < p1;
-            v[u] = in ? gv[i] : 0u;
-            px[u] = (in && do_glcm) ? gx[i] : 0u;
-            py[u] = (in && do_glcm) ? gy[i] : 0u;
+            const uint64_t g = gb + 4ull * ((uint64_t)u * BS + tid);
+            whole[u] = A.vec_ok && g >= roi_lo && g + 4 <= ge;
+            if (whole[u]) {
+                v4[u] = *(const uint4*)(A.inten + g);
+                if (do_glcm) { x2[u] = *(const uint2*)(A.x + g); y2[u] = *(const uint2*)(A.y + g); }
+            }
         }
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            if (base + u * BS + tid >= p1) continue;
-            sum += v[u];
-            sumsq += (uint32_t)(v[u] * v[u]);                                 // unsigned-int product, wraps (intensity.cpp:90)
-            if (do_int) {
-                const uint32_t ci = v[u] - R.vmin;
-                if (tab_in_lds) atomicAdd(&s_tab[ci >> 1], 1u << (16 * (ci & 1u)));
-                else if (ci <= R.range) atomicAdd(&T[ci], 1u);
-            }
-            if (do_glcm) {
-                uint32_t lvl = 0;
-                if (v[u] != 0) {                                               // original intensity 0 is skipped by the scan (glcm.cpp:445)
-                    lvl = greyInfo > 0 ? bin_matlab(v[u], mslope, greyInfo) : greyInfo < 0 ? bin_radiomix(v[u], R.vmin, R.vmax, -greyInfo) : v[u];
-                    if (greyInfo < 0 && lvl <= R.lvl_cap) flags[lvl] = 1;
-                }
-                const uint64_t cell = (uint64_t)py[u] * R.w + px[u];
-                if (px[u] < R.w && cell < R.area)
-                    plane[cell] = (plane_t)(lvl > (P16 ? 0xFFFFu : 0xFFu) ? (P16 ? 0xFFFFu : 0xFFu) : lvl);
+            const uint64_t g = gb + 4ull * ((uint64_t)u * BS + tid);
+            if (whole[u]) {
+                const uint32_t xa = do_glcm ? x2[u].x : 0u, xb = do_glcm ? x2[u].y : 0u, ya = do_glcm ? y2[u].x : 0u, yb = do_glcm ? y2[u].y : 0u;
+                pixel(v4[u].x, xa & 0xFFFFu, ya & 0xFFFFu);
+                pixel(v4[u].y, xa >> 16, ya >> 16);
+                pixel(v4[u].z, xb & 0xFFFFu, yb & 0xFFFFu);
+                pixel(v4[u].w, xb >> 16, yb >> 16);
+            } else {
+                for (uint64_t i = g > roi_lo ? g : roi_lo; i < g + 4 && i < ge; i++)
+                    pixel(A.inten[i], do_glcm ? (uint32_t)A.x[i] : 0u, do_glcm ? (uint32_t)A.y[i] : 0u);
             }
         }
     }
@@ -178,7 +230,7 @@ __global__ __launch_bounds__(1024) void large_load_kernel(const LargeArgs A)
         atomicAdd(&hdr[0], a);
         atomicAdd(&hdr[1], b);
     }
-    if (tab_in_lds) {
+    if (tab_in_lds && !(A.dbg & 4)) {
         const uint16_t* const t16 = (const uint16_t*)s_tab;
         for (uint32_t i = tid; i <= R.range; i += BS) {                       // contiguous adds: a wave covers 256 bytes of the table
             const uint32_t c = t16[i];
@@ -231,10 +283,17 @@ __global__ __launch_bounds__(256) void large_cooc_kernel(const LargeArgs A)
     const int na = A.glcm_na;
     const uint64_t NN = (uint64_t)Ng * Ng;
     uint32_t* const gP = (uint32_t*)(R.base + R.L.P);
-    const bool in_lds = 4ull * na * NN + map_bytes <= A.lds_P_bytes;
+    // LDS matrices have order Ng + 1 and are indexed by the level itself: row 0 / column 0 collect the pairs whose partner is
+    // skipped (level 0: background, zero intensity, outside the box), so the offset-1 sweep needs no test per pair; the flush
+    // drops them.  Matrices that do not fit LDS are counted in place (plain Ng x Ng, one test per pair).
+    const uint32_t NG1 = (uint32_t)Ng + 1u;
+    const uint64_t CC = (uint64_t)NG1 * NG1;
+    const bool in_lds = 4ull * na * CC + map_bytes <= A.lds_P_bytes;
     uint32_t* const P = in_lds ? s_P : gP;
+    const uint32_t ldP = in_lds ? NG1 : (uint32_t)Ng, off1 = in_lds ? 0u : 1u;        // cell of (a, b) = q * cells + (a - off1) * ldP + (b - off1)
+    const uint64_t cellsP = in_lds ? CC : NN;
     if (in_lds) {
-        for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) s_P[i] = 0;
+        for (uint32_t i = tid; i < (uint32_t)(na * CC); i += BS) s_P[i] = 0;
         __syncthreads();
     }
     const bool symmetric = A.glcm_symmetric || greyInfo <= 0;                 // glcm.cpp:475
@@ -242,16 +301,139 @@ __global__ __launch_bounds__(256) void large_cooc_kernel(const LargeArgs A)
 #pragma unroll
     for (int q = 0; q < kMaxAngles; q++) {
         const int ang = A.glcm_angles[q < na ? q : 0];                        // glcm.cpp:234-255
-        ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
-        ddy[q] = ang == 0 ? 0 : A.glcm_offset;
+        const int dx = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset, dy = ang == 0 ? 0 : A.glcm_offset;
+        ddx[q] = R.tr ? dy : dx;                                               // (a column-major plane: its rows are the image's columns)
+        ddy[q] = R.tr ? dx : dy;
     }
     using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
     const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
-    const uint32_t rps = rows_per_strip(R.w);
-    const uint32_t r0 = job.y * rps, r1 = r0 + rps < R.h ? r0 + rps : R.h;
-    const int w = (int)R.w, h = (int)R.h;
+    const uint32_t rps = rows_per_strip(R.pw);
+    const uint32_t r0 = job.y * rps, r1 = r0 + rps < R.ph ? r0 + rps : R.ph;
+    const int w = (int)R.pw, h = (int)R.ph;
+    // The strip and its halo rows (offset rows above and below: a column-major plane has its 135-degree neighbours above) are staged
+    // in LDS with 16-byte loads; the pair loop then reads LDS bytes.  (Reading the plane from global memory left the kernel waiting
+    // on one dependent L2 round trip per 64 cells.)  Strips whose rows do not fit -- boxes tens of thousands of cells wide -- read
+    // the workspace directly.
+    const int d = A.glcm_offset;
+    const int s0 = (int)r0 - d > 0 ? (int)r0 - d : 0, s1 = (int)r1 + d < h ? (int)r1 + d : h;     // staged rows [s0, s1)
+    const uint64_t st_cells = (uint64_t)(s1 - s0) * R.pw;
+    const uint32_t p_bytes = in_lds ? (uint32_t)((4ull * na * CC + 15) & ~15ull) : 0u;
+    const bool staged = map_bytes + p_bytes + st_cells * sizeof(plane_t) + 16 <= A.lds_P_bytes + A.lds_strip_bytes;
+    plane_t* const s_strip = (plane_t*)(lds_raw + map_bytes + p_bytes);
+    if (staged) {
+        const plane_t* const src = plane + (uint64_t)s0 * R.pw;
+        const uint64_t nbytes = st_cells * sizeof(plane_t);
+        const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);                 // (the strip starts anywhere inside the plane: align the vector loads down)
+        const uint4* const src16 = (const uint4*)((const unsigned char*)src - mis);
+        uint4* const dst16 = (uint4*)s_strip;                                  // staged at the same misalignment: cell k of the strip sits at byte mis + k
+        const uint64_t nvec = (mis + nbytes + 15) / 16;
+        for (uint64_t i = tid; i < nvec; i += BS) dst16[i] = src16[i];         // (reads up to 15 bytes around the strip: inside the ROI's block, which is padded)
+        __syncthreads();
+    }
+    const plane_t* const strip = staged ? (const plane_t*)((const unsigned char*)s_strip + ((uintptr_t)(plane + (uint64_t)s0 * R.pw) & 15u)) : nullptr;
+    int slot_of[4] = {-1, -1, -1, -1};                                        // matrix of the pass that angle 0 / 45 / 90 / 135 counts into
+#pragma unroll
+    for (int q = 0; q < kMaxAngles; q++)
+        if (q < na) { const int ang = A.glcm_angles[q]; slot_of[ang == 0 ? 0 : ang == 45 ? 1 : ang == 90 ? 2 : 3] = q; }
+    const bool usual = na == 4 && slot_of[0] >= 0 && slot_of[1] >= 0 && slot_of[2] >= 0 && slot_of[3] >= 0 && !symmetric && greyInfo >= 0;
+    if (staged && d == 1 && in_lds && usual) {
+        // ---- the usual request (four angles, offset 1, asymmetric counts, level = matrix index): the sweep below as straight-line
+        // code -- levels travel as byte offsets (4 * level), a cell address is matrix base + row offset + neighbour offset, a skipped
+        // partner lands in row / column 0 of the (Ng + 1)-order matrices, so a row of 62 centres costs one LDS read, three lane
+        // shifts, one multiply and four add + atomic pairs.  (The general sweep spent ~48 vector instructions per row on 64-bit
+        // index arithmetic and per-angle selects.)
+        const uint32_t ccb = (uint32_t)CC * 4u;
+        char* const T0 = (char*)s_P + (uint32_t)slot_of[0] * ccb;
+        char* const T1 = (char*)s_P + (uint32_t)slot_of[1] * ccb;
+        char* const T2 = (char*)s_P + (uint32_t)slot_of[2] * ccb;
+        char* const T3 = (char*)s_P + (uint32_t)slot_of[3] * ccb;
+        const uint32_t ncs = ((uint32_t)w + 61u) / 62u;
+        const uint32_t nrb = ncs >= (uint32_t)NW ? 1u : (uint32_t)NW / ncs;
+        const uint32_t rows_blk = (r1 - r0 + nrb - 1) / nrb;
+        const uint32_t pw = R.pw, tr = R.tr;
+        for (uint32_t t = (uint32_t)wave; t < ncs * nrb; t += NW) {
+            const uint32_t cs = t % ncs, rbi = t / ncs;
+            const uint32_t ra = r0 + rbi * rows_blk, rz = ra + rows_blk < r1 ? ra + rows_blk : r1;
+            const int c = (int)(cs * 62u) - 1 + lane;
+            const bool in_col = c >= 0 && c < w;
+            const bool centre = in_col && lane >= 1 && lane <= 62;
+            const plane_t* pp = strip + (uint32_t)((int)ra - s0) * pw + (uint32_t)(in_col ? c : 0);
+            uint32_t cur4 = 0;
+            if (in_col && ra < rz) cur4 = (uint32_t)pp[0] << 2;
+            for (uint32_t row = ra; row < rz; row++) {
+                pp += pw;
+                uint32_t nxt4 = 0;
+                if (in_col && (int)row + 1 < h) nxt4 = (uint32_t)pp[0] << 2;
+                const uint32_t e4 = lane_plus1_z(cur4), se4 = lane_plus1_z(nxt4), sw4 = lane_minus1_z(nxt4);
+                if (centre && cur4 != 0) {
+                    const uint32_t rowb = mul_u24_su(cur4, NG1);
+                    if (!tr) {
+                        atomicAdd((uint32_t*)(T0 + rowb + e4), 1u);
+                        atomicAdd((uint32_t*)(T1 + rowb + se4), 1u);
+                        atomicAdd((uint32_t*)(T2 + rowb + nxt4), 1u);
+                        atomicAdd((uint32_t*)(T3 + rowb + sw4), 1u);
+                    } else {                               // column-major plane: 0 degrees is the cell below, 90 the cell to the right, and the
+                        atomicAdd((uint32_t*)(T0 + rowb + nxt4), 1u);   // 135-degree pair is counted from its neighbour (this cell): its centre is below-left
+                        atomicAdd((uint32_t*)(T1 + rowb + se4), 1u);
+                        atomicAdd((uint32_t*)(T2 + rowb + e4), 1u);
+                        atomicAdd((uint32_t*)(T3 + mul_u24_su(sw4, NG1) + cur4), 1u);
+                    }
+                }
+                cur4 = nxt4;
+            }
+        }
+    } else
+    if (staged && d == 1) {
+        // ---- offset 1 on a staged strip: lane = column, the horizontal neighbours through DPP lane shifts, the row below read once
+        // and kept as the next centre row (the sweep of roi_features.hip).  A column strip is 62 centre columns between two halo
+        // lanes; (column strip, row block) tasks are dealt to the four waves.  Every angle is one of E / SE / S / SW of the centre in
+        // plane coordinates -- a column-major plane turns 135 degrees into "north-east", which is counted from the neighbour's
+        // side instead (rev: the cell below-left is the centre of the pair).
+        int dir[kMaxAngles], rev[kMaxAngles];
+#pragma unroll
+        for (int q = 0; q < kMaxAngles; q++) {
+            int ex = ddx[q], ey = ddy[q];
+            rev[q] = (ey < 0 || (ey == 0 && ex < 0)) ? 1 : 0;
+            if (rev[q]) { ex = -ex; ey = -ey; }
+            dir[q] = ey == 0 ? 0 : ex > 0 ? 1 : ex == 0 ? 2 : 3;
+        }
+        const uint32_t ncs = ((uint32_t)w + 61u) / 62u;
+        const uint32_t nrb = ncs >= (uint32_t)NW ? 1u : (uint32_t)NW / ncs;
+        const uint32_t rows_blk = (r1 - r0 + nrb - 1) / nrb;
+        const bool remap = greyInfo < 0;
+        for (uint32_t t = (uint32_t)wave; t < ncs * nrb; t += NW) {
+            const uint32_t cs = t % ncs, rbi = t / ncs;
+            const uint32_t ra = r0 + rbi * rows_blk, rz = ra + rows_blk < r1 ? ra + rows_blk : r1;
+            const int c = (int)(cs * 62u) - 1 + lane;
+            const bool in_col = c >= 0 && c < w;
+            const bool centre = in_col && lane >= 1 && lane <= 62;
+            auto lvl = [&](uint32_t row) -> uint32_t {
+                uint32_t v = (in_col && (int)row < h) ? (uint32_t)strip[(uint64_t)((int)row - s0) * R.pw + (uint32_t)c] : 0u;
+                if (remap && v) v = s_map[v];
+                return v;
+            };
+            uint32_t cur = ra < rz ? lvl(ra) : 0u;
+            for (uint32_t row = ra; row < rz; row++) {
+                const uint32_t nxt = lvl(row + 1);
+                const uint32_t nb_e = lane_plus1(cur, 0), nb_se = lane_plus1(nxt, 0), nb_sw = lane_minus1(nxt, 0);
+                if (centre && cur != 0) {
+#pragma unroll
+                    for (int q = 0; q < kMaxAngles; q++) {
+                        if (q >= na) break;
+                        const uint32_t nb = dir[q] == 0 ? nb_e : dir[q] == 1 ? nb_se : dir[q] == 2 ? nxt : nb_sw;
+                        if (!in_lds && nb == 0) continue;                                    // (LDS matrices: a skipped partner lands in row / column 0)
+                        const uint32_t ca = rev[q] ? nb : cur, cb = rev[q] ? cur : nb;       // matrix row = the centre's level
+                        uint32_t* const Pq = P + (uint64_t)q * cellsP;
+                        atomicAdd(&Pq[(uint64_t)(ca - off1) * ldP + (cb - off1)], 1u);
+                        if (symmetric) atomicAdd(&Pq[(uint64_t)(cb - off1) * ldP + (ca - off1)], 1u);
+                    }
+                }
+                cur = nxt;
+            }
+        }
+    } else
     for (uint32_t row = r0 + wave; row < r1; row += NW) {
-        const plane_t* const prow = plane + (uint64_t)row * R.w;
+        const plane_t* const prow = staged ? strip + (uint64_t)((int)row - s0) * R.pw : plane + (uint64_t)row * R.pw;
         for (int col = lane; col < w; col += 64) {
             const uint32_t lb = prow[col];
             if (lb == 0) continue;
@@ -261,19 +443,21 @@ __global__ __launch_bounds__(256) void large_cooc_kernel(const LargeArgs A)
                 if (q >= na) break;
                 const int r2 = (int)row + ddy[q], c2 = col + ddx[q];
                 if (r2 < 0 || r2 >= h || c2 < 0 || c2 >= w) continue;
-                const uint32_t la = plane[(uint64_t)r2 * R.w + (uint32_t)c2];
+                const uint32_t la = staged ? strip[(uint64_t)(r2 - s0) * R.pw + (uint32_t)c2] : plane[(uint64_t)r2 * R.pw + (uint32_t)c2];
                 if (la == 0) continue;
                 const int ia = greyInfo < 0 ? (int)s_map[la] - 1 : (int)la - 1;
-                atomicAdd(&P[q * NN + (uint64_t)ib * Ng + ia], 1u);
-                if (symmetric) atomicAdd(&P[q * NN + (uint64_t)ia * Ng + ib], 1u);
+                uint32_t* const Pq = P + (uint64_t)q * cellsP;
+                atomicAdd(&Pq[(uint64_t)(ib + 1 - (int)off1) * ldP + (uint32_t)(ia + 1 - (int)off1)], 1u);
+                if (symmetric) atomicAdd(&Pq[(uint64_t)(ia + 1 - (int)off1) * ldP + (uint32_t)(ib + 1 - (int)off1)], 1u);
             }
         }
     }
     if (in_lds) {
         __syncthreads();
-        for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) {
-            const uint32_t c = s_P[i];
-            if (c) atomicAdd(&gP[i], c);
+        for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) {          // cell (q, r, c) of the workspace matrices <- (q, r + 1, c + 1) here
+            const uint32_t q = i / (uint32_t)NN, rem = i - q * (uint32_t)NN, r = rem / (uint32_t)Ng, c = rem - r * (uint32_t)Ng;
+            const uint32_t v = s_P[(uint64_t)q * CC + (uint64_t)(r + 1) * NG1 + c + 1];
+            if (v) atomicAdd(&gP[i], v);
         }
     }
 }
@@ -326,7 +510,15 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
     if (do_int) {
         double* const o = out_row + A.col_intensity;
         const unsigned long long* const hdr = (const unsigned long long*)R.base;
-        uint32_t* const T = (uint32_t*)(R.base + R.L.tab);                    // counts, then (in place) inclusive prefix sums
+        // counts, then (in place) inclusive prefix sums: staged in LDS when the table fits (every later pass -- the prefix sums, the
+        // order statistics' searches, the robust sweeps -- is then a chain of LDS instead of L2 round trips)
+        uint32_t* T = (uint32_t*)(R.base + R.L.tab);
+        if (4ull * ((uint64_t)range + 1) <= A.fin_tab_bytes) {
+            uint32_t* const s_T = (uint32_t*)lds_raw;
+            for (uint32_t i = tid; i <= range; i += BS) s_T[i] = T[i];
+            T = s_T;
+            __syncthreads();
+        }
         const double tot = (double)hdr[0], totsq = (double)hdr[1];
         const double mean = tot / dn;
         const bool blank = vmin == 0 && vmax == 0;                            // intensity.cpp:121-122
@@ -385,7 +577,6 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
             if (lane == 0) { s_w[4 + wave] = mc_w; s_w[8 + wave] = bi_w; }
         }
         wg_sum<6>(acc, s_x, tid);                                             // (its barriers also publish the mode words and the prefix sums)
-        __threadfence_block();
         auto cum = [=](uint32_t i) -> uint32_t { return T[i]; };              // number of values <= vmin + i
         if (tid == 0) {
             uint32_t mc = 0, mi = 0;
@@ -421,7 +612,7 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
             // ---- histogram bin populations (histogram.h:55-78): lower bounds of the 100 percentile bins and the n custom bins over
             // the value domain -- the bin index is monotone in the value, so a bin's population is a difference of prefix sums
             const uint32_t nb = (uint32_t)A.n_hist;
-            uint32_t* const s_lb100 = (uint32_t*)lds_raw;                     // [104]
+            uint32_t* const s_lb100 = (uint32_t*)(lds_raw + A.fin_tab_bytes);  // [104]
             uint32_t* const s_lbc = s_lb100 + 104;                            // [nb + 8]
             const double binW100 = (double)range / 100.;
             for (uint32_t t = tid; t < 100 + nb; t += BS) {
@@ -488,8 +679,9 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
                         const uint32_t i = i64 > range ? range : (uint32_t)i64;
                         const unsigned long long hit = __ballot(cum(i) > k);
                         const uint32_t first = hit ? (uint32_t)__builtin_ctzll(hit) : 63u;
-                        lo += first * B;
-                        span = (uint64_t)lo + B > (uint64_t)range + 1 ? range + 1 - lo : B;
+                        const uint64_t lo64 = (uint64_t)lo + (uint64_t)first * B;
+                        lo = lo64 > range ? range : (uint32_t)lo64;          // (a histogram that holds fewer than n values -- intensities outside the
+                        span = (uint64_t)lo + B > (uint64_t)range + 1 ? range + 1 - lo : B;   //  stated [min, max] -- must not walk off the table: the search always ends)
                     }
                     return lo;
                 };
@@ -569,24 +761,32 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
         const int Ng = large_matrix_order<uint16_t>(A, R, (uint16_t*)nullptr, greyInfo < 0 ? s_I : (double*)nullptr, tid, BS);
         if (greyInfo >= 0)
             for (int i = tid; i < Ng; i += BS) s_I[i] = (double)(i + 1);
-        __syncthreads();
-        __threadfence();
         const uint32_t* const gP = (const uint32_t*)(R.base + R.L.P);
         const uint64_t NN = (uint64_t)Ng * Ng;
         if (Ng <= 0) {
             for (int c = tid; c < ncol_g; c += BS) o[c] = A.soft_nan;
             return;
         }
-        if (Ng <= 16) {                                   // small matrices: the angles share one wave's instruction stream
-            if (wave == 0)
-                glcm_features_rows<true, 16, 900>(gP, na, Ng, s_I, s_scr, 6 * (int)ngb, A.soft_nan, s_f, lane);
-        } else
-            for (int a0 = 0; a0 < na; a0 += NW)          // a wave per angle, 64 lanes over the cells
-                if (a0 + wave < na)
-                    glcm_features_rows<true, 64, 901>(gP + (size_t)(a0 + wave) * NN, 1, Ng, s_I, s_scr + (size_t)(a0 + wave) * 6 * ngb, 6 * (int)ngb, A.soft_nan,
-                                                      s_f + (a0 + wave) * 32, lane);
+        // the matrices: staged in LDS behind the scratch when they fit (the feature routine makes ~10 passes over them), else read in place
+        const bool scr_lds = scratch == (double*)lds_raw;
+        const bool p_lds = scr_lds && 4ull * na * NN <= A.fin_P_bytes;
+        uint32_t* const s_Pm = (uint32_t*)(lds_raw + ((large_glcm_scratch_bytes(ngb) + 15) & ~15ull));
+        if (p_lds)
+            for (uint32_t i = tid; i < (uint32_t)(na * NN); i += BS) s_Pm[i] = gP[i];
+        const uint32_t* const Pm = p_lds ? s_Pm : gP;
         __syncthreads();
-        __threadfence();
+        if (p_lds) {
+            if (Ng <= 16) {                               // small matrices: the angles share one wave's instruction stream
+                if (wave == 0) glcm_features_rows<false, 16, 900>(Pm, na, Ng, s_I, s_scr, 6 * (int)ngb, A.soft_nan, s_f, lane);
+            } else if (wave < na)                         // a wave per angle, 64 lanes over the cells
+                glcm_features_rows<false, 64, 901>(Pm + (size_t)wave * NN, 1, Ng, s_I, s_scr + (size_t)wave * 6 * ngb, 6 * (int)ngb, A.soft_nan, s_f + wave * 32, lane);
+        } else {
+            if (Ng <= 16) {
+                if (wave == 0) glcm_features_rows<true, 16, 902>(Pm, na, Ng, s_I, s_scr, 6 * (int)ngb, A.soft_nan, s_f, lane);
+            } else if (wave < na)
+                glcm_features_rows<true, 64, 903>(Pm + (size_t)wave * NN, 1, Ng, s_I, s_scr + (size_t)wave * 6 * ngb, 6 * (int)ngb, A.soft_nan, s_f + wave * 32, lane);
+        }
+        __syncthreads();
         for (int c = tid; c < kGlcmAngled * na; c += BS) {   // feature-major, angle-minor (output_2_buffer.cpp:336-346)
             const int k = c / na, a = c - k * na;
             o[c] = s_f[a * 32 + k];
@@ -618,25 +818,23 @@ int launch_large_features(const LargeArgs& a, void* stream)
             // (dynamic LDS beyond 64 KiB is an opt-in per kernel; the static words of a kernel count against the CU's 160 KiB too)
             const struct { const void* f; int bytes; } k[] = {
                 {(const void*)large_load_kernel<false>, 136 * 1024}, {(const void*)large_load_kernel<true>, 136 * 1024},
-                {(const void*)large_cooc_kernel<false>, 104 * 1024}, {(const void*)large_cooc_kernel<true>, 104 * 1024},
+                {(const void*)large_cooc_kernel<false>, 120 * 1024}, {(const void*)large_cooc_kernel<true>, 120 * 1024},
                 {(const void*)large_finish_kernel, 64 * 1024}};
             for (const auto& e : k)
                 if (hipError_t rc = hipFuncSetAttribute(e.f, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes); rc != hipSuccess) return (int)rc;
             return 0;
         }))
         return orc;
-    hipLaunchKernelGGL(large_prep_kernel, dim3((a.n_list + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(large_prep_kernel, dim3((a.n_list + 255) / 256), dim3(256), 0, st, a);
     const size_t lds_load = 2ull * a.tab_lds + 2 * 16 * 8;
-    const uint32_t bs_load = a.px_per_wg > 8192 ? 1024u : 256u;
+    const uint32_t bs_load = a.px_per_wg / 32u;                              // 32 pixels per thread: 256 / 512 / 1024 threads
     if (a.plane16) hipLaunchKernelGGL(large_load_kernel<true>, dim3(a.cap_load), dim3(bs_load), lds_load, st, a);
     else hipLaunchKernelGGL(large_load_kernel<false>, dim3(a.cap_load), dim3(bs_load), lds_load, st, a);
     if (a.mask & NYXHIP_FAM_GLCM) {
-        if (a.plane16) hipLaunchKernelGGL(large_cooc_kernel<true>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes, st, a);
-        else hipLaunchKernelGGL(large_cooc_kernel<false>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes, st, a);
+        if (a.plane16) hipLaunchKernelGGL(large_cooc_kernel<true>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes + a.lds_strip_bytes, st, a);
+        else hipLaunchKernelGGL(large_cooc_kernel<false>, dim3(a.cap_cooc), dim3(256), a.lds_P_bytes + a.lds_strip_bytes, st, a);
     }
-    size_t lds_fin = 4ull * (104 + (size_t)a.n_hist + 8);
-    if (a.mask & NYXHIP_FAM_GLCM) lds_fin = std::max<size_t>(lds_fin, kLargeScratchLds);   // (larger scratch lives in the ROI's block)
-    hipLaunchKernelGGL(large_finish_kernel, dim3(a.n_list), dim3(256), lds_fin, st, a);
+    hipLaunchKernelGGL(large_finish_kernel, dim3(a.n_list), dim3(256), a.lds_fin_bytes, st, a);
     return (int)hipGetLastError();
 }
 

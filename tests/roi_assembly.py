@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _abi
+from nyxus_amd import _abi
 
 
 def assemble(inten: np.ndarray, label: np.ndarray, slide_min=None, slide_max=None) -> _abi.HostBatch:

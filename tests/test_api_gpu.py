@@ -18,7 +18,7 @@ def _moment_floors(images, masks, want, cols):
     the cancelling terms (tests/parity.py: moment_atol), per ROI, from the same pixels the call saw.  None without such columns."""
     if not any(c.startswith(("CENTRAL_MOMENT_", "IMOM_CM_")) for c in cols):
         return None
-    from nyxus_amd import roi_assembly
+    from tests import roi_assembly
     r0, atol = 0, {}
     for it, sg in zip(images, masks):
         it = np.asarray(it).astype(np.float64)

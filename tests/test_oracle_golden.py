@@ -319,7 +319,7 @@ def test_reference_tile_workflow_equals_assembly_plus_oracle():
     if not po.have_ref():
         import pytest
         pytest.skip("oracle/_ref not built")
-    from nyxus_amd import roi_assembly
+    from tests import roi_assembly
     from tests import synth
     rng = np.random.default_rng(4)
     lab = synth.disk_label_tile(size=128, pitch=32, radius=12)

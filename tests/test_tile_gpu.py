@@ -1,9 +1,10 @@
 """GPU tests of the fused tile path (nyxhip_featurize_tile): device label scan + ROI assembly + reduce,
-against host assembly (nyxus_amd.roi_assembly, the restated phases 1-2) + the CPU oracle."""
+against host assembly (tests.roi_assembly, the restated phases 1-2) + the CPU oracle."""
 import numpy as np
 import pytest
 
-from nyxus_amd import _abi, _lib, roi_assembly
+from nyxus_amd import _abi, _lib
+from tests import roi_assembly
 from oracle import pyoracle as po
 from tests import parity, synth
 

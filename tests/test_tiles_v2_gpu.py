@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 import nyxus_amd
-from nyxus_amd import _abi, _lib, roi_assembly
+from nyxus_amd import _abi, _lib
+from tests import roi_assembly
 from oracle import pyoracle as po
 from tests import parity, synth
 
