@@ -1931,20 +1931,44 @@ static int res_reserve(nyxhip_ctx* ctx, size_t rows, size_t n_cols, hipStream_t 
 // Pins a caller's host arrays for the duration of a call (hipHostRegister): a pinned source makes the chunk copies true DMA
 // transfers that overlap the kernels (50-57 GB/s measured); left pageable, an asynchronous copy goes through the runtime's staging
 // path at 8-20 GB/s.  The runtime keeps the pinning cached across calls on the same buffer (first call ~22 us/MB, later ones
-// ~0.01 ms).  Only arrays of at least kPinMinBytes are pinned: below that the staging path costs nothing measurable, and a small
-// array lives in the allocator's heap, sharing its first and last page with unrelated objects -- registering and unregistering such
-// pages call after call ended one full run of the GPU test suite in six with "Memory access fault by GPU ... on address <a page
-// of the host heap>" inside a later call's copy (never with the tile tests alone; large arrays are mapped regions of their own).
+// ~0.01 ms).
+// Only WHOLE PAGES that lie inside the array are registered (the range is rounded inward to 4 KiB; the bytes in front of the
+// first and behind the last whole page travel as pageable copies of their own, h2d below).  Round 3 registered the array as it
+// came: an array that starts or ends inside a page shares that page with whatever the allocator put next to it -- another array
+// of the same call, typically -- and two registrations that overlap in a page, released one after the other, left the second
+// one's cached mapping without that page: "Memory access fault by GPU ... on address <a page of the host heap>" inside a later
+// call's copy (5 of 48 runs of the GPU suite; never with page-aligned or private mappings).  Rounded inward, no two
+// registrations can share a page.  Arrays below kPinMinBytes are not pinned at all (their staging copies cost nothing
+// measurable; NYXHIP_PIN_MIN overrides the threshold: tests/test_pin_stress_gpu.py runs with 0).
 // One guard per ARRAY: the sharded entry pins the whole stack once, before its threads copy their shares -- per-share
-// registrations would overlap in the pages that hold a share boundary and be released at different times.
+// registrations would be released at different times while other shares still copy.
 struct HostPin {
     void* p[2] = {nullptr, nullptr};
+    uintptr_t lo[2] = {0, 0}, hi[2] = {0, 0};          // registered byte range of array k (empty: lo == hi)
     static constexpr size_t kPinMinBytes = (size_t)8 << 20;
+    static constexpr uintptr_t kPage = 4096;
     void pin(int k, const void* ptr, size_t bytes)
     {
         static const bool no_pin = [] { const char* e = getenv("NYXHIP_NO_PIN"); return e && *e && *e != '0'; }();   // A/B knob
-        if (no_pin || bytes < kPinMinBytes || !ptr) return;
-        if (hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p[k] = (void*)ptr; else (void)hipGetLastError();
+        const char* const me = getenv("NYXHIP_PIN_MIN");
+        const size_t pin_min = me && *me ? (size_t)atoll(me) : kPinMinBytes;
+        if (no_pin || bytes < pin_min || !ptr) return;
+        const uintptr_t a = ((uintptr_t)ptr + kPage - 1) & ~(kPage - 1), z = ((uintptr_t)ptr + bytes) & ~(kPage - 1);
+        if (z <= a) return;                                   // no whole page inside the array
+        if (hipHostRegister((void*)a, z - a, hipHostRegisterDefault) == hipSuccess) { p[k] = (void*)a; lo[k] = a; hi[k] = z; } else (void)hipGetLastError();
+    }
+    // host -> device copy of [src, src + bytes) of array k: the part inside the registered pages as one (DMA) copy, what lies in
+    // front of and behind them as pageable copies
+    hipError_t h2d(int k, void* dst, const void* src, size_t bytes, hipStream_t st) const
+    {
+        const uintptr_t b0 = (uintptr_t)src, b1 = b0 + bytes;
+        const uintptr_t m0 = std::min(std::max(b0, lo[k]), b1), m1 = std::max(std::min(b1, hi[k]), m0);   // the pinned middle [m0, m1)
+        if (lo[k] == hi[k] || m0 == m1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        hipError_t e = hipSuccess;
+        if (m0 > b0) e = hipMemcpyAsync(dst, src, m0 - b0, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)dst + (m0 - b0), (const void*)m0, m1 - m0, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && b1 > m1) e = hipMemcpyAsync((char*)dst + (m1 - b0), (const void*)m1, b1 - m1, hipMemcpyHostToDevice, st);
+        return e;
     }
     ~HostPin() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
 };
@@ -1952,7 +1976,7 @@ struct HostPin {
 // The whole stack in chunks.  label_limit: v1's max_label (validated only).  prepinned: the caller has pinned the arrays.
 static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mask, const nyxhip_settings* s, uint32_t* out_labels, uint32_t* out_tile_index,
                      uint64_t max_rows, double* out_table, size_t out_ld, uint64_t* n_roi_out, uint32_t label_limit, uint32_t tile_index_base = 0,
-                     bool prepinned = false)
+                     const HostPin* prepinned = nullptr)
 {
     if (int vrc = tiles_validate(ctx, t, family_mask, s, n_roi_out)) return vrc;
     const int n_cols = nyxhip_n_columns(family_mask, s);
@@ -2034,23 +2058,22 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         if (int grc = grow(ctx, &ctx->d_slot[k], &ctx->slot_bytes[k], slot_need, st)) return grc;
     auto slot_inten = [&](int k) { return (char*)ctx->d_slot[k]; };
     auto slot_label = [&](int k, uint32_t nt) { return (char*)ctx->d_slot[k] + (((size_t)nt * tile_px * t->inten_dtype + 255) & ~(size_t)255); };
-    auto upload = [&](uint64_t c) -> int {                                  // chunk c -> slot c & 1 on the copy stream
-        const int k = (int)(c & 1);
-        const uint64_t t0 = c * chunk;
-        const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
-        if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
-        HIP_TRY(ctx, hipMemcpyAsync(slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype,
-                                    hipMemcpyHostToDevice, ctx->copy_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype,
-                                    hipMemcpyHostToDevice, ctx->copy_stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
-        return NYXHIP_OK;
-    };
     HostPin pin;                                        // (see HostPin: arrays of at least 8 MiB, unless the caller pinned the stack)
     if (!prepinned) {
         pin.pin(0, t->inten, (size_t)t->n_tiles * tile_px * t->inten_dtype);
         pin.pin(1, t->label, (size_t)t->n_tiles * tile_px * t->label_dtype);
     }
+    const HostPin* const pins = prepinned ? prepinned : &pin;
+    auto upload = [&](uint64_t c) -> int {                                  // chunk c -> slot c & 1 on the copy stream
+        const int k = (int)(c & 1);
+        const uint64_t t0 = c * chunk;
+        const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
+        if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
+        HIP_TRY(ctx, pins->h2d(0, slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype, ctx->copy_stream));
+        HIP_TRY(ctx, pins->h2d(1, slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype, ctx->copy_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
+        return NYXHIP_OK;
+    };
     // every exit below -- the error returns included -- first waits for the copies and kernels still in flight: the pin guard above
     // unregisters the caller's arrays, and the caller may free them the moment this function returns
     struct Drain {
@@ -2175,7 +2198,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
             if (tiles->slide_min) part.slide_min = tiles->slide_min + lo[g];
             if (tiles->slide_max) part.slide_max = tiles->slide_max + lo[g];
             if (part.n_tiles == 0) { rcs[g] = 0; return; }
-            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu, (uint32_t)lo[g], true);   // tile indices of the whole stack
+            rcs[g] = tiles_run(ctxs[g], &part, family_mask, s, nullptr, nullptr, 0, nullptr, 0, &cnt[g], 0xFFFFFFFFu, (uint32_t)lo[g], &pin);   // tile indices of the whole stack
         });
     for (auto& t : th) t.join();
     for (int g = 0; g < G; g++)

@@ -1,0 +1,67 @@
+"""Stress test of the host-array pinning of the tile path (nyxhip_api.hip: HostPin).
+
+Round 3 saw "Memory access fault by GPU ... on address <a page of the host heap>" in 5 of 48 runs of the GPU suite, inside
+featurize_tiles_host, and worked around it by not pinning arrays below 8 MiB.  The cause: an array was registered as it came, so
+an array that starts or ends inside a page shared that page's registration with its neighbour in the heap.  HostPin now registers
+whole pages inside the array only and copies the edges as pageable memory.  This test drives the pattern that used to fault --
+hundreds of calls alternating small heap arrays, large arrays and unaligned slices of larger arrays -- once with the default
+threshold and once with NYXHIP_PIN_MIN=0 (every array with a whole page inside it is pinned)."""
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+MASK = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+
+
+def _labels(n, size, rng):
+    lab = np.zeros((n, size, size), np.uint32)
+    yy, xx = np.mgrid[0:size, 0:size]
+    for t in range(n):
+        for k in range(1, 5):
+            cy, cx, r = rng.integers(8, size - 8, 2).tolist() + [int(rng.integers(3, 8))]
+            lab[t][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = k
+    return lab
+
+
+@pytest.mark.parametrize("pin_min", [None, "0"])
+def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, monkeypatch, pin_min):
+    if pin_min is not None:
+        monkeypatch.setenv("NYXHIP_PIN_MIN", pin_min)
+    rng = np.random.default_rng(23)
+    s = _abi.default_settings(8)
+    # small: two 64 x 64 tiles (32 KB per array: heap-allocated, neighbours share pages)
+    sm_lab = _labels(2, 64, rng)
+    sm_int = rng.integers(1, 4096, sm_lab.shape).astype(np.uint32)
+    # large: three 1024 x 1024 tiles (12 MiB per array: a mapping of its own)
+    lg_lab = _labels(3, 1024, rng)
+    lg_int = rng.integers(1, 4096, lg_lab.shape).astype(np.uint32)
+    # unaligned: a 9 MiB slice that starts 12 bytes into a larger array and ends short of it (edge pages shared with the rest)
+    n_sl = 9 * 512 * 512
+    big_i = rng.integers(1, 4096, n_sl + 1000).astype(np.uint32)
+    big_l = np.zeros(n_sl + 1000, np.uint32)
+    sl_lab = big_l[3:3 + n_sl].reshape(9, 512, 512)
+    sl_lab[:] = _labels(9, 512, rng)
+    sl_int = big_i[3:3 + n_sl].reshape(9, 512, 512)
+    assert sl_int.ctypes.data % 4096 != 0 and sl_lab.ctypes.data % 4096 != 0
+    cases = [(sm_int, sm_lab), (lg_int, lg_lab), (sl_int, sl_lab)]
+    first = [None, None, None]
+    churn = []
+    for it in range(300):
+        k = it % 3
+        # fresh small arrays now and then: the allocator hands their pages out again and again
+        if k == 0 and it % 9 == 0:
+            churn = [rng.integers(1, 4096, sm_lab.shape).astype(np.uint32) for _ in range(3)]
+            inten, lab = churn[it % 3], sm_lab.copy()
+            _t, labels, table = hip_ctx.featurize_tiles_host(inten, lab, MASK, s)
+            assert len(labels) == 8 and np.isfinite(table[:, 0]).all()
+            continue
+        inten, lab = cases[k]
+        _t, labels, table = hip_ctx.featurize_tiles_host(inten, lab, MASK, s)
+        if first[k] is None:
+            first[k] = (labels.copy(), table.copy())
+        else:
+            assert np.array_equal(labels, first[k][0])
+            assert np.array_equal(table, first[k][1], equal_nan=True)
