@@ -385,7 +385,8 @@ def main():
             try:
                 import hashlib
                 tj = json.load(open(tpath))
-                src = hashlib.sha256(open(os.path.join(ROOT, "nyxus_amd", "csrc", "roi_features.hip"), "rb").read()).hexdigest()
+                src = hashlib.sha256(b"".join(open(os.path.join(ROOT, "nyxus_amd", "csrc", f_), "rb").read()     # every source the metric kernels are built from
+                                                for f_ in ("roi_features.hip", "glcm_rows.h", "device_math.h", "roi_kernel.h"))).hexdigest()
                 if tj.get("tiles") == a.tiles and tj.get("gray_depth") == a.gray_depth and tj.get("kernel_source_sha256") == src:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:

@@ -661,7 +661,11 @@ int launch_roi_moments(const MomArgs& a, void* stream, uint32_t grid)
     const uint32_t dyn = 8u * a.px_cap + 4u * a.k_cap + 2u * a.step_cap;
     // static LDS of the kernel (exchange area + the four total blocks) is 1296 B; LDS is allocated in 1280-byte granules
     const uint32_t granules = (dyn + 1296u + 1279u) / 1280u;
-    if (6u * granules * 1280u <= (uint32_t)roi_features_max_lds())
+    // (A/B knob.  The six-per-CU build carries 12 spilled VGPRs -- 40 B of scratch per lane, the 1.9 GB the counters see written per
+    //  196 k ROIs -- and is still the faster one: 16.5 ms for both moment families against 17.7 ms for the spill-free build at four
+    //  workgroups per CU and 16.7 ms for a 96-register build, which spills 10 all the same: the kernel wants 108.)
+    static const int occ_knob = [] { const char* e = getenv("NYXHIP_MOM_OCC"); return e && *e ? atoi(e) : 6; }();
+    if (occ_knob >= 6 && 6u * granules * 1280u <= (uint32_t)roi_features_max_lds())
         hipLaunchKernelGGL(roi_moments_kernel<6>, dim3(grid), dim3(kMB), dyn, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(roi_moments_kernel<4>, dim3(grid), dim3(kMB), dyn, (hipStream_t)stream, a);

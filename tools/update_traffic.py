@@ -1,5 +1,5 @@
 """profiles/hbm_traffic.json from a tools/profile_bench.sh run: python tools/update_traffic.py <tag>  (reads gpurun_out/prof_<tag>/summary.txt).
-bench.py reports the value as `roofline.traffic` only while nyxus_amd/csrc/roi_features.hip still hashes to what was measured."""
+bench.py reports the value as `roofline.traffic` only while the sources of the metric kernels (roi_features.hip, glcm_rows.h, device_math.h, roi_kernel.h) still hash to what was measured."""
 import hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -12,7 +12,8 @@ rec = {"round": tag, "kernel": "roi_features_kernel_occ8<1, 0>", "tiles": 1000, 
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
        "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
        "rocprof_kernel_ms": [float(kern.group(1)), float(kern.group(2))] if kern else None,
-       "kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, "nyxus_amd", "csrc", "roi_features.hip"), "rb").read()).hexdigest(),
+       "kernel_source_sha256": hashlib.sha256(b"".join(open(os.path.join(ROOT, "nyxus_amd", "csrc", f_), "rb").read()
+                                                       for f_ in ("roi_features.hip", "glcm_rows.h", "device_math.h", "roi_kernel.h"))).hexdigest(),
        "collected": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), bench.py --steps 5 --warmup 2; "
                     f"metric-workload dispatches only (profiles/{tag}_summary.txt)"}
 json.dump(rec, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
