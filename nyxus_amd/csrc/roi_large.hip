@@ -26,6 +26,7 @@
 #include "roi_kernel.h"
 #include "launch_util.h"
 #include "glcm_rows.h"
+#include "intensity_table.h"
 #include "../../include/nyxhip.h"
 
 namespace nyxhip {
@@ -463,31 +464,6 @@ __global__ __launch_bounds__(256) void large_cooc_kernel(const LargeArgs A)
 }
 
 // ---- finish: one workgroup per ROI ----------------------------------------------------------------------------------------------
-// fixed-order workgroup sums (wave DPP tree, then the four wave partials in wave order); every thread gets the totals
-template <int N>
-__device__ __forceinline__ void wg_sum(double (&v)[N], double* s_x, int tid)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < N; k++) v[k] = wave_sum(v[k]);
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < N; k++) s_x[wave * 8 + k] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < N; k++) v[k] = ((s_x[k] + s_x[8 + k]) + s_x[16 + k]) + s_x[24 + k];
-}
-__device__ __forceinline__ unsigned long long wg_sum_u64(unsigned long long v, unsigned long long* s_x, int tid)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    v = wave_sum_u64(v);
-    __syncthreads();
-    if (lane == 0) s_x[wave] = v;
-    __syncthreads();
-    return s_x[0] + s_x[1] + s_x[2] + s_x[3];
-}
-
 __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -519,44 +495,13 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
             T = s_T;
             __syncthreads();
         }
-        const double tot = (double)hdr[0], totsq = (double)hdr[1];
-        const double mean = tot / dn;
-        const bool blank = vmin == 0 && vmax == 0;                            // intensity.cpp:121-122
-        if (tid == 0) {
-            o[I_MIN] = (double)vmin;                                           // intensity.cpp:67-69
-            o[I_MAX] = (double)vmax;
-            o[I_RANGE] = (double)vmax - (double)vmin;
-            if (A.slide_min && A.slide_max)                                    // intensity.cpp:72-77
-                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[R.roi] - A.slide_min[R.roi]);
-            o[I_MEAN] = mean;                                                  // intensity.cpp:95-99
-            o[I_ENERGY] = totsq;
-            o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
-            o[I_INTEGRATED_INTENSITY] = tot;
-            if (!blank)
-                o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0;   // :162
-        }
-        // ---- sweep 1 over the histogram: central sums (intensity.cpp:102-109, :177-183; M2..M4 of moments.h:53-74 equal the plain
-        // central sums), the mode (largest count, smallest value on ties: histogram.h:289-309), inclusive prefix sums in place
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t best_c = 0, best_i = 0, carry = 0;
+        // inclusive prefix sums in place: four entries per thread and step, wave scan, cross-wave carry
+        uint32_t carry = 0;
         for (uint32_t i0 = 0; i0 <= range; i0 += BS * 4) {
             const uint32_t i = i0 + 4u * (uint32_t)tid;
             uint32_t c[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) c[k] = i + k <= range ? T[i + k] : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (c[k] > best_c) { best_c = c[k]; best_i = i + k; }
-                if (c[k] && !blank) {
-                    const double cd = (double)c[k], d = (double)(vmin + i + k) - mean, d2 = d * d;
-                    acc[0] += cd * fabs(d);
-                    acc[1] += cd * d2;
-                    acc[2] += cd * (d2 * d);
-                    acc[3] += cd * (d2 * d2);
-                    acc[4] += cd * (d2 * d2 * d);
-                    acc[5] += cd * (d2 * d2 * d2);
-                }
-            }
             c[1] += c[0]; c[2] += c[1]; c[3] += c[2];
             const uint32_t sc = wave_scan_u32(c[3]);
             __syncthreads();
@@ -569,178 +514,17 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
                 if (i + k <= range) T[i + k] = c[k] + excl;
             carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         }
-        {   // mode: (count desc, index asc) over the workgroup
-            const uint32_t mc_w = wave_max_u32(best_c);
-            const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
-            const uint32_t bi_w = ~wave_max_u32(~cand);
-            __syncthreads();
-            if (lane == 0) { s_w[4 + wave] = mc_w; s_w[8 + wave] = bi_w; }
-        }
-        wg_sum<6>(acc, s_x, tid);                                             // (its barriers also publish the mode words and the prefix sums)
-        auto cum = [=](uint32_t i) -> uint32_t { return T[i]; };              // number of values <= vmin + i
-        if (tid == 0) {
-            uint32_t mc = 0, mi = 0;
-            for (int wv = 0; wv < NW; wv++) {
-                const uint32_t c = s_w[4 + wv], i = s_w[8 + wv];
-                if (c > mc || (c == mc && i < mi)) { mc = c; mi = i; }
-            }
-            if (!blank) o[I_MODE] = (double)(vmin + mi);
-            // everything that depends only on the central sums (intensity.cpp:110-118, :166-191)
-            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
-            const double variance = dn > 1 ? acc[1] / (dn - 1) : 0.0, variance_b = dn > 1 ? acc[1] / dn : 0.0;
-            const double sd = sqrt(variance);
-            o[I_VARIANCE] = variance;
-            o[I_VARIANCE_BIASED] = variance_b;
-            o[I_STANDARD_DEVIATION] = sd;
-            o[I_STANDARD_DEVIATION_BIASED] = sqrt(variance_b);
-            o[I_COV] = sd / mean;
-            o[I_STANDARD_ERROR] = sd / sqrt(dn);
-            if (!blank) {
-                const double M2 = acc[1], M3 = acc[2], M4 = acc[3];           // moments.h:79-109
-                if (M2 != 0.0) {
-                    const double kurt = n > 4 ? (dn * M4) / (M2 * M2) : 0.0;
-                    o[I_SKEWNESS] = n > 3 ? (sqrt(dn) * M3) / (M2 * sqrt(M2)) : 0.0;
-                    o[I_KURTOSIS] = kurt;
-                    o[I_EXCESS_KURTOSIS] = n > 4 ? kurt - 3 : 0.0;
-                }
-                const double sd2 = sd * sd, d5 = dn * (sd2 * sd2 * sd), d6 = dn * (sd2 * sd2 * sd2);   // intensity.cpp:186-191
-                o[I_HYPERSKEWNESS] = d5 == 0. ? 0. : acc[4] / d5;
-                o[I_HYPERFLATNESS] = d6 == 0. ? 0. : acc[5] / d6;
-            }
-        }
-        if (!blank) {
-            // ---- histogram bin populations (histogram.h:55-78): lower bounds of the 100 percentile bins and the n custom bins over
-            // the value domain -- the bin index is monotone in the value, so a bin's population is a difference of prefix sums
-            const uint32_t nb = (uint32_t)A.n_hist;
-            uint32_t* const s_lb100 = (uint32_t*)(lds_raw + A.fin_tab_bytes);  // [104]
-            uint32_t* const s_lbc = s_lb100 + 104;                            // [nb + 8]
-            const double binW100 = (double)range / 100.;
-            for (uint32_t t = tid; t < 100 + nb; t += BS) {
-                const bool is100 = t < 100;
-                const uint32_t b = is100 ? t : t - 100;
-                auto bin_of = [=](uint32_t dd) -> uint32_t {
-                    if (is100) {
-                        const double realIdx = (double)dd / binW100;          // (h - minVal) / binW100, histogram.h:57-60
-                        return (realIdx != realIdx) ? 0u : (uint32_t)(int)realIdx;
-                    }
-                    return to_grayscale(vmin + dd, vmin, range, nb);
-                };
-                // smallest offset d in [0, range + 1] whose bin index reaches b: start from the real-valued boundary and settle with
-                // the exact (reference) bin function
-                const double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
-                uint32_t d = !(edge < (double)range + 1.0) ? range + 1 : (uint32_t)edge;
-                while (d > 0 && bin_of(d - 1) >= b) d--;
-                while (d <= range && bin_of(d) < b) d++;
-                const uint32_t lo = d > 0 ? cum(d - 1) : 0u;
-                if (is100) s_lb100[b] = lo; else s_lbc[b] = lo;
-            }
-            __syncthreads();
-            if (wave == 0) {
-                // percentiles P01, P10, P25, P75, P90, P99 (histogram.h:214-243): the LAST bin i with runSum_i <= cnt <= runSum_i + bins_i
-                // wins (every matching bin overwrites); runSum_i is the lower bound of bin i.  Lanes test bins i and i + 64.
-                const int i0 = lane, i1 = lane + 64;
-                const uint32_t r0 = s_lb100[i0], e0 = (i0 < 99 ? s_lb100[i0 + 1] : n);
-                const uint32_t r1 = i1 < 100 ? s_lb100[i1] : 0u, e1 = i1 < 100 ? (i1 < 99 ? s_lb100[i1 + 1] : n) : 0u;
-                int mywin = -1;
-                double mycnt = 0;
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    const double frac = q == 0 ? 0.01 : q == 1 ? 0.1 : q == 2 ? 0.25 : q == 3 ? 0.75 : q == 4 ? 0.9 : 0.99;
-                    const double cnt_p = dn * frac;
-                    const bool m0 = (double)r0 <= cnt_p && cnt_p <= (double)e0;
-                    const bool m1 = i1 < 100 && (double)r1 <= cnt_p && cnt_p <= (double)e1;
-                    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
-                    const int win = b1 ? 64 + (63 - __clzll((long long)b1)) : (b0 ? 63 - __clzll((long long)b0) : -1);
-                    if (lane == q) { mywin = win; mycnt = cnt_p; }
-                }
-                double pv = 0;
-                if (mywin >= 0) {
-                    const uint32_t rs = s_lb100[mywin], bi = (mywin < 99 ? s_lb100[mywin + 1] : n) - rs;
-                    pv = (mycnt - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)mywin;
-                }
-                if (lane < 6) s_pq[lane] = pv;
-                wav_sync<false>();
-                if (lane == 0) {
-                    const double* const pq = s_pq;
-                    o[I_P01] = pq[0]; o[I_P10] = pq[1]; o[I_P25] = pq[2]; o[I_P75] = pq[3]; o[I_P90] = pq[4]; o[I_P99] = pq[5];
-                    o[I_QCOD] = (pq[3] - pq[2]) / (pq[3] + pq[2]);
-                    o[I_INTERQUARTILE_RANGE] = pq[3] - pq[2];
-                    s_stat[0] = pq[1];
-                    s_stat[1] = pq[4];
-                }
-            }
-            if (wave == 2) {
-                // median (histogram.h:268-287): order statistics n/2 and n/2 - 1 = smallest i with cum(i) > k, by a 64-way search
-                auto kth = [&](uint32_t k) -> uint32_t {
-                    uint32_t lo = 0, span = range + 1;                       // the answer lies in [lo, lo + span)
-                    while (span > 1) {
-                        const uint32_t B = (span + 63) >> 6;
-                        uint64_t i64 = (uint64_t)lo + (uint64_t)((uint32_t)lane + 1) * B - 1;   // last position of this lane's block
-                        const uint32_t i = i64 > range ? range : (uint32_t)i64;
-                        const unsigned long long hit = __ballot(cum(i) > k);
-                        const uint32_t first = hit ? (uint32_t)__builtin_ctzll(hit) : 63u;
-                        const uint64_t lo64 = (uint64_t)lo + (uint64_t)first * B;
-                        lo = lo64 > range ? range : (uint32_t)lo64;          // (a histogram that holds fewer than n values -- intensities outside the
-                        span = (uint64_t)lo + B > (uint64_t)range + 1 ? range + 1 - lo : B;   //  stated [min, max] -- must not walk off the table: the search always ends)
-                    }
-                    return lo;
-                };
-                const uint32_t hi_v = vmin + kth(n / 2), lo_v = vmin + kth(n / 2 ? n / 2 - 1 : 0);
-                if (lane == 0) {
-                    const double median = (n & 1) ? (double)hi_v : (double)(uint32_t)(hi_v + lo_v) / 2.0;
-                    o[I_MEDIAN] = median;
-                    s_stat[2] = median;
-                }
-            }
-            if (wave == 1) {
-                // entropy / uniformity over the n + 1 slots (histogram.h:145-151): slot n is empty
-                double e = 0, u = 0;
-                for (uint32_t k = lane; k < nb; k += 64) {
-                    const uint32_t ck = (k < nb - 1 ? s_lbc[k + 1] : n) - s_lbc[k];
-                    const double p = (double)ck / dn;
-                    e += p * log2(p + 2.2e-16);
-                    u += p * p;
-                }
-                e = wave_sum(e);
-                u = wave_sum(u);
-                if (lane == 0) { o[I_ENTROPY] = -e; o[I_UNIFORMITY] = u; }
-            }
-            __syncthreads();
-            // ---- robust statistics over [p10, p90] (intensity.cpp:139-149, histogram.h:90-112) and the median deviation (:156-159)
-            const double p10 = s_stat[0], p90 = s_stat[1], median = s_stat[2];
-            uint32_t lox = 1, hix = 0;                                         // empty unless the bounds say otherwise (NaN: empty)
-            if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
-                const double cl = ceil(p10), fl = floor(p90);
-                const uint32_t lo_v = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_v = fl >= (double)vmax ? vmax : (uint32_t)fl;
-                if (lo_v <= hi_v) { lox = lo_v - vmin; hix = hi_v - vmin; }
-            }
-            const bool some = lox <= hix;
-            const uint32_t K = some ? cum(hix) - (lox ? cum(lox - 1) : 0u) : 0u;
-            auto count_at = [=](uint32_t i) -> uint32_t { return cum(i) - (i ? cum(i - 1) : 0u); };
-            unsigned long long sx = 0;                                         // exact integer sum of the values inside the bounds
-            double medad[1] = {0};
-            for (uint32_t i = tid; i <= range; i += BS) {
-                const uint32_t c = count_at(i);
-                if (!c) continue;
-                if (some && i >= lox && i <= hix) sx += (unsigned long long)c * (vmin + i);
-                medad[0] += (double)c * fabs((double)(vmin + i) - median);
-            }
-            sx = wg_sum_u64(sx, s_u, tid);
-            wg_sum<1>(medad, s_x, tid);
-            const double mean1090 = K ? (double)sx / (double)K : 0.0;
-            double ad[1] = {0};
-            if (K)
-                for (uint32_t i = lox + tid; i <= hix; i += BS) {
-                    const uint32_t c = count_at(i);
-                    if (c) ad[0] += (double)c * fabs((double)(vmin + i) - mean1090);
-                }
-            wg_sum<1>(ad, s_x, tid);
-            if (tid == 0) {
-                o[I_ROBUST_MEAN] = mean1090;
-                o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? ad[0] / (double)K : 0.0;
-                o[I_MEDIAN_ABSOLUTE_DEVIATION] = medad[0] / dn;
-            }
-        }
+        __syncthreads();
+        struct DenseTab {                                  // entry i = value vmin + i
+            const uint32_t* T; uint32_t m;
+            __device__ __forceinline__ uint32_t off(uint32_t i) const { return i; }
+            __device__ __forceinline__ uint32_t cum(uint32_t i) const { return T[i]; }
+            __device__ __forceinline__ uint32_t first_ge(uint64_t d) const { return d < m ? (uint32_t)d : m; }
+        } tab{T, range + 1};
+        IntensityScratch S{s_x, s_u, s_stat, s_pq, s_w, (uint32_t*)(lds_raw + A.fin_tab_bytes), (uint32_t*)(lds_raw + A.fin_tab_bytes) + 104};
+        const bool have_slide = A.slide_min && A.slide_max;
+        intensity_from_table(tab, n, vmin, vmax, (double)hdr[0], (double)hdr[1], have_slide, have_slide ? A.slide_max[R.roi] - A.slide_min[R.roi] : 0.0,
+                             (uint32_t)A.n_hist, o, S, tid);
         __syncthreads();
     }
 
