@@ -803,7 +803,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // raw buffer descriptors (32-bit lane offsets, the row advance in the scalar offset: no 64-bit address arithmetic),
             // eight rows per wave and trip with every load of the trip issued before the first use, where a row-at-a-time loop left
             // the kernel waiting on ~30 dependent round trips per ROI (3.7 ms per 196 k ROIs against 2.0 ms from pre-assembled clouds).
-            constexpr int UW = 8;                                                        // rows per wave and trip
+            constexpr int UW = 4;                                                        // rows per wave and trip
             const int dtl = A.win.dt_label, dti = A.win.dt_inten;
             // The element sizes are launch constants, but a test per load put two scalar branches between any two loads of a trip
             // (1.6 k scalar instructions per wave, the loads trickling out behind taken branches): the loader body is instantiated
@@ -852,7 +852,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     for (int u = 0; u < UW; u++) rc[u * NW + wave] = (uint32_t)__popcll(bal[u]);
                 }
                 grp_sync<GS, NW>();
-                const uint32_t inc = wave_scan_u32(lane < 32 ? rc[lane & 31] : 0u);       // inclusive prefix over the trip's rows in row order
+                const uint32_t inc = wave_scan_u32(lane < NW * UW ? rc[lane & (NW * UW - 1)] : 0u);   // inclusive prefix over the trip's rows in row order
 #pragma unroll
                 for (int u = 0; u < UW; u++) {
                     const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)inc, u * NW + wave);
@@ -861,7 +861,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     if (((bal[u] >> lane) & 1ull) && i < n)
                         member(vv[u], i, (r0 + (uint32_t)(u * NW) + (uint32_t)wave) * w + (uint32_t)lane);
                 }
-                base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
+                base += (uint32_t)__builtin_amdgcn_readlane((int)inc, NW * UW - 1);
             }
             grp_sync<GS, NW>();                                                          // (the exchange words are the reduction scratch of what follows)
             };   // window_load
