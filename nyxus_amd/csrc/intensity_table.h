@@ -57,12 +57,76 @@ __device__ __forceinline__ unsigned long long wg4_sum_u64(unsigned long long v, 
     return s_x[0] + s_x[1] + s_x[2] + s_x[3];
 }
 
+// the sums over the table's entries: entry i stands for count(i) pixels of value vmin + off(i)
+template <class TAB>
+struct TableSums {
+    const TAB& tab; uint32_t vmin;
+    __device__ __forceinline__ uint32_t count_at(uint32_t i) const { return tab.cum(i) - (i ? tab.cum(i - 1) : 0u); }
+    __device__ __forceinline__ void central(double mean, bool blank, double (&acc)[6], uint32_t& mode_off, const IntensityScratch& S, int tid) const
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t best_c = 0, best_i = 0;
+        for (uint32_t i = tid; i < tab.m; i += 256) {
+            const uint32_t c = count_at(i);
+            if (c > best_c) { best_c = c; best_i = i; }
+            if (c && !blank) {
+                const double cd = (double)c, d = (double)(vmin + tab.off(i)) - mean, d2 = d * d;
+                acc[0] += cd * fabs(d);
+                acc[1] += cd * d2;
+                acc[2] += cd * (d2 * d);
+                acc[3] += cd * (d2 * d2);
+                acc[4] += cd * (d2 * d2 * d);
+                acc[5] += cd * (d2 * d2 * d2);
+            }
+        }
+        // mode: (count desc, index asc) over the workgroup
+        const uint32_t mc_w = wave_max_u32(best_c);
+        const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
+        const uint32_t bi_w = ~wave_max_u32(~cand);
+        __syncthreads();
+        if (lane == 0) { S.w[4 + wave] = mc_w; S.w[8 + wave] = bi_w; }
+        __syncthreads();
+        uint32_t mc = 0, mi = 0;
+        for (int wv = 0; wv < 4; wv++) {
+            const uint32_t c = S.w[4 + wv], i = S.w[8 + wv];
+            if (c > mc || (c == mc && i < mi)) { mc = c; mi = i; }
+        }
+        mode_off = tab.off(mi);
+    }
+    __device__ __forceinline__ void robust(uint32_t lo_off, uint32_t hi_off, bool some, double median, unsigned long long& sx, double& medad, int tid) const
+    {
+        for (uint32_t i = tid; i < tab.m; i += 256) {
+            const uint32_t c = count_at(i);
+            if (!c) continue;
+            const uint32_t off = tab.off(i), v = vmin + off;
+            if (some && off >= lo_off && off <= hi_off) sx += (unsigned long long)c * v;
+            medad += (double)c * fabs((double)v - median);
+        }
+    }
+    __device__ __forceinline__ void spread(uint32_t lo_off, uint32_t hi_off, double mean1090, double& ad, int tid) const
+    {
+        const uint32_t i0 = tab.first_ge((uint64_t)lo_off), i1 = tab.first_ge((uint64_t)hi_off + 1u);
+        for (uint32_t i = i0 + tid; i < i1; i += 256) {
+            const uint32_t c = count_at(i);
+            if (c) ad += (double)c * fabs((double)(vmin + tab.off(i)) - mean1090);
+        }
+    }
+};
+
 // n pixels, extrema vmin / vmax, tot = sum of the intensities, totsq = sum of the (32-bit wrapping) squares, both exact.
 // slide: slide_max - slide_min, or NaN when the slide extrema are not given.  o: the 36 columns (zeroed by the caller).
 // Every thread of the 256-thread workgroup calls this; barriers inside.
-template <class TAB>
-__device__ __forceinline__ void intensity_from_table(const TAB& tab, uint32_t n, uint32_t vmin, uint32_t vmax, double tot, double totsq, bool have_slide,
-                                                     double slide_range, uint32_t n_hist, double* o, const IntensityScratch& S, int tid)
+// SUMS supplies the sums that run over the pixels' VALUES -- over the table's entries (TableSums below: entry i stands for
+// count(i) pixels) or over the ROI's values themselves when the table is not worth walking (roi_wide.hip: 2821 keys against a
+// 65536-entry domain):
+//   central(mean, acc[6], mode_off)   per-thread partial sums of |d|, d^2 .. d^6 over the pixels (d = value - mean); mode_off: the
+//                                     offset of the most frequent value (smallest on ties), the same on every thread
+//   robust(lo_off, hi_off, some, median, sx, medad)   per-thread partials: exact sum of the values whose offset lies in
+//                                     [lo_off, hi_off] (when `some`), sum of |value - median|
+//   spread(lo_off, hi_off, mean1090)  per-thread partial of sum |value - mean1090| over the same pixels
+template <class TAB, class SUMS>
+__device__ __forceinline__ void intensity_from_table(const TAB& tab, const SUMS& sums, uint32_t n, uint32_t vmin, uint32_t vmax, double tot, double totsq,
+                                                     bool have_slide, double slide_range, uint32_t n_hist, double* o, const IntensityScratch& S, int tid)
 {
     constexpr int BS = 256, NW = 4;
     const int lane = tid & 63, wave = tid >> 6;
@@ -83,39 +147,14 @@ __device__ __forceinline__ void intensity_from_table(const TAB& tab, uint32_t n,
         if (!blank)
             o[I_UNIFORMITY_PIU] = (1.0 - (double)(vmax - vmin) / (double)(uint32_t)(vmax + vmin)) * 100.0;   // :162
     }
-    auto count_at = [&](uint32_t i) -> uint32_t { return tab.cum(i) - (i ? tab.cum(i - 1) : 0u); };
     // ---- sweep 1: central sums (intensity.cpp:102-109, :177-183; M2..M4 of moments.h:53-74 equal the plain central sums) and
     // the mode (largest count, smallest value on ties: histogram.h:289-309)
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t best_c = 0, best_i = 0;
-    for (uint32_t i = tid; i < m; i += BS) {
-        const uint32_t c = count_at(i);
-        if (c > best_c) { best_c = c; best_i = i; }
-        if (c && !blank) {
-            const double cd = (double)c, d = (double)(vmin + tab.off(i)) - mean, d2 = d * d;
-            acc[0] += cd * fabs(d);
-            acc[1] += cd * d2;
-            acc[2] += cd * (d2 * d);
-            acc[3] += cd * (d2 * d2);
-            acc[4] += cd * (d2 * d2 * d);
-            acc[5] += cd * (d2 * d2 * d2);
-        }
-    }
-    {   // mode: (count desc, index asc) over the workgroup
-        const uint32_t mc_w = wave_max_u32(best_c);
-        const uint32_t cand = best_c == mc_w ? best_i : 0xFFFFFFFFu;
-        const uint32_t bi_w = ~wave_max_u32(~cand);
-        __syncthreads();
-        if (lane == 0) { S.w[4 + wave] = mc_w; S.w[8 + wave] = bi_w; }
-    }
-    wg4_sum<6>(acc, S.x, tid);                                                // (its barriers also publish the mode words)
+    uint32_t mode_off = 0;
+    sums.central(mean, blank, acc, mode_off, S, tid);
+    wg4_sum<6>(acc, S.x, tid);
     if (tid == 0) {
-        uint32_t mc = 0, mi = 0;
-        for (int wv = 0; wv < NW; wv++) {
-            const uint32_t c = S.w[4 + wv], i = S.w[8 + wv];
-            if (c > mc || (c == mc && i < mi)) { mc = c; mi = i; }
-        }
-        if (!blank) o[I_MODE] = (double)(vmin + tab.off(mi));
+        if (!blank) o[I_MODE] = (double)(vmin + mode_off);
         // everything that depends only on the central sums (intensity.cpp:110-118, :166-191)
         o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] / dn;
         const double variance = dn > 1 ? acc[1] / (dn - 1) : 0.0, variance_b = dn > 1 ? acc[1] / dn : 0.0;
@@ -156,10 +195,24 @@ __device__ __forceinline__ void intensity_from_table(const TAB& tab, uint32_t n,
         };
         // smallest offset d in [0, range + 1] whose bin index reaches b: start from the real-valued boundary and settle with the
         // exact (reference) bin function; the bin's lower bound is the number of pixels below that offset
-        const double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
-        uint64_t d = !(edge < (double)range + 1.0) ? (uint64_t)range + 1 : (uint64_t)edge;     // (64 bits: range + 1 of a full 32-bit range)
-        while (d > 0 && bin_of((uint32_t)(d - 1)) >= b) d--;
-        while (d <= range && bin_of((uint32_t)d) < b) d++;
+        uint64_t d;
+        if (range < 65536u) {
+            // The real-valued boundary is P = b * (bin width).  Unless P lies within 1e-6 of an integer, the answer is floor(P) + 1
+            // with certainty: the reference's bin function (one or two fp64 roundings of a value below 2^16) cannot move a value
+            // that is >= 1e-6 / range away from the boundary across it.  Next to an integer m the exact bin function decides
+            // between m and m + 1: one evaluation, no search (roi_features.hip takes its table bounds the same way).
+            const double Wl = is100 ? binW100 : (double)range / (double)nb;
+            const double P = (double)b * Wl;
+            const uint32_t mi = (uint32_t)(P + 0.5);
+            d = (uint64_t)(uint32_t)P + 1;
+            if (b == 0) d = 0;
+            else if (fabs(P - (double)mi) < 1e-6) d = bin_of(mi) >= b ? mi : mi + 1;
+        } else {
+            const double edge = is100 ? (double)b * binW100 : (double)b * (double)range / (double)nb;
+            d = !(edge < (double)range + 1.0) ? (uint64_t)range + 1 : (uint64_t)edge;          // (64 bits: range + 1 of a full 32-bit range)
+            while (d > 0 && bin_of((uint32_t)(d - 1)) >= b) d--;
+            while (d <= range && bin_of((uint32_t)d) < b) d++;
+        }
         const uint32_t idx = tab.first_ge(d);
         const uint32_t lo = idx > 0 ? tab.cum(idx - 1) : 0u;
         if (is100) S.lb100[b] = lo; else S.lbc[b] = lo;
@@ -249,24 +302,15 @@ __device__ __forceinline__ void intensity_from_table(const TAB& tab, uint32_t n,
     }
     const bool some = i0 <= i1;
     const uint32_t K = some ? tab.cum(i1) - (i0 ? tab.cum(i0 - 1) : 0u) : 0u;
+    const uint32_t lo_off = some ? tab.off(i0) : 1u, hi_off = some ? tab.off(i1) : 0u;
     unsigned long long sx = 0;                                                 // exact integer sum of the values inside the bounds
     double medad[1] = {0};
-    for (uint32_t i = tid; i < m; i += BS) {
-        const uint32_t c = count_at(i);
-        if (!c) continue;
-        const uint32_t v = vmin + tab.off(i);
-        if (some && i >= i0 && i <= i1) sx += (unsigned long long)c * v;
-        medad[0] += (double)c * fabs((double)v - median);
-    }
+    sums.robust(lo_off, hi_off, some, median, sx, medad[0], tid);
     sx = wg4_sum_u64(sx, S.u, tid);
     wg4_sum<1>(medad, S.x, tid);
     const double mean1090 = K ? (double)sx / (double)K : 0.0;
     double ad[1] = {0};
-    if (K)
-        for (uint32_t i = i0 + tid; i <= i1; i += BS) {
-            const uint32_t c = count_at(i);
-            if (c) ad[0] += (double)c * fabs((double)(vmin + tab.off(i)) - mean1090);
-        }
+    if (K) sums.spread(lo_off, hi_off, mean1090, ad[0], tid);
     wg4_sum<1>(ad, S.x, tid);
     if (tid == 0) {
         o[I_ROBUST_MEAN] = mean1090;

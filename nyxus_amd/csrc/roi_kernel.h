@@ -442,6 +442,27 @@ struct LargeArgs {
 };
 int launch_large_features(const LargeArgs& a, void* stream);
 
+// ---- LDS-sized ROIs of 16-bit data: first-order features without a sort (roi_wide.hip) ----------------------------------------------
+constexpr int kWideDupCap = 256;   // duplicate values the fast path lists per ROI (more: the sort-based slow path of the same kernel)
+struct WideArgs {
+    const uint64_t* px_offset;
+    const uint32_t* inten;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    const double* slide_min;
+    const double* slide_max;
+    double* out;
+    uint64_t ld;
+    int* status;
+    int32_t col_intensity, n_hist;
+    const uint32_t* list;          // the members of the class (ROI indices)
+    uint32_t n_list;
+    uint32_t key_cap;              // keys the carve-out holds
+    uint32_t o_keys, o_work, slow_hist, o_lb, lds_bytes;   // byte offsets: keys | bitmap + prefixes + lists (slow path: second keys, counts, digit counts at slow_hist) | bin bounds
+};
+bool make_wide_layout(uint32_t max_px, uint32_t n_hist, WideArgs& a);
+int launch_roi_wide(const WideArgs& a, void* stream);
+
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid);

@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
         } tab{T, range + 1};
         IntensityScratch S{s_x, s_u, s_stat, s_pq, s_w, (uint32_t*)(lds_raw + A.fin_tab_bytes), (uint32_t*)(lds_raw + A.fin_tab_bytes) + 104};
         const bool have_slide = A.slide_min && A.slide_max;
-        intensity_from_table(tab, n, vmin, vmax, (double)hdr[0], (double)hdr[1], have_slide, have_slide ? A.slide_max[R.roi] - A.slide_min[R.roi] : 0.0,
+        const TableSums<DenseTab> tsums{tab, vmin};
+        intensity_from_table(tab, tsums, n, vmin, vmax, (double)hdr[0], (double)hdr[1], have_slide, have_slide ? A.slide_max[R.roi] - A.slide_min[R.roi] : 0.0,
                              (uint32_t)A.n_hist, o, S, tid);
         __syncthreads();
     }

@@ -1,0 +1,80 @@
+"""GPU tests of the 16-bit path (nyxus_amd/csrc/roi_wide.hip): LDS-sized ROIs whose intensity range rules the dense counting table out
+get their first-order features from a presence bitmap + a duplicate list (no sort), the GLCM columns from the GLCM-only build.
+
+Reference semantics pinned here: the exact columns (MEDIAN / MODE / percentiles / ROBUST_MEAN ...) of
+/root/reference/src/nyx/features/histogram.h:214-309 on data with few, some and very many repeated values -- the last kind overflows
+the duplicate list and takes the sort-based slow path of the same kernel."""
+import numpy as np
+import pytest
+
+from nyxus_amd import _abi, _lib
+from oracle import pyoracle as po
+from tests import parity
+from tests.test_size_classes_gpu import ellipse_roi
+
+pytestmark = pytest.mark.gpu
+
+MASK = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+
+
+def check(ctx, rois, mask, s):
+    b = _abi.batch_from_rois(rois)
+    G = ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    bad = parity.compare_tables(G, O, _lib.column_names(mask, s), batch=b)
+    assert not bad, "\n".join(bad[:20])
+    return G
+
+
+@pytest.mark.parametrize("gd", [8, 64, -16])
+def test_sixteen_bit_rois_match_oracle(hip_ctx, gd):
+    rng = np.random.default_rng(31)
+    rois = [ellipse_roi(int(a), int(b), rng, hi=65536, lo=0 if k % 4 == 0 else 1, holes=0.1 if k % 3 == 0 else 0.0)
+            for k, (a, b) in enumerate(zip(rng.integers(3, 60, 40), rng.integers(3, 60, 40)))]
+    check(hip_ctx, rois, MASK, _abi.default_settings(gd))
+    check(hip_ctx, rois[:10], _abi.FAM_INTENSITY, _abi.default_settings(gd))
+
+
+def test_quantised_sixteen_bit_data_takes_the_slow_path(hip_ctx):
+    """8-bit content in a 16-bit container (values k * 257): ~256 distinct values, each many times -- the duplicate list overflows."""
+    rng = np.random.default_rng(32)
+    rois = []
+    for k in range(12):
+        r = ellipse_roi(int(rng.integers(20, 60)), int(rng.integers(20, 60)), rng)
+        r["inten"] = (rng.integers(0 if k % 2 else 1, 256, len(r["x"])) * 257).astype(np.uint32)
+        rois.append(r)
+    # two values only, far apart; a heavy mode; a range of exactly 65535 and of exactly 16384
+    r = ellipse_roi(30, 30, rng); r["inten"] = np.where(rng.random(len(r["x"])) < 0.5, 5, 60005).astype(np.uint32); rois.append(r)
+    r = ellipse_roi(25, 28, rng); v = rng.integers(100, 60000, len(r["x"])); v[rng.random(len(v)) < 0.3] = 31337; r["inten"] = v.astype(np.uint32); rois.append(r)
+    r = ellipse_roi(20, 20, rng); v = rng.integers(0, 65536, len(r["x"])); v[0] = 0; v[1] = 65535; r["inten"] = v.astype(np.uint32); rois.append(r)
+    r = ellipse_roi(20, 20, rng); v = rng.integers(7, 16392, len(r["x"])); v[0] = 7; v[1] = 16391; r["inten"] = v.astype(np.uint32); rois.append(r)
+    check(hip_ctx, rois, MASK, _abi.default_settings(8))
+
+
+def test_sixteen_bit_offsets_from_a_large_minimum(hip_ctx):
+    """uint32 intensities around 3e9 with a 16-bit spread: the keys are offsets from the ROI minimum, the sums are not."""
+    rng = np.random.default_rng(33)
+    rois = []
+    for k in range(8):
+        r = ellipse_roi(int(rng.integers(10, 40)), int(rng.integers(10, 40)), rng)
+        r["inten"] = (3_000_000_000 + rng.integers(0, 50000, len(r["x"]))).astype(np.uint32)
+        rois.append(r)
+    check(hip_ctx, rois, MASK, _abi.default_settings(8))
+
+
+def test_sixteen_bit_tiles_through_the_tile_path(hip_ctx):
+    """uint16 tiles: the wide classes of a window-mode chunk ask for the clouds; rows equal the batch path's."""
+    from tests import synth
+    rng = np.random.default_rng(34)
+    lab = synth.disk_label_tile(size=256, pitch=64, radius=25).astype(np.uint16)
+    inten = rng.integers(1, 65536, (2, 256, 256)).astype(np.uint16)
+    s = _abi.default_settings(8)
+    tiles, labels, T = hip_ctx.featurize_tiles_host(inten, np.stack([lab, lab]), MASK, s)
+    rows = []
+    for t in range(2):
+        b = _abi.batch_from_rois(synth.rois_from_tile(inten[t].astype(np.uint32), lab.astype(np.uint32)))
+        rows.append(po.oracle_featurize(b, MASK, s))
+    O = np.concatenate(rows)
+    assert len(labels) == len(O)
+    bad = parity.compare_tables(T, O, _lib.column_names(MASK, s))
+    assert not bad, "\n".join(bad[:20])
