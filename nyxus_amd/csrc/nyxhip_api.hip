@@ -47,6 +47,7 @@ struct nyxhip_ctx {
     int* d_status = nullptr;
     // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
     double* d_bank = nullptr;
+    float* d_bank32 = nullptr;       // the bank rounded to fp32 (Gabor screening pass)
     std::vector<double> bank_key;
     uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
     uint32_t bank_box_mask = 0;                                  // ShapeArgs::gabor_box_mask of the uploaded bank
@@ -520,8 +521,15 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
             if (box) ctx->bank_box_mask |= 1u << f;
         }
     if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
+    if (ctx->d_bank32) { HIP_TRY(ctx, hipFree(ctx->d_bank32)); ctx->d_bank32 = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank, bank.size() * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_bank, bank.data(), bank.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<float> b32(bank.size());
+        for (size_t i = 0; i < bank.size(); i++) b32[i] = (float)bank[i];      // round to nearest: relative 2^-24 (the bound of the screening pass counts it)
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank32, b32.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bank32, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     ctx->bank_key = key;
     return NYXHIP_OK;
 }
@@ -827,7 +835,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= kClassPx[0] && E.side <= kClassSide[0]) ? 1 : 0;   // the smallest size class (a function of the ROI: roi_class)
-        g.gabor_bank = ctx->d_bank; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
     }
@@ -1615,6 +1623,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->h_cls_hdr) (void)hipHostFree(ctx->h_cls_hdr);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);
+    if (ctx->d_bank32) (void)hipFree(ctx->d_bank32);
     if (ctx->d_stamps) {
         unsigned long long h[32];
         if (hipMemcpy(h, ctx->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -336,6 +336,7 @@ struct ShapeArgs {
     int32_t col_gabor, col_zernike;
     double soft_nan;
     const double* gabor_bank; // device: (F+1) filters (low-pass first), n*n complex taps each
+    const float* gabor_bank32; // the same taps rounded to fp32 (the screening pass of roi_gabor_tiled_kernel, MODE 3)
     int32_t gabor_nf, gabor_n;
     // 16 x 16 banks: per filter, bit j = every real part of tap row j is +-0, bit 16 + j = every imaginary part is.  Such a row adds
     // +-0 to the running sums, which leaves them as they are (they start at +0 and no sum of the scan is -0): the tiled kernel

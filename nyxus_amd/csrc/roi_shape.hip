@@ -179,6 +179,8 @@ __global__ __launch_bounds__(NW * 64) void roi_gabor_kernel(const ShapeArgs A)
 // response is bit-identical to the reference's clipped loops (gabor.cpp:333-390), in the same (j, i) order.
 // The low-pass energies are not kept: count(e > min) = area - count(e == min), carried through the min reduction.
 typedef const double __attribute__((address_space(4))) * bank_ptr_t;
+typedef const float __attribute__((address_space(4))) * bank32_ptr_t;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // FUSED (opt-in, NYXHIP_GABOR_FUSED=1): each tap is one fused multiply-add -- 1.56x faster, responses a few ulp off the
 // reference's.  On noisy or smooth intensity fields that never moved a feature (0 of 18 000 fuzzed ROIs), but on fields with
@@ -200,6 +202,15 @@ typedef const double __attribute__((address_space(4))) * bank_ptr_t;
 // minimum -- which are recomputed with the reference's arithmetic; a list overflow (ties on a flat field) runs the filter again
 // unfused.  (A filter whose taps are one real constant is a box filter: exact integer sums, nothing to check.  The one-wave
 // kernel of small ROIs keeps the unfused low-pass: two recomputation calls cost more than it saves there.)
+// MODE 3 (the default since round 4): the same decisions from a SCREENING pass in packed fp32.  `v_pk_fma_f32` does two fp32 FMAs
+// per lane and instruction -- a tap's real and imaginary products in one -- at twice the fp64 rate (tools/pipe_probe.hip: 132.7
+// against 66.5 TFLOP/s; the fp64 matrix pipe does not overlap the vector pipe on gfx950 and adds nothing).  Intensities below
+// 2^24 are exact in fp32, the taps are rounded once (relative 2^-24), and a 256-term FMA chain in fp32 stays within
+// gamma_258 sum |a w| <= 1.54e-5 a_max of the exact sum per component (the bank is L1-normalised), so the screened energy is within
+// 3.1e-5 a_max of the reference's: a pixel farther than 3.2e-5 a_max (+ 1e-15 (e + T)) from the threshold is decided as the
+// reference decides it; the others -- a few per thousand on ordinary data -- are recomputed with the reference's fp64 arithmetic,
+// and the low-pass extrema come from exactly recomputed candidates, as in MODE 2.  An ROI with an intensity of 2^24 or more runs
+// every filter with the reference's arithmetic.
 constexpr int kGaborRedoCap = 512;
 // The response of one pixel with the reference's arithmetic: separate multiply and add, taps in (j, i) order (gabor.cpp:333-390; a
 // zero tap adds +-0, which leaves a sum that started at +0 as it is: the same bits as the scans that skip zero rows).  Not inlined:
@@ -221,7 +232,7 @@ __device__ __attribute__((noinline)) double gabor_exact_energy(const uint32_t* s
 }
 
 template <int T, int NW, int MODE, bool ZR = false>
-__global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_kernel(const ShapeArgs A)   // (MODE 2: held to 128 registers, four waves per SIMD like the other two)
+__global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_kernel(const ShapeArgs A)   // (MODE 2 / 3: held to 128 registers, four waves per SIMD like the other two)
 {
     constexpr int N = 16, kBlk = NW * 64, W4 = (T + 16) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
     __syncthreads();
 
     const bank_ptr_t bank = (bank_ptr_t)(uintptr_t)A.gabor_bank;
+    const bank32_ptr_t bank32 = (bank32_ptr_t)(uintptr_t)A.gabor_bank32;
     const uint32_t ntiles = tpr * h;
     double maxval = 0;
     double tmax = -1.0, tmin = 1.7976931348623157e308;
@@ -294,7 +306,9 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
         const uint32_t zero_rows = ZR ? A.gabor_zero_rows[f] : 0u;
         const bool box = ZR && ((A.gabor_box_mask >> f) & 1u) && A.max_inten[roi] < (1u << 24);
         const double box_c = box ? G[0] : 0.0;
-        const double thr_max = A.gabor_thr * maxval, thr_slack = __builtin_fma(2.5e-13, amax, 1e-15 * thr_max);
+        constexpr bool f32 = MODE == 3 && fuse;             // this copy screens in packed fp32 (see the kernel's header)
+        constexpr double kErr = f32 ? 3.2e-5 : 2.5e-13;     // |screened energy - reference's energy| <= kErr a_max
+        const double thr_max = A.gabor_thr * maxval, thr_slack = __builtin_fma(kErr, amax, 1e-15 * thr_max);
         uint32_t sc = 0;
         // MODE 2, low-pass filter with fused taps: its strict maximum and minimum (and the number of pixels AT the minimum) carry
         // every feature, so they are the reference's -- found among CANDIDATES.  One pixel per thread, spread over the box, is
@@ -303,8 +317,8 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
         // least Bs minus the error bound, and only such pixels go to the list (on a continuous field ~ area / 256 of them; a flat
         // field, where thousands tie, overflows the list and the filter runs again with the reference's arithmetic throughout).
         double Bs = 0.0, bs = 0.0;
-        const bool lp_cand = MODE == 2 && fuse && f == 0 && !box;     // (a box filter's sums are exact integers: nothing to check)
-        if (MODE == 2 && fuse) {
+        const bool lp_cand = MODE >= 2 && fuse && f == 0 && !box;     // (a box filter's sums are exact integers: nothing to check)
+        if (MODE >= 2 && fuse) {
             if (tid == 0) s_redo[0] = 0;
             if (lp_cand) {
                 if (wave == 0) {                          // (64 samples: one wave's worth of the reference's arithmetic)
@@ -350,11 +364,44 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                 }
 #pragma unroll
                 for (int t = 0; t < T; t++) re[t] = (double)S[t] * box_c;
+            } else if constexpr (f32) {
+                // packed fp32: (re, im) of an output in one register pair, a tap's two products in one v_pk_fma_f32
+                v2f acc[T];
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t] = v2f{0.0f, 0.0f};
+                const bank32_ptr_t G32 = bank32 + (size_t)f * N * N * 2;
+#pragma unroll 1
+                for (int j = 0; j < N; j++, row -= pitch) {
+                    if (((zero_rows >> j) & 1u) && ((zero_rows >> (16 + j)) & 1u))
+                        continue;                                // (a row of +-0 taps adds nothing to either component)
+                    float win[T + 16];
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        const uint4 u = ((const uint4*)row)[q];
+                        win[4 * q + 0] = (float)u.x; win[4 * q + 1] = (float)u.y;
+                        win[4 * q + 2] = (float)u.z; win[4 * q + 3] = (float)u.w;
+                    }
+                    const bank32_ptr_t Gj = G32 + j * N * 2;
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        const v2f g = v2f{Gj[2 * i], Gj[2 * i + 1]};
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const float av = win[t + 16 - i];
+                            acc[t] = __builtin_elementwise_fma(v2f{av, av}, g, acc[t]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) { re[t] = (double)acc[t].x; im[t] = (double)acc[t].y; }
             } else
 #pragma unroll 1
             for (int j = 0; j < N; j++, row -= pitch) {
                 // tap rows whose real (imaginary) parts are all +-0 leave re (im) as it is: see ShapeArgs::gabor_zero_rows
-                const bool re0 = (zero_rows >> j) & 1u, im0 = (zero_rows >> (16 + j)) & 1u;
+                // (MODE 3 keeps the row tests out of this copy -- it runs for the odd ROI only, and three variants of the tap block
+                //  next to the fp32 copy cost the kernel 45 spilled registers; a row of +-0 taps adds +-0: the same bits)
+                constexpr bool ZRU = ZR && MODE != 3;
+                const bool re0 = ZRU && ((zero_rows >> j) & 1u), im0 = ZRU && ((zero_rows >> (16 + j)) & 1u);
                 if (re0 && im0)
                     continue;
                 double win[T + 16];
@@ -385,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                 };
                 // (a row whose real parts alone vanish does not occur in a Gabor bank -- cos(x' f0) has no exact zeros on the tap
                 //  grid -- and takes the full block)
-                if (ZR && im0) taps(std::true_type{}, std::false_type{}, fuse_c);
+                if (ZRU && im0) taps(std::true_type{}, std::false_type{}, fuse_c);
                 else taps(std::true_type{}, std::true_type{}, fuse_c);
             }
 #pragma unroll
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                 const double e = sqrt(re[t] * re[t] + im[t] * im[t]);   // :505
                 if (lp_cand) {
                     // (the same bound as below, against Bs and bs instead of the threshold)
-                    const double m0 = __builtin_fma(1e-15, e, 2.5e-13 * amax);
+                    const double m0 = __builtin_fma(1e-15, e, kErr * amax);
                     if (e >= Bs - __builtin_fma(1e-15, Bs, m0) || e <= bs + __builtin_fma(1e-15, bs, m0)) {
                         const uint32_t k = atomicAdd(&s_redo[0], 1u);
                         if (k < (uint32_t)kGaborRedoCap) s_redo[1 + k] = b * w + a0 + (uint32_t)t;
@@ -404,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
                     tmax = e > tmax ? e : tmax;
                     if (e < tmin) { tmin = e; n_min = 1; }
                     else if (e == tmin) n_min++;
-                } else if (MODE == 2 && fuse) {
+                } else if (MODE >= 2 && fuse) {
                     // The reference decides fl(e / max) > thr (:117).  With T = thr * max: an e above T (1 + 4 u) gives a quotient above
                     // thr, one below T (1 - 4 u) a quotient below it, whatever the rounding of the division; and the fused e is within
                     // |d re| + |d im| + 4 u e <= 0.9e-13 a_max + 4 u e of the reference's (see the kernel's header).  So outside
@@ -435,7 +482,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
             __syncthreads();
             if (lp_overflow) return true;                 // (block-uniform) the caller runs the filter again, unfused
         } else
-        if (MODE == 2 && fuse && f != 0) {                 // the pixels too close to the threshold, with the reference's arithmetic
+        if (MODE >= 2 && fuse && f != 0) {                 // the pixels too close to the threshold, with the reference's arithmetic
             __syncthreads();
             const uint32_t nr = s_redo[0];
             if (nr > (uint32_t)kGaborRedoCap) {
@@ -485,6 +532,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 2 ? 4 : 1) void roi_gabor_tiled_ke
         bool go;
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
         else if constexpr (MODE == 1) go = run_filter(f, std::true_type{});
+        else if (MODE == 3 && !(amax < 16777216.0)) go = run_filter(f, std::false_type{});   // an intensity that fp32 does not hold exactly: the reference's arithmetic throughout
         else if (f == 0 && NW == 1) go = run_filter(0, std::false_type{});   // one-wave launches (small ROIs): two recomputation calls cost more than the unfused low-pass
         else {
             go = run_filter(f, std::true_type{});
@@ -663,7 +711,9 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
                                (const void*)roi_gabor_tiled_kernel<8, 4, 1, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 1, false>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 1, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 1, true>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 2, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, false>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, 2, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, true>};
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 2, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 3, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, false>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 3, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, true>};
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -682,11 +732,14 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
     if ((a.mask & NYXHIP_FAM_GABOR) && a.L.tiled) {
         // 2 (default): fused taps with the reference's decisions; NYXHIP_GABOR_EXACT=1 -> 0: the reference's arithmetic throughout (A/B);
         // NYXHIP_GABOR_FUSED=1 -> 1: fused taps, decisions unchecked (changes results on tie-laden inputs: INTEGRATION.md)
+        // 3 (default): packed-fp32 screening with the reference's decisions; NYXHIP_GABOR_MODE=2: the fp64 fused taps of round 3 (A/B)
         static const int mode = [] {
             const char* e = getenv("NYXHIP_GABOR_FUSED");
             if (e && *e && *e != '0') return 1;
             e = getenv("NYXHIP_GABOR_EXACT");
-            return (e && *e && *e != '0') ? 0 : 2;
+            if (e && *e && *e != '0') return 0;
+            e = getenv("NYXHIP_GABOR_MODE");
+            return (e && *e == '2') ? 2 : 3;
         }();
         // worth its registers (the build with the row tests needs ~25 more: one wave per SIMD less) when at least 4 % of the
         // bank's arithmetic falls away: the reference's default bank (f0 = 0 in its first filter) saves 10.6 %, the 8-orientation
@@ -703,7 +756,8 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, M, Z>), dim3(grid), dim3(64), a.L.total, st, a);               \
             else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, M, Z>), dim3(grid), dim3(256), a.L.total, st, a);                    \
         } while (0)
-        if (mode == 2) { if (zr) NYX_GABOR_LAUNCH(2, true); else NYX_GABOR_LAUNCH(2, false); }
+        if (mode == 3 && a.gabor_bank32) { if (zr) NYX_GABOR_LAUNCH(3, true); else NYX_GABOR_LAUNCH(3, false); }
+        else if (mode >= 2) { if (zr) NYX_GABOR_LAUNCH(2, true); else NYX_GABOR_LAUNCH(2, false); }
         else if (mode == 1) { if (zr) NYX_GABOR_LAUNCH(1, true); else NYX_GABOR_LAUNCH(1, false); }
         else { if (zr) NYX_GABOR_LAUNCH(0, true); else NYX_GABOR_LAUNCH(0, false); }
 #undef NYX_GABOR_LAUNCH
