@@ -333,7 +333,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         const int gi = s->ibsi ? 0 : s->grey_depth;
         const bool c16_pred = do_int && max_px < 65536u && (uint64_t)max_range + 1 <= kCountCapMax && max_range < 65536u;
         const bool split_pred = do_glcm && !spill && gi > 0 && gi <= 16 && s->glcm_n_angles > 0;
-        L.dense8 = (c16_pred && split_pred) ? 1u : 0u;
+        L.dense8 = ((c16_pred || !do_int) && split_pred) ? 1u : 0u;           // (GLCM alone: nothing of the intensity block constrains the plane)
     }
     {   // the reference's default grey depth on LDS launches: 16-bit matrices + 8-bit plane (roi_features_kernel_g16)
         const int gi = s->ibsi ? 0 : s->grey_depth;

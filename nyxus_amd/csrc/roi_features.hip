@@ -608,10 +608,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         return;                                       // another launch of this call serves the ROI's size class
     if (GS && vmax - vmin < A.sp.min_range)
         return;                                       // served by the histogram path (roi_large.hip)
-    constexpr bool FAST = FAM == 1;
+    constexpr bool FAST = FAM == 1 || FAM == 3;       // (3: GLCM alone under the same conditions -- BASELINE configs[2], and the GLCM columns of the 16-bit path)
     constexpr int kRowsTag = 16 + TIER * 4 + (C16 ? 2 : 0) + (D8 ? 1 : 0);
-    const bool do_int = FAM != 0 || (A.mask & NYXHIP_FAM_INTENSITY) != 0;
-    const bool do_glcm = FAM == 1 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);
+    const bool do_int = FAM == 1 || FAM == 2 || (FAM == 0 && (A.mask & NYXHIP_FAM_INTENSITY) != 0);
+    const bool do_glcm = FAM == 1 || FAM == 3 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);
     double* const out_row = A.out + roi * A.ld;
 #ifdef NYX_STAMP
     unsigned long long t_prev__ = __builtin_readcyclecounter();
@@ -1592,7 +1592,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         double* o = out_row + A.col_glcm;
         const int na = A.glcm_na;
         const int Ng = greyInfo, NG1 = Ng + 1, NN = Ng * Ng, cells = NG1 * NG1;
-        const bool degenerate = s_stat[S_NG] != 0.0;
+        // (the guard of glcm.cpp:27-95 on GLCM_GREYDEPTH: taken beside the mean when the intensity block runs, here when it does not)
+        const bool degenerate = FAM == 3 ? bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth) : s_stat[S_NG] != 0.0;
         if (tid == 0)
             A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
         if (degenerate) {
@@ -2327,7 +2328,7 @@ __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiA
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 8, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 8, false, WIN>(A, blockIdx.x);
 }
 // The same compile-time family sets and loaders at seven and six workgroups per CU: batches whose largest ROI needs a bigger
 // carve-out than the benchmark's (mixed-size data: the launch is sized by its largest ROI) keep the specialised body instead of
@@ -2335,12 +2336,12 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_fam7(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 7, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 7, false, WIN>(A, blockIdx.x);
 }
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_fam6(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1, true, FAM, 6, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 6, false, WIN>(A, blockIdx.x);
 }
 
 // the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
@@ -2434,14 +2435,17 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
 {
     static DeviceOnce optin;
     if (int orc = optin.run([]() -> int {
-        const void* fns[16] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
+        const void* fns[22] = {(const void*)roi_features_kernel<false, C16, SPLIT, D8>, (const void*)roi_features_kernel_occ5<C16, SPLIT, D8>,
                                (const void*)roi_features_kernel_occ6<C16, SPLIT, D8>, (const void*)roi_features_kernel_occ7<C16, SPLIT, D8>,
                                (const void*)roi_features_kernel_occ8<1, 0>, (const void*)roi_features_kernel_occ8<2, 0>,
                                (const void*)roi_features_kernel_occ8<1, 1>, (const void*)roi_features_kernel_occ8<2, 1>,
                                (const void*)roi_features_kernel_fam7<1, 0>, (const void*)roi_features_kernel_fam7<2, 0>,
                                (const void*)roi_features_kernel_fam7<1, 1>, (const void*)roi_features_kernel_fam7<2, 1>,
                                (const void*)roi_features_kernel_fam6<1, 0>, (const void*)roi_features_kernel_fam6<2, 0>,
-                               (const void*)roi_features_kernel_fam6<1, 1>, (const void*)roi_features_kernel_fam6<2, 1>};
+                               (const void*)roi_features_kernel_fam6<1, 1>, (const void*)roi_features_kernel_fam6<2, 1>,
+                               (const void*)roi_features_kernel_occ8<3, 0>, (const void*)roi_features_kernel_occ8<3, 1>,
+                               (const void*)roi_features_kernel_fam7<3, 0>, (const void*)roi_features_kernel_fam7<3, 1>,
+                               (const void*)roi_features_kernel_fam6<3, 0>, (const void*)roi_features_kernel_fam6<3, 1>};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
             if (e != hipSuccess)
@@ -2458,13 +2462,23 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
     const bool int_only = !(a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY);
     const bool int_glcm = (a.mask & NYXHIP_FAM_GLCM) && (a.mask & NYXHIP_FAM_INTENSITY) && a.L.dense8 && a.glcm_ws != nullptr && !a.ibsi &&
                           a.grey_depth > 0 && a.grey_depth <= 16;
-    const bool fam_ok = C16 && SPLIT && D8 && (int_only || int_glcm);   // a compile-time family set of the compact builds applies
+    const bool glcm_only = (a.mask & NYXHIP_FAM_GLCM) && !(a.mask & NYXHIP_FAM_INTENSITY) && a.L.dense8 && a.glcm_ws != nullptr && !a.ibsi &&
+                           a.grey_depth > 0 && a.grey_depth <= 16;
+    const bool fam_ok = C16 && SPLIT && D8 && (int_only || int_glcm || glcm_only);   // a compile-time family set of the compact builds applies
     int occ = 4;
     for (int o = fam_ok ? 8 : 7; o > 4; o--)
         if ((size_t)o * a.L.total <= lds) { occ = o; break; }
     if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
     const bool win = a.win.inten != nullptr;
-    if (occ == 8 && int_only && win) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+    if (fam_ok && glcm_only && occ >= 6) {
+        if (occ == 8) { if (win) hipLaunchKernelGGL((roi_features_kernel_occ8<3, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+                        else hipLaunchKernelGGL((roi_features_kernel_occ8<3, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a); }
+        else if (occ == 7) { if (win) hipLaunchKernelGGL((roi_features_kernel_fam7<3, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+                             else hipLaunchKernelGGL((roi_features_kernel_fam7<3, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a); }
+        else { if (win) hipLaunchKernelGGL((roi_features_kernel_fam6<3, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
+               else hipLaunchKernelGGL((roi_features_kernel_fam6<3, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a); }
+    }
+    else if (occ == 8 && int_only && win) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 8 && int_only) hipLaunchKernelGGL((roi_features_kernel_occ8<2, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 8 && win) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
     else if (occ == 8) hipLaunchKernelGGL((roi_features_kernel_occ8<1, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a);
