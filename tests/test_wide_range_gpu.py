@@ -78,3 +78,41 @@ def test_sixteen_bit_tiles_through_the_tile_path(hip_ctx):
     assert len(labels) == len(O)
     bad = parity.compare_tables(T, O, _lib.column_names(MASK, s))
     assert not bad, "\n".join(bad[:20])
+
+
+def test_glcm_alone_through_the_tile_path_and_the_batch_path(hip_ctx):
+    """GLCM alone has a compile-time build of its own (roi_features_kernel_occ8<3, WIN>): the window loader (tile path) and the cloud
+    loader (batch path) against the oracle, 8 and 16 levels, and a degenerate (constant) ROI among them."""
+    from tests import synth
+    rng = np.random.default_rng(41)
+    lab = synth.disk_label_tile(size=256, pitch=64, radius=27).astype(np.uint32)
+    inten = rng.integers(1, 4096, (3, 256, 256)).astype(np.uint32)
+    inten[1][lab == 3] = 500                                               # a constant ROI: every GLCM column is the soft NaN
+    for gd in (8, 16):
+        s = _abi.default_settings(gd)
+        tiles, labels, T = hip_ctx.featurize_tiles_host(inten, np.stack([lab] * 3), _abi.FAM_GLCM, s)
+        rows = []
+        for t in range(3):
+            b = _abi.batch_from_rois(synth.rois_from_tile(inten[t], lab))
+            rows.append(po.oracle_featurize(b, _abi.FAM_GLCM, s))
+            G = hip_ctx.featurize_host(b, _abi.FAM_GLCM, s)
+            assert not parity.compare_tables(G, rows[-1], _lib.column_names(_abi.FAM_GLCM, s))
+        bad = parity.compare_tables(T, np.concatenate(rows), _lib.column_names(_abi.FAM_GLCM, s))
+        assert not bad, "\n".join(bad[:20])
+
+
+def test_gabor_on_intensities_beyond_fp32_integers(hip_ctx):
+    """The Gabor screening pass runs in fp32, which holds integers below 2^24 exactly: an ROI with larger intensities takes the
+    reference's arithmetic for every filter (exact columns), next to ordinary ROIs in the same launch."""
+    rng = np.random.default_rng(42)
+    rois = []
+    for k in range(12):
+        r = ellipse_roi(int(rng.integers(6, 30)), int(rng.integers(6, 30)), rng)
+        hi = 2 ** 26 if k % 3 == 0 else 4096
+        r["inten"] = rng.integers(1, hi, len(r["x"])).astype(np.uint32)
+        rois.append(r)
+    s = _abi.default_settings(8)
+    b = _abi.batch_from_rois(rois)
+    G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+    O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+    assert np.array_equal(G, O, equal_nan=True), np.abs(G - O).max()
