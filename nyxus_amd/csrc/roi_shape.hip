@@ -231,6 +231,36 @@ __device__ __attribute__((noinline)) double gabor_exact_energy(const uint32_t* s
     return sqrt(re * re + im * im);
 }
 
+// A tile's window of T + 16 words as 16-byte reads that stay 16-byte reads: word 0 of the window is never used (taps reach words
+// 1 .. T + 15), and left alone the compiler drops it, which shifts the rest off their 16-byte alignment -- the window came in as
+// twelve ds_read2_b32 (4 LDS cycles each, banks of a 128-byte period) instead of six ds_read_b128.  The empty asm behind the last
+// load makes every word live (one statement for the whole window: the loads are all in flight before the first wait).
+template <int W4>
+__device__ __forceinline__ void lds_load_window(const uint32_t* row, uint4 (&u)[W4])
+{
+#pragma unroll
+    for (int q = 0; q < W4; q++) u[q] = ((const uint4*)row)[q];
+    static_assert(W4 == 5 || W4 == 6, "window of 20 or 24 words");
+    if constexpr (W4 == 6)
+        asm volatile("" : "+v"(u[0].x), "+v"(u[0].y), "+v"(u[0].z), "+v"(u[0].w), "+v"(u[1].x), "+v"(u[1].y), "+v"(u[1].z), "+v"(u[1].w),
+                          "+v"(u[2].x), "+v"(u[2].y), "+v"(u[2].z), "+v"(u[2].w), "+v"(u[3].x), "+v"(u[3].y), "+v"(u[3].z), "+v"(u[3].w),
+                          "+v"(u[4].x), "+v"(u[4].y), "+v"(u[4].z), "+v"(u[4].w), "+v"(u[5].x), "+v"(u[5].y), "+v"(u[5].z), "+v"(u[5].w));
+    else
+        asm volatile("" : "+v"(u[0].x), "+v"(u[0].y), "+v"(u[0].z), "+v"(u[0].w), "+v"(u[1].x), "+v"(u[1].y), "+v"(u[1].z), "+v"(u[1].w),
+                          "+v"(u[2].x), "+v"(u[2].y), "+v"(u[2].z), "+v"(u[2].w), "+v"(u[3].x), "+v"(u[3].y), "+v"(u[3].z), "+v"(u[3].w),
+                          "+v"(u[4].x), "+v"(u[4].y), "+v"(u[4].z), "+v"(u[4].w));
+}
+
+// acc += {a, a} * g with a = the low (HI = 0) or high (HI = 1) half of the register pair `pair`: the window stays in the registers the
+// 16-byte loads delivered it to, and the half is picked by the instruction's op_sel bits.  (Written by the compiler, a window value in
+// an odd register is first copied to an even one -- v_pk_fma_f32 takes 64-bit sources -- one v_mov per value and tap row.)
+template <int HI>
+__device__ __forceinline__ void pk_fma_bcast(v2f& acc, const v2f pair, const v2f g)
+{
+    if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(pair), "s"(g));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(pair), "s"(g));
+}
+
 template <int T, int NW, int MODE, bool ZR = false>
 __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_kernel(const ShapeArgs A)   // (MODE 2 / 3: held to 128 registers, four waves per SIMD like the other two)
 {
@@ -280,6 +310,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             p4[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
+    // (The plane stays u32 in every mode.  Holding fp32 bit patterns for the screening pass -- no conversions in front of its FMAs,
+    //  24.2 k instead of 26.7 k vector instructions per wave -- was built and measured in round 4: 46.6 against 41.5 ms per 196 k
+    //  ROIs; the conversions cost less than what the build lost around them.)
     for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         if (px < w && py < h)
             s_plane[(py + 7) * pitch + px + 8] = v;
@@ -288,7 +321,18 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 
     const bank_ptr_t bank = (bank_ptr_t)(uintptr_t)A.gabor_bank;
     const bank32_ptr_t bank32 = (bank32_ptr_t)(uintptr_t)A.gabor_bank32;
-    const uint32_t ntiles = tpr * h;
+    // Tiles are dealt to lanes COLUMN-major in blocks of 16 rows: the LDS serves a ds_read_b128 in four fixed groups of 16 lanes
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} of each half-wave; MI355X_MICROARCH.md, LDS), and a group whose 16 lanes read the
+    // same tile column of 16 consecutive rows touches 16 different 16-byte units of the 256-byte bank period (the pitch is an odd
+    // number of units) -- conflict-free for every box width.  Row-major dealing (lanes = consecutive tiles of a row, 32 bytes
+    // apart) put two lanes of a group on one unit: SQ_LDS_BANK_CONFLICT 67 % of SQ_LDS_IDX_ACTIVE, the LDS pipe busy 40 of the
+    // kernel's 48 ms.  vtid: the thread's index with the lanes of a hardware group made contiguous.
+    // (Row blocks pad the box to a multiple of 16 rows: where that would add a trip to the tile loop -- boxes a little over 16 or 32
+    //  rows -- and in the one-wave kernel of small ROIs, which does not saturate the LDS, the tiles stay row-major.)
+    const bool colmajor = NW == 4 && (((h + 15u) & ~15u) * tpr + kBlk - 1) / kBlk == (h * tpr + kBlk - 1) / kBlk;
+    const uint32_t vtid = !colmajor ? (uint32_t)tid
+                                    : ((uint32_t)tid & ~31u) | ((0x73261540u >> (((uint32_t)tid >> 2 & 7u) * 4u)) & 7u) << 2 | ((uint32_t)tid & 3u);
+    const uint32_t ntiles = (colmajor ? (h + 15u) & ~15u : h) * tpr;
     double maxval = 0;
     double tmax = -1.0, tmin = 1.7976931348623157e308;
     uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
@@ -332,8 +376,11 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             }
             __syncthreads();
         }
-        for (uint32_t tile = tid; tile < ntiles; tile += kBlk) {
-            const uint32_t b = tile / tpr, a0 = (tile - b * tpr) * T;
+        for (uint32_t tile = vtid; tile < ntiles; tile += kBlk) {
+            // column-major: (row block, tile column, row in block); row-major: (row, tile column)
+            const uint32_t cb = colmajor ? tile >> 4 : tile, rb = cb / tpr, b = colmajor ? rb * 16u + (tile & 15u) : rb, a0 = (cb - rb * tpr) * T;
+            if (b >= h)
+                continue;
             double re[T], im[T];
 #pragma unroll
             for (int t = 0; t < T; t++) { re[t] = 0.0; im[t] = 0.0; }
@@ -350,9 +397,11 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll 1
                 for (int j = 0; j < N; j++, row -= pitch) {
                     uint32_t wd[T + 16];
+                    uint4 uw[W4];
+                    lds_load_window<W4>(row, uw);
 #pragma unroll
                     for (int q = 0; q < W4; q++) {
-                        const uint4 u = ((const uint4*)row)[q];
+                        const uint4 u = uw[q];
                         wd[4 * q + 0] = u.x; wd[4 * q + 1] = u.y; wd[4 * q + 2] = u.z; wd[4 * q + 3] = u.w;
                     }
                     uint32_t sm = 0;                             // taps i = 0..15 of output t read words t + 16 - i = t + 1 .. t + 16
@@ -374,12 +423,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 for (int j = 0; j < N; j++, row -= pitch) {
                     if (((zero_rows >> j) & 1u) && ((zero_rows >> (16 + j)) & 1u))
                         continue;                                // (a row of +-0 taps adds nothing to either component)
-                    float win[T + 16];
+                    v2f win2[(T + 16) / 2];                      // window words 2 k, 2 k + 1
 #pragma unroll
                     for (int q = 0; q < W4; q++) {
-                        const uint4 u = ((const uint4*)row)[q];
-                        win[4 * q + 0] = (float)u.x; win[4 * q + 1] = (float)u.y;
-                        win[4 * q + 2] = (float)u.z; win[4 * q + 3] = (float)u.w;
+                        const uint4 u = ((const uint4*)row)[q];  // (every pair is used whole by the asm below: nothing for the compiler to narrow)
+                        win2[2 * q] = v2f{(float)u.x, (float)u.y};
+                        win2[2 * q + 1] = v2f{(float)u.z, (float)u.w};
                     }
                     const bank32_ptr_t Gj = G32 + j * N * 2;
 #pragma unroll
@@ -387,8 +436,10 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                         const v2f g = v2f{Gj[2 * i], Gj[2 * i + 1]};
 #pragma unroll
                         for (int t = 0; t < T; t++) {
-                            const float av = win[t + 16 - i];
-                            acc[t] = __builtin_elementwise_fma(v2f{av, av}, g, acc[t]);
+                            constexpr int kOdd = 1;
+                            const int e = t + 16 - i;            // window word of output t and tap i (a constant once unrolled)
+                            if ((e & kOdd) == 0) pk_fma_bcast<0>(acc[t], win2[e >> 1], g);
+                            else pk_fma_bcast<1>(acc[t], win2[e >> 1], g);
                         }
                     }
                 }
@@ -405,9 +456,11 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 if (re0 && im0)
                     continue;
                 double win[T + 16];
+                uint4 uw[W4];
+                lds_load_window<W4>(row, uw);
 #pragma unroll
                 for (int q = 0; q < W4; q++) {
-                    const uint4 u = ((const uint4*)row)[q];
+                    const uint4 u = uw[q];
                     win[4 * q + 0] = (double)u.x; win[4 * q + 1] = (double)u.y;
                     win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
                 }
