@@ -216,18 +216,31 @@ constexpr int kGaborRedoCap = 512;
 // zero tap adds +-0, which leaves a sum that started at +0 as it is: the same bits as the scans that skip zero rows).  Not inlined:
 // it runs for a handful of pixels, and inlined into the unrolled output loop it cost the kernel 50 registers (two waves per SIMD
 // instead of four).
-__device__ __attribute__((noinline)) double gabor_exact_energy(const uint32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G)
+// PF: the plane holds the intensities as fp32 bit patterns (MODE 3, every intensity of the ROI below 2^24: see the kernel) -- a
+// compile-time fact of the copy: as a run-time flag it put a branch on every tap of this loop (46.6 against 38.9 ms per 196 k ROIs).
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (the plane through LDS instructions: behind a generic pointer this function read it with flat loads)
+template <bool PF>
+__device__ __attribute__((noinline)) double gabor_exact_energy(const lds_u32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G)
 {
+    // (the bank pointer is the same in every lane; said so, the taps come through the scalar cache -- sixteen s_load per tap row
+    //  instead of 512 vector loads per call -- and a row's sixteen window words are read before the first is used)
+    const uint64_t gp = (uint64_t)(uintptr_t)G;
+    const bank_ptr_t Gu = (bank_ptr_t)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gp >> 32)) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gp));
     double re = 0.0, im = 0.0;
-    const uint32_t* rp = s_plane + (b + 15) * pitch + a + 16;
+    const lds_u32_t* rp = s_plane + (b + 15) * pitch + a + 16;
 #pragma unroll 1
-    for (int j = 0; j < 16; j++, rp -= pitch)
-#pragma unroll 4
+    for (int j = 0; j < 16; j++, rp -= pitch) {
+        uint32_t wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = rp[-i];
+#pragma unroll
         for (int i = 0; i < 16; i++) {
-            const double av = (double)rp[-i];
-            re += av * G[(j * 16 + i) * 2];
-            im += av * G[(j * 16 + i) * 2 + 1];
+            const double av = PF ? (double)__uint_as_float(wv[i]) : (double)wv[i];
+            re += av * Gu[(j * 16 + i) * 2];
+            im += av * Gu[(j * 16 + i) * 2 + 1];
         }
+    }
     return sqrt(re * re + im * im);
 }
 
@@ -310,12 +323,14 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             p4[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    // (The plane stays u32 in every mode.  Holding fp32 bit patterns for the screening pass -- no conversions in front of its FMAs,
-    //  24.2 k instead of 26.7 k vector instructions per wave -- was built and measured in round 4: 46.6 against 41.5 ms per 196 k
-    //  ROIs; the conversions cost less than what the build lost around them.)
+    // MODE 3: the plane holds fp32 bit patterns when every intensity of the ROI is an fp32 integer (below 2^24) -- the screening pass
+    // then reads its window without 23 conversions per tap row (26.7 k -> 24.2 k vector instructions per wave, 41.4 -> 38.9 ms per
+    // 196 k ROIs); the copies that follow the reference's arithmetic convert fp32 -> fp64 instead of u32 -> fp64, the same value.
+    // Zero padding is +0.0f.
+    const bool pf = MODE == 3 && A.max_inten[roi] < (1u << 24);
     for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         if (px < w && py < h)
-            s_plane[(py + 7) * pitch + px + 8] = v;
+            s_plane[(py + 7) * pitch + px + 8] = pf ? __float_as_uint((float)v) : v;
     });
     __syncthreads();
 
@@ -337,7 +352,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     double tmax = -1.0, tmin = 1.7976931348623157e308;
     uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
 
-    auto exact_energy = [&](uint32_t a, uint32_t b, const bank_ptr_t G) -> double { return gabor_exact_energy(s_plane, pitch, a, b, G); };
+    auto exact_energy = [&](uint32_t a, uint32_t b, const bank_ptr_t G) -> double { const lds_u32_t* pl = (const lds_u32_t*)s_plane;
+        return pf ? gabor_exact_energy<true>(pl, pitch, a, b, G) : gabor_exact_energy<false>(pl, pitch, a, b, G);
+    };
     bool lp_overflow = false;                          // MODE 2: the fused low-pass pass found more candidates than its list holds
     const double amax = (double)A.max_inten[roi];
 
@@ -402,7 +419,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll
                     for (int q = 0; q < W4; q++) {
                         const uint4 u = uw[q];
-                        wd[4 * q + 0] = u.x; wd[4 * q + 1] = u.y; wd[4 * q + 2] = u.z; wd[4 * q + 3] = u.w;
+                        if (MODE == 3) {                           // (a box filter implies intensities below 2^24: fp32 patterns)
+                            wd[4 * q + 0] = (uint32_t)__uint_as_float(u.x); wd[4 * q + 1] = (uint32_t)__uint_as_float(u.y);
+                            wd[4 * q + 2] = (uint32_t)__uint_as_float(u.z); wd[4 * q + 3] = (uint32_t)__uint_as_float(u.w);
+                        } else {
+                            wd[4 * q + 0] = u.x; wd[4 * q + 1] = u.y; wd[4 * q + 2] = u.z; wd[4 * q + 3] = u.w;
+                        }
                     }
                     uint32_t sm = 0;                             // taps i = 0..15 of output t read words t + 16 - i = t + 1 .. t + 16
 #pragma unroll
@@ -427,8 +449,8 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll
                     for (int q = 0; q < W4; q++) {
                         const uint4 u = ((const uint4*)row)[q];  // (every pair is used whole by the asm below: nothing for the compiler to narrow)
-                        win2[2 * q] = v2f{(float)u.x, (float)u.y};
-                        win2[2 * q + 1] = v2f{(float)u.z, (float)u.w};
+                        win2[2 * q] = v2f{__uint_as_float(u.x), __uint_as_float(u.y)};      // (this copy runs with pf only)
+                        win2[2 * q + 1] = v2f{__uint_as_float(u.z), __uint_as_float(u.w)};
                     }
                     const bank32_ptr_t Gj = G32 + j * N * 2;
 #pragma unroll
@@ -461,8 +483,13 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll
                 for (int q = 0; q < W4; q++) {
                     const uint4 u = uw[q];
-                    win[4 * q + 0] = (double)u.x; win[4 * q + 1] = (double)u.y;
-                    win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
+                    if (MODE == 3 && pf) {
+                        win[4 * q + 0] = (double)__uint_as_float(u.x); win[4 * q + 1] = (double)__uint_as_float(u.y);
+                        win[4 * q + 2] = (double)__uint_as_float(u.z); win[4 * q + 3] = (double)__uint_as_float(u.w);
+                    } else {
+                        win[4 * q + 0] = (double)u.x; win[4 * q + 1] = (double)u.y;
+                        win[4 * q + 2] = (double)u.z; win[4 * q + 3] = (double)u.w;
+                    }
                 }
                 const bank_ptr_t Gj = G + j * N * 2;
                 auto taps = [&](auto do_re_c, auto do_im_c, auto fuse_c) {
