@@ -393,6 +393,18 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             }
             __syncthreads();
         }
+        // The screening copy decides in the SQUARED domain -- no square root per output (a correctly rounded fp64 sqrt is ~15
+        // instructions).  S bounds the slack of the comparison below for every possible energy (e <= sqrt(2) a_max: the bank is
+        // L1-normalised), so "e within S of the threshold" contains every pixel the e-domain test would recompute; s2 = fl(re^2 +
+        // im^2) is within one rounding of e^2 (the squares of fp32 values are exact in fp64) and the bounds carry a factor
+        // (1 +- 1e-15) for it and for their own rounding: s2 > thr_hi2 implies e > T + S, s2 < thr_lo2 implies e < T - S.
+        const double S_thr = thr_slack + 3e-15 * amax;
+        const double t_lo = thr_max - S_thr > 0.0 ? thr_max - S_thr : 0.0, t_hi = thr_max + S_thr;
+        const double thr_lo2 = t_lo * t_lo * (1.0 - 1e-15), thr_hi2 = t_hi * t_hi * (1.0 + 1e-15);
+        // (low-pass candidates, same construction: at least Bs - M, or at most bs + M)
+        const double M_lp = kErr * amax + 3e-15 * amax + 1e-15 * (Bs > bs ? Bs : bs);
+        const double b_lo = Bs - M_lp > 0.0 ? Bs - M_lp : 0.0, b_hi = bs + M_lp;
+        const double lp_hi2 = b_lo * b_lo * (1.0 - 1e-15), lp_lo2 = b_hi * b_hi * (1.0 + 1e-15);
         for (uint32_t tile = vtid; tile < ntiles; tile += kBlk) {
             // column-major: (row block, tile column, row in block); row-major: (row, tile column)
             const uint32_t cb = colmajor ? tile >> 4 : tile, rb = cb / tpr, b = colmajor ? rb * 16u + (tile & 15u) : rb, a0 = (cb - rb * tpr) * T;
@@ -519,15 +531,21 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             for (int t = 0; t < T; t++) {
                 if (a0 + t >= w)
                     continue;
-                const double e = sqrt(re[t] * re[t] + im[t] * im[t]);   // :505
+                const double s2 = re[t] * re[t] + im[t] * im[t];
                 if (lp_cand) {
-                    // (the same bound as below, against Bs and bs instead of the threshold)
-                    const double m0 = __builtin_fma(1e-15, e, kErr * amax);
-                    if (e >= Bs - __builtin_fma(1e-15, Bs, m0) || e <= bs + __builtin_fma(1e-15, bs, m0)) {
+                    bool cand;
+                    if constexpr (f32) cand = s2 >= lp_hi2 || s2 <= lp_lo2;
+                    else {
+                        // (the same bound as below, against Bs and bs instead of the threshold)
+                        const double e = sqrt(s2), m0 = __builtin_fma(1e-15, e, kErr * amax);
+                        cand = e >= Bs - __builtin_fma(1e-15, Bs, m0) || e <= bs + __builtin_fma(1e-15, bs, m0);
+                    }
+                    if (cand) {
                         const uint32_t k = atomicAdd(&s_redo[0], 1u);
                         if (k < (uint32_t)kGaborRedoCap) s_redo[1 + k] = b * w + a0 + (uint32_t)t;
                     }
                 } else if (f == 0) {
+                    const double e = sqrt(s2);                              // :505
                     tmax = e > tmax ? e : tmax;
                     if (e < tmin) { tmin = e; n_min = 1; }
                     else if (e == tmin) n_min++;
@@ -537,13 +555,19 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     // |d re| + |d im| + 4 u e <= 0.9e-13 a_max + 4 u e of the reference's (see the kernel's header).  So outside
                     // |e - T| <= 2.5e-13 a_max + 1e-15 (e + T) the comparison of the fused e with T IS the reference's decision -- no
                     // division per pixel -- and inside it the pixel is recomputed.
-                    const double dlt = e - thr_max;
-                    if (fabs(dlt) <= __builtin_fma(1e-15, e, thr_slack)) {
+                    bool redo, above;
+                    if constexpr (f32) { above = s2 > thr_hi2; redo = !above && s2 >= thr_lo2; }
+                    else {
+                        const double e = sqrt(s2), dlt = e - thr_max;
+                        redo = fabs(dlt) <= __builtin_fma(1e-15, e, thr_slack);
+                        above = dlt > 0.0;
+                    }
+                    if (redo) {
                         const uint32_t k = atomicAdd(&s_redo[0], 1u);
                         if (k < (uint32_t)kGaborRedoCap) s_redo[1 + k] = b * w + a0 + (uint32_t)t;
-                    } else if (dlt > 0.0)
+                    } else if (above)
                         sc++;
-                } else if (e / maxval > A.gabor_thr)                    // :117
+                } else if (sqrt(s2) / maxval > A.gabor_thr)             // :117
                     sc++;
             }
         }
