@@ -11,11 +11,14 @@ import numpy as np
 sys.path.insert(0, ".")
 
 
+MAX_SIDE = int(__import__("os").environ.get("GABOR_FUZZ_MAX_SIDE", "70"))   # 70: small + medium classes; up to ~180 still takes the tiled kernel
+
+
 def batch(seed, n_rois):
     rng = np.random.default_rng(seed)
     rois = []
     for k in range(n_rois):
-        h, w = rng.integers(3, 71, 2)
+        h, w = rng.integers(3, MAX_SIDE + 1, 2)
         yy, xx = np.mgrid[0:h, 0:w]
         m = (((xx - w / 2) / (w / 2 + .5)) ** 2 + ((yy - h / 2) / (h / 2 + .5)) ** 2) <= 1
         kind = rng.integers(0, 5)
