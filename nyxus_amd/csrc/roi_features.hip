@@ -576,7 +576,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     // NW = waves per ROI.  Only 4 (one workgroup per ROI) is built.  A one-wave build -- four ROIs per workgroup, for the smallest
     // size class -- was measured and dropped: at 12 KB of LDS per wave (16-bit counting table) or 77 .. 120 VGPRs (sort engine) it
     // keeps 12 .. 24 ROIs in flight per CU against 8 here, but every ROI's chain of dependent LDS / HBM round trips gets longer:
-    // 49-pixel ROIs 8.4 -> 7.3 ns, 253-pixel ROIs 8.7 -> 8.9 ns per ROI.
+    // 49-pixel ROIs 8.4 -> 7.3 ns, 253-pixel ROIs 8.7 -> 8.9 ns per ROI.  A two-wave build of the metric configuration
+    // (round 4: what a wave pays once per phase whatever its share of the pixels is paid twice per ROI instead of four times, but
+    // the same eight workgroups per CU are four waves per SIMD instead of eight) took 2.39 ms per 196 k ROIs against 2.16.
     static_assert(NW == 4 && NW == kMaxAngles, "one workgroup of four waves per ROI (and a wave per GLCM angle)");
     constexpr int BS = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
