@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -1998,6 +1999,24 @@ struct HostPin {
         if (no_pin || bytes < pin_min || !ptr) return;
         const uintptr_t a = ((uintptr_t)ptr + kPage - 1) & ~(kPage - 1), z = ((uintptr_t)ptr + bytes) & ~(kPage - 1);
         if (z <= a) return;                                   // no whole page inside the array
+        // Never pages of the program-break heap (malloc's main arena).  Registered and released again they left the process in a
+        // state in which a LATER copy from an unrelated array at those addresses faulted on the GPU ("Memory access fault ... on
+        // address <heap page>", 4 of 33 runs of the GPU suite with NYXHIP_PIN_MIN=0, none of 20 without the small-array case):
+        // the allocator trims, grows and re-issues those pages, and the driver's user-pointer bookkeeping does not survive it.
+        // Arrays above malloc's mmap threshold -- the ones worth pinning -- are mappings of their own.  (The threshold adapts
+        // up to 32 MiB, so an array of 8 .. 32 MiB can live in the heap too: it then travels as a pageable copy.)
+        static const uintptr_t heap_lo = [] () -> uintptr_t {
+            uintptr_t lo_ = 0;
+            if (FILE* f = fopen("/proc/self/maps", "r")) {
+                char line[512];
+                while (fgets(line, sizeof(line), f))
+                    if (strstr(line, "[heap]")) { lo_ = (uintptr_t)strtoull(line, nullptr, 16); break; }
+                fclose(f);
+            }
+            return lo_;
+        }();
+        const uintptr_t brk_now = (uintptr_t)sbrk(0);
+        if (heap_lo == 0 || (a < brk_now && z > heap_lo)) return;   // (no [heap] line found: nothing is known about the layout -- no pinning)
         if (hipHostRegister((void*)a, z - a, hipHostRegisterDefault) == hipSuccess) { p[k] = (void*)a; lo[k] = a; hi[k] = z; } else (void)hipGetLastError();
     }
     // host -> device copy of [src, src + bytes) of array k: the part inside the registered pages as one (DMA) copy, what lies in
@@ -2013,7 +2032,14 @@ struct HostPin {
         if (e == hipSuccess && b1 > m1) e = hipMemcpyAsync((char*)dst + (m1 - b0), (const void*)m1, b1 - m1, hipMemcpyHostToDevice, st);
         return e;
     }
-    ~HostPin() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
+    ~HostPin()
+    {
+        for (void* q : p)
+            if (q && hipHostUnregister(q) != hipSuccess) {
+                (void)hipGetLastError();
+                if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] hipHostUnregister(%p) failed\n", q);
+            }
+    }
 };
 
 // The whole stack in chunks.  label_limit: v1's max_label (validated only).  prepinned: the caller has pinned the arrays.

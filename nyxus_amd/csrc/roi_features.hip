@@ -346,17 +346,25 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     uint32_t cc = 0, rc = 0, dc = 0;
     uint32_t pxpy_c[2] = {0u, 0u};                     // counts of p_{x+y}: k = lane and k = lane + 64
     {
-        uint32_t W = 0, X = 0, eup = 0, dlo = 0;
+        uint32_t W = 0, X = 0;
         const uint16_t* pcol_cells = P + S + lane + 1; // (row 1, column lane + 1)
+        // (a complete diagonal is stored by the one lane that holds it -- the row-marginal scratch is free until the pass is over --
+        //  and collected with one read per lane behind the loop: a v_readlane + compare + select per family and row before)
+        uint32_t* const pickX = (uint32_t*)prow_s;     // [k]: anti-diagonal k <= Ng - 2, complete in lane 0 before the shift of row k + 1
+        uint32_t* const pickW = pickX + Ng;            // [r]: upper diagonal Ng - 1 - r, complete in lane Ng - 1 after row r  (2 Ng words = the Ng doubles)
+        const bool first = lane == 0, last = lane == Ng - 1;
         for (int r = 0; r < Ng; r++) {
             const uint32_t cnt = act ? pcol_cells[r * S] : 0u;
             cc += cnt;
-            if (r >= 1)                                // anti-diagonal r - 1 is complete in lane 0 (before this row's shift)
-                dlo = lane == r - 1 ? (uint32_t)__builtin_amdgcn_readlane((int)X, 0) : dlo;
+            if (r >= 1 && first) pickX[r - 1] = X;
             X = lane_plus1_z(X) + cnt;
             W = lane_minus1_z(W) + cnt;
-            eup = lane == Ng - 1 - r ? (uint32_t)__builtin_amdgcn_readlane((int)W, Ng - 1) : eup;                     // upper diagonal Ng - 1 - r
+            if (last) pickW[r] = W;
         }
+        wav_sync<false>();
+        const uint32_t dlo = lane < Ng - 1 ? pickX[lane] : 0u;
+        const uint32_t eup = act ? pickW[Ng - 1 - lane] : 0u;
+        wav_sync<false>();                             // (the scratch takes the row marginals below)
         // lower diagonal d (>= 1) waits in lane Ng - 1 - d of W; anti-diagonal k >= Ng - 1 in lane k - (Ng - 1) of X
         const uint32_t wrev = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (Ng - 1 - lane), (int)W);
         dc = act ? eup + (lane >= 1 ? wrev : 0u) : 0u;
@@ -393,10 +401,10 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     // acor * sum_p - S_r * S_c exactly, JMAX from the largest count; sum_p < 65536 in a G16 launch, so every sum fits 32 bits);
     // the entropy term p lg(p + eps) depends on the count alone: the 16 smallest counts -- all of them on a textured ROI -- come
     // from a table built once per angle; only the two HXY terms need a float log per cell.
-    double* const Tent = sm + 32 - 16;                               // sm[16..31]: entropy terms of counts 0..15 (batch 2 uses sm[8..23] later)
+    double* const Tent = sm + 32 - 16;                               // sm[16..31]: entropy terms of counts 0..14, [15] = 0 (batch 2 uses sm[8..23] later)
     if (lane < 16) {
         const double pk = (double)lane * inv_sum_p;
-        Tent[lane] = pk * (double)fast_log2f(pk + 0.000000001);
+        Tent[lane] = lane < 15 ? pk * (double)fast_log2f(pk + 0.000000001) : 0.0;
     }
     wav_sync<false>();
     double ent = 0, hxy1c = 0, hxy2 = 0;
@@ -405,9 +413,13 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     // Rows are visited in GROUPS of equal row marginal: the float log of p_x(i) p_y(j) + eps -- the reference's quadratic, 19 of a
     // cell's 45 instructions with its conversions -- depends on the row only through its marginal count, and the 64 rows of a
     // textured ROI share ~25 distinct counts (Poisson around n / 64).  One log per group and column; HXY2 takes the group's
-    // multiplicity, HXY1 the cells' counts against the group's log (scaled by 1 / sum_p once at the end).  Rows with an empty
-    // marginal hold no pair and are skipped (narrow histograms: most of the 64 levels of real images).  The group loop runs on
-    // the scalar unit (ballot, s_ff1, bit clears).
+    // multiplicity, HXY1 the group's count per column against the group's log (scaled by 1 / sum_p once at the end).  Rows with an
+    // empty marginal hold no pair and are skipped (narrow histograms: most of the 64 levels of real images).  The group loop runs
+    // on the scalar unit (ballot, s_ff1, bit clears).
+    // The row step is seven vector instructions: lanes beyond the matrix order read cells of the next row and are cleared behind the
+    // loop (no mask inside it), a cell's count joins its group's integer sum (one conversion and one multiply-add per group, not
+    // per cell), and the entropy term is a table read for every cell -- counts of 15 and more (none on textured data: a 64 x 64
+    // matrix of a 2821-pixel ROI holds 0.7 pairs per cell) read a zero and are added by a second walk that runs only if one exists.
     unsigned long long rem = __ballot(act && rc != 0u);
     while (rem) {
         const int r0 = (int)__builtin_ctzll(rem);
@@ -420,16 +432,26 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
         const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
         const double lg = (double)fast_log2f(pp + 0.000000001);
         hxy2 = __builtin_fma(pp * (double)(uint32_t)__popcll(grp), lg, hxy2);
+        uint32_t gsum = 0;
         while (grp) {
             const int r = (int)__builtin_ctzll(grp);
             grp &= grp - 1ull;
-            const uint32_t cnt = act ? pcell[r * S] : 0u;
+            const uint32_t cnt = pcell[r * S];
             asm_i = mad24(cnt, cnt, asm_i);                          // f_asm :555 / f_energy :927-928
             cmax = cnt > cmax ? cnt : cmax;                          // f_GLCM_JMAX :1178-1179
-            double et = Tent[cnt < 15u ? cnt : 15u];
-            if (cnt >= 15u) { const double p = (double)cnt * inv_sum_p; et = p * (double)fast_log2f(p + 0.000000001); }
-            ent += et;                                               // f_entropy :734-735, JE :1160-1161, HXY :868
-            hxy1c = __builtin_fma((double)cnt, lg, hxy1c);
+            ent += Tent[cnt < 15u ? cnt : 15u];                      // f_entropy :734-735, JE :1160-1161, HXY :868
+            gsum += cnt;
+        }
+        hxy1c = __builtin_fma((double)gsum, lg, hxy1c);
+    }
+    if (!act) { asm_i = 0; cmax = 0; ent = 0.0; hxy1c = 0.0; }
+    if (__ballot(cmax >= 15u)) {                                     // the entropy terms of the large counts, which the table left out
+        rem = __ballot(act && rc != 0u);
+        while (rem) {
+            const int r = (int)__builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            const uint32_t cnt = act ? pcell[r * S] : 0u;
+            if (cnt >= 15u) { const double p = (double)cnt * inv_sum_p; ent += p * (double)fast_log2f(p + 0.000000001); }
         }
     }
     const double hxy1 = hxy1c * inv_sum_p;
@@ -1915,6 +1937,34 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 const uint32_t stride = in_col ? w : 0u;
                 uint32_t cur = r_begin < r_end ? (uint32_t)(*(const lds_u8_t*)adr) : 0u;
                 const uint32_t ng1 = (uint32_t)NG1;
+                if (slot0 >= 0 && slot1 >= 0 && slot2 >= 0 && slot3 >= 0 && !symmetric) {
+                    // the usual request -- four angles, asymmetric -- straight-line: levels travel doubled (the byte offset of a 16-bit
+                    // cell in its row), the matrix bases are folded into the centre's row offset per direction, and a pair is
+                    // add (cell's byte offset) / and (its word) / two shifts (1 << 16 * odd cell) / ds_add: four vector
+                    // instructions instead of six, no scalar branch per pair
+                    typedef __attribute__((address_space(3))) uint32_t lds_word_t;
+                    lds_word_t* const Pw = (lds_word_t*)s_P;
+                    const uint32_t B0 = (uint32_t)(uintptr_t)(Pw + slot0 * cellsw), B1 = (uint32_t)(uintptr_t)(Pw + slot1 * cellsw),
+                                   B2 = (uint32_t)(uintptr_t)(Pw + slot2 * cellsw), B3 = (uint32_t)(uintptr_t)(Pw + slot3 * cellsw);
+                    auto bump2 = [&](uint32_t a2) {        // a2: LDS byte address of the 16-bit cell
+                        (void)__hip_atomic_fetch_add((lds_word_t*)(uintptr_t)(a2 & ~3u), 1u << ((a2 << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    uint32_t cur2 = cur << 1;
+                    const uint32_t ng1x = ng1;              // (row offset in bytes = 2 * level * NG1 = cur2 * NG1)
+                    for (int row = r_begin; row < r_end; row++) {
+                        adr += stride;
+                        const uint32_t nxt2 = (uint32_t)(*(const lds_u8_t*)adr) << 1;
+                        const uint32_t e2 = lane_plus1_z(cur2), se2 = lane_plus1_z(nxt2), sw2 = lane_minus1_z(nxt2);
+                        if (cur2 != 0) {
+                            const uint32_t rowb = mul24(cur2, ng1x);
+                            bump2(B0 + rowb + e2);
+                            bump2(B1 + rowb + se2);
+                            bump2(B2 + rowb + nxt2);
+                            bump2(B3 + rowb + sw2);
+                        }
+                        cur2 = nxt2;
+                    }
+                } else
                 for (int row = r_begin; row < r_end; row++) {
                     adr += stride;
                     const uint32_t nxt = (uint32_t)(*(const lds_u8_t*)adr);
