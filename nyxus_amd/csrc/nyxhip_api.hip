@@ -1999,24 +1999,29 @@ struct HostPin {
         if (no_pin || bytes < pin_min || !ptr) return;
         const uintptr_t a = ((uintptr_t)ptr + kPage - 1) & ~(kPage - 1), z = ((uintptr_t)ptr + bytes) & ~(kPage - 1);
         if (z <= a) return;                                   // no whole page inside the array
-        // Never pages of the program-break heap (malloc's main arena).  Registered and released again they left the process in a
-        // state in which a LATER copy from an unrelated array at those addresses faulted on the GPU ("Memory access fault ... on
-        // address <heap page>", 4 of 33 runs of the GPU suite with NYXHIP_PIN_MIN=0, none of 20 without the small-array case):
-        // the allocator trims, grows and re-issues those pages, and the driver's user-pointer bookkeeping does not survive it.
-        // Arrays above malloc's mmap threshold -- the ones worth pinning -- are mappings of their own.  (The threshold adapts
-        // up to 32 MiB, so an array of 8 .. 32 MiB can live in the heap too: it then travels as a pageable copy.)
-        static const uintptr_t heap_lo = [] () -> uintptr_t {
-            uintptr_t lo_ = 0;
-            if (FILE* f = fopen("/proc/self/maps", "r")) {
-                char line[512];
-                while (fgets(line, sizeof(line), f))
-                    if (strstr(line, "[heap]")) { lo_ = (uintptr_t)strtoull(line, nullptr, 16); break; }
-                fclose(f);
+        // Never pages of malloc's arenas.  Registered and released again they left the process in a state in which a LATER copy
+        // from an unrelated array at those addresses faulted on the GPU ("Memory access fault ... on address <heap page>", 4 of 33
+        // runs of the GPU suite with NYXHIP_PIN_MIN=0, none of 20 without the small-array case): the allocator trims, grows and
+        // re-issues those pages, and the driver's user-pointer bookkeeping does not survive it.  Arrays above malloc's mmap
+        // threshold -- the ones worth pinning -- live in anonymous mappings outside the arenas (neighbouring ones merge into one
+        // line of /proc/self/maps, so "a mapping of its own" cannot be asked for).  The page range must lie in one line that is
+        // neither `[heap]` (the main arena) nor shaped like another thread's arena (64-MiB aligned, at most 64 MiB long); an array
+        // of 8 .. 32 MiB that malloc placed in an arena -- its threshold adapts -- travels as a pageable copy.
+        bool outside_arenas = false;
+        if (FILE* f = fopen("/proc/self/maps", "r")) {
+            char line[512];
+            while (fgets(line, sizeof(line), f)) {
+                unsigned long m0 = 0, m1 = 0;
+                if (sscanf(line, "%lx-%lx", &m0, &m1) != 2) continue;
+                if ((uintptr_t)m0 <= a && a < (uintptr_t)m1) {
+                    const bool arena_like = (m0 & ((64ul << 20) - 1)) == 0 && m1 - m0 <= (64ul << 20);
+                    outside_arenas = z <= (uintptr_t)m1 && !strstr(line, "[heap]") && !arena_like;
+                    break;
+                }
             }
-            return lo_;
-        }();
-        const uintptr_t brk_now = (uintptr_t)sbrk(0);
-        if (heap_lo == 0 || (a < brk_now && z > heap_lo)) return;   // (no [heap] line found: nothing is known about the layout -- no pinning)
+            fclose(f);
+        }
+        if (!outside_arenas) return;
         if (hipHostRegister((void*)a, z - a, hipHostRegisterDefault) == hipSuccess) { p[k] = (void*)a; lo[k] = a; hi[k] = z; } else (void)hipGetLastError();
     }
     // host -> device copy of [src, src + bytes) of array k: the part inside the registered pages as one (DMA) copy, what lies in

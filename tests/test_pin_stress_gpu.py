@@ -5,8 +5,8 @@ featurize_tiles_host, and worked around it by not pinning arrays below 8 MiB.  T
 an array that starts or ends inside a page shared that page's registration with its neighbour in the heap.  HostPin now registers
 whole pages inside the array only and copies the edges as pageable memory.  This test drives the pattern that used to fault --
 hundreds of calls alternating small heap arrays, large arrays and unaligned slices of larger arrays -- once with the default
-threshold and once with NYXHIP_PIN_MIN=0 (every array with a whole page inside it is pinned -- except pages of the program-break
-heap, which HostPin never registers: with them registered, 4 of 33 runs of the GPU suite died of the same fault in a LATER test's
+threshold and once with NYXHIP_PIN_MIN=0 (every array with a whole page inside it is pinned -- except pages of malloc's
+arenas, which HostPin never registers: with them registered, 4 of 33 runs of the GPU suite died of the same fault in a LATER test's
 copy; the small arrays of this test live there, its large arrays and the unaligned slice are mappings of their own)."""
 import numpy as np
 import pytest
