@@ -514,6 +514,33 @@ def test_gabor_tiled_kernel_edge_shapes_exact(hip_ctx):
             assert ((G == Rf) | (np.isnan(G) & np.isnan(Rf))).all()
 
 
+def test_gabor_tile_dealing_boundaries_exact(hip_ctx):
+    """Round 4 deals the tiles of the 256-thread Gabor kernel column-major in blocks of 16 rows (conflict-free 16-byte window reads),
+    except where padding the box to a multiple of 16 rows would add a trip to the tile loop: heights on either side of 16 / 32 / 48 /
+    64, widths on either side of the 8-pixel tile and of 64 / 128, smooth, noisy and flat fields -- count ratios bit-exact against the
+    oracle for the default bank and the 8-orientation bank."""
+    rng = np.random.default_rng(77)
+    rois = []
+    for k, (w, h) in enumerate([(61, 15), (61, 16), (61, 17), (40, 31), (40, 32), (40, 33), (64, 48), (65, 49), (57, 64), (56, 65), (120, 20), (129, 35),
+                                (23, 100), (9, 129), (140, 61), (33, 47), (8, 16), (72, 33), (128, 17), (16, 64)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = ((xx - w / 2 + .5) ** 2 / (w / 2) ** 2 + (yy - h / 2 + .5) ** 2 / (h / 2) ** 2 <= 1.0) if k % 3 else np.ones((h, w), bool)
+        if k % 4 == 0:
+            v = rng.integers(1, 4096, (h, w))
+        elif k % 4 == 1:
+            v = (1500 + 900 * np.sin(xx / 4.0) * np.cos(yy / 6.0) + rng.normal(0, 15, (h, w))).clip(1)
+        elif k % 4 == 2:
+            v = np.where((xx // 5 + yy // 3) % 2 == 0, 300, 2500)
+        else:
+            v = rng.integers(0, 1 << 16, (h, w))
+        rois.append(dict(x=xx[m].astype(np.uint16), y=yy[m].astype(np.uint16), inten=np.asarray(v)[m].astype(np.uint32)))
+    b = _abi.batch_from_rois(rois)
+    for s in (_abi.default_settings(8), _bank8(_abi.default_settings(8))):
+        G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+        O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
+        assert ((G == O) | (np.isnan(G) & np.isnan(O))).all(), np.argwhere(~((G == O) | (np.isnan(G) & np.isnan(O))))[:5]
+
+
 @pytest.mark.parametrize("top", [255, (1 << 24) - 1, 1 << 24, (1 << 32) - 1])
 def test_gabor_default_bank_box_filter_and_zero_rows_exact(hip_ctx, top):
     """The default bank's first filter has f0 = 0 (gabor.cpp:19-25 consumed as :107-110): every tap is (2^-8, 0).  The tiled
