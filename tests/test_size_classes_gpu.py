@@ -110,6 +110,22 @@ def test_a_wrong_statement_about_the_batch_is_an_error(hip_ctx):
     with pytest.raises(_lib.NyxHipError) as ei:
         hip_ctx.sync()
     assert ei.value.code == 5
+    # the same wrong statement with a shape-only mask (the hinted path launches the shape kernels over the whole batch, filtered by
+    # class: an ROI outside the stated classes must not be skipped by both launches -- round-3 advisor).  Either the flag is raised
+    # (Gabor: the ROI's plane does not fit the carve-out the statement sized) or the rows are right all the same (Zernike keeps no
+    # ROI-sized state: an ROI above its staging cap is read from HBM) -- never silence with unwritten columns.
+    for shape_mask in (_abi.FAM_ZERNIKE, _abi.FAM_GABOR, _abi.FAM_ZERNIKE | _abi.FAM_GABOR):
+        nc2 = hip_ctx.n_columns(shape_mask, s)
+        out2 = torch.full((b.n_roi, nc2), -12345.0, dtype=torch.float64, device=dev)
+        hip_ctx.featurize_device_async(cb, shape_mask, s, out2.data_ptr(), nc2)
+        try:
+            hip_ctx.sync()
+        except _lib.NyxHipError as e2:
+            assert e2.code == 5, shape_mask
+            assert shape_mask & _abi.FAM_GABOR
+        else:
+            assert shape_mask == _abi.FAM_ZERNIKE
+            assert not parity.compare_tables(out2.cpu().numpy(), po.oracle_featurize(b, shape_mask, s), _lib.column_names(shape_mask, s))
     cb.max_px = cb.max_bbox_area = cb.max_bbox_side = 0                           # no statement: the classifier derives everything
     hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)
     hip_ctx.sync()
