@@ -292,12 +292,13 @@ int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launch
 /* The size classes of the LAST nyxhip_featurize_batch[_async] call on this context, as launched: a JSON array written to
  * buf (NUL-terminated, truncated to buf_len), one object per launch group:
  *   {"class": c, "size_class": 0..4, "wide_range": 0|1, "rois": n, "max_px": .., "max_bbox_area": .., "max_range": ..,
- *    "max_side": .., "workspace": <bit mask>, "cooperative": 0|1, "ms": t, "lane_ms": t2}
+ *    "max_side": .., "workspace": <bit mask>, "cooperative": <bit mask>, "ms": t, "lane_ms": t2}
  * "class" < 0 = a launch over the whole batch, enqueued without counting anything because the stated batch extrema rule out
  * all but the two smallest size classes and wide intensity ranges (-1: texture + dependence kernels, -2: feature kernels,
  * -4 / -5: one-wave / four-wave shape kernels; "rois" is then the batch size); "workspace" 0 = kernels
  * with their state in LDS, else the kernel groups that run from the global workspace (bit 0 INTENSITY + GLCM, 1 texture,
- * 2 shape, 3 dependence); "cooperative" 1 = INTENSITY + GLCM of the class by several workgroups per ROI (ROIs beyond LDS);
+ * 2 shape, 3 dependence); "cooperative" = families of the class served by several workgroups per ROI (ROIs beyond LDS): bit 0 INTENSITY +
+ * GLCM, bit 1 GLRLM + GLSZM + NGTDM;
  * "ms" = device time of the class's launches on the call's stream and "lane_ms" = fork-to-end time of the class's workspace
  * launches on their own stream (large classes run them beside the main stream; null otherwise) when
  * nyxhip_timing_enable(ctx, 1) was in force for the call (waits for them), else null.  Counterpart in the

@@ -33,7 +33,7 @@ struct ClassRun {              // one size class of one call, as launched (nyxhi
     int workspace;             // kernel groups that ran from a global workspace instead of LDS: bit 0 INTENSITY + GLCM, 1 texture, 2 shape, 3 dependence
     hipEvent_t e0, e1;         // around the class's launches on the main stream (timing enabled), else NULL
     hipEvent_t e2 = nullptr;   // ... and the end of its launches on its workspace lane
-    int cooperative = 0;       // 1: INTENSITY + GLCM by the several-workgroups-per-ROI kernels of roi_large.hip
+    int cooperative = 0;       // bit 0: INTENSITY + GLCM by the several-workgroups-per-ROI kernels of roi_large.hip, bit 1: the texture families (roi_large_tex.hip)
 };
 struct ClassTotals {           // sums over the members of a class (class header): what the large-ROI path sizes its workspace from
     uint64_t px, area, range1; // pixels, bounding-box cells, histogram entries (range + 1 of the members whose range the path serves)
@@ -108,6 +108,11 @@ struct nyxhip_ctx {
     unsigned char* lane_buf[kLanes] = {};
     size_t lane_bytes[kLanes] = {};
     bool lane_used[kLanes] = {};
+    // ... and of the texture families (roi_large_tex.hip): one pair per lane (+ one for the main stream), the lanes run side by side
+    void* ltex_buf[kLanes + 1] = {};
+    size_t ltex_bytes[kLanes + 1] = {};
+    void* ltex_aux[kLanes + 1] = {};
+    size_t ltex_aux_bytes[kLanes + 1] = {};
     void* d_large = nullptr;
     size_t large_bytes = 0;
     void* d_large_aux = nullptr;
@@ -1144,6 +1149,110 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
     return NYXHIP_OK;
 }
 
+// GLRLM + GLSZM + NGTDM of one class by the several-workgroups-per-ROI kernels of roi_large_tex.hip, on stream `st` with the
+// workspace pair `slot`.  *served: 0 = the class does not qualify (nothing launched), 1 = every member was served, 2 = the members
+// outside ltex_eligible are left to the caller (the one-workgroup launch with SpillArgs::skip_ltex).
+static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
+                         const ClassTotals& tot, const uint32_t* list, uint32_t count, hipStream_t st, int slot, int* served)
+{
+    *served = 0;
+    const uint32_t mask2 = full & kTexture;
+    if (!mask2 || !count) return NYXHIP_OK;
+    const int greyInfo = s->ibsi ? 0 : s->grey_depth;
+    const uint32_t ng = greyInfo != 0 ? (uint32_t)abs(greyInfo) : E.vmax;         // bound of the class's level counts
+    if (ng == 0 || ng > kLtexLevels) return NYXHIP_OK;
+    LtexArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_roi = b->n_roi;
+    a.px_offset = b->px_offset; a.x = b->x; a.y = b->y; a.inten = b->inten;
+    a.bbox_w = b->bbox_w; a.bbox_h = b->bbox_h; a.min_inten = b->min_inten; a.max_inten = b->max_inten;
+    a.out = d_out; a.ld = ld; a.status = ctx->d_status;
+    a.mask = mask2; a.n_cols = nyxhip_n_columns(mask2, s);
+    a.col0 = nyxhip_n_columns(full & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM), s);
+    a.gap_after_glrlm = (full & NYXHIP_FAM_GLDZM) ? kGldzmCols : 0;
+    a.gap_after_glszm = ((full & NYXHIP_FAM_GLDM) ? kGldmCols : 0) + ((full & NYXHIP_FAM_NGLDM) ? kNgldmCols : 0);
+    a.soft_nan = s->soft_nan; a.grey_depth = s->grey_depth; a.ibsi = s->ibsi;
+    a.vec_ok = (((uintptr_t)b->inten & 15u) == 0 && ((uintptr_t)b->x & 7u) == 0 && ((uintptr_t)b->y & 7u) == 0) ? 1u : 0u;
+    a.plane16 = ng > 255 ? 1u : 0u;
+    a.px_per_wg = 8192;
+    const uint64_t cb = a.plane16 ? 2 : 1;
+    auto al16 = [](uint64_t v) { return (v + 15) & ~15ull; };
+    auto al256 = [](uint64_t v) { return (v + 255) & ~255ull; };
+    // ---- dynamic LDS at the bounds of what the path serves in this class (box sides of eligible members: <= kLtexMaxW wide)
+    const uint64_t side_w = std::min<uint32_t>(E.side, kLtexMaxW);
+    const uint32_t ng1 = ng + 1;
+    const uint64_t ngt_rep = ng1 <= 16 ? 8 : ng1 <= 32 ? 4 : ng1 <= 64 ? 2 : 1, ngt_stride = (((ng1 + 2) * 12ull + 16 + 7) & ~7ull) | 8;
+    const uint64_t cells = kLtexCells + 2 * side_w + 2 * std::min<uint64_t>(kLtexCells, std::max<uint64_t>(E.side, 1)) + 8;
+    // (under IBSI a member's level count is its own largest intensity, anything up to the class's: every term below covers the
+    //  smaller counts as well)
+    uint64_t strip = al16(2ull * (ng + 2)) + al16(cb * cells);
+    if (mask2 & NYXHIP_FAM_NGTDM) strip += ng1 <= 1024 ? std::max<uint64_t>(2048, al16(ngt_rep * ngt_stride)) : al16(12ull * 1026 + 32);
+    if (mask2 & NYXHIP_FAM_GLRLM) strip += al16(16ull * std::min<uint32_t>(ng, 128) * kLtexRlmLds);
+    const uint64_t sweep = (mask2 & NYXHIP_FAM_GLSZM) ? al16(8 * (side_w + 2)) + 2 * (al16(std::max<uint64_t>(4096, cb * side_w)) + 32) : 0;
+    const uint64_t lds_strip = std::max(strip, sweep) + 64;
+    const uint64_t S = ng <= 256 ? kLtexSmall : 0;
+    const uint64_t lds_zone = al16(2ull * (ng + 2)) + 4ull * std::min<uint32_t>(ng, 256) * kLtexSmall + 64;
+    const uint64_t side_e = std::min<uint64_t>(std::max<uint32_t>(E.side, 1), (1u << 20) - 1);     // an eligible box has fewer than 2^20 cells
+    const uint64_t slot_max = (uint64_t)ng * side_e + ng + side_e + 4;
+    const uint64_t fin_fixed = al16(8ull * a.n_cols) + al16(2ull * (ng + 2)) + al16(4ull * (ng + 2)) + al16(16ull * (std::min<uint32_t>(ng, 256) + 2));
+    const uint64_t fin_work = std::max<uint64_t>({8 * side_w, 16ull * (ng + 2), std::min<uint64_t>(16 * slot_max, 64 * 1024)});
+    const uint64_t lds_fin = fin_fixed + al16(fin_work) + 64;
+    if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] large texture: count %u ng %u side %u area %u lds strip %llu zone %llu fin %llu\n", count, ng, E.side, E.area,
+                                        (unsigned long long)lds_strip, (unsigned long long)lds_zone, (unsigned long long)lds_fin);
+    if (lds_strip > 144 * 1024 || lds_zone > 64 * 1024 || lds_fin > 144 * 1024) return NYXHIP_OK;
+    a.lds_strip_bytes = (uint32_t)lds_strip; a.lds_zone_bytes = (uint32_t)lds_zone; a.lds_fin_bytes = (uint32_t)lds_fin;
+    // ---- workspace: bounds of a member's block and of the class as a whole (ltex_ws_layout)
+    const uint64_t area_e = std::min<uint64_t>(std::max<uint32_t>(E.area, 1), (1u << 20) - 1);
+    const uint64_t rmin = std::max<uint64_t>(1, kLtexCells / std::max<uint64_t>(side_w, 1));
+    const uint64_t fixed = 256 + al256(ng + 8) + al256(12ull * (ng + 2)) + al256(16 * slot_max) + al256(4ull * std::min<uint32_t>(ng, 256) * kLtexSmall) +
+                           al256(8ull * szm_hash_cap(ng + 1, (uint32_t)area_e)) + 12 * 256;
+    auto var_bytes = [&](uint64_t area, uint64_t members) {
+        return cb * area + 64 * members + 4 * (area + 2 * members) + 4 * (area / (S + 1) + 8 * members) + 24 * (area / rmin + members * side_w);
+    };
+    const char* const be = getenv("NYXHIP_LARGE_BUDGET_MB");                  // (tests: a small budget sends a class through the chunked form)
+    const size_t budget = be && atoll(be) > 0 ? (size_t)atoll(be) << 20 : (size_t)8 << 30;
+    const uint64_t all_bytes = (uint64_t)count * fixed + var_bytes(tot.area, count);
+    const uint64_t one_max = fixed + var_bytes(area_e, 1);
+    uint32_t chunk = count;
+    uint64_t ws_need = all_bytes;
+    if (all_bytes > budget) {
+        if (one_max > budget) return NYXHIP_OK;              // (the one-workgroup path serves the class)
+        chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, budget / one_max));
+        ws_need = (uint64_t)chunk * one_max;
+    }
+    const uint64_t slabs_max = ((uint64_t)E.px + 3 + a.px_per_wg - 1) / a.px_per_wg, strips_max = area_e / 4096 + 2;
+    uint64_t cap_load = chunk == count ? tot.px / a.px_per_wg + 2ull * count : (uint64_t)chunk * slabs_max;
+    uint64_t cap_strip = chunk == count ? tot.area / 4096 + 2ull * count : (uint64_t)chunk * strips_max;
+    if (cap_load > 0x3FFFFFFFull || cap_strip > 0x3FFFFFFFull) return NYXHIP_OK;
+    const size_t o_ctr = 0, o_off = 256, o_ml = al256(o_off + 8ull * chunk), o_ms = al256(o_ml + 8ull * cap_load), aux_need = al256(o_ms + 8ull * cap_strip);
+    if (ws_need > ctx->ltex_bytes[slot]) {
+        if (ctx->ltex_buf[slot]) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->ltex_buf[slot])); ctx->ltex_buf[slot] = nullptr; ctx->ltex_bytes[slot] = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->ltex_buf[slot], ws_need));
+        ctx->ltex_bytes[slot] = ws_need;
+    }
+    if (aux_need > ctx->ltex_aux_bytes[slot]) {
+        if (ctx->ltex_aux[slot]) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->ltex_aux[slot])); ctx->ltex_aux[slot] = nullptr; ctx->ltex_aux_bytes[slot] = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->ltex_aux[slot], aux_need + aux_need / 4));
+        ctx->ltex_aux_bytes[slot] = aux_need + aux_need / 4;
+    }
+    char* const aux = (char*)ctx->ltex_aux[slot];
+    a.ws = (unsigned char*)ctx->ltex_buf[slot]; a.ws_bytes = ws_need;
+    a.ctr = (uint32_t*)(aux + o_ctr); a.ws_off = (uint64_t*)(aux + o_off);
+    a.map_load = (uint2*)(aux + o_ml); a.map_strip = (uint2*)(aux + o_ms);
+    a.cap_load = (uint32_t)cap_load; a.cap_strip = (uint32_t)cap_strip;
+    for (uint32_t o = 0; o < count; o += chunk) {
+        a.list = list + o; a.n_list = std::min(chunk, count - o);
+        HIP_TRY(ctx, hipMemsetAsync(a.ws, 0, ws_need, st));
+        HIP_TRY(ctx, hipMemsetAsync(a.ctr, 0, 256, st));
+        if (int rc = launch_large_texture(a, st))
+            return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI texture kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    *served = (E.side <= kLtexMaxW && (uint64_t)E.area < (1ull << 20)) ? 1 : 2;
+    if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] large texture: served %d, workspace %llu MiB, chunk %u, caps %llu / %llu\n", *served, (unsigned long long)(ws_need >> 20), chunk,
+                                        (unsigned long long)cap_load, (unsigned long long)cap_strip);
+    return NYXHIP_OK;
+}
+
 // One launch group.
 //   list != NULL: the members of one class (cls), `grid` of them (exact launches).  Which kernel groups of the class run from LDS is
 //   decided on the class BOUNDS (class_bounds); the carve-outs then follow the class's extrema E.  A group that does not fit runs
@@ -1279,25 +1388,9 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         if (!gs) return NYXHIP_OK;
     }
 
-    // ---- one workgroup per ROI over a global workspace: the groups of `gs` ------------------------------------------------------
-    RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
-    int lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs);
-    if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
-    if (coop) a2.sp.min_range = kLargeRangeMax;          // the histogram path served everybody below
-    size_t stride = 0;
-    if (gs & 1) stride = std::max<size_t>(stride, a2.L.total);
-    if (gs & 2) stride = std::max<size_t>(stride, t2.L.total);
-    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
-    if (gs & 8) stride = std::max<size_t>(stride, d2.L.total);
-    stride = (stride + 255) & ~(size_t)255;
-    const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(stride, 1)));
-    const size_t need = stride * chunk;
     // the lane of this class (nyxhip_ctx::lane_stream): large classes only -- the workspace fallback of an LDS class stays on the main stream
     static const bool no_lanes = [] { const char* e = getenv("NYXHIP_NO_LANES"); return e && *e && *e != '0'; }();   // A/B knob
     const int lane = (!no_lanes && cls / 2 >= kFirstLargeSizeClass) ? (cls - 2 * kFirstLargeSizeClass) % nyxhip_ctx::kLanes : -1;
-    unsigned char** const bufp = lane >= 0 ? &ctx->lane_buf[lane] : &ctx->d_spill;
-    size_t* const bytesp = lane >= 0 ? &ctx->lane_bytes[lane] : &ctx->spill_bytes;
     if (lane >= 0) {
         if (!ctx->lane_stream[lane]) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
@@ -1309,6 +1402,41 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         }
         st = ctx->lane_stream[lane];
     }
+    auto lane_stamp = [&]() -> int {
+        if (lane >= 0 && report && ctx->timing) {
+            HIP_TRY(ctx, hipEventCreate(&report->e2));
+            HIP_TRY(ctx, hipEventRecord(report->e2, st));
+        }
+        return NYXHIP_OK;
+    };
+
+    // ---- GLRLM + GLSZM + NGTDM of the class by several workgroups per ROI (roi_large_tex.hip) ---------------------------------------
+    static const bool no_coop_tex = [] { const char* e = getenv("NYXHIP_NO_COOP_TEX"); return e && *e && *e != '0'; }();   // A/B knob
+    int tex_served = 0;
+    if ((gs & 2) && tot && !no_coop && !no_coop_tex && cls / 2 >= kFirstLargeSizeClass) {
+        if (int lrc = run_large_tex(ctx, b, full, s, d_out, ld, E, *tot, list, grid, st, lane >= 0 ? lane : nyxhip_ctx::kLanes, &tex_served)) return lrc;
+        if (tex_served && report) report->cooperative |= 2;
+        if (tex_served == 1) gs &= ~2u;
+        if (!gs) return lane_stamp();
+    }
+
+    // ---- one workgroup per ROI over a global workspace: the groups of `gs` ------------------------------------------------------
+    RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
+    int lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs);
+    if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
+    if (coop) a2.sp.min_range = kLargeRangeMax;          // the histogram path served everybody below
+    if (tex_served == 2) t2.sp.skip_ltex = 1;            // ... and the strip path every box it takes
+    size_t stride = 0;
+    if (gs & 1) stride = std::max<size_t>(stride, a2.L.total);
+    if (gs & 2) stride = std::max<size_t>(stride, t2.L.total);
+    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
+    if (gs & 8) stride = std::max<size_t>(stride, d2.L.total);
+    stride = (stride + 255) & ~(size_t)255;
+    const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(stride, 1)));
+    const size_t need = stride * chunk;
+    unsigned char** const bufp = lane >= 0 ? &ctx->lane_buf[lane] : &ctx->d_spill;
+    size_t* const bytesp = lane >= 0 ? &ctx->lane_bytes[lane] : &ctx->spill_bytes;
     if (need > *bytesp) {
         if (*bufp) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(*bufp)); *bufp = nullptr; *bytesp = 0; }
         HIP_TRY(ctx, hipMalloc((void**)bufp, need));
@@ -1333,11 +1461,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
-    if (lane >= 0 && report && ctx->timing) {
-        HIP_TRY(ctx, hipEventCreate(&report->e2));
-        HIP_TRY(ctx, hipEventRecord(report->e2, st));
-    }
-    return NYXHIP_OK;
+    return lane_stamp();
 }
 
 static void clear_runs(nyxhip_ctx* ctx)
@@ -1616,6 +1740,10 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
         if (ctx->lane_buf[k]) (void)hipFree(ctx->lane_buf[k]);
     }
     if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
+    for (int k = 0; k <= nyxhip_ctx::kLanes; k++) {
+        if (ctx->ltex_buf[k]) (void)hipFree(ctx->ltex_buf[k]);
+        if (ctx->ltex_aux[k]) (void)hipFree(ctx->ltex_aux[k]);
+    }
     if (ctx->d_large) (void)hipFree(ctx->d_large);
     if (ctx->d_large_aux) (void)hipFree(ctx->d_large_aux);
     clear_runs(ctx);

@@ -55,6 +55,8 @@ struct SpillArgs {
     uint32_t class_mask;
     uint32_t min_range;          // workspace launches of the feature kernel: serve only ROIs whose intensity range reaches this (0: all) -- the
                                  // rest of the class went through the histogram path of roi_large.hip
+    uint32_t skip_ltex;          // workspace launches of the texture kernel: 1 = leave out the ROIs the several-workgroups-per-ROI texture
+                                 // path serves (ltex_eligible, roi_large_tex.hip)
 };
 __device__ __forceinline__ bool roi_in_launch(const SpillArgs& sp, uint32_t n, uint32_t w, uint32_t h, uint32_t range)
 {
@@ -442,6 +444,101 @@ struct LargeArgs {
     uint32_t dbg;                  // timing experiments only (NYXHIP_LARGE_DBG): 1 no plane stores, 2 no histogram counts, 4 no table flush, 8 no sums
 };
 int launch_large_features(const LargeArgs& a, void* stream);
+
+// ---- large-ROI path, texture families: GLRLM + GLSZM + NGTDM of an ROI by several workgroups (roi_large_tex.hip) -------------------
+// Same recipe as above: the binned plane of an ROI beyond the LDS classes goes to its block of a global workspace (load pass, slabs
+// of the cloud), strips of plane rows are workgroups of their own, and what crosses a strip is an integer: the NGTDM
+// accumulators (counts and sums of |i - mean| in units of 1/840), the run-length counts, the runs that touch a strip's first or
+// last row (recorded per column and joined by the finishing workgroup), the zone sizes at their owner pixels.  The GLSZM owner
+// sweep (a chain over the rows, features/glszm.cpp:108-185) is one wave per ROI beside the strips.
+constexpr uint32_t kLtexCells = 8192;             // plane cells per strip workgroup (whole rows)
+constexpr uint32_t kLtexMaxW = 8192;              // widest box the strip kernels stage
+constexpr uint32_t kLtexLevels = 4094;            // largest level (grey depth, or intensity under IBSI): 12 bits next to a 20-bit length / label
+constexpr uint32_t kLtexSmall = 32;               // GLSZM: zones of up to this many pixels are counted in a direct [level][size] table
+constexpr uint32_t kLtexRlmLds = 16;              // GLRLM: runs of up to this many pixels are counted in LDS first
+// served by this path: non-empty, box at most kLtexMaxW wide, fewer than 2^20 cells (owner labels travel in 20 bits).  A function
+// of the ROI alone; everybody else takes the one-workgroup workspace launch of roi_texture.hip.
+__host__ __device__ inline bool ltex_eligible(uint32_t n, uint32_t w, uint32_t h)
+{
+    return n != 0 && w != 0 && h != 0 && w <= kLtexMaxW && (uint64_t)w * h < (1ull << 20);
+}
+__host__ __device__ inline uint32_t ltex_rows_per_strip(uint32_t w, uint32_t h)
+{
+    uint32_t r = kLtexCells / (w ? w : 1u);
+    if (r < 1u) r = 1u;
+    return r < h ? r : (h ? h : 1u);
+}
+struct LtexWs {                                   // byte offsets inside an ROI's workspace block (header: 256 bytes of u32 words)
+    uint64_t flags, plane, ngt, rlm, rec, cnt, small, hash, big, total;
+    uint32_t rows, K;                             // rows per strip, strips
+    uint32_t slot_words;                          // words of one direction's run-length matrix + its marginals
+    uint32_t hcap, S, big_cap;                    // GLSZM: hash slots, direct-table sizes (0 or kLtexSmall), entries of the list of larger zones
+};
+enum { LTEX_H_NP_ORIG = 0, LTEX_H_NP_BIN, LTEX_H_NZONE, LTEX_H_SZMAX, LTEX_H_NBIG };   // header words
+// ng: bound of the ROI's level count (grey depth, or its largest intensity under IBSI)
+__host__ __device__ inline LtexWs ltex_ws_layout(uint32_t w, uint32_t h, uint32_t ng, bool plane16, uint32_t mask)
+{
+    LtexWs L;
+    const uint64_t area = (uint64_t)w * h;
+    const uint32_t side = w > h ? w : h;
+    L.rows = ltex_rows_per_strip(w, h);
+    L.K = (h + L.rows - 1) / L.rows;
+    auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
+    uint64_t o = 256;
+    L.flags = o; o += al((uint64_t)ng + 8);
+    L.plane = o; o += al((plane16 ? 2ull : 1ull) * area + 64);
+    L.ngt = o; if (mask & NYXHIP_FAM_NGTDM) o += al(12ull * ((uint64_t)ng + 2));            // u64 S[ng + 2] | u32 N[ng + 2]
+    L.slot_words = ng * side + ng + side + 4;
+    L.rlm = o; if (mask & NYXHIP_FAM_GLRLM) o += al(16ull * L.slot_words);
+    L.rec = o; if (mask & NYXHIP_FAM_GLRLM) o += al(24ull * L.K * w);                      // [K][2][3][w] u32: runs touching a strip's first / last row
+    L.hcap = 0; L.S = 0; L.big_cap = 0;
+    L.cnt = o; L.small = o; L.hash = o; L.big = o;
+    if (mask & NYXHIP_FAM_GLSZM) {
+        L.hcap = szm_hash_cap(ng + 1, (uint32_t)area);
+        L.S = ng <= 256 ? kLtexSmall : 0u;
+        L.big_cap = (uint32_t)(area / (L.S + 1)) + 8;
+        L.cnt = o; o += al(4ull * (area + 2));
+        L.small = o; o += al(4ull * ng * L.S);
+        L.hash = o; o += al(8ull * L.hcap);
+        L.big = o; o += al(4ull * L.big_cap);
+    }
+    L.total = o;
+    return L;
+}
+struct LtexArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    double* out;
+    uint64_t ld;
+    int* status;
+    uint32_t mask;                 // subset of GLRLM | GLSZM | NGTDM
+    int32_t n_cols, col0, gap_after_glrlm, gap_after_glszm;   // as TexArgs
+    double soft_nan;
+    int32_t grey_depth, ibsi;
+    const uint32_t* list;          // the members of this launch group (ROI indices)
+    uint32_t n_list;
+    unsigned char* ws;             // workspace of the group, zeroed before the prep kernel
+    uint64_t ws_bytes;
+    uint64_t* ws_off;              // [n_list] byte offset of a member's block (prep kernel); ~0: not served by this path
+    uint32_t* ctr;                 // [8] zeroed: 0-1 u64 cursor of workspace bytes, 2 load workgroups, 3 strip workgroups
+    uint2* map_load;               // [cap_load] (member, slab)
+    uint2* map_strip;              // [cap_strip] (member, strip)
+    uint32_t cap_load, cap_strip;
+    uint32_t px_per_wg;            // pixels of a slab
+    uint32_t plane16;              // 1: the plane holds 16-bit levels
+    uint32_t vec_ok;               // as LargeArgs
+    uint32_t lds_strip_bytes;      // dynamic LDS of the strip / sweep kernel
+    uint32_t lds_zone_bytes;       // ... of the zone kernel
+    uint32_t lds_fin_bytes;        // dynamic LDS of the finishing kernel
+};
+int launch_large_texture(const LtexArgs& a, void* stream);
 
 // ---- LDS-sized ROIs of 16-bit data: first-order features without a sort (roi_wide.hip) ----------------------------------------------
 constexpr int kWideDupCap = 256;   // duplicate values the fast path lists per ROI (more: the sort-based slow path of the same kernel)

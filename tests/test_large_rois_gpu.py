@@ -88,6 +88,44 @@ def test_intensity_alone_and_glcm_alone(hip_ctx):
 
 def test_config4_on_large_rois(hip_ctx):
     check(hip_ctx, large_rois(seed=11)[:3], CONFIG4, _abi.default_settings(8))
+    assert any(r["cooperative"] & 2 for r in hip_ctx.launch_report())
+
+
+@pytest.mark.parametrize("gd,ibsi", [(8, 0), (64, 0), (-16, 0), (100, 0), (300, 0), (8, 1)])
+def test_texture_families_of_large_rois_match_oracle(hip_ctx, gd, ibsi):
+    """GLRLM + GLSZM + NGTDM by several workgroups per ROI (roi_large_tex.hip) under every binning mode and plane width: the 20 k /
+    100 k (zeros, holes) / 400 k-pixel ellipses, the constant and the all-zero ROI, the 2000 x 12 strip."""
+    s = _abi.default_settings(gd)
+    s.ibsi = ibsi
+    tex = _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
+    check(hip_ctx, large_rois(seed=23, hi=200 if ibsi else 4096), tex, s, expect_coop=False)
+    assert any(r["cooperative"] & 2 for r in hip_ctx.launch_report())
+
+
+@pytest.mark.parametrize("fam", ["GLRLM", "GLSZM", "NGTDM"])
+def test_each_texture_family_alone_on_large_rois(hip_ctx, fam):
+    check(hip_ctx, large_rois(seed=29)[:4], getattr(_abi, "FAM_" + fam), _abi.default_settings(8), expect_coop=False)
+
+
+def test_pin_holed_ellipse_of_400k_pixels(hip_ctx):
+    """A 400 k-pixel ellipse with 2 % of its pixels missing (background inside the box everywhere: long zero runs end, zones of the
+    background level split) and flat patches (long runs and zones that cross many strips), config-4 families."""
+    rng = np.random.default_rng(31)
+    r = ellipse_roi(400, 320, rng, holes=0.02)
+    flat = (r["x"] // 37 + r["y"] // 29) % 5 == 0
+    r["inten"][flat] = 2000
+    check(hip_ctx, [r, ellipse_roi(120, 90, rng, holes=0.3, hi=300)], CONFIG4, _abi.default_settings(8))
+    check(hip_ctx, [r], CONFIG4, _abi.default_settings(64))
+
+
+def test_boxes_beyond_the_strip_path_fall_back(hip_ctx):
+    """A 9000 x 20 box (wider than the strip kernels stage) next to boxes the path serves: the class is split between the two
+    paths, every row matches."""
+    rng = np.random.default_rng(37)
+    yy, xx = np.mgrid[0:20, 0:9000]
+    o = np.lexsort((yy.ravel(), xx.ravel()))
+    wide = dict(x=xx.ravel()[o], y=yy.ravel()[o], inten=rng.integers(1, 4096, xx.size).astype(np.uint32))
+    check(hip_ctx, [wide, ellipse_roi(300, 200, rng), ellipse_roi(90, 72, rng)], CONFIG4, _abi.default_settings(8))
 
 
 def test_large_rows_do_not_depend_on_companions_budget_or_chunking(hip_ctx, monkeypatch):
