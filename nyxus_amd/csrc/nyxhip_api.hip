@@ -1182,24 +1182,30 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
     const uint64_t side_w = std::min<uint32_t>(E.side, kLtexMaxW);
     const uint32_t ng1 = ng + 1;
     const uint64_t ngt_rep = ng1 <= 16 ? 8 : ng1 <= 32 ? 4 : ng1 <= 64 ? 2 : 1, ngt_stride = (((ng1 + 2) * 12ull + 16 + 7) & ~7ull) | 8;
-    const uint64_t cells = kLtexCells + 2 * side_w + 2 * std::min<uint64_t>(kLtexCells, std::max<uint64_t>(E.side, 1)) + 8;
+    const uint64_t cells = std::max<uint64_t>(kLtexCells, side_w) + 2 * side_w + 64;       // a strip's rows and its two halo rows, staged as they lie in the plane
     // (under IBSI a member's level count is its own largest intensity, anything up to the class's: every term below covers the
     //  smaller counts as well)
     uint64_t strip = al16(2ull * (ng + 2)) + al16(cb * cells);
     if (mask2 & NYXHIP_FAM_NGTDM) strip += ng1 <= 1024 ? std::max<uint64_t>(2048, al16(ngt_rep * ngt_stride)) : al16(12ull * 1026 + 32);
-    if (mask2 & NYXHIP_FAM_GLRLM) strip += al16(16ull * std::min<uint32_t>(ng, 128) * kLtexRlmLds);
-    const uint64_t sweep = (mask2 & NYXHIP_FAM_GLSZM) ? al16(8 * (side_w + 2)) + 2 * (al16(std::max<uint64_t>(4096, cb * side_w)) + 32) : 0;
+    // (replicated short-run tables, roi_large_tex.hip: ltex_rl_rep x ltex_rl_words -- at most 8 x 65 x 16 words, reached at 16 levels)
+    const uint64_t rl_bytes = (mask2 & NYXHIP_FAM_GLRLM) ? al16(4ull * 8 * 65 * std::min<uint32_t>(std::max<uint32_t>(ng, 1), 16)) : 0;
+    strip += rl_bytes;
+    // sweep: two rows of owners, the chunk hand-overs, the ring of plane rows (rows of up to 1008 bytes: 1040-byte slots)
+    const uint64_t sweep = (mask2 & NYXHIP_FAM_GLSZM) ? al16(8 * (side_w + 2) + 16 * (side_w / 64 + 4)) + 1040 * (8 + side_w / 64 + 2 + 5) : 0;
+    // a wave per 64 columns of the class's widest box, and the wave that feeds the ring
+    a.strip_threads = 64u * (uint32_t)(std::min<uint64_t>(15, std::max<uint64_t>(3, (std::min<uint64_t>(side_w, 1024) + 62) / 64 + 1)) + 1);
+    a.lds_load_bytes = 32 * 1024;
     const uint64_t lds_strip = std::max(strip, sweep) + 64;
     const uint64_t S = ng <= 256 ? kLtexSmall : 0;
-    const uint64_t lds_zone = al16(2ull * (ng + 2)) + 4ull * std::min<uint32_t>(ng, 256) * kLtexSmall + 64;
+    const uint64_t lds_zone = al16(2ull * (ng + 2)) + al16(4ull * std::min<uint32_t>(ng, 256) * kLtexSmall) + rl_bytes + 64;
     const uint64_t side_e = std::min<uint64_t>(std::max<uint32_t>(E.side, 1), (1u << 20) - 1);     // an eligible box has fewer than 2^20 cells
     const uint64_t slot_max = (uint64_t)ng * side_e + ng + side_e + 4;
     const uint64_t fin_fixed = al16(8ull * a.n_cols) + al16(2ull * (ng + 2)) + al16(4ull * (ng + 2)) + al16(16ull * (std::min<uint32_t>(ng, 256) + 2));
-    const uint64_t fin_work = std::max<uint64_t>({8 * side_w, 16ull * (ng + 2), std::min<uint64_t>(16 * slot_max, 64 * 1024)});
+    const uint64_t fin_work = std::max<uint64_t>(16ull * (ng + 2), std::min<uint64_t>(16 * slot_max, 64 * 1024));
     const uint64_t lds_fin = fin_fixed + al16(fin_work) + 64;
     if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] large texture: count %u ng %u side %u area %u lds strip %llu zone %llu fin %llu\n", count, ng, E.side, E.area,
                                         (unsigned long long)lds_strip, (unsigned long long)lds_zone, (unsigned long long)lds_fin);
-    if (lds_strip > 144 * 1024 || lds_zone > 64 * 1024 || lds_fin > 144 * 1024) return NYXHIP_OK;
+    if (lds_strip > 144 * 1024 || lds_zone > 96 * 1024 || lds_fin > 144 * 1024) return NYXHIP_OK;
     a.lds_strip_bytes = (uint32_t)lds_strip; a.lds_zone_bytes = (uint32_t)lds_zone; a.lds_fin_bytes = (uint32_t)lds_fin;
     // ---- workspace: bounds of a member's block and of the class as a whole (ltex_ws_layout)
     const uint64_t area_e = std::min<uint64_t>(std::max<uint32_t>(E.area, 1), (1u << 20) - 1);

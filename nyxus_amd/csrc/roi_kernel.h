@@ -534,8 +534,10 @@ struct LtexArgs {
     uint32_t px_per_wg;            // pixels of a slab
     uint32_t plane16;              // 1: the plane holds 16-bit levels
     uint32_t vec_ok;               // as LargeArgs
+    uint32_t lds_load_bytes;       // dynamic LDS of the load kernel: its transposing tile
+    uint32_t strip_threads;        // workgroup size of the strip / sweep kernel: a wave per 64 columns of the class's widest box, 4 .. 16 waves
     uint32_t lds_strip_bytes;      // dynamic LDS of the strip / sweep kernel
-    uint32_t lds_zone_bytes;       // ... of the zone kernel
+    uint32_t lds_zone_bytes;       // ... of the join / zone kernel
     uint32_t lds_fin_bytes;        // dynamic LDS of the finishing kernel
 };
 int launch_large_texture(const LtexArgs& a, void* stream);

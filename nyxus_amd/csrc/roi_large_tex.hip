@@ -13,11 +13,13 @@
 //                                strip are counted; a run that touches the strip's first or last row is RECORDED per column
 //                                (level, length) and joined with its continuation by the finishing workgroup
 //                       and, in the same launch, one workgroup per ROI for the
-//                         GLSZM  owner sweep (glszm.cpp:108-185 as directed reachability, roi_texture.hip): a chain over the rows, one
-//                                wave, the other three stage the rows ahead of it; zone sizes by atomics at the owner pixel
-//   ltex_zone_kernel    one workgroup per strip: zones -> (level, size) multiplicities (direct table for sizes <= 32, a list for
-//                       the few larger ones), number of zones, largest zone
-//   ltex_finish_kernel  one workgroup per ROI: joins the recorded runs, then the 80 + 16 + 5 columns in a fixed order
+//                         GLSZM  owner sweep (glszm.cpp:108-185 as directed reachability, roi_texture.hip): a chain over the rows, run as a
+//                                pipeline -- one wave per 64 columns, chunk j of row r at step 2 r + j; zone sizes by atomics at the
+//                                owner pixel
+//   ltex_post_kernel    one workgroup per strip: joins the recorded runs that start in its strip with their continuations and counts
+//                       them; zones -> (level, size) multiplicities (direct table for sizes <= 32, a list for the few larger
+//                       ones), number of zones, largest zone
+//   ltex_finish_kernel  one workgroup per ROI: the 80 + 16 + 5 columns in a fixed order
 //
 // Everything that crosses a workgroup is an integer (atomic adds) or a record written once, so a row does not depend on the cut,
 // the arrival order, the companions or the workspace budget.  Kernel boundaries are the only synchronisation.
@@ -45,6 +47,7 @@ struct LtexRoi {
     uint32_t ng;                                           // bound of the level count = capacity of the level map
     LtexWs L;
     unsigned char* base;
+    uint32_t colmajor;                                     // the cloud runs down the columns (phase2_2d.cpp:655-656): the load kernel transposes through LDS
 };
 
 __device__ __forceinline__ bool ltex_roi(const LtexArgs& A, uint32_t j, LtexRoi& R, bool need_block)
@@ -65,7 +68,8 @@ __device__ __forceinline__ bool ltex_roi(const LtexArgs& A, uint32_t j, LtexRoi&
     if (need_block) {
         const uint64_t o = A.ws_off[j];
         if (o == ~0ull) return false;
-        R.base = A.ws + o;
+        R.base = A.ws + (o & ~255ull);                      // (blocks are 256-byte aligned: bit 0 carries the scan order)
+        R.colmajor = (uint32_t)(o & 1ull);
     }
     return true;
 }
@@ -113,21 +117,31 @@ __global__ __launch_bounds__(256) void ltex_prep_kernel(const LtexArgs A)
         atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         return;
     }
-    A.ws_off[j] = off;
+    // scan order of the cloud, read off a pair of pixels in its middle (the first column of a disk is a single pixel)
+    const uint64_t m = R.off + (R.n >= 2 ? R.n / 2 - 1 : 0);
+    const uint32_t cm = (R.n >= 2 && A.x[m + 1] == A.x[m] && (uint32_t)A.y[m + 1] == (uint32_t)A.y[m] + 1u) ? 1u : 0u;
+    A.ws_off[j] = off | cm;
     for (uint32_t s = 0; s < g_load; s++) A.map_load[b_load + s] = make_uint2(j, s);
     for (uint32_t s = 0; s < g_strip; s++) A.map_strip[b_strip + s] = make_uint2(j, s);
 }
 
 // ---- load: one workgroup per slab of the cloud ---------------------------------------------------------------------------------
+// The plane is row-major (the GLSZM sweep follows the raster order).  A cloud that runs down the columns (the in-memory workflow)
+// would store every pixel of a wave to a cache line of its own -- the stores were nine tenths of this kernel's time -- so the
+// slab's levels go to an LDS tile first (the slab covers a few whole columns of the box: [its first pixel's x, its last pixel's
+// x] x all rows) and leave it row by row.  Cells that stayed 0 are not stored (the slabs that share a boundary column each write
+// their own pixels; 0 is what the zeroed workspace holds anyway).  Pixels outside the tile -- a cloud in any other order -- are
+// stored directly.
 template <bool P16>
 __global__ __launch_bounds__(256) void ltex_load_kernel(const LtexArgs A)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= A.ctr[2]) return;
     const uint2 job = A.map_load[blockIdx.x];
     LtexRoi R;
     if (!ltex_roi(A, job.x, R, true)) return;
     constexpr int BS = 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
     plane_t* const plane = (plane_t*)(R.base + R.L.plane);
     uint8_t* const flags = R.base + R.L.flags;
@@ -140,8 +154,22 @@ __global__ __launch_bounds__(256) void ltex_load_kernel(const LtexArgs A)
     const uint64_t roi_lo = R.off, roi_hi = R.off + R.n;
     const uint64_t gs = (R.off & ~3ull) + (uint64_t)job.y * A.px_per_wg;      // slabs are cut in the batch's global pixel index (roi_large.hip)
     const uint64_t ge = gs + A.px_per_wg < roi_hi ? gs + A.px_per_wg : roi_hi;
-    uint32_t nz_orig = 0, nz_bin = 0;
     const uint32_t w = R.w, h = R.h;
+    // the tile: columns [tx0, tx0 + tnc) of the box, all rows, column-major in LDS
+    plane_t* const tile = (plane_t*)lds_raw;
+    uint32_t tx0 = 0, tnc = 0;
+    if (R.colmajor && ge > (gs > roi_lo ? gs : roi_lo)) {
+        const uint64_t first = gs > roi_lo ? gs : roi_lo;
+        const uint32_t xa = A.x[first], xb = A.x[ge - 1];
+        const uint32_t fit = A.lds_load_bytes / ((uint32_t)sizeof(plane_t) * h);
+        if (xb >= xa && xa < w && fit) { tx0 = xa; tnc = min(min(xb - xa + 1u, fit), w - xa); }
+    }
+    if (tnc) {
+        uint32_t* const t32 = (uint32_t*)tile;
+        for (uint32_t i = tid; i < (tnc * h * (uint32_t)sizeof(plane_t) + 3u) / 4u; i += BS) t32[i] = 0;
+        __syncthreads();
+    }
+    uint32_t nz_orig = 0, nz_bin = 0;
     auto pixel = [&](uint32_t v, uint32_t px, uint32_t py) {
         uint32_t lvl;
         if (greyInfo > 0) {     // bin_matlab: floor(slope v + 1) >= 1, 0 -> 1 (the conversion truncates a positive value)
@@ -152,7 +180,8 @@ __global__ __launch_bounds__(256) void ltex_load_kernel(const LtexArgs A)
         nz_orig += v != 0;
         if (lvl > Lcap) lvl = Lcap;
         if (px < w && py < h) {
-            plane[py * w + px] = (plane_t)lvl;
+            if (px - tx0 < tnc) tile[(px - tx0) * h + py] = (plane_t)lvl;
+            else plane[py * w + px] = (plane_t)lvl;
             if (lvl != 0) { flags[lvl] = 1; nz_bin++; }
         }
     };
@@ -189,7 +218,14 @@ __global__ __launch_bounds__(256) void ltex_load_kernel(const LtexArgs A)
         if (nz_orig) atomicAdd(&hdr[LTEX_H_NP_ORIG], nz_orig);
         if (nz_bin) atomicAdd(&hdr[LTEX_H_NP_BIN], nz_bin);
     }
-    (void)wave;
+    if (tnc) {
+        __syncthreads();
+        RowCol rc((uint32_t)tid, BS, tnc);                  // row of the box, column of the tile
+        for (uint32_t i = tid; i < tnc * h; i += BS, rc.advance()) {
+            const plane_t v = tile[rc.col * h + rc.row];
+            if (v != 0) plane[rc.row * w + tx0 + rc.col] = v;
+        }
+    }
 }
 
 // ---- the levels of an ROI: level -> row + 1, row -> level (glrlm.cpp:101-105, glszm.cpp:97-101, ngtdm.cpp:53-67) -----------------
@@ -228,13 +264,48 @@ __device__ __forceinline__ uint32_t align16u(uint32_t v) { return (v + 15u) & ~1
 __device__ __forceinline__ uint32_t ltex_ngt_rep(uint32_t ng1) { return ng1 <= 16 ? 8u : ng1 <= 32 ? 4u : ng1 <= 64 ? 2u : 1u; }
 __device__ __forceinline__ uint32_t ltex_ngt_stride(uint32_t ng1) { return (((ng1 + 2) * 12u + 16u + 7u) & ~7u) | 8u; }
 
+// GLRLM: runs of up to kLtexRlmLds pixels are counted in LDS first, in REPLICAS of a [direction][length][level] table: with a
+// handful of levels and most runs one or two pixels long, the 64 lanes of an atomic would meet on a dozen addresses, which LDS
+// serialises (two thirds of the strip kernel's time).  A lane adds into replica lane % R; levels are the minor index and the
+// replicas lie Lcap words (mod 64) apart, so the lanes of one instruction spread over the banks.
+__device__ __forceinline__ uint32_t ltex_rl_rep(uint32_t Lcap) { return Lcap <= 16 ? 8u : Lcap <= 32 ? 4u : Lcap <= 64 ? 2u : 1u; }
+__device__ __forceinline__ uint32_t ltex_rl_words(uint32_t Lcap) { return 4u * kLtexRlmLds * Lcap + Lcap; }
+__device__ __forceinline__ uint32_t ltex_rl_index(uint32_t Lcap, uint32_t dir, uint32_t m, uint32_t len) { return (dir * kLtexRlmLds + (len - 1u)) * Lcap + m; }
+// the replicas of a table summed into the global matrices (integers: any order)
+__device__ __forceinline__ void ltex_rl_flush(const uint32_t* s_short, uint32_t Lcap, uint32_t* gP, uint32_t slot_words, uint32_t Nr, int tid, int BS)
+{
+    const uint32_t rep = ltex_rl_rep(Lcap), words = ltex_rl_words(Lcap);
+    for (uint32_t i = (uint32_t)tid; i < 4u * kLtexRlmLds * Lcap; i += (uint32_t)BS) {
+        uint32_t cn = 0;
+        for (uint32_t r = 0; r < rep; r++) cn += s_short[r * words + i];
+        if (cn == 0) continue;
+        const uint32_t dl = i / Lcap, m = i - dl * Lcap, dir = dl / kLtexRlmLds, j = dl - dir * kLtexRlmLds;
+        if (j < Nr) atomicAdd(&gP[dir * slot_words + m * Nr + j], cn);
+    }
+}
+
+// in place: a zero level becomes 1 (matlab binning's background), four bytes / two half-words at a time
+template <bool P16>
+__device__ __forceinline__ uint32_t zero_to_one(uint32_t v)
+{
+    uint32_t m;
+    if (P16) { m = v | (v >> 8); m |= m >> 4; m |= m >> 2; m |= m >> 1; return v | (~m & 0x00010001u); }
+    m = v | (v >> 4); m |= m >> 2; m |= m >> 1;
+    return v | (~m & 0x01010101u);
+}
+
+__device__ __forceinline__ void lds_barrier()               // workgroup barrier that orders LDS only: loads from global memory stay in flight
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- strips: NGTDM + GLRLM; and the GLSZM owner sweep, one workgroup per ROI in front of them -------------------------------------
 template <bool P16>
-__global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint32_t n_sweep)
+__global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint32_t n_sweep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_res[2];
-    constexpr int BS = 256, NW = 4;
+    const int BS = (int)blockDim.x, NW = BS >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
@@ -243,71 +314,117 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
     if (blockIdx.x < n_sweep) {
         // =============================================================================================================
         // GLSZM owner sweep of member blockIdx.x: owner(p) = min(p, owner(W), owner(NW), owner(N), owner(NE)) over the predecessors of
-        // p's level (roi_texture.hip).  A cell travels as X = level << 20 | owner; the previous row's X sit in LDS between two border
-        // entries.  Wave 0 sweeps a batch of rows while waves 1-3 stage the next batch of the plane.
+        // p's level (roi_texture.hip).  A cell travels as X = level << 20 | owner; the X of the last two rows sit in LDS between
+        // border entries.  The chain over the rows runs as a pipeline of 64-column chunks that DRIFT one column to the left per row
+        // (chunk j of row r covers the columns 64 j - (r mod 64) + 0 .. 63; every 64 rows the drift starts over): then the three
+        // predecessors of a chunk's cells in the previous row lie in the same chunk and its left neighbour, and chunk j of row r can
+        // run at step r + floor(r / 64) + j -- one step per row and chunk diagonal instead of one per row and chunk (the start-over
+        // costs one idle step per 64 rows: the NE cell of the last lane then belongs to the right neighbour).
         // =============================================================================================================
         LtexRoi R;
         if (blockIdx.x >= A.n_list || !ltex_roi(A, blockIdx.x, R, true)) return;
+        if (R.vmin == R.vmax) return;                       // blank: no zones are asked for (glszm.cpp:61-65)
         const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
         uint32_t* const cnt = (uint32_t*)(R.base + R.L.cnt);
         const uint32_t w = R.w, h = R.h;
-        uint32_t* rowA = (uint32_t*)lds_raw;                                        // [w + 2]
-        uint32_t* rowB = rowA + (w + 2);
-        const uint32_t rb = [&] { uint32_t r = 4096u / (w * (uint32_t)sizeof(plane_t)); r = r ? r : 1u; return r < h ? r : h; }();   // rows per batch
-        plane_t* const buf0 = (plane_t*)(lds_raw + align16u(8u * (w + 2)));
-        plane_t* const buf1 = buf0 + ((rb * w + 15u) & ~15u);
-        for (uint32_t i = tid; i < 2 * (w + 2); i += BS) rowA[i] = kNone;
-        auto stage = [&](uint32_t b, plane_t* dst, int t0, int nt) {
-            const uint32_t r0 = b * rb, r1 = r0 + rb < h ? r0 + rb : h;
-            const plane_t* const src = plane + (uint64_t)r0 * w;
-            for (uint32_t i = (uint32_t)t0; i < (r1 - r0) * w; i += (uint32_t)nt) dst[i] = src[i];
+        const uint32_t nch = (w + 62u) / 64u + 1u;          // chunks 0 .. nch - 1 cover the columns -63 .. w - 1 at every drift
+        // Plane rows come through an LDS ring filled by the workgroup's LAST wave, which requests the rows eight rows ahead and does
+        // nothing else: the sweeping waves then have no loads from global memory in flight -- next to their zone-size atomics those
+        // made every wait a wait for everything (vmcnt counts both, out of order), one L2 round trip per step.
+        // (Rows beyond 1008 bytes -- one 16-byte load per lane at any misalignment -- are read directly: every wave sweeps.)
+        const uint32_t row_bytes = w * (uint32_t)sizeof(plane_t);
+        const bool piped = row_bytes <= 1008u && NW >= 2;
+        const int NWs = piped ? NW - 1 : NW;                // sweeping waves
+        constexpr uint32_t kSlot = 1040u, kAhead = 8u;
+        const uint32_t RR = kAhead + nch + 4u;              // ring slots (row r: slot r mod RR); slot RR: requests that carry no row
+        uint32_t* const rowbuf = (uint32_t*)lds_raw;                                // [2][w + 2]
+        uint32_t* const carry = rowbuf + 2 * (w + 2);                               // [2][nch + 1][2]: level and owner that enter chunk j from its left, by row parity
+        unsigned char* const ring = lds_raw + align16u(4u * (2u * (w + 2) + 4u * (nch + 1)));
+        for (uint32_t i = tid; i < 2 * (w + 2) + 4 * (nch + 1); i += (uint32_t)BS) rowbuf[i] = i < 2 * (w + 2) ? kNone : 0u;
+        auto row_mis = [=](uint32_t row) -> uint32_t { return (uint32_t)((uintptr_t)(plane + (uint64_t)row * w) & 15u); };
+        // the row whose chunk 0 runs at step tau, or kNone at the idle step that follows every 64 rows
+        auto row_at = [](uint32_t tau) -> uint32_t { const uint32_t q = tau / 65u, m = tau - q * 65u; return m == 64u ? kNone : q * 64u + m; };
+        // lane's 16 bytes of the row, from the 16-byte boundary below its first cell, straight into the row's ring slot (LDS-DMA: no
+        // register in between, so nothing makes the compiler wait; completion is counted by hand below).  Always one request per
+        // call -- a call without a row re-reads the last row into a slot of its own -- so that "at most kAhead requests outstanding"
+        // means "everything older has landed".
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        typedef const __attribute__((address_space(1))) void glb_void_t;
+        auto row_request = [=](uint32_t row) {
+            const uint32_t rr = row < h ? row : h - 1u, slot = row < h ? row % RR : RR;
+            const uint32_t mis = row_mis(rr);
+            if ((uint32_t)lane * 16u < mis + row_bytes)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)((const unsigned char*)(plane + (uint64_t)rr * w) - mis + (uint32_t)lane * 16u),
+                                                 (lds_void_t*)(ring + slot * kSlot), 16, 0, 0);
         };
-        const uint32_t nb = (h + rb - 1) / rb;
-        stage(0, buf0, tid, BS);
+        const bool loader = piped && wave == NW - 1;
+        if (loader) {
+            for (uint32_t tau = 0; tau <= kAhead; tau++) row_request(row_at(tau));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        for (uint32_t b = 0; b < nb; b++) {
-            plane_t* const cur = (b & 1u) ? buf1 : buf0;
-            plane_t* const nxt = (b & 1u) ? buf0 : buf1;
-            if (wave != 0) {
-                if (b + 1 < nb) stage(b + 1, nxt, tid - 64, BS - 64);
-            } else {
-                const uint32_t r0 = b * rb, r1 = r0 + rb < h ? r0 + rb : h;
-                for (uint32_t row = r0; row < r1; row++) {
-                    uint32_t carry_v = 0, carry_l = 0;
-                    const plane_t* const prow = cur + (row - r0) * w;
-                    for (uint32_t c0 = 0; c0 < w; c0 += 64) {
-                        const uint32_t c = c0 + (uint32_t)lane;
-                        const bool in = c < w;
-                        const uint32_t ci = in ? c : w - 1;
-                        const uint32_t raw = (uint32_t)prow[ci];
-                        const uint32_t v = in ? (raw > bgmin ? raw : bgmin) : 0u;
-                        const uint32_t p = row * w + c, V20 = v << 20;
-                        const uint32_t XW = rowA[ci], XN = rowA[ci + 1], XE = rowA[ci + 2];
-                        // (X' - V20 is the owner (< 2^20) when the predecessor has this level, something >= 2^20 otherwise)
-                        uint32_t lab = v != 0 ? min(min(p, XN - V20), min(XW - V20, XE - V20)) : p;
-                        // W chain: segmented prefix-min over runs of equal level; the run index travels in bits 20.. so a plain
-                        // prefix-min serves (roi_texture.hip)
-                        const uint32_t vl = lane_minus1(v, carry_v);
-                        const bool start = v == 0 || vl != v;
-                        if (lane == 0 && !start) lab = min(lab, carry_l);
-                        const unsigned long long smk = __builtin_amdgcn_ballot_w64(start);
-                        const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(smk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smk, 0u)) + (start ? 1u : 0u);
-                        lab = wave_scan_min_u32(((64u - ri) << 20) | lab) & kLenMask;
-                        const bool zp = in && v != 0;
-                        if (in) rowB[c + 1] = zp ? (V20 | lab) : kNone;
-                        // zone sizes: one atomic per string of equal owners in the chunk
-                        const uint32_t ln = lane_plus1(lab, kNone);
-                        const unsigned long long same = __builtin_amdgcn_ballot_w64(zp && c + 1u < w && lane < 63 && ln == lab);
-                        if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                            atomicAdd(&cnt[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
-                        carry_v = readlane63(v);
-                        carry_l = readlane63(lab);
-                    }
-                    wav_sync<false>();
-                    uint32_t* const t = rowA; rowA = rowB; rowB = t;
-                }
+        auto process = [&](uint32_t row, uint32_t j, uint32_t raw, int c) {
+            const bool in = (uint32_t)c < w;
+            const uint32_t ci = in ? (uint32_t)c : 0u;
+            const uint32_t* const prev = rowbuf + ((row + 1u) & 1u) * (w + 2);
+            uint32_t* const cur = rowbuf + (row & 1u) * (w + 2);
+            const uint32_t XW = prev[ci], XN = prev[ci + 1], XE = prev[ci + 2];
+            uint32_t* const cr = carry + (row & 1u) * 2u * (nch + 1);          // (chunk j - 1 of the NEXT row writes its hand-over in this very step)
+            const uint32_t carry_v = cr[2 * j], carry_l = cr[2 * j + 1];
+            const uint32_t v = in ? (raw > bgmin ? raw : bgmin) : 0u;
+            const uint32_t p = row * w + (uint32_t)c, V20 = v << 20;
+            // (X' - V20 is the owner (< 2^20) when the predecessor has this level, something >= 2^20 otherwise)
+            uint32_t lab = v != 0 ? min(min(p, XN - V20), min(XW - V20, XE - V20)) : p;
+            // W chain: segmented prefix-min over runs of equal level; the run index travels in bits 20.. so a plain prefix-min serves
+            const uint32_t vl = lane_minus1(v, carry_v);
+            const bool start = v == 0 || vl != v;
+            if (lane == 0 && !start) lab = min(lab, carry_l);
+            const unsigned long long smk = __builtin_amdgcn_ballot_w64(start);
+            const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(smk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smk, 0u)) + (start ? 1u : 0u);
+            lab = wave_scan_min_u32(((64u - ri) << 20) | (lab & kLenMask)) & kLenMask;
+            const bool zp = in && v != 0;
+            if (in) cur[ci + 1] = zp ? (V20 | lab) : kNone;
+            if (lane == 63) { cr[2 * (j + 1)] = v; cr[2 * (j + 1) + 1] = lab; }
+            // zone sizes: one atomic per string of equal owners in the chunk
+            const uint32_t ln = lane_plus1(lab, kNone);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(zp && (uint32_t)c + 1u < w && lane < 63 && ln == lab);
+            if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                atomicAdd(&cnt[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
+        };
+        const uint32_t n_steps = (h - 1u) + ((h - 1u) >> 6) + nch;
+        // Three loops, one per role, with the same number of barriers each.  (One loop with the roles as branches made the compiler
+        // merge their memory state: the loader then waited for every load it had in flight, the sweepers read the ring through
+        // flat loads and waited for their atomics at every step.)
+        if (loader) {
+            for (uint32_t t = 0; t < n_steps; t++) {
+                row_request(row_at(t + 1u + kAhead));       // the row that starts at step t + 1 must be in the ring after this step's barrier
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAhead) : "memory");
+                lds_barrier();
             }
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (piped) {
+            for (uint32_t t = 0; t < n_steps; t++) {
+                for (uint32_t j = (uint32_t)wave; j < nch; j += (uint32_t)NWs) {
+                    const uint32_t row = t >= j ? row_at(t - j) : kNone;
+                    if (row >= h) continue;                 // (kNone included)
+                    const int c = (int)(64u * j + (uint32_t)lane) - (int)(row & 63u);
+                    if ((int)(64u * j) - (int)(row & 63u) >= (int)w) continue;
+                    const plane_t* const rrow = (const plane_t*)(ring + (row % RR) * kSlot + row_mis(row));
+                    process(row, j, (uint32_t)rrow[(uint32_t)c < w ? (uint32_t)c : 0u], c);
+                }
+                lds_barrier();
+            }
+        } else {
+            for (uint32_t t = 0; t < n_steps; t++) {
+                for (uint32_t j = (uint32_t)wave; j < nch; j += (uint32_t)NWs) {
+                    const uint32_t row = t >= j ? row_at(t - j) : kNone;
+                    if (row >= h) continue;
+                    const int c = (int)(64u * j + (uint32_t)lane) - (int)(row & 63u);
+                    if ((int)(64u * j) - (int)(row & 63u) >= (int)w) continue;
+                    process(row, j, (uint32_t)plane[row * w + ((uint32_t)c < w ? (uint32_t)c : 0u)], c);
+                }
+                lds_barrier();
+            }
         }
         return;
     }
@@ -327,43 +444,46 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
     const uint32_t r0 = job.y * rows_full, r1 = r0 + rows_full < h ? r0 + rows_full : h;
     const uint32_t rows = r1 - r0;
     const uint32_t Lcap = R.ng;
-    // ---- LDS: level map | padded strip | NGTDM accumulators | short-run table
+    // staged rows [sa, sz): the strip with a row above and below where the box has them
+    const uint32_t sa = r0 ? r0 - 1u : 0u, sz = r1 + 1u < h ? r1 + 1u : h;
+    const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
+    const plane_t* const src = plane + (uint64_t)sa * w;
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);  // the block starts anywhere inside the plane: it is staged at the same misalignment
+    const uint32_t st_bytes = (sz - sa) * w * (uint32_t)sizeof(plane_t);
+    // ---- LDS: level map | strip | NGTDM accumulators | short-run table
     uint32_t o = 0;
     uint16_t* const s_lvlmap = (uint16_t*)(lds_raw + o); o = align16u(o + 2u * (Lcap + 2));
-    const uint32_t pitch = w + 2;
-    plane_t* const s_strip = (plane_t*)(lds_raw + o); o = align16u(o + (uint32_t)sizeof(plane_t) * (rows + 2) * pitch);
+    unsigned char* const s_stage = lds_raw + o; o = align16u(o + mis + st_bytes + 16u);
     const uint32_t ng1 = Lcap + 1;                          // NGTDM rows: up to Ng + 1 (IBSI: row = level, 0 .. max)
     const bool ngt_lds = do_ngt && ng1 <= 1024;
     const uint32_t ngt_rep = ltex_ngt_rep(ng1), ngt_stride = ltex_ngt_stride(ng1), ngt_words = ngt_stride / 4u;
     unsigned long long* const s_S = (unsigned long long*)(lds_raw + o); if (ngt_lds) o = align16u(o + ngt_rep * ngt_stride);
     uint32_t* const s_N = (uint32_t*)(s_S + ng1 + 2);
     const bool rlm_lds = do_rlm && Lcap <= 128;
-    uint32_t* const s_short = (uint32_t*)(lds_raw + o); if (rlm_lds) o = align16u(o + 16u * Lcap * kLtexRlmLds);   // [4][Lcap][kLtexRlmLds]
+    uint32_t* const s_short = (uint32_t*)(lds_raw + o); if (rlm_lds) o = align16u(o + 4u * ltex_rl_rep(Lcap) * ltex_rl_words(Lcap));
     if (o > A.lds_strip_bytes) {                            // (sized by the host from the class bounds: cannot happen)
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         return;
     }
-    ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res, tid);
-    // the strip with one row above and below and one column left and right; 0 = outside the box
-    const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
-    for (uint32_t i = tid; i < (rows + 2) * pitch; i += BS) s_strip[i] = 0;
-    if (ngt_lds) for (uint32_t i = tid; i < ngt_rep * ngt_words; i += BS) ((uint32_t*)s_S)[i] = 0;
-    if (rlm_lds) for (uint32_t i = tid; i < 4u * Lcap * kLtexRlmLds; i += BS) s_short[i] = 0;
-    __syncthreads();
     {
-        const int ra = (int)r0 - 1 < 0 ? 0 : (int)r0 - 1, rz = (int)r1 + 1 > (int)h ? (int)h : (int)r1 + 1;
-        for (int r = ra + wave; r < rz; r += NW) {
-            const plane_t* const src = plane + (uint64_t)r * w;
-            plane_t* const dst = s_strip + (uint32_t)(r - (int)r0 + 1) * pitch + 1;
-            for (uint32_t c = lane; c < w; c += 64) {
-                const uint32_t raw = (uint32_t)src[c];
-                dst[c] = (plane_t)(raw > bgmin ? raw : bgmin);
-            }
+        // the rows are one contiguous block of the plane: 16-byte loads (reads up to 15 bytes around it: inside the ROI's padded block)
+        const uint4* const src16 = (const uint4*)((const unsigned char*)src - mis);
+        uint4* const dst16 = (uint4*)s_stage;
+        const uint32_t nvec = (mis + st_bytes + 15u) / 16u;
+        for (uint32_t i = tid; i < nvec; i += (uint32_t)BS) {
+            uint4 q = src16[i];
+            if (bgmin) { q.x = zero_to_one<P16>(q.x); q.y = zero_to_one<P16>(q.y); q.z = zero_to_one<P16>(q.z); q.w = zero_to_one<P16>(q.w); }
+            dst16[i] = q;
         }
     }
+    ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res, tid);
+    if (ngt_lds) for (uint32_t i = tid; i < ngt_rep * ngt_words; i += (uint32_t)BS) ((uint32_t*)s_S)[i] = 0;
+    if (rlm_lds) for (uint32_t i = tid; i < ltex_rl_rep(Lcap) * ltex_rl_words(Lcap); i += (uint32_t)BS) s_short[i] = 0;
     __syncthreads();
     const int Ng = s_res[0], Nuniq = s_res[1];
-    auto cell = [=](uint32_t lr, int c) -> uint32_t { return (uint32_t)s_strip[lr * pitch + (uint32_t)(c + 1)]; };   // lr = row - r0 + 1; c in -1 .. w
+    const plane_t* const strip = (const plane_t*)(s_stage + mis);
+    // cell of box row r, column c; 0 outside the box (the callers test the column, a missing halo row is handled per row)
+    auto cell = [=](uint32_t r, uint32_t c) -> uint32_t { return (uint32_t)strip[(r - sa) * w + c]; };
 
     // ---- NGTDM (ngtdm.cpp:83-183): 62 centre columns per wave-chunk between two halo lanes; a level travels with a "present" flag in
     // bit 24, so one sum over the eight neighbours yields their level sum and their number (roi_texture.hip: ngtdm_rows)
@@ -371,39 +491,38 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
     unsigned long long* const g_S = (unsigned long long*)(R.base + R.L.ngt);
     uint32_t* const g_N = (uint32_t*)(g_S + R.ng + 2);
     if (do_ngt && NgT >= 2) {
-        const uint32_t lvl_max = Lcap;
-        const bool sum32 = ngt_lds && (unsigned long long)rows * w * 840ull * lvl_max < (1ull << 32);
+        const bool sum32 = ngt_lds && (unsigned long long)rows * w * 840ull * Lcap < (1ull << 32);
         const uint32_t rep_off = mul24((uint32_t)lane & (ngt_rep - 1u), ngt_words);
         uint32_t* const r_N = ngt_lds ? s_N + rep_off : g_N;
         unsigned long long* const r_S = ngt_lds ? s_S + (rep_off >> 1) : g_S;
         const uint32_t ncs = (w + 61u) / 62u;
         const uint32_t nrb = ncs >= (uint32_t)NW ? 1u : (uint32_t)NW / ncs;
         const uint32_t rows_blk = (rows + nrb - 1) / nrb;
-        for (uint32_t t = (uint32_t)wave; t < ncs * nrb; t += NW) {
+        for (uint32_t t = (uint32_t)wave; t < ncs * nrb; t += (uint32_t)NW) {
             const uint32_t cs = t % ncs, rbi = t / ncs;
-            const uint32_t la = 1u + rbi * rows_blk, lz = la + rows_blk < rows + 1u ? la + rows_blk : rows + 1u;   // local rows [la, lz)
+            const uint32_t ra = r0 + rbi * rows_blk, rz = ra + rows_blk < r1 ? ra + rows_blk : r1;
             const int c = (int)(cs * 62u) - 1 + lane;
-            const bool in_col = c >= -1 && c <= (int)w;
-            const bool centre = c >= 0 && c < (int)w && lane >= 1 && lane <= 62;
-            auto code_at = [&](uint32_t lr) -> uint32_t {
-                const uint32_t v = in_col ? cell(lr, c) : 0u;
+            const bool in_col = c >= 0 && c < (int)w;
+            const bool centre = in_col && lane >= 1 && lane <= 62;
+            auto code_at = [&](int r) -> uint32_t {
+                const uint32_t v = (in_col && r >= (int)sa && r < (int)sz) ? cell((uint32_t)r, (uint32_t)c) : 0u;
                 return v | (min(v, 1u) << 24);
             };
-            if (la >= lz) continue;
-            uint32_t prv = code_at(la - 1), cur = code_at(la);
-            for (uint32_t lr = la; lr < lz; lr++) {
-                const uint32_t nxt = code_at(lr + 1);
+            if (ra >= rz) continue;
+            uint32_t prv = code_at((int)ra - 1), cur = code_at((int)ra);
+            for (uint32_t r = ra; r < rz; r++) {
+                const uint32_t nxt = code_at((int)r + 1);
                 const uint32_t col3 = prv + cur + nxt;
                 const uint32_t tot = lane_minus1(col3, 0u) + lane_plus1(col3, 0u) + (prv + nxt);
                 if (centre && cur != 0 && tot >= (1u << 24)) {
                     const uint32_t lvl = cur & 0xFFFFFFu, sum = tot & 0xFFFFFFu, nd = tot >> 24;
-                    const uint32_t r = greyInfo == 0 ? lvl : (uint32_t)s_lvlmap[lvl] - 1u;
+                    const uint32_t rr = greyInfo == 0 ? lvl : (uint32_t)s_lvlmap[lvl] - 1u;
                     const uint32_t q = (uint32_t)(840.0f * __builtin_amdgcn_rcpf((float)nd) + 0.5f);   // 840 / nd, exact: 840 = lcm(1 .. 8)
                     const uint32_t a = mul24(lvl, 840u), b2 = mul24(sum, q);
                     const uint32_t d = a > b2 ? a - b2 : b2 - a;                    // |840 i - sum * (840 / nd)|
-                    atomicAdd(&r_N[r], 1u);
-                    if (sum32) atomicAdd((uint32_t*)&r_S[r], d);
-                    else atomicAdd(&r_S[r], (unsigned long long)d);
+                    atomicAdd(&r_N[rr], 1u);
+                    if (sum32) atomicAdd((uint32_t*)&r_S[rr], d);
+                    else atomicAdd(&r_S[rr], (unsigned long long)d);
                 }
                 prv = cur; cur = nxt;
             }
@@ -415,9 +534,10 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
         const uint32_t Nr = R.side;
         uint32_t* const gP = (uint32_t*)(R.base + R.L.rlm);
         const uint32_t slot_words = R.L.slot_words;
+        uint32_t* const my_short = s_short + ((uint32_t)lane & (ltex_rl_rep(Lcap) - 1u)) * ltex_rl_words(Lcap);
         auto count_run = [&](uint32_t dir, uint32_t v, uint32_t len) {
             const uint32_t m = (uint32_t)s_lvlmap[v] - 1u;
-            if (rlm_lds && len <= kLtexRlmLds) atomicAdd(&s_short[(dir * Lcap + m) * kLtexRlmLds + (len - 1u)], 1u);
+            if (rlm_lds && len <= kLtexRlmLds) atomicAdd(&my_short[ltex_rl_index(Lcap, dir, m, len)], 1u);
             else atomicAdd(&gP[dir * slot_words + m * Nr + (len - 1u)], 1u);
         };
         // records of this strip: [K][2][3][w], level << 20 | length; 0 = none (the workspace was zeroed)
@@ -427,15 +547,15 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
         const uint32_t nl_diag = w + rows - 1u;
         const uint32_t ch_s = (w + 63u) / 64u, ch_d = (nl_diag + 63u) / 64u;
         const uint32_t n_tasks = rows + ch_s + 2u * ch_d;
-        for (uint32_t t = (uint32_t)wave; t < n_tasks; t += NW) {
+        for (uint32_t t = (uint32_t)wave; t < n_tasks; t += (uint32_t)NW) {
             if (t < rows) {
                 // 0 degrees, one row: a run starts where a cell differs from its left neighbour; a start lane reads its run's length off
                 // the ballot of starts; the run that is open at the end of a chunk is carried (wave-uniform) into the next one
-                const uint32_t lr = t + 1u;
+                const uint32_t r = r0 + t;
                 uint32_t cv = 0, cl = 0, last_v = 0;
                 for (uint32_t c0 = 0; c0 < w; c0 += 64) {
                     const uint32_t c = c0 + (uint32_t)lane;
-                    const uint32_t v = c < w ? cell(lr, (int)c) : 0u;
+                    const uint32_t v = c < w ? cell(r, c) : 0u;
                     const uint32_t prev = lane_minus1(v, last_v);
                     const bool start = v != prev || c == 0;
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(start);
@@ -469,7 +589,7 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
                 bool top = false;
                 int c = c_top;
                 for (uint32_t tt = 0; tt < rows; tt++, c += dx) {
-                    const uint32_t v = (uint32_t)c < w ? cell(tt + 1u, c) : 0u;
+                    const uint32_t v = (uint32_t)c < w ? cell(r0 + tt, (uint32_t)c) : 0u;
                     if (v == rv) { rl += v != 0 ? 1u : 0u; continue; }
                     if (rv != 0) {
                         if (top) rec_top[(dir - 1u) * w + (uint32_t)c_top] = (rv << 20) | rl;
@@ -493,21 +613,17 @@ __global__ __launch_bounds__(256) void ltex_strip_kernel(const LtexArgs A, uint3
             if (sN) { atomicAdd(&g_N[i], sN); atomicAdd(&g_S[i], sS); }
         }
     }
-    if (rlm_lds) {
-        const uint32_t Nr = R.side;
-        uint32_t* const gP = (uint32_t*)(R.base + R.L.rlm);
-        for (uint32_t i = tid; i < 4u * Lcap * kLtexRlmLds; i += BS) {
-            const uint32_t cn = s_short[i];
-            if (cn == 0) continue;
-            const uint32_t dir = i / (Lcap * kLtexRlmLds), rem = i - dir * (Lcap * kLtexRlmLds), m = rem / kLtexRlmLds, j = rem - m * kLtexRlmLds;
-            if (j < Nr) atomicAdd(&gP[dir * R.L.slot_words + m * Nr + j], cn);
-        }
-    }
+    if (rlm_lds) ltex_rl_flush(s_short, Lcap, (uint32_t*)(R.base + R.L.rlm), R.L.slot_words, R.side, tid, BS);
 }
 
-// ---- zones: one workgroup per strip --------------------------------------------------------------------------------------------
+// ---- after the strips: one workgroup per strip ------------------------------------------------------------------------------------
+// GLRLM: the recorded runs are pieces of runs that cross strips.  A piece is a HEAD when nothing of its level ends above it on its line
+// -- every bottom record (its run started inside the strip), and a top record whose predecessor cell holds another level or lies
+// outside the box.  The thread that finds a head follows its continuation down the strips (top records of its level that span their
+// strip, then one that does not) and counts the run once.
+// GLSZM: zones -> (level, size) multiplicities (direct table for sizes <= 32, a list for the few larger ones), zones, largest zone.
 template <bool P16>
-__global__ __launch_bounds__(256) void ltex_zone_kernel(const LtexArgs A)
+__global__ __launch_bounds__(256) void ltex_post_kernel(const LtexArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_res[2];
@@ -517,51 +633,118 @@ __global__ __launch_bounds__(256) void ltex_zone_kernel(const LtexArgs A)
     const uint2 job = A.map_strip[blockIdx.x];
     LtexRoi R;
     if (!ltex_roi(A, job.x, R, true)) return;
-    if (R.vmin == R.vmax) return;                           // blank: no zones are asked for (glszm.cpp:61-65)
+    if (R.vmin == R.vmax) return;                           // blank: neither runs nor zones are asked for (glrlm.cpp:29-52, glszm.cpp:61-65)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
     const uint32_t bgmin = greyInfo > 0 ? 1u : 0u;
-    const uint32_t Lcap = R.ng, S = R.L.S;
+    const uint32_t Lcap = R.ng, S = R.L.S, w = R.w, h = R.h, K = R.L.K, rows_full = R.L.rows;
+    const bool do_rlm = (A.mask & NYXHIP_FAM_GLRLM) != 0, do_szm = (A.mask & NYXHIP_FAM_GLSZM) != 0;
     uint32_t o = 0;
     uint16_t* const s_lvlmap = (uint16_t*)(lds_raw + o); o = align16u(o + 2u * (Lcap + 2));
-    uint32_t* const s_small = (uint32_t*)(lds_raw + o);
+    uint32_t* const s_small = (uint32_t*)(lds_raw + o); if (do_szm) o = align16u(o + 4u * Lcap * S);
+    const bool rlm_lds = do_rlm && Lcap <= 128;
+    uint32_t* const s_short = (uint32_t*)(lds_raw + o);
     ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res, tid);
-    for (uint32_t i = tid; i < Lcap * S; i += BS) s_small[i] = 0;
+    if (do_szm) for (uint32_t i = tid; i < Lcap * S; i += BS) s_small[i] = 0;
+    if (rlm_lds) for (uint32_t i = tid; i < ltex_rl_rep(Lcap) * ltex_rl_words(Lcap); i += BS) s_short[i] = 0;
     __syncthreads();
-    const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
-    uint32_t* const cnt = (uint32_t*)(R.base + R.L.cnt);
-    uint32_t* const hdr = (uint32_t*)R.base;
-    uint32_t* const big = (uint32_t*)(R.base + R.L.big);
-    const uint32_t p0 = job.y * R.L.rows * R.w, p1 = min(p0 + R.L.rows * R.w, R.area);
-    uint32_t nzone = 0, sz_max = 0;
-    for (uint32_t p = p0 + (uint32_t)tid; p < p1; p += BS) {
-        const uint32_t sz = cnt[p];
-        if (sz == 0) continue;
-        cnt[p] = 0;                                         // (the table serves as "zones per size" in the finishing kernel)
-        nzone++;
-        sz_max = sz > sz_max ? sz : sz_max;
-        const uint32_t raw = (uint32_t)plane[p];
-        const uint32_t rowi = (uint32_t)s_lvlmap[raw > bgmin ? raw : bgmin] - 1u;
-        if (sz <= S) atomicAdd(&s_small[rowi * kLtexSmall + (sz - 1u)], 1u);
-        else {
-            const uint32_t slot = atomicAdd(&hdr[LTEX_H_NBIG], 1u);
-            if (slot < R.L.big_cap) big[slot] = (rowi << 20) | sz;
+
+    if (do_rlm && s_res[0] >= 1) {
+        const uint32_t Nr = R.side, slot_words = R.L.slot_words;
+        uint32_t* const gP = (uint32_t*)(R.base + R.L.rlm);
+        const uint32_t* const rec = (const uint32_t*)(R.base + R.L.rec);
+        const uint32_t k = job.y;
+        auto rows_of = [=](uint32_t kk) { return min(rows_full, h - kk * rows_full); };
+        auto top_of = [=](uint32_t kk, uint32_t dir, uint32_t c) { return rec[((uint64_t)kk * 6u + (dir - 1u)) * w + c]; };
+        auto bot_of = [=](uint32_t kk, uint32_t dir, uint32_t c) { return rec[((uint64_t)kk * 6u + 3u + (dir - 1u)) * w + c]; };
+        uint32_t* const my_short = s_short + ((uint32_t)lane & (ltex_rl_rep(Lcap) - 1u)) * ltex_rl_words(Lcap);
+        auto count_rec = [&](uint32_t dir, uint32_t lvl, uint32_t len) {
+            const uint32_t m = (uint32_t)s_lvlmap[lvl] - 1u;
+            if (rlm_lds && len <= kLtexRlmLds) atomicAdd(&my_short[ltex_rl_index(Lcap, dir, m, len)], 1u);
+            else atomicAdd(&gP[dir * slot_words + m * Nr + (len - 1u)], 1u);
+        };
+        // the run (level lvl, len pixels so far) is alive in the last row of strip kk at column cb: follow it down
+        auto follow = [&](uint32_t dir, int dx, uint32_t lvl, uint32_t len, uint32_t kk, uint32_t cb) {
+            while (kk + 1u < K) {
+                const int nc = (int)cb + dx;
+                if ((uint32_t)nc >= w) break;
+                const uint32_t T = top_of(kk + 1u, dir, (uint32_t)nc);
+                if (T == 0 || (T >> 20) != lvl) break;
+                len += T & kLenMask;
+                const uint32_t rk = rows_of(kk + 1u);
+                if ((T & kLenMask) != rk) break;             // it ends inside that strip
+                kk++; cb = (uint32_t)(nc + dx * ((int)rk - 1));
+            }
+            count_rec(dir, lvl, len);
+        };
+        const uint32_t rows_k = rows_of(k);
+        for (uint32_t i = tid; i < 3u * w; i += BS) {
+            const uint32_t dir = 1u + i / w, c = i - (dir - 1u) * w;
+            const int dx = dir == 1u ? 1 : dir == 2u ? 0 : -1;
+            const uint32_t B = bot_of(k, dir, c);
+            if (B != 0) follow(dir, dx, B >> 20, B & kLenMask, k, c);
+            const uint32_t T = top_of(k, dir, c);
+            if (T == 0) continue;
+            bool head = true;
+            const int pc = (int)c - dx;
+            if (k > 0 && (uint32_t)pc < w) {                 // the run that is alive in the cell above on the line, if any
+                uint32_t P = bot_of(k - 1u, dir, (uint32_t)pc);
+                if (P == 0) {
+                    const uint32_t rp = rows_of(k - 1u);
+                    const int ct = pc - dx * ((int)rp - 1);
+                    if ((uint32_t)ct < w) {
+                        const uint32_t Tp = top_of(k - 1u, dir, (uint32_t)ct);
+                        if (Tp != 0 && (Tp & kLenMask) == rp) P = Tp;
+                    }
+                }
+                if (P != 0 && (P >> 20) == (T >> 20)) head = false;
+            }
+            if (!head) continue;
+            if ((T & kLenMask) == rows_k) follow(dir, dx, T >> 20, rows_k, k, (uint32_t)((int)c + dx * ((int)rows_k - 1)));
+            else count_rec(dir, T >> 20, T & kLenMask);
+        }
+        if (rlm_lds) {
+            __syncthreads();
+            ltex_rl_flush(s_short, Lcap, gP, slot_words, Nr, tid, BS);
         }
     }
-    nzone = wave_sum_t<uint32_t>(nzone);
-    sz_max = wave_max_u32(sz_max);
-    if (lane == 0) { s_nz[wave] = nzone; s_mx[wave] = sz_max; }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t nz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
-        const uint32_t mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
-        if (nz) { atomicAdd(&hdr[LTEX_H_NZONE], nz); atomicMax(&hdr[LTEX_H_SZMAX], mx); }
-    }
-    uint32_t* const g_small = (uint32_t*)(R.base + R.L.small);
-    for (uint32_t i = tid; i < Lcap * S; i += BS) {
-        const uint32_t v = s_small[i];
-        if (v) atomicAdd(&g_small[i], v);
+
+    if (do_szm) {
+        const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
+        uint32_t* const cnt = (uint32_t*)(R.base + R.L.cnt);
+        uint32_t* const hdr = (uint32_t*)R.base;
+        uint32_t* const big = (uint32_t*)(R.base + R.L.big);
+        const uint32_t p0 = job.y * rows_full * w, p1 = min(p0 + rows_full * w, R.area);
+        uint32_t nzone = 0, sz_max = 0;
+        for (uint32_t p = p0 + (uint32_t)tid; p < p1; p += BS) {
+            const uint32_t sz = cnt[p];
+            if (sz == 0) continue;
+            cnt[p] = 0;                                     // (the table serves as "zones per size" in the finishing kernel)
+            nzone++;
+            sz_max = sz > sz_max ? sz : sz_max;
+            const uint32_t raw = (uint32_t)plane[p];
+            const uint32_t rowi = (uint32_t)s_lvlmap[raw > bgmin ? raw : bgmin] - 1u;
+            if (sz <= S) atomicAdd(&s_small[rowi * kLtexSmall + (sz - 1u)], 1u);
+            else {
+                const uint32_t slot = atomicAdd(&hdr[LTEX_H_NBIG], 1u);
+                if (slot < R.L.big_cap) big[slot] = (rowi << 20) | sz;
+            }
+        }
+        nzone = wave_sum_t<uint32_t>(nzone);
+        sz_max = wave_max_u32(sz_max);
+        if (lane == 0) { s_nz[wave] = nzone; s_mx[wave] = sz_max; }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t nz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+            const uint32_t mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+            if (nz) { atomicAdd(&hdr[LTEX_H_NZONE], nz); atomicMax(&hdr[LTEX_H_SZMAX], mx); }
+        }
+        uint32_t* const g_small = (uint32_t*)(R.base + R.L.small);
+        for (uint32_t i = tid; i < Lcap * S; i += BS) {
+            const uint32_t v = s_small[i];
+            if (v) atomicAdd(&g_small[i], v);
+        }
     }
 }
 
@@ -588,7 +771,7 @@ __global__ __launch_bounds__(256) void ltex_finish_kernel(const LtexArgs A)
     }
     const bool do_rlm = (A.mask & NYXHIP_FAM_GLRLM) != 0, do_szm = (A.mask & NYXHIP_FAM_GLSZM) != 0, do_ngt = (A.mask & NYXHIP_FAM_NGTDM) != 0;
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
-    const uint32_t w = R.w, h = R.h, area = R.area, Lcap = R.ng;
+    const uint32_t area = R.area, Lcap = R.ng;
     const uint32_t* const hdr = (const uint32_t*)R.base;
     // ---- LDS: output row | level map | levels | level squares | a region the families use one after the other
     uint32_t o = 0;
@@ -614,7 +797,7 @@ __global__ __launch_bounds__(256) void ltex_finish_kernel(const LtexArgs A)
     int col = 0;
 
     // =====================================================================================
-    // GLRLM: join the recorded runs, then the features of the four matrices (a wave each)
+    // GLRLM: the features of the four matrices (a wave each)
     // =====================================================================================
     if (do_rlm) {
         double* const oo = s_out + col;
@@ -626,48 +809,6 @@ __global__ __launch_bounds__(256) void ltex_finish_kernel(const LtexArgs A)
         } else if (Ng < 1) {
             for (int c = tid; c < 80; c += BS) oo[c] = 0.0;
         } else {
-            const uint32_t* const rec = (const uint32_t*)(R.base + R.L.rec);
-            uint32_t* carry = (uint32_t*)s_work;             // [w] run that ends in the previous strip's last row at this column
-            uint32_t* fresh = carry + w;
-            auto count_rec = [&](uint32_t dir, uint32_t x) {
-                atomicAdd(&gP[dir * slot_words + ((uint32_t)s_lvlmap[x >> 20] - 1u) * Nr + ((x & kLenMask) - 1u)], 1u);
-            };
-            for (uint32_t dir = 1; dir <= 3; dir++) {
-                const int dx = dir == 1 ? 1 : dir == 2 ? 0 : -1;
-                for (uint32_t c = tid; c < 2 * w; c += BS) ((uint32_t*)s_work)[c] = 0;
-                __syncthreads();
-                for (uint32_t k = 0; k < R.L.K; k++) {
-                    const uint32_t rows_k = min(R.L.rows, h - k * R.L.rows);
-                    const uint32_t* const top = rec + (uint64_t)k * 6u * w + (dir - 1u) * w;
-                    const uint32_t* const bot = top + 3u * w;
-                    for (uint32_t c = tid; c < w; c += BS) {
-                        const uint32_t T = top[c];
-                        const int pc = (int)c - dx;
-                        const uint32_t prev = (uint32_t)pc < w ? carry[pc] : 0u;
-                        const bool joined = T != 0 && prev != 0 && (T >> 20) == (prev >> 20);
-                        if (prev != 0 && !joined) count_rec(dir, prev);
-                        if (T != 0) {
-                            const uint32_t x = T + (joined ? (prev & kLenMask) : 0u);
-                            if ((T & kLenMask) == rows_k) fresh[(uint32_t)((int)c + dx * ((int)rows_k - 1))] = x;   // spans the strip: still open
-                            else count_rec(dir, x);
-                        }
-                        const uint32_t B = bot[c];
-                        if (B != 0) fresh[c] = B;
-                    }
-                    if (dx != 0 && tid == 0) {               // the run whose line leaves the box through its side
-                        const uint32_t x = carry[dx == 1 ? w - 1u : 0u];
-                        if (x != 0) count_rec(dir, x);
-                    }
-                    __syncthreads();
-                    { uint32_t* const t = carry; carry = fresh; fresh = t; }
-                    for (uint32_t c = tid; c < w; c += BS) fresh[c] = 0;
-                    __syncthreads();
-                }
-                for (uint32_t c = tid; c < w; c += BS)
-                    if (carry[c] != 0) count_rec(dir, carry[c]);
-                __syncthreads();
-            }
-            blk_sync<true>();
             // the matrices from LDS when the four fit the work region, else in place
             const uint32_t Np = hdr[LTEX_H_NP_ORIG];
             if (16ull * slot_words <= work_bytes) {
@@ -950,8 +1091,9 @@ int launch_large_texture(const LtexArgs& a, void* stream)
     static DeviceOnce optin;
     if (int orc = optin.run([]() -> int {
             const struct { const void* f; int bytes; } k[] = {
+                {(const void*)ltex_load_kernel<false>, 64 * 1024}, {(const void*)ltex_load_kernel<true>, 64 * 1024},
                 {(const void*)ltex_strip_kernel<false>, 144 * 1024}, {(const void*)ltex_strip_kernel<true>, 144 * 1024},
-                {(const void*)ltex_zone_kernel<false>, 64 * 1024}, {(const void*)ltex_zone_kernel<true>, 64 * 1024},
+                {(const void*)ltex_post_kernel<false>, 96 * 1024}, {(const void*)ltex_post_kernel<true>, 96 * 1024},
                 {(const void*)ltex_finish_kernel, 144 * 1024}};
             for (const auto& e : k)
                 if (hipError_t rc = hipFuncSetAttribute(e.f, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes); rc != hipSuccess) return (int)rc;
@@ -959,18 +1101,18 @@ int launch_large_texture(const LtexArgs& a, void* stream)
         }))
         return orc;
     hipLaunchKernelGGL(ltex_prep_kernel, dim3((a.n_list + 255) / 256), dim3(256), 0, st, a);
-    if (a.plane16) hipLaunchKernelGGL(ltex_load_kernel<true>, dim3(a.cap_load), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(ltex_load_kernel<false>, dim3(a.cap_load), dim3(256), 0, st, a);
+    if (a.plane16) hipLaunchKernelGGL(ltex_load_kernel<true>, dim3(a.cap_load), dim3(256), a.lds_load_bytes, st, a);
+    else hipLaunchKernelGGL(ltex_load_kernel<false>, dim3(a.cap_load), dim3(256), a.lds_load_bytes, st, a);
     const uint32_t n_sweep = (a.mask & NYXHIP_FAM_GLSZM) ? a.n_list : 0u;
     const bool strips = (a.mask & (NYXHIP_FAM_GLRLM | NYXHIP_FAM_NGTDM)) != 0;
     const uint32_t grid = n_sweep + (strips ? a.cap_strip : 0u);
     if (grid) {
-        if (a.plane16) hipLaunchKernelGGL(ltex_strip_kernel<true>, dim3(grid), dim3(256), a.lds_strip_bytes, st, a, n_sweep);
-        else hipLaunchKernelGGL(ltex_strip_kernel<false>, dim3(grid), dim3(256), a.lds_strip_bytes, st, a, n_sweep);
+        if (a.plane16) hipLaunchKernelGGL(ltex_strip_kernel<true>, dim3(grid), dim3(a.strip_threads), a.lds_strip_bytes, st, a, n_sweep);
+        else hipLaunchKernelGGL(ltex_strip_kernel<false>, dim3(grid), dim3(a.strip_threads), a.lds_strip_bytes, st, a, n_sweep);
     }
-    if (a.mask & NYXHIP_FAM_GLSZM) {
-        if (a.plane16) hipLaunchKernelGGL(ltex_zone_kernel<true>, dim3(a.cap_strip), dim3(256), a.lds_zone_bytes, st, a);
-        else hipLaunchKernelGGL(ltex_zone_kernel<false>, dim3(a.cap_strip), dim3(256), a.lds_zone_bytes, st, a);
+    if (a.mask & (NYXHIP_FAM_GLSZM | NYXHIP_FAM_GLRLM)) {
+        if (a.plane16) hipLaunchKernelGGL(ltex_post_kernel<true>, dim3(a.cap_strip), dim3(256), a.lds_zone_bytes, st, a);
+        else hipLaunchKernelGGL(ltex_post_kernel<false>, dim3(a.cap_strip), dim3(256), a.lds_zone_bytes, st, a);
     }
     hipLaunchKernelGGL(ltex_finish_kernel, dim3(a.n_list), dim3(256), a.lds_fin_bytes, st, a);
     return (int)hipGetLastError();
