@@ -101,7 +101,7 @@ struct nyxhip_ctx {
     // by a few hundred workgroups at most -- a fraction of the chip.  Each large class runs them on a stream of its own beside the
     // main stream (which goes on with the several-workgroups-per-ROI kernels and the LDS classes), with scratch of its own; the
     // lanes are forked from the main stream at the start of a call and joined into it at its end.
-    static constexpr int kLanes = 4;
+    static constexpr int kLanes = 8;               // 0-3: the large classes; 4-6: the LDS size classes of an exact call (run_class)
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t lane_done[kLanes] = {};
     hipEvent_t lane_fork = nullptr;
@@ -1317,6 +1317,26 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
 
     hipStream_t st = ctx->stream();
     int rc = 0;
+    auto enter_lane = [&](int lane) -> int {             // the class's launches go to lane `lane`, forked from the main stream at the start of the call
+        if (!ctx->lane_stream[lane]) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+        }
+        if (!ctx->lane_used[lane]) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork, 0));   // the batch and the class lists are complete on the main stream
+            ctx->lane_used[lane] = true;
+        }
+        st = ctx->lane_stream[lane];
+        return NYXHIP_OK;
+    };
+    // The launch groups of the LDS size classes are independent of each other and could each take a stream of their own (the tail of
+    // one class's grid beside the next class's launches).  Measured on the mixed batch with the config-4 families: 3.51 ms against
+    // 3.28 ms on one stream -- the chip is busy either way, and the interleaved classes evict each other's L2 lines.  Off unless asked
+    // for (NYXHIP_LDS_LANES=1, A/B knob).
+    static const bool lds_lanes = [] { const char* e = getenv("NYXHIP_LDS_LANES"); return e && *e && *e != '0'; }();
+    const bool on_lds_lane = lds && !gs && lds_lanes && list && cls >= 0 && cls / 2 < kFirstLargeSizeClass && !ctx->win_next.inten;
+    if (on_lds_lane)
+        if (int lrc = enter_lane(4 + cls / 2)) return lrc;
     if (lds) {
         for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
@@ -1380,8 +1400,13 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
-    if (!gs)
+    if (!gs) {
+        if (on_lds_lane && report && ctx->timing) {
+            HIP_TRY(ctx, hipEventCreate(&report->e2));
+            HIP_TRY(ctx, hipEventRecord(report->e2, st));
+        }
         return NYXHIP_OK;
+    }
 
     // ---- INTENSITY + GLCM of the class by several workgroups per ROI (every member whose intensity range the histogram holds) ------
     static const bool no_coop = [] { const char* e = getenv("NYXHIP_NO_COOP"); return e && *e && *e != '0'; }();   // A/B knob: the one-workgroup path
@@ -1396,18 +1421,9 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
 
     // the lane of this class (nyxhip_ctx::lane_stream): large classes only -- the workspace fallback of an LDS class stays on the main stream
     static const bool no_lanes = [] { const char* e = getenv("NYXHIP_NO_LANES"); return e && *e && *e != '0'; }();   // A/B knob
-    const int lane = (!no_lanes && cls / 2 >= kFirstLargeSizeClass) ? (cls - 2 * kFirstLargeSizeClass) % nyxhip_ctx::kLanes : -1;
-    if (lane >= 0) {
-        if (!ctx->lane_stream[lane]) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
-        }
-        if (!ctx->lane_used[lane]) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork, 0));   // the batch and the class lists are complete on the main stream
-            ctx->lane_used[lane] = true;
-        }
-        st = ctx->lane_stream[lane];
-    }
+    const int lane = (!no_lanes && cls / 2 >= kFirstLargeSizeClass) ? (cls - 2 * kFirstLargeSizeClass) % 4 : -1;
+    if (lane >= 0)
+        if (int lrc2 = enter_lane(lane)) return lrc2;
     auto lane_stamp = [&]() -> int {
         if (lane >= 0 && report && ctx->timing) {
             HIP_TRY(ctx, hipEventCreate(&report->e2));
