@@ -480,8 +480,42 @@ def main():
                              f"with {thr} threads, reduce stage only ({sec:.2f} s)" if kind == "reference"
                              else f"single-threaded C restatement ({sec:.2f} s)"),
                 "host_cpus": cores}
+        def cpu_leg(hb_, msk, st, what, budget_rois):
+            """north_star: every ROIs/s figure "next to Nyxus's own multithreaded CPU path".  The reference's classes (oracle/_ref, its
+            runParallel ladder over all host cores) -- or, where that library is absent, the single-threaded C restatement -- on the
+            first `budget_rois` ROIs of the leg's own batch."""
+            if a.no_cpu_baseline:
+                return None
+            from oracle import pyoracle as po
+            cores_ = os.cpu_count() or 1
+            kind_ = "reference" if po.have_ref() else "port"
+            thr_ = cores_ if kind_ == "reference" else 1
+            k_ = int(min(hb_.n_roi, budget_rois if kind_ == "reference" else max(64, budget_rois // 64)))
+            sub = _abi.HostBatch(hb_.roi_label[:k_], hb_.px_offset[:k_ + 1], hb_.x[:int(hb_.px_offset[k_])], hb_.y[:int(hb_.px_offset[k_])],
+                                 hb_.inten[:int(hb_.px_offset[k_])], hb_.bbox_w[:k_], hb_.bbox_h[:k_], hb_.min_inten[:k_], hb_.max_inten[:k_])
+            try:
+                if kind_ == "reference":
+                    tm_ = []
+                    po.ref_featurize(sub, msk, st, n_threads=thr_, timing=tm_)
+                    sec_ = tm_[0]
+                else:
+                    c0_ = time.perf_counter()
+                    po.oracle_featurize(sub, msk, st)
+                    sec_ = time.perf_counter() - c0_
+            except Exception as ec:
+                return {"error": repr(ec)}
+            return {"value": k_ / sec_, "unit": "ROIs/s", "cores": thr_, "kind": kind_, "host_cpus": cores_,
+                    "sample": f"the first {k_} ROIs of this leg's batch, {what}, reduce stage only ({sec_:.2f} s)"}
         # ---- informational legs on the same resident batch: the reference's DEFAULT grey depth, BASELINE.json configs[3] and [4] ----
         if world == 1 and not a.no_extras and mask == 3:
+            cpu_rows = min(n_roi, rois_per_tile * max(2, min(a.tiles, os.cpu_count() or 1)))     # a tile per host thread
+            hb_cpu = None
+            if not a.no_cpu_baseline:                  # (the first ROIs of the batch are one contiguous slice of every array)
+                kq = cpu_rows
+                hb_cpu = _abi.HostBatch(labels[:kq].cpu().numpy().astype(np.uint32), off[:kq + 1].cpu().numpy().astype(np.uint64),
+                                        x[:kq * n_px_roi].cpu().numpy().view(np.uint16), y[:kq * n_px_roi].cpu().numpy().view(np.uint16),
+                                        inten[:kq * n_px_roi].cpu().numpy().view(np.uint32), bw[:kq].cpu().numpy().view(np.uint32),
+                                        bh[:kq].cpu().numpy().view(np.uint32), mn[:kq].cpu().numpy().view(np.uint32), mx[:kq].cpu().numpy().view(np.uint32))
             def timed(msk, st, cbatch, n_rows, reps=3, check_rows=None, arrays=None, all_rows=False):
                 """One leg: warm-up call, `reps` timed calls; the parity gate (rows `check_rows` of the table vs the oracle) on what it left."""
                 nc = ctx.n_columns(msk, st)
@@ -516,6 +550,8 @@ def main():
                               "roofline": {"bound": "hbm", "achieved": b2 / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / dt2 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b2},
                               "what": "BASELINE.json configs[1]: *ALL_INTENSITY* alone (36 columns, 64 histogram bins = the default coarse_gray_depth) on the same 1000 tiles"}
+            if hb_cpu is not None:
+                rec["config2"]["cpu_baseline"] = cpu_leg(hb_cpu, _abi.FAM_INTENSITY, s64, "PixelIntensityFeatures::reduce via runParallel", cpu_rows)
             dt3, nc3, par3 = timed(_abi.FAM_GLCM, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays)
             mg3 = timed.margin
             b3 = n_px * 8 + n_roi * nc3 * 8
@@ -523,10 +559,14 @@ def main():
                               "roofline": {"bound": "hbm", "achieved": b3 / dt3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b3 / dt3 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b3},
                               "what": "BASELINE.json configs[2]: *ALL_GLCM* alone (8 grey levels, 4 angles, d = 1; 149 columns) on the same 1000 tiles"}
+            if hb_cpu is not None:
+                rec["config3"]["cpu_baseline"] = cpu_leg(hb_cpu, _abi.FAM_GLCM, s, "GLCMFeature::parallel_process_1_batch via runParallel", cpu_rows)
             dt64, _, par64 = timed(mask, s64, cb, n_roi, check_rows=last_tile, arrays=dev_arrays, all_rows=True)
             mg64 = timed.margin
             rec["gray_depth_64"] = {"value": n_roi / dt64, "unit": "ROIs/s", "ms_per_step": 1e3 * dt64, "parity_check": par64, "max_rel_err": mg64,
                                     "what": "the metric workload at the reference's default coarse_gray_depth=64 (64 x 64 co-occurrence matrices, 64 histogram bins)"}
+            if hb_cpu is not None:
+                rec["gray_depth_64"]["cpu_baseline"] = cpu_leg(hb_cpu, mask, s64, "intensity + GLCM at grey depth 64 via runParallel", cpu_rows)
             m4 = _abi.FAM_INTENSITY | _abi.FAM_GLCM | _abi.FAM_GLRLM | _abi.FAM_GLSZM | _abi.FAM_NGTDM
             dt4, nc4, par4 = timed(m4, s, cb, n_roi, check_rows=last_tile, arrays=dev_arrays, all_rows=True)
             mg4 = timed.margin
@@ -535,6 +575,8 @@ def main():
                               "roofline": {"bound": "hbm", "achieved": b4 / dt4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b4 / dt4 / 1e9 / HBM_PEAK_GBS,
                                            "algorithmic_bytes_per_launch": b4},
                               "what": "BASELINE.json configs[3] per GPU: *ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY* (gd 8) on the same 1000 tiles"}
+            if hb_cpu is not None:
+                rec["config4"]["cpu_baseline"] = cpu_leg(hb_cpu, m4, s, "the five families' reduce functions via runParallel, one family after the other", cpu_rows)
             try:
                 from tests import fixtures
                 rng5 = np.random.default_rng(5)
@@ -571,6 +613,7 @@ def main():
                                                "note": "peak = AMD's MI355X data sheet (fp64 vector = fp64 matrix, 78.6 TFLOP/s; MI355X_MICROARCH.md lists no fp64 row); "
                                                        "the direct convolution is bit-exact with the reference, DESIGN 4.3"},
                                   "what": "BASELINE.json configs[4]: GABOR (8-filter bank, 16x16) + ZERNIKE2D on DSB2018-shaped ROIs (fixture shapes replicated with seeded noise)"}
+                rec["config5"]["cpu_baseline"] = cpu_leg(hb5, m5k, s5, "GaborFeature + ZernikeFeature reduce via runParallel", 8192)
                 del keep5
             except Exception as e5:           # informational leg: never costs the headline line
                 rec["config5"] = {"error": repr(e5)}
@@ -731,7 +774,7 @@ def main():
             # PCIe-inclusive variants (what Nyxus.featurize() pays): host tiles in, host table out, through the chunked
             # copy / compute pipeline of nyxhip_featurize_tiles_v2 -- uint32 tiles, and the same images in the element types a
             # microscope hands over (uint16 intensities, uint8 labels: H2D carries 3 B per pixel instead of 8)
-            nh = min(nt, 64)
+            nh = min(nt, 256)                        # (2 GiB of host tiles; the call itself goes through them in chunks)
             h_in32 = tin[:nh].cpu().numpy().view(np.uint32)
             h_lab32 = labs[:nh].cpu().numpy().view(np.uint32)
             for tag, hi, hl in (("pcie_inclusive", h_in32, h_lab32), ("pcie_inclusive_u16_u8", h_in32.astype(np.uint16), h_lab32.astype(np.uint8))):
@@ -743,7 +786,46 @@ def main():
                 rec["tile_path"][tag] = {"value": len(hl_out) / dth, "unit": "ROIs/s", "tiles": nh, "ms_per_call": 1e3 * dth,
                                          "host_GBps": (hi.nbytes + hl.nbytes) / dth / 1e9,
                                          "what": "pageable host tiles (" + str(hi.dtype) + " intensity, " + str(hl.dtype) + " labels) in, host table out"}
+            # "(a) end-to-end featurize() (tile arrays in host memory -> feature table in host memory) and (b) reduce
+            # stage only ...  Both are reported; the headline ratio is (a) vs (a)."
+            cb_t = rec["tile_path"].get("cpu_baseline") or {}
+            if cb_t.get("wall_seconds") and rec["tile_path"].get("pcie_inclusive", {}).get("value"):
+                cpu_a = (cb_t["value"] * (cb_t["scan_seconds"] + cb_t["reduce_seconds"])) / cb_t["wall_seconds"]      # ROIs / wall second of the workflow
+                rec["ratios"] = {"a_vs_a_end_to_end": rec["tile_path"]["pcie_inclusive"]["value"] / cpu_a,
+                                 "a_vs_a_u16_u8": rec["tile_path"]["pcie_inclusive_u16_u8"]["value"] / cpu_a,
+                                 "tiles_resident_vs_cpu_workflow": rec["tile_path"]["value"] / cb_t["value"],
+                                 "b_vs_b_reduce_stage": (value / rec["cpu_baseline"]["value"]) if rec.get("cpu_baseline", {}).get("value") else None,
+                                 "what": "GPU ROIs/s over the reference's CPU ROIs/s on this box: (a) host tiles -> host table against the reference's in-memory "
+                                         "workflow (scans + reduce, wall clock); (b) the reduce stage alone (the headline metric against cpu_baseline)"}
         gate_rc = apply_gates(rec)           # a leg whose features do not match loses its value; exit code 4 below
+        # the driver keeps the TAIL of this line: one number + the gate + the CPU figure per leg, last
+        def brief(o, key="value"):
+            if not isinstance(o, dict):
+                return None
+            cb_ = o.get("cpu_baseline") if isinstance(o.get("cpu_baseline"), dict) else {}
+            pc = o.get("parity_check")
+            return [o.get(key), "ok" if (pc is not None and gate_ok(pc)) else ("unchecked" if pc is None else "FAILED"), cb_.get("value")]
+        summ = {"headline": [rec.get("value"), "ok" if gate_ok(rec["config"].get("parity_check")) else "FAILED", (rec.get("cpu_baseline") or {}).get("value")],
+                "columns": ["GPU ROIs/s (ms_per_call for mixed_sizes)", "parity gate", "CPU ROIs/s (reference classes, all host cores)"]}
+        for leg in ("config2", "config3", "config4", "config5", "gray_depth_64", "tile_path"):
+            if leg in rec:
+                summ[leg] = brief(rec[leg])
+        if isinstance(rec.get("tile_path"), dict):
+            for sub in ("irregular", "pcie_inclusive", "pcie_inclusive_u16_u8"):
+                if sub in rec["tile_path"]:
+                    summ["tile_path." + sub] = brief(rec["tile_path"][sub])
+        if isinstance(rec.get("mixed_sizes"), dict) and "ms_per_call" in rec["mixed_sizes"]:
+            summ["mixed_sizes"] = brief(rec["mixed_sizes"], "ms_per_call")
+            if isinstance(rec["mixed_sizes"].get("config4_set"), dict):
+                summ["mixed_sizes.config4_set"] = brief(rec["mixed_sizes"]["config4_set"], "ms_per_call")
+        if isinstance(rec.get("size_sweep"), dict):
+            summ["size_sweep_ns_per_roi"] = {str(r_["n_px"]): round(r_["ns_per_roi"], 2) for r_ in rec["size_sweep"].get("rows", []) if r_.get("ns_per_roi") is not None}
+        if isinstance(rec.get("intensity_range"), dict):
+            summ["intensity_range_ns_per_roi"] = {r_["intensities"]: (round(r_["ns_per_roi"], 2) if r_.get("ns_per_roi") is not None else None) for r_ in rec["intensity_range"].get("rows", [])}
+        if "ratios" in rec:
+            summ["ratios"] = {k_: v_ for k_, v_ in rec["ratios"].items() if k_ != "what"}
+        summ["roofline_frac"] = rec["roofline"]["frac"]
+        rec["summary"] = summ
         print(json.dumps(rec))
     if world > 1:
         grc = torch.tensor([gate_rc], dtype=torch.int32, device=dev)

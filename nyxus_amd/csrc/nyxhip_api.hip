@@ -1047,8 +1047,9 @@ static Extrema class_bounds(int cls, const nyxhip_settings* s)
 // INTENSITY + GLCM of one class by the several-workgroups-per-ROI kernels of roi_large.hip.  Members whose intensity range the
 // histogram workspace does not hold (kLargeRangeMax) are left to the caller (the one-workgroup sort path).
 static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E,
-                     const ClassTotals& tot, const uint32_t* list, uint32_t count)
-{
+                     const ClassTotals& tot, const uint32_t* list, uint32_t count, bool* served)
+{   // *served = false: the settings do not fit the path's kernels (nothing launched; the one-workgroup workspace path takes the class)
+    *served = true;
     const uint32_t mask1 = mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM);
     if (!mask1 || !count) return NYXHIP_OK;
     hipStream_t st = ctx->stream();
@@ -1096,7 +1097,12 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
         const uint64_t pm = 4ull * na * ng_max * ng_max;
         a.fin_P_bytes = (do_glcm && pm <= 32 * 1024) ? (uint32_t)pm : 0u;
         a.fin_tab_bytes = do_int ? (uint32_t)((4ull * (std::min<uint32_t>(r_max, 8191u) + 1) + 15) & ~15ull) : 0u;   // up to 32 KiB of histogram
-        a.lds_fin_bytes = (uint32_t)std::max<uint64_t>(a.fin_tab_bytes + 4ull * (112 + (uint64_t)abs(s->grey_depth)), scr + a.fin_P_bytes + 16);
+        // (the bin bounds of the n-bin histogram sit behind the table: with thousands of bins the table shrinks, beyond ~16000 the
+        //  finishing kernel's 64 KiB cannot hold the bounds at all -- round-4 advisor)
+        const uint64_t bounds = 4ull * (112 + (uint64_t)abs(s->grey_depth));
+        if (do_int && bounds + 16 > 64 * 1024) { *served = false; return NYXHIP_OK; }
+        if (do_int && a.fin_tab_bytes + bounds > 64 * 1024) a.fin_tab_bytes = (uint32_t)((64 * 1024 - bounds) & ~15ull);
+        a.lds_fin_bytes = (uint32_t)std::max<uint64_t>(a.fin_tab_bytes + bounds, scr + a.fin_P_bytes + 16);
     }
     // ---- workspace: the members' blocks back to back (offsets handed out by the prep kernel) when the class fits the budget, else
     // chunks of the list with room for the class's largest block each
@@ -1363,9 +1369,11 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         // duplicate list instead of a sort (roi_wide.hip), the GLCM columns from the GLCM-only build.  (The sort engine inside the
         // fused kernel cost 43 ns per 2821-pixel ROI against 12.5 ns on 12-bit data.)
         static const bool no_wide = [] { const char* e = getenv("NYXHIP_NO_WIDE"); return e && *e && *e != '0'; }();   // A/B knob
+        // Which engine serves a member is decided by ITS range (<= 0xFFFF: roi_wide + the GLCM-only build; beyond: the fused sort
+        // kernel), never by the class's observed extrema: both launches run over the class and each skips the other's members.
         auto launch_features_wide = [&](bool& done) -> int {
             done = false;
-            if (no_wide || !list || !(cls & 1) || !(a.mask & NYXHIP_FAM_INTENSITY) || E.range > 0xFFFFu) return 0;
+            if (no_wide || !list || !(cls & 1) || !(a.mask & NYXHIP_FAM_INTENSITY)) return 0;
             WideArgs wa;
             memset(&wa, 0, sizeof(wa));
             if (!make_wide_layout(E.px, (uint32_t)abs(s->grey_depth), wa)) return 0;
@@ -1374,7 +1382,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             if (with_glcm) {
                 std::string w2;
                 const int ncol_g = a.n_cols - kIntensityCols;
-                if (make_layout(NYXHIP_FAM_GLCM, s, ncol_g, E.px, E.area, E.range, ag.L, w2, 0, E.vmax) != NYXHIP_OK) return 0;
+                if (make_layout(NYXHIP_FAM_GLCM, s, ncol_g, E.px, E.area, std::min(E.range, 0xFFFFu), ag.L, w2, 0, E.vmax) != NYXHIP_OK) return 0;
                 ag.mask = NYXHIP_FAM_GLCM; ag.n_cols = ncol_g; ag.col_glcm = 0; ag.col_intensity = -1; ag.out = a.out + kIntensityCols;
                 if (a.glcm_ws && ag.L.ng_cap != a.L.ng_cap) return 0;          // (the count workspace was sized for the fused layout)
             }
@@ -1386,7 +1394,14 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             wa.list = list; wa.n_list = grid;
             if (int r1 = launch_roi_wide(wa, st)) return r1;
             done = true;
-            return with_glcm ? launch_roi_features(ag, st, grid) : 0;
+            ag.sp.max_range = 0xFFFFu;
+            if (with_glcm)
+                if (int r2 = launch_roi_features(ag, st, grid)) return r2;
+            if (E.range > 0xFFFFu) {                                          // members beyond 16 bits: the fused kernel, as if they were alone
+                a.sp.min_range = 0x10000u;
+                return launch_features_main();
+            }
+            return 0;
         };
         if (lds & 1) {
             bool wide_done = false;
@@ -1412,11 +1427,12 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     static const bool no_coop = [] { const char* e = getenv("NYXHIP_NO_COOP"); return e && *e && *e != '0'; }();   // A/B knob: the one-workgroup path
     bool coop = false;
     if ((gs & 1) && tot && !no_coop) {
-        if (int lrc = run_large(ctx, b, full, s, d_out, ld, E, *tot, list, grid)) return lrc;
-        coop = true;
-        if (report) report->cooperative = 1;
-        if (E.range < kLargeRangeMax) gs &= ~1u;         // nobody left for the sort path below
-        if (!gs) return NYXHIP_OK;
+        if (int lrc = run_large(ctx, b, full, s, d_out, ld, E, *tot, list, grid, &coop)) return lrc;
+        if (coop) {
+            if (report) report->cooperative = 1;
+            if (E.range < kLargeRangeMax) gs &= ~1u;     // nobody left for the sort path below
+            if (!gs) return NYXHIP_OK;
+        }
     }
 
     // the lane of this class (nyxhip_ctx::lane_stream): large classes only -- the workspace fallback of an LDS class stays on the main stream
@@ -2137,6 +2153,9 @@ static int res_reserve(nyxhip_ctx* ctx, size_t rows, size_t n_cols, hipStream_t 
 // One guard per ARRAY: the sharded entry pins the whole stack once, before its threads copy their shares -- per-share
 // registrations would be released at different times while other shares still copy.
 struct HostPin {
+    struct Mapping { uintptr_t lo, hi; bool arena; };
+    std::vector<Mapping> maps;                          // /proc/self/maps of this call
+    bool maps_read = false;
     void* p[2] = {nullptr, nullptr};
     uintptr_t lo[2] = {0, 0}, hi[2] = {0, 0};          // registered byte range of array k (empty: lo == hi)
     static constexpr size_t kPinMinBytes = (size_t)8 << 20;
@@ -2157,21 +2176,28 @@ struct HostPin {
         // line of /proc/self/maps, so "a mapping of its own" cannot be asked for).  The page range must lie in one line that is
         // neither `[heap]` (the main arena) nor shaped like another thread's arena (64-MiB aligned, at most 64 MiB long); an array
         // of 8 .. 32 MiB that malloc placed in an arena -- its threshold adapts -- travels as a pageable copy.
-        bool outside_arenas = false;
-        if (FILE* f = fopen("/proc/self/maps", "r")) {
-            char line[512];
-            while (fgets(line, sizeof(line), f)) {
-                unsigned long m0 = 0, m1 = 0;
-                if (sscanf(line, "%lx-%lx", &m0, &m1) != 2) continue;
-                if ((uintptr_t)m0 <= a && a < (uintptr_t)m1) {
+        // (the map is read once per call -- both arrays of a call are looked up in the same copy; a python + torch process has
+        //  thousands of lines there.  The rule knows glibc's malloc only: INTEGRATION.md, "Host memory".)
+        if (!maps_read) {
+            maps_read = true;
+            if (FILE* f = fopen("/proc/self/maps", "r")) {
+                char line[512];
+                while (fgets(line, sizeof(line), f)) {
+                    unsigned long m0 = 0, m1 = 0;
+                    if (sscanf(line, "%lx-%lx", &m0, &m1) != 2) continue;
                     const bool arena_like = (m0 & ((64ul << 20) - 1)) == 0 && m1 - m0 <= (64ul << 20);
-                    outside_arenas = z <= (uintptr_t)m1 && !strstr(line, "[heap]") && !arena_like;
-                    break;
+                    maps.push_back({(uintptr_t)m0, (uintptr_t)m1, strstr(line, "[heap]") != nullptr || arena_like});
                 }
+                fclose(f);
             }
-            fclose(f);
         }
-        if (!outside_arenas) return;
+        bool outside_arenas = false;
+        for (const Mapping& m : maps)
+            if (m.lo <= a && a < m.hi) { outside_arenas = z <= m.hi && !m.arena; break; }
+        if (!outside_arenas) {
+            if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] host array %p (%zu MiB) lies in a malloc arena (or spans mappings): copied pageable\n", ptr, bytes >> 20);
+            return;
+        }
         if (hipHostRegister((void*)a, z - a, hipHostRegisterDefault) == hipSuccess) { p[k] = (void*)a; lo[k] = a; hi[k] = z; } else (void)hipGetLastError();
     }
     // host -> device copy of [src, src + bytes) of array k: the part inside the registered pages as one (DMA) copy, what lies in

@@ -630,8 +630,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
     if (!roi_in_launch(A.sp, n, w, h, vmax - vmin))
         return;                                       // another launch of this call serves the ROI's size class
-    if (GS && vmax - vmin < A.sp.min_range)
-        return;                                       // served by the histogram path (roi_large.hip)
+    if (vmax - vmin < A.sp.min_range || (A.sp.max_range != 0u && vmax - vmin > A.sp.max_range))
+        return;                                       // served by the histogram path (roi_large.hip) / the other launch of a wide-range class (run_class)
     constexpr bool FAST = FAM == 1 || FAM == 3;       // (3: GLCM alone under the same conditions -- BASELINE configs[2], and the GLCM columns of the 16-bit path)
     constexpr int kRowsTag = 16 + TIER * 4 + (C16 ? 2 : 0) + (D8 ? 1 : 0);
     const bool do_int = FAM == 1 || FAM == 2 || (FAM == 0 && (A.mask & NYXHIP_FAM_INTENSITY) != 0);

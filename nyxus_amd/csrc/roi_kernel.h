@@ -53,8 +53,9 @@ struct SpillArgs {
     // everybody else returns at once (the kernel derives the class from what it loads anyway: no list, no dependent load in
     // front of the ROI's own data).  0 = no filter.
     uint32_t class_mask;
-    uint32_t min_range;          // workspace launches of the feature kernel: serve only ROIs whose intensity range reaches this (0: all) -- the
-                                 // rest of the class went through the histogram path of roi_large.hip
+    uint32_t min_range;          // launches of the feature kernel: serve only ROIs whose intensity range reaches this (0: all) -- the rest of
+                                 // the class went through the histogram path of roi_large.hip / the 16-bit path of roi_wide.hip
+    uint32_t max_range;          // ... and only ROIs whose range stays within this (0: no bound): the GLCM-only launch beside roi_wide.hip
     uint32_t skip_ltex;          // workspace launches of the texture kernel: 1 = leave out the ROIs the several-workgroups-per-ROI texture
                                  // path serves (ltex_eligible, roi_large_tex.hip)
 };

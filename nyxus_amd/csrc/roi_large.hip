@@ -468,8 +468,15 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     LargeRoi R;
-    if (blockIdx.x >= A.n_list || !large_roi(A, blockIdx.x, R, true)) return;
-    constexpr int BS = 256, NW = 4;
+    if (blockIdx.x >= A.n_list) return;
+    if (!large_roi(A, blockIdx.x, R, true)) {
+        // not served here.  An EMPTY member (a box with no pixel) is nobody else's either: the columns of the LDS kernels' early exit
+        // (ranges beyond the histogram are the sort path's, which writes the row)
+        if (R.n == 0)
+            for (int c = threadIdx.x; c < A.n_cols; c += 256) A.out[R.roi * A.ld + c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    constexpr int BS = 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool do_int = (A.mask & NYXHIP_FAM_INTENSITY) != 0, do_glcm = (A.mask & NYXHIP_FAM_GLCM) != 0;
     double* const out_row = A.out + R.roi * A.ld;
@@ -480,7 +487,6 @@ __global__ __launch_bounds__(256) void large_finish_kernel(const LargeArgs A)
     __shared__ double s_pq[8];
     __shared__ uint32_t s_w[16];
     const uint32_t n = R.n, vmin = R.vmin, vmax = R.vmax, range = R.range;
-    const double dn = (double)n;
     __syncthreads();
 
     if (do_int) {

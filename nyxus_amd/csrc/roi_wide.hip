@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256, 7) void roi_wide16_kernel(const WideArgs A)   
     __shared__ double s_stat[8];
     __shared__ double s_pq[8];
     __shared__ uint32_t s_w[16];
+    if (range > 0xFFFFu) return;                                              // a member beyond 16 bits: the sort engine of roi_features.hip serves it (run_class)
     for (int c = tid; c < kIntensityCols; c += BS) o[c] = 0.0;               // skipped features stay 0 (class members default to 0)
-    if (n == 0 || n > A.key_cap || range > 0xFFFFu) {                         // (the host sized the launch from the class extrema: cannot happen)
+    if (n == 0 || n > A.key_cap) {                                            // (the host sized the launch from the class extrema: cannot happen)
         if (tid == 0 && n != 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         if (n != 0)
             for (int c = tid; c < kIntensityCols; c += BS) o[c] = __longlong_as_double(0x7ff8000000000000LL);

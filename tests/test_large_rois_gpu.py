@@ -181,3 +181,13 @@ def test_tile_path_with_a_large_roi_falls_back_to_clouds(hip_ctx):
     assert list(labels) == [2, 5, 9]
     bad = parity.compare_tables(T, O, _lib.column_names(MASK, s), batch=b)
     assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("gabor", [False, True])
+def test_default_grey_depth_on_large_rois(hip_ctx, gabor):
+    """The reference's default grey depth (64 levels: 64 x 64 matrices, 64 histogram bins) on 20 k / 100 k-pixel ROIs, every family
+    of BASELINE configs[3], with and without Gabor beside them."""
+    rng = np.random.default_rng(43)
+    rois = [ellipse_roi(90, 72, rng), ellipse_roi(200, 160, rng, lo=0, holes=0.03), ellipse_roi(20, 18, rng)]
+    mask = CONFIG4 | (_abi.FAM_GABOR if gabor else 0)
+    check(hip_ctx, rois, mask, _abi.default_settings(64))

@@ -67,3 +67,48 @@ def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, 
         else:
             assert np.array_equal(labels, first[k][0])
             assert np.array_equal(table, first[k][1], equal_nan=True)
+
+
+@pytest.mark.parametrize("arenas", ["1", "64"])
+def test_pinning_under_other_arena_settings(arenas):
+    """The page rule of HostPin knows glibc's arenas by their shape; MALLOC_ARENA_MAX changes how many there are and where the
+    threshold-sized arrays land (1: everything in the program-break heap or mappings of its own; 64: up to 64 arenas with threads).
+    A fresh process per setting (the variable is read when the allocator starts) runs a short version of the stress loop, a thread
+    allocating beside it."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import threading, numpy as np
+from nyxus_amd import _abi, _lib
+ctx = _lib.Context(0)
+rng = np.random.default_rng(5)
+s = _abi.default_settings(8)
+mask = _abi.FAM_INTENSITY | _abi.FAM_GLCM
+stop = False
+def churn():
+    keep = []
+    while not stop:
+        keep.append(np.ones(int(rng.integers(1, 3_000_000)), np.uint8))
+        if len(keep) > 8: keep.pop(0)
+th = threading.Thread(target=churn); th.start()
+first = {}
+try:
+    for it in range(60):
+        n, size = ((2, 64), (3, 1024), (9, 512))[it % 3]
+        lab = np.zeros((n, size, size), np.uint32); lab[:, 8:30, 8:40] = 1; lab[:, size - 30:size - 5, 5:25] = 2
+        inten = np.random.default_rng(it % 3).integers(1, 4096, lab.shape).astype(np.uint32)
+        _t, labels, table = ctx.featurize_tiles_host(inten, lab, mask, s)
+        assert len(labels) == 2 * n and np.isfinite(table[:, 0]).all()
+        k = it % 3
+        if k in first: assert np.array_equal(table, first[k], equal_nan=True)
+        else: first[k] = table.copy()
+finally:
+    stop = True; th.join()
+ctx.close()
+print("ok")
+"""
+    env = dict(os.environ, MALLOC_ARENA_MAX=arenas, NYXHIP_PIN_MIN="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])

@@ -222,3 +222,44 @@ def test_window_mode_is_bit_identical_to_cloud_mode(hip_ctx, gd):
     assert np.array_equal(T1, T2[:, sel], equal_nan=True)
     wt, wl, want = _oracle_stack(I, M, MASK, s)
     assert not parity.compare_tables(T1, want, n1)
+
+
+@pytest.mark.parametrize("hi", [200, 256, 1001])
+def test_tile_path_under_ibsi_with_levels_beyond_lds(hip_ctx, hi):
+    """ibsi=True through the tile path (round-3 advisor's first trigger, never exercised): the co-occurrence matrix is as large as
+    the ROI's largest intensity, so with intensities >= ~170 a window-mode chunk meets a class that needs the workspace -- the
+    chunk materialises its clouds and runs again.  Rows equal host assembly + oracle."""
+    rng = np.random.default_rng(51)
+    s = _abi.default_settings(8)
+    s.ibsi = 1
+    lab = synth.disk_label_tile(size=192, pitch=48, radius=20)
+    I = rng.integers(1, hi, (2, 192, 192)).astype(np.uint32)
+    M = np.stack([lab, lab[::-1].copy()]).astype(np.uint32)
+    for mask in (MASK, MASK | _abi.FAM_GLRLM | _abi.FAM_NGTDM):
+        tiles, labels, T = hip_ctx.featurize_tiles_host(I, M, mask, s)
+        wt, wl, want = _oracle_stack(I, M, mask, s)
+        assert tiles.tolist() == wt.tolist() and labels.tolist() == wl.tolist()
+        bad = parity.compare_tables(T, want, _lib.column_names(mask, s))
+        assert not bad, "\n".join(bad[:10])
+
+
+def test_tile_path_with_a_large_wide_range_roi(hip_ctx):
+    """A 25 k-pixel ROI whose uint32 intensities span more than 16 bits, next to small ROIs, through the tile path: the chunk falls
+    back to clouds (the ROI is beyond the LDS classes) and the histogram / sort engines behind it see the full range."""
+    rng = np.random.default_rng(52)
+    H = W = 384
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab = np.zeros((H, W), np.uint32)
+    lab[(yy - 150) ** 2 + (xx - 150) ** 2 <= 90 ** 2] = 7            # 25.4 k pixels
+    lab[(yy - 330) ** 2 + (xx - 330) ** 2 <= 25 ** 2] = 3
+    lab[(yy - 40) ** 2 + (xx - 330) ** 2 <= 12 ** 2] = 11
+    I = rng.integers(1, 4096, (1, H, W)).astype(np.uint32)
+    big = lab == 7
+    I[0][big] = rng.integers(5, 100_000, int(big.sum())).astype(np.uint32)
+    I[0][150, 150] = 3_000_000                                        # one hot pixel: a range of 3e6, beyond every 16-bit table
+    s = _abi.default_settings(8)
+    tiles, labels, T = hip_ctx.featurize_tiles_host(I, lab[None], MASK, s)
+    wt, wl, want = _oracle_stack(I, lab[None], MASK, s)
+    assert labels.tolist() == wl.tolist() == [3, 7, 11]
+    bad = parity.compare_tables(T, want, _lib.column_names(MASK, s))
+    assert not bad, "\n".join(bad[:10])

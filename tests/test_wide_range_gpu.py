@@ -116,3 +116,24 @@ def test_gabor_on_intensities_beyond_fp32_integers(hip_ctx):
     G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
     O = po.oracle_featurize(b, _abi.FAM_GABOR, s)
     assert np.array_equal(G, O, equal_nan=True), np.abs(G - O).max()
+
+
+@pytest.mark.parametrize("gd", [8, 64])
+def test_a_sixteen_bit_row_does_not_depend_on_wider_companions(hip_ctx, gd):
+    """The engine that serves a wide-range ROI follows ITS range (<= 0xFFFF: bitmap path + GLCM-only build; beyond: the fused sort
+    kernel), not the extrema of the class it shares (round-4 advisor, medium): rows of 16-bit ROIs alone, and next to 2^31-range
+    ROIs of the same size classes, are equal bit for bit; so are the wide ones' rows; all of them match the oracle."""
+    rng = np.random.default_rng(41)
+    s = _abi.default_settings(gd)
+    narrow = [ellipse_roi(7, 6, rng, hi=60000), ellipse_roi(30, 25, rng, hi=65536, lo=0), ellipse_roi(60, 50, rng, hi=40000)]
+    wide = [ellipse_roi(8, 7, rng, hi=2 ** 31), ellipse_roi(28, 27, rng, hi=2 ** 31), ellipse_roi(20, 31, rng, hi=70000)]
+    names = _lib.column_names(MASK, s)
+
+    def diff(a, c):
+        return [(names[j], i) for i, j in zip(*np.nonzero(~((a == c) | (np.isnan(a) & np.isnan(c)))))]
+    alone_n = hip_ctx.featurize_host(_abi.batch_from_rois(narrow), MASK, s)
+    alone_w = hip_ctx.featurize_host(_abi.batch_from_rois(wide), MASK, s)
+    mixed = [narrow[0], wide[0], wide[1], narrow[1], wide[2], narrow[2]]
+    G = check(hip_ctx, mixed, MASK, s)
+    assert not diff(alone_n, G[[0, 3, 5]]), diff(alone_n, G[[0, 3, 5]])[:10]
+    assert not diff(alone_w, G[[1, 2, 4]]), diff(alone_w, G[[1, 2, 4]])[:10]
