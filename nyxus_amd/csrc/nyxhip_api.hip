@@ -1343,6 +1343,29 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     const bool on_lds_lane = lds && !gs && lds_lanes && list && cls >= 0 && cls / 2 < kFirstLargeSizeClass && !ctx->win_next.inten;
     if (on_lds_lane)
         if (int lrc = enter_lane(4 + cls / 2)) return lrc;
+    // Size class 2 (boxes up to 128 x 128, up to 16384 pixels) fits LDS, but its texture kernel is one workgroup walking 16 k cells through
+    // a dozen passes and a serial zone sweep: ~0.3 ms per ROI whatever the batch, and a class of two thousand such ROIs is a round and
+    // a tail of them (0.7-0.9 ms of the mixed batch's 3.3).  Its GLRLM / GLSZM / NGTDM go through the several-workgroups-per-ROI path
+    // as well (roi_large_tex.hip), on a lane beside the main stream.  A function of the class, i.e. of the ROI.
+    static const bool no_sc2_tex = [] { const char* e = getenv("NYXHIP_NO_COOP_TEX_SC2"); const char* f = getenv("NYXHIP_NO_COOP_TEX"); const char* g0 = getenv("NYXHIP_NO_COOP");
+                                        return (e && *e && *e != '0') || (f && *f && *f != '0') || (g0 && *g0 && *g0 != '0'); }();   // A/B knob
+    if (list && cls / 2 == 2 && (lds & 2) && tot && !no_sc2_tex && b->inten) {
+        const hipStream_t main_st = st;
+        int served2 = 0;
+        // (the lane of size class 3 -- usually a handful of ROIs: streams beyond the device's four hardware queues share one, and a
+        //  lane of its own landed on the queue of the largest class's lane, behind 2 ms of its kernels)
+        const int lane2 = cls & 1;
+        if (int lrc = enter_lane(lane2)) return lrc;
+        if (int lrc = run_large_tex(ctx, b, full, s, d_out, ld, E, *tot, list, grid, st, lane2, &served2)) return lrc;
+        if (served2 == 1) {
+            lds &= ~2u;
+            if (report) {
+                report->cooperative |= 2;
+                if (ctx->timing) { HIP_TRY(ctx, hipEventCreate(&report->e2)); HIP_TRY(ctx, hipEventRecord(report->e2, st)); }
+            }
+        }
+        st = main_st;
+    }
     if (lds) {
         for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
