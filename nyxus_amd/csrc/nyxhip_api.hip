@@ -1201,9 +1201,18 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
     // a wave per 64 columns of the class's widest box, and the wave that feeds the ring
     a.strip_threads = 64u * (uint32_t)(std::min<uint64_t>(15, std::max<uint64_t>(3, (std::min<uint64_t>(side_w, 1024) + 62) / 64 + 1)) + 1);
     a.lds_load_bytes = 32 * 1024;
-    const uint64_t lds_strip = std::max(strip, sweep) + 64;
+    if (!(mask2 & NYXHIP_FAM_GLSZM)) a.strip_threads = 256;            // no sweep in the launch
+    a.strip_groups = std::max<uint32_t>(1, a.strip_threads / 256);
+    a.lds_group_bytes = (uint32_t)((strip + 64 + 15) & ~15ull);
+    while (a.strip_groups > 1 && (uint64_t)a.strip_groups * a.lds_group_bytes > 144 * 1024) a.strip_groups--;
+    const uint64_t lds_strip = std::max<uint64_t>((uint64_t)a.strip_groups * a.lds_group_bytes, sweep + 64);
     const uint64_t S = ng <= 256 ? kLtexSmall : 0;
-    const uint64_t lds_zone = al16(2ull * (ng + 2)) + al16(4ull * std::min<uint32_t>(ng, 256) * kLtexSmall) + rl_bytes + 64;
+    // (tables that exist only below a level count: under IBSI a member may have any count up to the class's, else all have ng)
+    const bool any_ng = greyInfo == 0;
+    const uint64_t small_b = (mask2 & NYXHIP_FAM_GLSZM) ? (any_ng ? 4ull * std::min<uint32_t>(ng, 256) * kLtexSmall : ng <= 256 ? 4ull * ng * kLtexSmall : 0) : 0;
+    const uint64_t rl2_b = (mask2 & NYXHIP_FAM_GLRLM) ? (any_ng ? 4ull * 2 * 65 * std::min<uint32_t>(ng, 128) : ng <= 128 ? 4ull * 2 * 65 * ng : 0) : 0;   // two replicas of the run table
+    const uint64_t lds_zone = al16(2ull * (ng + 2)) + al16(small_b) + al16(rl2_b) +
+                              ((mask2 & NYXHIP_FAM_GLSZM) ? al16(2 * std::max<uint64_t>(kLtexCells, side_w) + 8) : 0) + 64;   // ... and the strip's 16-bit zone counters
     const uint64_t side_e = std::min<uint64_t>(std::max<uint32_t>(E.side, 1), (1u << 20) - 1);     // an eligible box has fewer than 2^20 cells
     const uint64_t slot_max = (uint64_t)ng * side_e + ng + side_e + 4;
     const uint64_t fin_fixed = al16(8ull * a.n_cols) + al16(2ull * (ng + 2)) + al16(4ull * (ng + 2)) + al16(16ull * (std::min<uint32_t>(ng, 256) + 2));
@@ -1211,7 +1220,7 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
     const uint64_t lds_fin = fin_fixed + al16(fin_work) + 64;
     if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] large texture: count %u ng %u side %u area %u lds strip %llu zone %llu fin %llu\n", count, ng, E.side, E.area,
                                         (unsigned long long)lds_strip, (unsigned long long)lds_zone, (unsigned long long)lds_fin);
-    if (lds_strip > 144 * 1024 || lds_zone > 96 * 1024 || lds_fin > 144 * 1024) return NYXHIP_OK;
+    if (lds_strip > 144 * 1024 || lds_zone > 128 * 1024 || lds_fin > 144 * 1024) return NYXHIP_OK;
     a.lds_strip_bytes = (uint32_t)lds_strip; a.lds_zone_bytes = (uint32_t)lds_zone; a.lds_fin_bytes = (uint32_t)lds_fin;
     // ---- workspace: bounds of a member's block and of the class as a whole (ltex_ws_layout)
     const uint64_t area_e = std::min<uint64_t>(std::max<uint32_t>(E.area, 1), (1u << 20) - 1);
@@ -1219,7 +1228,7 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
     const uint64_t fixed = 256 + al256(ng + 8) + al256(12ull * (ng + 2)) + al256(16 * slot_max) + al256(4ull * std::min<uint32_t>(ng, 256) * kLtexSmall) +
                            al256(8ull * szm_hash_cap(ng + 1, (uint32_t)area_e)) + 12 * 256;
     auto var_bytes = [&](uint64_t area, uint64_t members) {
-        return cb * area + 64 * members + 4 * (area + 2 * members) + 4 * (area / (S + 1) + 8 * members) + 24 * (area / rmin + members * side_w);
+        return cb * area + 64 * members + 8 * (area + 2 * members) + 4 * (area / (S + 1) + 8 * members) + 28 * (area / rmin + members * side_w) + 64 * members;
     };
     const char* const be = getenv("NYXHIP_LARGE_BUDGET_MB");                  // (tests: a small budget sends a class through the chunked form)
     const size_t budget = be && atoll(be) > 0 ? (size_t)atoll(be) << 20 : (size_t)8 << 30;

@@ -470,12 +470,13 @@ __host__ __device__ inline uint32_t ltex_rows_per_strip(uint32_t w, uint32_t h)
     return r < h ? r : (h ? h : 1u);
 }
 struct LtexWs {                                   // byte offsets inside an ROI's workspace block (header: 256 bytes of u32 words)
-    uint64_t flags, plane, ngt, rlm, rec, cnt, small, hash, big, total;
+    uint64_t flags, plane, ngt, rlm, rec, cnt, small, hash, big, lab, open, total;
     uint32_t rows, K;                             // rows per strip, strips
     uint32_t slot_words;                          // words of one direction's run-length matrix + its marginals
     uint32_t hcap, S, big_cap;                    // GLSZM: hash slots, direct-table sizes (0 or kLtexSmall), entries of the list of larger zones
+    uint32_t open_cap;                            // ... entries of the list of zones that reach their strip's last row
 };
-enum { LTEX_H_NP_ORIG = 0, LTEX_H_NP_BIN, LTEX_H_NZONE, LTEX_H_SZMAX, LTEX_H_NBIG };   // header words
+enum { LTEX_H_NP_ORIG = 0, LTEX_H_NP_BIN, LTEX_H_NZONE, LTEX_H_SZMAX, LTEX_H_NBIG, LTEX_H_NOPEN };   // header words
 // ng: bound of the ROI's level count (grey depth, or its largest intensity under IBSI)
 __host__ __device__ inline LtexWs ltex_ws_layout(uint32_t w, uint32_t h, uint32_t ng, bool plane16, uint32_t mask)
 {
@@ -492,8 +493,8 @@ __host__ __device__ inline LtexWs ltex_ws_layout(uint32_t w, uint32_t h, uint32_
     L.slot_words = ng * side + ng + side + 4;
     L.rlm = o; if (mask & NYXHIP_FAM_GLRLM) o += al(16ull * L.slot_words);
     L.rec = o; if (mask & NYXHIP_FAM_GLRLM) o += al(24ull * L.K * w);                      // [K][2][3][w] u32: runs touching a strip's first / last row
-    L.hcap = 0; L.S = 0; L.big_cap = 0;
-    L.cnt = o; L.small = o; L.hash = o; L.big = o;
+    L.hcap = 0; L.S = 0; L.big_cap = 0; L.open_cap = 0;
+    L.cnt = o; L.small = o; L.hash = o; L.big = o; L.lab = o; L.open = o;
     if (mask & NYXHIP_FAM_GLSZM) {
         L.hcap = szm_hash_cap(ng + 1, (uint32_t)area);
         L.S = ng <= 256 ? kLtexSmall : 0u;
@@ -502,6 +503,9 @@ __host__ __device__ inline LtexWs ltex_ws_layout(uint32_t w, uint32_t h, uint32_
         L.small = o; o += al(4ull * ng * L.S);
         L.hash = o; o += al(8ull * L.hcap);
         L.big = o; o += al(4ull * L.big_cap);
+        L.open_cap = L.K * w + 8;
+        L.open = o; o += al(4ull * L.open_cap);
+        L.lab = o; o += al(4ull * (area + 2));                                             // owner of every cell (written whole by the sweep)
     }
     L.total = o;
     return L;
@@ -537,6 +541,8 @@ struct LtexArgs {
     uint32_t vec_ok;               // as LargeArgs
     uint32_t lds_load_bytes;       // dynamic LDS of the load kernel: its transposing tile
     uint32_t strip_threads;        // workgroup size of the strip / sweep kernel: a wave per 64 columns of the class's widest box, 4 .. 16 waves
+    uint32_t strip_groups;         // strips per strip workgroup: one per group of four waves
+    uint32_t lds_group_bytes;      // dynamic LDS of one such group
     uint32_t lds_strip_bytes;      // dynamic LDS of the strip / sweep kernel
     uint32_t lds_zone_bytes;       // ... of the join / zone kernel
     uint32_t lds_fin_bytes;        // dynamic LDS of the finishing kernel

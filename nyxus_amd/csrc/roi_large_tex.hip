@@ -272,9 +272,9 @@ __device__ __forceinline__ uint32_t ltex_rl_rep(uint32_t Lcap) { return Lcap <= 
 __device__ __forceinline__ uint32_t ltex_rl_words(uint32_t Lcap) { return 4u * kLtexRlmLds * Lcap + Lcap; }
 __device__ __forceinline__ uint32_t ltex_rl_index(uint32_t Lcap, uint32_t dir, uint32_t m, uint32_t len) { return (dir * kLtexRlmLds + (len - 1u)) * Lcap + m; }
 // the replicas of a table summed into the global matrices (integers: any order)
-__device__ __forceinline__ void ltex_rl_flush(const uint32_t* s_short, uint32_t Lcap, uint32_t* gP, uint32_t slot_words, uint32_t Nr, int tid, int BS)
+__device__ __forceinline__ void ltex_rl_flush(const uint32_t* s_short, uint32_t Lcap, uint32_t* gP, uint32_t slot_words, uint32_t Nr, int tid, int BS, uint32_t rep)
 {
-    const uint32_t rep = ltex_rl_rep(Lcap), words = ltex_rl_words(Lcap);
+    const uint32_t words = ltex_rl_words(Lcap);
     for (uint32_t i = (uint32_t)tid; i < 4u * kLtexRlmLds * Lcap; i += (uint32_t)BS) {
         uint32_t cn = 0;
         for (uint32_t r = 0; r < rep; r++) cn += s_short[r * words + i];
@@ -304,12 +304,24 @@ template <bool P16>
 __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint32_t n_sweep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ int s_res[2];
-    const int BS = (int)blockDim.x, NW = BS >> 6;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int s_res_all[8];
+    int BS = (int)blockDim.x, NW = BS >> 6;
+    int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     using plane_t = typename std::conditional<P16, uint16_t, uint8_t>::type;
     const int greyInfo = A.ibsi ? 0 : A.grey_depth;
     const uint32_t bgmin = greyInfo > 0 ? 1u : 0u;         // an unwritten cell of the box: background, level 1 under matlab binning
+    // The workgroup size follows the sweep (a wave per 64 columns), but a strip is four waves' work: a strip workgroup takes one strip
+    // per GROUP of four waves, each group with its own part of the dynamic LDS (waves beyond the last whole group leave at once).
+    // The groups share the workgroup's barriers and nothing else.
+    unsigned char* lds_g = lds_raw;
+    int grp = 0;
+    if (blockIdx.x >= n_sweep && NW > 4) {
+        grp = wave >> 2;
+        if (grp >= (int)A.strip_groups) return;
+        lds_g = lds_raw + (size_t)grp * A.lds_group_bytes;
+        tid &= 255; wave &= 3; NW = 4; BS = 256;
+    }
 
     if (blockIdx.x < n_sweep) {
         // =============================================================================================================
@@ -325,11 +337,11 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
         if (blockIdx.x >= A.n_list || !ltex_roi(A, blockIdx.x, R, true)) return;
         if (R.vmin == R.vmax) return;                       // blank: no zones are asked for (glszm.cpp:61-65)
         const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
-        uint32_t* const cnt = (uint32_t*)(R.base + R.L.cnt);
+        uint32_t* const labp = (uint32_t*)(R.base + R.L.lab);
         const uint32_t w = R.w, h = R.h;
         const uint32_t nch = (w + 62u) / 64u + 1u;          // chunks 0 .. nch - 1 cover the columns -63 .. w - 1 at every drift
         // Plane rows come through an LDS ring filled by the workgroup's LAST wave, which requests the rows eight rows ahead and does
-        // nothing else: the sweeping waves then have no loads from global memory in flight -- next to their zone-size atomics those
+        // nothing else: the sweeping waves then have no loads from global memory in flight -- next to their stores those
         // made every wait a wait for everything (vmcnt counts both, out of order), one L2 round trip per step.
         // (Rows beyond 1008 bytes -- one 16-byte load per lane at any misalignment -- are read directly: every wave sweeps.)
         const uint32_t row_bytes = w * (uint32_t)sizeof(plane_t);
@@ -385,11 +397,9 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
             const bool zp = in && v != 0;
             if (in) cur[ci + 1] = zp ? (V20 | lab) : kNone;
             if (lane == 63) { cr[2 * (j + 1)] = v; cr[2 * (j + 1) + 1] = lab; }
-            // zone sizes: one atomic per string of equal owners in the chunk
-            const uint32_t ln = lane_plus1(lab, kNone);
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(zp && (uint32_t)c + 1u < w && lane < 63 && ln == lab);
-            if (zp && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
-                atomicAdd(&cnt[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
+            // the owners go to the label plane (one coalesced store; the strips count the zones: a global atomic per pixel here --
+            // zones of a textured image are a pixel or two -- was 40 % of the sweep's time and the chip's whole L2 atomic rate)
+            if (in) labp[p] = zp ? lab : kNone;
         };
         const uint32_t n_steps = (h - 1u) + ((h - 1u) >> 6) + nch;
         // Three loops, one per role, with the same number of barriers each.  (One loop with the roles as branches made the compiler
@@ -432,7 +442,8 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
     // =================================================================================================================
     // strip role
     // =================================================================================================================
-    const uint32_t sb = blockIdx.x - n_sweep;
+    int* const s_res_g = s_res_all + 2 * grp;
+    const uint32_t sb = (blockIdx.x - n_sweep) * A.strip_groups + (uint32_t)grp;
     if (sb >= A.ctr[3]) return;
     const uint2 job = A.map_strip[sb];
     LtexRoi R;
@@ -452,16 +463,16 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
     const uint32_t st_bytes = (sz - sa) * w * (uint32_t)sizeof(plane_t);
     // ---- LDS: level map | strip | NGTDM accumulators | short-run table
     uint32_t o = 0;
-    uint16_t* const s_lvlmap = (uint16_t*)(lds_raw + o); o = align16u(o + 2u * (Lcap + 2));
-    unsigned char* const s_stage = lds_raw + o; o = align16u(o + mis + st_bytes + 16u);
+    uint16_t* const s_lvlmap = (uint16_t*)(lds_g + o); o = align16u(o + 2u * (Lcap + 2));
+    unsigned char* const s_stage = lds_g + o; o = align16u(o + mis + st_bytes + 16u);
     const uint32_t ng1 = Lcap + 1;                          // NGTDM rows: up to Ng + 1 (IBSI: row = level, 0 .. max)
     const bool ngt_lds = do_ngt && ng1 <= 1024;
     const uint32_t ngt_rep = ltex_ngt_rep(ng1), ngt_stride = ltex_ngt_stride(ng1), ngt_words = ngt_stride / 4u;
-    unsigned long long* const s_S = (unsigned long long*)(lds_raw + o); if (ngt_lds) o = align16u(o + ngt_rep * ngt_stride);
+    unsigned long long* const s_S = (unsigned long long*)(lds_g + o); if (ngt_lds) o = align16u(o + ngt_rep * ngt_stride);
     uint32_t* const s_N = (uint32_t*)(s_S + ng1 + 2);
     const bool rlm_lds = do_rlm && Lcap <= 128;
-    uint32_t* const s_short = (uint32_t*)(lds_raw + o); if (rlm_lds) o = align16u(o + 4u * ltex_rl_rep(Lcap) * ltex_rl_words(Lcap));
-    if (o > A.lds_strip_bytes) {                            // (sized by the host from the class bounds: cannot happen)
+    uint32_t* const s_short = (uint32_t*)(lds_g + o); if (rlm_lds) o = align16u(o + 4u * ltex_rl_rep(Lcap) * ltex_rl_words(Lcap));
+    if (o > A.lds_group_bytes) {                            // (sized by the host from the class bounds: cannot happen)
         if (tid == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
         return;
     }
@@ -476,11 +487,11 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
             dst16[i] = q;
         }
     }
-    ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res, tid);
+    ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res_g, tid);
     if (ngt_lds) for (uint32_t i = tid; i < ngt_rep * ngt_words; i += (uint32_t)BS) ((uint32_t*)s_S)[i] = 0;
     if (rlm_lds) for (uint32_t i = tid; i < ltex_rl_rep(Lcap) * ltex_rl_words(Lcap); i += (uint32_t)BS) s_short[i] = 0;
     __syncthreads();
-    const int Ng = s_res[0], Nuniq = s_res[1];
+    const int Ng = s_res_g[0], Nuniq = s_res_g[1];
     const plane_t* const strip = (const plane_t*)(s_stage + mis);
     // cell of box row r, column c; 0 outside the box (the callers test the column, a missing halo row is handled per row)
     auto cell = [=](uint32_t r, uint32_t c) -> uint32_t { return (uint32_t)strip[(r - sa) * w + c]; };
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(1024) void ltex_strip_kernel(const LtexArgs A, uint
             if (sN) { atomicAdd(&g_N[i], sN); atomicAdd(&g_S[i], sS); }
         }
     }
-    if (rlm_lds) ltex_rl_flush(s_short, Lcap, (uint32_t*)(R.base + R.L.rlm), R.L.slot_words, R.side, tid, BS);
+    if (rlm_lds) ltex_rl_flush(s_short, Lcap, (uint32_t*)(R.base + R.L.rlm), R.L.slot_words, R.side, tid, BS, ltex_rl_rep(Lcap));
 }
 
 // ---- after the strips: one workgroup per strip ------------------------------------------------------------------------------------
@@ -629,6 +640,7 @@ __global__ __launch_bounds__(256) void ltex_post_kernel(const LtexArgs A)
     __shared__ int s_res[2];
     __shared__ uint32_t s_nz[4], s_mx[4];
     constexpr int BS = 256;
+    constexpr uint32_t kPostRep = 2;                       // replicas of the run table: the joined runs are a few hundred per strip -- LDS per workgroup matters more
     if (blockIdx.x >= A.ctr[3]) return;
     const uint2 job = A.map_strip[blockIdx.x];
     LtexRoi R;
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(256) void ltex_post_kernel(const LtexArgs A)
     uint32_t* const s_short = (uint32_t*)(lds_raw + o);
     ltex_levels(R.base + R.L.flags, Lcap, greyInfo, s_lvlmap, (uint32_t*)nullptr, s_res, tid);
     if (do_szm) for (uint32_t i = tid; i < Lcap * S; i += BS) s_small[i] = 0;
-    if (rlm_lds) for (uint32_t i = tid; i < ltex_rl_rep(Lcap) * ltex_rl_words(Lcap); i += BS) s_short[i] = 0;
+    if (rlm_lds) for (uint32_t i = tid; i < kPostRep * ltex_rl_words(Lcap); i += BS) s_short[i] = 0;
     __syncthreads();
 
     if (do_rlm && s_res[0] >= 1) {
@@ -658,7 +670,7 @@ __global__ __launch_bounds__(256) void ltex_post_kernel(const LtexArgs A)
         auto rows_of = [=](uint32_t kk) { return min(rows_full, h - kk * rows_full); };
         auto top_of = [=](uint32_t kk, uint32_t dir, uint32_t c) { return rec[((uint64_t)kk * 6u + (dir - 1u)) * w + c]; };
         auto bot_of = [=](uint32_t kk, uint32_t dir, uint32_t c) { return rec[((uint64_t)kk * 6u + 3u + (dir - 1u)) * w + c]; };
-        uint32_t* const my_short = s_short + ((uint32_t)lane & (ltex_rl_rep(Lcap) - 1u)) * ltex_rl_words(Lcap);
+        uint32_t* const my_short = s_short + ((uint32_t)lane & (kPostRep - 1u)) * ltex_rl_words(Lcap);
         auto count_rec = [&](uint32_t dir, uint32_t lvl, uint32_t len) {
             const uint32_t m = (uint32_t)s_lvlmap[lvl] - 1u;
             if (rlm_lds && len <= kLtexRlmLds) atomicAdd(&my_short[ltex_rl_index(Lcap, dir, m, len)], 1u);
@@ -706,21 +718,68 @@ __global__ __launch_bounds__(256) void ltex_post_kernel(const LtexArgs A)
         }
         if (rlm_lds) {
             __syncthreads();
-            ltex_rl_flush(s_short, Lcap, gP, slot_words, Nr, tid, BS);
+            ltex_rl_flush(s_short, Lcap, gP, slot_words, Nr, tid, BS, kPostRep);
         }
     }
 
     if (do_szm) {
+        // Zones: the sweep left every cell's owner in the label plane.  A strip counts the cells of the owners that lie inside it in LDS
+        // (16-bit counters: a strip has at most 8192 cells, or one row); cells whose owner lies in an earlier strip add to the owner's
+        // global counter.  A zone none of whose cells sits in the strip's last row is complete here and is entered at once; the
+        // others -- they may go on below -- add their local count to the global counter and are listed for the finishing kernel.
         const plane_t* const plane = (const plane_t*)(R.base + R.L.plane);
+        const uint32_t* const labp = (const uint32_t*)(R.base + R.L.lab);
         uint32_t* const cnt = (uint32_t*)(R.base + R.L.cnt);
         uint32_t* const hdr = (uint32_t*)R.base;
         uint32_t* const big = (uint32_t*)(R.base + R.L.big);
+        uint32_t* const openl = (uint32_t*)(R.base + R.L.open);
         const uint32_t p0 = job.y * rows_full * w, p1 = min(p0 + rows_full * w, R.area);
+        const bool last_strip = job.y + 1u >= K;
+        uint32_t* const s_loc = s_short + (rlm_lds ? kPostRep * ltex_rl_words(Lcap) : 0u);   // [(p1 - p0 + 1) / 2] words of two 16-bit counters
+        __syncthreads();                                        // (the run tables above are flushed)
+        for (uint32_t i = tid; i < (p1 - p0 + 2u) / 2u; i += BS) s_loc[i] = 0;
+        __syncthreads();
+        for (uint32_t p = p0 + (uint32_t)tid; p < p1; p += BS) {
+            const uint32_t lab = labp[p];
+            if (lab == kNone) continue;
+            if (lab >= p0) { const uint32_t q = lab - p0; atomicAdd(&s_loc[q >> 1], 1u << (16u * (q & 1u))); }
+        }
+        // cells of zones owned above the strip: one atomic per string of equal owners among a wave's 64 consecutive cells (the
+        // background corners of a box are ONE zone each: cell by cell, its millions of adds would all go to one address)
+        for (uint32_t pb = p0 + (uint32_t)(wave * 64); pb < p1; pb += BS) {
+            const uint32_t p = pb + (uint32_t)lane;
+            const uint32_t lab = p < p1 ? labp[p] : kNone;
+            const bool far = lab != kNone && lab < p0;
+            const uint32_t ln = lane_plus1(lab, kNone);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(far && lane < 63 && ln == lab);
+            if (far && !(lane > 0 && ((same >> (lane - 1)) & 1ull)))
+                atomicAdd(&cnt[lab], (uint32_t)__ffsll((long long)~(same >> lane)));
+        }
+        __syncthreads();
+        if (!last_strip)
+            for (uint32_t p = p1 - w + (uint32_t)tid; p < p1; p += BS) {
+                const uint32_t lab = labp[p];
+                if (lab != kNone && lab >= p0) { const uint32_t q = lab - p0; atomicOr(&s_loc[q >> 1], 0x8000u << (16u * (q & 1u))); }
+            }
+        __syncthreads();
         uint32_t nzone = 0, sz_max = 0;
         for (uint32_t p = p0 + (uint32_t)tid; p < p1; p += BS) {
-            const uint32_t sz = cnt[p];
-            if (sz == 0) continue;
-            cnt[p] = 0;                                     // (the table serves as "zones per size" in the finishing kernel)
+            const uint32_t q = p - p0;
+            const uint32_t c = (s_loc[q >> 1] >> (16u * (q & 1u))) & 0xFFFFu;
+            if (c == 0) continue;
+            const uint32_t sz = c & 0x7FFFu;
+            if (c & 0x8000u) {                                  // may go on below: the finishing kernel enters it
+                atomicAdd(&cnt[p], sz);
+                // (one cursor add per wave: a thousand zones per ROI adding to the one word serialise in L2)
+                const unsigned long long om = __builtin_amdgcn_ballot_w64(true);
+                const int leader = (int)__builtin_ctzll(om);
+                uint32_t base_slot = 0;
+                if (lane == leader) base_slot = atomicAdd(&hdr[LTEX_H_NOPEN], (uint32_t)__builtin_popcountll(om));
+                base_slot = (uint32_t)__builtin_amdgcn_readlane((int)base_slot, leader);
+                const uint32_t slot = base_slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+                if (slot < R.L.open_cap) openl[slot] = p;
+                continue;
+            }
             nzone++;
             sz_max = sz > sz_max ? sz : sz_max;
             const uint32_t raw = (uint32_t)plane[p];
@@ -847,11 +906,41 @@ __global__ __launch_bounds__(256) void ltex_finish_kernel(const LtexArgs A)
             uint32_t* const hkey = (uint32_t*)(R.base + R.L.hash);
             uint32_t* const hval = hkey + hcap;
             uint32_t* const g_small = (uint32_t*)(R.base + R.L.small);
-            uint32_t* const sj = (uint32_t*)(R.base + R.L.cnt);        // zones per size (zeroed again by the zone kernel)
+            uint32_t* const sj = (uint32_t*)(R.base + R.L.cnt);        // zones per size (all zero again once the open zones are read off below)
             const uint32_t* const big = (const uint32_t*)(R.base + R.L.big);
             uint32_t* const s_si = (uint32_t*)s_work;        // [Ng] zones per level
-            const uint32_t n_big = min(hdr[LTEX_H_NBIG], R.L.big_cap);
-            if (tid == 0) s_flag = hdr[LTEX_H_NBIG] > R.L.big_cap ? 1u : 0u;
+            // the zones that reached their strip's last row: their cells were counted by several strips into the owner's counter
+            uint32_t* const bigw = (uint32_t*)(R.base + R.L.big);
+            {
+                const uint32_t n_open = min(hdr[LTEX_H_NOPEN], R.L.open_cap);
+                const uint32_t* const openl = (const uint32_t*)(R.base + R.L.open);
+                const bool P16r = A.plane16 != 0;
+                const unsigned char* const pl = R.base + R.L.plane;
+                const uint32_t bgmin = greyInfo > 0 ? 1u : 0u;
+                uint32_t nz = 0, mx = 0;
+                for (uint32_t i = tid; i < n_open; i += BS) {
+                    const uint32_t p = openl[i];
+                    const uint32_t sz = sj[p];
+                    sj[p] = 0;                               // (the table serves as "zones per size" below)
+                    nz++;
+                    mx = sz > mx ? sz : mx;
+                    const uint32_t raw = P16r ? (uint32_t)((const uint16_t*)pl)[p] : (uint32_t)pl[p];
+                    const uint32_t rowi = (uint32_t)s_lvlmap[raw > bgmin ? raw : bgmin] - 1u;
+                    if (sz <= S) atomicAdd(&g_small[rowi * kLtexSmall + (sz - 1u)], 1u);
+                    else {
+                        const uint32_t slot = atomicAdd((uint32_t*)&hdr[LTEX_H_NBIG], 1u);
+                        if (slot < R.L.big_cap) bigw[slot] = (rowi << 20) | sz;
+                    }
+                }
+                nz = wave_sum_t<uint32_t>(nz);
+                mx = wave_max_u32(mx);
+                if (lane == 0 && nz) { atomicAdd((uint32_t*)&hdr[LTEX_H_NZONE], nz); atomicMax((uint32_t*)&hdr[LTEX_H_SZMAX], mx); }
+                if (tid == 0 && hdr[LTEX_H_NOPEN] > R.L.open_cap) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);   // (sized for every boundary cell: cannot happen)
+                blk_sync<true>();
+            }
+            const uint32_t n_bigr = __hip_atomic_load(&hdr[LTEX_H_NBIG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t n_big = min(n_bigr, R.L.big_cap);
+            if (tid == 0) s_flag = n_bigr > R.L.big_cap ? 1u : 0u;
             for (int i = tid; i < Ng; i += BS) s_si[i] = 0;
             // the larger zones: an ORDERED linear-probing hash (a key is displaced only by a larger one), so the layout -- hence the
             // order of the floating-point sums over it -- is a function of the key set (roi_texture.hip)
@@ -886,8 +975,8 @@ __global__ __launch_bounds__(256) void ltex_finish_kernel(const LtexArgs A)
                     key = val ? ((idx / kLtexSmall) << 20) | ((idx % kLtexSmall) + 1u) : 0u;
                 }
             };
-            const double sum_p = (double)hdr[LTEX_H_NZONE];
-            const uint32_t sz_max = hdr[LTEX_H_SZMAX];
+            const double sum_p = (double)__hip_atomic_load(&hdr[LTEX_H_NZONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t sz_max = __hip_atomic_load(&hdr[LTEX_H_SZMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (uint32_t i = tid; i < n_cells; i += BS) {
                 uint32_t key, val;
                 cell(i, key, val);
@@ -1093,7 +1182,7 @@ int launch_large_texture(const LtexArgs& a, void* stream)
             const struct { const void* f; int bytes; } k[] = {
                 {(const void*)ltex_load_kernel<false>, 64 * 1024}, {(const void*)ltex_load_kernel<true>, 64 * 1024},
                 {(const void*)ltex_strip_kernel<false>, 144 * 1024}, {(const void*)ltex_strip_kernel<true>, 144 * 1024},
-                {(const void*)ltex_post_kernel<false>, 96 * 1024}, {(const void*)ltex_post_kernel<true>, 96 * 1024},
+                {(const void*)ltex_post_kernel<false>, 128 * 1024}, {(const void*)ltex_post_kernel<true>, 128 * 1024},
                 {(const void*)ltex_finish_kernel, 144 * 1024}};
             for (const auto& e : k)
                 if (hipError_t rc = hipFuncSetAttribute(e.f, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes); rc != hipSuccess) return (int)rc;
@@ -1105,7 +1194,7 @@ int launch_large_texture(const LtexArgs& a, void* stream)
     else hipLaunchKernelGGL(ltex_load_kernel<false>, dim3(a.cap_load), dim3(256), a.lds_load_bytes, st, a);
     const uint32_t n_sweep = (a.mask & NYXHIP_FAM_GLSZM) ? a.n_list : 0u;
     const bool strips = (a.mask & (NYXHIP_FAM_GLRLM | NYXHIP_FAM_NGTDM)) != 0;
-    const uint32_t grid = n_sweep + (strips ? a.cap_strip : 0u);
+    const uint32_t grid = n_sweep + (strips ? (a.cap_strip + a.strip_groups - 1) / a.strip_groups : 0u);
     if (grid) {
         if (a.plane16) hipLaunchKernelGGL(ltex_strip_kernel<true>, dim3(grid), dim3(a.strip_threads), a.lds_strip_bytes, st, a, n_sweep);
         else hipLaunchKernelGGL(ltex_strip_kernel<false>, dim3(grid), dim3(a.strip_threads), a.lds_strip_bytes, st, a, n_sweep);
