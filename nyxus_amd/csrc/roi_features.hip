@@ -327,6 +327,197 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
     wav_sync<false>();
 }
 
+// ---- the same for matrices of up to 8 levels: EIGHT lanes per angle, two ROIs per wave ---------------------------------------------
+// At eight levels (the metric's coarse grey depth) half of a 16-lane row idles in everything but the cell pass.  Here a group of
+// eight lanes owns an angle; groups 0-3 take the angles of the wave's first ROI, groups 4-7 those of its second: the instruction
+// stream is issued once for two ROIs (1086 -> ~600 vector instructions per ROI).  Same quantities, same formulas as
+// glcm_features_wave16; only the grouping of the lane sums differs (1e-15 level).
+__device__ __forceinline__ uint32_t grp8_sum(uint32_t v) { v += dpp_perm<0xB1>(v); v += dpp_perm<0x4E>(v); v += dpp_perm<0x141>(v); return v; }
+__device__ __forceinline__ double grp8_sum(double v) { v += dpp_perm<0xB1>(v); v += dpp_perm<0x4E>(v); v += dpp_perm<0x141>(v); return v; }
+__device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const uint32_t* P_b, int n_slots, int Ng_a, int Ng_b, double* scr_base, int scr_stride,
+                                                    double soft_nan, double* fslots, double* sums, int lane)
+{
+    const int grp = lane >> 3, l = lane & 7, sel = grp >> 2, slot_raw = grp & 3;
+    const int Ng = sel ? Ng_b : Ng_a;
+    const int NN = Ng * Ng;
+    const bool live = slot_raw < n_slots && Ng != 0;
+    const int slot = slot_raw < n_slots ? slot_raw : 0;            // idle groups shadow slot 0 of their ROI and never store
+    const uint32_t* P = (sel ? P_b : P_a) + mul24((uint32_t)slot, (uint32_t)NN);
+    const int gslot = sel * kMaxAngles + slot;
+    double* pcol_s = scr_base + mul24((uint32_t)gslot, (uint32_t)scr_stride);
+    double* prow_s = pcol_s + 8;
+    double* Pxpy = pcol_s + 16;                                    // [2 Ng - 1 <= 15]
+    double* f = fslots + gslot * 32;
+    double* sm = sums + gslot * 32;
+
+    // ---- marginal counts: lane i < Ng owns column i, row i and the diagonal pair |x - y| = i
+    uint32_t cc = 0, rc = 0, dc = 0;
+    if (l < Ng) {
+        const uint32_t lN = mul24((uint32_t)l, (uint32_t)Ng);
+        uint32_t ic = (uint32_t)l;
+#pragma unroll 1
+        for (int j = 0; j < Ng; j++, ic += (uint32_t)Ng) {
+            cc += P[ic];
+            rc += P[lN + (uint32_t)j];
+        }
+        uint32_t i1 = lN, i2 = (uint32_t)l;
+#pragma unroll 1
+        for (int x = l; x < Ng; x++, i1 += (uint32_t)Ng + 1u, i2 += (uint32_t)Ng + 1u) {
+            dc += P[i1];
+            if (l > 0) dc += P[i2];
+        }
+    }
+    const uint32_t l1 = (uint32_t)l + 1u;
+    const uint32_t csum = grp8_sum(rc);                            // sum_p (glcm.cpp:481-484)
+    const uint32_t Sr_i = grp8_sum(mul24(rc, l1)), Sc_i = grp8_sum(mul24(cc, l1));
+    const uint32_t con_i = grp8_sum(mul24(dc, (uint32_t)(l * l))), dis_i = grp8_sum(mul24(dc, (uint32_t)l));
+    const bool empty = csum == 0;                                  // glcm.cpp:260-295 -> soft NaN for this angle
+    const double sum_p = empty ? 1.0 : (double)csum;
+    const double inv_sum_p = fdiv(1.0, sum_p);
+    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
+    const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
+    if (live && l < Ng) { pcol_s[l] = pcol; prow_s[l] = prow; }
+    double pxpy[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = l + 8 * u;
+        if (k < 2 * Ng - 1) {
+            uint32_t c = 0;
+            const int x0 = k - (Ng - 1) > 0 ? k - (Ng - 1) : 0, x1 = k < Ng - 1 ? k : Ng - 1;
+            uint32_t ix = mad24((uint32_t)x0, (uint32_t)Ng, (uint32_t)(k - x0));
+#pragma unroll 1
+            for (int x = x0; x <= x1; x++, ix += (uint32_t)Ng - 1u) c += P[ix];
+            pxpy[u] = fdiv((double)c, sum_p);
+        }
+    }
+    (void)Pxpy;
+    wav_sync<false>();
+
+    // ---- the cell pass
+    double ent = 0, hxy1 = 0, hxy2 = 0, asm_d = 0;
+    uint32_t acor_i = 0, asm_i = 0, cmax = 0;
+    const bool big = csum >= 65536u;
+    {
+        RowCol rcw((uint32_t)l, 8u, (uint32_t)(Ng ? Ng : 1), RowCol::small_t{});
+        for (int e = l; e < NN; e += 8, rcw.advance()) {
+            const uint32_t r = rcw.row, c = rcw.col, cnt = P[e];
+            const double p = (double)cnt * inv_sum_p;
+            if (big) asm_d = __builtin_fma(p, p, asm_d);
+            else asm_i = mad24(cnt, cnt, asm_i);
+            acor_i = mad24(cnt, mul24(r + 1u, c + 1u), acor_i);
+            cmax = cnt > cmax ? cnt : cmax;
+            ent = __builtin_fma(p, (double)fast_log2f(p + 0.000000001), ent);
+            const double pp = pcol_s[c] * prow_s[r];
+            const double lg = (double)fast_log2f(pp + 0.000000001);
+            hxy1 = __builtin_fma(p, lg, hxy1);
+            hxy2 = __builtin_fma(pp, lg, hxy2);
+        }
+    }
+    const double hx_t = l < Ng ? plogp(pcol, pcol) : 0.0;
+    {
+        double t4[4] = {ent, hxy1, hxy2, hx_t};
+        transpose_sum_step<0x141, 2>(t4, (l & 4) != 0);              // lane l of the group ends with the group total of slot 2 * bit2 + bit1
+        transpose_sum_step<0x4E, 1>(t4, (l & 2) != 0);
+        double tot = t4[0];
+        tot += dpp_perm<0xB1>(tot);
+        if (live && (l & 1) == 0) sm[1 + (l >> 1)] = tot;            // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
+    }
+    acor_i = grp8_sum(acor_i);
+    asm_i = grp8_sum(asm_i);
+    if (big) asm_d = grp8_sum(asm_d);
+    {
+        uint32_t o;
+        o = dpp_perm<0xB1>(cmax); cmax = o > cmax ? o : cmax;
+        o = dpp_perm<0x4E>(cmax); cmax = o > cmax ? o : cmax;
+        o = dpp_perm<0x141>(cmax); cmax = o > cmax ? o : cmax;
+    }
+
+    // ---- one term per lane: features of the marginal distributions
+    double t16[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t16[k] = 0.0;
+    if (l < Ng) {
+        const double dr = (double)l1 - mr, dcl = (double)l1 - mc, dr2 = dr * dr;
+        t16[0] = prow * dr2;                                         // f_corr :617
+        t16[1] = pcol * (dcl * dcl);                                 // :626
+        t16[2] = (double)rc * dr2;                                   // f_var :672
+        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
+        const double q = pxmy, kd = (double)l, Ngd = (double)Ng;
+        t16[4] = fdiv(q, (double)(1 + l * l));                       // f_idm :685-687
+        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
+        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
+        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
+        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
+        t16[9] = l >= 1 ? q / (kd * kd) : 0.0;                       // :1123-1128
+        t16[10] = kd * q;                                            // f_difference_avg :791-792
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = l + 8 * u;
+        if (k < 2 * Ng - 1) {
+            const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
+            t16[11] += ks * q;                                       // f_savg :700-701
+            t16[12] += plogp(q, q);                                  // f_sentropy :712-716
+            const double m = ks - mc - mc, m2 = m * m;               // CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+            t16[13] += m2 * m2 * q;
+            t16[14] += m2 * m * q;
+            t16[15] += m2 * q;
+        }
+    }
+    {
+        transpose_sum_step<0x141, 8>(t16, (l & 4) != 0);             // lane l of the group ends with the totals of slots 2 l and 2 l + 1
+        transpose_sum_step<0x4E, 4>(t16, (l & 2) != 0);
+        transpose_sum_step<0xB1, 2>(t16, (l & 1) != 0);
+        if (live) { sm[8 + 2 * l] = t16[0]; sm[8 + 2 * l + 1] = t16[1]; }
+    }
+    wav_sync<false>();
+    const double davg = sm[8 + 10];
+    double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
+    if (l < Ng) { const double dk = (double)l - davg; dv = dk * dk * pxmy; }
+    dv = grp8_sum(dv);
+
+    if (live && l == 0) {
+        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
+        const double asm_t = big ? asm_d : (double)asm_i * inv_sum_p * inv_sum_p;
+        const double cov_t = ((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i) * (inv_sum_p * inv_sum_p);
+        f[G_ASM] = asm_t;
+        f[G_ENERGY] = asm_t;
+        f[G_CONTRAST] = (double)con_i * inv_sum_p;
+        f[G_ACOR] = (double)acor_i * inv_sum_p;
+        f[G_ENTROPY] = -ent_t;
+        f[G_JE] = -ent_t;
+        f[G_DIS] = (double)dis_i * inv_sum_p;
+        f[G_JMAX] = (double)cmax * inv_sum_p;
+        f[G_JAVE] = mr;
+        f[G_VARIANCE] = sm[8 + 2] * inv_sum_p;
+        f[G_CLUPROM] = sm[8 + 13];
+        f[G_CLUSHADE] = sm[8 + 14];
+        f[G_CLUTEND] = sm[8 + 15];
+        f[G_SUMVARIANCE] = sm[8 + 15];
+        f[G_JVAR] = sm[8 + 3];
+        const double vv = sm[8 + 0] * sm[8 + 1];
+        f[G_CORRELATION] = !(sm[8 + 0] > 0.0 && sm[8 + 1] > 0.0) ? soft_nan : cov_t * frsq(vv);
+        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t))));
+        f[G_IDM] = sm[8 + 4];
+        f[G_HOM2] = sm[8 + 4];
+        f[G_HOM1] = sm[8 + 7];
+        f[G_SUMAVERAGE] = sm[8 + 11];
+        f[G_SUMENTROPY] = -sm[8 + 12];
+        f[G_DIFENTRO] = -sm[8 + 5];
+        f[G_DIFAVE] = davg;
+        f[G_DIFVAR] = dv;
+        f[G_IDMN] = sm[8 + 6];
+        f[G_ID] = sm[8 + 7];
+        f[G_IDN] = sm[8 + 8];
+        f[G_IV] = sm[8 + 9];
+        const double r1 = (ent_t - hxy1_t) / hx;
+        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+        if (empty)
+            for (int k = 0; k < kGlcmAngled; k++) f[k] = soft_nan;
+    }
+    wav_sync<false>();
+}
+
 // ---- GLCM features of a matrix of up to 64 levels: one wave per angle, lane = column (the reference's default grey depth) ----
 // Same organisation as glcm_features_wave16 (marginal sums carry everything they can, only ASM / ACOR / ENTROPY / JMAX / the
 // covariance term / HXY1 / HXY2 visit the cells), on the 16-bit matrices of the G16 launches: element (centre, neighbour) of
@@ -2459,6 +2650,74 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
     }
 }
 
+// The same for matrices of up to 8 levels: two ROIs per wave (glcm_features_wave8), eight per workgroup.
+__global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t slot0 = ((uint64_t)blockIdx.x * kWaves + wave) * 2;
+    uint64_t roi[2] = {0, 0};
+    int Ng[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (roi_of_slot(A.sp, slot0 + q, A.n_roi, roi[q])) Ng[q] = (int)A.glcm_ng[roi[q]];
+    if (Ng[0] == 0 && Ng[1] == 0)
+        return;                                       // degenerate / skipped ROIs: roi_features_kernel wrote the columns
+    const int na = A.glcm_na, ngc = (int)A.L.ng_cap;
+    // per-wave carve-out: counts [2][na * ngc^2] u32 | per group (8): pcol [8] prow [8] pxpy [16] | features [8][32] | sums [8][32]  (doubles)
+    const size_t cnt_bytes = ((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15;
+    const size_t per_wave = 2 * cnt_bytes + 8ull * (2 * kMaxAngles * 32 + 2 * 2 * kMaxAngles * 32);
+    unsigned char* base = lds_raw + (size_t)wave * per_wave;
+    uint32_t* s_P[2] = {(uint32_t*)base, (uint32_t*)(base + cnt_bytes)};
+    double* s_scr = (double*)(base + 2 * cnt_bytes);
+    double* s_f = s_scr + 2 * kMaxAngles * 32;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (Ng[q] == 0) continue;
+        const uint32_t* src = A.glcm_ws + roi[q] * A.glcm_ws_stride;
+        const int nw = na * Ng[q] * Ng[q];
+        if (((nw | (int)A.glcm_ws_stride) & 3) == 0) {
+#pragma unroll 1
+            for (int i = lane; i < (nw >> 2); i += 64) ((uint4*)s_P[q])[i] = ((const uint4*)src)[i];
+        } else {
+#pragma unroll 1
+            for (int i = lane; i < nw; i += 64) s_P[q][i] = src[i];
+        }
+    }
+    wav_sync<false>();
+    glcm_features_wave8(s_P[0], s_P[1], na, Ng[0], Ng[1], s_scr, 32, A.soft_nan, s_f, s_f + 2 * kMaxAngles * 32, lane);
+    wav_sync<false>();
+    const int sh = na == 4 ? 2 : na == 2 ? 1 : na == 1 ? 0 : -1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (Ng[q] == 0) continue;
+        double* o = A.out + roi[q] * A.ld + A.col_glcm;
+        const double* fq = s_f + q * kMaxAngles * 32;
+        for (int c = lane; c < kGlcmAngled * na; c += 64) {           // feature-major, angle-minor (output_2_buffer.cpp:336-346)
+            const int k = sh >= 0 ? c >> sh : c / na, a = c - k * na;
+            o[c] = fq[a * 32 + k];
+        }
+        for (int j = lane; j < kGlcmAve; j += 64) {                   // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+            const int k = c_glcm_ave_order[j];
+            double init = 0.0;
+            int a = 0;
+            for (; na - a >= 4; a += 4) {
+                const double v1 = fq[a * 32 + k] + fq[(a + 1) * 32 + k];
+                const double v2 = fq[(a + 2) * 32 + k] + fq[(a + 3) * 32 + k];
+                init = init + (v1 + v2);
+            }
+            for (; a < na; a++) init = init + fq[a * 32 + k];
+            o[kGlcmAngled * na + j] = na == 4 ? init * 0.25 : na == 2 ? init * 0.5 : na ? init / (double)na : 0.0;
+        }
+    }
+}
+
+size_t glcm_features8_lds(uint32_t ng_cap)
+{
+    const size_t cnt_bytes = ((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15;
+    return (2 * cnt_bytes + 8ull * (2 * kMaxAngles * 32 + 2 * 2 * kMaxAngles * 32)) * kWaves;
+}
+
 size_t glcm_features_lds(uint32_t ng_cap)
 {
     const size_t per_wave = (((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15) + 8ull * (ng_cap + kMaxAngles * 6 * ng_cap + 2 * kMaxAngles * 32);
@@ -2587,7 +2846,11 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
            : c16 ? (split ? launch_lds_variant<true, true, false>(a, st, grid) : launch_lds_variant<true, false, false>(a, st, grid))
                  : (split ? launch_lds_variant<false, true, false>(a, st, grid) : launch_lds_variant<false, false, false>(a, st, grid));
     if (rc == 0 && split) {
-        hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
+        static const bool no_pairs = [] { const char* e = getenv("NYXHIP_GLCM_NO_PAIRS"); return e && *e && *e != '0'; }();   // A/B knob
+        if (a.L.ng_cap <= 8 && !no_pairs)         // eight lanes per angle, two ROIs per wave
+            hipLaunchKernelGGL(glcm_features_kernel8, dim3((grid + 2 * kWaves - 1) / (2 * kWaves)), dim3(kBlock), glcm_features8_lds(a.L.ng_cap), st, a);
+        else
+            hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
         rc = (int)hipGetLastError();
     }
     return rc;
