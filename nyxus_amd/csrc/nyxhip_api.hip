@@ -1334,7 +1334,12 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     int rc = 0;
     auto enter_lane = [&](int lane) -> int {             // the class's launches go to lane `lane`, forked from the main stream at the start of the call
         if (!ctx->lane_stream[lane]) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
+            // (the lanes carry chains of short, latency-bound kernels -- a few hundred workgroups each -- beside the main stream's
+            //  chip-filling grids: at the device's highest priority their workgroups are placed first and the chain is not starved)
+            static const bool no_prio = [] { const char* e = getenv("NYXHIP_NO_LANE_PRIORITY"); return e && *e && *e != '0'; }();   // A/B knob
+            int lo = 0, hi = 0;
+            if (no_prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->lane_stream[lane], hipStreamNonBlocking, hi));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
         }
         if (!ctx->lane_used[lane]) {
@@ -1671,7 +1676,31 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
                     max_range = std::max(max_range, h[H_RANGE]); max_side = std::max(max_side, h[H_SIDE]);
                 }
             }
-            for (int cls = kClasses - 1; cls >= 0 && (mask & ~kMoments); cls--) {   // largest ROIs first: their long workgroups start early
+            // The size classes beyond LDS (3 and 4, either table width) go through the same several-workgroups-per-ROI kernels, which cut
+            // every ROI by its own box: they run as ONE launch group (their lists are neighbours in the class order) -- four groups of
+            // a handful of ROIs each cost four times the ten-odd launches and workspace clears of a group (~0.1 ms apiece on the mixed
+            // batch).  Nothing an ROI's row depends on changes: the slab / strip cut is invisible by construction.
+            static const bool no_merge = [] { const char* e = getenv("NYXHIP_NO_MERGE_LARGE"); return e && *e && *e != '0'; }();   // A/B knob
+            int first_cls = kClasses - 1;
+            if (!no_merge && (mask & ~kMoments)) {
+                uint32_t cnt = 0; int top = -1;
+                Extrema Em{0, 0, 0, 0, 0, false};
+                ClassTotals tm{0, 0, 0};
+                for (int cls = 2 * kFirstLargeSizeClass; cls < kClasses; cls++) {
+                    const uint32_t* h = H + cls * H_WORDS;
+                    if (h[H_COUNT] == 0) continue;
+                    cnt += h[H_COUNT]; top = cls;
+                    Em.px = std::max(Em.px, h[H_PX]); Em.area = std::max(Em.area, h[H_AREA]); Em.range = std::max(Em.range, h[H_RANGE]);
+                    Em.side = std::max(Em.side, h[H_SIDE]); Em.vmax = std::max(Em.vmax, h[H_VMAX]);
+                    tm.px += ((uint64_t)h[H_SUMPX_HI] << 32) | h[H_SUMPX]; tm.area += ((uint64_t)h[H_SUMAREA_HI] << 32) | h[H_SUMAREA];
+                    tm.range1 += ((uint64_t)h[H_SUMRANGE_HI] << 32) | h[H_SUMRANGE];
+                }
+                if (top >= 0)
+                    if (int rc = timed_class(top, cnt, Em, list + H[2 * kFirstLargeSizeClass * H_WORDS + H_OFFSET], cnt, 0, 0xF, &tm))
+                        return rc;
+                first_cls = 2 * kFirstLargeSizeClass - 1;
+            }
+            for (int cls = first_cls; cls >= 0 && (mask & ~kMoments); cls--) {   // largest ROIs first: their long workgroups start early
                 const uint32_t* h = H + cls * H_WORDS;
                 if (h[H_COUNT] == 0) continue;
                 const Extrema E{h[H_PX], h[H_AREA], h[H_RANGE], h[H_SIDE], h[H_VMAX], (cls & 1) != 0 && cls / 2 < kSizeClasses - 1};
