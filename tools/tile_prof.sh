@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 TAG=${1:-tile}; N=${2:-1000}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 1 --warmup 1 --tiles 16 --no-cpu-baseline --no-check --tile-path-tiles $N > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 1 --warmup 1 --tiles 16 --no-cpu-baseline --no-check --no-extras --tile-path-tiles $N > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['tile_path'])"
 python3 - <<PY
 import csv,glob
