@@ -49,6 +49,7 @@ struct nyxhip_ctx {
     // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
     double* d_bank = nullptr;
     float* d_bank32 = nullptr;       // the bank rounded to fp32 (Gabor screening pass)
+    void* d_bank16 = nullptr;        // 16 x 16 banks: the band-pass filters as f16 B operands of the MFMA screening stage (ShapeArgs::gabor_bank16)
     std::vector<double> bank_key;
     uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
     uint32_t bank_box_mask = 0;                                  // ShapeArgs::gabor_box_mask of the uploaded bank
@@ -528,6 +529,7 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
         }
     if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
     if (ctx->d_bank32) { HIP_TRY(ctx, hipFree(ctx->d_bank32)); ctx->d_bank32 = nullptr; }
+    if (ctx->d_bank16) { HIP_TRY(ctx, hipFree(ctx->d_bank16)); ctx->d_bank16 = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank, bank.size() * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_bank, bank.data(), bank.size() * sizeof(double), hipMemcpyHostToDevice));
     {
@@ -535,6 +537,30 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
         for (size_t i = 0; i < bank.size(); i++) b32[i] = (float)bank[i];      // round to nearest: relative 2^-24 (the bound of the screening pass counts it)
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bank32, b32.size() * sizeof(float)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_bank32, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (n == 16 && nF > 0) {
+        // MFMA screening stage of roi_gabor_tiled_kernel (MODE 4): the band-pass filters in groups of four as B operands of
+        // v_mfma_f32_16x16x32_f16.  Operand (group g, tap-row pair jp), lane l = (column nn = l % 16, k block kb = l / 16), element t:
+        // tap (j', i') = (2 jp + kb / 2, 8 (kb % 2) + t) of the FLIPPED kernel -- the convolution as a correlation over the padded
+        // plane: out(a, b) = sum P[b + j'][a + 1 + i'] G[15 - j'][15 - i'] -- of filter 1 + 4 g + (nn % 8) / 2, component nn % 2,
+        // scaled by 2^14; columns 0 .. 7 carry the f16 nearest to the scaled tap, columns 8 .. 15 the f16 nearest to the rest.
+        const int groups = (nF + 3) / 4;
+        std::vector<_Float16> ops((size_t)groups * 8 * 64 * 8);
+        for (int g = 0; g < groups; g++)
+            for (int jp = 0; jp < 8; jp++)
+                for (int l = 0; l < 64; l++)
+                    for (int t = 0; t < 8; t++) {
+                        const int nn = l & 15, kb = l >> 4, f = 1 + 4 * g + ((nn & 7) >> 1), c = nn & 1, jq = 2 * jp + (kb >> 1), iq = 8 * (kb & 1) + t;
+                        _Float16 v = (_Float16)0.0f;
+                        if (f <= nF) {
+                            const double tap = bank[(((size_t)f * 16 + (15 - jq)) * 16 + (15 - iq)) * 2 + c] * kGaborTapScale;
+                            const _Float16 hi = (_Float16)tap;
+                            v = nn < 8 ? hi : (_Float16)(tap - (double)hi);
+                        }
+                        ops[(((size_t)g * 8 + jp) * 64 + l) * 8 + t] = v;
+                    }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bank16, ops.size() * sizeof(_Float16)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bank16, ops.data(), ops.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     }
     ctx->bank_key = key;
     return NYXHIP_OK;
@@ -841,7 +867,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= kClassPx[0] && E.side <= kClassSide[0]) ? 1 : 0;   // the smallest size class (a function of the ROI: roi_class)
-        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
     }
@@ -1852,6 +1878,7 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_bank) (void)hipFree(ctx->d_bank);
     if (ctx->d_bank32) (void)hipFree(ctx->d_bank32);
+    if (ctx->d_bank16) (void)hipFree(ctx->d_bank16);
     if (ctx->d_stamps) {
         unsigned long long h[32];
         if (hipMemcpy(h, ctx->d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -306,6 +306,7 @@ struct MomArgs {
 };
 
 // ---- third kernel pair: Gabor + Zernike (roi_shape.hip) -------------------------------------
+constexpr double kGaborTapScale = 16384.0;   // taps of the MFMA screening stage: f16 parts of tap x 2^14 (|tap| <= 1: the bank is L1-normalised)
 constexpr int kZernikeCols = 30;          // ZernikeFeature::NUM_FEATURE_VALS (zernike.h:30)
 
 struct ShapeLayout {
@@ -340,6 +341,8 @@ struct ShapeArgs {
     double soft_nan;
     const double* gabor_bank; // device: (F+1) filters (low-pass first), n*n complex taps each
     const float* gabor_bank32; // the same taps rounded to fp32 (the screening pass of roi_gabor_tiled_kernel, MODE 3)
+    const void* gabor_bank16; // 16 x 16 banks: [ceil(F / 4)][8 tap-row pairs][64 lanes] x 8 f16 -- the band-pass filters as B operands of the MFMA
+                              // screening stage (roi_gabor_tiled_kernel MODE 4; built by ensure_gabor_bank), or null
     int32_t gabor_nf, gabor_n;
     // 16 x 16 banks: per filter, bit j = every real part of tap row j is +-0, bit 16 + j = every imaginary part is.  Such a row adds
     // +-0 to the running sums, which leaves them as they are (they start at +0 and no sum of the scan is -0): the tiled kernel

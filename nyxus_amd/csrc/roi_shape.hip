@@ -218,9 +218,12 @@ constexpr int kGaborRedoCap = 512;
 // instead of four).
 // PF: the plane holds the intensities as fp32 bit patterns (MODE 3, every intensity of the ROI below 2^24: see the kernel) -- a
 // compile-time fact of the copy: as a run-time flag it put a branch on every tap of this loop (46.6 against 38.9 ms per 196 k ROIs).
+typedef __attribute__((address_space(3))) _Float16 lds_f16_t;
+typedef _Float16 gabor_h8 __attribute__((ext_vector_type(8)));
+typedef float gabor_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (the plane through LDS instructions: behind a generic pointer this function read it with flat loads)
-template <bool PF>
-__device__ __attribute__((noinline)) double gabor_exact_energy(const lds_u32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G)
+template <int PF>
+__device__ __attribute__((noinline)) double gabor_exact_energy(const lds_u32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G, uint32_t words = 0)
 {
     // (the bank pointer is the same in every lane; said so, the taps come through the scalar cache -- sixteen s_load per tap row
     //  instead of 512 vector loads per call -- and a row's sixteen window words are read before the first is used)
@@ -228,6 +231,24 @@ __device__ __attribute__((noinline)) double gabor_exact_energy(const lds_u32_t* 
     const bank_ptr_t Gu = (bank_ptr_t)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gp >> 32)) << 32) |
                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gp));
     double re = 0.0, im = 0.0;
+    if constexpr (PF == 2) {
+        // MODE 4 after the low-pass filter: the plane is two planes of f16 digits (same rows and pitch, `words` elements apart), whose
+        // sum is the intensity -- both conversions and the sum are exact
+        const lds_f16_t* rp = (const lds_f16_t*)s_plane + (b + 15) * pitch + a + 16;
+#pragma unroll 1
+        for (int j = 0; j < 16; j++, rp -= pitch) {
+            _Float16 wh[16], wl[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { wh[i] = rp[-i]; wl[i] = rp[(int)words - i]; }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double av = (double)((float)wh[i] + (float)wl[i]);
+                re += av * Gu[(j * 16 + i) * 2];
+                im += av * Gu[(j * 16 + i) * 2 + 1];
+            }
+        }
+        return sqrt(re * re + im * im);
+    }
     const lds_u32_t* rp = s_plane + (b + 15) * pitch + a + 16;
 #pragma unroll 1
     for (int j = 0; j < 16; j++, rp -= pitch) {
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // then reads its window without 23 conversions per tap row (26.7 k -> 24.2 k vector instructions per wave, 41.4 -> 38.9 ms per
     // 196 k ROIs); the copies that follow the reference's arithmetic convert fp32 -> fp64 instead of u32 -> fp64, the same value.
     // Zero padding is +0.0f.
-    const bool pf = MODE == 3 && A.max_inten[roi] < (1u << 24);
+    const bool pf = MODE >= 3 && A.max_inten[roi] < (1u << 24);
     for_each_cloud_pixel<kBlk>(A.inten + off, A.x + off, A.y + off, npx, tid, [&](uint32_t, uint32_t v, uint32_t px, uint32_t py) {
         if (px < w && py < h)
             s_plane[(py + 7) * pitch + px + 8] = pf ? __float_as_uint((float)v) : v;
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     uint32_t n_min = 0;                                // pixels of this thread whose low-pass energy equals tmin
 
     auto exact_energy = [&](uint32_t a, uint32_t b, const bank_ptr_t G) -> double { const lds_u32_t* pl = (const lds_u32_t*)s_plane;
-        return pf ? gabor_exact_energy<true>(pl, pitch, a, b, G) : gabor_exact_energy<false>(pl, pitch, a, b, G);
+        return pf ? gabor_exact_energy<1>(pl, pitch, a, b, G) : gabor_exact_energy<0>(pl, pitch, a, b, G);
     };
     bool lp_overflow = false;                          // MODE 2: the fused low-pass pass found more candidates than its list holds
     const double amax = (double)A.max_inten[roi];
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         const uint32_t zero_rows = ZR ? A.gabor_zero_rows[f] : 0u;
         const bool box = ZR && ((A.gabor_box_mask >> f) & 1u) && A.max_inten[roi] < (1u << 24);
         const double box_c = box ? G[0] : 0.0;
-        constexpr bool f32 = MODE == 3 && fuse;             // this copy screens in packed fp32 (see the kernel's header)
+        constexpr bool f32 = MODE >= 3 && fuse;             // this copy screens in packed fp32 (see the kernel's header)
         constexpr double kErr = f32 ? 3.2e-5 : 2.5e-13;     // |screened energy - reference's energy| <= kErr a_max
         const double thr_max = A.gabor_thr * maxval, thr_slack = __builtin_fma(kErr, amax, 1e-15 * thr_max);
         uint32_t sc = 0;
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll
                     for (int q = 0; q < W4; q++) {
                         const uint4 u = uw[q];
-                        if (MODE == 3) {                           // (a box filter implies intensities below 2^24: fp32 patterns)
+                        if (MODE >= 3) {                           // (a box filter implies intensities below 2^24: fp32 patterns)
                             wd[4 * q + 0] = (uint32_t)__uint_as_float(u.x); wd[4 * q + 1] = (uint32_t)__uint_as_float(u.y);
                             wd[4 * q + 2] = (uint32_t)__uint_as_float(u.z); wd[4 * q + 3] = (uint32_t)__uint_as_float(u.w);
                         } else {
@@ -485,7 +506,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 // tap rows whose real (imaginary) parts are all +-0 leave re (im) as it is: see ShapeArgs::gabor_zero_rows
                 // (MODE 3 keeps the row tests out of this copy -- it runs for the odd ROI only, and three variants of the tap block
                 //  next to the fp32 copy cost the kernel 45 spilled registers; a row of +-0 taps adds +-0: the same bits)
-                constexpr bool ZRU = ZR && MODE != 3;
+                constexpr bool ZRU = ZR && MODE < 3;
                 const bool re0 = ZRU && ((zero_rows >> j) & 1u), im0 = ZRU && ((zero_rows >> (16 + j)) & 1u);
                 if (re0 && im0)
                     continue;
@@ -495,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
 #pragma unroll
                 for (int q = 0; q < W4; q++) {
                     const uint4 u = uw[q];
-                    if (MODE == 3 && pf) {
+                    if (MODE >= 3 && pf) {
                         win[4 * q + 0] = (double)__uint_as_float(u.x); win[4 * q + 1] = (double)__uint_as_float(u.y);
                         win[4 * q + 2] = (double)__uint_as_float(u.z); win[4 * q + 3] = (double)__uint_as_float(u.w);
                     } else {
@@ -632,11 +653,148 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         }
         return true;
     };
+    // MODE 4: the band-pass filters' screening pass on the matrix pipe (measured standalone in tools/gabor_mfma_probe.hip).  After the
+    // low-pass filter the fp32 plane is rewritten IN PLACE as two planes of f16 digits -- intensity = main + rest, main the top eleven
+    // significant bits (exact in f16 below 2^16), rest the bits under them (a zero plane, skipped, when the ROI's intensities stay below
+    // 2^11) -- and four filters at a time run as v_mfma_f32_16x16x32_f16: M = 16 box rows at one column, K = two tap rows, N = (filter,
+    // re / im) x (hi, lo part of the tap x 2^14: ensure_gabor_bank), both digits into one fp32 accumulator.  A lane's eight K-elements
+    // are eight consecutive pixels of a plane row: a window of twelve pixels, three 8-byte LDS reads, serves four columns.
+    // Error of a screened component against the exact sum: taps (hi + lo) within 2^-22 relative + 2^-28 absolute even if f16
+    // subnormals were flushed (256 taps: <= 2.2e-6 a_max); accumulation: sixteen instructions of 32 products and one addend each -- were
+    // every one of those 33 additions TRUNCATED to 24 bits, <= 16 * 33 * 2^-23 sum |a w| -- and sqrt((sum |w_re|)^2 + (sum |w_im|)^2) <= sum
+    // |w| = 1 (the bank is L1-normalised), so the screened energy is within 6.3e-5 a_max + 2.2e-6 a_max (+ the epilogue's four fp32
+    // roundings, 3e-7 a_max) of the reference's: kErr = 6.8e-5, twice the band of the packed-fp32 pass; the probe measures 1.0e-8 a_max.
+    // Pixels inside the band go to the same list and are recomputed by the reference's arithmetic from the digit planes.
+    auto run_bands_mfma = [&]() {
+        constexpr int kHold = 32;
+        constexpr uint32_t kSub = (uint32_t)kGaborRedoCap / 4u;
+        const uint32_t maxi = A.max_inten[roi];
+        const uint32_t low_bits = maxi < 2048u ? 0u : (uint32_t)(21 - __builtin_clz(maxi)), low_mask = (1u << low_bits) - 1u;   // (bits - 11)
+        const bool two = low_bits != 0;
+        {
+            uint32_t hold[kHold];
+#pragma unroll
+            for (int q = 0; q < kHold; q++) { const uint32_t i = (uint32_t)tid + (uint32_t)q * kBlk; hold[q] = i < words ? s_plane[i] : 0u; }
+            __syncthreads();
+            _Float16* const dp = (_Float16*)s_plane;
+#pragma unroll
+            for (int q = 0; q < kHold; q++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)q * kBlk;
+                if (i < words) {
+                    const uint32_t v = (uint32_t)__uint_as_float(hold[q]);
+                    dp[i] = (_Float16)(float)(v & ~low_mask);
+                    dp[words + i] = (_Float16)(float)(v & low_mask);
+                }
+            }
+        }
+        constexpr double kErr = 6.8e-5, kScale2 = kGaborTapScale * kGaborTapScale;
+        const double thr_max = A.gabor_thr * maxval, S_thr = __builtin_fma(kErr, amax, 1e-15 * thr_max) + 3e-15 * amax;
+        const double t_lo = thr_max - S_thr > 0.0 ? thr_max - S_thr : 0.0, t_hi = thr_max + S_thr;
+        // (squared, in the accumulators' scale, rounded outwards: the conversion to fp32 moves a bound by 6e-8 relative at most)
+        const float lo2f = (float)(t_lo * t_lo * kScale2 * (1.0 - 3e-7)), hi2f = (float)(t_hi * t_hi * kScale2 * (1.0 + 3e-7));
+        const uint32_t n_x4 = w / 4u + 1u, n_rt = (h + 15u) / 16u, n_units = n_x4 * n_rt;   // columns 4 x4 - 1 .. 4 x4 + 2, rows 16 rt .. 16 rt + 15
+        const int nn = lane & 15, kb = lane >> 4;
+        const lds_f16_t* const dplane = (const lds_f16_t*)s_plane;
+        const gabor_h8* const ops = (const gabor_h8*)A.gabor_bank16;
+        for (int g = 0; 4 * g < nF; g++) {
+            if (tid < 4) s_redo[tid] = 0;                                          // four lists, one per filter of the group: [4 counters][4][kSub]
+            __syncthreads();
+            gabor_h8 Bw[8];
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++) Bw[jp] = ops[(g * 8 + jp) * 64 + lane];
+            const int f_lane = 1 + 4 * g + ((nn & 7) >> 1);                        // this lane's filter in the epilogue
+            const uint32_t fl_lane = (uint32_t)(nn & 7) >> 1;
+            const bool col_ok = (nn & 9) == 0 && f_lane <= nF;                     // (even column below 8: re^2 + im^2 of hi + lo lands there)
+            uint32_t cnt = 0;
+            for (uint32_t u = (uint32_t)wave; u < n_units; u += (uint32_t)NW) {
+                const uint32_t rt = u / n_x4, x4 = u - rt * n_x4;
+                // (rows beyond the box repeat its last row: their outputs are dropped, their reads stay inside the plane)
+                const uint32_t brow = min(16u * rt + (uint32_t)nn, h - 1u);
+                const lds_f16_t* const base = dplane + (brow + (uint32_t)(kb >> 1)) * pitch + 8u * (uint32_t)(kb & 1) + 4u * x4;
+                gabor_f4 C[4];
+#pragma unroll
+                for (int xs = 0; xs < 4; xs++) C[xs] = gabor_f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int jp = 0; jp < 8; jp++) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        if (d == 1 && !two) continue;
+                        const lds_f16_t* const rowp = base + (2 * jp) * pitch + (d ? words : 0u);
+                        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                        typedef const __attribute__((address_space(3))) u32x2_t* lds_u32x2_ptr;
+                        const u32x2_t q0 = *(lds_u32x2_ptr)rowp, q1 = *(lds_u32x2_ptr)(rowp + 4), q2 = *(lds_u32x2_ptr)(rowp + 8);
+                        const uint32_t w0 = q0.x, w1 = q0.y, w2 = q1.x, w3 = q1.y, w4 = q2.x, w5 = q2.y;
+                        uint4 av[4];
+                        av[0] = uint4{w0, w1, w2, w3};
+                        av[1] = uint4{__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16), __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16)};
+                        av[2] = uint4{w1, w2, w3, w4};
+                        av[3] = uint4{__builtin_amdgcn_alignbit(w2, w1, 16), __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16), __builtin_amdgcn_alignbit(w5, w4, 16)};
+#pragma unroll
+                        for (int xs = 0; xs < 4; xs++) {
+                            gabor_h8 Av;
+                            __builtin_memcpy(&Av, &av[xs], 16);
+                            C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, Bw[jp], C[xs], 0, 0, 0);
+                        }
+                    }
+                }
+                // epilogue: lane (column nn, rows 4 kb + r): hi-part column + lo-part column (eight lanes on), re^2 + im^2 (the lane beside)
+#pragma unroll
+                for (int xs = 0; xs < 4; xs++) {
+                    const uint32_t a = 4u * x4 + (uint32_t)xs - 1u;                // (column -1 of the first group: no such pixel)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float c = C[xs][r];
+                        c += __uint_as_float(dpp_perm<0x128>(__float_as_uint(c)));          // row_ror:8
+                        const float sq = c * c;
+                        const float e2 = sq + __uint_as_float(dpp_perm<0xB1>(__float_as_uint(sq)));   // quad_perm [1, 0, 3, 2]
+                        const uint32_t b = 16u * rt + 4u * (uint32_t)kb + (uint32_t)r;
+                        const bool valid = col_ok && a < w && b < h;
+                        const bool above = e2 > hi2f;
+                        if (valid && above) cnt++;
+                        if (valid && !above && e2 >= lo2f) {
+                            const uint32_t k = atomicAdd(&s_redo[fl_lane], 1u);
+                            if (k < kSub) s_redo[4u + fl_lane * kSub + k] = b * w + a;
+                        }
+                    }
+                }
+            }
+            // the four 16-lane rows of the wave hold the same columns
+            cnt += __shfl_xor(cnt, 16, 64);
+            cnt += __shfl_xor(cnt, 32, 64);
+            if (lane < 16 && col_ok) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + f_lane - 1] = (double)cnt;   // [wave][filter]
+            __syncthreads();
+            const lds_u32_t* const pl = (const lds_u32_t*)s_plane;
+            for (int fl = 0; fl < 4 && 4 * g + fl < nF; fl++) {                      // (a list per filter: the recomputation reads its taps through the scalar cache)
+                const bank_ptr_t G = bank + (size_t)(1 + 4 * g + fl) * N * N * 2;
+                const uint32_t nr = s_redo[fl];
+                uint32_t sc = 0;
+                if (nr > kSub) {
+                    // more pixels in the band than the list holds: this filter over the whole box with the reference's arithmetic
+                    for (uint32_t p = tid; p < area; p += kBlk) {
+                        const uint32_t b = p / w, a = p - b * w;
+                        if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
+                    }
+                    const uint32_t tot = (uint32_t)wave_sum_u64(sc);
+                    if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] = (double)tot;
+                } else if (nr != 0) {
+                    for (uint32_t k = tid; k < nr; k += kBlk) {
+                        const uint32_t p = s_redo[4u + (uint32_t)fl * kSub + k], b = p / w, a = p - b * w;
+                        if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
+                    }
+                    const uint32_t tot = (uint32_t)wave_sum_u64(sc);
+                    if (lane == 0 && tot) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] += (double)tot;
+                }
+            }
+            __syncthreads();
+        }
+    };
     for (int f = 0; f <= nF; f++) {
+        if constexpr (MODE == 4)
+            if (f == 1 && pf && A.max_inten[roi] < 65536u && words <= 32u * kBlk && A.gabor_bank16) { run_bands_mfma(); break; }
         bool go;
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
         else if constexpr (MODE == 1) go = run_filter(f, std::true_type{});
-        else if (MODE == 3 && !(amax < 16777216.0)) go = run_filter(f, std::false_type{});   // an intensity that fp32 does not hold exactly: the reference's arithmetic throughout
+        else if (MODE >= 3 && !(amax < 16777216.0)) go = run_filter(f, std::false_type{});   // an intensity that fp32 does not hold exactly: the reference's arithmetic throughout
         else if (f == 0 && NW == 1) go = run_filter(0, std::false_type{});   // one-wave launches (small ROIs): two recomputation calls cost more than the unfused low-pass
         else {
             go = run_filter(f, std::true_type{});
@@ -817,7 +975,8 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
                                (const void*)roi_gabor_tiled_kernel<8, 4, 2, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, false>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 2, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, true>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 3, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, false>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, 3, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, true>};
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 3, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, true>,
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 4, false>, (const void*)roi_gabor_tiled_kernel<8, 4, 4, true>};
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -843,7 +1002,7 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             e = getenv("NYXHIP_GABOR_EXACT");
             if (e && *e && *e != '0') return 0;
             e = getenv("NYXHIP_GABOR_MODE");
-            return (e && *e == '2') ? 2 : 3;
+            return (e && *e == '2') ? 2 : (e && *e == '3') ? 3 : 4;
         }();
         // worth its registers (the build with the row tests needs ~25 more: one wave per SIMD less) when at least 4 % of the
         // bank's arithmetic falls away: the reference's default bank (f0 = 0 in its first filter) saves 10.6 %, the 8-orientation
@@ -860,7 +1019,10 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, M, Z>), dim3(grid), dim3(64), a.L.total, st, a);               \
             else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, M, Z>), dim3(grid), dim3(256), a.L.total, st, a);                    \
         } while (0)
-        if (mode == 3 && a.gabor_bank32) { if (zr) NYX_GABOR_LAUNCH(3, true); else NYX_GABOR_LAUNCH(3, false); }
+        if (mode == 4 && a.gabor_bank32 && a.gabor_bank16 && !small) {
+            if (zr) hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, 4, true>), dim3(grid), dim3(256), a.L.total, st, a);
+            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, 4, false>), dim3(grid), dim3(256), a.L.total, st, a);
+        } else if (mode >= 3 && a.gabor_bank32) { if (zr) NYX_GABOR_LAUNCH(3, true); else NYX_GABOR_LAUNCH(3, false); }
         else if (mode >= 2) { if (zr) NYX_GABOR_LAUNCH(2, true); else NYX_GABOR_LAUNCH(2, false); }
         else if (mode == 1) { if (zr) NYX_GABOR_LAUNCH(1, true); else NYX_GABOR_LAUNCH(1, false); }
         else { if (zr) NYX_GABOR_LAUNCH(0, true); else NYX_GABOR_LAUNCH(0, false); }
