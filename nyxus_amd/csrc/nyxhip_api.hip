@@ -867,7 +867,7 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= kClassPx[0] && E.side <= kClassSide[0]) ? 1 : 0;   // the smallest size class (a function of the ROI: roi_class)
-        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; g.dbg_phase = getenv("NYXHIP_DBG_PHASE") ? atoi(getenv("NYXHIP_DBG_PHASE")) : 0; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
     }

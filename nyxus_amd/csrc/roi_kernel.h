@@ -355,6 +355,7 @@ struct ShapeArgs {
     uint32_t gabor_box_mask;
     double gabor_thr;
     int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
+    int32_t dbg_phase;        // diagnostic builds of roi_shape.hip (NYXHIP_GABOR_PHASE_EXITS): leave after phase 1..4; 0 otherwise
     SpillArgs sp;
     ShapeLayout L;
 };

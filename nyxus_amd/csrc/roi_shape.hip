@@ -295,6 +295,13 @@ __device__ __forceinline__ void pk_fma_bcast(v2f& acc, const v2f pair, const v2f
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(pair), "s"(g));
 }
 
+// Diagnostic builds only (-DNYXHIP_GABOR_PHASE_EXITS, NYXHIP_DBG_PHASE=1..4 at run time): a workgroup leaves after the plane build /
+// the low-pass filter / the digit planes / the MFMA screening -- the instruction counters of such runs give the phases' shares.
+#ifdef NYXHIP_GABOR_PHASE_EXITS
+#define NYX_GABOR_PHASE_EXIT(cond, stmt) do { if (cond) stmt; } while (0)
+#else
+#define NYX_GABOR_PHASE_EXIT(cond, stmt) do { } while (0)
+#endif
 template <int T, int NW, int MODE, bool ZR = false>
 __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_kernel(const ShapeArgs A)   // (MODE 2 / 3: held to 128 registers, four waves per SIMD like the other two)
 {
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     });
     __syncthreads();
 
+    NYX_GABOR_PHASE_EXIT(MODE == 4 && A.dbg_phase == 1, return);
     const bank_ptr_t bank = (bank_ptr_t)(uintptr_t)A.gabor_bank;
     const bank32_ptr_t bank32 = (bank32_ptr_t)(uintptr_t)A.gabor_bank32;
     // Tiles are dealt to lanes COLUMN-major in blocks of 16 rows: the LDS serves a ds_read_b128 in four fixed groups of 16 lanes
@@ -426,6 +434,83 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         const double M_lp = kErr * amax + 3e-15 * amax + 1e-15 * (Bs > bs ? Bs : bs);
         const double b_lo = Bs - M_lp > 0.0 ? Bs - M_lp : 0.0, b_hi = bs + M_lp;
         const double lp_hi2 = b_lo * b_lo * (1.0 - 1e-15), lp_lo2 = b_hi * b_hi * (1.0 + 1e-15);
+        // The low-pass filter as a box filter over intensities below 2^16 (the reference's default bank on 8- to 16-bit images): the
+        // 16 x 16 window sums stay below 2^24, so fp32 additions of the plane's fp32 patterns are exact in any order.  A thread owns
+        // T columns of TWO rows: the column sums over the fourteen tap rows the two outputs share are formed once, the three rows
+        // that differ (first, last of the upper output; last of the lower) go on top, and a sliding sum along the row finishes each
+        // -- 29 additions per output instead of the 122 operations of the tile loop below, half its LDS reads.  Threads a row pair
+        // apart walk the shared rows in opposite directions: with the row stride of a pair an even number of 16-byte units their
+        // reads would otherwise meet on half of the banks.  Energies are c * sum exactly (c a power of two; the square is exact,
+        // so is its root): extrema and the count at the minimum are taken on the sums.
+        const bool fbox = MODE >= 3 && ZR && box && f == 0 && amax < 65536.0;
+        if (fbox) {
+            const uint32_t n_rp = (h + 1u) / 2u, n_it = n_rp * tpr;
+            float smax = -1.0f, smin = __builtin_inff();
+            uint32_t cmin = 0;
+            for (uint32_t it = (uint32_t)tid; it < n_it; it += kBlk) {
+                const uint32_t cb = it / n_rp, rpi = it - cb * n_rp, b0 = 2u * rpi, a0 = cb * T;
+                const bool down = (rpi & 1u) != 0;
+                const uint32_t* const top = s_plane + b0 * pitch + a0;            // padded row b0: the first tap row of output row b0
+                const uint32_t* rowp = top + (down ? 14u : 1u) * pitch;
+                const int stride = down ? -(int)pitch : (int)pitch;
+                float V[T + 16];
+                {
+                    uint4 uw[W4];
+                    lds_load_window<W4>(rowp, uw);
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        V[4 * q] = __uint_as_float(uw[q].x); V[4 * q + 1] = __uint_as_float(uw[q].y);
+                        V[4 * q + 2] = __uint_as_float(uw[q].z); V[4 * q + 3] = __uint_as_float(uw[q].w);
+                    }
+                }
+#pragma unroll 1
+                for (int j = 1; j < 14; j++) {
+                    rowp += stride;
+                    uint4 uw[W4];
+                    lds_load_window<W4>(rowp, uw);
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        V[4 * q] += __uint_as_float(uw[q].x); V[4 * q + 1] += __uint_as_float(uw[q].y);
+                        V[4 * q + 2] += __uint_as_float(uw[q].z); V[4 * q + 3] += __uint_as_float(uw[q].w);
+                    }
+                }
+                const bool two_rows = b0 + 1u < h;                                 // (an odd box height: the last pair has one row; padded row b0 + 16 does not exist then)
+                {
+                    uint4 uz[W4];
+                    lds_load_window<W4>(top + 15u * pitch, uz);
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        V[4 * q] += __uint_as_float(uz[q].x); V[4 * q + 1] += __uint_as_float(uz[q].y);
+                        V[4 * q + 2] += __uint_as_float(uz[q].z); V[4 * q + 3] += __uint_as_float(uz[q].w);
+                    }
+                }
+                auto finish = [&](const uint32_t* erow, bool on) {
+                    uint4 ue[W4];
+                    lds_load_window<W4>(erow, ue);
+                    float wd[T + 16];
+#pragma unroll
+                    for (int q = 0; q < W4; q++) {
+                        wd[4 * q] = V[4 * q] + __uint_as_float(ue[q].x); wd[4 * q + 1] = V[4 * q + 1] + __uint_as_float(ue[q].y);
+                        wd[4 * q + 2] = V[4 * q + 2] + __uint_as_float(ue[q].z); wd[4 * q + 3] = V[4 * q + 3] + __uint_as_float(ue[q].w);
+                    }
+                    float sm = 0.0f;                                               // taps i = 0..15 of output t read words t + 1 .. t + 16
+#pragma unroll
+                    for (int k = 1; k <= 16; k++) sm += wd[k];
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        if (t) sm = (sm + wd[t + 16]) - wd[t];
+                        if (on && a0 + (uint32_t)t < w) {
+                            smax = sm > smax ? sm : smax;
+                            if (sm < smin) { smin = sm; cmin = 1; }
+                            else if (sm == smin) cmin++;
+                        }
+                    }
+                };
+                finish(top, true);
+                finish(top + (two_rows ? 16u : 15u) * pitch, two_rows);
+            }
+            if (smax >= 0.0f) { tmax = (double)smax * box_c; tmin = (double)smin * box_c; n_min = cmin; }
+        } else
         for (uint32_t tile = vtid; tile < ntiles; tile += kBlk) {
             // column-major: (row block, tile column, row in block); row-major: (row, tile column)
             const uint32_t cb = colmajor ? tile >> 4 : tile, rb = cb / tpr, b = colmajor ? rb * 16u + (tile & 15u) : rb, a0 = (cb - rb * tpr) * T;
@@ -660,10 +745,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // re / im) x (hi, lo part of the tap x 2^14: ensure_gabor_bank), both digits into one fp32 accumulator.  A lane's eight K-elements
     // are eight consecutive pixels of a plane row: a window of twelve pixels, three 8-byte LDS reads, serves four columns.
     // Error of a screened component against the exact sum: taps (hi + lo) within 2^-22 relative + 2^-28 absolute even if f16
-    // subnormals were flushed (256 taps: <= 2.2e-6 a_max); accumulation: sixteen instructions of 32 products and one addend each -- were
-    // every one of those 33 additions TRUNCATED to 24 bits, <= 16 * 33 * 2^-23 sum |a w| -- and sqrt((sum |w_re|)^2 + (sum |w_im|)^2) <= sum
-    // |w| = 1 (the bank is L1-normalised), so the screened energy is within 6.3e-5 a_max + 2.2e-6 a_max (+ the epilogue's four fp32
-    // roundings, 3e-7 a_max) of the reference's: kErr = 6.8e-5, twice the band of the packed-fp32 pass; the probe measures 1.0e-8 a_max.
+    // subnormals were flushed (256 taps: <= 2.2e-6 a_max); accumulation: an instruction adds 32 products and one addend -- were every
+    // one of those 33 additions TRUNCATED to 24 bits, its error is <= 33 * 2^-23 of the absolute sum that has gone in so far.  The
+    // rest plane's eight instructions run first (absolute sum <= 2^-11 of the whole), then the main plane's eight: <= 8 * 33 * 2^-23
+    // (1 + 2^-10) sum |a w|, and sqrt((sum |w_re|)^2 + (sum |w_im|)^2) <= sum |w| = 1 (the bank is L1-normalised), so the screened energy
+    // is within 3.15e-5 a_max + 2.2e-6 a_max (+ the epilogue's four fp32 roundings, 3e-7 a_max) of the reference's: kErr = 3.45e-5, the
+    // band of the packed-fp32 pass; the probe measures 1.0e-8 a_max.
     // Pixels inside the band go to the same list and are recomputed by the reference's arithmetic from the digit planes.
     auto run_bands_mfma = [&]() {
         constexpr int kHold = 32;
@@ -687,7 +774,8 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 }
             }
         }
-        constexpr double kErr = 6.8e-5, kScale2 = kGaborTapScale * kGaborTapScale;
+        NYX_GABOR_PHASE_EXIT(A.dbg_phase == 3, return);
+        constexpr double kErr = 3.45e-5, kScale2 = kGaborTapScale * kGaborTapScale;
         const double thr_max = A.gabor_thr * maxval, S_thr = __builtin_fma(kErr, amax, 1e-15 * thr_max) + 3e-15 * amax;
         const double t_lo = thr_max - S_thr > 0.0 ? thr_max - S_thr : 0.0, t_hi = thr_max + S_thr;
         // (squared, in the accumulators' scale, rounded outwards: the conversion to fp32 moves a bound by 6e-8 relative at most)
@@ -706,6 +794,33 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             const uint32_t fl_lane = (uint32_t)(nn & 7) >> 1;
             const bool col_ok = (nn & 9) == 0 && f_lane <= nF;                     // (even column below 8: re^2 + im^2 of hi + lo lands there)
             uint32_t cnt = 0;
+            // (the thresholds of a lane whose column carries no energy are infinite: its comparisons are false)
+            const float inf = __builtin_inff(), hi_lane = col_ok ? hi2f : inf, lo_lane = col_ok ? lo2f : inf;
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(3))) u32x2_t* lds_u32x2_ptr;
+            // four MFMAs of one tap-row pair and one digit plane: the twelve-pixel window at `rowp`, columns 4 x4 - 1 + (0 .. 3)
+            auto pair_mfma = [&](const lds_f16_t* rowp, const gabor_h8 B, gabor_f4 (&C)[4]) {
+                // (the window's words 1 .. 4 are read a second time, into registers of their own: the operand of column + 2 must be an
+                //  aligned register tuple, and assembling it from the first read costs four moves on the vector pipe per tap-row pair --
+                //  the LDS has the cycles to spare, the vector pipe has not)
+                typedef u32x2_t __attribute__((aligned(4))) u32x2_a4_t;
+                typedef const __attribute__((address_space(3))) u32x2_a4_t* lds_u32x2_a4_ptr;
+                const u32x2_t q0 = *(lds_u32x2_ptr)rowp, q1 = *(lds_u32x2_ptr)(rowp + 4);
+                const u32x2_t p0 = *(lds_u32x2_a4_ptr)(rowp + 2), p1 = *(lds_u32x2_a4_ptr)(rowp + 6);
+                const uint32_t w5 = *(const __attribute__((address_space(3))) uint32_t*)(rowp + 10);
+                uint4 av[4];
+                av[0] = uint4{q0.x, q0.y, q1.x, q1.y};
+                av[2] = uint4{p0.x, p0.y, p1.x, p1.y};
+                av[1] = uint4{__builtin_amdgcn_alignbit(p0.x, q0.x, 16), __builtin_amdgcn_alignbit(p0.y, q0.y, 16), __builtin_amdgcn_alignbit(p1.x, q1.x, 16), __builtin_amdgcn_alignbit(p1.y, q1.y, 16)};
+                av[3] = uint4{__builtin_amdgcn_alignbit(q1.x, p0.x, 16), __builtin_amdgcn_alignbit(q1.y, p0.y, 16), __builtin_amdgcn_alignbit(p1.y, p1.x, 16), __builtin_amdgcn_alignbit(w5, p1.y, 16)};
+#pragma unroll
+                for (int xs = 0; xs < 4; xs++) {
+                    gabor_h8 Av;
+                    __builtin_memcpy(&Av, &av[xs], 16);
+                    C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, B, C[xs], 0, 0, 0);
+                }
+            };
+            const uint32_t step = 2u * pitch;                                      // plane elements per tap-row pair
             for (uint32_t u = (uint32_t)wave; u < n_units; u += (uint32_t)NW) {
                 const uint32_t rt = u / n_x4, x4 = u - rt * n_x4;
                 // (rows beyond the box repeat its last row: their outputs are dropped, their reads stay inside the plane)
@@ -714,50 +829,50 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 gabor_f4 C[4];
 #pragma unroll
                 for (int xs = 0; xs < 4; xs++) C[xs] = gabor_f4{0.0f, 0.0f, 0.0f, 0.0f};
+                // The rest digits FIRST: an instruction's rounding is relative to what it adds up, and while only the rest plane has
+                // gone in that is 2^-11 of the whole -- the bound above then counts the eight instructions of the main plane only.
+                if (two) {
+                    const lds_f16_t* rp = base + words;
 #pragma unroll
-                for (int jp = 0; jp < 8; jp++) {
+                    for (int jp = 0; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C);
+                }
+                {
+                    const lds_f16_t* rp = base;
 #pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        if (d == 1 && !two) continue;
-                        const lds_f16_t* const rowp = base + (2 * jp) * pitch + (d ? words : 0u);
-                        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-                        typedef const __attribute__((address_space(3))) u32x2_t* lds_u32x2_ptr;
-                        const u32x2_t q0 = *(lds_u32x2_ptr)rowp, q1 = *(lds_u32x2_ptr)(rowp + 4), q2 = *(lds_u32x2_ptr)(rowp + 8);
-                        const uint32_t w0 = q0.x, w1 = q0.y, w2 = q1.x, w3 = q1.y, w4 = q2.x, w5 = q2.y;
-                        uint4 av[4];
-                        av[0] = uint4{w0, w1, w2, w3};
-                        av[1] = uint4{__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16), __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16)};
-                        av[2] = uint4{w1, w2, w3, w4};
-                        av[3] = uint4{__builtin_amdgcn_alignbit(w2, w1, 16), __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16), __builtin_amdgcn_alignbit(w5, w4, 16)};
-#pragma unroll
-                        for (int xs = 0; xs < 4; xs++) {
-                            gabor_h8 Av;
-                            __builtin_memcpy(&Av, &av[xs], 16);
-                            C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, Bw[jp], C[xs], 0, 0, 0);
-                        }
-                    }
+                    for (int jp = 0; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C);
                 }
                 // epilogue: lane (column nn, rows 4 kb + r): hi-part column + lo-part column (eight lanes on), re^2 + im^2 (the lane beside)
+                const uint32_t b0 = 16u * rt + 4u * (uint32_t)kb;
+                float hi_r[4], lo_r[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const bool rv = b0 + (uint32_t)r < h; hi_r[r] = rv ? hi_lane : inf; lo_r[r] = rv ? lo_lane : inf; }
 #pragma unroll
                 for (int xs = 0; xs < 4; xs++) {
                     const uint32_t a = 4u * x4 + (uint32_t)xs - 1u;                // (column -1 of the first group: no such pixel)
+                    if (a >= w) continue;                                          // (the same in every lane)
+                    float e2[4];
+                    bool band = false;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         float c = C[xs][r];
                         c += __uint_as_float(dpp_perm<0x128>(__float_as_uint(c)));          // row_ror:8
                         const float sq = c * c;
-                        const float e2 = sq + __uint_as_float(dpp_perm<0xB1>(__float_as_uint(sq)));   // quad_perm [1, 0, 3, 2]
-                        const uint32_t b = 16u * rt + 4u * (uint32_t)kb + (uint32_t)r;
-                        const bool valid = col_ok && a < w && b < h;
-                        const bool above = e2 > hi2f;
-                        if (valid && above) cnt++;
-                        if (valid && !above && e2 >= lo2f) {
-                            const uint32_t k = atomicAdd(&s_redo[fl_lane], 1u);
-                            if (k < kSub) s_redo[4u + fl_lane * kSub + k] = b * w + a;
-                        }
+                        e2[r] = sq + __uint_as_float(dpp_perm<0xB1>(__float_as_uint(sq)));  // quad_perm [1, 0, 3, 2]
+                        const bool above = e2[r] > hi_r[r];
+                        cnt += above ? 1u : 0u;
+                        band = band || (!above && e2[r] >= lo_r[r]);
+                    }
+                    if (band) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (!(e2[r] > hi_r[r]) && e2[r] >= lo_r[r]) {
+                                const uint32_t k = atomicAdd(&s_redo[fl_lane], 1u);
+                                if (k < kSub) s_redo[4u + fl_lane * kSub + k] = (b0 + (uint32_t)r) * w + a;
+                            }
                     }
                 }
             }
+            NYX_GABOR_PHASE_EXIT(A.dbg_phase == 4, continue);
             // the four 16-lane rows of the wave hold the same columns
             cnt += __shfl_xor(cnt, 16, 64);
             cnt += __shfl_xor(cnt, 32, 64);
@@ -790,6 +905,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     };
     for (int f = 0; f <= nF; f++) {
         if constexpr (MODE == 4)
+            NYX_GABOR_PHASE_EXIT(f == 1 && A.dbg_phase == 2, return);
             if (f == 1 && pf && A.max_inten[roi] < 65536u && words <= 32u * kBlk && A.gabor_bank16) { run_bands_mfma(); break; }
         bool go;
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
