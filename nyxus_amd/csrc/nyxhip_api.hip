@@ -52,6 +52,8 @@ struct nyxhip_ctx {
     void* d_bank16 = nullptr;        // 16 x 16 banks: the band-pass filters as f16 B operands of the MFMA screening stage (ShapeArgs::gabor_bank16)
     std::vector<double> bank_key;
     uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
+    uint32_t bank_lp_sep = 0;          // ShapeArgs::gabor_lp_sep / _B / _C of the uploaded bank
+    float bank_lp_B[16] = {}, bank_lp_C[36] = {};
     uint32_t bank_box_mask = 0;                                  // ShapeArgs::gabor_box_mask of the uploaded bank
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
@@ -527,6 +529,39 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
                 box = t[2 * k] == t[0] && t[2 * k + 1] == 0.0;
             if (box) ctx->bank_box_mask |= 1u << f;
         }
+    // the low-pass filter as an outer product C_j B_i (ShapeArgs::gabor_lp_sep): pivot at the tap of largest magnitude
+    ctx->bank_lp_sep = 0;
+    if (n == 16) {
+        const double* t = bank.data();
+        int j0 = 0, i0 = 0;
+        double best = -1.0, l1 = 0.0;
+        for (int j = 0; j < 16; j++)
+            for (int i = 0; i < 16; i++) {
+                const double m = std::hypot(t[(j * 16 + i) * 2], t[(j * 16 + i) * 2 + 1]);
+                l1 += m;
+                if (m > best) { best = m; j0 = j; i0 = i; }
+            }
+        double B[16], resid = 0.0;
+        bool ok = best > 0.0 && std::isfinite(l1);
+        for (int i = 0; i < 16 && ok; i++) {
+            // B_i = tap(j0, i) / tap(j0, i0), which must be real and non-negative
+            const double ar = t[(j0 * 16 + i) * 2], ai = t[(j0 * 16 + i) * 2 + 1], pr = t[(j0 * 16 + i0) * 2], pi = t[(j0 * 16 + i0) * 2 + 1];
+            B[i] = (ar * pr + ai * pi) / (pr * pr + pi * pi);
+            ok = B[i] >= 0.0;
+        }
+        for (int j = 0; j < 16 && ok; j++)
+            for (int i = 0; i < 16; i++) {
+                const double cr = t[(j * 16 + i0) * 2], ci = t[(j * 16 + i0) * 2 + 1];
+                resid += std::hypot(t[(j * 16 + i) * 2] - cr * B[i], t[(j * 16 + i) * 2 + 1] - ci * B[i]);
+            }
+        if (ok && resid <= 1e-12 * l1) {
+            ctx->bank_lp_sep = 1;
+            memset(ctx->bank_lp_C, 0, sizeof(ctx->bank_lp_C));
+            for (int i = 0; i < 16; i++) ctx->bank_lp_B[i] = (float)B[i];
+            for (int j = 0; j < 16; j++) { ctx->bank_lp_C[2 * (j + 1)] = (float)t[(j * 16 + i0) * 2]; ctx->bank_lp_C[2 * (j + 1) + 1] = (float)t[(j * 16 + i0) * 2 + 1]; }
+        }
+        if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] gabor low-pass: separable %u (residual %.3g of %.3g)\n", ctx->bank_lp_sep, resid, l1);
+    }
     if (ctx->d_bank) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream())); HIP_TRY(ctx, hipFree(ctx->d_bank)); ctx->d_bank = nullptr; }
     if (ctx->d_bank32) { HIP_TRY(ctx, hipFree(ctx->d_bank32)); ctx->d_bank32 = nullptr; }
     if (ctx->d_bank16) { HIP_TRY(ctx, hipFree(ctx->d_bank16)); ctx->d_bank16 = nullptr; }
@@ -870,6 +905,8 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; g.dbg_phase = getenv("NYXHIP_DBG_PHASE") ? atoi(getenv("NYXHIP_DBG_PHASE")) : 0; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
+        g.gabor_lp_sep = ctx->bank_lp_sep && !getenv("NYXHIP_GABOR_NO_LPSEP");
+        memcpy(g.gabor_lp_B, ctx->bank_lp_B, sizeof(g.gabor_lp_B)); memcpy(g.gabor_lp_C, ctx->bank_lp_C, sizeof(g.gabor_lp_C));
     }
     return NYXHIP_OK;
 }

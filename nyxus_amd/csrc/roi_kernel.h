@@ -355,6 +355,12 @@ struct ShapeArgs {
     uint32_t gabor_box_mask;
     double gabor_thr;
     int32_t small_rois;       // batch extrema say every ROI is small: one wave per ROI instead of four
+    // 16 x 16 banks whose low-pass filter factors as tap(j, i) = C_j * B_i, C complex, B real >= 0 (the reference's always does: it is
+    // built at theta = pi / 2, where the wave runs along the tap rows and the Gaussian envelope splits; ensure_gabor_bank checks the
+    // taps it built, residual <= 1e-12 sum |tap|): fp32 factors for the separable screening pass of roi_gabor_tiled_kernel.
+    uint32_t gabor_lp_sep;
+    float gabor_lp_B[16];     // B_i
+    float gabor_lp_C[36];     // (re, im) of C_j at [2 (j + 1)], zero pairs at both ends
     int32_t dbg_phase;        // diagnostic builds of roi_shape.hip (NYXHIP_GABOR_PHASE_EXITS): leave after phase 1..4; 0 otherwise
     SpillArgs sp;
     ShapeLayout L;
