@@ -222,14 +222,15 @@ typedef __attribute__((address_space(3))) _Float16 lds_f16_t;
 typedef _Float16 gabor_h8 __attribute__((ext_vector_type(8)));
 typedef float gabor_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // (the plane through LDS instructions: behind a generic pointer this function read it with flat loads)
-template <int PF>
+// UNI = false: the lanes of a call belong to different filters (the merged lists of the MFMA stage) -- taps through vector loads.
+template <int PF, bool UNI = true>
 __device__ __attribute__((noinline)) double gabor_exact_energy(const lds_u32_t* s_plane, uint32_t pitch, uint32_t a, uint32_t b, bank_ptr_t G, uint32_t words = 0)
 {
     // (the bank pointer is the same in every lane; said so, the taps come through the scalar cache -- sixteen s_load per tap row
     //  instead of 512 vector loads per call -- and a row's sixteen window words are read before the first is used)
     const uint64_t gp = (uint64_t)(uintptr_t)G;
-    const bank_ptr_t Gu = (bank_ptr_t)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gp >> 32)) << 32) |
-                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gp));
+    const bank_ptr_t Gu = !UNI ? G : (bank_ptr_t)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gp >> 32)) << 32) |
+                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gp));
     double re = 0.0, im = 0.0;
     if constexpr (PF == 2) {
         // MODE 4 after the low-pass filter: the plane is two planes of f16 digits (same rows and pitch, `words` elements apart), whose
@@ -320,6 +321,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     if (!roi_of_slot(A.sp, blockIdx.x, A.n_roi, roi))
         return;
     double* s_red = (double*)(lds_raw + A.L.red);
+#ifdef NYXHIP_GABOR_PHASE_EXITS
+    uint32_t* const diag_cnt = (uint32_t*)(s_red + 12);  // (slots no reduction of the default bank touches)
+#endif
     uint32_t* s_plane = (uint32_t*)(lds_raw + A.L.plane);   // [(h + 15)][pitch] original intensities, zero padding
     uint32_t* s_redo = (uint32_t*)(lds_raw + A.L.redo);     // MODE 2: [0] pixels to recompute, [1 ..] their indices b * w + a
 
@@ -761,6 +765,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         if (lp_cand) {                                    // the candidates for maximum / minimum, with the reference's arithmetic
             __syncthreads();
             const uint32_t nr = s_redo[0];
+            NYX_GABOR_PHASE_EXIT(A.dbg_phase == 6 && tid == 0, diag_cnt[0] = nr);
             lp_overflow = nr > (uint32_t)kGaborRedoCap;
             if (!lp_overflow)
                 for (uint32_t k = tid; k < nr; k += kBlk) {
@@ -826,12 +831,14 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // re / im) x (hi, lo part of the tap x 2^14: ensure_gabor_bank), both digits into one fp32 accumulator.  A lane's eight K-elements
     // are eight consecutive pixels of a plane row: a window of twelve pixels, three 8-byte LDS reads, serves four columns.
     // Error of a screened component against the exact sum: taps (hi + lo) within 2^-22 relative + 2^-28 absolute even if f16
-    // subnormals were flushed (256 taps: <= 2.2e-6 a_max); accumulation: an instruction adds 32 products and one addend -- were every
-    // one of those 33 additions TRUNCATED to 24 bits, its error is <= 33 * 2^-23 of the absolute sum that has gone in so far.  The
-    // rest plane's eight instructions run first (absolute sum <= 2^-11 of the whole), then the main plane's eight: <= 8 * 33 * 2^-23
-    // (1 + 2^-10) sum |a w|, and sqrt((sum |w_re|)^2 + (sum |w_im|)^2) <= sum |w| = 1 (the bank is L1-normalised), so the screened energy
-    // is within 3.15e-5 a_max + 2.2e-6 a_max (+ the epilogue's four fp32 roundings, 3e-7 a_max) of the reference's: kErr = 3.45e-5, the
-    // band of the packed-fp32 pass; the probe measures 1.0e-8 a_max.
+    // subnormals were flushed (256 taps: <= 2.2e-6 a_max).  Accumulation, as measured (tools/mfma_rounding_probe.hip,
+    // profiles/r05_mfma_rounding_probe.txt): the instruction sums its 32 products and the addend BEFORE it rounds, to nearest even,
+    // each term first cut to a grid of 2^-24 of the largest term -- so one instruction errs by less than 33 * 2^-24 of the absolute sum
+    // that has gone in so far (observed worst over 20 000 random instructions: 3.1 * 2^-24).  The rest plane's eight instructions run
+    // first (absolute sum <= 2^-11 of the whole), then the main plane's eight: <= 8 * 33 * 2^-24 (1 + 2^-10) sum |a w|, and
+    // sqrt((sum |w_re|)^2 + (sum |w_im|)^2) <= sum |w| = 1 (the bank is L1-normalised), so the screened energy is within 1.58e-5 a_max
+    // + 2.2e-6 a_max (+ the epilogue's four fp32 roundings, 3e-7 a_max) of the reference's: kErr = 1.85e-5, half the band of the
+    // packed-fp32 pass; the Gabor probe measures 1.0e-8 a_max.
     // Pixels inside the band go to the same list and are recomputed by the reference's arithmetic from the digit planes.
     auto run_bands_mfma = [&]() {
         constexpr int kHold = 32;
@@ -856,7 +863,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             }
         }
         NYX_GABOR_PHASE_EXIT(A.dbg_phase == 3, return);
-        constexpr double kErr = 3.45e-5, kScale2 = kGaborTapScale * kGaborTapScale;
+        constexpr double kErr = 1.85e-5, kScale2 = kGaborTapScale * kGaborTapScale;
         const double thr_max = A.gabor_thr * maxval, S_thr = __builtin_fma(kErr, amax, 1e-15 * thr_max) + 3e-15 * amax;
         const double t_lo = thr_max - S_thr > 0.0 ? thr_max - S_thr : 0.0, t_hi = thr_max + S_thr;
         // (squared, in the accumulators' scale, rounded outwards: the conversion to fp32 moves a bound by 6e-8 relative at most)
@@ -960,26 +967,41 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             if (lane < 16 && col_ok) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + f_lane - 1] = (double)cnt;   // [wave][filter]
             __syncthreads();
             const lds_u32_t* const pl = (const lds_u32_t*)s_plane;
-            for (int fl = 0; fl < 4 && 4 * g + fl < nF; fl++) {                      // (a list per filter: the recomputation reads its taps through the scalar cache)
-                const bank_ptr_t G = bank + (size_t)(1 + 4 * g + fl) * N * N * 2;
-                const uint32_t nr = s_redo[fl];
-                uint32_t sc = 0;
-                if (nr > kSub) {
-                    // more pixels in the band than the list holds: this filter over the whole box with the reference's arithmetic
-                    for (uint32_t p = tid; p < area; p += kBlk) {
-                        const uint32_t b = p / w, a = p - b * w;
-                        if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
-                    }
-                    const uint32_t tot = (uint32_t)wave_sum_u64(sc);
-                    if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] = (double)tot;
-                } else if (nr != 0) {
-                    for (uint32_t k = tid; k < nr; k += kBlk) {
-                        const uint32_t p = s_redo[4u + (uint32_t)fl * kSub + k], b = p / w, a = p - b * w;
-                        if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
-                    }
-                    const uint32_t tot = (uint32_t)wave_sum_u64(sc);
-                    if (lane == 0 && tot) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] += (double)tot;
+            // The four filters' lists as ONE run over the workgroup's threads (a handful of pixels each on ordinary data: as four runs
+            // they cost four wave-long recomputations of a few live lanes; the taps then differ from lane to lane and come through
+            // vector loads).  A list that overflowed is left out here and its filter recomputed over the whole box below.
+            uint32_t n_q[4], n_all = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t nr = 4 * g + q < nF ? s_redo[q] : 0u; n_q[q] = nr > kSub ? 0u : nr; n_all += n_q[q]; }
+            NYX_GABOR_PHASE_EXIT(A.dbg_phase == 6 && tid < 4, diag_cnt[1 + tid] = s_redo[tid]);
+            for (uint32_t k0 = (uint32_t)wave * 64u; k0 < n_all; k0 += kBlk) {          // (the same trips in every lane of a wave: the ballots below)
+                uint32_t k = k0 + (uint32_t)lane, fl = 0;
+                const bool live = k < n_all;
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (live && fl == (uint32_t)q && k >= n_q[q]) { k -= n_q[q]; fl = (uint32_t)q + 1u; }
+                bool hit = false;
+                if (live) {
+                    const uint32_t p = s_redo[4u + fl * kSub + k], b = p / w, a = p - b * w;
+                    hit = gabor_exact_energy<2, false>(pl, pitch, a, b, bank + (size_t)(1 + 4 * g + (int)fl) * N * N * 2, words) / maxval > A.gabor_thr;
                 }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit && fl == q));
+                    if (lane == 0 && c) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + (int)q] += (double)c;
+                }
+            }
+            for (int fl = 0; fl < 4 && 4 * g + fl < nF; fl++) {
+                if (s_redo[fl] <= kSub)
+                    continue;
+                // more pixels in the band than the list holds: this filter over the whole box with the reference's arithmetic
+                const bank_ptr_t G = bank + (size_t)(1 + 4 * g + fl) * N * N * 2;
+                uint32_t sc = 0;
+                for (uint32_t p = tid; p < area; p += kBlk) {
+                    const uint32_t b = p / w, a = p - b * w;
+                    if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
+                }
+                const uint32_t tot = (uint32_t)wave_sum_u64(sc);
+                if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] = (double)tot;
             }
             __syncthreads();
         }
@@ -1005,6 +1027,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     }
     const double baseline = (double)n_min;
     __syncthreads();
+#ifdef NYXHIP_GABOR_PHASE_EXITS
+    if (A.dbg_phase == 6) {                              // the output row carries the list lengths: low-pass candidates, band pixels of filters 1 .. 3
+        for (int k = tid; k < nF; k += kBlk) o[k] = (double)diag_cnt[k < 4 ? k : 0];
+        return;
+    }
+#endif
     for (int k = tid; k < nF; k += kBlk) {
         double scv = 0;
         for (int wv = 0; wv < NW; wv++) scv += s_red[wv * NYXHIP_MAX_GABOR_FILTERS + k];
