@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         const double kErrLp = lpsep ? 2.3e-6 : kErr;
         if (MODE >= 2 && fuse) {
             if (tid == 0) s_redo[0] = 0;
-            if (lp_cand) {
+            if (lp_cand && !lpsep) {                      // (the separable pass takes its bounds from its own first trip: see there)
                 if (wave == 0) {                          // (64 samples: one wave's worth of the reference's arithmetic)
                     const uint32_t p = (uint32_t)(((unsigned long long)(uint32_t)lane * area) / 64u), pb = p / w, pa = p - pb * w;
                     const double es = exact_energy(pa, pb, G);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         // (low-pass candidates, same construction: at least Bs - M, or at most bs + M)
         const double M_lp = kErrLp * amax + 3e-15 * amax + 1e-15 * (Bs > bs ? Bs : bs);
         const double b_lo = Bs - M_lp > 0.0 ? Bs - M_lp : 0.0, b_hi = bs + M_lp;
-        const double lp_hi2 = b_lo * b_lo * (1.0 - 1e-15), lp_lo2 = b_hi * b_hi * (1.0 + 1e-15);
+        double lp_hi2 = b_lo * b_lo * (1.0 - 1e-15), lp_lo2 = b_hi * b_hi * (1.0 + 1e-15);
         // The low-pass filter as a box filter over intensities below 2^16 (the reference's default bank on 8- to 16-bit images): the
         // 16 x 16 window sums stay below 2^24, so fp32 additions of the plane's fp32 patterns are exact in any order.  A thread owns
         // T columns of TWO rows: the column sums over the fourteen tap rows the two outputs share are formed once, the three rows
@@ -467,7 +467,36 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             v2f Bp[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) Bp[k] = v2f{A.gabor_lp_B[2 * k], A.gabor_lp_B[2 * k + 1]};
-            for (uint32_t it = (uint32_t)tid; it < n_it; it += kBlk) {
+            // Candidates for the extrema without a single sample of the reference's arithmetic: the FIRST trip of the item loop
+            // keeps its screened energies in registers; their largest and smallest over the workgroup bound the true maximum from
+            // below (largest - M) and the true minimum from above (smallest + M), and a pixel is a candidate when its screened
+            // energy lies within 2 M of them -- the pixel that attains the true maximum does, and so does every pixel AT the true
+            // minimum.  Later trips (boxes of more items than threads) compare against the first trip's bounds.
+            double keep[2 * T];
+            bool kept = false;
+            uint32_t kb0 = 0, ka0 = 0;
+            double lmax = -1.0, lmin = 1.7976931348623157e308;
+            bool first = true;
+            auto push_item = [&](const double (&v)[2 * T], uint32_t b0, uint32_t a0) {
+#pragma unroll
+                for (int q = 0; q < 2 * T; q++)
+                    if (v[q] >= 0.0 && (v[q] >= lp_hi2 || v[q] <= lp_lo2)) {
+                        const uint32_t kk = atomicAdd(&s_redo[0], 1u);
+                        if (kk < (uint32_t)kGaborRedoCap) s_redo[1 + kk] = (b0 + (uint32_t)(q & 1)) * w + a0 + (uint32_t)(q >> 1);
+                    }
+            };
+            auto return_item = [&](const double (&v)[2 * T], uint32_t b0, uint32_t a0) {
+                if (first) {
+#pragma unroll
+                    for (int q = 0; q < 2 * T; q++) {
+                        keep[q] = v[q];
+                        if (v[q] >= 0.0) { lmax = v[q] > lmax ? v[q] : lmax; lmin = v[q] < lmin ? v[q] : lmin; }
+                    }
+                    kept = true; kb0 = b0; ka0 = a0;
+                } else
+                    push_item(v, b0, a0);
+            };
+            auto do_item = [&](uint32_t it) {
                 const uint32_t cb = it / n_rp, rpi = it - cb * n_rp, b0 = 2u * rpi, a0 = cb * T;
                 const bool two_rows = b0 + 1u < h;                                 // (an odd box height: the last pair has one row; padded row b0 + 16 does not exist then)
                 const uint32_t* const top = s_plane + b0 * pitch + a0;            // padded row b0 + k: tap row 15 - k of output row b0, 16 - k of b0 + 1
@@ -509,23 +538,32 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                         else { pk_fma_bcast<1>(o0[t], Hp[t / 2], c0); pk_fma_bcast<1>(o1[t], Hp[t / 2], c1); }
                     }
                 }
+                double s2v[2 * T];                                                 // (-1: no such pixel)
 #pragma unroll
-                for (int t = 0; t < T; t++) {
-                    if (a0 + (uint32_t)t >= w)
-                        continue;
+                for (int t = 0; t < T; t++)
 #pragma unroll
                     for (int rr = 0; rr < 2; rr++) {
-                        if (rr == 1 && !two_rows)
-                            continue;
                         const double re_ = (double)(rr ? o1[t].x : o0[t].x), im_ = (double)(rr ? o1[t].y : o0[t].y);
-                        const double s2 = re_ * re_ + im_ * im_;
-                        if (s2 >= lp_hi2 || s2 <= lp_lo2) {
-                            const uint32_t kk = atomicAdd(&s_redo[0], 1u);
-                            if (kk < (uint32_t)kGaborRedoCap) s_redo[1 + kk] = (b0 + (uint32_t)rr) * w + a0 + (uint32_t)t;
-                        }
+                        s2v[2 * t + rr] = (a0 + (uint32_t)t < w && (rr == 0 || two_rows)) ? re_ * re_ + im_ * im_ : -1.0;
                     }
-                }
+                return_item(s2v, b0, a0);
+            };
+            if ((uint32_t)tid < n_it) do_item((uint32_t)tid);
+            {
+                const double wmx = wave_max_d(lmax), wmn = wave_min_d(lmin);
+                if (lane == 0) { s_red[wave * 8] = wmx; s_red[wave * 8 + 1] = wmn; }
+                __syncthreads();
+                double mx = s_red[0], mn = s_red[1];
+                for (int wv = 1; wv < NW; wv++) { mx = s_red[wv * 8] > mx ? s_red[wv * 8] : mx; mn = s_red[wv * 8 + 1] < mn ? s_red[wv * 8 + 1] : mn; }
+                __syncthreads();
+                // (square roots within one rounding: the bounds below carry 1e-15 relative for them)
+                const double e_hi = sqrt(mx), e_lo = sqrt(mn), M2 = 2.0 * (kErrLp * amax + 3e-15 * amax) + 4e-15 * e_hi;
+                const double c_lo = e_hi - M2 > 0.0 ? e_hi - M2 : 0.0, c_hi = e_lo + M2;
+                lp_hi2 = c_lo * c_lo * (1.0 - 1e-15); lp_lo2 = c_hi * c_hi * (1.0 + 1e-15);
             }
+            first = false;
+            if (kept) push_item(keep, kb0, ka0);
+            for (uint32_t it = (uint32_t)tid + kBlk; it < n_it; it += kBlk) do_item(it);
         }
         if (f32 && lpsep) {
         } else if (fbox) {
