@@ -977,7 +977,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     const uint32_t a = 4u * x4 + (uint32_t)xs - 1u;                // (column -1 of the first group: no such pixel)
                     if (a >= w) continue;                                          // (the same in every lane)
                     float e2[4];
-                    bool band = false;
+                    unsigned long long band = 0;                                   // lanes with a pixel inside the band (kept as wave masks: scalar logic)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         float c = C[xs][r];
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                         e2[r] = sq + __uint_as_float(dpp_perm<0xB1>(__float_as_uint(sq)));  // quad_perm [1, 0, 3, 2]
                         const bool above = e2[r] > hi_r[r];
                         cnt += above ? 1u : 0u;
-                        band = band || (!above && e2[r] >= lo_r[r]);
+                        band |= __builtin_amdgcn_ballot_w64(e2[r] >= lo_r[r]) & ~__builtin_amdgcn_ballot_w64(above);
                     }
                     if (band) {
 #pragma unroll
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});
         else if constexpr (MODE == 1) go = run_filter(f, std::true_type{});
         else if (MODE >= 3 && !(amax < 16777216.0)) go = run_filter(f, std::false_type{});   // an intensity that fp32 does not hold exactly: the reference's arithmetic throughout
-        else if (f == 0 && NW == 1) go = run_filter(0, std::false_type{});   // one-wave launches (small ROIs): two recomputation calls cost more than the unfused low-pass
+        else if (f == 0 && NW == 1 && !A.gabor_lp_sep) go = run_filter(0, std::false_type{});   // one-wave launches (small ROIs): two recomputation calls cost more than the unfused low-pass (the separable pass needs none)
         else {
             go = run_filter(f, std::true_type{});
             if (f == 0 && lp_overflow) {                  // too many candidates (ties): the low-pass filter again, the reference's arithmetic throughout
@@ -1240,7 +1240,8 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
                                (const void*)roi_gabor_tiled_kernel<8, 4, 2, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 2, true>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 3, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, false>,
                                (const void*)roi_gabor_tiled_kernel<8, 4, 3, true>, (const void*)roi_gabor_tiled_kernel<4, 1, 3, true>,
-                               (const void*)roi_gabor_tiled_kernel<8, 4, 4, false>, (const void*)roi_gabor_tiled_kernel<8, 4, 4, true>};
+                               (const void*)roi_gabor_tiled_kernel<8, 4, 4, false>, (const void*)roi_gabor_tiled_kernel<8, 4, 4, true>,
+                               (const void*)roi_gabor_tiled_kernel<4, 1, 4, false>, (const void*)roi_gabor_tiled_kernel<4, 1, 4, true>};
         for (const void* fn : tiled)
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds());
@@ -1283,10 +1284,8 @@ int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid)
             if (small) hipLaunchKernelGGL((roi_gabor_tiled_kernel<4, 1, M, Z>), dim3(grid), dim3(64), a.L.total, st, a);               \
             else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, M, Z>), dim3(grid), dim3(256), a.L.total, st, a);                    \
         } while (0)
-        if (mode == 4 && a.gabor_bank32 && a.gabor_bank16 && !small) {
-            if (zr) hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, 4, true>), dim3(grid), dim3(256), a.L.total, st, a);
-            else hipLaunchKernelGGL((roi_gabor_tiled_kernel<8, 4, 4, false>), dim3(grid), dim3(256), a.L.total, st, a);
-        } else if (mode >= 3 && a.gabor_bank32) { if (zr) NYX_GABOR_LAUNCH(3, true); else NYX_GABOR_LAUNCH(3, false); }
+        if (mode == 4 && a.gabor_bank32 && a.gabor_bank16) { if (zr) NYX_GABOR_LAUNCH(4, true); else NYX_GABOR_LAUNCH(4, false); }
+        else if (mode >= 3 && a.gabor_bank32) { if (zr) NYX_GABOR_LAUNCH(3, true); else NYX_GABOR_LAUNCH(3, false); }
         else if (mode >= 2) { if (zr) NYX_GABOR_LAUNCH(2, true); else NYX_GABOR_LAUNCH(2, false); }
         else if (mode == 1) { if (zr) NYX_GABOR_LAUNCH(1, true); else NYX_GABOR_LAUNCH(1, false); }
         else { if (zr) NYX_GABOR_LAUNCH(0, true); else NYX_GABOR_LAUNCH(0, false); }
