@@ -37,6 +37,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_PEAK_TF = 78.6    # AMD Instinct MI355X data sheet: peak fp64 vector = fp64 matrix, 78.6 TFLOP/s (the guide has no fp64 row)
 FP32_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (vector) 157.3 TFLOPS
+F16_MFMA_PEAK_TF = 2500.0   # same guide: BF16 / F16 MFMA ~2.5 PFLOP/s dense
+
+
+def gabor_roofline(alg_flops, dt, bbox_w, bbox_h, max_inten, n_filters):
+    """The Gabor kernel against the pipe that executes it: `achieved` = algorithmic flops / time against the dense f16 MFMA peak; beside
+    it the flops the MFMA stage issues: (w / 4 + 1) column groups x ceil(h / 16) row tiles x 8 tap-row pairs x 4 columns x digit planes
+    (1 below 2^11, 2 below 2^16) x groups of four filters, 2 * 16 * 16 * 32 flops each."""
+    w = np.asarray(bbox_w, np.float64); h = np.asarray(bbox_h, np.float64); mx = np.asarray(max_inten, np.float64)
+    units = (np.floor(w / 4) + 1) * np.ceil(h / 16)
+    digits = np.where(mx < 2048, 1.0, 2.0)
+    on_mfma = mx < 65536
+    ex = float(np.sum(units * 32.0 * digits * np.ceil(n_filters / 4.0) * 16384.0 * on_mfma))
+    return {"bound": "mfma", "achieved": alg_flops / dt / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": alg_flops / dt / 1e12 / F16_MFMA_PEAK_TF,
+            "algorithmic_flops_per_launch": alg_flops, "executed_mfma_flops_per_launch": ex, "executed_mfma_TFLOPs": ex / dt / 1e12}
+
 
 
 def parse():
@@ -578,6 +593,16 @@ def main():
                               "what": "BASELINE.json configs[3] per GPU: *ALL_GLCM*+*ALL_GLRLM*+*ALL_GLSZM*+*ALL_NGTDM*+*ALL_INTENSITY* (gd 8) on the same 1000 tiles"}
             if hb_cpu is not None:
                 rec["config4"]["cpu_baseline"] = cpu_leg(hb_cpu, m4, s, "the five families' reduce functions via runParallel, one family after the other", cpu_rows)
+            # ---- the Gabor family alone on the metric ROIs, default bank (the review's 33.9 ms per 196 k ROIs figure) ------------------------
+            try:
+                dtg, ncg, parg = timed(_abi.FAM_GABOR, s, cb, n_roi, check_rows=last_tile[:64], arrays=dev_arrays)
+                flg = float(5.0 * 4.0 * side * side * 256.0) * n_roi
+                rec["gabor_metric"] = {"value": n_roi / dtg, "unit": "ROIs/s", "ms_per_step": 1e3 * dtg, "ms_per_196k_rois": 1e3 * dtg * 196000.0 / n_roi, "n_columns": ncg,
+                                       "parity_check": parg,
+                                       "roofline": gabor_roofline(flg, dtg, np.full(n_roi, side), np.full(n_roi, side), np.full(n_roi, 4095), 4),
+                                       "what": "GaborFeature alone (default bank: low-pass + 4 filters, 16 x 16 taps) on the metric workload's ROIs"}
+            except Exception as eg:
+                rec["gabor_metric"] = {"error": repr(eg)}
             try:
                 from tests import fixtures
                 rng5 = np.random.default_rng(5)
@@ -609,12 +634,11 @@ def main():
                 fl5 = float(np.sum(9.0 * 4.0 * hb5.bbox_w.astype(np.float64) * hb5.bbox_h * 256.0) + 110.0 * hb5.n_px)
                 rec["config5"] = {"value": hb5.n_roi / dt5, "unit": "ROIs/s", "ms_per_step": 1e3 * dt5, "rois": int(hb5.n_roi), "mean_px": hb5.n_px / hb5.n_roi,
                                   "parity_check": par5, "max_rel_err": mg5,
-                                  "roofline": {"bound": "fp32 vector (packed FMA)", "achieved": fl5 / dt5 / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": fl5 / dt5 / 1e12 / FP32_PEAK_TF,
-                                               "algorithmic_flops_per_launch": fl5,
-                                               "note": "the Gabor kernel's arithmetic is its packed-fp32 screening pass (v_pk_fma_f32: 19.4 k of 22.8 k vector instructions "
-                                                       "per wave), the fp64 recomputation touches the few pixels inside the error band: peak = 157.3 TFLOP/s fp32 vector "
-                                                       "(MI355X_MICROARCH.md).  Flops by SURVEY 8(d)'s 2*2*w*h*n^2 per filter -- an upper bound of the taps that meet image pixels "
-                                                       "(the kernel runs all 256 taps per output over the zero-padded plane); counts are bit-exact with the reference, DESIGN 4.4"},
+                                  "roofline": dict(gabor_roofline(fl5, dt5, hb5.bbox_w, hb5.bbox_h, hb5.max_inten, 8),
+                                                   note="the eight band-pass filters run on the matrix pipe (v_mfma_f32_16x16x32_f16 over f16 digit planes, two groups of four filters; "
+                                                        "DESIGN 4.4), the low-pass filter as a separable packed-fp32 pass, pixels inside the error band in fp64: peak = the dense f16 MFMA "
+                                                        "rate (MI355X_MICROARCH.md).  `achieved` counts SURVEY 8(d)'s 2*2*w*h*n^2 flops per filter; `executed_mfma_flops_per_launch` what "
+                                                        "the stage issues (16-row tiles x 4-column groups x hi / lo tap parts x digit planes): small boxes fill a fraction of a tile"),
                                   "what": "BASELINE.json configs[4]: GABOR (8-filter bank, 16x16) + ZERNIKE2D on DSB2018-shaped ROIs (fixture shapes replicated with seeded noise)"}
                 rec["config5"]["cpu_baseline"] = cpu_leg(hb5, m5k, s5, "GaborFeature + ZernikeFeature reduce via runParallel", 8192)
                 del keep5
@@ -813,6 +837,8 @@ def main():
         for leg in ("config2", "config3", "config4", "config5", "gray_depth_64", "tile_path"):
             if leg in rec:
                 summ[leg] = brief(rec[leg])
+        if isinstance(rec.get("gabor_metric"), dict) and "ms_per_196k_rois" in rec["gabor_metric"]:
+            summ["gabor_metric_ms_per_196k_rois"] = [round(rec["gabor_metric"]["ms_per_196k_rois"], 2), "ok" if gate_ok(rec["gabor_metric"].get("parity_check")) else "FAILED"]
         if isinstance(rec.get("tile_path"), dict):
             for sub in ("irregular", "pcie_inclusive", "pcie_inclusive_u16_u8"):
                 if sub in rec["tile_path"]:
