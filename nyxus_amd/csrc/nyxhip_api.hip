@@ -53,7 +53,7 @@ struct nyxhip_ctx {
     std::vector<double> bank_key;
     uint32_t bank_zero_rows[NYXHIP_MAX_GABOR_FILTERS + 1] = {};   // ShapeArgs::gabor_zero_rows of the uploaded bank (16 x 16 kernels)
     uint32_t bank_lp_sep = 0;          // ShapeArgs::gabor_lp_sep / _B / _C of the uploaded bank
-    float bank_lp_B[16] = {}, bank_lp_C[36] = {};
+    float bank_lp_B[16] = {}, bank_lp_C[44] = {};
     uint32_t bank_box_mask = 0;                                  // ShapeArgs::gabor_box_mask of the uploaded bank
     unsigned long long* d_stamps = nullptr; // diagnostic (NYXHIP_STAMPS=1 + -DNYX_STAMP build): [32] phase cycle sums
     std::string err;
@@ -558,7 +558,7 @@ int ensure_gabor_bank(nyxhip_ctx* ctx, const nyxhip_settings* s)
             ctx->bank_lp_sep = 1;
             memset(ctx->bank_lp_C, 0, sizeof(ctx->bank_lp_C));
             for (int i = 0; i < 16; i++) ctx->bank_lp_B[i] = (float)B[i];
-            for (int j = 0; j < 16; j++) { ctx->bank_lp_C[2 * (j + 1)] = (float)t[(j * 16 + i0) * 2]; ctx->bank_lp_C[2 * (j + 1) + 1] = (float)t[(j * 16 + i0) * 2 + 1]; }
+            for (int j = 0; j < 16; j++) { ctx->bank_lp_C[2 * (j + 3)] = (float)t[(j * 16 + i0) * 2]; ctx->bank_lp_C[2 * (j + 3) + 1] = (float)t[(j * 16 + i0) * 2 + 1]; }
         }
         if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] gabor low-pass: separable %u (residual %.3g of %.3g)\n", ctx->bank_lp_sep, resid, l1);
     }

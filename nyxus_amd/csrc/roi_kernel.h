@@ -360,7 +360,7 @@ struct ShapeArgs {
     // taps it built, residual <= 1e-12 sum |tap|): fp32 factors for the separable screening pass of roi_gabor_tiled_kernel.
     uint32_t gabor_lp_sep;
     float gabor_lp_B[16];     // B_i
-    float gabor_lp_C[36];     // (re, im) of C_j at [2 (j + 1)], zero pairs at both ends
+    float gabor_lp_C[44];     // (re, im) of C_j at [2 (j + 3)], three zero pairs at both ends
     int32_t dbg_phase;        // diagnostic builds of roi_shape.hip (NYXHIP_GABOR_PHASE_EXITS): leave after phase 1..4; 0 otherwise
     SpillArgs sp;
     ShapeLayout L;

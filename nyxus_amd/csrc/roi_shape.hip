@@ -463,7 +463,10 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         // so is its root): extrema and the count at the minimum are taken on the sums.
         const bool fbox = MODE >= 3 && ZR && box && f == 0 && amax < 65536.0;
         if constexpr (f32) if (lpsep) {
-            const uint32_t n_rp = (h + 1u) / 2u, n_it = n_rp * tpr;
+            // a thread owns TL = 4 columns of RL rows (four in the 256-thread kernel, two in the one-wave kernel of small boxes: fewer
+            // rows to filter for nothing); lanes run along the column blocks -- 16-byte window reads one unit apart: conflict-free
+            constexpr int TL = 4, RL = NW == 4 ? 4 : 2, WL4 = (TL + 16) / 4, NV = TL * RL;
+            const uint32_t n_cb = (w + (uint32_t)TL - 1u) / (uint32_t)TL, n_rp = (h + (uint32_t)RL - 1u) / (uint32_t)RL, n_it = n_rp * n_cb;
             v2f Bp[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) Bp[k] = v2f{A.gabor_lp_B[2 * k], A.gabor_lp_B[2 * k + 1]};
@@ -472,23 +475,23 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             // below (largest - M) and the true minimum from above (smallest + M), and a pixel is a candidate when its screened
             // energy lies within 2 M of them -- the pixel that attains the true maximum does, and so does every pixel AT the true
             // minimum.  Later trips (boxes of more items than threads) compare against the first trip's bounds.
-            double keep[2 * T];
+            double keep[NV];
             bool kept = false;
             uint32_t kb0 = 0, ka0 = 0;
             double lmax = -1.0, lmin = 1.7976931348623157e308;
             bool first = true;
-            auto push_item = [&](const double (&v)[2 * T], uint32_t b0, uint32_t a0) {
+            auto push_item = [&](const double (&v)[NV], uint32_t b0, uint32_t a0) {      // v[RL * t + rr]: column a0 + t, row b0 + rr
 #pragma unroll
-                for (int q = 0; q < 2 * T; q++)
+                for (int q = 0; q < NV; q++)
                     if (v[q] >= 0.0 && (v[q] >= lp_hi2 || v[q] <= lp_lo2)) {
                         const uint32_t kk = atomicAdd(&s_redo[0], 1u);
-                        if (kk < (uint32_t)kGaborRedoCap) s_redo[1 + kk] = (b0 + (uint32_t)(q & 1)) * w + a0 + (uint32_t)(q >> 1);
+                        if (kk < (uint32_t)kGaborRedoCap) s_redo[1 + kk] = (b0 + (uint32_t)(q % RL)) * w + a0 + (uint32_t)(q / RL);
                     }
             };
-            auto return_item = [&](const double (&v)[2 * T], uint32_t b0, uint32_t a0) {
+            auto return_item = [&](const double (&v)[NV], uint32_t b0, uint32_t a0) {
                 if (first) {
 #pragma unroll
-                    for (int q = 0; q < 2 * T; q++) {
+                    for (int q = 0; q < NV; q++) {
                         keep[q] = v[q];
                         if (v[q] >= 0.0) { lmax = v[q] > lmax ? v[q] : lmax; lmin = v[q] < lmin ? v[q] : lmin; }
                     }
@@ -497,54 +500,62 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     push_item(v, b0, a0);
             };
             auto do_item = [&](uint32_t it) {
-                const uint32_t cb = it / n_rp, rpi = it - cb * n_rp, b0 = 2u * rpi, a0 = cb * T;
-                const bool two_rows = b0 + 1u < h;                                 // (an odd box height: the last pair has one row; padded row b0 + 16 does not exist then)
-                const uint32_t* const top = s_plane + b0 * pitch + a0;            // padded row b0 + k: tap row 15 - k of output row b0, 16 - k of b0 + 1
-                v2f o0[T], o1[T];
+                const uint32_t rpi = it / n_cb, cb = it - rpi * n_cb, b0 = (uint32_t)RL * rpi, a0 = cb * (uint32_t)TL;
+                // padded row b0 + k is tap row 15 + rr - k of output row b0 + rr.  (The last row group of a box whose height is not a
+                // multiple of RL asks for padded rows that do not exist: they only feed output rows that do not exist either, and the
+                // last row that does is read in their place.)
+                const uint32_t k_last = h + 14u - b0;
+                const uint32_t* const top = s_plane + b0 * pitch + a0;
+                v2f o[RL][TL];
 #pragma unroll
-                for (int t = 0; t < T; t++) { o0[t] = v2f{0.0f, 0.0f}; o1[t] = v2f{0.0f, 0.0f}; }
+                for (int rr = 0; rr < RL; rr++)
+#pragma unroll
+                    for (int t = 0; t < TL; t++) o[rr][t] = v2f{0.0f, 0.0f};
 #pragma unroll 1
-                for (int k = 0; k <= 16; k++) {
-                    const uint32_t* const row = top + (uint32_t)(k < 16 || two_rows ? k : 15) * pitch;
-                    v2f win2[(T + 16) / 2];                      // window words 2 q, 2 q + 1
+                for (int k = 0; k < 16 + RL - 1; k++) {
+                    const uint32_t* const row = top + ((uint32_t)k < k_last ? (uint32_t)k : k_last) * pitch;
+                    v2f win2[(TL + 16) / 2];                     // window words 2 q, 2 q + 1
 #pragma unroll
-                    for (int q = 0; q < W4; q++) {
+                    for (int q = 0; q < WL4; q++) {
                         const uint4 u = ((const uint4*)row)[q];
                         win2[2 * q] = v2f{__uint_as_float(u.x), __uint_as_float(u.y)};
                         win2[2 * q + 1] = v2f{__uint_as_float(u.z), __uint_as_float(u.w)};
                     }
                     // row filter: tap i of output t reads word t + 16 - i.  Even taps on the output pairs (t, t + 1), t even -- an
                     // aligned register pair of the window; odd taps on the pairs (t - 1, t): the same pairs serve them
-                    v2f ae[T / 2], ao[T / 2 + 1];
+                    v2f ae[TL / 2], ao[TL / 2 + 1];
 #pragma unroll
-                    for (int q = 0; q < T / 2; q++) ae[q] = v2f{0.0f, 0.0f};
+                    for (int q = 0; q < TL / 2; q++) ae[q] = v2f{0.0f, 0.0f};
 #pragma unroll
-                    for (int q = 0; q <= T / 2; q++) ao[q] = v2f{0.0f, 0.0f};
+                    for (int q = 0; q <= TL / 2; q++) ao[q] = v2f{0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) {
 #pragma unroll
-                        for (int t = 0; t < T; t += 2) pk_fma_sb<0>(ae[t / 2], win2[(t + 16 - i) / 2], Bp[i / 2]);
+                        for (int t = 0; t < TL; t += 2) pk_fma_sb<0>(ae[t / 2], win2[(t + 16 - i) / 2], Bp[i / 2]);
 #pragma unroll
-                        for (int t = 0; t <= T; t += 2) pk_fma_sb<1>(ao[t / 2], win2[(t + 14 - i) / 2], Bp[i / 2]);   // tap i + 1
+                        for (int t = 0; t <= TL; t += 2) pk_fma_sb<1>(ao[t / 2], win2[(t + 14 - i) / 2], Bp[i / 2]);   // tap i + 1
                     }
-                    v2f Hp[T / 2];
+                    v2f Hp[TL / 2];
 #pragma unroll
-                    for (int q = 0; q < T / 2; q++) Hp[q] = v2f{ae[q].x + ao[q].y, ae[q].y + ao[q + 1].x};
-                    const v2f c0 = v2f{A.gabor_lp_C[2 * (16 - k)], A.gabor_lp_C[2 * (16 - k) + 1]};     // C_{15 - k} (zero at k = 16)
-                    const v2f c1 = v2f{A.gabor_lp_C[2 * (17 - k)], A.gabor_lp_C[2 * (17 - k) + 1]};     // C_{16 - k} (zero at k = 0)
+                    for (int q = 0; q < TL / 2; q++) Hp[q] = v2f{ae[q].x + ao[q].y, ae[q].y + ao[q + 1].x};
 #pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        if ((t & 1) == 0) { pk_fma_bcast<0>(o0[t], Hp[t / 2], c0); pk_fma_bcast<0>(o1[t], Hp[t / 2], c1); }
-                        else { pk_fma_bcast<1>(o0[t], Hp[t / 2], c0); pk_fma_bcast<1>(o1[t], Hp[t / 2], c1); }
+                    for (int rr = 0; rr < RL; rr++) {
+                        const int ci = 2 * (15 + rr - k + 3);                          // C_{15 + rr - k} (zero pairs outside 0 .. 15)
+                        const v2f cj = v2f{A.gabor_lp_C[ci], A.gabor_lp_C[ci + 1]};
+#pragma unroll
+                        for (int t = 0; t < TL; t++) {
+                            if ((t & 1) == 0) pk_fma_bcast<0>(o[rr][t], Hp[t / 2], cj);
+                            else pk_fma_bcast<1>(o[rr][t], Hp[t / 2], cj);
+                        }
                     }
                 }
-                double s2v[2 * T];                                                 // (-1: no such pixel)
+                double s2v[NV];                                                    // (-1: no such pixel)
 #pragma unroll
-                for (int t = 0; t < T; t++)
+                for (int t = 0; t < TL; t++)
 #pragma unroll
-                    for (int rr = 0; rr < 2; rr++) {
-                        const double re_ = (double)(rr ? o1[t].x : o0[t].x), im_ = (double)(rr ? o1[t].y : o0[t].y);
-                        s2v[2 * t + rr] = (a0 + (uint32_t)t < w && (rr == 0 || two_rows)) ? re_ * re_ + im_ * im_ : -1.0;
+                    for (int rr = 0; rr < RL; rr++) {
+                        const double re_ = (double)o[rr][t].x, im_ = (double)o[rr][t].y;
+                        s2v[RL * t + rr] = (a0 + (uint32_t)t < w && b0 + (uint32_t)rr < h) ? re_ * re_ + im_ * im_ : -1.0;
                     }
                 return_item(s2v, b0, a0);
             };
