@@ -936,7 +936,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
             typedef const __attribute__((address_space(3))) u32x2_t* lds_u32x2_ptr;
             // four MFMAs of one tap-row pair and one digit plane: the twelve-pixel window at `rowp`, columns 4 x4 - 1 + (0 .. 3)
-            auto pair_mfma = [&](const lds_f16_t* rowp, const gabor_h8 B, gabor_f4 (&C)[4]) {
+            auto pair_mfma = [&](const lds_f16_t* rowp, const gabor_h8 B, gabor_f4 (&C)[4], auto zero_c) {   // zero_c: the accumulators start here (a literal zero addend: no moves)
                 // (the window's words 1 .. 4 are read a second time, into registers of their own: the operand of column + 2 must be an
                 //  aligned register tuple, and assembling it from the first read costs four moves on the vector pipe per tap-row pair --
                 //  the LDS has the cycles to spare, the vector pipe has not)
@@ -954,7 +954,8 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 for (int xs = 0; xs < 4; xs++) {
                     gabor_h8 Av;
                     __builtin_memcpy(&Av, &av[xs], 16);
-                    C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, B, C[xs], 0, 0, 0);
+                    if constexpr (decltype(zero_c)::value) C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, B, gabor_f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                    else C[xs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Av, B, C[xs], 0, 0, 0);
                 }
             };
             const uint32_t step = 2u * pitch;                                      // plane elements per tap-row pair
@@ -964,19 +965,23 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 const uint32_t brow = min(16u * rt + (uint32_t)nn, h - 1u);
                 const lds_f16_t* const base = dplane + (brow + (uint32_t)(kb >> 1)) * pitch + 8u * (uint32_t)(kb & 1) + 4u * x4;
                 gabor_f4 C[4];
-#pragma unroll
-                for (int xs = 0; xs < 4; xs++) C[xs] = gabor_f4{0.0f, 0.0f, 0.0f, 0.0f};
                 // The rest digits FIRST: an instruction's rounding is relative to what it adds up, and while only the rest plane has
                 // gone in that is 2^-11 of the whole -- the bound above then counts the eight instructions of the main plane only.
                 if (two) {
                     const lds_f16_t* rp = base + words;
+                    pair_mfma(rp, Bw[0], C, std::true_type{});
+                    rp += step;
 #pragma unroll
-                    for (int jp = 0; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C);
-                }
-                {
+                    for (int jp = 1; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C, std::false_type{});
+                    rp = base;
+#pragma unroll
+                    for (int jp = 0; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C, std::false_type{});
+                } else {
                     const lds_f16_t* rp = base;
+                    pair_mfma(rp, Bw[0], C, std::true_type{});
+                    rp += step;
 #pragma unroll
-                    for (int jp = 0; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C);
+                    for (int jp = 1; jp < 8; jp++, rp += step) pair_mfma(rp, Bw[jp], C, std::false_type{});
                 }
                 // epilogue: lane (column nn, rows 4 kb + r): hi-part column + lo-part column (eight lanes on), re^2 + im^2 (the lane beside)
                 const uint32_t b0 = 16u * rt + 4u * (uint32_t)kb;
