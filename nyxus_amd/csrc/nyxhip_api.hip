@@ -1743,6 +1743,17 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             // every ROI by its own box: they run as ONE launch group (their lists are neighbours in the class order) -- four groups of
             // a handful of ROIs each cost four times the ten-odd launches and workspace clears of a group (~0.1 ms apiece on the mixed
             // batch).  Nothing an ROI's row depends on changes: the slab / strip cut is invisible by construction.
+            // A window-mode chunk (no clouds materialised) with a class that reads clouds -- the classes beyond LDS, and the wide-range
+            // classes the bitmap kernel serves -- goes back for them BEFORE anything is launched: raised from inside the class loop it
+            // made the caller run the whole chunk again, every LDS class computed twice (16-bit tiles: on every chunk).
+            if (ctx->win_next.inten && !b->inten && (mask & ~kMoments)) {
+                static const bool no_wide_pre = [] { const char* e = getenv("NYXHIP_NO_WIDE"); return e && *e && *e != '0'; }();
+                for (int cls = 0; cls < kClasses; cls++) {
+                    if (H[cls * H_WORDS + H_COUNT] == 0) continue;
+                    if (cls / 2 >= kFirstLargeSizeClass || ((cls & 1) && (mask & NYXHIP_FAM_INTENSITY) && !no_wide_pre))
+                        return NYXHIP_INTERNAL_NEEDS_CLOUDS;
+                }
+            }
             static const bool no_merge = [] { const char* e = getenv("NYXHIP_NO_MERGE_LARGE"); return e && *e && *e != '0'; }();   // A/B knob
             int first_cls = kClasses - 1;
             if (!no_merge && (mask & ~kMoments)) {
