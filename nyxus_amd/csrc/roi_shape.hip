@@ -890,12 +890,14 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // packed-fp32 pass; the Gabor probe measures 1.0e-8 a_max.
     // Pixels inside the band go to the same list and are recomputed by the reference's arithmetic from the digit planes.
     auto run_bands_mfma = [&]() {
-        constexpr int kHold = 32;
         constexpr uint32_t kSub = (uint32_t)kGaborRedoCap / 4u;
         const uint32_t maxi = A.max_inten[roi];
         const uint32_t low_bits = maxi < 2048u ? 0u : (uint32_t)(21 - __builtin_clz(maxi)), low_mask = (1u << low_bits) - 1u;   // (bits - 11)
         const bool two = low_bits != 0;
-        {
+        // the rewrite holds the whole fp32 plane in registers across a barrier: 32 words per thread for the common boxes, 64 for the
+        // largest LDS-resident ones (two builds of the loop: the wide one costs the metric boxes 0.7 ms per 196 k ROIs in idle trips)
+        auto rewrite = [&](auto hold_c) {
+            constexpr int kHold = decltype(hold_c)::value;
             uint32_t hold[kHold];
 #pragma unroll
             for (int q = 0; q < kHold; q++) { const uint32_t i = (uint32_t)tid + (uint32_t)q * kBlk; hold[q] = i < words ? s_plane[i] : 0u; }
@@ -910,7 +912,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     dp[words + i] = (_Float16)(float)(v & low_mask);
                 }
             }
-        }
+        };
+        if (words <= 32u * kBlk) rewrite(std::integral_constant<int, 32>{});
+        else rewrite(std::integral_constant<int, 64>{});
         NYX_GABOR_PHASE_EXIT(A.dbg_phase == 3, return);
         constexpr double kErr = 1.85e-5, kScale2 = kGaborTapScale * kGaborTapScale;
         const double thr_max = A.gabor_thr * maxval, S_thr = __builtin_fma(kErr, amax, 1e-15 * thr_max) + 3e-15 * amax;
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     for (int f = 0; f <= nF; f++) {
         if constexpr (MODE == 4) {
             NYX_GABOR_PHASE_EXIT(f == 1 && A.dbg_phase == 2, return);
-            if (f == 1 && pf && A.max_inten[roi] < 65536u && words <= 32u * kBlk && A.gabor_bank16) { run_bands_mfma(); break; }
+            if (f == 1 && pf && A.max_inten[roi] < 65536u && words <= 64u * kBlk && A.gabor_bank16) { run_bands_mfma(); break; }
         }
         bool go;
         if constexpr (MODE == 0) go = run_filter(f, std::false_type{});

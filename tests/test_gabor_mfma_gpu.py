@@ -101,3 +101,14 @@ def test_low_pass_that_does_not_factor(hip_ctx):
         s = _abi.default_settings(8)
         s.gabor_gamma, s.gabor_f0lp, s.gabor_sig2lam = gamma, f0lp, s2l
         assert _same(hip_ctx.featurize_host(b, _abi.FAM_GABOR, s), po.oracle_featurize(b, _abi.FAM_GABOR, s))
+
+
+def test_largest_lds_resident_boxes(hip_ctx):
+    """The in-place rewrite of the fp32 plane as digit planes holds the plane in registers: 32 words per thread up to 8192 words, 64
+    beyond (boxes of ~75 x 75 up to the LDS bound) -- both builds, next to a box of the first kind."""
+    rng = np.random.default_rng(8)
+    rois = [_roi(100, 90, rng.integers(1, 4096, (90, 100)), True), _roi(126, 119, rng.integers(1, 60000, (119, 126))),
+            _roi(74, 76, rng.integers(1, 256, (76, 74))), _roi(61, 61, rng.integers(1, 4096, (61, 61)), True)]
+    b = _abi.batch_from_rois(rois)
+    for s in (_abi.default_settings(8), _bank(_abi.default_settings(8), 8)):
+        assert _same(hip_ctx.featurize_host(b, _abi.FAM_GABOR, s), po.oracle_featurize(b, _abi.FAM_GABOR, s))
