@@ -303,6 +303,11 @@ __device__ __forceinline__ void pk_fma_bcast(v2f& acc, const v2f pair, const v2f
 #else
 #define NYX_GABOR_PHASE_EXIT(cond, stmt) do { } while (0)
 #endif
+// The value again, but opaque to the optimiser at this point: per-lane address arithmetic that depends only on the thread index is
+// otherwise hoisted to the kernel's entry and -- alive across every phase -- spilled there (five scratch stores per wave: 1.5 GB of
+// HBM writes per 196 k ROIs for 6 MB of results).
+__device__ __forceinline__ int here(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // acc += pair * {b, b} with b the low (HI = 0) or high (HI = 1) half of the scalar register pair `bpair`
 template <int HI>
 __device__ __forceinline__ void pk_fma_sb(v2f& acc, const v2f pair, const v2f bpair)
@@ -386,8 +391,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // (Row blocks pad the box to a multiple of 16 rows: where that would add a trip to the tile loop -- boxes a little over 16 or 32
     //  rows -- and in the one-wave kernel of small ROIs, which does not saturate the LDS, the tiles stay row-major.)
     const bool colmajor = NW == 4 && (((h + 15u) & ~15u) * tpr + kBlk - 1) / kBlk == (h * tpr + kBlk - 1) / kBlk;
-    const uint32_t vtid = !colmajor ? (uint32_t)tid
-                                    : ((uint32_t)tid & ~31u) | ((0x73261540u >> (((uint32_t)tid >> 2 & 7u) * 4u)) & 7u) << 2 | ((uint32_t)tid & 3u);
+    auto vtid_of = [&](uint32_t t) -> uint32_t {        // (formed where a tile loop starts: see here())
+        return !colmajor ? t : (t & ~31u) | ((0x73261540u >> ((t >> 2 & 7u) * 4u)) & 7u) << 2 | (t & 3u);
+    };
     const uint32_t ntiles = (colmajor ? (h + 15u) & ~15u : h) * tpr;
     double maxval = 0;
     double tmax = -1.0, tmin = 1.7976931348623157e308;
@@ -475,15 +481,15 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             // below (largest - M) and the true minimum from above (smallest + M), and a pixel is a candidate when its screened
             // energy lies within 2 M of them -- the pixel that attains the true maximum does, and so does every pixel AT the true
             // minimum.  Later trips (boxes of more items than threads) compare against the first trip's bounds.
-            double keep[NV];
+            float keep[NV];                              // (fp32 copies: the bounds below carry 1e-6 relative for them)
             bool kept = false;
             uint32_t kb0 = 0, ka0 = 0;
             double lmax = -1.0, lmin = 1.7976931348623157e308;
             bool first = true;
-            auto push_item = [&](const double (&v)[NV], uint32_t b0, uint32_t a0) {      // v[RL * t + rr]: column a0 + t, row b0 + rr
+            auto push_item = [&](const auto (&v)[NV], uint32_t b0, uint32_t a0) {        // v[RL * t + rr]: column a0 + t, row b0 + rr
 #pragma unroll
                 for (int q = 0; q < NV; q++)
-                    if (v[q] >= 0.0 && (v[q] >= lp_hi2 || v[q] <= lp_lo2)) {
+                    if (v[q] >= 0 && ((double)v[q] >= lp_hi2 || (double)v[q] <= lp_lo2)) {
                         const uint32_t kk = atomicAdd(&s_redo[0], 1u);
                         if (kk < (uint32_t)kGaborRedoCap) s_redo[1 + kk] = (b0 + (uint32_t)(q % RL)) * w + a0 + (uint32_t)(q / RL);
                     }
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 if (first) {
 #pragma unroll
                     for (int q = 0; q < NV; q++) {
-                        keep[q] = v[q];
+                        keep[q] = (float)v[q];
                         if (v[q] >= 0.0) { lmax = v[q] > lmax ? v[q] : lmax; lmin = v[q] < lmin ? v[q] : lmin; }
                     }
                     kept = true; kb0 = b0; ka0 = a0;
@@ -559,7 +565,8 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     }
                 return_item(s2v, b0, a0);
             };
-            if ((uint32_t)tid < n_it) do_item((uint32_t)tid);
+            const uint32_t tid_h = (uint32_t)here(tid);
+            if (tid_h < n_it) do_item(tid_h);
             {
                 const double wmx = wave_max_d(lmax), wmn = wave_min_d(lmin);
                 if (lane == 0) { s_red[wave * 8] = wmx; s_red[wave * 8 + 1] = wmn; }
@@ -570,18 +577,18 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 // (square roots within one rounding: the bounds below carry 1e-15 relative for them)
                 const double e_hi = sqrt(mx), e_lo = sqrt(mn), M2 = 2.0 * (kErrLp * amax + 3e-15 * amax) + 4e-15 * e_hi;
                 const double c_lo = e_hi - M2 > 0.0 ? e_hi - M2 : 0.0, c_hi = e_lo + M2;
-                lp_hi2 = c_lo * c_lo * (1.0 - 1e-15); lp_lo2 = c_hi * c_hi * (1.0 + 1e-15);
+                lp_hi2 = c_lo * c_lo * (1.0 - 1e-6); lp_lo2 = c_hi * c_hi * (1.0 + 1e-6);       // (1e-6: the first trip's energies wait as fp32)
             }
             first = false;
             if (kept) push_item(keep, kb0, ka0);
-            for (uint32_t it = (uint32_t)tid + kBlk; it < n_it; it += kBlk) do_item(it);
+            for (uint32_t it = tid_h + kBlk; it < n_it; it += kBlk) do_item(it);
         }
         if (f32 && lpsep) {
         } else if (fbox) {
             const uint32_t n_rp = (h + 1u) / 2u, n_it = n_rp * tpr;
             float smax = -1.0f, smin = __builtin_inff();
             uint32_t cmin = 0;
-            for (uint32_t it = (uint32_t)tid; it < n_it; it += kBlk) {
+            for (uint32_t it = (uint32_t)here(tid); it < n_it; it += kBlk) {
                 const uint32_t cb = it / n_rp, rpi = it - cb * n_rp, b0 = 2u * rpi, a0 = cb * T;
                 const bool down = (rpi & 1u) != 0;
                 const uint32_t* const top = s_plane + b0 * pitch + a0;            // padded row b0: the first tap row of output row b0
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             }
             if (smax >= 0.0f) { tmax = (double)smax * box_c; tmin = (double)smin * box_c; n_min = cmin; }
         } else
-        for (uint32_t tile = vtid; tile < ntiles; tile += kBlk) {
+        for (uint32_t tile = vtid_of((uint32_t)here(tid)); tile < ntiles; tile += kBlk) {
             // column-major: (row block, tile column, row in block); row-major: (row, tile column)
             const uint32_t cb = colmajor ? tile >> 4 : tile, rb = cb / tpr, b = colmajor ? rb * 16u + (tile & 15u) : rb, a0 = (cb - rb * tpr) * T;
             if (b >= h)
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             NYX_GABOR_PHASE_EXIT(A.dbg_phase == 6 && tid == 0, diag_cnt[0] = nr);
             lp_overflow = nr > (uint32_t)kGaborRedoCap;
             if (!lp_overflow)
-                for (uint32_t k = tid; k < nr; k += kBlk) {
+                for (uint32_t k = (uint32_t)here(tid); k < nr; k += kBlk) {
                     const uint32_t p = s_redo[1 + k], b = p / w, a = p - b * w;
                     const double e = exact_energy(a, b, G);
                     tmax = e > tmax ? e : tmax;
@@ -834,12 +841,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 // more of them than the list holds (a flat field whose common energy IS the threshold): every pixel of the box is
                 // decided by the reference's arithmetic -- slow, rare, and the same answer
                 sc = 0;
-                for (uint32_t p = tid; p < area; p += kBlk) {
+                for (uint32_t p = (uint32_t)here(tid); p < area; p += kBlk) {
                     const uint32_t b = p / w, a = p - b * w;
                     if (exact_energy(a, b, G) / maxval > A.gabor_thr) sc++;
                 }
             } else
-                for (uint32_t k = tid; k < nr; k += kBlk) {
+                for (uint32_t k = (uint32_t)here(tid); k < nr; k += kBlk) {
                     const uint32_t p = s_redo[1 + k], b = p / w, a = p - b * w;
                     if (exact_energy(a, b, G) / maxval > A.gabor_thr) sc++;
                 }
@@ -899,13 +906,14 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         auto rewrite = [&](auto hold_c) {
             constexpr int kHold = decltype(hold_c)::value;
             uint32_t hold[kHold];
+            const uint32_t tid_r = (uint32_t)here(tid);
 #pragma unroll
-            for (int q = 0; q < kHold; q++) { const uint32_t i = (uint32_t)tid + (uint32_t)q * kBlk; hold[q] = i < words ? s_plane[i] : 0u; }
+            for (int q = 0; q < kHold; q++) { const uint32_t i = tid_r + (uint32_t)q * kBlk; hold[q] = i < words ? s_plane[i] : 0u; }
             __syncthreads();
             _Float16* const dp = (_Float16*)s_plane;
 #pragma unroll
             for (int q = 0; q < kHold; q++) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)q * kBlk;
+                const uint32_t i = tid_r + (uint32_t)q * kBlk;
                 if (i < words) {
                     const uint32_t v = (uint32_t)__uint_as_float(hold[q]);
                     dp[i] = (_Float16)(float)(v & ~low_mask);
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         // (squared, in the accumulators' scale, rounded outwards: the conversion to fp32 moves a bound by 6e-8 relative at most)
         const float lo2f = (float)(t_lo * t_lo * kScale2 * (1.0 - 3e-7)), hi2f = (float)(t_hi * t_hi * kScale2 * (1.0 + 3e-7));
         const uint32_t n_x4 = w / 4u + 1u, n_rt = (h + 15u) / 16u, n_units = n_x4 * n_rt;   // columns 4 x4 - 1 .. 4 x4 + 2, rows 16 rt .. 16 rt + 15
-        const int nn = lane & 15, kb = lane >> 4;
+        const int lane_h = here(lane), nn = lane_h & 15, kb = lane_h >> 4;
         const lds_f16_t* const dplane = (const lds_f16_t*)s_plane;
         const gabor_h8* const ops = (const gabor_h8*)A.gabor_bank16;
         for (int g = 0; 4 * g < nF; g++) {
@@ -930,7 +938,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             __syncthreads();
             gabor_h8 Bw[8];
 #pragma unroll
-            for (int jp = 0; jp < 8; jp++) Bw[jp] = ops[(g * 8 + jp) * 64 + lane];
+            for (int jp = 0; jp < 8; jp++) Bw[jp] = ops[(g * 8 + jp) * 64 + lane_h];
             const int f_lane = 1 + 4 * g + ((nn & 7) >> 1);                        // this lane's filter in the epilogue
             const uint32_t fl_lane = (uint32_t)(nn & 7) >> 1;
             const bool col_ok = (nn & 9) == 0 && f_lane <= nF;                     // (even column below 8: re^2 + im^2 of hi + lo lands there)
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                 // more pixels in the band than the list holds: this filter over the whole box with the reference's arithmetic
                 const bank_ptr_t G = bank + (size_t)(1 + 4 * g + fl) * N * N * 2;
                 uint32_t sc = 0;
-                for (uint32_t p = tid; p < area; p += kBlk) {
+                for (uint32_t p = (uint32_t)here(tid); p < area; p += kBlk) {
                     const uint32_t b = p / w, a = p - b * w;
                     if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
                 }
