@@ -448,11 +448,16 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, body);
     };
     MSTAMP(0);
-    // ---- pass 1: raw moments m_pq = sum I x^p y^q, all p, q in 0..3 (calcRawMoments :266-281, normRawMom :204-209);
-    //      one sweep per variant (0 = shape, INTEN = 1; 1 = intensity): 16 accumulators stay in registers
-    // (the kernel is bound by vector-instruction issue: a term I x^p y^q is (I x^p) -- four products per pixel -- times y^q,
-    //  accumulated with one fused multiply-add; the shape variant has I = 1 and skips the first product; a variant whose family
-    //  is not requested is not swept at all)
+    // ---- pass 1 + 2 as ONE sweep: moments about the box centre o = ((w - 1) / 2, (h - 1) / 2), mu_o[p][q] = sum I (x - o_x)^p (y - o_y)^q for
+    //      all p, q in 0..3 -- then, by the binomial theorem, the raw moments (origin 0: calcRawMoments :266-281) and the central ones
+    //      (origin = the centroid: :152-181, :298-316) as fixed combinations of the sixteen sums:
+    //          m[p][q] = sum_{k <= p, l <= q} C(p, k) C(q, l) e_x^(p - k) e_y^(q - l) mu_o[k][l],   e = o - (new origin).
+    //      The reference sweeps the pixels once per origin; here one sweep serves both (a third of the kernel's sums less).  Rounding:
+    //      |x - o| <= side / 2, so every term of a combination is at most (1 + |e| / (side / 2))^(p + q) times the size of the terms of
+    //      the direct sum -- <= 64 x for an origin one half-side away -- and the combination's error stays below 1e-14 of
+    //      m00 (side / 2)^(p + q), an order under the floor the parity tests grant a central moment that cancels (tests/parity.py).
+    const double obx = 0.5 * (double)(bw_ - 1u), oby = 0.5 * (double)(bh_ - 1u);
+    __shared__ double s_mo[2][16], s_wo[2][10];
 #pragma unroll 1
     for (int var = 0; var < 2; var++) {
         double acc[16];
@@ -460,36 +465,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
         for (int k = 0; k < 16; k++) acc[k] = 0;
         if (var ? do_i : do_s)
         sweep([&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double X = (double)xi, Y = (double)yi;
-            const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
-            if (var) {
-                const double I = (double)vi;
-                const double ix[4] = {I, I * xp[1], I * xp[2], I * xp[3]};
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = q ? __builtin_fma(ix[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + ix[p];
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
-            }
-        });
-        mom_block_sum<16, false>(acc, s_red, s_raw[var], tid);
-    }
-    __syncthreads();
-    MSTAMP(1);
-    // ---- pass 2: central moments about (m10 / m00, m01 / m00) (:152-160, :172-181, :298-316); each variant has its own origin
-#pragma unroll 1
-    for (int var = 0; var < 2; var++) {
-        const double ox = s_raw[var][4] / s_raw[var][0], oy = s_raw[var][1] / s_raw[var][0];
-        double acc[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = 0;
-        if (var ? do_i : do_s)
-        sweep([&](uint32_t, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double dx = (double)xi - ox, dy = (double)yi - oy;
+            const double dx = (double)xi - obx, dy = (double)yi - oby;
             const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
             if (var) {
                 const double I = (double)vi;
@@ -505,9 +481,30 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
                     for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
             }
         });
-        mom_block_sum<16, false>(acc, s_red, s_cen[var], tid);
+        mom_block_sum<16, false>(acc, s_red, s_mo[var], tid);
     }
     __syncthreads();
+    // m[p][q] about the origin o - e from the sums about o (binomial coefficients of orders 0..3)
+    auto shifted = [](const double* mo, int p, int q, double ex, double ey) -> double {
+        constexpr double C[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+        double exp_[4] = {1.0, ex, ex * ex, ex * ex * ex}, eyp[4] = {1.0, ey, ey * ey, ey * ey * ey};
+        double r = 0.0;
+        for (int k = 0; k <= p; k++)
+            for (int l = 0; l <= q; l++) r += C[p][k] * C[q][l] * exp_[p - k] * eyp[q - l] * mo[k * 4 + l];
+        return r;
+    };
+    if (tid < 32) {                                       // raw moments: origin 0, e = o
+        const int var = tid >> 4, pq = tid & 15;
+        s_raw[var][pq] = shifted(s_mo[var], pq >> 2, pq & 3, obx, oby);
+    }
+    __syncthreads();
+    if (tid < 32) {                                       // central moments: origin (m10 / m00, m01 / m00), each variant its own
+        const int var = tid >> 4, pq = tid & 15;
+        const double cx = s_raw[var][4] / s_raw[var][0], cy = s_raw[var][1] / s_raw[var][0];
+        s_cen[var][pq] = shifted(s_mo[var], pq >> 2, pq & 3, obx - cx, oby - cy);
+    }
+    __syncthreads();
+    MSTAMP(1);
     MSTAMP(2);
     // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
     constexpr int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
@@ -534,7 +531,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
         //  the twenty accumulators live across the hill descent the 80-register build spilled and reloaded them per pixel)
         sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
             const double lg = compact ? A.log_tab[s_d2[i]] : L[i];
-            const double X = (double)xi, Y = (double)yi;
+            const double X = (double)xi - obx, Y = (double)yi - oby;           // (about the box centre, like the sums of pass 1 + 2)
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
             const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
             const double sx[4] = {Ws, Ws * xp[1], Ws * xp[2], Ws * xp[3]}, ix[4] = {Wi, Wi * xp[1], Wi * xp[2], Wi * xp[3]};
@@ -544,38 +541,34 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
                 ai[k] = wr_q[k] ? __builtin_fma(ix[wr_p[k]], yp[wr_q[k]], ai[k]) : ai[k] + ix[wr_p[k]];
             }
         });
-        mom_block_sum<10, false>(as, s_red, s_wraw[0], tid);
-        mom_block_sum<10, false>(ai, s_red, s_wraw[1], tid);
+        mom_block_sum<10, false>(as, s_red, s_wo[0], tid);
+        mom_block_sum<10, false>(ai, s_red, s_wo[1], tid);
     }
     __syncthreads();
     MSTAMP(3);
-    // ---- pass 4: weighted central moments about the weighted origin (:162-167, :318-327) -----------------------------------
-    {
-        const double oxs = s_wraw[0][4] / s_wraw[0][0], oys = s_wraw[0][1] / s_wraw[0][0];
-        const double oxi = s_wraw[1][4] / s_wraw[1][0], oyi = s_wraw[1][1] / s_wraw[1][0];
-        double as[7], ai[7];
+    // ---- pass 4 without a sweep: the weighted raw moments (origin 0, :283-296) and the weighted central ones about the weighted
+    //      origin (:162-167, :318-327) from the ten weighted sums about the box centre, as above.  (The weighted origin may lie far
+    //      outside the box when the weighted mass nearly cancels: then |e| >> side and the shifted sum is dominated by its e^(p + q)
+    //      term -- as the reference's direct sum is.)
+    if (tid < 20) {
+        const int var = tid / 10, k = tid % 10;
+        double mo[16];
 #pragma unroll
-        for (int k = 0; k < 7; k++) { as[k] = 0; ai[k] = 0; }
-        sweep([&](uint32_t i, uint32_t vi, uint32_t xi, uint32_t yi) {
-            const double X = (double)xi, Y = (double)yi, lg = compact ? A.log_tab[s_d2[i]] : L[i];
-            const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
-            {
-                const double dx = X - oxs, dy = Y - oys;
-                const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
-                const double wx[4] = {Ws, Ws * xp[1], Ws * xp[2], Ws * xp[3]};
+        for (int q = 0; q < 16; q++) mo[q] = 0.0;
 #pragma unroll
-                for (int k = 0; k < 7; k++) as[k] = nc_q[k] ? __builtin_fma(wx[nc_p[k]], yp[nc_q[k]], as[k]) : as[k] + wx[nc_p[k]];
-            }
-            {
-                const double dx = X - oxi, dy = Y - oyi;
-                const double xp[4] = {1.0, dx, dx * dx, dx * dx * dx}, yp[4] = {1.0, dy, dy * dy, dy * dy * dy};
-                const double wx[4] = {Wi, Wi * xp[1], Wi * xp[2], Wi * xp[3]};
+        for (int q = 0; q < 10; q++) mo[wr_p[q] * 4 + wr_q[q]] = s_wo[var][q];
+        s_wraw[var][k] = shifted(mo, wr_p[k], wr_q[k], obx, oby);
+    }
+    __syncthreads();
+    if (tid < 14) {
+        const int var = tid / 7, k = tid % 7;
+        double mo[16];
 #pragma unroll
-                for (int k = 0; k < 7; k++) ai[k] = nc_q[k] ? __builtin_fma(wx[nc_p[k]], yp[nc_q[k]], ai[k]) : ai[k] + wx[nc_p[k]];
-            }
-        });
-        mom_block_sum<7, false>(as, s_red, s_wcen[0], tid);
-        mom_block_sum<7, false>(ai, s_red, s_wcen[1], tid);
+        for (int q = 0; q < 16; q++) mo[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 10; q++) mo[wr_p[q] * 4 + wr_q[q]] = s_wo[var][q];
+        const double ox = s_wraw[var][4] / s_wraw[var][0], oy = s_wraw[var][1] / s_wraw[var][0];
+        s_wcen[var][k] = shifted(mo, nc_p[k], nc_q[k], obx - ox, oby - oy);
     }
     __syncthreads();
     MSTAMP(4);
