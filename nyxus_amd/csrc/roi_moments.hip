@@ -343,6 +343,37 @@ __device__ __forceinline__ double min_sqdist_v2(int px, int py, const uint32_t* 
     return (double)extrem_d;
 }
 
+// The same search for boxes whose squared distances stay below 2^17 and contours below 2^15 - 1 points (every compact-staged ROI but
+// the 255 .. 256-pixel corner case): distance and index travel as ONE word, d << 15 | (i + 1), the incumbent with a zero index field,
+// so a round's "smaller distance wins, the incumbent keeps ties, the first of equal candidates wins" is one v_min_u32 per candidate
+// (a compare, a minimum and a select before), and v_dot2_i32_i16 takes a literal zero addend (the two-operand form the compiler picks
+// needs a move per candidate).  K1 = the contour array minus one element (candidate i is K1[i + 1]).
+__device__ __forceinline__ double min_sqdist_packed(int px, int py, const uint32_t* K1, int n, int step0, const uint16_t* tab, int tab_n)
+{
+    const uint32_t ppack = ((uint32_t)px & 0xFFFFu) | ((uint32_t)py << 16);
+    auto sqd1 = [&](uint32_t ip1) -> uint32_t {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 d = __builtin_bit_cast(s16x2, K1[ip1]) - __builtin_bit_cast(s16x2, ppack);
+        uint32_t r;
+        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(d));
+        return r;
+    };
+    uint32_t key = sqd1(1u) << 15;
+    if (n == 1) return (double)(key >> 15);
+    uint32_t a = 0, b = (uint32_t)n, extrem_i = 0;
+    uint32_t step = (uint32_t)step0;
+    do {
+        for (uint32_t ip1 = a + step + 1u; ip1 <= b; ip1 += step) key = min(key, (sqd1(ip1) << 15) | ip1);
+        if (key & 0x7FFFu) { extrem_i = (key & 0x7FFFu) - 1u; key &= ~0x7FFFu; }
+        const uint32_t stepL = extrem_i >= step ? step : extrem_i,
+                       stepR = extrem_i + step < (uint32_t)n ? step : (uint32_t)n - extrem_i;
+        a = extrem_i - stepL;
+        b = extrem_i + stepR;
+        step = (uint32_t)descent_step((size_t)(b - a), tab, tab_n);
+    } while (b - a > 2);
+    return (double)(key >> 15);
+}
+
 __device__ __forceinline__ double ipow(double a, int b) { double r = 1.0; for (int i = 0; i < b; i++) r *= a; return r; }
 
 __device__ void hu7(double _02, double _03, double _11, double _12, double _20, double _21, double _30, double* h)
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     //      the direct sum -- <= 64 x for an origin one half-side away -- and the combination's error stays below 1e-14 of
     //      m00 (side / 2)^(p + q), an order under the floor the parity tests grant a central moment that cancels (tests/parity.py).
     const double obx = 0.5 * (double)(bw_ - 1u), oby = 0.5 * (double)(bh_ - 1u);
-    __shared__ double s_mo[2][16], s_wo[2][10];
+    __shared__ double s_mo[2][16], s_wo[2][10], s_wo16[2][16];
 #pragma unroll 1
     for (int var = 0; var < 2; var++) {
         double acc[16];
@@ -485,12 +516,13 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     }
     __syncthreads();
     // m[p][q] about the origin o - e from the sums about o (binomial coefficients of orders 0..3)
+    // (no local arrays: an array indexed at run time lives in scratch memory)
     auto shifted = [](const double* mo, int p, int q, double ex, double ey) -> double {
-        constexpr double C[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
-        double exp_[4] = {1.0, ex, ex * ex, ex * ex * ex}, eyp[4] = {1.0, ey, ey * ey, ey * ey * ey};
+        auto binom = [](int n, int k) -> double { return (n == 3 && (k == 1 || k == 2)) ? 3.0 : (n == 2 && k == 1) ? 2.0 : 1.0; };
+        auto pw = [](double e, int n) -> double { const double e2 = e * e; return n == 0 ? 1.0 : n == 1 ? e : n == 2 ? e2 : e2 * e; };
         double r = 0.0;
         for (int k = 0; k <= p; k++)
-            for (int l = 0; l <= q; l++) r += C[p][k] * C[q][l] * exp_[p - k] * eyp[q - l] * mo[k * 4 + l];
+            for (int l = 0; l <= q; l++) r += binom(p, k) * binom(q, l) * pw(ex, p - k) * pw(ey, q - l) * mo[k * 4 + l];
         return r;
     };
     if (tid < 32) {                                       // raw moments: origin 0, e = o
@@ -507,8 +539,9 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     MSTAMP(1);
     MSTAMP(2);
     // (p, q) of the 10 weighted raw moments and of the 7 (weighted / normalized) central ones
-    constexpr int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
-    constexpr int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
+    static constexpr int wr_p[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, wr_q[10] = {0, 1, 2, 3, 0, 1, 2, 0, 1, 0};
+    static constexpr int nc_p[7] = {0, 0, 1, 1, 2, 2, 3}, nc_q[7] = {2, 3, 1, 2, 0, 1, 0};
+    const bool packed = compact && K == s_K && nK >= 1 && nK <= 32766 && (bw_ + 2u) * (bw_ + 2u) + (bh_ + 2u) * (bh_ + 2u) < (1u << 17);   // (min_sqdist_packed)
     // ---- pass 3: log(distance to contour + eps) per pixel (:32-53) and the weighted raw moments (:283-296); the weighted
     //      intensity passes through float (realintens is a vector<float>)
     {
@@ -521,6 +554,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             // (the contour normally sits in LDS: passing the array itself -- not a pointer that may also be global -- turns the
             //  descent's loads into ds_read instead of flat loads with 64-bit addresses)
             const double dsq = !small_xy ? min_sqdist_v2<false>((int)xi, (int)yi, K, nK, step0, s_step, tab_n)
+                             : packed ? min_sqdist_packed((int)xi, (int)yi, s_K - 1, nK, step0, s_step, tab_n)
                              : K == s_K ? min_sqdist_v2<true>((int)xi, (int)yi, s_K, nK, step0, s_step, tab_n)
                                         : min_sqdist_v2<true>((int)xi, (int)yi, K, nK, step0, s_step, tab_n);
             if (compact) { s_d2[i] = (uint16_t)(uint32_t)dsq; return; }       // (dsq <= the box's squared diagonal < log_tab_n <= 65536)
@@ -550,25 +584,19 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     //      origin (:162-167, :318-327) from the ten weighted sums about the box centre, as above.  (The weighted origin may lie far
     //      outside the box when the weighted mass nearly cancels: then |e| >> side and the shifted sum is dominated by its e^(p + q)
     //      term -- as the reference's direct sum is.)
+    if (tid < 32) s_wo16[tid >> 4][tid & 15] = 0.0;         // the ten sums in the [p * 4 + q] layout of `shifted` (the other six: zero)
+    __syncthreads();
+    if (tid < 20) { const int var = tid / 10, k = tid % 10; s_wo16[var][wr_p[k] * 4 + wr_q[k]] = s_wo[var][k]; }
+    __syncthreads();
     if (tid < 20) {
         const int var = tid / 10, k = tid % 10;
-        double mo[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) mo[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 10; q++) mo[wr_p[q] * 4 + wr_q[q]] = s_wo[var][q];
-        s_wraw[var][k] = shifted(mo, wr_p[k], wr_q[k], obx, oby);
+        s_wraw[var][k] = shifted(s_wo16[var], wr_p[k], wr_q[k], obx, oby);
     }
     __syncthreads();
     if (tid < 14) {
         const int var = tid / 7, k = tid % 7;
-        double mo[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) mo[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 10; q++) mo[wr_p[q] * 4 + wr_q[q]] = s_wo[var][q];
         const double ox = s_wraw[var][4] / s_wraw[var][0], oy = s_wraw[var][1] / s_wraw[var][0];
-        s_wcen[var][k] = shifted(mo, nc_p[k], nc_q[k], obx - ox, oby - oy);
+        s_wcen[var][k] = shifted(s_wo16[var], nc_p[k], nc_q[k], obx - ox, oby - oy);
     }
     __syncthreads();
     MSTAMP(4);
