@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(NW * 64) void roi_zernike_kernel(const ShapeArgs A)
     // combinations of the 30 complex sums  T[m][j] = sum_pixels f / r * (r^2)^j * (x - i y)^(m + 1),  j = 0 .. (9 - m) / 2:
     // per pixel one complex power recurrence (4 operations per m), five weights and two multiply-adds per sum -- ~125 vector
     // instructions instead of ~290 (the radial recurrence, a product and two multiply-adds per (n, m)).  The combination runs once
-    // per ROI; its cancellation (coefficients up to 630) costs three of fp64's sixteen digits: 1e-13 against the oracle, the moments
+    // per ROI; its cancellation (coefficients up to 630) costs three of fp64's sixteen digits: 1e-13 against the per-pixel recurrence, the moments
     // carry a 1e-5 tolerance (the reference's regression vector: 1e-9 absolute).
     constexpr int kZT = 30;                             // pairs (m, j): m = 0 .. 9, j = 0 .. (9 - m) / 2
     double TR[kZT], TI[kZT];
