@@ -107,20 +107,25 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
                     if (lane == 0) img[p0] = v | kBorder;             // undiscovered border point: trace around it
                     int pos = (int)p0, loc = 1, counter = 0;
                     for (;;) {
+                        // (the kernel is bound by the CU's scalar unit -- 18 k scalar against 8.5 k vector instructions per wave, one
+                        //  scalar issue per cycle and CU -- so the step keeps the scalar unit out of what the lanes can do: every lane
+                        //  probes (lanes 8 .. 63 repeat lanes 0 .. 7: no lane mask to set up; the position is a pixel, so all eight
+                        //  neighbours lie inside the padded plane: no bounds to test), and the winner's position comes out of the
+                        //  winning lane's register with one v_readlane instead of a scalar decode of its direction)
                         const int d = (loc - 1 + lane) & 7;
                         const int cpl = pos + mul_i24((int)((kDy >> (2 * d)) & 3u) - 1, W2) + ((int)((kDx >> (2 * d)) & 3u) - 1);   // (24-bit product: full rate)
-                        const bool hit = lane < 8 && cpl >= 0 && (uint32_t)cpl < np && (img[cpl] & kPix);
-                        const uint32_t hm = (uint32_t)__ballot(hit) & 0xFFu;
+                        const uint32_t hm = (uint32_t)__ballot((img[cpl] & kPix) != 0) & 0xFFu;
                         if (hm == 0) break;
-                        const int dk = (loc - 1 + (__ffs((int)hm) - 1)) & 7;
-                        const int cp = pos + ((int)((kDy >> (2 * dk)) & 3u) - 1) * W2 + ((int)((kDx >> (2 * dk)) & 3u) - 1);
+                        const int kwin = __ffs((int)hm) - 1;
+                        const int dk = (loc - 1 + kwin) & 7;
+                        const int cp = __builtin_amdgcn_readlane(cpl, kwin);
                         const int nloc = ((dk & ~1) + 7) & 7;
                         if (cp == (int)p0) {
                             counter++;
                             if (nloc == 1 || counter >= 3) { inside = true; break; }
                         }
                         loc = nloc; pos = cp;
-                        if (lane == 0) img[cp] = (uint8_t)(kPix | kBorder);     // (a hit is a pixel and no other flag exists yet: a plain store, no read on the chain)
+                        img[cp] = (uint8_t)(kPix | kBorder);     // (a hit is a pixel and no other flag exists yet: a plain store, no read on the chain; every lane stores the same byte: no lane mask)
                     }
                 }
             }
