@@ -27,6 +27,10 @@ namespace {
 
 constexpr uint8_t kPix = 1, kBorder = 2, kCand = 4, kAlive = 8;
 
+// the value as a VECTOR register the optimiser cannot look through (a store indexed by it takes scalar base + vector offset: no
+// 64-bit address arithmetic on the scalar unit, which bounds the contour kernel)
+__device__ __forceinline__ int here_i(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ int dial_pos(int dx, int dy)     // contour.cpp:218-262
 {
     if (dx > 0) return dy < 0 ? 2 : dy > 0 ? -1 : 1;
@@ -205,9 +209,14 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
     // ---- contour by contour (:587-619) with check_loop (:306-379) on the alive bits.  The walk state is wave-uniform;
     //      lanes 0-3 probe the straight neighbours and lanes 4-7 the diagonal ones, each group ordered by falling dial
     //      position (W 5, N 3, E 1, S -2; NW 4, NE 2, SE -1, SW -3), so prune_cands' winner is the lowest set lane.
-    const int pdx = lane == 0 ? -1 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? -1 : lane == 5 ? 1 : lane == 6 ? 1 : -1;
-    const int pdy = lane == 0 ? 0 : lane == 1 ? -1 : lane == 2 ? 0 : lane == 3 ? 1 : lane == 4 ? -1 : lane == 5 ? -1 : lane == 6 ? 1 : 1;
+    // (every lane probes -- lanes 8 .. 63 repeat lanes 0 .. 7 -- and the winner's step comes out of the winning lane's registers with
+    //  v_readlane; stores are issued by every lane to the one address: no lane masks, no scalar address arithmetic.  The kernel is
+    //  bound by the scalar unit, see the trace above.)
+    const int l8 = lane & 7;
+    const int pdx = l8 == 0 ? -1 : l8 == 1 ? 0 : l8 == 2 ? 1 : l8 == 3 ? 0 : l8 == 4 ? -1 : l8 == 5 ? 1 : l8 == 6 ? 1 : -1;
+    const int pdy = l8 == 0 ? 0 : l8 == 1 ? -1 : l8 == 2 ? 0 : l8 == 3 ? 1 : l8 == 4 ? -1 : l8 == 5 ? -1 : l8 == 6 ? 1 : 1;
     const int noff = pdx + pdy * W2;                              // this lane's neighbour as an offset in the plane
+    const int pstep = pdx + pdy * 65536;                          // both steps in one register: x | y << 16 plus this is (x + dx) | (y + dy) << 16 (padded coordinates are >= 1: no borrow leaves a field)
     uint32_t nK = 0, cursor = 0;
     while (n_u != 0) {
         for (;;) {                                                // U.front(): the raster-first unordered pixel
@@ -221,37 +230,39 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         int looplen = 0, result = -1;
         // (an alive position carries all four flags: clearing kAlive is a plain store of the other three -- no read-modify-write
         //  on the walk's serial chain)
-        if (lane == 0) { K[nK] = (uint32_t)ox | ((uint32_t)oy << 16); img[cursor] = (uint8_t)(kPix | kBorder | kCand); }
+        // the walk's position: txy = x | y << 16 and tpos = y * W2 + x, both wave-uniform
+        uint32_t txy = (uint32_t)ox | ((uint32_t)oy << 16);
+        int tpos = (int)cursor;
+        {
+            const uint32_t kidx = (uint32_t)here_i((int)nK);        // (a vector register: the store takes base + offset, no 64-bit scalar arithmetic)
+            K[kidx] = txy; img[here_i(tpos)] = (uint8_t)(kPix | kBorder | kCand);
+        }
         ns = 1; n_u--;
-        int tx = ox, ty = oy;
         wav_sync<GS>();
         while (n_u != 0) {
             // (padded coordinates: the walk stands on a pixel, so all eight neighbours lie inside the plane -- the probe is one add
-            //  on the position, which travels in a scalar register next to tx / ty)
-            const bool alive = lane < 8 && (img[(uint32_t)(ty * W2 + tx + noff)] & kAlive);
-            const uint32_t m = (uint32_t)__ballot(alive);
+            //  on the position)
+            const uint32_t m = (uint32_t)__ballot((img[(uint32_t)(tpos + noff)] & kAlive) != 0) & 0xFFu;
             const uint32_t cands = (m & 0xFu) ? (m & 0xFu) : (m >> 4);   // find_cands :193-216: straight neighbours first
             const bool diag = (m & 0xFu) == 0;
             const int nc = __popc(cands);
-            if (nc > 1) { if (lane == 0) stk[nP] = (uint32_t)tx | ((uint32_t)ty << 16); nP++; }
+            if (nc > 1) { if (lane == 0) stk[nP] = txy; nP++; }
             if (nc == 0) {
-                const int ddx = tx - ox, ddy = ty - oy;
+                const int ddx = (int)(txy & 0xFFFFu) - ox, ddy = (int)(txy >> 16) - oy;
                 if (ddx == 1 || ddx == -1 || ddy == 1 || ddy == -1) { looplen++; result = looplen; break; }
                 if (nP == 0) { result = 0; break; }
                 --nP;
                 uint32_t t = lane == 0 ? stk[nP] : 0u;
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                tx = (int)(t & 0xFFFFu); ty = (int)(t >> 16);
+                txy = t; tpos = (int)((t >> 16) * (uint32_t)W2 + (t & 0xFFFFu));
             } else {
                 const int k = (__ffs((int)cands) - 1) + (diag ? 4 : 0);
-                const int bdx = k == 0 ? -1 : k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 0 : k == 4 ? -1 : k == 5 ? 1 : k == 6 ? 1 : -1;
-                const int bdy = k == 0 ? 0 : k == 1 ? -1 : k == 2 ? 0 : k == 3 ? 1 : k == 4 ? -1 : k == 5 ? -1 : k == 6 ? 1 : 1;
                 looplen++;
-                tx += bdx; ty += bdy;
-                if (lane == 0) {
-                    K[nK + ns] = (uint32_t)tx | ((uint32_t)ty << 16);
-                    img[mad24((uint32_t)ty, (uint32_t)W2, (uint32_t)tx)] = (uint8_t)(kPix | kBorder | kCand);
-                }
+                txy += (uint32_t)__builtin_amdgcn_readlane(pstep, k);
+                tpos += __builtin_amdgcn_readlane(noff, k);
+                const uint32_t kidx = (uint32_t)here_i((int)(nK + ns));
+                K[kidx] = txy;
+                img[here_i(tpos)] = (uint8_t)(kPix | kBorder | kCand);
                 ns++; n_u--;
                 wav_sync<GS>();
             }
