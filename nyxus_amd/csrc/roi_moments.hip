@@ -230,13 +230,13 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
         int looplen = 0, result = -1;
         // (an alive position carries all four flags: clearing kAlive is a plain store of the other three -- no read-modify-write
         //  on the walk's serial chain)
-        // the walk's position: txy = x | y << 16 and tpos = y * W2 + x, both wave-uniform
-        uint32_t txy = (uint32_t)ox | ((uint32_t)oy << 16);
-        int tpos = (int)cursor;
-        {
-            const uint32_t kidx = (uint32_t)here_i((int)nK);        // (a vector register: the store takes base + offset, no 64-bit scalar arithmetic)
-            K[kidx] = txy; img[here_i(tpos)] = (uint8_t)(kPix | kBorder | kCand);
-        }
+        // the walk's position -- txy = x | y << 16, tpos = y * W2 + x -- and the output index travel in VECTOR registers (the same value
+        // in every lane): their updates and the stores' addresses then cost the vector unit one instruction each and the scalar unit none
+        uint32_t txy = (uint32_t)here_i((int)((uint32_t)ox | ((uint32_t)oy << 16)));
+        int tpos = here_i((int)cursor);
+        uint32_t kidx = (uint32_t)here_i((int)nK);
+        K[kidx] = txy; img[tpos] = (uint8_t)(kPix | kBorder | kCand);
+        kidx++;
         ns = 1; n_u--;
         wav_sync<GS>();
         while (n_u != 0) {
@@ -248,21 +248,22 @@ __global__ __launch_bounds__(64 * kContourWaves) void roi_contour_kernel(const M
             const int nc = __popc(cands);
             if (nc > 1) { if (lane == 0) stk[nP] = txy; nP++; }
             if (nc == 0) {
-                const int ddx = (int)(txy & 0xFFFFu) - ox, ddy = (int)(txy >> 16) - oy;
+                const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)txy);
+                const int ddx = (int)(cur & 0xFFFFu) - ox, ddy = (int)(cur >> 16) - oy;
                 if (ddx == 1 || ddx == -1 || ddy == 1 || ddy == -1) { looplen++; result = looplen; break; }
                 if (nP == 0) { result = 0; break; }
                 --nP;
                 uint32_t t = lane == 0 ? stk[nP] : 0u;
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                txy = t; tpos = (int)((t >> 16) * (uint32_t)W2 + (t & 0xFFFFu));
+                txy = (uint32_t)here_i((int)t); tpos = here_i((int)((t >> 16) * (uint32_t)W2 + (t & 0xFFFFu)));
             } else {
                 const int k = (__ffs((int)cands) - 1) + (diag ? 4 : 0);
                 looplen++;
                 txy += (uint32_t)__builtin_amdgcn_readlane(pstep, k);
                 tpos += __builtin_amdgcn_readlane(noff, k);
-                const uint32_t kidx = (uint32_t)here_i((int)(nK + ns));
                 K[kidx] = txy;
-                img[here_i(tpos)] = (uint8_t)(kPix | kBorder | kCand);
+                img[tpos] = (uint8_t)(kPix | kBorder | kCand);
+                kidx++;
                 ns++; n_u--;
                 wav_sync<GS>();
             }
