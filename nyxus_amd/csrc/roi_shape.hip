@@ -897,7 +897,9 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
     // packed-fp32 pass; the Gabor probe measures 1.0e-8 a_max.
     // Pixels inside the band go to the same list and are recomputed by the reference's arithmetic from the digit planes.
     auto run_bands_mfma = [&]() {
-        constexpr uint32_t kSub = (uint32_t)kGaborRedoCap / 4u;
+        // lists of band pixels, one per filter, for ALL groups: [16 counters][n filters x kSub entries]; they are recomputed in one run
+        // behind the last group (per group it was one wave-long recomputation each: two of the three on an 8-filter bank's small ROIs)
+        const uint32_t n_lists = (uint32_t)(4 * ((nF + 3) / 4)), kSub = ((uint32_t)kGaborRedoCap - 12u) / n_lists;
         const uint32_t maxi = A.max_inten[roi];
         const uint32_t low_bits = maxi < 2048u ? 0u : (uint32_t)(21 - __builtin_clz(maxi)), low_mask = (1u << low_bits) - 1u;   // (bits - 11)
         const bool two = low_bits != 0;
@@ -934,13 +936,12 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
         const lds_f16_t* const dplane = (const lds_f16_t*)s_plane;
         const gabor_h8* const ops = (const gabor_h8*)A.gabor_bank16;
         for (int g = 0; 4 * g < nF; g++) {
-            if (tid < 4) s_redo[tid] = 0;                                          // four lists, one per filter of the group: [4 counters][4][kSub]
-            __syncthreads();
+            if (g == 0) { if (tid < 16) s_redo[tid] = 0; __syncthreads(); }
             gabor_h8 Bw[8];
 #pragma unroll
             for (int jp = 0; jp < 8; jp++) Bw[jp] = ops[(g * 8 + jp) * 64 + lane_h];
             const int f_lane = 1 + 4 * g + ((nn & 7) >> 1);                        // this lane's filter in the epilogue
-            const uint32_t fl_lane = (uint32_t)(nn & 7) >> 1;
+            const uint32_t fl_lane = 4u * (uint32_t)g + ((uint32_t)(nn & 7) >> 1);   // this lane's list
             const bool col_ok = (nn & 9) == 0 && f_lane <= nF;                     // (even column below 8: re^2 + im^2 of hi + lo lands there)
             uint32_t cnt = 0;
             // (the thresholds of a lane whose column carries no energy are infinite: its comparisons are false)
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                         for (int r = 0; r < 4; r++)
                             if (!(e2[r] > hi_r[r]) && e2[r] >= lo_r[r]) {
                                 const uint32_t k = atomicAdd(&s_redo[fl_lane], 1u);
-                                if (k < kSub) s_redo[4u + fl_lane * kSub + k] = (b0 + (uint32_t)r) * w + a;
+                                if (k < kSub) s_redo[16u + fl_lane * kSub + k] = (b0 + (uint32_t)r) * w + a;
                             }
                     }
                 }
@@ -1031,43 +1032,45 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
             cnt += __shfl_xor(cnt, 16, 64);
             cnt += __shfl_xor(cnt, 32, 64);
             if (lane < 16 && col_ok) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + f_lane - 1] = (double)cnt;   // [wave][filter]
-            __syncthreads();
+        }
+        __syncthreads();
+        {
             const lds_u32_t* const pl = (const lds_u32_t*)s_plane;
-            // The four filters' lists as ONE run over the workgroup's threads (a handful of pixels each on ordinary data: as four runs
-            // they cost four wave-long recomputations of a few live lanes; the taps then differ from lane to lane and come through
+            // All filters' lists as ONE run over the workgroup's threads (a handful of pixels each on ordinary data: as a run per filter
+            // they cost a wave-long recomputation of a few live lanes each; the taps then differ from lane to lane and come through
             // vector loads).  A list that overflowed is left out here and its filter recomputed over the whole box below.
-            uint32_t n_q[4], n_all = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const uint32_t nr = 4 * g + q < nF ? s_redo[q] : 0u; n_q[q] = nr > kSub ? 0u : nr; n_all += n_q[q]; }
+            uint32_t n_all = 0;
+            for (int q = 0; q < nF; q++) { const uint32_t nr = s_redo[q]; n_all += nr > kSub ? 0u : nr; }
             NYX_GABOR_PHASE_EXIT(A.dbg_phase == 6 && tid < 4, diag_cnt[1 + tid] = s_redo[tid]);
             for (uint32_t k0 = (uint32_t)wave * 64u; k0 < n_all; k0 += kBlk) {          // (the same trips in every lane of a wave: the ballots below)
                 uint32_t k = k0 + (uint32_t)lane, fl = 0;
                 const bool live = k < n_all;
-#pragma unroll
-                for (int q = 0; q < 3; q++) if (live && fl == (uint32_t)q && k >= n_q[q]) { k -= n_q[q]; fl = (uint32_t)q + 1u; }
+                for (int q = 0; q < nF - 1; q++) {
+                    const uint32_t nr = s_redo[q], nq = nr > kSub ? 0u : nr;
+                    if (live && fl == (uint32_t)q && k >= nq) { k -= nq; fl = (uint32_t)q + 1u; }
+                }
                 bool hit = false;
                 if (live) {
-                    const uint32_t p = s_redo[4u + fl * kSub + k], b = p / w, a = p - b * w;
-                    hit = gabor_exact_energy<2, false>(pl, pitch, a, b, bank + (size_t)(1 + 4 * g + (int)fl) * N * N * 2, words) / maxval > A.gabor_thr;
+                    const uint32_t p = s_redo[16u + fl * kSub + k], b = p / w, a = p - b * w;
+                    hit = gabor_exact_energy<2, false>(pl, pitch, a, b, bank + (size_t)(1 + (int)fl) * N * N * 2, words) / maxval > A.gabor_thr;
                 }
-#pragma unroll
-                for (uint32_t q = 0; q < 4; q++) {
+                for (uint32_t q = 0; q < (uint32_t)nF; q++) {
                     const uint32_t c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit && fl == q));
-                    if (lane == 0 && c) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + (int)q] += (double)c;
+                    if (lane == 0 && c) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + (int)q] += (double)c;
                 }
             }
-            for (int fl = 0; fl < 4 && 4 * g + fl < nF; fl++) {
+            for (int fl = 0; fl < nF; fl++) {
                 if (s_redo[fl] <= kSub)
                     continue;
                 // more pixels in the band than the list holds: this filter over the whole box with the reference's arithmetic
-                const bank_ptr_t G = bank + (size_t)(1 + 4 * g + fl) * N * N * 2;
+                const bank_ptr_t G = bank + (size_t)(1 + fl) * N * N * 2;
                 uint32_t sc = 0;
                 for (uint32_t p = (uint32_t)here(tid); p < area; p += kBlk) {
                     const uint32_t b = p / w, a = p - b * w;
                     if (gabor_exact_energy<2>(pl, pitch, a, b, G, words) / maxval > A.gabor_thr) sc++;
                 }
                 const uint32_t tot = (uint32_t)wave_sum_u64(sc);
-                if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + 4 * g + fl] = (double)tot;
+                if (lane == 0) s_red[wave * NYXHIP_MAX_GABOR_FILTERS + fl] = (double)tot;
             }
             __syncthreads();
         }
