@@ -652,6 +652,9 @@ def main():
                 import size_legs as sl
                 rec["size_sweep"] = {"rows": sl.size_sweep(ctx, dev, mask, s),
                                      "what": "ns per ROI of homogeneous batches of disks (radius 4, 9, 18, 30, 51, 102), *ALL_GLCM*+*ALL_INTENSITY*, gd 8"}
+                # the same at the reference's default grey depth, small boxes (where the dense 64 x 64 feature pass is the whole cost)
+                rec["size_sweep_gd64"] = {"rows": sl.size_sweep(ctx, dev, mask, _abi.default_settings(64), radii=(4, 9, 18, 30)),
+                                          "what": "ns per ROI of homogeneous batches of disks (radius 4, 9, 18, 30), *ALL_GLCM*+*ALL_INTENSITY*, grey depth 64"}
 
                 def chk_mixed(bm, om, mk=mask):
                     rng = np.random.default_rng(1)
@@ -849,6 +852,8 @@ def main():
                 summ["mixed_sizes.config4_set"] = brief(rec["mixed_sizes"]["config4_set"], "ms_per_call")
         if isinstance(rec.get("size_sweep"), dict):
             summ["size_sweep_ns_per_roi"] = {str(r_["n_px"]): round(r_["ns_per_roi"], 2) for r_ in rec["size_sweep"].get("rows", []) if r_.get("ns_per_roi") is not None}
+        if isinstance(rec.get("size_sweep_gd64"), dict):
+            summ["size_sweep_gd64_ns_per_roi"] = {str(r_["n_px"]): round(r_["ns_per_roi"], 2) for r_ in rec["size_sweep_gd64"].get("rows", []) if r_.get("ns_per_roi") is not None}
         if isinstance(rec.get("intensity_range"), dict):
             summ["intensity_range_ns_per_roi"] = {r_["intensities"]: (round(r_["ns_per_roi"], 2) if r_.get("ns_per_roi") is not None else None) for r_ in rec["intensity_range"].get("rows", [])}
         if "ratios" in rec:

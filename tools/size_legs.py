@@ -105,11 +105,11 @@ def time_call(ctx, batch, mask, s, out, reps=3):
 SWEEP_RADII = (4, 9, 18, 30, 51, 102)          # disks of 49, 253, 1009, 2821, 8171, 32697 pixels
 
 
-def size_sweep(ctx, dev, mask, s, px_budget=120_000_000, max_rois=196_000):
+def size_sweep(ctx, dev, mask, s, px_budget=120_000_000, max_rois=196_000, radii=None):
     """ns per ROI of homogeneous batches, one per radius."""
     import torch
     rows = []
-    for r in SWEEP_RADII:
+    for r in (radii or SWEEP_RADII):
         n1 = len(ellipse_cloud(r, r)[0])
         n_roi = int(max(256, min(max_rois, px_budget // n1)))
         b = DeviceBatch([(r, r)] * n_roi, dev, seed=100 + r)
