@@ -355,7 +355,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
     //  sweep is through, and the feature pass's scratch -- features, sums, row marginals: 4.6 KB -- takes its place: the carve-out
     //  of the benchmark ROI drops from 43.1 to 39.3 KB, four workgroups per CU instead of three)
     uint32_t plane_bytes = L.dense8 ? 1u * L.dense_cap + 64 + 8 : 2u * L.dense_cap + 8;
-    const uint32_t g16_scratch = L.g16 ? 8u * ((uint32_t)s->grey_depth + 2u * kMaxAngles * 32u + kMaxAngles * (uint32_t)s->grey_depth) : 0u;
+    const uint32_t g16_scratch = L.g16 ? 8u * ((uint32_t)s->grey_depth + kMaxAngles * 128u) : 0u;          // level values | a 1 KiB block per angle-wave (glcm_features_wave64_v2)
     if (plane_bytes < g16_scratch) plane_bytes = g16_scratch;
     off = align16(off + plane_bytes);
     if (do_glcm) {
@@ -378,7 +378,7 @@ int make_layout(uint32_t mask, const nyxhip_settings* s, int n_cols, uint32_t ma
         L.radix = off; off = align16(off + (L.radix_k16 ? 0u : 4u * L.sort_cap) + 4u * (kWaves * 256 + kWaves) + 16);
     }
     if (do_glcm && L.g16) {
-        const uint32_t ng = (uint32_t)s->grey_depth, cellsw = ((ng + 1) * (ng + 1) + 1) / 2;
+        const uint32_t ng = (uint32_t)s->grey_depth, cellsw = ((ng + 1) * ((ng + 3) & ~1u)) / 2;     // rows 0..ng of an even pitch (roi_features.hip, G16 block)
         L.ng_cap = ng; L.app = 4;
         uint32_t goff = shared0;
         L.P = goff; goff = align16(goff + 4u * 4u * cellsw);

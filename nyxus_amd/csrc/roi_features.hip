@@ -748,6 +748,262 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
     wav_sync<false>();
 }
 
+// ---- round 6: the same features from matrices of pitch `pitch` (even) whose data cells are word-aligned pairs ---------------------
+// Layout (roi_features_kernel_g16): u16 cells, rows 0..Ng (row = centre level, row 0 unused), element (centre a, neighbour b) at
+// P[a * pitch + b - 1], pitch = (Ng + 3) & ~1: data columns 0..Ng-1 hold neighbour levels 1..Ng, a skipped neighbour (level 0)
+// lands in the LAST column of the previous row (never read), and column Ng of every row stays zero.  A row starts on a word, so
+// two cells travel in one register: row sums with v_pk_add_u16, the per-cell terms of two rows at once (lanes 0..31 one row, lanes
+// 32..63 another; v_dot2_u32_u16 for sum cnt^2, v_pk_max_u16, the entropy terms of BOTH cells of a word from one read of an
+// 8 x 8 table), completed diagonals leave the travelling accumulators through one store per row from every lane (the lanes that
+// do not hold a complete diagonal write to a junk strip: no exec juggling).  Per angle-wave 3136 -> ~2300 vector instructions.
+// blk: 256 words of LDS per wave: [f: 32 doubles | sm: 32 doubles | T2: 64 doubles], the diagonal picks lie over all of it
+// (PX 64 words | PW 64 words | junk 127 words) while nothing else is live.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+template <int NG>
+__device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int Ng_rt, uint32_t* blk, double soft_nan, int lane)
+{
+    const int Ng = NG ? NG : Ng_rt;                    // (NG = 64: the reference's default grey depth as a compile-time fact -- row offsets become immediates)
+    typedef __attribute__((address_space(3))) const uint16_t lds_cu16_t;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    const int pitch = (Ng + 3) & ~1;
+    double* const f = (double*)blk;
+    double* const sm = f + 32;
+    double* const T2 = f + 64;
+    const bool act = lane < Ng;                        // lane l owns column l, row l and the diagonal pair |x - y| = l
+    const uint16_t* const Pd = P + pitch;              // row of level 1
+    // ---- row sums: lane = row, the row's words (pitch / 2 apart per lane: no bank conflict) ------------------------------------
+    uint32_t rc = 0;
+    {
+        const int nw = (Ng + 1) >> 1;
+        lds_cu32_t* rw = (lds_cu32_t*)(uintptr_t)(Pd + (act ? lane : 0) * pitch);
+        us2_t a2 = {0, 0};
+#pragma unroll 8
+        for (int j = 0; j < nw; j++) a2 = a2 + __builtin_bit_cast(us2_t, rw[j]);
+        rc = act ? (uint32_t)a2.x + (uint32_t)a2.y : 0u;
+    }
+    // ---- column sums and the two families of diagonals in one pass over the rows (lane = column; see glcm_features_wave64_u16) --
+    uint32_t cc = 0, dc = 0;
+    uint32_t pxpy_c[2] = {0u, 0u};
+    {
+        uint32_t W = 0, X = 0;
+        const int cj = lane < Ng ? lane : Ng;          // (lanes beyond the matrix read the zero column)
+        lds_cu16_t* pc = (lds_cu16_t*)(uintptr_t)(Pd + cj);
+        lds_u32_t* const b0 = (lds_u32_t*)(uintptr_t)blk;
+        lds_u32_t* px = lane == 0 ? b0 : b0 + 128 + lane;           // [i]: anti-diagonal i, complete in lane 0 after row i
+        lds_u32_t* pw = lane == Ng - 1 ? b0 + 64 : b0 + 128 + lane; // [i]: upper diagonal Ng - 1 - i, complete in lane Ng - 1 after row i
+#pragma unroll 8
+        for (int i = 0; i < Ng; i++) {
+            const uint32_t cnt = pc[i * pitch];
+            cc += cnt;
+            X = lane_plus1_z(X) + cnt;
+            W = lane_minus1_z(W) + cnt;
+            px[i] = X;
+            pw[i] = W;
+        }
+        wav_sync<false>();
+        const uint32_t dlo = act ? blk[lane] : 0u;
+        const uint32_t eup = act ? blk[64 + Ng - 1 - lane] : 0u;
+        wav_sync<false>();
+        // lower diagonal d (>= 1) waits in lane Ng - 1 - d of W; anti-diagonal k >= Ng - 1 in lane k - (Ng - 1) of X
+        const uint32_t wrev = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (Ng - 1 - lane), (int)W);
+        dc = act ? eup + (lane >= 1 ? wrev : 0u) : 0u;
+        const int k1 = lane + 64;
+        const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane - (Ng - 1)), (int)X);
+        const uint32_t xb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (k1 - (Ng - 1)), (int)X);
+        pxpy_c[0] = lane < Ng ? dlo : (lane <= 2 * Ng - 2 ? xa : 0u);
+        pxpy_c[1] = k1 <= 2 * Ng - 2 ? xb : 0u;
+        if (!act) cc = 0;
+    }
+    const uint32_t l1 = (uint32_t)lane + 1u;
+    const uint32_t csum = wave_sum_t<uint32_t>(rc);    // sum_p (glcm.cpp:481-484)
+    const uint32_t Sr_i = wave_sum_t<uint32_t>(mul24(rc, l1)), Sc_i = wave_sum_t<uint32_t>(mul24(cc, l1));
+    const uint32_t con_i = wave_sum_t<uint32_t>(mul24(dc, mul24((uint32_t)lane, (uint32_t)lane))), dis_i = wave_sum_t<uint32_t>(mul24(dc, (uint32_t)lane));
+    const bool empty = csum == 0;
+    const double sum_p = empty ? 1.0 : (double)csum;
+    const double inv_sum_p = fdiv(1.0, sum_p);
+    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
+    const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
+    double pxpy[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (lane + 64 * u < 2 * Ng - 1) pxpy[u] = fdiv((double)pxpy_c[u], sum_p);
+
+    // ---- entropy terms of a word's two cells: T2[a + 8 b] = T[a] + T[b], T[c] = (c / sum_p) lg(c / sum_p + eps) for c <= 6, T[7] = 0
+    // (counts of 7 and more -- one ROI-angle in thirty on the benchmark's uniform data -- are added by a walk of their own below)
+    {
+        const int ca = lane & 7;
+        const double pk = (double)ca * inv_sum_p;
+        const double t = ca < 7 ? pk * (double)fast_log2f(pk + 0.000000001) : 0.0;
+        if (lane < 8) sm[lane] = t;
+        wav_sync<false>();
+        T2[lane] = t + sm[lane >> 3];
+        wav_sync<false>();
+    }
+    // ---- per-cell terms, two rows per step: lanes 0..31 row s, lanes 32..63 row s + half; a lane holds columns 2 l, 2 l + 1 -------
+    // A cell's own quantities are integer work (ASM = sum cnt^2 / sum_p^2, JMAX from the largest count; sum_p < 65536 in a G16
+    // launch, so every sum fits 32 bits); the entropy term p lg(p + eps) depends on the count alone.
+    double ent = 0;
+    uint32_t asm_i = 0, cmax = 0;
+    {
+        const int half = (Ng + 1) >> 1, l32 = lane & 31;
+        const bool hi = lane >= 32, colp = 2 * l32 < Ng;
+        lds_cu32_t* pwd = (lds_cu32_t*)(uintptr_t)(Pd + (hi ? half : 0) * pitch) + (colp ? l32 : 0);
+        typedef __attribute__((address_space(3))) const double lds_cd_t;
+        lds_cd_t* const T2l = (lds_cd_t*)(uintptr_t)T2;
+        us2_t mx = {0, 0};
+#pragma unroll 8
+        for (int s = 0; s < half; s++) {
+            uint32_t w = pwd[s * (pitch >> 1)];
+            if (Ng & 1) w = (colp && (!hi || s + half < Ng)) ? w : 0u;   // (an even order: every lane holds two data columns of a row of the matrix)
+            else if (Ng < 64) w = colp ? w : 0u;
+            const us2_t v = __builtin_bit_cast(us2_t, w);
+            asm_i = __builtin_amdgcn_udot2(v, v, asm_i, false);      // f_asm :555 / f_energy :927-928
+            mx = __builtin_elementwise_max(mx, v);                   // f_GLCM_JMAX :1178-1179
+            const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, (us2_t){7, 7}));
+            ent += T2l[(m & 7u) | (m >> 13)];                        // f_entropy :734-735, JE :1160-1161, HXY :868
+        }
+        cmax = mx.x > mx.y ? (uint32_t)mx.x : (uint32_t)mx.y;
+    }
+    // ---- HXY1 / HXY2: lane = column, rows visited in groups of equal row marginal (see glcm_features_wave64_u16) ----------------
+    double hxy1c = 0, hxy2 = 0;
+    {
+        const int cj = lane < Ng ? lane : Ng;
+        lds_cu16_t* pc = (lds_cu16_t*)(uintptr_t)(Pd + cj);
+        unsigned long long rem = __ballot(act && rc != 0u);
+        while (rem) {
+            const int r0 = (int)__builtin_ctzll(rem);
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)rc, r0);
+            const unsigned long long pbits = (unsigned long long)__double_as_longlong(prow);
+            const double pr = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), r0) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, r0)));
+            unsigned long long grp = __ballot(act && rc == v);
+            rem &= ~grp;
+            const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
+            const double lg = (double)fast_log2f(pp + 0.000000001);
+            hxy2 = __builtin_fma(pp * (double)(uint32_t)__popcll(grp), lg, hxy2);
+            uint32_t gsum = 0;
+            while (grp) {
+                const int r = (int)__builtin_ctzll(grp);
+                grp &= grp - 1ull;
+                gsum += pc[r * pitch];
+            }
+            hxy1c = __builtin_fma((double)gsum, lg, hxy1c);
+        }
+    }
+    if (__ballot(cmax >= 7u)) {                                      // the entropy terms of the large counts, which the table left out
+        const int cj = lane < Ng ? lane : Ng;
+        lds_cu16_t* pc = (lds_cu16_t*)(uintptr_t)(Pd + cj);
+        unsigned long long rem = __ballot(act && rc != 0u);
+        while (rem) {
+            const int r = (int)__builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            const uint32_t cnt = pc[r * pitch];
+            if (cnt >= 7u) { const double p = (double)cnt * inv_sum_p; ent += p * (double)fast_log2f(p + 0.000000001); }
+        }
+    }
+    const double hxy1 = hxy1c * inv_sum_p;
+    const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
+    wav_sync<false>();
+    {
+        double t4[4] = {ent, hxy1, hxy2, hx_t};
+        const double tot = wave_transpose_sum4(t4);                  // lane L holds the total of slot (L >> 4) & 3
+        if ((lane & 15) == 0) sm[1 + (lane >> 4)] = tot;             // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
+    }
+    // f_GLCM_ACOR :961 from the two families of diagonals: 4 ACOR = sum_k (k + 2)^2 n_{x+y}(k) - sum_d d^2 n_{x-y}(d)
+    uint32_t acor_i;
+    {
+        const uint32_t k0 = (uint32_t)lane + 2u, k1 = (uint32_t)lane + 66u;
+        acor_i = (wave_sum_t<uint32_t>(mad24(pxpy_c[1], mul24(k1, k1), mul24(pxpy_c[0], mul24(k0, k0)))) - con_i) >> 2;
+    }
+    asm_i = wave_sum_t<uint32_t>(asm_i);
+    cmax = wave_max_u32(cmax);
+
+    // ---- one term per lane: features of the marginal distributions -----------------------------------------------------------
+    double t16[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t16[k] = 0.0;
+    if (act) {
+        const double dr = (double)l1 - mr, dr2 = dr * dr, dcl = (double)l1 - mc;
+        t16[0] = prow * dr2;                                         // f_corr :617
+        t16[1] = pcol * (dcl * dcl);                                 // :626
+        t16[2] = (double)rc * dr2;                                   // f_var :672
+        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
+        const double q = pxmy, kd = (double)lane, Ngd = (double)Ng;
+        t16[4] = fdiv(q, (double)(1 + lane * lane));                 // f_idm :685-687
+        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
+        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
+        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
+        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
+        t16[9] = lane >= 1 ? q / (kd * kd) : 0.0;                    // :1123-1128
+        t16[10] = kd * q;                                            // f_difference_avg :791-792
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = lane + 64 * u;
+        if (k < 2 * Ng - 1) {
+            const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
+            t16[11] += ks * q;                                       // f_savg :700-701
+            t16[12] += plogp(q, q);                                  // f_sentropy :712-716
+            const double m = ks - mc - mc, m2 = m * m;               // by_row_mean (:531-536) = mc; CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+            t16[13] += m2 * m2 * q;
+            t16[14] += m2 * m * q;
+            t16[15] += m2 * q;
+        }
+    }
+    {
+        const double tot = wave_transpose_sum16(t16, lane);          // lane L holds the total of slot (L >> 2) & 15
+        if ((lane & 3) == 0) sm[8 + (lane >> 2)] = tot;
+    }
+    wav_sync<false>();
+    const double davg = sm[8 + 10];
+    double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
+    if (act) { const double dk = (double)lane - davg; dv = dk * dk * pxmy; }
+    dv = wave_sum(dv);
+
+    if (lane == 0) {
+        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
+        const double asm_t = (double)asm_i * inv_sum_p * inv_sum_p;
+        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
+        f[G_ASM] = asm_t;
+        f[G_ENERGY] = asm_t;
+        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
+        f[G_ACOR] = fdiv((double)acor_i, sum_p);
+        f[G_ENTROPY] = -ent_t;
+        f[G_JE] = -ent_t;
+        f[G_DIS] = fdiv((double)dis_i, sum_p);
+        f[G_JMAX] = (double)cmax * inv_sum_p;
+        f[G_JAVE] = mr;
+        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
+        f[G_CLUPROM] = sm[8 + 13];
+        f[G_CLUSHADE] = sm[8 + 14];
+        f[G_CLUTEND] = sm[8 + 15];
+        f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
+        f[G_JVAR] = sm[8 + 3];
+        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
+        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
+        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
+        f[G_IDM] = sm[8 + 4];
+        f[G_HOM2] = sm[8 + 4];
+        f[G_HOM1] = sm[8 + 7];
+        f[G_SUMAVERAGE] = sm[8 + 11];
+        f[G_SUMENTROPY] = -sm[8 + 12];
+        f[G_DIFENTRO] = -sm[8 + 5];
+        f[G_DIFAVE] = davg;
+        f[G_DIFVAR] = dv;
+        f[G_IDMN] = sm[8 + 6];
+        f[G_ID] = sm[8 + 7];
+        f[G_IDN] = sm[8 + 8];
+        f[G_IV] = sm[8 + 9];
+        const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
+        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+        if (empty)                                    // blank matrix: all 30 values = soft NaN (glcm.cpp:260-295)
+            for (int k = 0; k < kGlcmAngled; k++)
+                f[k] = soft_nan;
+    }
+    wav_sync<false>();
+}
+
 // Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
 // workgroup adds the cycles spent between consecutive stamps to A.stamps[phase].  The
 // product build compiles the macro away.
@@ -2051,16 +2307,17 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // with a shifted increment (halves never carry); order Ng + 1, indexed by the level itself -- column 0 takes the pairs
             // with a skipped neighbour, as in the split launches.  With the marginal-based feature routine (no 25 Ng doubles of
             // scratch per angle) the carve-out drops from ~87 to ~43 KiB: three workgroups per CU.
-            const int NG1 = Ng + 1, cellsw = (NG1 * NG1 + 1) >> 1;    // words per matrix
+            // Round 6 layout (glcm_features_wave64_v2): rows 0..Ng of an even pitch, cell (centre a, neighbour b) at a * pitch + b - 1:
+            // data cells are word-aligned pairs, a skipped neighbour lands in the previous row's last column, column Ng stays zero.
+            const int NG1 = (Ng + 3) & ~1, cellsw = ((Ng + 1) * NG1) >> 1;    // NG1: the pitch; words per matrix
             const bool symmetric = A.glcm_symmetric != 0;
-            double* s_sum = s_f + kMaxAngles * 32;
-            double* s_prow = s_sum + kMaxAngles * 32;                 // [kMaxAngles][Ng]
+            uint32_t* const s_blk = (uint32_t*)(s_f);                 // [kMaxAngles][256 words]: per-wave scratch of the feature pass; a wave's f = its first 32 doubles
             grp_sync<GS, NW>();
             for (int i = tid; i < na * cellsw; i += BS)
                 s_P[i] = 0;
             grp_sync<GS, NW>();
             STAMP(10);
-            auto bump16 = [&](uint32_t* M, uint32_t idx) { atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
+            auto bump16 = [&](uint32_t* M, uint32_t idx) { idx -= 1u; atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
             if (A.glcm_offset == 1 && w > 64 && w <= 128) {
                 // boxes 65 .. 128 wide: lane = column and column + 64, the pairs across column 63 | 64 through v_readlane (see the
                 // <= 16-level block above); any angle subset, symmetric counts included
@@ -2135,8 +2392,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     // instructions instead of six, no scalar branch per pair
                     typedef __attribute__((address_space(3))) uint32_t lds_word_t;
                     lds_word_t* const Pw = (lds_word_t*)s_P;
-                    const uint32_t B0 = (uint32_t)(uintptr_t)(Pw + slot0 * cellsw), B1 = (uint32_t)(uintptr_t)(Pw + slot1 * cellsw),
-                                   B2 = (uint32_t)(uintptr_t)(Pw + slot2 * cellsw), B3 = (uint32_t)(uintptr_t)(Pw + slot3 * cellsw);
+                    const uint32_t B0 = (uint32_t)(uintptr_t)(Pw + slot0 * cellsw) - 2u, B1 = (uint32_t)(uintptr_t)(Pw + slot1 * cellsw) - 2u,     // (- 2: neighbour level b sits in column b - 1)
+                                   B2 = (uint32_t)(uintptr_t)(Pw + slot2 * cellsw) - 2u, B3 = (uint32_t)(uintptr_t)(Pw + slot3 * cellsw) - 2u;
                     auto bump2 = [&](uint32_t a2) {        // a2: LDS byte address of the 16-bit cell
                         (void)__hip_atomic_fetch_add((lds_word_t*)(uintptr_t)(a2 & ~3u), 1u << ((a2 << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     };
@@ -2239,26 +2496,27 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             }
             grp_sync<GS, NW>();
             STAMP(11);
-            if (wave < na)                               // (NW = 4 = kMaxAngles: a wave per angle)
-                glcm_features_wave64_u16((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_prow + (size_t)wave * Ng, A.soft_nan, s_f + wave * 32,
-                                         s_sum + wave * 32, lane);
+            if (wave < na) {                             // (NW = 4 = kMaxAngles: a wave per angle)
+                if (Ng == 64) glcm_features_wave64_v2<64>((const uint16_t*)(s_P + (size_t)wave * cellsw), 64, s_blk + wave * 256, A.soft_nan, lane);
+                else glcm_features_wave64_v2<0>((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_blk + wave * 256, A.soft_nan, lane);
+            }
             grp_sync<GS, NW>();
             STAMP(12);
             for (int c = tid; c < kGlcmAngled * na; c += BS) {
                 int k = c / na, a = c - k * na;
-                o[c] = s_f[a * 32 + k];
+                o[c] = s_f[a * 128 + k];
             }
             for (int j = tid; j < kGlcmAve; j += BS) {               // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
                 int k = c_glcm_ave_order[j];
                 double init = 0.0;
                 int a = 0;
                 for (; na - a >= 4; a += 4) {
-                    double v1 = s_f[a * 32 + k] + s_f[(a + 1) * 32 + k];
-                    double v2 = s_f[(a + 2) * 32 + k] + s_f[(a + 3) * 32 + k];
+                    double v1 = s_f[a * 128 + k] + s_f[(a + 1) * 128 + k];
+                    double v2 = s_f[(a + 2) * 128 + k] + s_f[(a + 3) * 128 + k];
                     init = init + (v1 + v2);
                 }
                 for (; a < na; a++)
-                    init = init + s_f[a * 32 + k];
+                    init = init + s_f[a * 128 + k];
                 o[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
             }
         } else {

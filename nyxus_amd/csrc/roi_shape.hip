@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NW * 64, MODE >= 2 ? 4 : 1) void roi_gabor_tiled_ke
                     for (int k = 1; k <= 16; k++) sm += wd[k];
 #pragma unroll
                     for (int t = 0; t < T; t++) {
-                        if (t) sm = (sm + wd[t + 16]) - wd[t];
+                        if (t) sm = (sm - wd[t]) + wd[t + 16];                        // (subtract first: both intermediates are window sums of integers <= 256 x 65535 < 2^24 -> exact; adding first can pass 2^24)
                         if (on && a0 + (uint32_t)t < w) {
                             smax = sm > smax ? sm : smax;
                             if (sm < smin) { smin = sm; cmin = 1; }

@@ -50,6 +50,22 @@ def test_digit_split_boundaries(hip_ctx, top):
             assert _same(hip_ctx.featurize_host(b, _abi.FAM_GABOR, s), po.oracle_featurize(b, _abi.FAM_GABOR, s))
 
 
+def test_saturated_sixteen_bit_windows(hip_ctx):
+    """The fp32 sliding box low-pass (default bank, intensities < 2^16): a 16 x 16 window of 65534 / 65535 sums to within 256 of 2^24,
+    so the slide must subtract the leaving column before it adds the entering one (add-first passes 2^24, where fp32 drops odd
+    integers: the low-pass maximum moved by one and every filter's threshold with it)."""
+    rng = np.random.default_rng(65535)
+    yy, xx = np.mgrid[0:48, 0:60]
+    v1 = rng.integers(65534, 65536, (48, 60))                                  # every window near saturation, odd sums everywhere
+    v2 = np.where((xx >= 10) & (xx < 45) & (yy >= 8) & (yy < 40), 65535 - (xx + yy) % 2, rng.integers(1, 3000, (48, 60)))
+    v3 = np.full((40, 40), 65535); v3[::7, ::5] = 65534
+    v4 = rng.integers(61000, 65536, (33, 47))
+    rois = [_roi(60, 48, v1), _roi(60, 48, v2), _roi(40, 40, v3), _roi(47, 33, v4), _roi(60, 48, v1, True), _roi(15, 13, v1[:13, :15])]
+    b = _abi.batch_from_rois(rois)
+    for s in (_abi.default_settings(8), _bank(_abi.default_settings(8), 8)):
+        assert _same(hip_ctx.featurize_host(b, _abi.FAM_GABOR, s), po.oracle_featurize(b, _abi.FAM_GABOR, s))
+
+
 @pytest.mark.parametrize("nf", [1, 3, 4, 5, 8, 9, 16])
 def test_filter_groups(hip_ctx, nf):
     """Filters run in groups of four operand columns: full groups, a last group of one to three, one filter alone."""
