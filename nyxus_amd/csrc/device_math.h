@@ -393,6 +393,21 @@ __device__ __forceinline__ double wave_transpose_sum8(double (&v)[8], int lane)
     t += dpp_perm<0xB1>(t);
     return t;
 }
+// 8 slots of 32-bit integers: lane L returns the wave total of slot (L >> 3) & 7.
+__device__ __forceinline__ uint32_t wave_transpose_sum8_u32(uint32_t (&v)[8], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) { auto r = __builtin_amdgcn_permlane32_swap(v[k], v[k + 4], false, false); v[k] = r[0] + r[1]; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) { auto r = __builtin_amdgcn_permlane16_swap(v[k], v[k + 2], false, false); v[k] = r[0] + r[1]; }
+    const bool upper = (lane & 8) != 0;
+    const uint32_t keep = upper ? v[1] : v[0], send = upper ? v[0] : v[1];
+    uint32_t t = keep + dpp_perm<0x140>(send);
+    t += dpp_perm<0x141>(t);
+    t += dpp_perm<0x4E>(t);
+    t += dpp_perm<0xB1>(t);
+    return t;
+}
 // 4 slots: lane L returns the wave total of slot (L >> 4) & 3.
 __device__ __forceinline__ double wave_transpose_sum4(double (&v)[4])
 {

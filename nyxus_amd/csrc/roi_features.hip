@@ -759,6 +759,23 @@ __device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int 
 // blk: 256 words of LDS per wave: [f: 32 doubles | sm: 32 doubles | T2: 64 doubles], the diagonal picks lie over all of it
 // (PX 64 words | PW 64 words | junk 127 words) while nothing else is live.
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// weights of the difference distribution at 64 levels, per |x - y| = l: 1 / (1 + l^2) (f_idm :685), 1 / (1 + l^2 / Ng^2) (:1083), 1 / (1 + l) (:1096),
+// 1 / (1 + l / Ng) (:1110), 1 / l^2 (:1123) -- five divisions per lane and angle otherwise
+struct GlcmW64 {
+    double w[5][64];
+    constexpr GlcmW64() : w{} {
+        for (int l = 0; l < 64; l++) {
+            w[0][l] = 1.0 / (double)(1 + l * l); w[1][l] = 1.0 / (1.0 + (double)(l * l) / 4096.0); w[2][l] = 1.0 / (1.0 + (double)l);
+            w[3][l] = 1.0 / (1.0 + (double)l / 64.0); w[4][l] = l ? 1.0 / ((double)l * (double)l) : 0.0;
+        }
+    }
+};
+__device__ const GlcmW64 c_glcm_w64{};
+#ifdef NYX_G16_EXIT      // diagnostic builds (tools/g16_exit_libs.sh): the feature pass ends after phase NYX_G16_EXIT; results are wrong by design
+#define G16_EXIT(k, keep) do { if ((k) == NYX_G16_EXIT) { ((double*)blk)[lane & 31] = (double)(keep); return; } } while (0)
+#else
+#define G16_EXIT(k, keep) do { } while (0)
+#endif
 template <int NG>
 __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int Ng_rt, uint32_t* blk, double soft_nan, int lane)
 {
@@ -772,6 +789,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
     double* const T2 = f + 64;
     const bool act = lane < Ng;                        // lane l owns column l, row l and the diagonal pair |x - y| = l
     const uint16_t* const Pd = P + pitch;              // row of level 1
+    G16_EXIT(0, lane);
     // ---- row sums: lane = row, the row's words (pitch / 2 apart per lane: no bank conflict) ------------------------------------
     uint32_t rc = 0;
     {
@@ -782,6 +800,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         for (int j = 0; j < nw; j++) a2 = a2 + __builtin_bit_cast(us2_t, rw[j]);
         rc = act ? (uint32_t)a2.x + (uint32_t)a2.y : 0u;
     }
+    G16_EXIT(1, rc);
     // ---- column sums and the two families of diagonals in one pass over the rows (lane = column; see glcm_features_wave64_u16) --
     uint32_t cc = 0, dc = 0;
     uint32_t pxpy_c[2] = {0u, 0u};
@@ -815,14 +834,12 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         pxpy_c[1] = k1 <= 2 * Ng - 2 ? xb : 0u;
         if (!act) cc = 0;
     }
+    G16_EXIT(2, rc + cc + dc + pxpy_c[0] + pxpy_c[1]);
     const uint32_t l1 = (uint32_t)lane + 1u;
     const uint32_t csum = wave_sum_t<uint32_t>(rc);    // sum_p (glcm.cpp:481-484)
-    const uint32_t Sr_i = wave_sum_t<uint32_t>(mul24(rc, l1)), Sc_i = wave_sum_t<uint32_t>(mul24(cc, l1));
-    const uint32_t con_i = wave_sum_t<uint32_t>(mul24(dc, mul24((uint32_t)lane, (uint32_t)lane))), dis_i = wave_sum_t<uint32_t>(mul24(dc, (uint32_t)lane));
     const bool empty = csum == 0;
     const double sum_p = empty ? 1.0 : (double)csum;
     const double inv_sum_p = fdiv(1.0, sum_p);
-    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
     const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
     double pxpy[2] = {0.0, 0.0};
 #pragma unroll
@@ -840,6 +857,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         T2[lane] = t + sm[lane >> 3];
         wav_sync<false>();
     }
+    G16_EXIT(3, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1]));
     // ---- per-cell terms, two rows per step: lanes 0..31 row s, lanes 32..63 row s + half; a lane holds columns 2 l, 2 l + 1 -------
     // A cell's own quantities are integer work (ASM = sum cnt^2 / sum_p^2, JMAX from the largest count; sum_p < 65536 in a G16
     // launch, so every sum fits 32 bits); the entropy term p lg(p + eps) depends on the count alone.
@@ -865,6 +883,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         }
         cmax = mx.x > mx.y ? (uint32_t)mx.x : (uint32_t)mx.y;
     }
+    G16_EXIT(4, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1] + ent) + asm_i + cmax);
     // ---- HXY1 / HXY2: lane = column, rows visited in groups of equal row marginal (see glcm_features_wave64_u16) ----------------
     double hxy1c = 0, hxy2 = 0;
     {
@@ -902,6 +921,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
             if (cnt >= 7u) { const double p = (double)cnt * inv_sum_p; ent += p * (double)fast_log2f(p + 0.000000001); }
         }
     }
+    G16_EXIT(5, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1] + ent + hxy1c + hxy2) + asm_i + cmax);
     const double hxy1 = hxy1c * inv_sum_p;
     const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
     wav_sync<false>();
@@ -910,14 +930,23 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         const double tot = wave_transpose_sum4(t4);                  // lane L holds the total of slot (L >> 4) & 3
         if ((lane & 15) == 0) sm[1 + (lane >> 4)] = tot;             // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
     }
-    // f_GLCM_ACOR :961 from the two families of diagonals: 4 ACOR = sum_k (k + 2)^2 n_{x+y}(k) - sum_d d^2 n_{x-y}(d)
-    uint32_t acor_i;
+    // ---- the integer sums in ONE transposed reduction (six six-step butterflies before): S_r, S_c, the contrast and dissimilarity
+    // numerators, 4 ACOR + contrast (f_GLCM_ACOR :961 from the two families of diagonals: I J = ((I + J)^2 - (I - J)^2) / 4, so
+    // 4 ACOR = sum_k (k + 2)^2 n_{x+y}(k) - sum_d d^2 n_{x-y}(d); sum_p < 65536 and k + 2 <= 130 keep everything inside 32 bits), sum cnt^2
+    uint32_t Sr_i, Sc_i, con_i, dis_i, acor_i;
     {
         const uint32_t k0 = (uint32_t)lane + 2u, k1 = (uint32_t)lane + 66u;
-        acor_i = (wave_sum_t<uint32_t>(mad24(pxpy_c[1], mul24(k1, k1), mul24(pxpy_c[0], mul24(k0, k0)))) - con_i) >> 2;
+        uint32_t t8[8] = {mul24(rc, l1), mul24(cc, l1), mul24(dc, mul24((uint32_t)lane, (uint32_t)lane)), mul24(dc, (uint32_t)lane),
+                          mad24(pxpy_c[1], mul24(k1, k1), mul24(pxpy_c[0], mul24(k0, k0))), asm_i, 0u, 0u};
+        const uint32_t tot = wave_transpose_sum8_u32(t8, lane);      // lane L holds the total of slot (L >> 3) & 7
+        Sr_i = (uint32_t)__builtin_amdgcn_readlane((int)tot, 0); Sc_i = (uint32_t)__builtin_amdgcn_readlane((int)tot, 8);
+        con_i = (uint32_t)__builtin_amdgcn_readlane((int)tot, 16); dis_i = (uint32_t)__builtin_amdgcn_readlane((int)tot, 24);
+        acor_i = ((uint32_t)__builtin_amdgcn_readlane((int)tot, 32) - con_i) >> 2;
+        asm_i = (uint32_t)__builtin_amdgcn_readlane((int)tot, 40);
     }
-    asm_i = wave_sum_t<uint32_t>(asm_i);
     cmax = wave_max_u32(cmax);
+    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
+    const double davg = fdiv((double)dis_i, sum_p);                  // f_difference_avg :791-792 = sum k p_{x-y}(k): the dissimilarity's exact numerator
 
     // ---- one term per lane: features of the marginal distributions -----------------------------------------------------------
     double t16[16];
@@ -930,13 +959,19 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         t16[2] = (double)rc * dr2;                                   // f_var :672
         t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
         const double q = pxmy, kd = (double)lane, Ngd = (double)Ng;
-        t16[4] = fdiv(q, (double)(1 + lane * lane));                 // f_idm :685-687
         t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
-        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
-        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
-        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
-        t16[9] = lane >= 1 ? q / (kd * kd) : 0.0;                    // :1123-1128
-        t16[10] = kd * q;                                            // f_difference_avg :791-792
+        if (NG == 64) {                                              // (reciprocal weights from the table: within an ulp of the quotients)
+            t16[4] = q * c_glcm_w64.w[0][lane]; t16[6] = q * c_glcm_w64.w[1][lane]; t16[7] = q * c_glcm_w64.w[2][lane];
+            t16[8] = q * c_glcm_w64.w[3][lane]; t16[9] = q * c_glcm_w64.w[4][lane];
+        } else {
+            t16[4] = fdiv(q, (double)(1 + lane * lane));             // f_idm :685-687
+            t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));        // :1083-1084
+            t16[7] = fdiv(q, 1.0 + kd);                              // :1096-1097
+            t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                   // :1110-1111
+            t16[9] = lane >= 1 ? q / (kd * kd) : 0.0;                // :1123-1128
+        }
+        const double dk = kd - davg;
+        t16[10] = dk * dk * q;                                       // f_dvar (glcm.cpp:742-766)
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -955,53 +990,63 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         const double tot = wave_transpose_sum16(t16, lane);          // lane L holds the total of slot (L >> 2) & 15
         if ((lane & 3) == 0) sm[8 + (lane >> 2)] = tot;
     }
-    wav_sync<false>();
-    const double davg = sm[8 + 10];
-    double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
-    if (act) { const double dk = (double)lane - davg; dv = dk * dk * pxmy; }
-    dv = wave_sum(dv);
-
+    // what the final formulas need beside the sums above (glcm_features_final: a LANE per angle, once per workgroup)
     if (lane == 0) {
-        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
-        const double asm_t = (double)asm_i * inv_sum_p * inv_sum_p;
-        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
-        f[G_ASM] = asm_t;
-        f[G_ENERGY] = asm_t;
-        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
-        f[G_ACOR] = fdiv((double)acor_i, sum_p);
-        f[G_ENTROPY] = -ent_t;
-        f[G_JE] = -ent_t;
-        f[G_DIS] = fdiv((double)dis_i, sum_p);
-        f[G_JMAX] = (double)cmax * inv_sum_p;
-        f[G_JAVE] = mr;
-        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
-        f[G_CLUPROM] = sm[8 + 13];
-        f[G_CLUSHADE] = sm[8 + 14];
-        f[G_CLUTEND] = sm[8 + 15];
-        f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
-        f[G_JVAR] = sm[8 + 3];
-        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
-        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
-        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
-        f[G_IDM] = sm[8 + 4];
-        f[G_HOM2] = sm[8 + 4];
-        f[G_HOM1] = sm[8 + 7];
-        f[G_SUMAVERAGE] = sm[8 + 11];
-        f[G_SUMENTROPY] = -sm[8 + 12];
-        f[G_DIFENTRO] = -sm[8 + 5];
-        f[G_DIFAVE] = davg;
-        f[G_DIFVAR] = dv;
-        f[G_IDMN] = sm[8 + 6];
-        f[G_ID] = sm[8 + 7];
-        f[G_IDN] = sm[8 + 8];
-        f[G_IV] = sm[8 + 9];
-        const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
-        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
-        if (empty)                                    // blank matrix: all 30 values = soft NaN (glcm.cpp:260-295)
-            for (int k = 0; k < kGlcmAngled; k++)
-                f[k] = soft_nan;
+        sm[0] = (double)csum; sm[5] = (double)Sr_i; sm[6] = (double)Sc_i; sm[7] = (double)con_i;
+        sm[24] = (double)dis_i; sm[25] = (double)acor_i; sm[26] = (double)asm_i; sm[27] = (double)cmax;
     }
     wav_sync<false>();
+}
+
+// The closing formulas of an angle from the sums glcm_features_wave64_v2 left in its block: run by ONE lane per angle after the
+// workgroup's barrier (as the last block of every angle's wave it was the same ~250 single-lane instructions four times over).
+__device__ __forceinline__ void glcm_features_final(uint32_t* blk, double soft_nan)
+{
+    double* const f = (double*)blk;
+    const double* const sm = f + 32;
+    const double csum = sm[0], Sr = sm[5], Sc = sm[6], con = sm[7], dis = sm[24], acor = sm[25], asm_s = sm[26], cmax = sm[27];
+    const bool empty = csum == 0.0;
+    const double sum_p = empty ? 1.0 : csum, inv_sum_p = fdiv(1.0, sum_p);
+    const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
+    const double asm_t = asm_s * inv_sum_p * inv_sum_p;
+    const double mr = fdiv(Sr, sum_p);
+    const double cov_t = fdiv(acor * sum_p - Sr * Sc, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
+    const double s8[16] = {sm[8], sm[9], sm[10], sm[11], sm[12], sm[13], sm[14], sm[15], sm[16], sm[17], sm[18], sm[19], sm[20], sm[21], sm[22], sm[23]};
+    f[G_ASM] = asm_t;
+    f[G_ENERGY] = asm_t;
+    f[G_CONTRAST] = fdiv(con, sum_p);
+    f[G_ACOR] = fdiv(acor, sum_p);
+    f[G_ENTROPY] = -ent_t;
+    f[G_JE] = -ent_t;
+    f[G_DIS] = fdiv(dis, sum_p);
+    f[G_JMAX] = cmax * inv_sum_p;
+    f[G_JAVE] = mr;
+    f[G_VARIANCE] = fdiv(s8[2], sum_p);
+    f[G_CLUPROM] = s8[13];
+    f[G_CLUSHADE] = s8[14];
+    f[G_CLUTEND] = s8[15];
+    f[G_SUMVARIANCE] = s8[15];                    // glcm.cpp:323-326
+    f[G_JVAR] = s8[3];
+    const double denom = sqrt(s8[0]) * sqrt(s8[1]);                  // f_corr tail, glcm.cpp:619-643
+    f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
+    f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t))));    // glcm.cpp:913 (HXY = ent)
+    f[G_IDM] = s8[4];
+    f[G_HOM2] = s8[4];
+    f[G_HOM1] = s8[7];
+    f[G_SUMAVERAGE] = s8[11];
+    f[G_SUMENTROPY] = -s8[12];
+    f[G_DIFENTRO] = -s8[5];
+    f[G_DIFAVE] = fdiv(dis, sum_p);
+    f[G_DIFVAR] = s8[10];
+    f[G_IDMN] = s8[6];
+    f[G_ID] = s8[7];
+    f[G_IDN] = s8[8];
+    f[G_IV] = s8[9];
+    const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
+    f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
+    if (empty)                                    // blank matrix: all 30 values = soft NaN (glcm.cpp:260-295)
+        for (int k = 0; k < kGlcmAngled; k++)
+            f[k] = soft_nan;
 }
 
 // Diagnostic build (-DNYX_STAMP, tools/stamp_probe.py): wave 0 / lane 0 of every
@@ -2313,8 +2358,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             const bool symmetric = A.glcm_symmetric != 0;
             uint32_t* const s_blk = (uint32_t*)(s_f);                 // [kMaxAngles][256 words]: per-wave scratch of the feature pass; a wave's f = its first 32 doubles
             grp_sync<GS, NW>();
-            for (int i = tid; i < na * cellsw; i += BS)
-                s_P[i] = 0;
+            {   // 16 bytes per store (word stores were 34 trips of four instructions: 1.1 ns of every ROI); the matrices' region is 16-byte aligned and 16 cellsw bytes long
+                uint4* const P4 = (uint4*)s_P;
+                const int n4 = (na * cellsw + 3) >> 2;
+                for (int i = tid; i < n4; i += BS)
+                    P4[i] = uint4{0u, 0u, 0u, 0u};
+            }
             grp_sync<GS, NW>();
             STAMP(10);
             auto bump16 = [&](uint32_t* M, uint32_t idx) { idx -= 1u; atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
@@ -2500,6 +2549,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 if (Ng == 64) glcm_features_wave64_v2<64>((const uint16_t*)(s_P + (size_t)wave * cellsw), 64, s_blk + wave * 256, A.soft_nan, lane);
                 else glcm_features_wave64_v2<0>((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_blk + wave * 256, A.soft_nan, lane);
             }
+            grp_sync<GS, NW>();
+            if (tid < na) glcm_features_final(s_blk + tid * 256, A.soft_nan);
             grp_sync<GS, NW>();
             STAMP(12);
             for (int c = tid; c < kGlcmAngled * na; c += BS) {
