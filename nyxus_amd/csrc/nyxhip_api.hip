@@ -2220,7 +2220,10 @@ static int tiles_chunk(nyxhip_ctx* ctx, const void* d_inten, int dtI, const void
         else hipLaunchKernelGGL(add_offset_kernel, dim3((unsigned)((n_roi + 255) / 256)), dim3(256), 0, st, R.tile, tile_base, (uint32_t)n_roi, d_til);
     }
     if (window)
-        ctx->win_next = WindowSrc{d_inten, d_label, dtI, dtL, W, H, R.tile, R.label, R.bbox_x0, R.bbox_y0};
+    {
+        static const bool no_swz = [] { const char* e = getenv("NYXHIP_NO_XCD_SWIZZLE"); return e && *e && *e != '0'; }();   // A/B
+        ctx->win_next = WindowSrc{d_inten, d_label, dtI, dtL, W, H, R.tile, R.label, R.bbox_x0, R.bbox_y0, no_swz ? 0u : 1u};
+    }
     int lrc = launch_device(ctx, &b, family_mask, s, d_out, d_ld, meta[3], meta[4], meta[5], meta[6]);
     ctx->win_next = WindowSrc{};
     if (lrc == NYXHIP_INTERNAL_NEEDS_CLOUDS) {

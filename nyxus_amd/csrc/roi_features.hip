@@ -2880,7 +2880,7 @@ __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_occ7(const RoiA
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiArgs A)   // 64 VGPRs: the fully compact build only
 {
-    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 8, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 8, false, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 // The same compile-time family sets and loaders at seven and six workgroups per CU: batches whose largest ROI needs a bigger
 // carve-out than the benchmark's (mixed-size data: the launch is sized by its largest ROI) keep the specialised body instead of
@@ -2888,19 +2888,19 @@ __global__ __launch_bounds__(kBlock, 8) void roi_features_kernel_occ8(const RoiA
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 7) void roi_features_kernel_fam7(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 7, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 7, false, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 template <int FAM, int WIN>
 __global__ __launch_bounds__(kBlock, 6) void roi_features_kernel_fam6(const RoiArgs A)
 {
-    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 6, false, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, FAM == 1 || FAM == 3, true, FAM, 6, false, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 
 // the reference's default grey depth: 16-bit matrices, marginal-based features (three workgroups per CU)
 template <int WIN>
 __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiArgs A)
 {
-    roi_features_body<false, true, false, true, 0, 9, true, WIN>(A, blockIdx.x);
+    roi_features_body<false, true, false, true, 0, 9, true, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
@@ -3090,6 +3090,7 @@ int launch_lds_variant(const RoiArgs& a, hipStream_t st, uint32_t grid)
         if ((size_t)o * a.L.total <= lds) { occ = o; break; }
     if (const char* e = getenv("NYXHIP_MAX_OCC")) occ = occ < atoi(e) ? occ : (atoi(e) < 4 ? 4 : atoi(e));   // tuning knob (bench experiments)
     const bool win = a.win.inten != nullptr;
+    if (win && a.win.xcd_swz) grid = (grid + 7u) & ~7u;               // (xcd_slot: every XCD walks its own eighth of the slots)
     if (fam_ok && glcm_only && occ >= 6) {
         if (occ == 8) { if (win) hipLaunchKernelGGL((roi_features_kernel_occ8<3, 1>), dim3(grid), dim3(kBlock), a.L.total, st, a);
                         else hipLaunchKernelGGL((roi_features_kernel_occ8<3, 0>), dim3(grid), dim3(kBlock), a.L.total, st, a); }
@@ -3143,7 +3144,7 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
                 return 0;
             }))
             return orc;
-        if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16<1>, dim3(grid), dim3(kBlock), a.L.total, st, a);
+        if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16<1>, dim3(a.win.xcd_swz ? (grid + 7u) & ~7u : grid), dim3(kBlock), a.L.total, st, a);
         else hipLaunchKernelGGL(roi_features_kernel_g16<0>, dim3(grid), dim3(kBlock), a.L.total, st, a);
         return (int)hipGetLastError();
     }

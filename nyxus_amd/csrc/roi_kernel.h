@@ -120,7 +120,11 @@ struct WindowSrc {
     const uint32_t* label;       // [n_roi] its label value
     const uint32_t* x0;          // [n_roi] bounding-box origin inside the tile
     const uint32_t* y0;
+    uint32_t xcd_swz;            // 1: workgroup b serves ROI xcd_slot(b): the eight XCDs (workgroups go to them round-robin) each take a
+                                 // contiguous eighth of the rows, so the ROIs whose windows share cache lines of a tile meet in ONE L2
 };
+// Workgroup -> slot of a window-mode launch (grid rounded up to a multiple of 8): XCD b & 7 walks slots [x per, (x + 1) per).
+__host__ __device__ inline uint64_t xcd_slot(uint32_t b, uint32_t grid) { const uint32_t per = (grid + 7u) >> 3; return (uint64_t)(b & 7u) * per + (b >> 3); }
 
 struct RoiArgs {
     uint64_t n_roi;
