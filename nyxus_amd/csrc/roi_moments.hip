@@ -418,6 +418,17 @@ __device__ void hu7(double _02, double _03, double _11, double _12, double _20, 
 // OCC: workgroups per CU the register budget is cut for (4: 128 registers, no spills; 6: 80 registers and ~30 spilled words
 // outside the pixel loops -- the hill descent is a chain of dependent LDS reads, so when six carve-outs fit a CU the extra
 // waves win: 11.7 -> 10.2 ms per 196 k benchmark ROIs).  The launcher picks by the launch's LDS bytes.
+// The value again, but opaque to the optimiser at this point (roi_shape.hip: here()): address arithmetic that depends only on the
+// thread index is otherwise formed at the kernel's entry and -- alive across every sweep -- spilled there.
+__device__ __forceinline__ int mom_here(int v) { asm volatile("" : "+v"(v)); return v; }
+// A workgroup-uniform double as a scalar-register pair (the conversions that produce it leave it in vector registers, where it lived --
+// and was spilled and reloaded inside the hill descent -- across every sweep)
+__device__ __forceinline__ double mom_uniform(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 template <int OCC>
 __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
 {
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     double* const L = A.ws_L + off;
 
     // window width -> step of the hill descent (first step from n, later ones from windows of at most two steps)
-    const int step0 = nK >= 2 ? (int)((double)nK / log((double)nK)) : 1;
+    const int step0 = __builtin_amdgcn_readfirstlane(nK >= 2 ? (int)((double)nK / log((double)nK)) : 1);
     const int tab_n = min((int)A.step_cap, 2 * step0 + 2);
     for (int m = 11 + tid; m < tab_n; m += kMB) s_step[m] = (uint16_t)(int)((double)m / log((double)m));
 
@@ -481,19 +492,28 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             s_px[i] = make_uint2(xi | (yi << 16), vi);
         });
     __syncthreads();
+    // the thread index, formed where it is used from the wave number (a scalar) and the lane count: as one value alive across the whole
+    // kernel it was spilled at the entry and reloaded per phase (with what else sat at the entry: 44 B of scratch per lane, the
+    // 2.2 GB of writes per 196 k ROIs the counters saw beside 0.28 GB of results)
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto TID = [&]() -> int {                             // (volatile: the optimiser would otherwise form it once and keep it)
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (wave_s << 6) + l;
+    };
     auto sweep = [&](auto&& body) {                      // body(i, intensity, x, y) for this thread's pixels i = tid, tid + 256, ...
         if (compact) {
-            for (uint32_t i = (uint32_t)tid; i < n; i += kMB) {
+            for (uint32_t i = (uint32_t)TID(); i < n; i += kMB) {
                 const uint32_t xy = s_xy8[i];
                 body(i, s_v[i], xy & 0xFFu, xy >> 8);
             }
         } else if (staged) {
-            for (uint32_t i = (uint32_t)tid; i < n; i += kMB) {
+            for (uint32_t i = (uint32_t)TID(); i < n; i += kMB) {
                 const uint2 q = s_px[i];
                 body(i, q.y, q.x & 0xFFFFu, q.x >> 16);
             }
         } else
-            for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, tid, body);
+            for_each_cloud_pixel<kMB>(A.inten + off, A.x + off, A.y + off, n, TID(), body);
     };
     MSTAMP(0);
     // ---- pass 1 + 2 as ONE sweep: moments about the box centre o = ((w - 1) / 2, (h - 1) / 2), mu_o[p][q] = sum I (x - o_x)^p (y - o_y)^q for
@@ -504,7 +524,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     //      |x - o| <= side / 2, so every term of a combination is at most (1 + |e| / (side / 2))^(p + q) times the size of the terms of
     //      the direct sum -- <= 64 x for an origin one half-side away -- and the combination's error stays below 1e-14 of
     //      m00 (side / 2)^(p + q), an order under the floor the parity tests grant a central moment that cancels (tests/parity.py).
-    const double obx = 0.5 * (double)(bw_ - 1u), oby = 0.5 * (double)(bh_ - 1u);
+    const double obx = mom_uniform(0.5 * (double)(bw_ - 1u)), oby = mom_uniform(0.5 * (double)(bh_ - 1u));
     __shared__ double s_mo[2][16], s_wo[2][10], s_wo16[2][16];
 #pragma unroll 1
     for (int var = 0; var < 2; var++) {
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
                     for (int q = 0; q < 4; q++) acc[p * 4 + q] = (p && q) ? __builtin_fma(xp[p], yp[q], acc[p * 4 + q]) : acc[p * 4 + q] + (p ? xp[p] : yp[q]);
             }
         });
-        mom_block_sum<16, false>(acc, s_red, s_mo[var], tid);
+        mom_block_sum<16, false>(acc, s_red, s_mo[var], TID());
     }
     __syncthreads();
     // m[p][q] about the origin o - e from the sums about o (binomial coefficients of orders 0..3)
@@ -542,13 +562,13 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             for (int l = 0; l <= q; l++) r += binom(p, k) * binom(q, l) * pw(ex, p - k) * pw(ey, q - l) * mo[k * 4 + l];
         return r;
     };
-    if (tid < 32) {                                       // raw moments: origin 0, e = o
-        const int var = tid >> 4, pq = tid & 15;
+    if (TID() < 32) {                                       // raw moments: origin 0, e = o
+        const int var = TID() >> 4, pq = TID() & 15;
         s_raw[var][pq] = shifted(s_mo[var], pq >> 2, pq & 3, obx, oby);
     }
     __syncthreads();
-    if (tid < 32) {                                       // central moments: origin (m10 / m00, m01 / m00), each variant its own
-        const int var = tid >> 4, pq = tid & 15;
+    if (TID() < 32) {                                       // central moments: origin (m10 / m00, m01 / m00), each variant its own
+        const int var = TID() >> 4, pq = TID() & 15;
         const double cx = s_raw[var][4] / s_raw[var][0], cy = s_raw[var][1] / s_raw[var][0];
         s_cen[var][pq] = shifted(s_mo[var], pq >> 2, pq & 3, obx - cx, oby - cy);
     }
@@ -584,16 +604,31 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
             const double lg = compact ? A.log_tab[s_d2[i]] : L[i];
             const double X = (double)xi - obx, Y = (double)yi - oby;           // (about the box centre, like the sums of pass 1 + 2)
             const double Ws = (double)(float)(1.0 * lg), Wi = (double)(float)((double)vi * lg);
-            const double xp[4] = {1.0, X, X * X, X * X * X}, yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
-            const double sx[4] = {Ws, Ws * xp[1], Ws * xp[2], Ws * xp[3]}, ix[4] = {Wi, Wi * xp[1], Wi * xp[2], Wi * xp[3]};
+            // (one power of x at a time, the shape sums before the intensity sums, the scheduler kept from interleaving the groups:
+            //  with sx[4], ix[4], xp, yp all live beside the twenty accumulators the 80-register build spilled around this loop)
+            const double yp[4] = {1.0, Y, Y * Y, Y * Y * Y};
+            double xpw = 1.0;
 #pragma unroll
-            for (int k = 0; k < 10; k++) {
-                as[k] = wr_q[k] ? __builtin_fma(sx[wr_p[k]], yp[wr_q[k]], as[k]) : as[k] + sx[wr_p[k]];
-                ai[k] = wr_q[k] ? __builtin_fma(ix[wr_p[k]], yp[wr_q[k]], ai[k]) : ai[k] + ix[wr_p[k]];
+            for (int p = 0; p < 4; p++) {
+                if (p) xpw = p == 1 ? X : xpw * X;               // X, X * X, (X * X) * X as before
+                {
+                    const double sx = p ? Ws * xpw : Ws;
+#pragma unroll
+                    for (int k = 0; k < 10; k++)
+                        if (wr_p[k] == p) as[k] = wr_q[k] ? __builtin_fma(sx, yp[wr_q[k]], as[k]) : as[k] + sx;
+                }
+
+                {
+                    const double ixv = p ? Wi * xpw : Wi;
+#pragma unroll
+                    for (int k = 0; k < 10; k++)
+                        if (wr_p[k] == p) ai[k] = wr_q[k] ? __builtin_fma(ixv, yp[wr_q[k]], ai[k]) : ai[k] + ixv;
+                }
+
             }
         });
-        mom_block_sum<10, false>(as, s_red, s_wo[0], tid);
-        mom_block_sum<10, false>(ai, s_red, s_wo[1], tid);
+        mom_block_sum<10, false>(as, s_red, s_wo[0], TID());
+        mom_block_sum<10, false>(ai, s_red, s_wo[1], TID());
     }
     __syncthreads();
     MSTAMP(3);
@@ -601,25 +636,25 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     //      origin (:162-167, :318-327) from the ten weighted sums about the box centre, as above.  (The weighted origin may lie far
     //      outside the box when the weighted mass nearly cancels: then |e| >> side and the shifted sum is dominated by its e^(p + q)
     //      term -- as the reference's direct sum is.)
-    if (tid < 32) s_wo16[tid >> 4][tid & 15] = 0.0;         // the ten sums in the [p * 4 + q] layout of `shifted` (the other six: zero)
+    if (TID() < 32) s_wo16[TID() >> 4][TID() & 15] = 0.0;         // the ten sums in the [p * 4 + q] layout of `shifted` (the other six: zero)
     __syncthreads();
-    if (tid < 20) { const int var = tid / 10, k = tid % 10; s_wo16[var][wr_p[k] * 4 + wr_q[k]] = s_wo[var][k]; }
+    if (TID() < 20) { const int var = TID() / 10, k = TID() % 10; s_wo16[var][wr_p[k] * 4 + wr_q[k]] = s_wo[var][k]; }
     __syncthreads();
-    if (tid < 20) {
-        const int var = tid / 10, k = tid % 10;
+    if (TID() < 20) {
+        const int var = TID() / 10, k = TID() % 10;
         s_wraw[var][k] = shifted(s_wo16[var], wr_p[k], wr_q[k], obx, oby);
     }
     __syncthreads();
-    if (tid < 14) {
-        const int var = tid / 7, k = tid % 7;
+    if (TID() < 14) {
+        const int var = TID() / 7, k = TID() % 7;
         const double ox = s_wraw[var][4] / s_wraw[var][0], oy = s_wraw[var][1] / s_wraw[var][0];
         s_wcen[var][k] = shifted(s_wo16[var], nc_p[k], nc_q[k], obx - ox, oby - oy);
     }
     __syncthreads();
     MSTAMP(4);
     // ---- derived values and output ------------------------------------------------------------------------------------------
-    if (tid < 2 && (tid ? do_i : do_s)) {
-        const int var = tid;
+    if (TID() < 2 && (TID() ? do_i : do_s)) {
+        const int var = TID();
         double* o = row_out + (var ? A.col_imoms : A.col_smoms);
         const double* raw = s_raw[var];
         const double* cen = s_cen[var];
