@@ -902,10 +902,10 @@ int build_args(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxh
         g.col_zernike = g.col_gabor + ((mask3 & NYXHIP_FAM_GABOR) ? s->gabor_n_filters : 0);
         g.soft_nan = s->soft_nan;
         g.small_rois = (E.px <= kClassPx[0] && E.side <= kClassSide[0]) ? 1 : 0;   // the smallest size class (a function of the ROI: roi_class)
-        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; g.dbg_phase = getenv("NYXHIP_DBG_PHASE") ? atoi(getenv("NYXHIP_DBG_PHASE")) : 0; g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
+        g.gabor_bank = ctx->d_bank; g.gabor_bank32 = ctx->d_bank32; g.gabor_bank16 = ctx->d_bank16; { static const int dbg_phase_env = [] { const char* e = getenv("NYXHIP_DBG_PHASE"); return e ? atoi(e) : 0; }(); g.dbg_phase = dbg_phase_env; } g.gabor_nf = s->gabor_n_filters; g.gabor_n = s->gabor_kersize; g.gabor_thr = s->gabor_graythr;
         for (int f = 0; f <= NYXHIP_MAX_GABOR_FILTERS; f++) g.gabor_zero_rows[f] = ctx->bank_zero_rows[f];
         g.gabor_box_mask = ctx->bank_box_mask;
-        g.gabor_lp_sep = ctx->bank_lp_sep && !getenv("NYXHIP_GABOR_NO_LPSEP");
+        { static const bool no_lpsep = getenv("NYXHIP_GABOR_NO_LPSEP") != nullptr; g.gabor_lp_sep = ctx->bank_lp_sep && !no_lpsep; }
         memcpy(g.gabor_lp_B, ctx->bank_lp_B, sizeof(g.gabor_lp_B)); memcpy(g.gabor_lp_C, ctx->bank_lp_C, sizeof(g.gabor_lp_C));
     }
     return NYXHIP_OK;
@@ -1218,6 +1218,47 @@ static int run_large(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, cons
     return NYXHIP_OK;
 }
 
+// Gabor of the ROIs `list[0 .. grid)` by several workgroups per ROI (roi_large_gabor.hip): tiles of 64 x 32 output pixels staged in LDS,
+// the reference's arithmetic per pixel, integer counts across workgroups.  Boxes beyond 8192 px a side (or kernels beyond 32 taps) are
+// left to the caller's one-workgroup kernel (*served stays false).  `g`: the shape arguments of the class (columns, bank, threshold).
+static int run_large_gabor(nyxhip_ctx* ctx, const nyxhip_batch* b, const nyxhip_settings* s, double* d_out, size_t ld, const Extrema& E, const ShapeArgs& g,
+                           const uint32_t* list, uint32_t grid, hipStream_t st, unsigned char** bufp, size_t* bytesp, bool* served)
+{
+    *served = false;
+    const bool no_coop_gabor = [] { const char* e = getenv("NYXHIP_NO_COOP_GABOR"); return e && *e && *e != '0'; }();   // A/B knob (read per call: the tests compare both paths in one process)
+    if (no_coop_gabor || !list || grid == 0 || E.side > kLgabMaxSide || (uint32_t)s->gabor_kersize > kLgabMaxN) return NYXHIP_OK;
+    LgabArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.n_roi = b->n_roi; ga.px_offset = b->px_offset; ga.x = b->x; ga.y = b->y; ga.inten = b->inten;
+    ga.bbox_w = b->bbox_w; ga.bbox_h = b->bbox_h; ga.min_inten = b->min_inten; ga.max_inten = b->max_inten;
+    ga.out = d_out; ga.ld = ld; ga.col_gabor = g.col_gabor; ga.nf = s->gabor_n_filters; ga.n = s->gabor_kersize;
+    ga.thr = g.gabor_thr; ga.soft_nan = s->soft_nan; ga.bank = g.gabor_bank;
+    const uint64_t area_cap = std::max<uint64_t>(E.area, 1);
+    // tiles of a w x h box: ceil(w / 64) ceil(h / 32) <= w h / 2048 + w / 64 + h / 32 + 1, and w, h <= side, w h <= area for every ROI of the class
+    ga.tiles_cap = (uint32_t)std::min<uint64_t>((uint64_t)((E.side + kLgabTileW - 1) / kLgabTileW) * ((E.side + kLgabTileH - 1) / kLgabTileH),
+                                                area_cap / (kLgabTileW * kLgabTileH) + E.side / kLgabTileW + E.side / kLgabTileH + 2);
+    ga.off_rec = (4 * area_cap + 255) & ~255ull;
+    ga.off_cnt = (ga.off_rec + 24ull * ga.tiles_cap + 255) & ~255ull;
+    ga.stride = (ga.off_cnt + 4ull * (uint64_t)(ga.nf + 1) + 255) & ~255ull;
+    const size_t gbudget = (size_t)2 << 30;
+    const uint32_t gchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<uint32_t>(grid, 65535u), gbudget / ga.stride));
+    const size_t gneed = ga.stride * gchunk;
+    if (gneed > *bytesp) {
+        if (*bufp) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(*bufp)); *bufp = nullptr; *bytesp = 0; }
+        HIP_TRY(ctx, hipMalloc((void**)bufp, gneed));
+        *bytesp = gneed;
+    }
+    ga.ws = *bufp;
+    for (uint32_t o = 0; o < grid; o += gchunk) {
+        const uint32_t nb = std::min(gchunk, grid - o);
+        set_slots(ga.sp, list + o, nb);
+        if (int rc = launch_large_gabor(ga, st, nb, E.px))
+            return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI Gabor launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    *served = true;
+    return NYXHIP_OK;
+}
+
 // GLRLM + GLSZM + NGTDM of one class by the several-workgroups-per-ROI kernels of roi_large_tex.hip, on stream `st` with the
 // workspace pair `slot`.  *served: 0 = the class does not qualify (nothing launched), 1 = every member was served, 2 = the members
 // outside ltex_eligible are left to the caller (the one-workgroup launch with SpillArgs::skip_ltex).
@@ -1294,7 +1335,7 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
         return cb * area + 64 * members + 8 * (area + 2 * members) + 4 * (area / (S + 1) + 8 * members) + 28 * (area / rmin + members * side_w) + 64 * members;
     };
     const char* const be = getenv("NYXHIP_LARGE_BUDGET_MB");                  // (tests: a small budget sends a class through the chunked form)
-    const size_t budget = be && atoll(be) > 0 ? (size_t)atoll(be) << 20 : (size_t)8 << 30;
+    const size_t budget = be && atoll(be) > 0 ? (size_t)atoll(be) << 20 : (size_t)2 << 30;   // per slot, kept until nyxhip_destroy (nine slots: 8 GiB each could pin 72 GiB of a context)
     const uint64_t all_bytes = (uint64_t)count * fixed + var_bytes(tot.area, count);
     const uint64_t one_max = fixed + var_bytes(area_e, 1);
     uint32_t chunk = count;
@@ -1308,12 +1349,21 @@ static int run_large_tex(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t full, 
     uint64_t cap_load = chunk == count ? tot.px / a.px_per_wg + 2ull * count : (uint64_t)chunk * slabs_max;
     uint64_t cap_strip = chunk == count ? tot.area / 4096 + 2ull * count : (uint64_t)chunk * strips_max;
     if (cap_load > 0x3FFFFFFFull || cap_strip > 0x3FFFFFFFull) return NYXHIP_OK;
-    const size_t o_ctr = 0, o_off = 256, o_ml = al256(o_off + 8ull * chunk), o_ms = al256(o_ml + 8ull * cap_load), aux_need = al256(o_ms + 8ull * cap_strip);
     if (ws_need > ctx->ltex_bytes[slot]) {
         if (ctx->ltex_buf[slot]) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->ltex_buf[slot])); ctx->ltex_buf[slot] = nullptr; ctx->ltex_bytes[slot] = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->ltex_buf[slot], ws_need));
+        // a device short of memory: smaller chunks (the form the budget already knows); when not even one member's block can be had the
+        // class goes to the one-workgroup kernels (*served stays 0) instead of failing the call
+        while (hipMalloc(&ctx->ltex_buf[slot], ws_need) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->ltex_buf[slot] = nullptr;
+            if (chunk <= 1) return NYXHIP_OK;
+            chunk = (chunk + 1) / 2;
+            ws_need = (uint64_t)chunk * one_max;
+            cap_load = (uint64_t)chunk * slabs_max; cap_strip = (uint64_t)chunk * strips_max;
+        }
         ctx->ltex_bytes[slot] = ws_need;
     }
+    const size_t o_ctr = 0, o_off = 256, o_ml = al256(o_off + 8ull * chunk), o_ms = al256(o_ml + 8ull * cap_load), aux_need = al256(o_ms + 8ull * cap_strip);
     if (aux_need > ctx->ltex_aux_bytes[slot]) {
         if (ctx->ltex_aux[slot]) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->ltex_aux[slot])); ctx->ltex_aux[slot] = nullptr; ctx->ltex_aux_bytes[slot] = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->ltex_aux[slot], aux_need + aux_need / 4));
@@ -1426,7 +1476,10 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     // as well (roi_large_tex.hip), on a lane beside the main stream.  A function of the class, i.e. of the ROI.
     static const bool no_sc2_tex = [] { const char* e = getenv("NYXHIP_NO_COOP_TEX_SC2"); const char* f = getenv("NYXHIP_NO_COOP_TEX"); const char* g0 = getenv("NYXHIP_NO_COOP");
                                         return (e && *e && *e != '0') || (f && *f && *f != '0') || (g0 && *g0 && *g0 != '0'); }();   // A/B knob
-    if (list && cls / 2 == 2 && (lds & 2) && tot && !no_sc2_tex && b->inten) {
+    if (list && cls / 2 == 2 && (lds & 2) && tot && !no_sc2_tex) {
+        // (a function of the class alone: a window-mode chunk -- INTENSITY / GLCM only by construction, so never here with texture families --
+        //  would come back with its clouds rather than take the other texture kernel)
+        if (!b->inten) return NYXHIP_INTERNAL_NEEDS_CLOUDS;
         const hipStream_t main_st = st;
         int served2 = 0;
         // (the lane of size class 3 -- usually a handful of ROIs: streams beyond the device's four hardware queues share one, and a
@@ -1438,11 +1491,14 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             lds &= ~2u;
             if (report) {
                 report->cooperative |= 2;
-                if (ctx->timing) { HIP_TRY(ctx, hipEventCreate(&report->e2)); HIP_TRY(ctx, hipEventRecord(report->e2, st)); }
+                if (ctx->timing) { if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2)); HIP_TRY(ctx, hipEventRecord(report->e2, st)); }
             }
         }
         st = main_st;
     }
+    // (Size class 2 and Gabor: a 128 x 128 box takes 87 KB of LDS in the tiled kernel -- one workgroup per CU, 10.9 ms for the 2 031 such
+    //  ROIs of the heavy-tailed batch.  Cut into 64 x 32 tiles by run_large_gabor the same ROIs took 15.5 ms -- boxes of 65..127 px fill
+    //  40 % of their tiles, and the strips compute every tap in fp64 where the tiled kernel screens on the matrix pipe: not routed there.)
     if (lds) {
         for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
@@ -1517,7 +1573,8 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     }
     if (!gs) {
         if (on_lds_lane && report && ctx->timing) {
-            HIP_TRY(ctx, hipEventCreate(&report->e2));
+            if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2));      // (the size-class-2 texture branch may have made it already: that one is on its lane's stream)
+            else return NYXHIP_OK;
             HIP_TRY(ctx, hipEventRecord(report->e2, st));
         }
         return NYXHIP_OK;
@@ -1542,7 +1599,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         if (int lrc2 = enter_lane(lane)) return lrc2;
     auto lane_stamp = [&]() -> int {
         if (lane >= 0 && report && ctx->timing) {
-            HIP_TRY(ctx, hipEventCreate(&report->e2));
+            if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2));
             HIP_TRY(ctx, hipEventRecord(report->e2, st));
         }
         return NYXHIP_OK;
@@ -1562,12 +1619,19 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     RoiArgs a2; TexArgs t2; ShapeArgs g2; DepArgs d2;
     int lrc = build_args(ctx, b, full, s, d_out, ld, E, (size_t)1 << 31, a2, t2, g2, d2, why, gs);
     if (lrc) return fail(ctx, lrc, "large-ROI workspace: " + why);
+    // ---- Gabor of the class by several workgroups per ROI (roi_large_gabor.hip) --------------------------------------------------------
+    bool gabor_served = false;
+    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR) && !no_coop) {
+        if (int grc = run_large_gabor(ctx, b, s, d_out, ld, E, g2, list, grid, st, lane >= 0 ? &ctx->lane_buf[lane] : &ctx->d_spill,
+                                      lane >= 0 ? &ctx->lane_bytes[lane] : &ctx->spill_bytes, &gabor_served)) return grc;
+        if (gabor_served && report) report->cooperative |= 4;
+    }
     if (coop) a2.sp.min_range = kLargeRangeMax;          // the histogram path served everybody below
     if (tex_served == 2) t2.sp.skip_ltex = 1;            // ... and the strip path every box it takes
     size_t stride = 0;
     if (gs & 1) stride = std::max<size_t>(stride, a2.L.total);
     if (gs & 2) stride = std::max<size_t>(stride, t2.L.total);
-    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR)) stride = std::max<size_t>(stride, g2.L.total);
+    if ((gs & 4) && (mask & NYXHIP_FAM_GABOR) && !gabor_served) stride = std::max<size_t>(stride, g2.L.total);
     if (gs & 8) stride = std::max<size_t>(stride, d2.L.total);
     stride = (stride + 255) & ~(size_t)255;
     const size_t budget = (size_t)4 << 30;         // at most 4 GiB of scratch in flight
@@ -1595,7 +1659,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         rc = (gs & 1) ? launch_roi_features(a2, st, nb) : 0;
         if (rc == 0 && (gs & 2)) rc = launch_roi_texture(t2, st, nb);
         if (rc == 0 && (gs & 8)) rc = launch_roi_dependence(d2, st, nb);
-        if (rc == 0 && (gs & 4) && (mask & NYXHIP_FAM_GABOR)) rc = launch_roi_shape(g2, st, nb);
+        if (rc == 0 && (gs & 4) && (mask & NYXHIP_FAM_GABOR) && !gabor_served) rc = launch_roi_shape(g2, st, nb);
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }

@@ -582,6 +582,33 @@ struct WideArgs {
     uint32_t o_keys, o_work, slow_hist, o_lb, lds_bytes;   // byte offsets: keys | bitmap + prefixes + lists (slow path: second keys, counts, digit counts at slow_hist) | bin bounds
 };
 bool make_wide_layout(uint32_t max_px, uint32_t n_hist, WideArgs& a);
+// ---- Gabor of ROIs beyond LDS: several workgroups per ROI (roi_large_gabor.hip) ------------------------------------------------------
+constexpr int kLgabTileW = 64, kLgabTileH = 32;       // output pixels of a tile (one workgroup)
+constexpr uint32_t kLgabSlab = 8192;                  // cloud pixels per workgroup of the plane kernel
+constexpr uint32_t kLgabMaxSide = 8192, kLgabMaxN = 32;
+struct LgabArgs {
+    uint64_t n_roi;
+    const uint64_t* px_offset;
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* inten;
+    const uint32_t* bbox_w;
+    const uint32_t* bbox_h;
+    const uint32_t* min_inten;
+    const uint32_t* max_inten;
+    double* out;
+    uint64_t ld;
+    int32_t col_gabor, nf, n;
+    double thr, soft_nan;
+    const double* bank;        // device: (nf + 1) filters (low-pass first), n * n complex taps each
+    unsigned char* ws;         // per slot of the launch: u32 plane [area_cap] | tile records [tiles_cap][3] doubles | counters [nf]
+    uint64_t stride, off_rec, off_cnt;
+    uint32_t tiles_cap;        // tiles of the largest box of the launch (grid.x)
+    SpillArgs sp;              // roi_index list + n_slots
+};
+size_t lgab_lds_bytes(int n);
+int launch_large_gabor(const LgabArgs& a, void* stream, uint32_t n_slots, uint32_t max_px);
+
 int launch_roi_wide(const WideArgs& a, void* stream);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip

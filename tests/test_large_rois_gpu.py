@@ -191,3 +191,72 @@ def test_default_grey_depth_on_large_rois(hip_ctx, gabor):
     rois = [ellipse_roi(90, 72, rng), ellipse_roi(200, 160, rng, lo=0, holes=0.03), ellipse_roi(20, 18, rng)]
     mask = CONFIG4 | (_abi.FAM_GABOR if gabor else 0)
     check(hip_ctx, rois, mask, _abi.default_settings(64))
+
+
+# ---- Gabor of ROIs beyond LDS by several workgroups per ROI (roi_large_gabor.hip, round 6) -------------------------------------------
+def _same(G, O):
+    return ((G == O) | (np.isnan(G) & np.isnan(O))).all()
+
+
+def gabor_rois(seed=5, hi=4096):
+    """Boxes on both sides of the 64 x 32 tiles of the strip path: 180 x 144 (20 k px), 401 x 321 with zeros and holes, a thin 2000 x 12
+    strip, a 129 x 33 box, one tile plus one pixel each way (65 x 33 is LDS-sized: 200 x 130 instead), a constant and a blank ROI."""
+    rng = np.random.default_rng(seed)
+    rois = [ellipse_roi(90, 72, rng, hi=hi), ellipse_roi(200, 160, rng, hi=hi, lo=0, holes=0.03), ellipse_roi(100, 65, rng, hi=hi)]
+    yy, xx = np.mgrid[0:12, 0:2000]
+    o = np.lexsort((yy.ravel(), xx.ravel()))
+    rois.append(dict(x=xx.ravel()[o], y=yy.ravel()[o], inten=rng.integers(1, hi, xx.size).astype(np.uint32)))
+    yy, xx = np.mgrid[0:257, 0:129]
+    v = (hi // 2 + (hi // 3) * np.sin(xx / 9.0) * np.cos(yy / 13.0)).astype(np.int64).clip(1, hi - 1)      # a smooth field: energies near the thresholds
+    o = np.lexsort((yy.ravel(), xx.ravel()))
+    rois.append(dict(x=xx.ravel()[o], y=yy.ravel()[o], inten=v.ravel()[o].astype(np.uint32)))
+    c = ellipse_roi(100, 70, rng); c["inten"][:] = 77
+    z = ellipse_roi(95, 75, rng); z["inten"][:] = 0
+    return rois + [c, z]
+
+
+@pytest.mark.parametrize("hi", [256, 4096, 65536, 1 << 25])
+def test_gabor_of_large_rois_is_bit_identical(hip_ctx, hi):
+    """Count ratios of every filter equal the oracle's bit for bit (default bank and an 8-filter bank), whatever the intensity depth:
+    the strip path computes every energy with the reference's arithmetic."""
+    b = _abi.batch_from_rois(gabor_rois(hi=hi))
+    for nf in (4, 8):
+        s = _abi.default_settings(8)
+        if nf == 8:
+            s.gabor_n_filters = 8
+            for i in range(8):
+                s.gabor_f0[i] = [4.0, 16.0, 32.0, 64.0][i % 4]
+                s.gabor_theta[i] = float(np.pi * i / 8)
+        G = hip_ctx.featurize_host(b, _abi.FAM_GABOR, s)
+        assert any(r["cooperative"] & 4 for r in hip_ctx.launch_report()), hip_ctx.launch_report()
+        assert _same(G, po.oracle_featurize(b, _abi.FAM_GABOR, s))
+
+
+def test_gabor_strips_equal_the_one_workgroup_kernel(hip_ctx, monkeypatch):
+    """Rows of large ROIs do not depend on the path (several workgroups per ROI or the one-workgroup workspace kernel), on companions
+    or on the other families of the call."""
+    rng = np.random.default_rng(8)
+    big = gabor_rois(seed=8)
+    small = [ellipse_roi(int(rng.integers(4, 30)), int(rng.integers(4, 30)), rng) for _ in range(40)]
+    s = _abi.default_settings(8)
+    alone = hip_ctx.featurize_host(_abi.batch_from_rois(big), _abi.FAM_GABOR, s)
+    mixed = [small[i // 2] if i % 2 == 0 else big[i // 2] for i in range(2 * len(big))] + small[len(big):]
+    idx_big = [i for i in range(2 * len(big)) if i % 2 == 1]
+    bm = _abi.batch_from_rois(mixed)
+    among = hip_ctx.featurize_host(bm, _abi.FAM_GABOR | _abi.FAM_ZERNIKE | _abi.FAM_INTENSITY, s)
+    names = _lib.column_names(_abi.FAM_GABOR | _abi.FAM_ZERNIKE | _abi.FAM_INTENSITY, s)
+    gcols = [i for i, n in enumerate(names) if n.startswith("GABOR")]
+    assert _same(among[idx_big][:, gcols], alone)
+    monkeypatch.setenv("NYXHIP_NO_COOP_GABOR", "1")
+    one_wg = hip_ctx.featurize_host(_abi.batch_from_rois(big), _abi.FAM_GABOR, s)
+    assert not any(r["cooperative"] & 4 for r in hip_ctx.launch_report())
+    assert _same(one_wg, alone)
+
+
+@pytest.mark.parametrize("n", [8, 16, 21])
+def test_gabor_strips_with_other_kernel_sizes(hip_ctx, n):
+    rng = np.random.default_rng(n)
+    s = _abi.default_settings(8)
+    s.gabor_kersize = n
+    b = _abi.batch_from_rois([ellipse_roi(100, 80, rng), ellipse_roi(70, 90, rng, lo=0, holes=0.05)])
+    assert _same(hip_ctx.featurize_host(b, _abi.FAM_GABOR, s), po.oracle_featurize(b, _abi.FAM_GABOR, s))
