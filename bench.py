@@ -843,11 +843,20 @@ class Bench:
         nh = min(nt, 256)                        # (2 GiB of host tiles; the call itself goes through them in chunks)
         h_in32 = tin[:nh].cpu().numpy().view(np.uint32)
         h_lab32 = labs[:nh].cpu().numpy().view(np.uint32)
-        for tag, hi, hl in (("pcie_inclusive", h_in32, h_lab32), ("pcie_inclusive_u16_u8", h_in32.astype(np.uint16), h_lab32.astype(np.uint8))):
-            ctx.featurize_tiles_host(hi, hl, mask, s)
+        def own_map(arr):
+            """The same bytes in an anonymous mapping of its own: what NYXHIP_MEM_HOST_OWN_MAPPING asks the caller to state."""
+            import mmap
+            m = mmap.mmap(-1, max(arr.nbytes, 4096))
+            out = np.frombuffer(m, dtype=arr.dtype, count=arr.size).reshape(arr.shape)
+            out[...] = arr
+            return out
+        legs_h = (("pcie_inclusive", h_in32, h_lab32, False), ("pcie_inclusive_u16_u8", h_in32.astype(np.uint16), h_lab32.astype(np.uint8), False),
+                  ("pcie_inclusive_own_mapping", own_map(h_in32), own_map(h_lab32), True))
+        for tag, hi, hl, own in legs_h:
+            ctx.featurize_tiles_host(hi, hl, mask, s, own_mapping=own)
             c0 = time.perf_counter()
             for _ in range(2):
-                htile_out, hl_out, htab_out = ctx.featurize_tiles_host(hi, hl, mask, s)
+                htile_out, hl_out, htab_out = ctx.featurize_tiles_host(hi, hl, mask, s, own_mapping=own)
             dth = (time.perf_counter() - c0) / 2
             par_h = None
             if not a.no_check:
@@ -863,7 +872,9 @@ class Bench:
                     par_h = "FAILED: " + repr(eh)
             rec["tile_path"][tag] = {"value": len(hl_out) / dth, "unit": "ROIs/s", "tiles": nh, "ms_per_call": 1e3 * dth,
                                      "host_GBps": (hi.nbytes + hl.nbytes) / dth / 1e9, "parity_check": par_h,
-                                     "what": "pageable host tiles (" + str(hi.dtype) + " intensity, " + str(hl.dtype) + " labels) in, host table out"}
+                                     "what": ("host tiles declared mappings of their own (NYXHIP_MEM_HOST_OWN_MAPPING: registered, DMA in place; " if own else
+                                              "pageable host tiles through the library's pinned staging ring (NYXHIP_MEM_HOST; ")
+                                             + str(hi.dtype) + " intensity, " + str(hl.dtype) + " labels) in, host table out"}
         # "(a) end-to-end featurize() (tile arrays in host memory -> feature table in host memory) and (b) reduce
         # stage only ...  Both are reported; the headline ratio is (a) vs (a)."
         cb_t = rec["tile_path"].get("cpu_baseline") or {}
@@ -901,7 +912,7 @@ class Bench:
         if isinstance(rec.get("tile_path"), dict):
             if rec["tile_path"].get("traffic_ratio") is not None:
                 summ["tile_path.traffic_ratio"] = round(rec["tile_path"]["traffic_ratio"], 3)
-            for sub in ("irregular", "pcie_inclusive", "pcie_inclusive_u16_u8"):
+            for sub in ("irregular", "pcie_inclusive", "pcie_inclusive_u16_u8", "pcie_inclusive_own_mapping"):
                 if sub in rec["tile_path"]:
                     summ["tile_path." + sub] = brief(rec["tile_path"][sub])
         if isinstance(rec.get("mixed_sizes"), dict) and "ms_per_call" in rec["mixed_sizes"]:

@@ -114,7 +114,12 @@ void nyxhip_default_settings(nyxhip_settings* s);
  * result depends on it beyond floating-point summation order.
  *
  * `memory` says where ALL pointers of the struct live. */
-enum { NYXHIP_MEM_HOST = 0, NYXHIP_MEM_DEVICE = 1 };
+enum { NYXHIP_MEM_HOST = 0, NYXHIP_MEM_DEVICE = 1,
+       /* nyxhip_tiles only: host memory AND the caller's statement that both tile arrays are mappings of their own (mmap, a
+        * page-aligned allocation that is not handed back to an allocator arena while the call runs).  Their whole pages are
+        * then registered for the call (hipHostRegister) and copied by DMA in place; plain NYXHIP_MEM_HOST goes through the
+        * library's own pinned staging ring and assumes nothing about the caller's allocator ("Host memory"). */
+       NYXHIP_MEM_HOST_OWN_MAPPING = 2 };
 
 typedef struct nyxhip_batch {
     uint64_t n_roi;

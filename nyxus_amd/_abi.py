@@ -33,6 +33,7 @@ FAM_ALL = 0xFFF
 
 MEM_HOST = 0
 MEM_DEVICE = 1
+MEM_HOST_OWN_MAPPING = 2   # nyxhip_tiles only: host arrays the caller declares mappings of their own (registered for DMA in place)
 
 U8, U16, U32 = 1, 2, 4                       # tile element types (bytes per element)
 SLIDE_MONTAGE, SLIDE_PER_TILE, SLIDE_GIVEN = 0, 1, 2

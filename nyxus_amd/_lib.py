@@ -214,11 +214,14 @@ class Context:
         return labels, table
 
     def featurize_tiles_host(self, inten: np.ndarray, label: np.ndarray, mask: int, s: _abi.Settings, slide_mode: int = _abi.SLIDE_MONTAGE,
-                             slide_min=None, slide_max=None, max_device_bytes: int = 0, contexts: Optional[list] = None):
+                             slide_min=None, slide_max=None, max_device_bytes: int = 0, contexts: Optional[list] = None, own_mapping: bool = False):
         """A stack [n_tiles, H, W] of host tiles through the fused device path (nyxhip_featurize_tiles_v2).  uint8 / uint16 /
         uint32 arrays are handed over as they are (the kernels widen); anything else is cast to uint32 first.  Label values are
         arbitrary.  Returns (tile_index, labels, table) with rows ordered by (tile, label), sized by the ROI count the device
-        scan found.  `contexts`: more contexts (one per GPU) -> nyxhip_featurize_tiles_sharded block-partitions the stack."""
+        scan found.  `contexts`: more contexts (one per GPU) -> nyxhip_featurize_tiles_sharded block-partitions the stack.
+        `own_mapping`: the caller's statement that both stacks are mappings of their own (e.g. numpy arrays over an mmap): they
+        are registered for DMA in place (NYXHIP_MEM_HOST_OWN_MAPPING); otherwise the bytes pass through the library's pinned
+        staging ring, which assumes nothing about the allocator."""
         if inten.shape != label.shape or inten.ndim != 3:
             raise ValueError("stacks must be 3-D arrays [n_tiles, H, W] of the same shape")
         dt = {np.dtype(np.uint8): _abi.U8, np.dtype(np.uint16): _abi.U16, np.dtype(np.uint32): _abi.U32}
@@ -229,7 +232,7 @@ class Context:
         t = _abi.Tiles()
         t.inten = inten.ctypes.data; t.label = label.ctypes.data
         t.inten_dtype = dt[inten.dtype]; t.label_dtype = dt[label.dtype]
-        t.width = w; t.height = h; t.n_tiles = nt; t.memory = _abi.MEM_HOST; t.slide_mode = slide_mode
+        t.width = w; t.height = h; t.n_tiles = nt; t.memory = _abi.MEM_HOST_OWN_MAPPING if own_mapping else _abi.MEM_HOST; t.slide_mode = slide_mode
         keep = []
         if slide_mode == _abi.SLIDE_GIVEN:
             keep = [np.ascontiguousarray(slide_min, np.float64), np.ascontiguousarray(slide_max, np.float64)]

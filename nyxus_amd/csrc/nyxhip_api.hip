@@ -84,6 +84,14 @@ struct nyxhip_ctx {
     size_t slot_bytes[2] = {0, 0};
     hipStream_t copy_stream = nullptr;         // H2D of the next chunk runs beside the kernels of the current one
     hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    // pinned staging ring of the host tile path (HostStager below): the library's own page-locked memory between a pageable
+    // caller and the DMA engine
+    static constexpr int kStageSlots = 4;
+    static constexpr size_t kStageSlotBytes = (size_t)32 << 20;
+    void* h_stage[kStageSlots] = {};
+    hipEvent_t h_stage_done[kStageSlots] = {};
+    bool h_stage_used[kStageSlots] = {};
+    int h_stage_next = 0;
     WindowSrc win_next = {};                   // set by the tile path for its next launch_device call: read ROIs from their tile windows
     uint32_t tile_cap_hint = 0;                // per-tile table size that served the last call
     // result kept for nyxhip_fetch_result() (host-memory calls with out_table == NULL): device-resident, grow-only
@@ -1965,6 +1973,10 @@ void nyxhip_destroy(nyxhip_ctx* ctx)
         if (ctx->slot_free[k]) (void)hipEventDestroy(ctx->slot_free[k]);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (int k = 0; k < nyxhip_ctx::kStageSlots; k++) {
+        if (ctx->h_stage_done[k]) (void)hipEventDestroy(ctx->h_stage_done[k]);
+        if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+    }
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_mom) (void)hipFree(ctx->d_mom);
     if (ctx->d_glcm_ws) (void)hipFree(ctx->d_glcm_ws);
@@ -2308,7 +2320,7 @@ static int tiles_validate(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t famil
     auto dt_ok = [](int d) { return d == NYXHIP_U8 || d == NYXHIP_U16 || d == NYXHIP_U32; };
     if (!dt_ok(t->inten_dtype) || !dt_ok(t->label_dtype)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "tile element types must be NYXHIP_U8 / U16 / U32");
     if (family_mask == 0 || (family_mask & ~kImplemented)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad family mask");
-    if (t->memory != NYXHIP_MEM_HOST && t->memory != NYXHIP_MEM_DEVICE) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
+    if (t->memory != NYXHIP_MEM_HOST && t->memory != NYXHIP_MEM_DEVICE && t->memory != NYXHIP_MEM_HOST_OWN_MAPPING) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad memory kind");
     if (t->slide_mode < NYXHIP_SLIDE_MONTAGE || t->slide_mode > NYXHIP_SLIDE_GIVEN) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "bad slide_mode");
     if (t->slide_mode == NYXHIP_SLIDE_GIVEN && (!t->slide_min || !t->slide_max)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "NYXHIP_SLIDE_GIVEN needs slide_min and slide_max");
     std::string why;
@@ -2341,79 +2353,82 @@ static int res_reserve(nyxhip_ctx* ctx, size_t rows, size_t n_cols, hipStream_t 
     return NYXHIP_OK;
 }
 
-// Pins a caller's host arrays for the duration of a call (hipHostRegister): a pinned source makes the chunk copies true DMA
-// transfers that overlap the kernels (50-57 GB/s measured); left pageable, an asynchronous copy goes through the runtime's staging
-// path at 8-20 GB/s.  The runtime keeps the pinning cached across calls on the same buffer (first call ~22 us/MB, later ones
-// ~0.01 ms).
-// Only WHOLE PAGES that lie inside the array are registered (the range is rounded inward to 4 KiB; the bytes in front of the
-// first and behind the last whole page travel as pageable copies of their own, h2d below).  Round 3 registered the array as it
-// came: an array that starts or ends inside a page shares that page with whatever the allocator put next to it -- another array
-// of the same call, typically -- and two registrations that overlap in a page, released one after the other, left the second
-// one's cached mapping without that page: "Memory access fault by GPU ... on address <a page of the host heap>" inside a later
-// call's copy (5 of 48 runs of the GPU suite; never with page-aligned or private mappings).  Rounded inward, no two
-// registrations can share a page.  Arrays below kPinMinBytes are not pinned at all (their staging copies cost nothing
-// measurable; NYXHIP_PIN_MIN overrides the threshold: tests/test_pin_stress_gpu.py runs with 0).
-// One guard per ARRAY: the sharded entry pins the whole stack once, before its threads copy their shares -- per-share
-// registrations would be released at different times while other shares still copy.
+// [src, src + bytes) of pageable host memory -> device through the context's pinned ring: per piece of at most kStageSlotBytes, wait for
+// the slot's previous DMA, copy the piece into the slot with a few host threads (one thread moves ~10 GB/s, the link takes 50), enqueue
+// the DMA, go on with the next slot.  Host copy of piece i + 1 and DMA of piece i overlap.
+static void parallel_copy(void* dst, const void* src, size_t n)
+{
+    static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, std::max(1u, hw / 2)), n >> 21);     // >= 2 MiB per thread
+    if (nt <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / nt) + 4095) & ~(size_t)4095;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t o = (size_t)t * per;
+        if (o >= n) break;
+        th.emplace_back([=]() { memcpy((char*)dst + o, (const char*)src + o, std::min(per, n - o)); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (auto& t : th) t.join();
+}
+static hipError_t staged_h2d(nyxhip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    static const bool no_stage = [] { const char* e = getenv("NYXHIP_NO_STAGING"); return e && *e && *e != '0'; }();   // A/B knob: the runtime's own pageable path
+    if (no_stage || bytes < ((size_t)1 << 20)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    for (size_t o = 0; o < bytes; o += nyxhip_ctx::kStageSlotBytes) {
+        const size_t len = std::min(nyxhip_ctx::kStageSlotBytes, bytes - o);
+        const int k = ctx->h_stage_next;
+        ctx->h_stage_next = (k + 1) % nyxhip_ctx::kStageSlots;
+        if (!ctx->h_stage[k]) {
+            if (hipError_t e = hipHostMalloc(&ctx->h_stage[k], nyxhip_ctx::kStageSlotBytes, hipHostMallocDefault); e != hipSuccess) { ctx->h_stage[k] = nullptr; return e; }
+            if (hipError_t e = hipEventCreateWithFlags(&ctx->h_stage_done[k], hipEventDisableTiming); e != hipSuccess) return e;
+        }
+        if (ctx->h_stage_used[k])
+            if (hipError_t e = hipEventSynchronize(ctx->h_stage_done[k]); e != hipSuccess) return e;      // the slot's previous piece has left it
+        parallel_copy(ctx->h_stage[k], (const char*)src + o, len);
+        if (hipError_t e = hipMemcpyAsync((char*)dst + o, ctx->h_stage[k], len, hipMemcpyHostToDevice, st); e != hipSuccess) return e;
+        if (hipError_t e = hipEventRecord(ctx->h_stage_done[k], st); e != hipSuccess) return e;
+        ctx->h_stage_used[k] = true;
+    }
+    return hipSuccess;
+}
+
+// Host tiles reach the device in one of two ways (nyxhip_tiles::memory):
+//   NYXHIP_MEM_HOST              any host memory.  The bytes go through the library's OWN pinned staging ring (HostStager: hipHostMalloc'ed
+//                                slots; a few host threads copy a piece into a slot, the DMA engine takes it from there, the next piece is
+//                                copied meanwhile).  Nothing is assumed about the caller's allocator.
+//   NYXHIP_MEM_HOST_OWN_MAPPING  the caller states that both arrays are mappings of their own (mmap, a page-aligned allocation that is not
+//                                handed back to an allocator's arena while the call runs): their whole pages are registered for the call
+//                                (hipHostRegister) and copied by DMA in place -- no staging copy.
+// Round 3-5 registered whatever looked like a mapping of its own in /proc/self/maps (a rule that knew glibc's malloc only): pages of a
+// malloc arena, registered and released, left the driver's user-pointer bookkeeping in a state in which a LATER copy from those
+// addresses faulted on the GPU.  The decision now lies with the one who knows -- the caller.
+// Only WHOLE PAGES inside the array are registered (rounded inward to 4 KiB; what lies in front of and behind them travels through the
+// staging ring): two arrays of a call that share a page never overlap in a registration.  One guard per ARRAY: the sharded entry pins
+// the whole stack once, before its threads copy their shares.
 struct HostPin {
-    struct Mapping { uintptr_t lo, hi; bool arena; };
-    std::vector<Mapping> maps;                          // /proc/self/maps of this call
-    bool maps_read = false;
     void* p[2] = {nullptr, nullptr};
     uintptr_t lo[2] = {0, 0}, hi[2] = {0, 0};          // registered byte range of array k (empty: lo == hi)
-    static constexpr size_t kPinMinBytes = (size_t)8 << 20;
     static constexpr uintptr_t kPage = 4096;
     void pin(int k, const void* ptr, size_t bytes)
     {
         static const bool no_pin = [] { const char* e = getenv("NYXHIP_NO_PIN"); return e && *e && *e != '0'; }();   // A/B knob
-        const char* const me = getenv("NYXHIP_PIN_MIN");
-        const size_t pin_min = me && *me ? (size_t)atoll(me) : kPinMinBytes;
-        if (no_pin || bytes < pin_min || !ptr) return;
+        if (no_pin || !ptr) return;
         const uintptr_t a = ((uintptr_t)ptr + kPage - 1) & ~(kPage - 1), z = ((uintptr_t)ptr + bytes) & ~(kPage - 1);
         if (z <= a) return;                                   // no whole page inside the array
-        // Never pages of malloc's arenas.  Registered and released again they left the process in a state in which a LATER copy
-        // from an unrelated array at those addresses faulted on the GPU ("Memory access fault ... on address <heap page>", 4 of 33
-        // runs of the GPU suite with NYXHIP_PIN_MIN=0, none of 20 without the small-array case): the allocator trims, grows and
-        // re-issues those pages, and the driver's user-pointer bookkeeping does not survive it.  Arrays above malloc's mmap
-        // threshold -- the ones worth pinning -- live in anonymous mappings outside the arenas (neighbouring ones merge into one
-        // line of /proc/self/maps, so "a mapping of its own" cannot be asked for).  The page range must lie in one line that is
-        // neither `[heap]` (the main arena) nor shaped like another thread's arena (64-MiB aligned, at most 64 MiB long); an array
-        // of 8 .. 32 MiB that malloc placed in an arena -- its threshold adapts -- travels as a pageable copy.
-        // (the map is read once per call -- both arrays of a call are looked up in the same copy; a python + torch process has
-        //  thousands of lines there.  The rule knows glibc's malloc only: INTEGRATION.md, "Host memory".)
-        if (!maps_read) {
-            maps_read = true;
-            if (FILE* f = fopen("/proc/self/maps", "r")) {
-                char line[512];
-                while (fgets(line, sizeof(line), f)) {
-                    unsigned long m0 = 0, m1 = 0;
-                    if (sscanf(line, "%lx-%lx", &m0, &m1) != 2) continue;
-                    const bool arena_like = (m0 & ((64ul << 20) - 1)) == 0 && m1 - m0 <= (64ul << 20);
-                    maps.push_back({(uintptr_t)m0, (uintptr_t)m1, strstr(line, "[heap]") != nullptr || arena_like});
-                }
-                fclose(f);
-            }
-        }
-        bool outside_arenas = false;
-        for (const Mapping& m : maps)
-            if (m.lo <= a && a < m.hi) { outside_arenas = z <= m.hi && !m.arena; break; }
-        if (!outside_arenas) {
-            if (getenv("NYXHIP_DEBUG")) fprintf(stderr, "[nyxhip] host array %p (%zu MiB) lies in a malloc arena (or spans mappings): copied pageable\n", ptr, bytes >> 20);
-            return;
-        }
         if (hipHostRegister((void*)a, z - a, hipHostRegisterDefault) == hipSuccess) { p[k] = (void*)a; lo[k] = a; hi[k] = z; } else (void)hipGetLastError();
     }
     // host -> device copy of [src, src + bytes) of array k: the part inside the registered pages as one (DMA) copy, what lies in
     // front of and behind them as pageable copies
-    hipError_t h2d(int k, void* dst, const void* src, size_t bytes, hipStream_t st) const
+    hipError_t h2d(nyxhip_ctx* ctx, int k, void* dst, const void* src, size_t bytes, hipStream_t st) const
     {
         const uintptr_t b0 = (uintptr_t)src, b1 = b0 + bytes;
-        const uintptr_t m0 = std::min(std::max(b0, lo[k]), b1), m1 = std::max(std::min(b1, hi[k]), m0);   // the pinned middle [m0, m1)
-        if (lo[k] == hi[k] || m0 == m1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        const uintptr_t m0 = std::min(std::max(b0, lo[k]), b1), m1 = std::max(std::min(b1, hi[k]), m0);   // the registered middle [m0, m1)
+        if (lo[k] == hi[k] || m0 == m1) return staged_h2d(ctx, dst, src, bytes, st);
         hipError_t e = hipSuccess;
-        if (m0 > b0) e = hipMemcpyAsync(dst, src, m0 - b0, hipMemcpyHostToDevice, st);
+        if (m0 > b0) e = staged_h2d(ctx, dst, src, m0 - b0, st);
         if (e == hipSuccess) e = hipMemcpyAsync((char*)dst + (m0 - b0), (const void*)m0, m1 - m0, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && b1 > m1) e = hipMemcpyAsync((char*)dst + (m1 - b0), (const void*)m1, b1 - m1, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && b1 > m1) e = staged_h2d(ctx, (char*)dst + (m1 - b0), (const void*)m1, b1 - m1, st);
         return e;
     }
     ~HostPin()
@@ -2433,7 +2448,7 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
 {
     if (int vrc = tiles_validate(ctx, t, family_mask, s, n_roi_out)) return vrc;
     const int n_cols = nyxhip_n_columns(family_mask, s);
-    const bool host = t->memory == NYXHIP_MEM_HOST;
+    const bool host = t->memory == NYXHIP_MEM_HOST || t->memory == NYXHIP_MEM_HOST_OWN_MAPPING;
     const bool keep = host && out_table == nullptr;                  // result stays in the context (nyxhip_fetch_result)
     if (!keep && (!out_labels || !out_table)) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "null output pointers");
     if (!keep && (int)out_ld < n_cols) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "out_ld smaller than the column count");
@@ -2511,8 +2526,8 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         if (int grc = grow(ctx, &ctx->d_slot[k], &ctx->slot_bytes[k], slot_need, st)) return grc;
     auto slot_inten = [&](int k) { return (char*)ctx->d_slot[k]; };
     auto slot_label = [&](int k, uint32_t nt) { return (char*)ctx->d_slot[k] + (((size_t)nt * tile_px * t->inten_dtype + 255) & ~(size_t)255); };
-    HostPin pin;                                        // (see HostPin: arrays of at least 8 MiB, unless the caller pinned the stack)
-    if (!prepinned) {
+    HostPin pin;                                        // (see HostPin: only on the caller's statement, unless the sharded entry pinned the stack)
+    if (!prepinned && t->memory == NYXHIP_MEM_HOST_OWN_MAPPING) {
         pin.pin(0, t->inten, (size_t)t->n_tiles * tile_px * t->inten_dtype);
         pin.pin(1, t->label, (size_t)t->n_tiles * tile_px * t->label_dtype);
     }
@@ -2522,8 +2537,8 @@ static int tiles_run(nyxhip_ctx* ctx, const nyxhip_tiles* t, uint32_t family_mas
         const uint64_t t0 = c * chunk;
         const uint32_t nt = (uint32_t)std::min<uint64_t>(chunk, t->n_tiles - t0);
         if (c >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_free[k], 0));      // the kernels of chunk c - 2 have let go of the slot
-        HIP_TRY(ctx, pins->h2d(0, slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype, ctx->copy_stream));
-        HIP_TRY(ctx, pins->h2d(1, slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype, ctx->copy_stream));
+        HIP_TRY(ctx, pins->h2d(ctx, 0, slot_inten(k), (const char*)t->inten + (size_t)t0 * tile_px * t->inten_dtype, (size_t)nt * tile_px * t->inten_dtype, ctx->copy_stream));
+        HIP_TRY(ctx, pins->h2d(ctx, 1, slot_label(k, nt), (const char*)t->label + (size_t)t0 * tile_px * t->label_dtype, (size_t)nt * tile_px * t->label_dtype, ctx->copy_stream));
         HIP_TRY(ctx, hipEventRecord(ctx->slot_ready[k], ctx->copy_stream));
         return NYXHIP_OK;
     };
@@ -2622,7 +2637,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
     if (!ctxs || n_ctx < 1 || !ctxs[0]) return NYXHIP_ERR_INVALID_ARG;
     nyxhip_ctx* c0 = ctxs[0];
     if (!tiles || !n_roi_out) return fail(c0, NYXHIP_ERR_INVALID_ARG, "null tiles / n_roi_out");
-    if (tiles->memory != NYXHIP_MEM_HOST) return fail(c0, NYXHIP_ERR_INVALID_ARG, "the sharded entry takes host-memory stacks (every context copies its own share)");
+    if (tiles->memory != NYXHIP_MEM_HOST && tiles->memory != NYXHIP_MEM_HOST_OWN_MAPPING) return fail(c0, NYXHIP_ERR_INVALID_ARG, "the sharded entry takes host-memory stacks (every context copies its own share)");
     const bool keep = out_table == nullptr;                              // results stay in the contexts (nyxhip_fetch_result_sharded)
     if (!keep && !out_labels) return fail(c0, NYXHIP_ERR_INVALID_ARG, "null output pointers");
     for (int g = 0; g < n_ctx; g++)
@@ -2637,7 +2652,7 @@ int nyxhip_featurize_tiles_sharded(nyxhip_ctx* const* ctxs, int n_ctx, const nyx
     const uint64_t tile_px = (uint64_t)tiles->width * tiles->height;
     for (int g = 0; g < n_ctx; g++) ctxs[g]->res_rows = 0;
     HostPin pin;                                        // the whole stack, once: released after every share's copies have drained (join below)
-    if (hipSetDevice(c0->device) == hipSuccess) {
+    if (tiles->memory == NYXHIP_MEM_HOST_OWN_MAPPING && hipSetDevice(c0->device) == hipSuccess) {
         pin.pin(0, tiles->inten, (size_t)tiles->n_tiles * tile_px * tiles->inten_dtype);
         pin.pin(1, tiles->label, (size_t)tiles->n_tiles * tile_px * tiles->label_dtype);
     } else (void)hipGetLastError();

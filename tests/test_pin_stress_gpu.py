@@ -1,13 +1,12 @@
-"""Stress test of the host-array pinning of the tile path (nyxhip_api.hip: HostPin).
+"""Stress test of the host side of the tile path (nyxhip_api.hip: staged_h2d / HostPin).
 
-Round 3 saw "Memory access fault by GPU ... on address <a page of the host heap>" in 5 of 48 runs of the GPU suite, inside
-featurize_tiles_host, and worked around it by not pinning arrays below 8 MiB.  The cause: an array was registered as it came, so
-an array that starts or ends inside a page shared that page's registration with its neighbour in the heap.  HostPin now registers
-whole pages inside the array only and copies the edges as pageable memory.  This test drives the pattern that used to fault --
-hundreds of calls alternating small heap arrays, large arrays and unaligned slices of larger arrays -- once with the default
-threshold and once with NYXHIP_PIN_MIN=0 (every array with a whole page inside it is pinned -- except pages of malloc's
-arenas, which HostPin never registers: with them registered, 4 of 33 runs of the GPU suite died of the same fault in a LATER test's
-copy; the small arrays of this test live there, its large arrays and the unaligned slice are mappings of their own)."""
+Rounds 3-5 registered the caller's arrays (hipHostRegister) whenever /proc/self/maps made them look like mappings of their own;
+pages of malloc arenas registered and released left the driver in a state in which a LATER copy faulted on the GPU ("Memory access
+fault by GPU ... on address <a page of the host heap>", 5 of 48 and later 4 of 33 runs of the GPU suite).  Round 6: pageable memory
+(NYXHIP_MEM_HOST) goes through the library's own pinned staging ring, and the caller's pages are registered only on the caller's
+statement (NYXHIP_MEM_HOST_OWN_MAPPING: whole pages inside the array, rounded inward).  These tests drive the pattern that used to
+fault -- hundreds of calls alternating small heap arrays, large arrays and unaligned slices of larger arrays -- through the staging
+ring, and the same with mmap-backed stacks declared as such."""
 import numpy as np
 import pytest
 
@@ -28,10 +27,16 @@ def _labels(n, size, rng):
     return lab
 
 
-@pytest.mark.parametrize("pin_min", [None, "0"])
-def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, monkeypatch, pin_min):
-    if pin_min is not None:
-        monkeypatch.setenv("NYXHIP_PIN_MIN", pin_min)
+def _mmap_array(shape, dtype):
+    """A numpy array over an anonymous mapping of its own (page-aligned, never part of an allocator arena)."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    m = mmap.mmap(-1, max(n, 4096))
+    return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+@pytest.mark.parametrize("mode", ["staged", "own_mapping"])
+def test_host_path_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, mode):
     rng = np.random.default_rng(23)
     s = _abi.default_settings(8)
     # small: two 64 x 64 tiles (32 KB per array: heap-allocated, neighbours share pages)
@@ -48,6 +53,15 @@ def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, 
     sl_lab[:] = _labels(9, 512, rng)
     sl_int = big_i[3:3 + n_sl].reshape(9, 512, 512)
     assert sl_int.ctypes.data % 4096 != 0 and sl_lab.ctypes.data % 4096 != 0
+    own = [False, False, False]
+    if mode == "own_mapping":                       # the large stacks again as mappings of their own, declared; the unaligned slices of one too
+        lg_lab2 = _mmap_array(lg_lab.shape, np.uint32); lg_lab2[:] = lg_lab
+        lg_int2 = _mmap_array(lg_int.shape, np.uint32); lg_int2[:] = lg_int
+        lg_lab, lg_int = lg_lab2, lg_int2
+        big_l2 = _mmap_array(big_l.shape, np.uint32); big_l2[:] = big_l
+        big_i2 = _mmap_array(big_i.shape, np.uint32); big_i2[:] = big_i
+        sl_lab = big_l2[3:3 + n_sl].reshape(9, 512, 512); sl_int = big_i2[3:3 + n_sl].reshape(9, 512, 512)
+        own = [False, True, True]
     cases = [(sm_int, sm_lab), (lg_int, lg_lab), (sl_int, sl_lab)]
     first = [None, None, None]
     churn = []
@@ -61,7 +75,7 @@ def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, 
             assert len(labels) == 8 and np.isfinite(table[:, 0]).all()
             continue
         inten, lab = cases[k]
-        _t, labels, table = hip_ctx.featurize_tiles_host(inten, lab, MASK, s)
+        _t, labels, table = hip_ctx.featurize_tiles_host(inten, lab, MASK, s, own_mapping=own[k])
         if first[k] is None:
             first[k] = (labels.copy(), table.copy())
         else:
@@ -70,11 +84,10 @@ def test_pinning_survives_alternating_small_large_and_unaligned_arrays(hip_ctx, 
 
 
 @pytest.mark.parametrize("arenas", ["1", "64"])
-def test_pinning_under_other_arena_settings(arenas):
-    """The page rule of HostPin knows glibc's arenas by their shape; MALLOC_ARENA_MAX changes how many there are and where the
-    threshold-sized arrays land (1: everything in the program-break heap or mappings of its own; 64: up to 64 arenas with threads).
-    A fresh process per setting (the variable is read when the allocator starts) runs a short version of the stress loop, a thread
-    allocating beside it."""
+def test_host_path_under_other_arena_settings(arenas):
+    """The host path no longer looks at the allocator at all; MALLOC_ARENA_MAX changes where the arrays land (1: everything in the
+    program-break heap or mappings of its own; 64: up to 64 arenas with threads).  A fresh process per setting (the variable is read
+    when the allocator starts) runs a short version of the stress loop, a thread allocating beside it."""
     import os
     import subprocess
     import sys
@@ -108,7 +121,7 @@ finally:
 ctx.close()
 print("ok")
 """
-    env = dict(os.environ, MALLOC_ARENA_MAX=arenas, NYXHIP_PIN_MIN="0")
+    env = dict(os.environ, MALLOC_ARENA_MAX=arenas)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
