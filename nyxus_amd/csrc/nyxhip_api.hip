@@ -1509,6 +1509,13 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     //  40 % of their tiles, and the strips compute every tap in fp64 where the tiled kernel screens on the matrix pipe: not routed there.)
     if (lds) {
         for (SpillArgs* sp : {&a.sp, &t.sp, &g.sp, &d.sp}) { set_slots(*sp, list, grid); sp->class_mask = list ? 0u : class_mask; }
+        // the smallest size class (roi_class == 0) runs INTENSITY / GLCM a wave per ROI (roi_small.hip; launch_roi_features decides whether
+        // the settings allow it): its exact list, a whole-batch launch filtered to it, or a whole batch that IS it by the stated extrema
+        if (list ? cls == 0 : class_mask == 0x1u) a.small_class = 1;
+        else if (!list && class_mask == 0 && E.px <= kClassPx[0] && E.side <= kClassSide[0] && E.range < 16384u) a.small_class = 2;
+        // the two filtered feature launches of a call on stated extrema (launch_device_all): ONE GLCM feature launch, behind the second
+        if (!list && class_mask == 0x1u) a.glcm_feats = 1;
+        else if (!list && class_mask == 0x3FEu) a.glcm_feats = 2;
         // INTENSITY + GLCM at the reference's default grey depth (17..64 levels): two launches instead of one.  The 16-bit-matrix
         // kernel holds 43 KB of LDS per workgroup (three per CU); the intensity block inside it ran at that occupancy, 2.9 ms per
         // 196 k ROIs against 1.4 ms for the intensity-only build at eight workgroups per CU.  Each launch zeroes and fills its own
@@ -1760,6 +1767,15 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             if (mask & (kTexture | kDependence)) groups.push_back({-1, Eall, 0u, 2u | 8u});
             // feature kernels: one launch, no filter (both size classes run the same build; a contradicting ROI raises the error flag
             // in the kernel)
+            // ... except that the smallest size class has a kernel of its own (a wave per ROI, roi_small.hip) for INTENSITY and for
+            // GLCM counts under matlab binning with <= 16 levels: then two launches, each filtered to its classes
+            static const bool no_small = [] { const char* e = getenv("NYXHIP_NO_SMALL"); return e && *e && *e != '0'; }();   // A/B knob
+            const bool small_fits = !no_small && ((mask & NYXHIP_FAM_INTENSITY) || (!s->ibsi && s->grey_depth > 0 && s->grey_depth <= 16));
+            if ((mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) && has_m1 && small_fits) {
+                const uint32_t sd0 = std::min(max_side, kClassSide[0]);
+                groups.push_back({-2, Extrema{std::min(max_px, kClassPx[0]), std::min(max_area, sd0 * sd0), max_range, sd0}, 0x1u, 1u});
+                groups.push_back({-3, Eall, 0x3FEu, 1u});
+            } else
             if (mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) groups.push_back({-2, Eall, 0u, 1u});
             // shape kernels: one-wave builds for the smallest size class, four-wave builds for the other
             if (mask & kShape) {

@@ -2903,6 +2903,14 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiAr
     roi_features_body<false, true, false, true, 0, 9, true, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 
+// A launch that serves some classes only (SpillArgs::class_mask, whole-batch launches): is this ROI one of them?  (The feature kernels
+// derive the class from what they load anyway; the two kernels below would otherwise redo the other launch group's ROIs.)
+__device__ __forceinline__ bool glcm_roi_in_launch(const RoiArgs& A, uint64_t roi)
+{
+    if (A.sp.class_mask == 0) return true;
+    return roi_in_launch(A.sp, (uint32_t)(A.px_offset[roi + 1] - A.px_offset[roi]), A.bbox_w[roi], A.bbox_h[roi], A.max_inten[roi] - A.min_inten[roi]);
+}
+
 // ---- GLCM features of small matrices as their own launch -------------------------------------------------------------
 // One wave per ROI, the four angles in the wave's four DPP rows (glcm_features_rows<.., 16>), four ROIs per workgroup: every
 // lane of every wave works, where the same code inside roi_features_kernel leaves three of four waves waiting.  Input: the
@@ -2914,7 +2922,7 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
     uint64_t roi;
     if (!roi_of_slot(A.sp, (uint64_t)blockIdx.x * kWaves + wave, A.n_roi, roi))
         return;
-    const int Ng = (int)A.glcm_ng[roi];
+    const int Ng = glcm_roi_in_launch(A, roi) ? (int)A.glcm_ng[roi] : 0;
     if (Ng == 0)
         return;                                       // degenerate / skipped ROI: roi_features_kernel wrote the columns
     const int na = A.glcm_na, ngc = (int)A.L.ng_cap, NN = Ng * Ng;
@@ -2969,7 +2977,7 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs
     int Ng[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < 2; q++)
-        if (roi_of_slot(A.sp, slot0 + q, A.n_roi, roi[q])) Ng[q] = (int)A.glcm_ng[roi[q]];
+        if (roi_of_slot(A.sp, slot0 + q, A.n_roi, roi[q]) && glcm_roi_in_launch(A, roi[q])) Ng[q] = (int)A.glcm_ng[roi[q]];
     if (Ng[0] == 0 && Ng[1] == 0)
         return;                                       // degenerate / skipped ROIs: roi_features_kernel wrote the columns
     const int na = A.glcm_na, ngc = (int)A.L.ng_cap;
@@ -3152,15 +3160,23 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
     // dense8 is set by the host only together with the 16-bit tables and the split; an intensity-only launch never touches
     // the GLCM code, so it can run the fully compact build (and its 64-VGPR tier) as well
     const bool d8 = a.L.dense8 != 0 || (c16 && !(a.mask & NYXHIP_FAM_GLCM));
-    int rc = d8 ? launch_lds_variant<true, true, true>(a, st, grid)
+    // the smallest size class on its own kernel: a wave per ROI (roi_small.hip).  small_class: 1 = a list / filtered launch of class 0,
+    // 2 = a whole-batch launch whose stated extrema promise class 0 only
+    static const bool no_small = [] { const char* e = getenv("NYXHIP_NO_SMALL"); return e && *e && *e != '0'; }();   // A/B knob
+    int rc;
+    if (a.small_class && !no_small && (c16 || !(a.mask & NYXHIP_FAM_INTENSITY)) && roi_small_supported(a)) rc = launch_roi_small(a, st, grid, a.small_class == 2);
+    else
+    rc = d8 ? launch_lds_variant<true, true, true>(a, st, grid)
            : c16 ? (split ? launch_lds_variant<true, true, false>(a, st, grid) : launch_lds_variant<true, false, false>(a, st, grid))
                  : (split ? launch_lds_variant<false, true, false>(a, st, grid) : launch_lds_variant<false, false, false>(a, st, grid));
-    if (rc == 0 && split) {
+    if (rc == 0 && split && a.glcm_feats != 1) {
         static const bool no_pairs = [] { const char* e = getenv("NYXHIP_GLCM_NO_PAIRS"); return e && *e && *e != '0'; }();   // A/B knob
+        RoiArgs af = a;
+        if (a.glcm_feats == 2) af.sp.class_mask = 0;          // (the class-0 group of this call left its counts for this launch: everybody with a matrix order is derived)
         if (a.L.ng_cap <= 8 && !no_pairs)         // eight lanes per angle, two ROIs per wave
-            hipLaunchKernelGGL(glcm_features_kernel8, dim3((grid + 2 * kWaves - 1) / (2 * kWaves)), dim3(kBlock), glcm_features8_lds(a.L.ng_cap), st, a);
+            hipLaunchKernelGGL(glcm_features_kernel8, dim3((grid + 2 * kWaves - 1) / (2 * kWaves)), dim3(kBlock), glcm_features8_lds(a.L.ng_cap), st, af);
         else
-            hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, a);
+            hipLaunchKernelGGL(glcm_features_kernel, dim3((grid + kWaves - 1) / kWaves), dim3(kBlock), glcm_features_lds(a.L.ng_cap), st, af);
         rc = (int)hipGetLastError();
     }
     return rc;

@@ -155,6 +155,10 @@ struct RoiArgs {
     uint32_t* glcm_ws;       // [n_roi][glcm_ws_stride] counts, angle-major; NULL = features inside this kernel
     uint32_t* glcm_ng;       // [n_roi] matrix order of the ROI, 0 = nothing to derive (degenerate / skipped ROI)
     uint32_t glcm_ws_stride; // words per ROI = n_angles * ng_cap^2
+    uint32_t small_class;    // launch_roi_features: 1 = this launch serves class 0 (roi_class) through a list or a class filter, 2 = a whole-batch
+                             // launch whose stated extrema promise class 0 only -> the wave-per-ROI kernel of roi_small.hip; 0 = roi_features_kernel
+    uint32_t glcm_feats;     // split GLCM launches: 0 = glcm_features_kernel follows this launch over the same slots; 1 = not after this launch (the next
+                             // launch group of the call derives this group's ROIs as well); 2 = it follows over ALL slots, class filter off
     SpillArgs sp;
     WindowSrc win;
     LdsLayout L;
@@ -613,6 +617,8 @@ int launch_roi_wide(const WideArgs& a, void* stream);
 
 // implemented in roi_features.hip / roi_texture.hip / roi_shape.hip
 int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid);
+bool roi_small_supported(const RoiArgs& a);
+int launch_roi_small(const RoiArgs& a, void* stream, uint32_t n_slots, bool promised);
 int launch_roi_texture(const TexArgs& a, void* stream, uint32_t grid);
 int launch_roi_shape(const ShapeArgs& a, void* stream, uint32_t grid);
 int launch_roi_dependence(const DepArgs& a, void* stream, uint32_t grid);

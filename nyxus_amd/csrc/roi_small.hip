@@ -1,0 +1,580 @@
+// roi_small.hip -- INTENSITY + GLCM counts of the smallest size class (<= 256 pixels, box sides <= 32): a WAVE per ROI (round 6).
+//
+// The reference gives every ROI, whatever its size, to one worker thread (/root/reference/src/nyx/parallel.h:34-41;
+// features/intensity.cpp:57-192, histogram.h:27-309, moments.h:48-109; glcm.cpp:343-485).  roi_features_kernel spends a 256-thread
+// workgroup and ~1250 vector instructions per wave on an ROI whatever it holds -- a 49-pixel nucleus costs what a 2821-pixel disk costs
+// minus a third (7.4 against 12.4 ns): every phase has a fixed part (the 4096-entry counting table is scanned even for 49 values, every
+// exchange is a workgroup barrier) and a workgroup costs 1.1 ns of dispatch alone.  Here everything is proportional to the ROI:
+//   * four ROIs per workgroup, one per wave, no workgroup barrier anywhere (a wave's LDS block is its own);
+//   * the values (<= 4 per lane) are SORTED (bitonic network over the wave's LDS block) instead of counted into a table over [min, max]:
+//     the sorted array IS the cumulative table -- "pixels below offset d" is a lower bound, the median two reads, the mode the
+//     longest run;
+//   * the 100 + n histogram-bin lower bounds (histogram.h:55-78) are three binary searches per lane; percentiles, entropy, robust
+//     statistics follow intensity_table.h (intensity_from_table) line by line, wave sums instead of workgroup sums;
+//   * GLCM (matlab binning, <= 16 levels): the plane and the four Ng x Ng matrices in the wave's block, counts exported for
+//     glcm_features_kernel8 / glcm_features_kernel in the layout roi_features_kernel exports (angle-major, Ng^2 words per angle).
+// Integer-exact columns follow the reference operation by operation (MIN, MAX, RANGE, MEAN, ENERGY, INTEGRATED_INTENSITY, RMS, MEDIAN,
+// MODE, percentiles, IQR, QCOD, ROBUST_MEAN, PIU); the floating-point sums run in a fixed order that is a function of the ROI.
+// Which ROIs come here is a function of the ROI alone: roi_class(...) == 0 (the launcher routes that class; anybody else returns or
+// -- in a launch that was promised class 0 only -- raises the error flag).
+#include <hip/hip_runtime.h>
+#include "device_math.h"
+#include "roi_kernel.h"
+#include "glcm_rows.h"
+#include "launch_util.h"
+#include "../../include/nyxhip.h"
+
+namespace nyxhip {
+namespace {
+
+#ifdef NYX_SMALL_EXIT   // diagnostic builds (tools/small_exit_libs.sh): the per-ROI routine ends after phase NYX_SMALL_EXIT; results are wrong by design
+#define SMALL_EXIT(k) do { if ((k) == NYX_SMALL_EXIT) return; } while (0)
+#else
+#define SMALL_EXIT(k) do { } while (0)
+#endif
+constexpr int kSmallPx = 256;                // kClassPx[0]
+constexpr uint32_t kSmallArea = 32 * 32;     // kClassSide[0]^2
+
+// per-wave LDS block (bytes): sorted offsets u32[256] | lb100 u32[104] | lbc u32[nb + 8] | pq double[8] | plane u8[1024 + 8] | P u32[na * Ng * Ng]
+struct SmallBlock { uint32_t S, lb100, lbc, pq, plane, P, total; };
+__host__ __device__ inline SmallBlock small_block(uint32_t nb, uint32_t na, uint32_t ng, bool glcm)
+{
+    SmallBlock b;
+    uint32_t o = 0;
+    b.S = o; o += 4u * kSmallPx;
+    b.lb100 = o; o += 4u * 104;
+    b.lbc = o; o += 4u * (nb + 8);
+    o = (o + 7u) & ~7u;
+    b.pq = o; o += 8u * 8;
+    b.plane = o; o += glcm ? kSmallArea + 8 : 0;
+    o = (o + 15u) & ~15u;
+    b.P = o; o += glcm ? 4u * na * ng * ng : 0;
+    b.total = (o + 15u) & ~15u;
+    return b;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* S, uint32_t n, uint32_t key)   // first i in [0, n] with S[i] >= key
+{
+    uint32_t lo = 0, len = n;
+    while (len > 0) {
+        const uint32_t half = len >> 1, mid = lo + half;
+        if (S[mid] < key) { lo = mid + 1; len -= half + 1; } else len = half;
+    }
+    return lo;
+}
+
+// Bitonic sort of P2 (a power of two, 64 <= P2 <= 64 NV) keys held NV per lane, position e = NV * lane + k, ascending in e.
+// P2 < 64 NV: only lanes below P2 / NV take part meaningfully -- the caller loads the padding key into every position >= n, and the
+// positions >= P2 form sorted-by-construction padding that the network never mixes with the first P2 (bit tests only reach below P2).
+template <int NV>
+__device__ __forceinline__ void small_sort(uint32_t (&x)[NV], int lane, uint32_t P2)
+{
+    constexpr int SH = NV == 4 ? 2 : 0;                   // log2(NV)
+    for (uint32_t kk = 2; kk <= P2; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= (uint32_t)NV) {
+                const int m = (int)(j >> SH);             // partner lane = lane ^ m, same register
+                const bool lower = ((uint32_t)lane & (uint32_t)m) == 0;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const uint32_t y = (uint32_t)__shfl_xor((int)x[k], m, 64);
+                    const bool up = ((((uint32_t)lane << SH) | (uint32_t)k) & kk) == 0;
+                    const uint32_t lo = x[k] < y ? x[k] : y, hi = x[k] < y ? y : x[k];
+                    x[k] = (lower == up) ? lo : hi;
+                }
+            } else if constexpr (NV == 4) {
+                // distance 1 or 2 inside the lane's four keys (compile-time register pairs: a run-time register index would live in scratch)
+                auto cx = [&](uint32_t& a, uint32_t& b, int k) {
+                    const bool up = ((((uint32_t)lane << SH) | (uint32_t)k) & kk) == 0;
+                    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                    a = up ? lo : hi;
+                    b = up ? hi : lo;
+                };
+                if (j == 2) { cx(x[0], x[2], 0); cx(x[1], x[3], 1); }
+                else { cx(x[0], x[1], 0); cx(x[2], x[3], 2); }
+            }
+        }
+}
+
+constexpr uint32_t kSmallSlotsPerWave = 8;   // consecutive slots a wave serves, one after the other
+
+template <bool DO_INT, bool DO_GLCM>
+__device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot, unsigned char* const blk, const int lane, const uint32_t promised)
+{
+    uint64_t roi;
+    if (!roi_of_slot(A.sp, slot, A.n_roi, roi)) return;
+    const uint64_t off = A.px_offset[roi];
+    const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    if (n > (uint32_t)kSmallPx && !promised) return;                       // (a filtered launch over a batch of larger ROIs: two loads and out)
+    const uint32_t w = A.bbox_w[roi], h = A.bbox_h[roi];
+    const uint32_t vmin = A.min_inten[roi], vmax = A.max_inten[roi];
+    const uint32_t range = vmax - vmin;
+    double* const out_row = A.out + roi * A.ld;
+    if (roi_class(n, w, h, range) != 0) {
+        // not of this launch's class: served by the other launch of the call -- unless the caller's statement about the batch promised
+        // that there is no such ROI (whole-batch launch on stated extrema)
+        if (promised && n != 0) {
+            if (lane == 0) atomicCAS(A.status, 0, NYXHIP_ERR_ROI_TOO_LARGE);
+            for (int c = lane; c < A.n_cols; c += 64) out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        return;
+    }
+    if (!roi_in_launch(A.sp, n, w, h, range)) return;
+    const int na = A.glcm_na, Ng = A.ibsi ? 0 : A.grey_depth;
+    const uint32_t nb = (uint32_t)A.n_hist;
+    const SmallBlock B = small_block(nb, (uint32_t)na, DO_GLCM ? (uint32_t)Ng : 0u, DO_GLCM);
+    uint32_t* const S = (uint32_t*)(blk + B.S);
+    uint32_t* const lb100 = (uint32_t*)(blk + B.lb100);
+    uint32_t* const lbc = (uint32_t*)(blk + B.lbc);
+    double* const pq = (double*)(blk + B.pq);
+    uint8_t* const plane = (uint8_t*)(blk + B.plane);
+    uint32_t* const P = (uint32_t*)(blk + B.P);
+    if (n == 0) {
+        if (DO_GLCM && lane == 0 && A.glcm_ng) A.glcm_ng[roi] = 0;
+        for (int c = lane; c < A.n_cols; c += 64) out_row[c] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    for (int c = lane; c < A.n_cols; c += 64) out_row[c] = 0.0;           // features that are skipped stay 0 (every later store follows in wave order)
+    double* const o = out_row + (DO_INT ? A.col_intensity : 0);
+    const double dn = (double)n;
+
+    // ---- load: value k of a lane is pixel lane + 64 k ------------------------------------------------------------------------------
+    uint32_t v[4];
+    bool in[4];
+    const bool degenerate = DO_GLCM && bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth);   // glcm.cpp:27-95
+    const double mslope = Ng > 0 ? (double)Ng / ((double)vmax - 0.) : 0.0;
+    if (DO_GLCM && !degenerate) {
+        const uint32_t area = w * h;
+        for (uint32_t i = lane; i < (area + 8 + 3) / 4; i += 64) ((uint32_t*)plane)[i] = 0;        // (the block's plane region is 4-byte aligned)
+        for (int i = lane; i < na * Ng * Ng; i += 64) P[i] = 0;
+        wav_sync<false>();
+    }
+    unsigned long long tot_i = 0, totsq_i = 0;
+    const int rounds = (int)((n + 63u) >> 6);                              // rounds of 64 positions that hold a pixel (wave-uniform: the other trips of the k loops are skipped, not masked)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = (uint32_t)lane + 64u * k;
+        in[k] = false; v[k] = 0u;
+        if (k >= rounds) {
+            if (DO_INT && n > 64) S[i] = 0xFFFFFFFFu;                      // (padding of the four-keys-per-lane sort)
+            continue;
+        }
+        in[k] = i < n;
+        v[k] = in[k] ? A.inten[off + i] : 0u;
+        if (in[k]) {
+            const uint32_t sq = v[k] * v[k];                               // unsigned-int product, wraps (intensity.cpp:90)
+            tot_i += v[k] - vmin;                                          // (offsets: < 2^14 each, four per lane)
+            totsq_i += (unsigned long long)(sq & 0xFFFFu) | ((unsigned long long)(sq >> 16) << 32);   // low digits | high digits: < 2^18 each per lane
+            if (DO_GLCM && !degenerate) {
+                const uint32_t px = A.x[off + i], py = A.y[off + i];
+                // original-intensity 0 is skipped by the scan (glcm.cpp:445): level 0; else matlab binning (texture_feature.h:138-167)
+                const uint32_t lvl = v[k] ? bin_matlab(v[k], mslope, Ng) : 0u;
+                if (px < w && py < h) plane[py * w + px] = (uint8_t)lvl;
+            }
+        }
+        if (DO_INT) S[i] = in[k] ? v[k] - vmin : 0xFFFFFFFFu;              // (all 256 slots: the sort network runs over a power of two)
+    }
+    wav_sync<false>();
+    SMALL_EXIT(1);
+
+    if (DO_INT) {
+        // exact sums: sum v = n vmin + sum (v - vmin) (offsets below 2^14), sum of the wrapped squares as two 16-bit digit sums -- three
+        // 32-bit slots of ONE transposed reduction instead of two 64-bit butterflies
+        double tot, totsq;
+        {
+            uint32_t t8[8] = {(uint32_t)(tot_i), (uint32_t)(totsq_i & 0xFFFFFFFFull), (uint32_t)(totsq_i >> 32), 0u, 0u, 0u, 0u, 0u};
+            // (tot_i here is the lane's sum of OFFSETS and totsq_i its digit sums: see the load loop)
+            const uint32_t r = wave_transpose_sum8_u32(t8, lane);
+            const unsigned long long so = (uint32_t)__builtin_amdgcn_readlane((int)r, 0), lo = (uint32_t)__builtin_amdgcn_readlane((int)r, 8), hi = (uint32_t)__builtin_amdgcn_readlane((int)r, 16);
+            tot = (double)((unsigned long long)n * vmin + so);             // exact: < 2^41
+            totsq = (double)(lo + (hi << 16));
+        }
+        const bool blank = vmin == 0 && vmax == 0;                         // intensity.cpp:121-122
+        // The IEEE quotients of this block in ONE division, a lane each (an fp64 division is ~25 instructions whoever takes part):
+        //   lane 0 tot / n (mean, :95)   1 totsq / n (:98)   2 range / (max + min as unsigned int) (:162)   3 range / 100 (histogram.h:55)
+        //   4 range / (slide max - slide min) (:72-77)
+        double qn = 0.0, qd = 1.0;
+        if (lane == 0) { qn = tot; qd = dn; }
+        else if (lane == 1) { qn = totsq; qd = dn; }
+        else if (lane == 2) { qn = (double)(vmax - vmin); qd = (double)(uint32_t)(vmax + vmin); }
+        else if (lane == 3) { qn = (double)range; qd = 100.; }
+        else if (lane == 4 && A.slide_min && A.slide_max) { qn = (double)(vmax - vmin); qd = A.slide_max[roi] - A.slide_min[roi]; }
+        const double qq = qn / qd;
+        auto lane_d = [&](double x, int l) -> double {
+            const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+            return __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l)));
+        };
+        const double mean = lane_d(qq, 0);
+        if (lane == 0) {
+            o[I_MIN] = (double)vmin;                                       // intensity.cpp:67-69
+            o[I_MAX] = (double)vmax;
+            o[I_RANGE] = (double)vmax - (double)vmin;
+            o[I_MEAN] = mean;                                              // intensity.cpp:95-99
+            o[I_ENERGY] = totsq;
+            o[I_INTEGRATED_INTENSITY] = tot;
+        }
+        if (lane == 1) o[I_ROOT_MEAN_SQUARED] = sqrt(qq);
+        if (lane == 2 && !blank) o[I_UNIFORMITY_PIU] = (1.0 - qq) * 100.0;
+        if (lane == 4 && A.slide_min && A.slide_max) o[I_COVERED_IMAGE_INTENSITY_RANGE] = qq;
+        // ---- central sums (intensity.cpp:102-109, :177-183; M2..M4 of moments.h:53-74 equal the plain central sums) -------------------
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (!blank) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < rounds && in[k]) {
+                    const double d = (double)v[k] - mean, d2 = d * d;
+                    acc[0] += fabs(d); acc[1] += d2; acc[2] += d2 * d; acc[3] += d2 * d2; acc[4] += d2 * d2 * d; acc[5] += d2 * d2 * d2;
+                }
+            // one transposed wave reduction for the six sums (lane L ends up with slot (L >> 3) & 7), fetched by the lane that writes the outputs
+            double t8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], 0.0, 0.0};
+            const double tot8 = wave_transpose_sum8(t8, lane);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(tot8);
+                acc[k] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 8 * k) << 32) |
+                                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 8 * k)));
+            }
+        }
+        if (lane == 0) {
+            // everything that depends only on the central sums (intensity.cpp:110-118, :166-191, moments.h:79-109).  Tolerance-class outputs:
+            // the quotients and roots go through reciprocal / reciprocal-square-root estimates with two Newton steps (1-2 ulp) and are
+            // shared, as in roi_features_kernel's central_outputs -- ten IEEE divisions and five IEEE roots on one lane were a fifth of
+            // this kernel's instructions
+            const double var = acc[1];
+            const double inv_n = frcp(dn);
+            o[I_MEAN_ABSOLUTE_DEVIATION] = acc[0] * inv_n;
+            const double variance = dn > 1 ? var * frcp(dn - 1) : 0.0;
+            const double variance_b = dn > 1 ? var * inv_n : 0.0;
+            const double rsd = variance > 0 ? frsq(variance) : 0.0;       // 1 / sd (0 stands for "sd == 0": every use below tests it)
+            const double sd = variance * rsd;
+            const double rs_n = frsq(dn);
+            o[I_VARIANCE] = variance;
+            o[I_VARIANCE_BIASED] = variance_b;
+            o[I_STANDARD_DEVIATION] = sd;
+            o[I_STANDARD_DEVIATION_BIASED] = variance_b > 0 ? variance_b * frsq(variance_b) : 0.0;
+            o[I_COV] = mean != 0.0 ? fdiv(sd, mean) : sd / mean;           // (a zero mean must give the reference's inf / NaN: the IEEE quotient then)
+            o[I_STANDARD_ERROR] = sd * rs_n;
+            if (!blank) {
+                const double M2 = acc[1], M3 = acc[2], M4 = acc[3];
+                if (M2 != 0.0) {
+                    const double r = frsq(M2), r2 = r * r;                 // 1 / sqrt(M2), 1 / M2
+                    const double kurt = n > 4 ? (dn * M4) * (r2 * r2) : 0.0;
+                    o[I_SKEWNESS] = n > 3 ? ((dn * rs_n) * M3) * (r2 * r) : 0.0;   // sqrt(n) M3 / pow(M2, 1.5)
+                    o[I_KURTOSIS] = kurt;
+                    o[I_EXCESS_KURTOSIS] = n > 4 ? kurt - 3 : 0.0;
+                }
+                const double rsd2 = rsd * rsd, t5 = inv_n * (rsd2 * rsd2 * rsd);   // 1 / (n sd^5); a zero denominator gives 0 (intensity.cpp:186-191)
+                o[I_HYPERSKEWNESS] = acc[4] * t5;
+                o[I_HYPERFLATNESS] = acc[5] * (t5 * rsd);
+            }
+        }
+        SMALL_EXIT(2);
+        if (!blank) {
+            // ---- sort the offsets (padding = 0xFFFFFFFF sorts to the end): a bitonic network in REGISTERS -- position e = NV * lane + k,
+            // so the exchanges at distance 1, 2 (NV = 4) stay inside a lane and the others are one wave shuffle per register
+            if (n <= 64) {
+                uint32_t x1[1] = {S[lane]};
+                small_sort<1>(x1, lane, 64);
+                S[lane] = x1[0];
+            } else {
+                const uint4 q4 = *(const uint4*)(S + 4 * lane);                             // position e = 4 lane + k holds S[e]: the first n are the ROI's
+                uint32_t x4[4] = {q4.x, q4.y, q4.z, q4.w};
+                small_sort<4>(x4, lane, n <= 128 ? 128 : 256);
+                *(uint4*)(S + 4 * lane) = make_uint4(x4[0], x4[1], x4[2], x4[3]);
+            }
+            wav_sync<false>();
+            SMALL_EXIT(3);
+            // ---- histogram bin populations (histogram.h:55-78): lower bounds of the 100 percentile bins and the n custom bins ------------
+            const double binW100 = lane_d(qq, 3);                          // (double)range / 100.
+            if (n <= 64 && nb <= 64) {
+                // one value per lane: the reference's own bin function per pixel (two IEEE divisions), LDS counters, a wave scan -- a third of
+                // the three binary searches per lane below
+                for (uint32_t t = lane; t < 104 + nb + 8; t += 64) lb100[t] = 0;        // (lb100 | lbc are neighbours in the block)
+                wav_sync<false>();
+                if ((uint32_t)lane < n) {
+                    const uint32_t dd = S[lane];
+                    const double realIdx = (double)dd / binW100;           // (h - minVal) / binW100, histogram.h:57-60
+                    uint32_t i100 = (realIdx != realIdx) ? 0u : (uint32_t)(int)realIdx;
+                    i100 = i100 > 99u ? 99u : i100;                        // slot 100 is folded into 99 (:64-66)
+                    uint32_t ic = to_grayscale(vmin + dd, vmin, range, nb);
+                    ic = ic > nb - 1 ? nb - 1 : ic;                        // slot n is folded into n - 1 (:76-78)
+                    atomicAdd(&lb100[i100], 1u);
+                    atomicAdd(&lbc[ic], 1u);
+                }
+                wav_sync<false>();
+                const uint32_t c0 = lb100[lane], c1 = lane < 36 ? lb100[64 + lane] : 0u, cc = (uint32_t)lane < nb ? lbc[lane] : 0u;
+                const uint32_t s0 = wave_scan_u32(c0), s1 = wave_scan_u32(c1), sc = wave_scan_u32(cc);
+                const uint32_t tot0 = readlane63(s0);
+                wav_sync<false>();
+                lb100[lane] = s0 - c0;
+                if (lane < 36) lb100[64 + lane] = tot0 + s1 - c1;
+                if ((uint32_t)lane < nb) lbc[lane] = sc - cc;
+            } else
+            for (uint32_t t = lane; t < 100 + nb; t += 64) {
+                const bool is100 = t < 100;
+                const uint32_t b = is100 ? t : t - 100;
+                auto bin_of = [=](uint32_t dd) -> uint32_t {
+                    if (is100) {
+                        const double realIdx = (double)dd / binW100;       // (h - minVal) / binW100, histogram.h:57-60
+                        return (realIdx != realIdx) ? 0u : (uint32_t)(int)realIdx;
+                    }
+                    return to_grayscale(vmin + dd, vmin, range, nb);
+                };
+                // smallest offset d in [0, range + 1] whose bin index reaches b (intensity_table.h: the real-valued boundary settles it
+                // unless it lies within 1e-6 of an integer, where the exact bin function decides) -- range < 16384 in this class
+                const double Wl = is100 ? binW100 : (double)range / (double)nb;
+                const double Pb = (double)b * Wl;
+                const uint32_t mi = (uint32_t)(Pb + 0.5);
+                uint32_t d = (uint32_t)Pb + 1;
+                if (b == 0) d = 0;
+                else if (fabs(Pb - (double)mi) < 1e-6) d = bin_of(mi) >= b ? mi : mi + 1;
+                const uint32_t lo = lower_bound_u32(S, n, d);              // pixels with an offset below d
+                if (is100) lb100[b] = lo; else lbc[b] = lo;
+            }
+            wav_sync<false>();
+            SMALL_EXIT(4);
+            {
+                // percentiles P01, P10, P25, P75, P90, P99 (histogram.h:214-243): the LAST bin i with runSum_i <= cnt <= runSum_i + bins_i
+                // wins (every matching bin overwrites); runSum_i is the lower bound of bin i.  Lanes test bins i and i + 64.
+                const int i0 = lane, i1 = lane + 64;
+                const uint32_t r0 = lb100[i0], e0 = (i0 < 99 ? lb100[i0 + 1] : n);
+                const uint32_t r1 = i1 < 100 ? lb100[i1] : 0u, e1 = i1 < 100 ? (i1 < 99 ? lb100[i1 + 1] : n) : 0u;
+                int mywin = -1;
+                double mycnt = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double frac = q == 0 ? 0.01 : q == 1 ? 0.1 : q == 2 ? 0.25 : q == 3 ? 0.75 : q == 4 ? 0.9 : 0.99;
+                    const double cnt_p = dn * frac;
+                    const bool m0 = (double)r0 <= cnt_p && cnt_p <= (double)e0;
+                    const bool m1 = i1 < 100 && (double)r1 <= cnt_p && cnt_p <= (double)e1;
+                    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+                    const int win = b1 ? 64 + (63 - __clzll((long long)b1)) : (b0 ? 63 - __clzll((long long)b0) : -1);
+                    if (lane == q) { mywin = win; mycnt = cnt_p; }
+                }
+                double pv = 0;
+                if (mywin >= 0) {
+                    const uint32_t rs = lb100[mywin], bi = (mywin < 99 ? lb100[mywin + 1] : n) - rs;
+                    pv = (mycnt - (double)rs) * binW100 / (double)bi + (double)vmin + binW100 * (double)mywin;
+                }
+                if (lane < 6) pq[lane] = pv;
+                wav_sync<false>();
+            }
+            const double p10 = pq[1], p90 = pq[4];
+            if (lane == 0) {
+                o[I_P01] = pq[0]; o[I_P10] = pq[1]; o[I_P25] = pq[2]; o[I_P75] = pq[3]; o[I_P90] = pq[4]; o[I_P99] = pq[5];
+                o[I_QCOD] = (pq[3] - pq[2]) / (pq[3] + pq[2]);
+                o[I_INTERQUARTILE_RANGE] = pq[3] - pq[2];
+            }
+            {
+                // entropy / uniformity over the n + 1 slots (histogram.h:145-151): slot n is empty
+                double e = 0, u = 0;
+                for (uint32_t k = lane; k < nb; k += 64) {
+                    const uint32_t ck = (k < nb - 1 ? lbc[k + 1] : n) - lbc[k];
+                    const double p = fdiv((double)ck, dn);
+                    e += p * log2(p + 2.2e-16);
+                    u += p * p;
+                }
+                double t4[4] = {e, u, 0.0, 0.0};
+                const double tt = wave_transpose_sum4(t4);                 // lane L holds the total of slot (L >> 4) & 3
+                if (lane == 0) o[I_ENTROPY] = -tt;
+                if (lane == 16) o[I_UNIFORMITY] = tt;
+            }
+            SMALL_EXIT(5);
+            // median (histogram.h:268-287): order statistics n / 2 and n / 2 - 1 of the sorted array
+            const uint32_t hi_v = vmin + S[n / 2], lo_v = vmin + S[n / 2 ? n / 2 - 1 : 0];
+            const double median = (n & 1) ? (double)hi_v : (double)(uint32_t)(hi_v + lo_v) / 2.0;
+            // mode (histogram.h:289-309): the longest run of the sorted array, the smallest value on ties.  A run starts where a value differs
+            // from its predecessor; the start masks of the (up to four) rounds of 64 positions are ballots, and a start finds the next one
+            // in its own mask (shift + count trailing zeros) or -- scalar -- in the first later round that has one.
+            // key = length << 16 | (0xFFFF - position)
+            uint32_t best = 0;
+            {
+                unsigned long long sm[4] = {0, 0, 0, 0};
+                uint32_t xs[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k < rounds) {
+                        const uint32_t i = (uint32_t)lane + 64u * k;
+                        const bool valid = i < n;
+                        xs[k] = valid ? S[i] : 0u;
+                        const uint32_t pv = (valid && i > 0) ? S[i - 1] : 0xFFFFFFFEu;
+                        sm[k] = __ballot(valid && (i == 0 || pv != xs[k]));
+                    }
+                uint32_t nxt[5];                                           // nxt[k]: first start at or behind position 64 k (n when there is none)
+                nxt[4] = n;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) nxt[k] = sm[k] ? 64u * k + (uint32_t)__builtin_ctzll(sm[k]) : nxt[k + 1];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k < rounds) {
+                        const uint32_t i = (uint32_t)lane + 64u * k;
+                        if ((sm[k] >> lane) & 1ull) {
+                            const unsigned long long above = lane == 63 ? 0ull : sm[k] >> (lane + 1);
+                            const uint32_t next = above ? i + 1u + (uint32_t)__builtin_ctzll(above) : nxt[k + 1];
+                            const uint32_t key = ((next - i) << 16) | (0xFFFFu - i);
+                            best = key > best ? key : best;
+                        }
+                    }
+            }
+            best = wave_max_u32(best);
+            const uint32_t mode_v = vmin + S[0xFFFFu - (best & 0xFFFFu)];
+            SMALL_EXIT(6);
+            // ---- robust statistics over [p10, p90] (intensity.cpp:139-149, histogram.h:90-112) and the median deviation (:156-159) ------
+            uint32_t a0 = 1, z0 = 0;                                       // positions [a0, z0) inside the bounds: empty unless the bounds say otherwise (NaN: empty)
+            if (p10 <= p90 && p90 >= (double)vmin && p10 <= (double)vmax) {
+                const double cl = ceil(p10), fl = floor(p90);
+                const uint32_t lo_b = cl <= (double)vmin ? vmin : (uint32_t)cl, hi_b = fl >= (double)vmax ? vmax : (uint32_t)fl;
+                if (lo_b <= hi_b) {
+                    // pixels below a key = set bits of a ballot over the sorted keys (one compare per round instead of a binary search)
+                    const uint32_t ka = lo_b - vmin, kz = hi_b - vmin + 1u;
+                    a0 = 0; z0 = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (k < rounds) {
+                            const uint32_t i = (uint32_t)lane + 64u * k;
+                            const uint32_t key = i < n ? S[i] : 0xFFFFFFFFu;
+                            a0 += (uint32_t)__popcll(__ballot(key < ka));
+                            z0 += (uint32_t)__popcll(__ballot(key < kz));
+                        }
+                }
+            }
+            const uint32_t K = z0 > a0 ? z0 - a0 : 0u;
+            unsigned long long sx = 0;
+            double medad = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = (uint32_t)lane + 64u * k;
+                if (k < rounds && i < n) {
+                    const uint32_t val = vmin + S[i];
+                    if (K && i >= a0 && i < z0) sx += val;
+                    medad += fabs((double)val - median);
+                }
+            }
+            sx = wave_sum_u64(sx);
+            medad = wave_sum(medad);
+            const double mean1090 = K ? (double)sx / (double)K : 0.0;
+            double ad = 0;
+            if (K) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = (uint32_t)lane + 64u * k;
+                    if (k < rounds && i >= a0 && i < z0) ad += fabs((double)(vmin + S[i]) - mean1090);
+                }
+                ad = wave_sum(ad);
+            }
+            if (lane == 0) {
+                o[I_MEDIAN] = median;
+                o[I_MODE] = (double)mode_v;
+                o[I_ROBUST_MEAN] = mean1090;
+                o[I_ROBUST_MEAN_ABSOLUTE_DEVIATION] = K ? fdiv(ad, (double)K) : 0.0;
+                o[I_MEDIAN_ABSOLUTE_DEVIATION] = fdiv(medad, dn);
+            }
+        }
+    }
+
+    SMALL_EXIT(7);
+    if (DO_GLCM) {
+        double* const og = out_row + A.col_glcm;
+        if (lane == 0 && A.glcm_ng) A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
+        if (degenerate) {
+            for (int c = lane; c < kGlcmAngled * na + kGlcmAve; c += 64) og[c] = A.soft_nan;
+            return;
+        }
+        // co-occurrence counts (glcm.cpp:343-485): centre b at (row, col), neighbour a at (row + dy, col + dx); pairs with a level-0
+        // member are skipped; the matrix is indexed (centre - 1, neighbour - 1); symmetric counts add the transposed cell too
+        const uint32_t area = w * h;
+        const int d = A.glcm_offset;
+        const bool symmetric = A.glcm_symmetric != 0;
+        for (uint32_t p = lane; p < area; p += 64) {
+            const uint32_t lb = plane[p];
+            if (lb == 0) continue;
+            const int row = (int)(p / w), col = (int)(p - (uint32_t)row * w);
+            for (int q = 0; q < na; q++) {
+                const int ang = A.glcm_angles[q];                          // glcm.cpp:234-255
+                const int dx = ang == 90 ? 0 : ang == 135 ? -d : d, dy = ang == 0 ? 0 : d;
+                const int r2 = row + dy, c2 = col + dx;
+                if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w) continue;
+                const uint32_t la = plane[(uint32_t)r2 * w + (uint32_t)c2];
+                if (la == 0) continue;
+                atomicAdd(&P[q * Ng * Ng + ((int)lb - 1) * Ng + (int)la - 1], 1u);
+                if (symmetric) atomicAdd(&P[q * Ng * Ng + ((int)la - 1) * Ng + (int)lb - 1], 1u);
+            }
+        }
+        wav_sync<false>();
+        uint32_t* const dst = A.glcm_ws + roi * A.glcm_ws_stride;
+        for (int i = lane; i < na * Ng * Ng; i += 64) dst[i] = P[i];
+    }
+}
+
+// SCAN = false: every slot of the launch is an ROI of this class (its exact list, or a whole batch that is class 0 by the caller's statement):
+// a wave per slot.  SCAN = true: a whole-batch launch FILTERED to class 0 -- over a batch that may hold none (the metric configuration:
+// 196 000 ROIs of 2821 pixels), which must cost next to nothing: a wave takes eight consecutive slots, reads their nine CSR offsets in
+// one load and is gone when none of the eight has <= 256 pixels (a wave per slot cost the headline 2 %, this form 0.7 %); the ROIs it
+// does find it serves one after the other (as a loop body the per-ROI code keeps every kernel argument alive across the loop: 116
+// registers instead of 58 -- slower per ROI, which is why the unfiltered launches keep the other form).
+template <bool DO_INT, bool DO_GLCM, bool SCAN>
+__global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const blk = small_lds + (size_t)wave * wave_bytes;
+    if (!SCAN) {
+        small_one<DO_INT, DO_GLCM>(A, (uint64_t)blockIdx.x * 4u + (uint32_t)wave, blk, lane, promised);
+        return;
+    }
+    const uint64_t slot0 = ((uint64_t)blockIdx.x * 4u + (uint32_t)wave) * kSmallSlotsPerWave;
+    if (!A.sp.roi_index) {
+        const uint64_t i = slot0 + (uint32_t)lane;
+        const uint64_t po = (lane <= (int)kSmallSlotsPerWave && i <= A.n_roi) ? A.px_offset[i] : 0;
+        const uint64_t nx = (uint64_t)__shfl_down((long long)po, 1, 64);
+        const bool cand = lane < (int)kSmallSlotsPerWave && i < A.n_roi && nx - po <= (uint64_t)kSmallPx;
+        if (!__ballot(cand)) return;
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; k < kSmallSlotsPerWave; k++) {
+        small_one<DO_INT, DO_GLCM>(A, slot0 + k, blk, lane, promised);
+        wav_sync<false>();                                               // (the block is the next ROI's)
+    }
+}
+
+} // namespace
+
+// Can the wave-per-ROI kernel serve this launch's family set and settings?  (INTENSITY with the 16-bit-table conditions of its class,
+// GLCM only as the split launch of matlab binning with <= 16 levels -- what roi_features_kernel_occ8's compile-time family sets cover.)
+bool roi_small_supported(const RoiArgs& a)
+{
+    if (a.sp.scratch || a.win.inten) return false;
+    const bool do_int = a.mask & NYXHIP_FAM_INTENSITY, do_glcm = a.mask & NYXHIP_FAM_GLCM;
+    if (a.mask & ~(uint32_t)(NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) return false;
+    if (!do_int && !do_glcm) return false;
+    if (do_glcm && !(a.glcm_ws != nullptr && a.glcm_ng != nullptr && !a.ibsi && a.grey_depth > 0 && a.grey_depth <= 16 && a.glcm_na >= 1 && a.glcm_na <= kMaxAngles))
+        return false;
+    if (do_int && (a.n_hist < 1 || a.n_hist > 1024)) return false;              // (the bin bounds sit in the wave's LDS block)
+    return true;
+}
+
+int launch_roi_small(const RoiArgs& a, void* stream, uint32_t n_slots, bool promised)
+{
+    if (n_slots == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool do_int = a.mask & NYXHIP_FAM_INTENSITY, do_glcm = a.mask & NYXHIP_FAM_GLCM;
+    const SmallBlock B = small_block((uint32_t)a.n_hist, (uint32_t)a.glcm_na, do_glcm ? (uint32_t)a.grey_depth : 0u, do_glcm);
+    const uint32_t lds = 4u * B.total;
+    const bool scan = !promised && a.sp.roi_index == nullptr;           // a filtered whole-batch launch: the batch may hold no ROI of the class
+    const uint32_t per_wg = scan ? 4 * kSmallSlotsPerWave : 4;
+    const dim3 grid((n_slots + per_wg - 1) / per_wg);
+    const uint32_t pr = promised ? 1u : 0u;
+#define NYX_SMALL_LAUNCH(I, G)                                                                                              \
+    do {                                                                                                                    \
+        if (scan) hipLaunchKernelGGL((roi_small_kernel<I, G, true>), grid, dim3(256), lds, st, a, B.total, pr);            \
+        else hipLaunchKernelGGL((roi_small_kernel<I, G, false>), grid, dim3(256), lds, st, a, B.total, pr);                \
+    } while (0)
+    if (do_int && do_glcm) NYX_SMALL_LAUNCH(true, true);
+    else if (do_int) NYX_SMALL_LAUNCH(true, false);
+    else NYX_SMALL_LAUNCH(false, true);
+#undef NYX_SMALL_LAUNCH
+    return (int)hipGetLastError();
+}
+
+} // namespace nyxhip

@@ -831,7 +831,13 @@ def test_grey_depth_64_split_launch_equals_fused(hip_ctx, monkeypatch):
     split = hip_ctx.featurize_host(b, MASK, s)
     monkeypatch.setenv("NYXHIP_G16_FUSED", "1")
     fused = hip_ctx.featurize_host(b, MASK, s)
-    assert np.array_equal(split.view(np.uint64), fused.view(np.uint64))
+    # (round 6: in the split form the INTENSITY columns of the smallest size class come from the wave-per-ROI kernel -- another fixed
+    #  summation order -- so those rows agree within the parity tolerance, everybody else bit for bit)
+    n_px = np.diff(np.asarray(b.px_offset).astype(np.int64))
+    side = np.maximum(np.asarray(b.bbox_w), np.asarray(b.bbox_h))
+    small = (n_px <= 256) & (side <= 32)
+    assert np.array_equal(split[~small].view(np.uint64), fused[~small].view(np.uint64))
+    assert small.any() and not parity.compare_tables(split[small], fused[small], _lib.column_names(MASK, s))
 
 
 def test_contour_wide_boxes_take_the_position_wise_pass(hip_ctx):

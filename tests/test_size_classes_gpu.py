@@ -77,10 +77,11 @@ def test_launch_report_of_a_hinted_batch_of_small_rois(hip_ctx):
     s = _abi.default_settings(8)
     hip_ctx.featurize_host(b, MASK, s)
     rep = hip_ctx.launch_report()
-    assert len(rep) == 1 and rep[0]["class"] == -2 and rep[0]["rois"] == 196 and rep[0]["workspace"] == 0, rep
+    # (round 6: two feature launches on stated extrema beyond the smallest class -- the wave-per-ROI kernel filtered to class 0, then everybody else)
+    assert [r["class"] for r in rep] == [-2, -3] and all(r["rois"] == 196 and r["workspace"] == 0 for r in rep), rep
     rois = synth.random_rois(40, seed=3, rmax=20, value_modes=(4096, 256, 8))         # both shape builds (one-wave for the smallest class)
     hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK | _abi.FAM_ZERNIKE | _abi.FAM_GLSZM, s)
-    assert sorted(r["class"] for r in hip_ctx.launch_report()) == [-5, -4, -2, -1]
+    assert sorted(r["class"] for r in hip_ctx.launch_report()) == [-5, -4, -3, -2, -1]
     rois = synth.random_rois(40, seed=3, rmax=20)                     # value modes up to 2^32 - 1: wide ranges are possible -> exact classes
     hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK, s)
     assert all(r["class"] >= 0 for r in hip_ctx.launch_report()) and any(r["wide_range"] == 1 for r in hip_ctx.launch_report())
@@ -164,3 +165,75 @@ def test_two_gpus_bench_and_sharded_api_agree_with_one():
     one = nyxus_amd.Nyxus(feats, coarse_gray_depth=8).featurize(I, M)
     two = nyxus_amd.Nyxus(feats, coarse_gray_depth=8, gpu_devices=[0, 1]).featurize(I, M)
     assert one.equals(two)
+
+
+# ---- the smallest size class on its own kernel: a wave per ROI (roi_small.hip, round 6) -------------------------------------------------
+def _small_rois(seed, hi=4096):
+    """ROIs of the smallest size class (<= 256 px, sides <= 32) around every boundary the wave-per-ROI kernel has: 1, 2, 63, 64, 65, 127, 128,
+    129, 255, 256 pixels (one / four keys per lane, the three sort widths), zeros, constants, a blank ROI, two values only, ties at the
+    percentile boundaries, thin strips, and shapes with holes."""
+    rng = np.random.default_rng(seed)
+    rois = []
+    for n in (1, 2, 3, 5, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256):
+        w = int(min(32, max(1, np.ceil(np.sqrt(n)))))
+        h = int(np.ceil(n / w))
+        if h > 32:
+            w, h = 32, int(np.ceil(n / 32))
+        yy, xx = np.divmod(np.arange(n), w)
+        rois.append(dict(x=xx, y=yy, inten=rng.integers(0 if n % 3 == 0 else 1, hi, n).astype(np.uint32)))
+    for r in (3, 4, 6, 8, 9):
+        rois.append(ellipse_roi(r, r, rng, hi=hi))
+        rois.append(ellipse_roi(r, max(2, r - 2), rng, hi=hi, lo=0, holes=0.15))
+    c = ellipse_roi(6, 5, rng); c["inten"][:] = 1234; rois.append(c)                       # constant
+    z = ellipse_roi(5, 5, rng); z["inten"][:] = 0; rois.append(z)                          # blank
+    t = ellipse_roi(8, 7, rng); t["inten"][:] = np.where(np.arange(len(t["inten"])) % 2, 10, 3000); rois.append(t)   # two values
+    q = ellipse_roi(7, 7, rng); q["inten"][:] = (np.arange(len(q["inten"])) // 4 * 25 + 100).astype(np.uint32); rois.append(q)   # ties
+    rois.append(dict(x=np.arange(32), y=np.zeros(32, int), inten=rng.integers(1, hi, 32).astype(np.uint32)))           # a row
+    rois.append(dict(x=np.zeros(30, int), y=np.arange(30), inten=rng.integers(1, 300, 30).astype(np.uint32)))          # a column
+    rois.append(dict(x=[0], y=[0], inten=[7]))
+    return rois
+
+
+@pytest.mark.parametrize("mask", [1, 2, 3])
+@pytest.mark.parametrize("gd,hi", [(8, 4096), (8, 256), (16, 16000), (3, 50), (64, 4096)])
+def test_smallest_class_matches_oracle(hip_ctx, mask, gd, hi):
+    """Every ROI of the batch is of class 0: a whole-batch launch of the wave-per-ROI kernel on stated extrema (grey depth 64: its INTENSITY
+    half only -- the GLCM half stays with the 64-level kernel)."""
+    s = _abi.default_settings(gd)
+    b = _abi.batch_from_rois(_small_rois(gd + hi, hi=hi))
+    G = hip_ctx.featurize_host(b, mask, s)
+    O = po.oracle_featurize(b, mask, s)
+    bad = parity.compare_tables(G, O, _lib.column_names(mask, s), batch=b)
+    assert not bad, "\\n".join(bad[:20])
+
+
+def test_smallest_class_rows_do_not_depend_on_companions_or_options(hip_ctx):
+    """A class-0 row is the same alone, among larger companions (filtered whole-batch launches / exact lists), with other families in
+    the call, with slide extrema given -- and symmetric counts, angle subsets, other offsets match the oracle."""
+    rng = np.random.default_rng(77)
+    small = _small_rois(5)
+    s = _abi.default_settings(8)
+    alone = hip_ctx.featurize_host(_abi.batch_from_rois(small), 3, s)
+    mid = [ellipse_roi(int(rng.integers(12, 30)), int(rng.integers(12, 30)), rng) for _ in range(12)]          # size class 1
+    big = [ellipse_roi(90, 70, rng)]                                                                            # a class that forces the exact path
+    for others in (mid, mid + big):
+        mixed = []
+        for i, r in enumerate(small):
+            mixed.append(r)
+            if i < len(others): mixed.append(others[i])
+        idx = [i for i, r in enumerate(mixed) if any(r is q for q in small)]
+        bm = _abi.batch_from_rois(mixed)
+        for m in (3, 3 | _abi.FAM_GLRLM | _abi.FAM_ZERNIKE):
+            T = hip_ctx.featurize_host(bm, m, s)
+            names = _lib.column_names(m, s)
+            keep = [i for i, nme in enumerate(names) if nme in _lib.column_names(3, s)]
+            assert np.array_equal(T[idx][:, keep].view(np.uint64), alone.view(np.uint64))
+            bad = parity.compare_tables(T, po.oracle_featurize(bm, m, s), names, batch=bm)
+            assert not bad, "\\n".join(bad[:10])
+    for sym, angles, offset in ((1, (0, 45, 90, 135), 1), (0, (45, 135), 1), (1, (90,), 2), (0, (0, 45, 90, 135), 3)):
+        s2 = _abi.default_settings(8)
+        s2.glcm_symmetric = sym; s2.glcm_offset = offset; s2.glcm_n_angles = len(angles)
+        for i, a in enumerate(angles): s2.glcm_angles[i] = a
+        b = _abi.batch_from_rois(small)
+        bad = parity.compare_tables(hip_ctx.featurize_host(b, 3, s2), po.oracle_featurize(b, 3, s2), _lib.column_names(3, s2), batch=b)
+        assert not bad, "\\n".join(bad[:10])
