@@ -35,7 +35,8 @@ namespace {
 constexpr int kSmallPx = 256;                // kClassPx[0]
 constexpr uint32_t kSmallArea = 32 * 32;     // kClassSide[0]^2
 
-// per-wave LDS block (bytes): sorted offsets u32[256] | lb100 u32[104] | lbc u32[nb + 8] | pq double[8] | plane u8[1024 + 8] | P u32[na * Ng * Ng]
+// per-wave LDS block (bytes): sorted offsets u32[256] | lb100 u32[104] | lbc u32[nb + 8] | pq double[8] | plane u8[(32 + 2) x 33 + 6] | P u32[na * Ng * Ng]
+// (the plane carries a zero column on either side and a zero row below: the four neighbours of the usual request need no bounds test)
 struct SmallBlock { uint32_t S, lb100, lbc, pq, plane, P, total; };
 __host__ __device__ inline SmallBlock small_block(uint32_t nb, uint32_t na, uint32_t ng, bool glcm)
 {
@@ -46,7 +47,7 @@ __host__ __device__ inline SmallBlock small_block(uint32_t nb, uint32_t na, uint
     b.lbc = o; o += 4u * (nb + 8);
     o = (o + 7u) & ~7u;
     b.pq = o; o += 8u * 8;
-    b.plane = o; o += glcm ? kSmallArea + 8 : 0;
+    b.plane = o; o += glcm ? 34 * 33 + 6 : 0;
     o = (o + 15u) & ~15u;
     b.P = o; o += glcm ? 4u * na * ng * ng : 0;
     b.total = (o + 15u) & ~15u;
@@ -145,34 +146,71 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
     const double mslope = Ng > 0 ? (double)Ng / ((double)vmax - 0.) : 0.0;
     if (DO_GLCM && !degenerate) {
         const uint32_t area = w * h;
-        for (uint32_t i = lane; i < (area + 8 + 3) / 4; i += 64) ((uint32_t*)plane)[i] = 0;        // (the block's plane region is 4-byte aligned)
+        for (uint32_t i = lane; i < ((w + 2) * (h + 1) + 3) / 4; i += 64) ((uint32_t*)plane)[i] = 0;   // (the block's plane region is 4-byte aligned)
         for (int i = lane; i < na * Ng * Ng; i += 64) P[i] = 0;
         wav_sync<false>();
     }
     unsigned long long tot_i = 0, totsq_i = 0;
     const int rounds = (int)((n + 63u) >> 6);                              // rounds of 64 positions that hold a pixel (wave-uniform: the other trips of the k loops are skipped, not masked)
+    // original-intensity 0 is skipped by the co-occurrence scan (glcm.cpp:445): level 0; else matlab binning (texture_feature.h:138-167)
+    auto level_of = [&](uint32_t val) -> uint32_t { return val ? bin_matlab(val, mslope, Ng) : 0u; };
+    const bool from_window = A.win.inten != nullptr;
+    if (from_window) {
+        // ---- window mode (fused tile path): the ROI's pixels are the cells of its bounding-box window of the tile whose label matches,
+        // in row-major order -- the order roi_cloud_kernel gives the cloud, so position i here is position i there and everything
+        // behind the load is bit-identical with the cloud path.  Two rows of the (<= 32 wide) window per step, ranks by ballot.
+        const uint32_t L = A.win.label[roi], x0 = A.win.x0[roi], y0 = A.win.y0[roi];
+        const int dtl = A.win.dt_label, dti = A.win.dt_inten;
+        const uint64_t tile_px = (uint64_t)A.win.H * A.win.W, t0 = (uint64_t)A.win.tile[roi] * tile_px;
+        const char* const labp = (const char*)A.win.lab + t0 * (uint64_t)dtl;
+        const char* const intp = (const char*)A.win.inten + t0 * (uint64_t)dti;
+        auto ld = [](const char* p, uint64_t i, int dt) -> uint32_t {
+            return dt == 4 ? ((const uint32_t*)p)[i] : dt == 2 ? (uint32_t)((const uint16_t*)p)[i] : (uint32_t)((const uint8_t*)p)[i];
+        };
+        if (DO_INT) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) S[(uint32_t)lane + 64u * k] = 0xFFFFFFFFu;
+            wav_sync<false>();
+        }
+        const uint32_t rr = (uint32_t)lane >> 5, cc = (uint32_t)lane & 31u;
+        uint32_t base = 0;
+        for (uint32_t r = 0; r < h; r += 2) {
+            const uint32_t row = r + rr;
+            const bool valid = cc < w && row < h;
+            const uint64_t e = (uint64_t)(y0 + row) * A.win.W + x0 + cc;
+            const uint32_t lb = valid ? ld(labp, e, dtl) : 0u, vv = valid ? ld(intp, e, dti) : 0u;
+            const bool mem = valid && lb == L;
+            const unsigned long long bal = __ballot(mem);
+            const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (mem && rank < n) {
+                if (DO_INT) S[rank] = vv - vmin;
+                if (DO_GLCM && !degenerate) plane[row * (w + 2) + cc + 1] = (uint8_t)level_of(vv);
+            }
+            base += (uint32_t)__popcll(bal);
+        }
+        wav_sync<false>();
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t i = (uint32_t)lane + 64u * k;
         in[k] = false; v[k] = 0u;
         if (k >= rounds) {
-            if (DO_INT && n > 64) S[i] = 0xFFFFFFFFu;                      // (padding of the four-keys-per-lane sort)
+            if (DO_INT && n > 64 && !from_window) S[i] = 0xFFFFFFFFu;      // (padding of the four-keys-per-lane sort)
             continue;
         }
         in[k] = i < n;
-        v[k] = in[k] ? A.inten[off + i] : 0u;
+        if (from_window) v[k] = (DO_INT && in[k]) ? vmin + S[i] : 0u;
+        else v[k] = in[k] ? A.inten[off + i] : 0u;
         if (in[k]) {
             const uint32_t sq = v[k] * v[k];                               // unsigned-int product, wraps (intensity.cpp:90)
             tot_i += v[k] - vmin;                                          // (offsets: < 2^14 each, four per lane)
             totsq_i += (unsigned long long)(sq & 0xFFFFu) | ((unsigned long long)(sq >> 16) << 32);   // low digits | high digits: < 2^18 each per lane
-            if (DO_GLCM && !degenerate) {
+            if (DO_GLCM && !degenerate && !from_window) {
                 const uint32_t px = A.x[off + i], py = A.y[off + i];
-                // original-intensity 0 is skipped by the scan (glcm.cpp:445): level 0; else matlab binning (texture_feature.h:138-167)
-                const uint32_t lvl = v[k] ? bin_matlab(v[k], mslope, Ng) : 0u;
-                if (px < w && py < h) plane[py * w + px] = (uint8_t)lvl;
+                if (px < w && py < h) plane[py * (w + 2) + px + 1] = (uint8_t)level_of(v[k]);
             }
         }
-        if (DO_INT) S[i] = in[k] ? v[k] - vmin : 0xFFFFFFFFu;              // (all 256 slots: the sort network runs over a power of two)
+        if (DO_INT && !from_window) S[i] = in[k] ? v[k] - vmin : 0xFFFFFFFFu;   // (the sort network runs over a power of two)
     }
     wav_sync<false>();
     SMALL_EXIT(1);
@@ -483,19 +521,36 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
         }
         // co-occurrence counts (glcm.cpp:343-485): centre b at (row, col), neighbour a at (row + dy, col + dx); pairs with a level-0
         // member are skipped; the matrix is indexed (centre - 1, neighbour - 1); symmetric counts add the transposed cell too
-        const uint32_t area = w * h;
+        const uint32_t area = w * h, pitch = w + 2;
         const int d = A.glcm_offset;
         const bool symmetric = A.glcm_symmetric != 0;
+        const bool usual = na == 4 && d == 1 && !symmetric && A.glcm_angles[0] == 0 && A.glcm_angles[1] == 45 && A.glcm_angles[2] == 90 && A.glcm_angles[3] == 135;
+        if (usual) {
+            // four angles at distance 1, asymmetric counts: E, SE, S, SW of every cell straight from the padded plane
+            const int NN = Ng * Ng;
+            for (uint32_t p = lane; p < area; p += 64) {
+                const uint32_t row = p / w, col = p - row * w;
+                const uint8_t* const c = plane + row * pitch + col + 1;
+                const uint32_t lb = c[0];
+                if (lb == 0) continue;
+                const uint32_t e = c[1], se = c[pitch + 1], so = c[pitch], sw = c[pitch - 1];
+                uint32_t* const Pr = P + (lb - 1) * (uint32_t)Ng - 1;
+                if (e) atomicAdd(Pr + e, 1u);
+                if (se) atomicAdd(Pr + NN + se, 1u);
+                if (so) atomicAdd(Pr + 2 * NN + so, 1u);
+                if (sw) atomicAdd(Pr + 3 * NN + sw, 1u);
+            }
+        } else
         for (uint32_t p = lane; p < area; p += 64) {
-            const uint32_t lb = plane[p];
-            if (lb == 0) continue;
             const int row = (int)(p / w), col = (int)(p - (uint32_t)row * w);
+            const uint32_t lb = plane[(uint32_t)row * pitch + (uint32_t)col + 1];
+            if (lb == 0) continue;
             for (int q = 0; q < na; q++) {
                 const int ang = A.glcm_angles[q];                          // glcm.cpp:234-255
                 const int dx = ang == 90 ? 0 : ang == 135 ? -d : d, dy = ang == 0 ? 0 : d;
                 const int r2 = row + dy, c2 = col + dx;
                 if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w) continue;
-                const uint32_t la = plane[(uint32_t)r2 * w + (uint32_t)c2];
+                const uint32_t la = plane[(uint32_t)r2 * pitch + (uint32_t)c2 + 1];
                 if (la == 0) continue;
                 atomicAdd(&P[q * Ng * Ng + ((int)lb - 1) * Ng + (int)la - 1], 1u);
                 if (symmetric) atomicAdd(&P[q * Ng * Ng + ((int)la - 1) * Ng + (int)lb - 1], 1u);
@@ -544,7 +599,7 @@ __global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const u
 // GLCM only as the split launch of matlab binning with <= 16 levels -- what roi_features_kernel_occ8's compile-time family sets cover.)
 bool roi_small_supported(const RoiArgs& a)
 {
-    if (a.sp.scratch || a.win.inten) return false;
+    if (a.sp.scratch) return false;
     const bool do_int = a.mask & NYXHIP_FAM_INTENSITY, do_glcm = a.mask & NYXHIP_FAM_GLCM;
     if (a.mask & ~(uint32_t)(NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) return false;
     if (!do_int && !do_glcm) return false;
