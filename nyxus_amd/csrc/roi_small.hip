@@ -18,6 +18,7 @@
 // Which ROIs come here is a function of the ROI alone: roi_class(...) == 0 (the launcher routes that class; anybody else returns or
 // -- in a launch that was promised class 0 only -- raises the error flag).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "glcm_rows.h"
@@ -97,7 +98,41 @@ __device__ __forceinline__ void small_sort(uint32_t (&x)[NV], int lane, uint32_t
         }
 }
 
-constexpr uint32_t kSmallSlotsPerWave = 8;   // consecutive slots a wave serves, one after the other
+
+// The same network for four keys per lane held as TWO registers of packed 16-bit keys (offsets from the ROI minimum are below 2^14 in this
+// class; padding 0xFFFF): r0 = k0 | k1 << 16, r1 = k2 | k3 << 16, position e = 4 lane + k.  A lane-crossing exchange is one shuffle and a
+// v_pk_min_u16 / v_pk_max_u16 pair per register (both keys of a register share direction and side once kk >= 8), distance 2 is
+// element-wise between the two registers, distance 1 a half-swap inside a register: ~300 vector instructions for 256 keys instead of ~750.
+typedef unsigned short small_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmin16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(small_us2, a), __builtin_bit_cast(small_us2, b))); }
+__device__ __forceinline__ uint32_t pkmax16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(small_us2, a), __builtin_bit_cast(small_us2, b))); }
+__device__ __forceinline__ void small_sort4_packed(uint32_t& r0, uint32_t& r1, int lane, uint32_t P2)
+{
+    // distance 1 inside a register: (lo, hi) -> (min, max) when `up`, (max, min) otherwise
+    auto cx1 = [](uint32_t r, bool up) -> uint32_t {
+        const uint32_t sw = (r >> 16) | (r << 16);
+        const uint32_t mn = pkmin16(r, sw), mx = pkmax16(r, sw);           // both halves hold the min / the max
+        const uint32_t a = up ? mn : mx, b = up ? mx : mn;
+        return (a & 0xFFFFu) | (b & 0xFFFF0000u);
+    };
+    // kk = 2: positions 0, 1 ascending, positions 2, 3 descending
+    r0 = cx1(r0, true); r1 = cx1(r1, false);
+    for (uint32_t kk = 4; kk <= P2; kk <<= 1) {
+        const bool up = (((uint32_t)lane << 2) & kk) == 0;                 // (e & kk) == 0: a fact of the lane for kk >= 4
+        for (uint32_t j = kk >> 1; j >= 4; j >>= 1) {
+            const int m = (int)(j >> 2);                                   // partner lane = lane ^ m, same key slot
+            const bool takemin = (((uint32_t)lane & (uint32_t)m) == 0) == up;
+            const uint32_t y0 = (uint32_t)__shfl_xor((int)r0, m, 64), y1 = (uint32_t)__shfl_xor((int)r1, m, 64);
+            r0 = takemin ? pkmin16(r0, y0) : pkmax16(r0, y0);
+            r1 = takemin ? pkmin16(r1, y1) : pkmax16(r1, y1);
+        }
+        {   // distance 2: key k against key k + 2 = register 0 against register 1, element-wise
+            const uint32_t mn = pkmin16(r0, r1), mx = pkmax16(r0, r1);
+            r0 = up ? mn : mx; r1 = up ? mx : mn;
+        }
+        r0 = cx1(r0, up); r1 = cx1(r1, up);                                // distance 1
+    }
+}
 
 template <bool DO_INT, bool DO_GLCM>
 __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot, unsigned char* const blk, const int lane, const uint32_t promised)
@@ -317,9 +352,11 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
                 S[lane] = x1[0];
             } else {
                 const uint4 q4 = *(const uint4*)(S + 4 * lane);                             // position e = 4 lane + k holds S[e]: the first n are the ROI's
-                uint32_t x4[4] = {q4.x, q4.y, q4.z, q4.w};
-                small_sort<4>(x4, lane, n <= 128 ? 128 : 256);
-                *(uint4*)(S + 4 * lane) = make_uint4(x4[0], x4[1], x4[2], x4[3]);
+                // (offsets are below 2^14; the padding 0xFFFFFFFF becomes 0xFFFF and sorts to the end all the same)
+                uint32_t r0 = (q4.x & 0xFFFFu) | (q4.y << 16), r1 = (q4.z & 0xFFFFu) | (q4.w << 16);
+                small_sort4_packed(r0, r1, lane, n <= 128 ? 128 : 256);
+                auto wide = [](uint32_t k16) -> uint32_t { return k16 == 0xFFFFu ? 0xFFFFFFFFu : k16; };
+                *(uint4*)(S + 4 * lane) = make_uint4(wide(r0 & 0xFFFFu), wide(r0 >> 16), wide(r1 & 0xFFFFu), wide(r1 >> 16));
             }
             wav_sync<false>();
             SMALL_EXIT(3);
@@ -564,12 +601,12 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
 
 // SCAN = false: every slot of the launch is an ROI of this class (its exact list, or a whole batch that is class 0 by the caller's statement):
 // a wave per slot.  SCAN = true: a whole-batch launch FILTERED to class 0 -- over a batch that may hold none (the metric configuration:
-// 196 000 ROIs of 2821 pixels), which must cost next to nothing: a wave takes eight consecutive slots, reads their nine CSR offsets in
-// one load and is gone when none of the eight has <= 256 pixels (a wave per slot cost the headline 2 %, this form 0.7 %); the ROIs it
+// 196 000 ROIs of 2821 pixels), which must cost next to nothing: a wave takes `spw` (8 .. 63) consecutive slots, reads their CSR offsets in
+// one load and is gone when none of them has <= 256 pixels (a wave per slot cost the headline 2 %, eight per wave 0.8 %); the ROIs it
 // does find it serves one after the other (as a loop body the per-ROI code keeps every kernel argument alive across the loop: 116
 // registers instead of 58 -- slower per ROI, which is why the unfiltered launches keep the other form).
 template <bool DO_INT, bool DO_GLCM, bool SCAN>
-__global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised)
+__global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised, const uint32_t spw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -578,16 +615,16 @@ __global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const u
         small_one<DO_INT, DO_GLCM>(A, (uint64_t)blockIdx.x * 4u + (uint32_t)wave, blk, lane, promised);
         return;
     }
-    const uint64_t slot0 = ((uint64_t)blockIdx.x * 4u + (uint32_t)wave) * kSmallSlotsPerWave;
+    const uint64_t slot0 = ((uint64_t)blockIdx.x * 4u + (uint32_t)wave) * spw;             // spw <= 63 consecutive slots per wave (one load covers their CSR offsets)
     if (!A.sp.roi_index) {
         const uint64_t i = slot0 + (uint32_t)lane;
-        const uint64_t po = (lane <= (int)kSmallSlotsPerWave && i <= A.n_roi) ? A.px_offset[i] : 0;
+        const uint64_t po = ((uint32_t)lane <= spw && i <= A.n_roi) ? A.px_offset[i] : 0;
         const uint64_t nx = (uint64_t)__shfl_down((long long)po, 1, 64);
-        const bool cand = lane < (int)kSmallSlotsPerWave && i < A.n_roi && nx - po <= (uint64_t)kSmallPx;
+        const bool cand = (uint32_t)lane < spw && i < A.n_roi && nx - po <= (uint64_t)kSmallPx;
         if (!__ballot(cand)) return;
     }
 #pragma unroll 1
-    for (uint32_t k = 0; k < kSmallSlotsPerWave; k++) {
+    for (uint32_t k = 0; k < spw; k++) {
         small_one<DO_INT, DO_GLCM>(A, slot0 + k, blk, lane, promised);
         wav_sync<false>();                                               // (the block is the next ROI's)
     }
@@ -617,13 +654,15 @@ int launch_roi_small(const RoiArgs& a, void* stream, uint32_t n_slots, bool prom
     const SmallBlock B = small_block((uint32_t)a.n_hist, (uint32_t)a.glcm_na, do_glcm ? (uint32_t)a.grey_depth : 0u, do_glcm);
     const uint32_t lds = 4u * B.total;
     const bool scan = !promised && a.sp.roi_index == nullptr;           // a filtered whole-batch launch: the batch may hold no ROI of the class
-    const uint32_t per_wg = scan ? 4 * kSmallSlotsPerWave : 4;
+    // slots per wave of a scanning launch: enough waves to fill the chip twice (8192 wave slots), at most 63 slots each
+    const uint32_t spw = scan ? std::min<uint32_t>(63u, std::max<uint32_t>(8u, n_slots / 16384u)) : 1u;
+    const uint32_t per_wg = 4 * spw;
     const dim3 grid((n_slots + per_wg - 1) / per_wg);
     const uint32_t pr = promised ? 1u : 0u;
 #define NYX_SMALL_LAUNCH(I, G)                                                                                              \
     do {                                                                                                                    \
-        if (scan) hipLaunchKernelGGL((roi_small_kernel<I, G, true>), grid, dim3(256), lds, st, a, B.total, pr);            \
-        else hipLaunchKernelGGL((roi_small_kernel<I, G, false>), grid, dim3(256), lds, st, a, B.total, pr);                \
+        if (scan) hipLaunchKernelGGL((roi_small_kernel<I, G, true>), grid, dim3(256), lds, st, a, B.total, pr, spw);       \
+        else hipLaunchKernelGGL((roi_small_kernel<I, G, false>), grid, dim3(256), lds, st, a, B.total, pr, spw);           \
     } while (0)
     if (do_int && do_glcm) NYX_SMALL_LAUNCH(true, true);
     else if (do_int) NYX_SMALL_LAUNCH(true, false);
