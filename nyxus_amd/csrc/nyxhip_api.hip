@@ -1768,9 +1768,9 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             // feature kernels: one launch, no filter (both size classes run the same build; a contradicting ROI raises the error flag
             // in the kernel)
             // ... except that the smallest size class has a kernel of its own (a wave per ROI, roi_small.hip) for INTENSITY and for
-            // GLCM counts under matlab binning with <= 16 levels: then two launches, each filtered to its classes
+            // GLCM under matlab binning with <= 64 levels: then two launches, each filtered to its classes
             static const bool no_small = [] { const char* e = getenv("NYXHIP_NO_SMALL"); return e && *e && *e != '0'; }();   // A/B knob
-            const bool small_fits = !no_small && ((mask & NYXHIP_FAM_INTENSITY) || (!s->ibsi && s->grey_depth > 0 && s->grey_depth <= 16));
+            const bool small_fits = !no_small && ((mask & NYXHIP_FAM_INTENSITY) || (!s->ibsi && s->grey_depth > 0 && s->grey_depth <= 64));
             if ((mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) && has_m1 && small_fits) {
                 const uint32_t sd0 = std::min(max_side, kClassSide[0]);
                 groups.push_back({-2, Extrema{std::min(max_px, kClassPx[0]), std::min(max_area, sd0 * sd0), max_range, sd0}, 0x1u, 1u});

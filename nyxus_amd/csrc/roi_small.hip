@@ -22,6 +22,7 @@
 #include "device_math.h"
 #include "roi_kernel.h"
 #include "glcm_rows.h"
+#include "glcm_w64.h"
 #include "launch_util.h"
 #include "../../include/nyxhip.h"
 
@@ -34,23 +35,30 @@ namespace {
 #define SMALL_EXIT(k) do { } while (0)
 #endif
 constexpr int kSmallPx = 256;                // kClassPx[0]
-constexpr uint32_t kSmallArea = 32 * 32;     // kClassSide[0]^2
 
 // per-wave LDS block (bytes): sorted offsets u32[256] | lb100 u32[104] | lbc u32[nb + 8] | pq double[8] | plane u8[(32 + 2) x 33 + 6] | P u32[na * Ng * Ng]
 // (the plane carries a zero column on either side and a zero row below: the four neighbours of the usual request need no bounds test)
-struct SmallBlock { uint32_t S, lb100, lbc, pq, plane, P, total; };
-__host__ __device__ inline SmallBlock small_block(uint32_t nb, uint32_t na, uint32_t ng, bool glcm)
+struct SmallBlock { uint32_t S, lb100, lbc, pq, plane, P, marg, pp, fs, pos, total; };
+// glcm: 0 none | 1: P = u32[na * Ng * Ng] counts for the feature launch | 2 (17..64 levels, features from the pairs): P = u8[64 x 64] counts of ONE angle,
+// marg = u32[64 + 64 + 64 + 128] row / column / difference / sum counts, pp = double[64 + 64] row / column probabilities, fs = double[4][64] an
+// angle's f | sm block (glcm_w64.h), pos = u16[256] plane address of pixel i (window mode ranks pixels by ballot).  10 160 bytes: four
+// workgroups of four waves per CU.
+__host__ __device__ inline SmallBlock small_block(uint32_t nb, uint32_t na, uint32_t ng, bool do_int, int glcm)
 {
     SmallBlock b;
     uint32_t o = 0;
-    b.S = o; o += 4u * kSmallPx;
-    b.lb100 = o; o += 4u * 104;
-    b.lbc = o; o += 4u * (nb + 8);
+    b.S = o; o += do_int ? 4u * kSmallPx : 0u;
+    b.lb100 = o; o += do_int ? 4u * 104 : 0u;
+    b.lbc = o; o += do_int ? 4u * (nb + 8) : 0u;
     o = (o + 7u) & ~7u;
     b.pq = o; o += 8u * 8;
     b.plane = o; o += glcm ? 34 * 33 + 6 : 0;
     o = (o + 15u) & ~15u;
-    b.P = o; o += glcm ? 4u * na * ng * ng : 0;
+    b.P = o; o += glcm == 1 ? 4u * na * ng * ng : glcm == 2 ? 64u * 64u : 0u;
+    b.marg = o; o += glcm == 2 ? 4u * 320u : 0u;
+    b.pp = o; o += glcm == 2 ? 8u * 128u : 0u;
+    b.fs = o; o += glcm == 2 ? 8u * 64u * kMaxAngles : 0u;
+    b.pos = o; o += glcm == 2 ? 2u * kSmallPx : 0u;
     b.total = (o + 15u) & ~15u;
     return b;
 }
@@ -134,7 +142,7 @@ __device__ __forceinline__ void small_sort4_packed(uint32_t& r0, uint32_t& r1, i
     }
 }
 
-template <bool DO_INT, bool DO_GLCM>
+template <bool DO_INT, int GLCM>      // GLCM: 0 none, 1 counts of <= 16-level matrices for the feature launch, 2 features of 17..64-level matrices from the pairs
 __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot, unsigned char* const blk, const int lane, const uint32_t promised)
 {
     uint64_t roi;
@@ -156,9 +164,10 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
         return;
     }
     if (!roi_in_launch(A.sp, n, w, h, range)) return;
+    constexpr bool DO_GLCM = GLCM != 0;
     const int na = A.glcm_na, Ng = A.ibsi ? 0 : A.grey_depth;
     const uint32_t nb = (uint32_t)A.n_hist;
-    const SmallBlock B = small_block(nb, (uint32_t)na, DO_GLCM ? (uint32_t)Ng : 0u, DO_GLCM);
+    const SmallBlock B = small_block(nb, (uint32_t)na, DO_GLCM ? (uint32_t)Ng : 0u, DO_INT, GLCM);
     uint32_t* const S = (uint32_t*)(blk + B.S);
     uint32_t* const lb100 = (uint32_t*)(blk + B.lb100);
     uint32_t* const lbc = (uint32_t*)(blk + B.lbc);
@@ -177,12 +186,13 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
     // ---- load: value k of a lane is pixel lane + 64 k ------------------------------------------------------------------------------
     uint32_t v[4];
     bool in[4];
+    uint32_t padr[4] = {0u, 0u, 0u, 0u};                                   // GLCM == 2: plane address of the lane's pixel k (0 = a border cell: level 0)
+    uint16_t* const pos = (uint16_t*)(blk + B.pos);
     const bool degenerate = DO_GLCM && bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth);   // glcm.cpp:27-95
     const double mslope = Ng > 0 ? (double)Ng / ((double)vmax - 0.) : 0.0;
     if (DO_GLCM && !degenerate) {
-        const uint32_t area = w * h;
         for (uint32_t i = lane; i < ((w + 2) * (h + 1) + 3) / 4; i += 64) ((uint32_t*)plane)[i] = 0;   // (the block's plane region is 4-byte aligned)
-        for (int i = lane; i < na * Ng * Ng; i += 64) P[i] = 0;
+        if (GLCM == 1) for (int i = lane; i < na * Ng * Ng; i += 64) P[i] = 0;
         wav_sync<false>();
     }
     unsigned long long tot_i = 0, totsq_i = 0;
@@ -220,6 +230,7 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
             if (mem && rank < n) {
                 if (DO_INT) S[rank] = vv - vmin;
                 if (DO_GLCM && !degenerate) plane[row * (w + 2) + cc + 1] = (uint8_t)level_of(vv);
+                if (GLCM == 2) pos[rank] = (uint16_t)(row * (w + 2) + cc + 1);
             }
             base += (uint32_t)__popcll(bal);
         }
@@ -234,7 +245,7 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
             continue;
         }
         in[k] = i < n;
-        if (from_window) v[k] = (DO_INT && in[k]) ? vmin + S[i] : 0u;
+        if (from_window) { v[k] = (DO_INT && in[k]) ? vmin + S[i] : 0u; if (GLCM == 2 && in[k]) padr[k] = pos[i]; }
         else v[k] = in[k] ? A.inten[off + i] : 0u;
         if (in[k]) {
             const uint32_t sq = v[k] * v[k];                               // unsigned-int product, wraps (intensity.cpp:90)
@@ -242,7 +253,7 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
             totsq_i += (unsigned long long)(sq & 0xFFFFu) | ((unsigned long long)(sq >> 16) << 32);   // low digits | high digits: < 2^18 each per lane
             if (DO_GLCM && !degenerate && !from_window) {
                 const uint32_t px = A.x[off + i], py = A.y[off + i];
-                if (px < w && py < h) plane[py * (w + 2) + px + 1] = (uint8_t)level_of(v[k]);
+                if (px < w && py < h) { plane[py * (w + 2) + px + 1] = (uint8_t)level_of(v[k]); if (GLCM == 2) padr[k] = py * (w + 2) + px + 1; }
             }
         }
         if (DO_INT && !from_window) S[i] = in[k] ? v[k] - vmin : 0xFFFFFFFFu;   // (the sort network runs over a power of two)
@@ -549,7 +560,130 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
     }
 
     SMALL_EXIT(7);
-    if (DO_GLCM) {
+    if (GLCM == 2) {
+        // ---- 17..64 levels (the reference's default depth): Haralick features straight from the <= 255 pairs of an angle ----------------
+        // The dense passes of glcm_features_wave64_v2 (row / column / diagonal sums and the per-cell terms over 64 x 64 cells) cost the
+        // same whatever the ROI holds.  Here the marginal counts are four LDS atomics per PAIR, and every per-cell sum is a sum over
+        // pairs: a cell of count c is hit by c pairs, so sum_cells c g(c) = sum_pairs g(c(pair)) -- sum c^2 (ASM), the entropy terms
+        // lg(c / sum_p + eps), HXY1's lg(px py + eps), JMAX.  Counts are kept asymmetric in 8-bit cells (an angle has at most n - 1
+        // <= 255 pairs); a symmetric request reads cell and transposed cell.  HXY2 and everything behind the marginals: glcm_w64.h,
+        // the code of the workgroup kernel.  One angle after the other over one 4 KiB matrix.
+        double* const og = out_row + A.col_glcm;
+        if (degenerate) {
+            for (int c = lane; c < kGlcmAngled * na + kGlcmAve; c += 64) og[c] = A.soft_nan;
+            return;
+        }
+        const uint32_t pitch = w + 2;
+        const bool symmetric = A.glcm_symmetric != 0;
+        const uint32_t inc = symmetric ? 2u : 1u;
+        const uint8_t* const M8 = (const uint8_t*)P;
+        uint32_t* const mR = (uint32_t*)(blk + B.marg);
+        uint32_t* const mC = mR + 64, * const mD = mR + 128, * const mX = mR + 192;
+        double* const prow_s = (double*)(blk + B.pp), * const pcol_s = prow_s + 64;
+        double* const fs = (double*)(blk + B.fs);
+        const bool act = lane < Ng;
+        uint32_t lc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) lc[k] = k < rounds ? (uint32_t)plane[padr[k]] : 0u;
+        for (int q = 0; q < na; q++) {
+            const int ang = A.glcm_angles[q];                              // glcm.cpp:234-255: 0 E, 45 SE, 90 S, 135 SW at distance 1
+            const uint32_t delta = ang == 0 ? 1u : ang == 45 ? pitch + 1u : ang == 90 ? pitch : pitch - 1u;
+#pragma unroll
+            for (int t = 0; t < 4; t++) ((uint4*)P)[lane + 64 * t] = uint4{0u, 0u, 0u, 0u};
+            ((uint4*)mR)[lane] = uint4{0u, 0u, 0u, 0u};
+            if (lane < 16) ((uint4*)mR)[64 + lane] = uint4{0u, 0u, 0u, 0u};
+            wav_sync<false>();
+            uint32_t ia[4], ib[4];
+            bool pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                pv[k] = false; ia[k] = 0; ib[k] = 0;
+                if (k >= rounds) continue;
+                const uint32_t nbv = (uint32_t)plane[padr[k] + delta];
+                pv[k] = lc[k] != 0 && nbv != 0;
+                if (pv[k]) {
+                    const uint32_t a = lc[k] - 1u, b = nbv - 1u, idx = (a << 6) + b;
+                    ia[k] = a; ib[k] = b;
+                    atomicAdd(&P[idx >> 2], 1u << ((idx & 3u) << 3));
+                    atomicAdd(&mR[a], 1u); atomicAdd(&mC[b], 1u);
+                    atomicAdd(&mD[a > b ? a - b : b - a], inc); atomicAdd(&mX[a + b], inc);
+                    if (symmetric) { atomicAdd(&mR[b], 1u); atomicAdd(&mC[a], 1u); }
+                }
+            }
+            wav_sync<false>();
+            const uint32_t rc = act ? mR[lane] : 0u, cc = act ? mC[lane] : 0u, dc = act ? mD[lane] : 0u;
+            uint32_t pxpy_c[2] = {lane <= 2 * Ng - 2 ? mX[lane] : 0u, lane + 64 <= 2 * Ng - 2 ? mX[64 + lane] : 0u};
+            const uint32_t csum = wave_sum_t<uint32_t>(rc);                // sum_p (glcm.cpp:481-484)
+            const bool empty = csum == 0;
+            const double sum_p = empty ? 1.0 : (double)csum;
+            const double inv_sum_p = fdiv(1.0, sum_p);
+            const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
+            double pxpy[2] = {0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (lane + 64 * u < 2 * Ng - 1) pxpy[u] = fdiv((double)pxpy_c[u], sum_p);
+            prow_s[lane] = prow; pcol_s[lane] = pcol;
+            wav_sync<false>();
+            // ---- per-pair terms
+            double ent = 0, hxy1c = 0, hxy2 = 0;
+            uint32_t asm_i = 0, cmax = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= rounds) continue;
+                if (pv[k]) {
+                    uint32_t cnt = M8[(ia[k] << 6) + ib[k]];
+                    if (symmetric) cnt += M8[(ib[k] << 6) + ia[k]];
+                    asm_i += inc * cnt;                                    // f_asm :555 / f_energy :927-928
+                    cmax = cmax > cnt ? cmax : cnt;                        // f_GLCM_JMAX :1178-1179
+                    const double pk = (double)cnt * inv_sum_p;
+                    ent += (double)inc * (double)fast_log2f(pk + 0.000000001);           // f_entropy :734-735, JE :1160-1161, HXY :868
+                    const double pxy = pcol_s[ib[k]] * prow_s[ia[k]];                    // :869, :909
+                    hxy1c += (double)inc * (double)fast_log2f(pxy + 0.000000001);
+                }
+            }
+            ent *= inv_sum_p;
+            // ---- HXY2 over all (row, column) products: rows in groups of equal row marginal (glcm_features_wave64_v2)
+            {
+                unsigned long long rem = __ballot(act && rc != 0u);
+                while (rem) {
+                    const int r0 = (int)__builtin_ctzll(rem);
+                    const uint32_t vr = (uint32_t)__builtin_amdgcn_readlane((int)rc, r0);
+                    const unsigned long long pbits = (unsigned long long)__double_as_longlong(prow);
+                    const double pr = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), r0) << 32) |
+                                                                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, r0)));
+                    const unsigned long long grp = __ballot(act && rc == vr);
+                    rem &= ~grp;
+                    const double ppr = pcol * pr;
+                    const double lg = (double)fast_log2f(ppr + 0.000000001);
+                    hxy2 = __builtin_fma(ppr * (double)(uint32_t)__popcll(grp), lg, hxy2);
+                }
+                if (!act) hxy2 = 0.0;
+            }
+            if (Ng == 64) glcm_w64_tail<64>(64, lane, rc, cc, dc, pxpy_c, csum, sum_p, inv_sum_p, pcol, prow, pxmy, pxpy, ent, hxy1c, hxy2, asm_i, cmax, fs + q * 64);
+            else glcm_w64_tail<0>(Ng, lane, rc, cc, dc, pxpy_c, csum, sum_p, inv_sum_p, pcol, prow, pxmy, pxpy, ent, hxy1c, hxy2, asm_i, cmax, fs + q * 64);
+        }
+        wav_sync<false>();
+        if (lane < na) glcm_features_final((uint32_t*)(fs + lane * 64), A.soft_nan);
+        wav_sync<false>();
+        for (int c = lane; c < kGlcmAngled * na; c += 64) {                // feature-major, angle-minor (output_2_buffer.cpp:336-346)
+            const int k = c / na, a = c - k * na;
+            og[c] = fs[a * 64 + k];
+        }
+        for (int j = lane; j < kGlcmAve; j += 64) {                        // calc_ave (glcm.cpp:1205-1214): std::reduce folds four at a time
+            const int k = c_glcm_ave_order[j];
+            double init = 0.0;
+            int a = 0;
+            for (; na - a >= 4; a += 4) {
+                const double v1 = fs[a * 64 + k] + fs[(a + 1) * 64 + k];
+                const double v2 = fs[(a + 2) * 64 + k] + fs[(a + 3) * 64 + k];
+                init = init + (v1 + v2);
+            }
+            for (; a < na; a++) init = init + fs[a * 64 + k];
+            og[kGlcmAngled * na + j] = na ? init / (double)na : 0.0;
+        }
+        return;
+    }
+    if (GLCM == 1) {
         double* const og = out_row + A.col_glcm;
         if (lane == 0 && A.glcm_ng) A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
         if (degenerate) {
@@ -605,14 +739,14 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
 // one load and is gone when none of them has <= 256 pixels (a wave per slot cost the headline 2 %, eight per wave 0.8 %); the ROIs it
 // does find it serves one after the other (as a loop body the per-ROI code keeps every kernel argument alive across the loop: 116
 // registers instead of 58 -- slower per ROI, which is why the unfiltered launches keep the other form).
-template <bool DO_INT, bool DO_GLCM, bool SCAN>
+template <bool DO_INT, int GLCM, bool SCAN>
 __global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised, const uint32_t spw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* const blk = small_lds + (size_t)wave * wave_bytes;
     if (!SCAN) {
-        small_one<DO_INT, DO_GLCM>(A, (uint64_t)blockIdx.x * 4u + (uint32_t)wave, blk, lane, promised);
+        small_one<DO_INT, GLCM>(A, (uint64_t)blockIdx.x * 4u + (uint32_t)wave, blk, lane, promised);
         return;
     }
     const uint64_t slot0 = ((uint64_t)blockIdx.x * 4u + (uint32_t)wave) * spw;             // spw <= 63 consecutive slots per wave (one load covers their CSR offsets)
@@ -625,7 +759,7 @@ __global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const u
     }
 #pragma unroll 1
     for (uint32_t k = 0; k < spw; k++) {
-        small_one<DO_INT, DO_GLCM>(A, slot0 + k, blk, lane, promised);
+        small_one<DO_INT, GLCM>(A, slot0 + k, blk, lane, promised);
         wav_sync<false>();                                               // (the block is the next ROI's)
     }
 }
@@ -640,6 +774,13 @@ bool roi_small_supported(const RoiArgs& a)
     const bool do_int = a.mask & NYXHIP_FAM_INTENSITY, do_glcm = a.mask & NYXHIP_FAM_GLCM;
     if (a.mask & ~(uint32_t)(NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) return false;
     if (!do_int && !do_glcm) return false;
+    if (do_glcm && a.L.g16) {
+        // 17..64 levels: the GLCM-only launch of the split (run_class), distance 1, the four directions
+        if (do_int || a.ibsi || a.grey_depth < 17 || a.grey_depth > 64 || a.glcm_offset != 1 || a.glcm_na < 1 || a.glcm_na > kMaxAngles) return false;
+        for (int q = 0; q < a.glcm_na; q++)
+            if (a.glcm_angles[q] != 0 && a.glcm_angles[q] != 45 && a.glcm_angles[q] != 90 && a.glcm_angles[q] != 135) return false;
+        return true;
+    }
     if (do_glcm && !(a.glcm_ws != nullptr && a.glcm_ng != nullptr && !a.ibsi && a.grey_depth > 0 && a.grey_depth <= 16 && a.glcm_na >= 1 && a.glcm_na <= kMaxAngles))
         return false;
     if (do_int && (a.n_hist < 1 || a.n_hist > 1024)) return false;              // (the bin bounds sit in the wave's LDS block)
@@ -651,7 +792,8 @@ int launch_roi_small(const RoiArgs& a, void* stream, uint32_t n_slots, bool prom
     if (n_slots == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool do_int = a.mask & NYXHIP_FAM_INTENSITY, do_glcm = a.mask & NYXHIP_FAM_GLCM;
-    const SmallBlock B = small_block((uint32_t)a.n_hist, (uint32_t)a.glcm_na, do_glcm ? (uint32_t)a.grey_depth : 0u, do_glcm);
+    const int gmode = !do_glcm ? 0 : a.L.g16 ? 2 : 1;
+    const SmallBlock B = small_block((uint32_t)a.n_hist, (uint32_t)a.glcm_na, do_glcm ? (uint32_t)a.grey_depth : 0u, do_int, gmode);
     const uint32_t lds = 4u * B.total;
     const bool scan = !promised && a.sp.roi_index == nullptr;           // a filtered whole-batch launch: the batch may hold no ROI of the class
     // slots per wave of a scanning launch: enough waves to fill the chip twice (8192 wave slots), at most 63 slots each
@@ -664,9 +806,10 @@ int launch_roi_small(const RoiArgs& a, void* stream, uint32_t n_slots, bool prom
         if (scan) hipLaunchKernelGGL((roi_small_kernel<I, G, true>), grid, dim3(256), lds, st, a, B.total, pr, spw);       \
         else hipLaunchKernelGGL((roi_small_kernel<I, G, false>), grid, dim3(256), lds, st, a, B.total, pr, spw);           \
     } while (0)
-    if (do_int && do_glcm) NYX_SMALL_LAUNCH(true, true);
-    else if (do_int) NYX_SMALL_LAUNCH(true, false);
-    else NYX_SMALL_LAUNCH(false, true);
+    if (gmode == 2) NYX_SMALL_LAUNCH(false, 2);
+    else if (do_int && do_glcm) NYX_SMALL_LAUNCH(true, 1);
+    else if (do_int) NYX_SMALL_LAUNCH(true, 0);
+    else NYX_SMALL_LAUNCH(false, 1);
 #undef NYX_SMALL_LAUNCH
     return (int)hipGetLastError();
 }

@@ -195,10 +195,10 @@ def _small_rois(seed, hi=4096):
 
 
 @pytest.mark.parametrize("mask", [1, 2, 3])
-@pytest.mark.parametrize("gd,hi", [(8, 4096), (8, 256), (16, 16000), (3, 50), (64, 4096)])
+@pytest.mark.parametrize("gd,hi", [(8, 4096), (8, 256), (16, 16000), (3, 50), (64, 4096), (64, 40), (33, 1000), (17, 300)])
 def test_smallest_class_matches_oracle(hip_ctx, mask, gd, hi):
-    """Every ROI of the batch is of class 0: a whole-batch launch of the wave-per-ROI kernel on stated extrema (grey depth 64: its INTENSITY
-    half only -- the GLCM half stays with the 64-level kernel)."""
+    """Every ROI of the batch is of class 0: a whole-batch launch of the wave-per-ROI kernel on stated extrema (17..64 levels: the GLCM
+    features come from the pairs of the ROI, not from the 64 x 64 matrix)."""
     s = _abi.default_settings(gd)
     b = _abi.batch_from_rois(_small_rois(gd + hi, hi=hi))
     G = hip_ctx.featurize_host(b, mask, s)
@@ -207,12 +207,13 @@ def test_smallest_class_matches_oracle(hip_ctx, mask, gd, hi):
     assert not bad, "\\n".join(bad[:20])
 
 
-def test_smallest_class_rows_do_not_depend_on_companions_or_options(hip_ctx):
+@pytest.mark.parametrize("gd", [8, 64])
+def test_smallest_class_rows_do_not_depend_on_companions_or_options(hip_ctx, gd):
     """A class-0 row is the same alone, among larger companions (filtered whole-batch launches / exact lists), with other families in
     the call, with slide extrema given -- and symmetric counts, angle subsets, other offsets match the oracle."""
     rng = np.random.default_rng(77)
     small = _small_rois(5)
-    s = _abi.default_settings(8)
+    s = _abi.default_settings(gd)
     alone = hip_ctx.featurize_host(_abi.batch_from_rois(small), 3, s)
     mid = [ellipse_roi(int(rng.integers(12, 30)), int(rng.integers(12, 30)), rng) for _ in range(12)]          # size class 1
     big = [ellipse_roi(90, 70, rng)]                                                                            # a class that forces the exact path
@@ -230,8 +231,8 @@ def test_smallest_class_rows_do_not_depend_on_companions_or_options(hip_ctx):
             assert np.array_equal(T[idx][:, keep].view(np.uint64), alone.view(np.uint64))
             bad = parity.compare_tables(T, po.oracle_featurize(bm, m, s), names, batch=bm)
             assert not bad, "\\n".join(bad[:10])
-    for sym, angles, offset in ((1, (0, 45, 90, 135), 1), (0, (45, 135), 1), (1, (90,), 2), (0, (0, 45, 90, 135), 3)):
-        s2 = _abi.default_settings(8)
+    for sym, angles, offset in ((1, (0, 45, 90, 135), 1), (0, (45, 135), 1), (1, (135, 0, 90), 1), (1, (90,), 2), (0, (0, 45, 90, 135), 3)):
+        s2 = _abi.default_settings(gd)
         s2.glcm_symmetric = sym; s2.glcm_offset = offset; s2.glcm_n_angles = len(angles)
         for i, a in enumerate(angles): s2.glcm_angles[i] = a
         b = _abi.batch_from_rois(small)
