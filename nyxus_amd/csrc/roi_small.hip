@@ -740,7 +740,7 @@ __device__ __forceinline__ void small_one(const RoiArgs& A, const uint64_t slot,
 // does find it serves one after the other (as a loop body the per-ROI code keeps every kernel argument alive across the loop: 116
 // registers instead of 58 -- slower per ROI, which is why the unfiltered launches keep the other form).
 template <bool DO_INT, int GLCM, bool SCAN>
-__global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised, const uint32_t spw)
+__global__ __launch_bounds__(256, (SCAN && GLCM != 2) ? 8 : 1) void roi_small_kernel(const RoiArgs A, const uint32_t wave_bytes, const uint32_t promised, const uint32_t spw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -759,7 +759,12 @@ __global__ __launch_bounds__(256) void roi_small_kernel(const RoiArgs A, const u
     }
 #pragma unroll 1
     for (uint32_t k = 0; k < spw; k++) {
-        small_one<DO_INT, GLCM>(A, slot0 + k, blk, lane, promised);
+        // (lane and block address made opaque per trip: what the per-ROI code derives from them is then computed inside the trip instead of
+        //  being hoisted out of the loop and kept in registers across it -- the hoisting doubled the kernel's register count)
+        int l2 = lane;
+        uint32_t b2 = (uint32_t)wave * wave_bytes;
+        asm volatile("" : "+v"(l2), "+s"(b2));
+        small_one<DO_INT, GLCM>(A, slot0 + k, small_lds + b2, l2, promised);
         wav_sync<false>();                                               // (the block is the next ROI's)
     }
 }
