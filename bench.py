@@ -663,6 +663,14 @@ class Bench:
                                                     "the stage issues (16-row tiles x 4-column groups x hi / lo tap parts x digit planes): small boxes fill a fraction of a tile"),
                               "what": "BASELINE.json configs[4]: GABOR (8-filter bank, 16x16) + ZERNIKE2D on DSB2018-shaped ROIs (fixture shapes replicated with seeded noise)"}
             rec["config5"]["cpu_baseline"] = self.cpu_leg(hb5, m5k, s5, "GaborFeature + ZernikeFeature reduce via runParallel", 8192)
+            # the same DSB2018-shaped batch (real nuclei: ~130 px, most of them in the smallest size class) through the families of
+            # BASELINE configs[3] and through the metric families at the reference's default grey depth
+            dsb = {"rois": int(hb5.n_roi), "mean_px": hb5.n_px / hb5.n_roi,
+                   "what": "the config5 batch (DSB2018 fixture shapes, 8-bit intensities) through other family sets: ns per ROI, gated on the first / last 64 ROIs"}
+            for key5, mk5, st5 in (("config4_set", self.m4, self.s), ("metric_families", self.mask, self.s), ("metric_families_gd64", self.mask, _abi.default_settings(64))):
+                dtd, _, pard, _ = self.timed(mk5, st5, cb5, hb5.n_roi, check_rows=chk5, arrays=keep5)
+                dsb[key5] = {"value": hb5.n_roi / dtd, "unit": "ROIs/s", "ns_per_roi": 1e9 * dtd / hb5.n_roi, "parity_check": pard}
+            rec["dsb_shaped"] = dsb
             del keep5
         except Exception as e5:           # informational leg: never costs the headline line
             rec["config5"] = {"error": repr(e5)}
@@ -924,6 +932,9 @@ class Bench:
             summ["size_sweep_ns_per_roi"] = {str(r_["n_px"]): round(r_["ns_per_roi"], 2) for r_ in rec["size_sweep"].get("rows", []) if r_.get("ns_per_roi") is not None}
         if isinstance(rec.get("size_sweep_gd64"), dict):
             summ["size_sweep_gd64_ns_per_roi"] = {str(r_["n_px"]): round(r_["ns_per_roi"], 2) for r_ in rec["size_sweep_gd64"].get("rows", []) if r_.get("ns_per_roi") is not None}
+        if isinstance(rec.get("dsb_shaped"), dict):
+            summ["dsb_shaped_ns_per_roi"] = {k_: [round(v_["ns_per_roi"], 2) if v_["ns_per_roi"] is not None else None, "ok" if gate_ok(v_.get("parity_check")) else ("unchecked" if v_.get("parity_check") is None else "FAILED")]
+                                             for k_, v_ in rec["dsb_shaped"].items() if isinstance(v_, dict) and "ns_per_roi" in v_}
         if isinstance(rec.get("intensity_range"), dict):
             summ["intensity_range_ns_per_roi"] = {r_["intensities"]: (round(r_["ns_per_roi"], 2) if r_.get("ns_per_roi") is not None else None) for r_ in rec["intensity_range"].get("rows", [])}
         if "ratios" in rec:

@@ -45,7 +45,12 @@ struct nyxhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
-    int* d_status = nullptr;
+    int* d_status = nullptr;           // [0] error flag of the kernels | [1] census: ROIs of <= 256 px met by the scanning form of roi_small_kernel (read with the flag)
+    // census of the recent calls: how many of the ROIs were of the smallest size class.  A batch on stated extrema that mixes that class
+    // with the next one runs either as two filtered whole-batch launches (nothing counted, no host round trip: right when the class is
+    // rare -- the metric configuration) or through the exact class lists (right when it is common: filtered launches spend a workgroup
+    // on every slot they skip).  Both give the same rows; the census only picks the cheaper one.  Host batches are counted on the host.
+    uint64_t census_small = 0, census_total = 0, census_pending = 0;
     // Gabor filter bank (host-built, gabor.cpp:393-449), re-uploaded when the settings change
     double* d_bank = nullptr;
     float* d_bank32 = nullptr;       // the bank rounded to fp32 (Gabor screening pass)
@@ -798,8 +803,13 @@ int ensure_stage(nyxhip_ctx* ctx, size_t bytes)
 
 int check_status(nyxhip_ctx* ctx)
 {
-    int st = 0;
-    HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    int two[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(two, ctx->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    const int st = two[0];
+    if (ctx->census_pending) {         // whole-batch launches on stated extrema ran since the last look: what their scan met
+        ctx->census_small = (uint32_t)two[1]; ctx->census_total = ctx->census_pending; ctx->census_pending = 0;
+    }
+    if (two[1]) HIP_TRY(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int), ctx->stream()));
     if (st != 0) {
         int zero = 0;
         HIP_TRY(ctx, hipMemcpy(ctx->d_status, &zero, sizeof(int), hipMemcpyHostToDevice));
@@ -1512,6 +1522,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         // the smallest size class (roi_class == 0) runs INTENSITY / GLCM a wave per ROI (roi_small.hip; launch_roi_features decides whether
         // the settings allow it): its exact list, a whole-batch launch filtered to it, or a whole batch that IS it by the stated extrema
         if (list ? cls == 0 : class_mask == 0x1u) a.small_class = 1;
+        if (!list && class_mask == 0x1u) a.census = (uint32_t*)(ctx->d_status + 1);
         else if (!list && class_mask == 0 && E.px <= kClassPx[0] && E.side <= kClassSide[0] && E.range < 16384u) a.small_class = 2;
         // the two filtered feature launches of a call on stated extrema (launch_device_all): ONE GLCM feature launch, behind the second
         if (!list && class_mask == 0x1u) a.glcm_feats = 1;
@@ -1530,6 +1541,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
                     make_layout(NYXHIP_FAM_GLCM, s, ncol_g, E.px, E.area, E.range, ag.L, w2) == NYXHIP_OK && ag.L.g16) {
                     ai.mask = NYXHIP_FAM_INTENSITY; ai.n_cols = kIntensityCols; ai.col_intensity = 0; ai.col_glcm = -1;
                     ag.mask = NYXHIP_FAM_GLCM; ag.n_cols = ncol_g; ag.col_glcm = 0; ag.col_intensity = -1; ag.out = a.out + kIntensityCols;
+                    ag.census = nullptr;                               // (the intensity launch counts)
                     if (int r1 = launch_roi_features(ag, st, grid)) return r1;
                     return launch_roi_features(ai, st, grid);
                 }
@@ -1757,9 +1769,16 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
         // (a stated range that allows wide-range ROIs takes the exact path as well: a whole-batch launch per table width would
         //  carve 43 KB for a class that 16-bit data leaves empty -- 100 k workgroups that only return, three per CU)
         const bool wide_possible = max_range >= 16384u && (mask & NYXHIP_FAM_INTENSITY);
-        if (hinted && !force_exact && !need_vmax && !wide_possible && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
+        const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]);
+        static const bool no_small = [] { const char* e = getenv("NYXHIP_NO_SMALL"); return e && *e && *e != '0'; }();   // A/B knob
+        static const bool no_adapt = [] { const char* e = getenv("NYXHIP_NO_ADAPT"); return e && *e && *e != '0'; }();   // A/B knob
+        const bool small_fits = !no_small && ((mask & NYXHIP_FAM_INTENSITY) || (!s->ibsi && s->grey_depth > 0 && s->grey_depth <= 64));
+        const bool two_filtered = (mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) && has_m1 && small_fits;
+        // (the recent calls held the smallest class in numbers: exact lists beat two launches that each skip the other's slots)
+        const bool prefer_lists = two_filtered && !no_adapt && ctx->census_total != 0 && 4 * ctx->census_small >= ctx->census_total;
+        if (hinted && !force_exact && !need_vmax && !wide_possible && !prefer_lists && max_px <= kClassPx[1] && max_side <= kClassSide[1]) {
             // ---- whole-batch launches, nothing counted -----------------------------------------------------------------------
-            const bool has_m1 = !(max_px <= kClassPx[0] && max_side <= kClassSide[0]);
+            if (two_filtered) ctx->census_pending += n_roi;
             const Extrema Eall{max_px, max_area, max_range, max_side};
             struct Group { int cls; Extrema E; uint32_t class_mask, group_sel; };
             std::vector<Group> groups;
@@ -1769,9 +1788,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             // in the kernel)
             // ... except that the smallest size class has a kernel of its own (a wave per ROI, roi_small.hip) for INTENSITY and for
             // GLCM under matlab binning with <= 64 levels: then two launches, each filtered to its classes
-            static const bool no_small = [] { const char* e = getenv("NYXHIP_NO_SMALL"); return e && *e && *e != '0'; }();   // A/B knob
-            const bool small_fits = !no_small && ((mask & NYXHIP_FAM_INTENSITY) || (!s->ibsi && s->grey_depth > 0 && s->grey_depth <= 64));
-            if ((mask & (NYXHIP_FAM_INTENSITY | NYXHIP_FAM_GLCM)) && has_m1 && small_fits) {
+            if (two_filtered) {
                 const uint32_t sd0 = std::min(max_side, kClassSide[0]);
                 groups.push_back({-2, Extrema{std::min(max_px, kClassPx[0]), std::min(max_area, sd0 * sd0), max_range, sd0}, 0x1u, 1u});
                 groups.push_back({-3, Eall, 0x3FEu, 1u});
@@ -1819,6 +1836,7 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cls_hdr, hdr, sizeof(uint32_t) * kClasses * H_WORDS, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
             const uint32_t* H = ctx->h_cls_hdr;
+            if (!ctx->census_pending) { ctx->census_small = H[H_COUNT]; ctx->census_total = n_roi; }   // (class 0 = the smallest size class, 16-bit tables)
             if (!hinted) {
                 max_px = max_area = max_range = max_side = 0;
                 for (int cls = 0; cls < kClasses; cls++) {
@@ -1959,7 +1977,7 @@ int nyxhip_init(int device, nyxhip_ctx** out_ctx)
     nyxhip_ctx* ctx = new nyxhip_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_status, 4 * sizeof(int)) != hipSuccess || hipMemset(ctx->d_status, 0, 4 * sizeof(int)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, NYXHIP_ERR_HIP, "failed to create the device context");
     }
@@ -2110,8 +2128,10 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
     // host batch: derive extrema, stage SoA arrays into one device slab, run, copy the table back
     const uint64_t nr = b->n_roi, npx = b->px_offset[nr];
     uint32_t max_px = 0, max_area = 0, max_range = 0, max_side = 0;
+    uint64_t n_small = 0;                                  // census of the smallest size class (launch_device_all picks lists or filtered launches by it)
     for (uint64_t r = 0; r < nr; r++) {
         if (b->px_offset[r + 1] < b->px_offset[r]) return fail(ctx, NYXHIP_ERR_INVALID_ARG, "px_offset is not monotone");
+        if (b->px_offset[r + 1] - b->px_offset[r] <= kClassPx[0] && b->bbox_w[r] <= kClassSide[0] && b->bbox_h[r] <= kClassSide[0]) n_small++;
         uint64_t n = b->px_offset[r + 1] - b->px_offset[r];
         uint64_t a = (uint64_t)b->bbox_w[r] * b->bbox_h[r];
         if (n > 0xFFFFFFFFull || a > 0xFFFFFFFFull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "ROI exceeds 2^32 pixels");
@@ -2152,6 +2172,7 @@ int nyxhip_featurize_batch(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask
     d.slide_min = b->slide_min ? (const double*)(base + o_smin) : nullptr;
     d.slide_max = b->slide_max ? (const double*)(base + o_smax) : nullptr;
     double* d_out = (double*)(base + o_out);
+    ctx->census_small = n_small; ctx->census_total = nr; ctx->census_pending = 0;
     rc = launch_device(ctx, &d, mask, s, d_out, (size_t)n_cols, max_px, max_area, max_range, max_side);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy2DAsync(out, ld * sizeof(double), d_out, (size_t)n_cols * sizeof(double),

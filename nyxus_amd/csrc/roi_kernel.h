@@ -155,6 +155,7 @@ struct RoiArgs {
     uint32_t* glcm_ws;       // [n_roi][glcm_ws_stride] counts, angle-major; NULL = features inside this kernel
     uint32_t* glcm_ng;       // [n_roi] matrix order of the ROI, 0 = nothing to derive (degenerate / skipped ROI)
     uint32_t glcm_ws_stride; // words per ROI = n_angles * ng_cap^2
+    uint32_t* census;        // roi_small_kernel, scanning form: += ROIs of <= 256 pixels met (nullptr: not counted); read with the status flag
     uint32_t small_class;    // launch_roi_features: 1 = this launch serves class 0 (roi_class) through a list or a class filter, 2 = a whole-batch
                              // launch whose stated extrema promise class 0 only -> the wave-per-ROI kernel of roi_small.hip; 0 = roi_features_kernel
     uint32_t glcm_feats;     // split GLCM launches: 0 = glcm_features_kernel follows this launch over the same slots; 1 = not after this launch (the next

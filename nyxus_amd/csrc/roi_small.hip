@@ -755,7 +755,9 @@ __global__ __launch_bounds__(256, (SCAN && GLCM != 2) ? 8 : 1) void roi_small_ke
         const uint64_t po = ((uint32_t)lane <= spw && i <= A.n_roi) ? A.px_offset[i] : 0;
         const uint64_t nx = (uint64_t)__shfl_down((long long)po, 1, 64);
         const bool cand = (uint32_t)lane < spw && i < A.n_roi && nx - po <= (uint64_t)kSmallPx;
-        if (!__ballot(cand)) return;
+        const unsigned long long found = __ballot(cand);
+        if (!found) return;
+        if (A.census && lane == 0) atomicAdd(A.census, (uint32_t)__popcll(found));
     }
 #pragma unroll 1
     for (uint32_t k = 0; k < spw; k++) {

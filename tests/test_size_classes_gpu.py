@@ -79,12 +79,57 @@ def test_launch_report_of_a_hinted_batch_of_small_rois(hip_ctx):
     rep = hip_ctx.launch_report()
     # (round 6: two feature launches on stated extrema beyond the smallest class -- the wave-per-ROI kernel filtered to class 0, then everybody else)
     assert [r["class"] for r in rep] == [-2, -3] and all(r["rois"] == 196 and r["workspace"] == 0 for r in rep), rep
-    rois = synth.random_rois(40, seed=3, rmax=20, value_modes=(4096, 256, 8))         # both shape builds (one-wave for the smallest class)
+    rois = synth.random_rois(80, seed=3, rmax=20, value_modes=(4096, 256, 8))         # both shape builds (one-wave for the smallest class)
+    big = [r for r in rois if len(r["x"]) > 256]
+    rois = big + [r for r in rois if len(r["x"]) <= 256][:len(big) // 6]              # (the smallest class rare: see the census test below)
     hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK | _abi.FAM_ZERNIKE | _abi.FAM_GLSZM, s)
     assert sorted(r["class"] for r in hip_ctx.launch_report()) == [-5, -4, -3, -2, -1]
     rois = synth.random_rois(40, seed=3, rmax=20)                     # value modes up to 2^32 - 1: wide ranges are possible -> exact classes
     hip_ctx.featurize_host(_abi.batch_from_rois(rois), MASK, s)
     assert all(r["class"] >= 0 for r in hip_ctx.launch_report()) and any(r["wide_range"] == 1 for r in hip_ctx.launch_report())
+
+
+def test_census_of_the_smallest_class_picks_lists_or_filtered_launches(hip_ctx):
+    """A batch on stated extrema that mixes the two smallest size classes: filtered whole-batch launches while the smallest class is rare
+    (nothing counted, no host round trip), exact class lists once the census of the previous calls says it is common.  Same rows either way;
+    a host batch is counted on the host, a device batch by the scanning kernel (read with the status flag at the next sync)."""
+    import torch
+    rng = np.random.default_rng(12)
+    small = [ellipse_roi(int(rng.integers(3, 9)), int(rng.integers(3, 9)), rng) for _ in range(60)]
+    mid = [ellipse_roi(int(rng.integers(12, 30)), int(rng.integers(12, 30)), rng) for _ in range(12)]
+    s = _abi.default_settings(8)
+    dev = torch.device("cuda", 0)
+
+    def device_call(rois):
+        b = _abi.batch_from_rois(rois)
+        keep = {k: torch.from_numpy(getattr(b, k).view({2: np.int16, 4: np.int32, 8: np.int64}[getattr(b, k).dtype.itemsize])).to(dev)
+                for k in ("px_offset", "x", "y", "inten", "bbox_w", "bbox_h", "min_inten", "max_inten")}
+        cb = b.c_struct()
+        for k, t in keep.items():
+            setattr(cb, k, t.data_ptr())
+        cb.slide_min = None; cb.slide_max = None; cb.memory = _abi.MEM_DEVICE
+        ncol = hip_ctx.n_columns(MASK, s)
+        out = torch.full((b.n_roi, ncol), -1.0, dtype=torch.float64, device=dev)
+        hip_ctx.featurize_device_async(cb, MASK, s, out.data_ptr(), ncol)
+        rep = [r["class"] for r in hip_ctx.launch_report()]
+        hip_ctx.sync()
+        return out.cpu().numpy(), rep, b
+    # a device batch of class 1 only resets the census (its scan meets no small ROI)
+    device_call(mid)
+    T1, rep1, b = device_call(small + mid)          # census: nothing small seen -> filtered launches; their scan counts 60 of 72
+    T2, rep2, _ = device_call(small + mid)          # -> exact lists
+    assert rep1 == [-2, -3] and all(c >= 0 for c in rep2) and 0 in rep2, (rep1, rep2)
+    assert np.array_equal(T1.view(np.uint64), T2.view(np.uint64))
+    assert not parity.compare_tables(T1, po.oracle_featurize(b, MASK, s), _lib.column_names(MASK, s), batch=b)
+    T3, rep3, _ = device_call(mid + small[:2])      # the lists' headers said 60 of 72: still lists; they now say 2 of 14
+    T4, rep4, _ = device_call(mid + small[:2])      # -> filtered launches again
+    assert all(c >= 0 for c in rep3) and rep4 == [-2, -3], (rep3, rep4)
+    assert np.array_equal(T3.view(np.uint64), T4.view(np.uint64))
+    # host batches are counted on the host: the right form at once
+    hip_ctx.featurize_host(_abi.batch_from_rois(small + mid), MASK, s)
+    assert all(r["class"] >= 0 for r in hip_ctx.launch_report())
+    hip_ctx.featurize_host(_abi.batch_from_rois(mid + small[:2]), MASK, s)
+    assert [r["class"] for r in hip_ctx.launch_report()] == [-2, -3]
 
 
 def test_a_wrong_statement_about_the_batch_is_an_error(hip_ctx):
