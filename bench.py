@@ -344,16 +344,20 @@ class Bench:
         for i in range(a.warmup):
             step(i)
         self.fence()
-        ctx.timing(True)
+        # roofline.achieved: the launch group's device time from TWO HIP events on the launch stream (the library launches on torch's
+        # current stream, make_batch) around the K timed steps.  (The library's own hooks -- nyxhip_timing_enable -- record two events per
+        # call: each is a marker packet the command processor handles between kernels, ~15 us per step boundary = 0.7 % of the headline.)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record()
         last = None
         for i in range(a.steps):
             last = step(i)
+        e1.record()
         self.fence()
         t1 = time.perf_counter()
         ctx.sync()                               # raises on a device-side error flag
-        self.kern_ms, self.n_launch = ctx.timing_get()
-        ctx.timing(False)
+        self.kern_ms, self.n_launch = e0.elapsed_time(e1) / max(a.steps, 1), a.steps
         self.last, self.t_steps = last, t1 - t0
 
     def ranks_and_gather(self):

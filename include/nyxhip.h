@@ -289,7 +289,10 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
  * Average device time (ms) per featurize call since the last nyxhip_timing_reset(),
  * measured with hipEvents recorded on the launch stream around EVERYTHING the call
  * enqueues (all kernel groups, the moments pair, the large-ROI passes).  Used by
- * bench.py for `roofline.achieved`. */
+ * bench.py for `roofline.achieved`.  on = 1: those two events per call; on = 2: also two
+ * events around every launch group of the call (the "ms" of nyxhip_launch_report) -- each
+ * recorded event is a marker packet on the stream, a handful of microseconds of device
+ * time, so the per-group level is for diagnosis, not for the timed region of a benchmark. */
 int nyxhip_timing_enable(nyxhip_ctx* ctx, int on);
 int nyxhip_timing_reset(nyxhip_ctx* ctx);
 int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launches);
@@ -306,7 +309,7 @@ int nyxhip_timing_get(nyxhip_ctx* ctx, double* avg_kernel_ms, uint64_t* n_launch
  * GLCM, bit 1 GLRLM + GLSZM + NGTDM;
  * "ms" = device time of the class's launches on the call's stream and "lane_ms" = fork-to-end time of the class's workspace
  * launches on their own stream (large classes run them beside the main stream; null otherwise) when
- * nyxhip_timing_enable(ctx, 1) was in force for the call (waits for them), else null.  Counterpart in the
+ * nyxhip_timing_enable(ctx, 2) was in force for the call (waits for them), else null.  Counterpart in the
  * reference: none -- its worker threads take ROIs of any size (parallel.h:23-42); here a launch is sized by its largest
  * ROI, so a call is split by ROI size.  Returns the number of bytes the full text needs (excluding the NUL), or < 0. */
 int nyxhip_launch_report(nyxhip_ctx* ctx, char* buf, size_t buf_len);

@@ -260,8 +260,9 @@ class Context:
     def sync(self):
         self._check(self._lib.nyxhip_sync(self._h))
 
-    def timing(self, on: bool):
-        self._check(self._lib.nyxhip_timing_enable(self._h, 1 if on else 0))
+    def timing(self, on: bool, groups: bool = False):
+        """on: two events around every call (timing_get); groups: also around every launch group (the "ms" of launch_report)."""
+        self._check(self._lib.nyxhip_timing_enable(self._h, (2 if groups else 1) if on else 0))
         self._check(self._lib.nyxhip_timing_reset(self._h))
 
     def timing_reset(self):

@@ -134,7 +134,7 @@ struct nyxhip_ctx {
     void* d_large_aux = nullptr;
     size_t large_aux_bytes = 0;
     // timing
-    bool timing = false;
+    int timing = 0;            // 0 off | 1 two events around every call (nyxhip_timing_get) | 2 also two events around every launch group (nyxhip_launch_report's ms)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t ev_used = 0;
     hipStream_t stream() const { return use_user_stream ? user_stream : own_stream; }
@@ -1509,7 +1509,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             lds &= ~2u;
             if (report) {
                 report->cooperative |= 2;
-                if (ctx->timing) { if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2)); HIP_TRY(ctx, hipEventRecord(report->e2, st)); }
+                if (ctx->timing >= 2) { if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2)); HIP_TRY(ctx, hipEventRecord(report->e2, st)); }
             }
         }
         st = main_st;
@@ -1599,7 +1599,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
             return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
     if (!gs) {
-        if (on_lds_lane && report && ctx->timing) {
+        if (on_lds_lane && report && ctx->timing >= 2) {
             if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2));      // (the size-class-2 texture branch may have made it already: that one is on its lane's stream)
             else return NYXHIP_OK;
             HIP_TRY(ctx, hipEventRecord(report->e2, st));
@@ -1625,7 +1625,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
     if (lane >= 0)
         if (int lrc2 = enter_lane(lane)) return lrc2;
     auto lane_stamp = [&]() -> int {
-        if (lane >= 0 && report && ctx->timing) {
+        if (lane >= 0 && report && ctx->timing >= 2) {
             if (!report->e2) HIP_TRY(ctx, hipEventCreate(&report->e2));
             HIP_TRY(ctx, hipEventRecord(report->e2, st));
         }
@@ -1751,13 +1751,13 @@ int launch_device_all(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, con
     auto timed_class = [&](int cls, uint32_t count, const Extrema& E, const uint32_t* lp, uint32_t grid, uint32_t class_mask = 0, uint32_t group_sel = 0xF,
                            const ClassTotals* tot = nullptr) -> int {
         ClassRun r{cls, count, E, 0, nullptr, nullptr};
-        if (ctx->timing) {
+        if (ctx->timing >= 2) {
             HIP_TRY(ctx, hipEventCreate(&r.e0));
             HIP_TRY(ctx, hipEventCreate(&r.e1));
             HIP_TRY(ctx, hipEventRecord(r.e0, st));
         }
         const int rc = run_class(ctx, b, mask, s, d_out, ld, E, lp, grid, false, nullptr, &r, class_mask, group_sel, cls, tot);
-        if (ctx->timing && rc == 0) HIP_TRY(ctx, hipEventRecord(r.e1, st));
+        if (ctx->timing >= 2 && rc == 0) HIP_TRY(ctx, hipEventRecord(r.e1, st));
         ctx->runs.push_back(r);
         return rc;
     };
@@ -2760,7 +2760,7 @@ int nyxhip_featurize_tiles(nyxhip_ctx* ctx, const uint32_t* inten, const uint32_
 int nyxhip_timing_enable(nyxhip_ctx* ctx, int on)
 {
     if (!ctx) return NYXHIP_ERR_INVALID_ARG;
-    ctx->timing = on != 0;
+    ctx->timing = on < 0 ? 0 : on > 2 ? 2 : on;
     return NYXHIP_OK;
 }
 

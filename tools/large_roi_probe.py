@@ -33,7 +33,7 @@ def main():
     b = sl.DeviceBatch([(a.a, a.b)] * a.n, dev, seed=9, hi=a.hi)
     out = torch.empty((b.n_roi, ctx.n_columns(a.families, s)), dtype=torch.float64, device=dev)
     dt = sl.time_call(ctx, b, a.families, s, out, reps=2)
-    ctx.timing(True)
+    ctx.timing(True, groups=True)
     ctx.featurize_device_async(b.cb, a.families, s, out.data_ptr(), out.shape[1])
     torch.cuda.synchronize()
     rep = ctx.launch_report()

@@ -146,7 +146,7 @@ def mixed_sizes(ctx, dev, mask, s, n_roi=40_000, check=None):
     rec["histogram"] = [{"px_le": e1, "rois": int(((n > e0) & (n <= e1)).sum()), "pixel_share": float(n[(n > e0) & (n <= e1)].sum() / n.sum())}
                         for e0, e1 in zip(edges[:-1], edges[1:])]
     if hasattr(ctx, "launch_report"):
-        ctx.timing(True)
+        ctx.timing(True, groups=True)
         ctx.featurize_device_async(b.cb, mask, s, out.data_ptr(), out.shape[1])
         torch.cuda.synchronize()
         rec["classes"] = ctx.launch_report()
