@@ -550,7 +550,7 @@ class Bench:
         return {"value": k_ / sec_, "unit": "ROIs/s", "cores": thr_, "kind": kind_, "host_cpus": cores_,
                 "sample": f"the first {k_} ROIs of this leg's batch, {what}, reduce stage only ({sec_:.2f} s)"}
 
-    def timed(self, msk, st, cbatch, n_rows, reps=3, check_rows=None, arrays=None, all_rows=False):
+    def timed(self, msk, st, cbatch, n_rows, reps=8, check_rows=None, arrays=None, all_rows=False):
         """One leg: warm-up call, `reps` timed calls; the parity gate (rows `check_rows` of the table vs the oracle) on what it left.
         Returns (seconds per call, columns, gate string or None, error margins)."""
         torch, ctx = self.torch, self.ctx
@@ -562,8 +562,8 @@ class Bench:
         for _ in range(reps):
             ctx.featurize_device_async(cbatch, msk, st, o.data_ptr(), nc)
         torch.cuda.synchronize()
-        ctx.sync()
         dt_ = (time.perf_counter() - c0) / reps
+        ctx.sync()                               # (reads the error flag: raises on a device-side error)
         par = None
         margin = {}
         if check_rows is not None and not self.a.no_check:

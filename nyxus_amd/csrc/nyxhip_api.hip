@@ -117,7 +117,10 @@ struct nyxhip_ctx {
     // by a few hundred workgroups at most -- a fraction of the chip.  Each large class runs them on a stream of its own beside the
     // main stream (which goes on with the several-workgroups-per-ROI kernels and the LDS classes), with scratch of its own; the
     // lanes are forked from the main stream at the start of a call and joined into it at its end.
-    static constexpr int kLanes = 8;               // 0-3: the large classes; 4-6: the LDS size classes of an exact call (run_class)
+    static constexpr int kLanes = 12;              // 0-3: the large classes; 4-6: the LDS size classes of an exact call (run_class);
+                                                   // 8, 10: contour + moments of a batch with boxes beyond LDS (the bulk | the big boxes);
+                                                   // 9: the dependence trio of a large class; 11: Gabor of size class 2 beside the smaller classes
+    static constexpr int kMomLane = 8, kDepLane = 9, kMomLaneBig = 10, kGaborLane = 11;
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t lane_done[kLanes] = {};
     hipEvent_t lane_fork = nullptr;
@@ -938,12 +941,42 @@ __global__ void classify_plane_kernel(uint64_t n_roi, const uint32_t* bw, const 
         list[atomicAdd(n_out, 1u)] = (uint32_t)i;
 }
 
+// A workspace lane: a high-priority stream forked from the call's stream (nyxhip_ctx::lane_fork, recorded at the start of launch_device_all),
+// joined into it at the end of the call (LaneJoin).  The lanes carry chains of short, latency-bound kernels -- a few hundred workgroups each --
+// beside the main stream's chip-filling grids: at the device's highest priority their workgroups are placed first and the chain is not starved.
+int use_lane(nyxhip_ctx* ctx, int lane, hipStream_t* st)
+{
+    if (!ctx->lane_stream[lane]) {
+        static const bool no_prio = [] { const char* e = getenv("NYXHIP_NO_LANE_PRIORITY"); return e && *e && *e != '0'; }();   // A/B knob
+        int lo = 0, hi = 0;
+        if (no_prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->lane_stream[lane], hipStreamNonBlocking, hi));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+    }
+    if (!ctx->lane_used[lane]) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork, 0));   // the batch and the class lists are complete on the main stream
+        ctx->lane_used[lane] = true;
+    }
+    *st = ctx->lane_stream[lane];
+    return NYXHIP_OK;
+}
+
 // Contour + 2-D geometric moments (roi_moments.hip).  The contour of every ROI goes to a context-owned workspace at the
 // ROI's CSR offset (a contour never has more points than the ROI has pixels); the moments kernel reads it back.
 int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhip_settings* s, double* d_out, size_t ld,
                    uint32_t max_px, uint32_t max_area, uint32_t max_side)
 {
     hipStream_t st = ctx->stream();
+    // A batch with boxes beyond the LDS plane sends those to a wave per ROI over a global workspace (a few hundred waves, ~10 ms of
+    // latency for the heavy-tailed batch): with other families in the call the whole moments chain goes to a lane of its own and
+    // runs beside them (enqueued last, dependent only on the batch).  Its scratch is the lane's, not the main stream's.
+    static const bool no_mom_lane = [] { const char* e = getenv("NYXHIP_NO_MOM_LANE"); return e && *e && *e != '0'; }();   // A/B knob
+    const bool big_boxes = (uint64_t)kContourWaves * (((uint64_t)max_area + 4ull * max_side + 4 + 15) & ~15ull) > (uint64_t)roi_features_max_lds();
+    const bool on_lane = !no_mom_lane && big_boxes && (mask & ~kMoments) && ctx->lane_fork;
+    if (on_lane)
+        if (int lrc = use_lane(ctx, nyxhip_ctx::kMomLane, &st)) return lrc;
+    unsigned char** const spillp = on_lane ? &ctx->lane_buf[nyxhip_ctx::kMomLane] : &ctx->d_spill;
+    size_t* const spill_bytesp = on_lane ? &ctx->lane_bytes[nyxhip_ctx::kMomLane] : &ctx->spill_bytes;
     uint64_t total_px = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total_px, b->px_offset + b->n_roi, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -983,49 +1016,61 @@ int launch_moments(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const 
     if ((uint64_t)kContourWaves * ((full_plane + 15) & ~15ull) <= lds_cap) {   // kContourWaves planes per workgroup
         m.plane_cap = (uint32_t)full_plane;
         rc = launch_roi_contour(m, st, grid);
+        if (rc == 0) rc = launch_roi_moments(m, st, grid);
     } else {
-        // the bulk of the batch from LDS (16 KiB planes keep ten waves per CU), the oversized ROIs from a global workspace
+        // the bulk of the batch from LDS (16 KiB planes keep ten waves per CU), the oversized ROIs from a global workspace: a wave per ROI,
+        // a few hundred waves and ~10 ms of latency for the heavy-tailed batch.  Two independent chains -- big boxes: list, contour over the
+        // workspace, moments of the list | bulk: contour from LDS (skipping the big boxes), moments of everybody else -- on two lanes when
+        // the call has lanes (other families to run beside), one after the other on the call's stream otherwise.
         m.plane_cap = 16 * 1024;
-        m.sp.defer_large = 1;
-        rc = launch_roi_contour(m, st, grid);
-        if (rc == 0) {
-            const size_t list_bytes = 4ull * b->n_roi + 256;
-            if (list_bytes > ctx->spill_list_bytes) {
-                if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
-                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
-                ctx->spill_list_bytes = list_bytes;
+        hipStream_t st_big = st;
+        if (on_lane)
+            if (int lrc = use_lane(ctx, nyxhip_ctx::kMomLaneBig, &st_big)) return lrc;
+        const size_t list_bytes = 4ull * b->n_roi + 256;
+        if (list_bytes > ctx->spill_list_bytes) {
+            if (ctx->d_spill_list) { HIP_TRY(ctx, hipStreamSynchronize(st_big)); HIP_TRY(ctx, hipFree(ctx->d_spill_list)); ctx->d_spill_list = nullptr; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_list, list_bytes));
+            ctx->spill_list_bytes = list_bytes;
+        }
+        uint32_t* d_cnt = ctx->d_spill_list;
+        uint32_t* d_list = ctx->d_spill_list + 64;
+        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st_big));
+        hipLaunchKernelGGL(classify_plane_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st_big, b->n_roi, b->bbox_w, b->bbox_h,
+                           m.plane_cap, d_list, d_cnt);
+        uint32_t n_large = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_large, d_cnt, 4, hipMemcpyDeviceToHost, st_big));
+        HIP_TRY(ctx, hipStreamSynchronize(st_big));
+        rc = 0;
+        if (n_large) {
+            if (full_plane > 0xFFFFFFF0ull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "bounding box too large for the contour plane");
+            const size_t stride = al((size_t)full_plane);
+            const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, ((size_t)4 << 30) / stride));
+            const size_t sneed = stride * chunk;
+            if (sneed > *spill_bytesp) {
+                if (*spillp) { HIP_TRY(ctx, hipFree(*spillp)); *spillp = nullptr; *spill_bytesp = 0; }
+                HIP_TRY(ctx, hipMalloc((void**)spillp, sneed));
+                *spill_bytesp = sneed;
             }
-            uint32_t* d_cnt = ctx->d_spill_list;
-            uint32_t* d_list = ctx->d_spill_list + 64;
-            HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st));
-            hipLaunchKernelGGL(classify_plane_kernel, dim3((unsigned)((b->n_roi + 255) / 256)), dim3(256), 0, st, b->n_roi, b->bbox_w, b->bbox_h,
-                               m.plane_cap, d_list, d_cnt);
-            uint32_t n_large = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&n_large, d_cnt, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (n_large) {
-                if (full_plane > 0xFFFFFFF0ull) return fail(ctx, NYXHIP_ERR_ROI_TOO_LARGE, "bounding box too large for the contour plane");
-                const size_t stride = al((size_t)full_plane);
-                const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_large, ((size_t)4 << 30) / stride));
-                const size_t sneed = stride * chunk;
-                if (sneed > ctx->spill_bytes) {
-                    if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
-                    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, sneed));
-                    ctx->spill_bytes = sneed;
-                }
-                MomArgs m2 = m;
-                m2.plane_cap = (uint32_t)full_plane;
-                m2.sp.defer_large = 0;
-                m2.sp.scratch = ctx->d_spill; m2.sp.stride = stride;
-                for (uint32_t o = 0; o < n_large && rc == 0; o += chunk) {
-                    m2.sp.roi_index = d_list + o;
-                    rc = launch_roi_contour(m2, st, std::min(chunk, n_large - o));
-                }
+            MomArgs m2 = m;
+            m2.plane_cap = (uint32_t)full_plane;
+            m2.sp.defer_large = 0;
+            m2.sp.scratch = *spillp; m2.sp.stride = stride;
+            for (uint32_t o = 0; o < n_large && rc == 0; o += chunk) {
+                m2.sp.roi_index = d_list + o;
+                rc = launch_roi_contour(m2, st_big, std::min(chunk, n_large - o));
+            }
+            if (rc == 0) {                                    // moments of the big boxes: the list
+                MomArgs m3 = m;
+                m3.sp.roi_index = d_list;
+                rc = launch_roi_moments(m3, st_big, n_large);
             }
         }
+        if (rc == 0) {
+            m.sp.defer_large = 1;                             // both kernels skip the big boxes
+            rc = launch_roi_contour(m, st, grid);
+            if (rc == 0) rc = launch_roi_moments(m, st, grid);
+        }
     }
-    if (rc == 0)
-        rc = launch_roi_moments(m, st, grid);
     if (rc != 0)
         return fail(ctx, NYXHIP_ERR_HIP, std::string("moments kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     return NYXHIP_OK;
@@ -1463,23 +1508,7 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
 
     hipStream_t st = ctx->stream();
     int rc = 0;
-    auto enter_lane = [&](int lane) -> int {             // the class's launches go to lane `lane`, forked from the main stream at the start of the call
-        if (!ctx->lane_stream[lane]) {
-            // (the lanes carry chains of short, latency-bound kernels -- a few hundred workgroups each -- beside the main stream's
-            //  chip-filling grids: at the device's highest priority their workgroups are placed first and the chain is not starved)
-            static const bool no_prio = [] { const char* e = getenv("NYXHIP_NO_LANE_PRIORITY"); return e && *e && *e != '0'; }();   // A/B knob
-            int lo = 0, hi = 0;
-            if (no_prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->lane_stream[lane], hipStreamNonBlocking, hi));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
-        }
-        if (!ctx->lane_used[lane]) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork, 0));   // the batch and the class lists are complete on the main stream
-            ctx->lane_used[lane] = true;
-        }
-        st = ctx->lane_stream[lane];
-        return NYXHIP_OK;
-    };
+    auto enter_lane = [&](int lane) -> int { return use_lane(ctx, lane, &st); };   // the class's launches go to lane `lane`, forked from the main stream at the start of the call
     // The launch groups of the LDS size classes are independent of each other and could each take a stream of their own (the tail of
     // one class's grid beside the next class's launches).  Measured on the mixed batch with the config-4 families: 3.51 ms against
     // 3.28 ms on one stream -- the chip is busy either way, and the interleaved classes evict each other's L2 lines.  Off unless asked
@@ -1594,7 +1623,16 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         }
         if (rc == 0 && (lds & 2)) rc = launch_roi_texture(t, st, grid);
         if (rc == 0 && (lds & 8)) rc = launch_roi_dependence(d, st, grid);
-        if (rc == 0 && (lds & 4)) rc = launch_roi_shape(g, st, grid);
+        if (rc == 0 && (lds & 4)) {
+            // Size class 2 and Gabor: boxes of 65..128 px hold 87 KB of LDS in the tiled kernel -- one workgroup per CU, ~11 ms for the
+            // 2 031 such ROIs of the heavy-tailed batch, with three quarters of every CU's wave slots idle.  On a lane of its own the
+            // smaller classes' launches (and this class's other families) run beside it instead of behind it.
+            static const bool no_gabor_lane = [] { const char* e = getenv("NYXHIP_NO_GABOR_LANE"); return e && *e && *e != '0'; }();   // A/B knob
+            hipStream_t gst = st;
+            if (!no_gabor_lane && list && cls / 2 == 2 && (mask & NYXHIP_FAM_GABOR) && !on_lds_lane && !ctx->win_next.inten)
+                if (int lrc = use_lane(ctx, nyxhip_ctx::kGaborLane, &gst)) return lrc;
+            rc = launch_roi_shape(g, gst, grid);
+        }
         if (rc != 0)
             return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     }
@@ -1677,6 +1715,30 @@ int run_class(nyxhip_ctx* ctx, const nyxhip_batch* b, uint32_t mask, const nyxhi
         set_slots(gz.sp, list, grid);
         rc = launch_roi_shape(gz, st, grid);
         if (rc != 0) return fail(ctx, NYXHIP_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    }
+    // The dependence trio of a large class (one workgroup per ROI over the workspace: a few hundred workgroups, ~11 ms for the heavy-tailed
+    // batch) on a lane and a scratch buffer of its own: it runs beside the class's other chains instead of behind them.
+    static const bool no_dep_lane = [] { const char* e = getenv("NYXHIP_NO_DEP_LANE"); return e && *e && *e != '0'; }();   // A/B knob
+    if ((gs & 8) && lane >= 0 && !no_dep_lane && gs != 8u) {
+        hipStream_t dst = st;
+        if (int lrc2 = use_lane(ctx, nyxhip_ctx::kDepLane, &dst)) return lrc2;
+        const size_t dstride = (d2.L.total + 255) & ~(size_t)255;
+        const uint32_t dchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(grid, budget / std::max<size_t>(dstride, 1)));
+        unsigned char** const dbuf = &ctx->lane_buf[nyxhip_ctx::kDepLane];
+        size_t* const dbytes = &ctx->lane_bytes[nyxhip_ctx::kDepLane];
+        if (dstride * dchunk > *dbytes) {
+            if (*dbuf) { HIP_TRY(ctx, hipStreamSynchronize(dst)); HIP_TRY(ctx, hipFree(*dbuf)); *dbuf = nullptr; *dbytes = 0; }
+            HIP_TRY(ctx, hipMalloc((void**)dbuf, dstride * dchunk));
+            *dbytes = dstride * dchunk;
+        }
+        for (uint32_t o = 0; o < grid; o += dchunk) {
+            const uint32_t nb = std::min(dchunk, grid - o);
+            set_slots(d2.sp, list + o, nb);
+            d2.sp.scratch = *dbuf; d2.sp.stride = dstride;
+            if (int drc = launch_roi_dependence(d2, dst, nb))
+                return fail(ctx, NYXHIP_ERR_HIP, std::string("large-ROI kernel launch failed: ") + hipGetErrorString((hipError_t)drc));
+        }
+        gs &= ~8u;
     }
     for (uint32_t o = 0; o < grid; o += chunk) {
         const uint32_t nb = std::min(chunk, grid - o);

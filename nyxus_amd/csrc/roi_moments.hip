@@ -441,11 +441,14 @@ __global__ __launch_bounds__(kMB, OCC) void roi_moments_kernel(const MomArgs A)
     uint32_t* const s_K = (uint32_t*)(mom_lds + 8u * A.px_cap);           // [A.k_cap]
     uint16_t* const s_step = (uint16_t*)(s_K + A.k_cap);                  // [A.step_cap]
     const int tid = threadIdx.x;
-    const uint64_t roi = blockIdx.x;
+    const uint64_t roi = A.sp.roi_index ? A.sp.roi_index[blockIdx.x] : blockIdx.x;   // (a list: the big boxes of a batch, launch_moments)
     if (roi >= A.n_roi)
         return;
     const uint64_t off = A.px_offset[roi];
     const uint32_t n = (uint32_t)(A.px_offset[roi + 1] - off);
+    // (a launch over the bulk of a batch whose big boxes -- planes beyond the LDS contour kernel's -- go through a list of their own)
+    if (A.sp.defer_large && (A.bbox_w[roi] + 2u) * (A.bbox_h[roi] + 2u) > A.plane_cap)
+        return;
     double* const row_out = A.out + roi * A.ld;
     const bool do_s = (A.mask & NYXHIP_FAM_SMOMS) != 0, do_i = (A.mask & NYXHIP_FAM_IMOMS) != 0;
     if (n == 0) {
