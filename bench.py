@@ -57,8 +57,8 @@ def gabor_roofline(alg_flops, dt, bbox_w, bbox_h, max_inten, n_filters):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tiles", type=int, default=1000, help="tiles per GPU per step")
     ap.add_argument("--gray-depth", type=int, default=8)
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU-baseline sample (0 = auto)")
@@ -811,7 +811,7 @@ class Bench:
                             "rois": int(nroi.value), "ms_per_call": 1e3 * dt, "parity_check": par_t, "max_rel_err": getattr(tile_gate, "margin", None),
                             "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                             "traffic_bytes_per_tile": tp_traffic, "traffic_ratio": (tp_traffic / (tile_bytes / nt)) if tp_traffic else None,
-                            "traffic_source": "replayed from profiles/hbm_traffic.json (profiles/r06_tilepath_traffic.txt)" if tp_traffic else None,
+                            "traffic_source": "replayed from profiles/hbm_traffic.json (profiles/r06c_tilepath_traffic.txt)" if tp_traffic else None,
                             "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                     "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
                                     "(no materialised clouds; one host sync inside for the ROI count)"}
