@@ -519,237 +519,25 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
     wav_sync<false>();
 }
 
-// ---- GLCM features of a matrix of up to 64 levels: one wave per angle, lane = column (the reference's default grey depth) ----
-// Same organisation as glcm_features_wave16 (marginal sums carry everything they can, only ASM / ACOR / ENTROPY / JMAX / the
-// covariance term / HXY1 / HXY2 visit the cells), on the 16-bit matrices of the G16 launches: element (centre, neighbour) of
-// level values 1..Ng sits at P[centre * S + neighbour], S = Ng + 1 (row 0 / column 0 collect the skipped pairs).
-// Level values are I[i] = i + 1 (matlab binning).  prow_s: [Ng] doubles of LDS (row marginals, broadcast to the lanes per row).
-__device__ __forceinline__ void glcm_features_wave64_u16(const uint16_t* P, int Ng, double* prow_s, double soft_nan, double* f, double* sm, int lane)
-{
-    const int S = Ng + 1;
-    const bool act = lane < Ng;                        // lane l owns column l, row l and the diagonal pair |x - y| = l
-    // ---- marginal counts in ONE pass over the rows (lane = column): the column sums accumulate in place, and the two families of
-    // diagonals ride along in registers that move one lane per row -- W(lane) holds the partial sum of the diagonal through
-    // (r, lane) (index c - r, shifts right), X(lane) that of the anti-diagonal (index r + c, shifts left).  A diagonal is
-    // complete when it leaves the matrix: upper diagonals (c - r = d >= 0) end in lane Ng - 1 at row Ng - 1 - d, anti-diagonals
-    // k <= Ng - 2 end in lane 0 at row k; each is picked off with a v_readlane and a select into the lane that owns it.
-    // What is still travelling after the last row -- the lower diagonals in W, the anti-diagonals k >= Ng - 1 in X -- is fetched
-    // with one ds_bpermute each.  ~10 vector instructions per row instead of three per-lane walks over the matrix (1.3 k -> 0.8 k).
-    uint32_t cc = 0, rc = 0, dc = 0;
-    uint32_t pxpy_c[2] = {0u, 0u};                     // counts of p_{x+y}: k = lane and k = lane + 64
-    {
-        uint32_t W = 0, X = 0;
-        const uint16_t* pcol_cells = P + S + lane + 1; // (row 1, column lane + 1)
-        // (a complete diagonal is stored by the one lane that holds it -- the row-marginal scratch is free until the pass is over --
-        //  and collected with one read per lane behind the loop: a v_readlane + compare + select per family and row before)
-        uint32_t* const pickX = (uint32_t*)prow_s;     // [k]: anti-diagonal k <= Ng - 2, complete in lane 0 before the shift of row k + 1
-        uint32_t* const pickW = pickX + Ng;            // [r]: upper diagonal Ng - 1 - r, complete in lane Ng - 1 after row r  (2 Ng words = the Ng doubles)
-        const bool first = lane == 0, last = lane == Ng - 1;
-        for (int r = 0; r < Ng; r++) {
-            const uint32_t cnt = act ? pcol_cells[r * S] : 0u;
-            cc += cnt;
-            if (r >= 1 && first) pickX[r - 1] = X;
-            X = lane_plus1_z(X) + cnt;
-            W = lane_minus1_z(W) + cnt;
-            if (last) pickW[r] = W;
-        }
-        wav_sync<false>();
-        const uint32_t dlo = lane < Ng - 1 ? pickX[lane] : 0u;
-        const uint32_t eup = act ? pickW[Ng - 1 - lane] : 0u;
-        wav_sync<false>();                             // (the scratch takes the row marginals below)
-        // lower diagonal d (>= 1) waits in lane Ng - 1 - d of W; anti-diagonal k >= Ng - 1 in lane k - (Ng - 1) of X
-        const uint32_t wrev = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (Ng - 1 - lane), (int)W);
-        dc = act ? eup + (lane >= 1 ? wrev : 0u) : 0u;
-        const int k0 = lane, k1 = lane + 64;
-        const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (k0 - (Ng - 1)), (int)X);
-        const uint32_t xb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (k1 - (Ng - 1)), (int)X);
-        pxpy_c[0] = k0 < Ng - 1 ? dlo : (k0 <= 2 * Ng - 2 ? xa : 0u);
-        pxpy_c[1] = k1 <= 2 * Ng - 2 ? xb : 0u;       // (k1 >= 64 > Ng - 2: always in X)
-        if (act) {                                     // row sums: lane = row, a walk along the row
-            const uint16_t* pr = P + (lane + 1) * S + 1;
-            for (int j = 0; j < Ng; j++) rc += pr[j];
-        }
-    }
-    const uint32_t l1 = (uint32_t)lane + 1u;
-    const uint32_t csum = wave_sum_t<uint32_t>(rc);    // sum_p (glcm.cpp:481-484)
-    // (24-bit products: a plain 32-bit multiply issues at a quarter of the rate)
-    const uint32_t Sr_i = wave_sum_t<uint32_t>(mul24(rc, l1)), Sc_i = wave_sum_t<uint32_t>(mul24(cc, l1));
-    const uint32_t con_i = wave_sum_t<uint32_t>(mul24(dc, mul24((uint32_t)lane, (uint32_t)lane))), dis_i = wave_sum_t<uint32_t>(mul24(dc, (uint32_t)lane));
-    const bool empty = csum == 0;
-    const double sum_p = empty ? 1.0 : (double)csum;
-    const double inv_sum_p = fdiv(1.0, sum_p);
-    const double mr = fdiv((double)Sr_i, sum_p), mc = fdiv((double)Sc_i, sum_p);
-    const double pcol = fdiv((double)cc, sum_p), prow = fdiv((double)rc, sum_p), pxmy = fdiv((double)dc, sum_p);
-    if (act) prow_s[lane] = prow;
-    // p_{x+y}: lane k owns k and k + 64 (k <= 2 Ng - 2); the counts were gathered by the pass above
-    double pxpy[2] = {0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-        if (lane + 64 * u < 2 * Ng - 1) pxpy[u] = fdiv((double)pxpy_c[u], sum_p);
-    wav_sync<false>();
-
-    // ---- the cell pass: lane = column, rows in sequence ------------------------------------------------------------------------
-    // A cell's own quantities are integer work (ASM = sum cnt^2 / sum_p^2, ACOR and the covariance numerator
-    // acor * sum_p - S_r * S_c exactly, JMAX from the largest count; sum_p < 65536 in a G16 launch, so every sum fits 32 bits);
-    // the entropy term p lg(p + eps) depends on the count alone: the 16 smallest counts -- all of them on a textured ROI -- come
-    // from a table built once per angle; only the two HXY terms need a float log per cell.
-    double* const Tent = sm + 32 - 16;                               // sm[16..31]: entropy terms of counts 0..14, [15] = 0 (batch 2 uses sm[8..23] later)
-    if (lane < 16) {
-        const double pk = (double)lane * inv_sum_p;
-        Tent[lane] = lane < 15 ? pk * (double)fast_log2f(pk + 0.000000001) : 0.0;
-    }
-    wav_sync<false>();
-    double ent = 0, hxy1c = 0, hxy2 = 0;
-    uint32_t acor_i = 0, asm_i = 0, cmax = 0;
-    const uint16_t* pcell = P + S + lane + 1;
-    // Rows are visited in GROUPS of equal row marginal: the float log of p_x(i) p_y(j) + eps -- the reference's quadratic, 19 of a
-    // cell's 45 instructions with its conversions -- depends on the row only through its marginal count, and the 64 rows of a
-    // textured ROI share ~25 distinct counts (Poisson around n / 64).  One log per group and column; HXY2 takes the group's
-    // multiplicity, HXY1 the group's count per column against the group's log (scaled by 1 / sum_p once at the end).  Rows with an
-    // empty marginal hold no pair and are skipped (narrow histograms: most of the 64 levels of real images).  The group loop runs
-    // on the scalar unit (ballot, s_ff1, bit clears).
-    // The row step is seven vector instructions: lanes beyond the matrix order read cells of the next row and are cleared behind the
-    // loop (no mask inside it), a cell's count joins its group's integer sum (one conversion and one multiply-add per group, not
-    // per cell), and the entropy term is a table read for every cell -- counts of 15 and more (none on textured data: a 64 x 64
-    // matrix of a 2821-pixel ROI holds 0.7 pairs per cell) read a zero and are added by a second walk that runs only if one exists.
-    unsigned long long rem = __ballot(act && rc != 0u);
-    while (rem) {
-        const int r0 = (int)__builtin_ctzll(rem);
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)rc, r0);
-        const unsigned long long pbits = (unsigned long long)__double_as_longlong(prow);
-        const double pr = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), r0) << 32) |
-                                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, r0)));
-        unsigned long long grp = __ballot(act && rc == v);
-        rem &= ~grp;
-        const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
-        const double lg = (double)fast_log2f(pp + 0.000000001);
-        hxy2 = __builtin_fma(pp * (double)(uint32_t)__popcll(grp), lg, hxy2);
-        uint32_t gsum = 0;
-        while (grp) {
-            const int r = (int)__builtin_ctzll(grp);
-            grp &= grp - 1ull;
-            const uint32_t cnt = pcell[r * S];
-            asm_i = mad24(cnt, cnt, asm_i);                          // f_asm :555 / f_energy :927-928
-            cmax = cnt > cmax ? cnt : cmax;                          // f_GLCM_JMAX :1178-1179
-            ent += Tent[cnt < 15u ? cnt : 15u];                      // f_entropy :734-735, JE :1160-1161, HXY :868
-            gsum += cnt;
-        }
-        hxy1c = __builtin_fma((double)gsum, lg, hxy1c);
-    }
-    if (!act) { asm_i = 0; cmax = 0; ent = 0.0; hxy1c = 0.0; }
-    if (__ballot(cmax >= 15u)) {                                     // the entropy terms of the large counts, which the table left out
-        rem = __ballot(act && rc != 0u);
-        while (rem) {
-            const int r = (int)__builtin_ctzll(rem);
-            rem &= rem - 1ull;
-            const uint32_t cnt = act ? pcell[r * S] : 0u;
-            if (cnt >= 15u) { const double p = (double)cnt * inv_sum_p; ent += p * (double)fast_log2f(p + 0.000000001); }
-        }
-    }
-    const double hxy1 = hxy1c * inv_sum_p;
-    const double hx_t = act ? plogp(pcol, pcol) : 0.0;               // :873-874
-    wav_sync<false>();                                               // the table is dead: sm[16..23] belong to batch 2 from here on
-    {
-        double t4[4] = {ent, hxy1, hxy2, hx_t};
-        const double tot = wave_transpose_sum4(t4);                  // lane L holds the total of slot (L >> 4) & 3
-        if ((lane & 15) == 0) sm[1 + (lane >> 4)] = tot;             // sm[1] ent, [2] hxy1, [3] hxy2, [4] hx
-    }
-    // f_GLCM_ACOR :961 = sum (r + 1)(c + 1) cnt, integer-exact, from the two families of diagonals instead of two multiplies per
-    // cell: I J = ((I + J)^2 - (I - J)^2) / 4, so 4 ACOR = sum_k (k + 2)^2 n_{x+y}(k) - sum_d d^2 n_{x-y}(d) (the second sum is the
-    // contrast numerator; sum_p < 65536 and k + 2 <= 130 keep everything inside 32 bits)
-    {
-        const uint32_t k0 = (uint32_t)lane + 2u, k1 = (uint32_t)lane + 66u;
-        acor_i = (wave_sum_t<uint32_t>(mad24(pxpy_c[1], mul24(k1, k1), mul24(pxpy_c[0], mul24(k0, k0)))) - con_i) >> 2;
-    }
-    asm_i = wave_sum_t<uint32_t>(asm_i);
-    cmax = wave_max_u32(cmax);
-
-    // ---- one term per lane: features of the marginal distributions -----------------------------------------------------------
-    double t16[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) t16[k] = 0.0;
-    if (act) {
-        const double dr = (double)l1 - mr, dr2 = dr * dr, dcl = (double)l1 - mc;
-        t16[0] = prow * dr2;                                         // f_corr :617
-        t16[1] = pcol * (dcl * dcl);                                 // :626
-        t16[2] = (double)rc * dr2;                                   // f_var :672
-        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
-        const double q = pxmy, kd = (double)lane, Ngd = (double)Ng;
-        t16[4] = fdiv(q, (double)(1 + lane * lane));                 // f_idm :685-687
-        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
-        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
-        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
-        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
-        t16[9] = lane >= 1 ? q / (kd * kd) : 0.0;                    // :1123-1128
-        t16[10] = kd * q;                                            // f_difference_avg :791-792
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int k = lane + 64 * u;
-        if (k < 2 * Ng - 1) {
-            const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
-            t16[11] += ks * q;                                       // f_savg :700-701
-            t16[12] += plogp(q, q);                                  // f_sentropy :712-716
-            const double m = ks - mc - mc, m2 = m * m;               // by_row_mean (:531-536) = mc; CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
-            t16[13] += m2 * m2 * q;
-            t16[14] += m2 * m * q;
-            t16[15] += m2 * q;
-        }
-    }
-    {
-        const double tot = wave_transpose_sum16(t16, lane);          // lane L holds the total of slot (L >> 2) & 15
-        if ((lane & 3) == 0) sm[8 + (lane >> 2)] = tot;
-    }
-    wav_sync<false>();
-    const double davg = sm[8 + 10];
-    double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
-    if (act) { const double dk = (double)lane - davg; dv = dk * dk * pxmy; }
-    dv = wave_sum(dv);
-
-    if (lane == 0) {
-        const double ent_t = sm[1], hxy1_t = sm[2], hxy2_t = sm[3], hx = sm[4];
-        const double asm_t = (double)asm_i * inv_sum_p * inv_sum_p;
-        const double cov_t = fdiv((double)acor_i * sum_p - (double)Sr_i * (double)Sc_i, sum_p * sum_p);   // sum (r - mr)(c - mc) p, exact numerator
-        f[G_ASM] = asm_t;
-        f[G_ENERGY] = asm_t;
-        f[G_CONTRAST] = fdiv((double)con_i, sum_p);
-        f[G_ACOR] = fdiv((double)acor_i, sum_p);
-        f[G_ENTROPY] = -ent_t;
-        f[G_JE] = -ent_t;
-        f[G_DIS] = fdiv((double)dis_i, sum_p);
-        f[G_JMAX] = (double)cmax * inv_sum_p;
-        f[G_JAVE] = mr;
-        f[G_VARIANCE] = fdiv(sm[8 + 2], sum_p);
-        f[G_CLUPROM] = sm[8 + 13];
-        f[G_CLUSHADE] = sm[8 + 14];
-        f[G_CLUTEND] = sm[8 + 15];
-        f[G_SUMVARIANCE] = sm[8 + 15];                // glcm.cpp:323-326
-        f[G_JVAR] = sm[8 + 3];
-        const double denom = sqrt(sm[8 + 0]) * sqrt(sm[8 + 1]);      // f_corr tail, glcm.cpp:619-643
-        f[G_CORRELATION] = !(denom > 0.0) ? soft_nan : cov_t / denom;
-        f[G_INFOMEAS2] = sqrt(fabs(1 - exp(-2 * (-hxy2_t + ent_t)))); // glcm.cpp:913 (HXY = ent)
-        f[G_IDM] = sm[8 + 4];
-        f[G_HOM2] = sm[8 + 4];
-        f[G_HOM1] = sm[8 + 7];
-        f[G_SUMAVERAGE] = sm[8 + 11];
-        f[G_SUMENTROPY] = -sm[8 + 12];
-        f[G_DIFENTRO] = -sm[8 + 5];
-        f[G_DIFAVE] = davg;
-        f[G_DIFVAR] = dv;
-        f[G_IDMN] = sm[8 + 6];
-        f[G_ID] = sm[8 + 7];
-        f[G_IDN] = sm[8 + 8];
-        f[G_IV] = sm[8 + 9];
-        const double r1 = (ent_t - hxy1_t) / hx;      // f_info_meas_corr1, glcm.cpp:880-883
-        f[G_INFOMEAS1] = isfinite(r1) ? r1 : soft_nan;
-        if (empty)                                    // blank matrix: all 30 values = soft NaN (glcm.cpp:260-295)
-            for (int k = 0; k < kGlcmAngled; k++)
-                f[k] = soft_nan;
-    }
-    wav_sync<false>();
-}
-
-// ---- round 6: the same features from matrices of pitch `pitch` (even) whose data cells are word-aligned pairs ---------------------
+// ---- GLCM features of a matrix of up to 64 levels: one wave per angle (the reference's default grey depth) -------------------------
+// Same organisation as glcm_features_wave16 (marginal sums carry everything they can, only ASM / ENTROPY / JMAX / HXY1 / HXY2 visit
+// the cells), on the 16-bit matrices of the G16 launches.  Level values are I[i] = i + 1 (matlab binning).
+//  * Marginal counts in ONE pass over the rows (lane = column): the column sums accumulate in place, and the two families of
+//    diagonals ride along in registers that move one lane per row -- W(lane) holds the partial sum of the diagonal through (r, lane)
+//    (index c - r, shifts right), X(lane) that of the anti-diagonal (index r + c, shifts left).  A diagonal is complete when it leaves
+//    the matrix: upper diagonals (c - r = d >= 0) end in lane Ng - 1 at row Ng - 1 - d, anti-diagonals k <= Ng - 2 end in lane 0 at
+//    row k.  What is still travelling after the last row -- the lower diagonals in W, the anti-diagonals k >= Ng - 1 in X -- is fetched
+//    with one ds_bpermute each.
+//  * A cell's own quantities are integer work (ASM = sum cnt^2 / sum_p^2, JMAX from the largest count; sum_p < 65536 in a G16 launch,
+//    so every sum fits 32 bits); ACOR and the covariance numerator acor * sum_p - S_r * S_c come exactly from the diagonals; the
+//    entropy term p lg(p + eps) depends on the count alone: small counts -- all of them on a textured ROI -- come from a table built
+//    once per angle.
+//  * HXY1 / HXY2: rows are visited in GROUPS of equal row marginal: the float log of p_x(i) p_y(j) + eps -- the reference's quadratic
+//    -- depends on the row only through its marginal count, and the 64 rows of a textured ROI share ~25 distinct counts (Poisson around
+//    n / 64).  One log per group and column; HXY2 takes the group's multiplicity, HXY1 the group's count per column against the
+//    group's log (scaled by 1 / sum_p once at the end).  Rows with an empty marginal hold no pair and are skipped.  The group loop
+//    runs on the scalar unit (ballot, s_ff1, bit clears).
+// Round 6: matrices of pitch `pitch` (even) whose data cells are word-aligned pairs.
 // Layout (roi_features_kernel_g16): u16 cells, rows 0..Ng (row = centre level, row 0 unused), element (centre a, neighbour b) at
 // P[a * pitch + b - 1], pitch = (Ng + 3) & ~1: data columns 0..Ng-1 hold neighbour levels 1..Ng, a skipped neighbour (level 0)
 // lands in the LAST column of the previous row (never read), and column Ng of every row stays zero.  A row starts on a word, so
@@ -790,7 +578,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         rc = act ? (uint32_t)a2.x + (uint32_t)a2.y : 0u;
     }
     G16_EXIT(1, rc);
-    // ---- column sums and the two families of diagonals in one pass over the rows (lane = column; see glcm_features_wave64_u16) --
+    // ---- column sums and the two families of diagonals in one pass over the rows (lane = column; see the header) --------------
     uint32_t cc = 0, dc = 0;
     uint32_t pxpy_c[2] = {0u, 0u};
     {
@@ -872,7 +660,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         cmax = mx.x > mx.y ? (uint32_t)mx.x : (uint32_t)mx.y;
     }
     G16_EXIT(4, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1] + ent) + asm_i + cmax);
-    // ---- HXY1 / HXY2: lane = column, rows visited in groups of equal row marginal (see glcm_features_wave64_u16) ----------------
+    // ---- HXY1 / HXY2: lane = column, rows visited in groups of equal row marginal (see the header) ---------------------------
     double hxy1c = 0, hxy2 = 0;
     {
         const int cj = lane < Ng ? lane : Ng;

@@ -16,5 +16,16 @@ rec = {"round": tag, "kernel": "roi_features_kernel_occ8<1, 0>", "tiles": 1000, 
                                                        for f_ in ("roi_features.hip", "glcm_rows.h", "device_math.h", "roi_kernel.h"))).hexdigest(),
        "collected": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh {tag}), bench.py --steps 5 --warmup 2; "
                     f"metric-workload dispatches only (profiles/{tag}_summary.txt)"}
+# the tile path's traffic per tile from the same round's PMC pass over tools/tile_ab.py (tools/final_prof_r06.sh): all kernels of the call
+tp = os.path.join(ROOT, "gpurun_out", f"{tag}_tilepath_traffic.txt")
+if os.path.exists(tp):
+    tot = 0.0
+    for line in open(tp):
+        m = re.search(r"dispatches (\d+) FETCH_GB\(x2 gfx950\) ([0-9.]+) WRITE_GB ([0-9.]+)", line)
+        if m:
+            tot += float(m.group(2)) + float(m.group(3))
+    rec["tile_path_bytes_per_tile"] = tot * 1e9 / 1000
+    rec["tile_path_source"] = (f"profiles/{tag}_tilepath_traffic.txt (tools/pmc.sh traffic all -- tools/tile_ab.py 1000 8): sum over the path's kernels of "
+                               "FETCH_SIZE x 2 + WRITE_SIZE per call / 1000 tiles")
 json.dump(rec, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(rec["hbm_bytes_per_launch"], rec["kernel_source_sha256"][:12])
