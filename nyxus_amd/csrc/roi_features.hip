@@ -393,6 +393,10 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
     }
     (void)Pxpy;
     wav_sync<false>();
+#if defined(NYX_G8_EXIT) && NYX_G8_EXIT == 1     // diagnostic builds (tools/g8_exit_libs.sh): the routine ends here; results are wrong by design
+    if (live && l < Ng) f[l] = pcol + prow + pxmy + pxpy[0] + pxpy[1] + mr + mc + (double)(con_i + dis_i);
+    return;
+#endif
 
     // ---- the cell pass
     double ent = 0, hxy1 = 0, hxy2 = 0, asm_d = 0;
@@ -414,6 +418,10 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
             hxy2 = __builtin_fma(pp, lg, hxy2);
         }
     }
+#if defined(NYX_G8_EXIT) && NYX_G8_EXIT == 2
+    if (live && l < Ng) f[l] = ent + hxy1 + hxy2 + asm_d + (double)(acor_i + asm_i + cmax);
+    return;
+#endif
     const double hx_t = l < Ng ? plogp(pcol, pcol) : 0.0;
     {
         double t4[4] = {ent, hxy1, hxy2, hx_t};
@@ -472,6 +480,9 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
         if (live) { sm[8 + 2 * l] = t16[0]; sm[8 + 2 * l + 1] = t16[1]; }
     }
     wav_sync<false>();
+#if defined(NYX_G8_EXIT) && NYX_G8_EXIT == 3
+    return;
+#endif
     const double davg = sm[8 + 10];
     double dv = 0;                                                   // f_dvar (glcm.cpp:742-766)
     if (l < Ng) { const double dk = (double)l - davg; dv = dk * dk * pxmy; }
