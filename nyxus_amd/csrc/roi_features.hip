@@ -336,7 +336,7 @@ __device__ __forceinline__ void glcm_features_wave16(const uint32_t* Pslots, int
 __device__ __forceinline__ uint32_t grp8_sum(uint32_t v) { v += dpp_perm<0xB1>(v); v += dpp_perm<0x4E>(v); v += dpp_perm<0x141>(v); return v; }
 __device__ __forceinline__ double grp8_sum(double v) { v += dpp_perm<0xB1>(v); v += dpp_perm<0x4E>(v); v += dpp_perm<0x141>(v); return v; }
 __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const uint32_t* P_b, int n_slots, int Ng_a, int Ng_b, double* scr_base, int scr_stride,
-                                                    double soft_nan, double* fslots, double* sums, int lane)
+                                                    double soft_nan, double* fslots, size_t f_gap, double* sums, int lane)
 {
     const int grp = lane >> 3, l = lane & 7, sel = grp >> 2, slot_raw = grp & 3;
     const int Ng = sel ? Ng_b : Ng_a;
@@ -347,8 +347,7 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
     const int gslot = sel * kMaxAngles + slot;
     double* pcol_s = scr_base + mul24((uint32_t)gslot, (uint32_t)scr_stride);
     double* prow_s = pcol_s + 8;
-    double* Pxpy = pcol_s + 16;                                    // [2 Ng - 1 <= 15]
-    double* f = fslots + gslot * 32;
+    double* f = fslots + gslot * 32 + (sel ? f_gap : 0);          // (the kernel lays an ROI's features over its count block: written after the last read of a count)
     double* sm = sums + gslot * 32;
 
     // ---- marginal counts: lane i < Ng owns column i, row i and the diagonal pair |x - y| = i
@@ -391,7 +390,6 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
             pxpy[u] = fdiv((double)c, sum_p);
         }
     }
-    (void)Pxpy;
     wav_sync<false>();
 #if defined(NYX_G8_EXIT) && NYX_G8_EXIT == 1     // diagnostic builds (tools/g8_exit_libs.sh): the routine ends here; results are wrong by design
     if (live && l < Ng) f[l] = pcol + prow + pxmy + pxpy[0] + pxpy[1] + mr + mc + (double)(con_i + dis_i);
@@ -2630,8 +2628,13 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel(const RoiArgs 
     }
 }
 
+__host__ __device__ inline size_t glcm8_cnt_bytes(uint32_t ngc)   // a count block, at least the 1 KiB the ROI's features take in its place
+{
+    const size_t c = ((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15, fbytes = 8ull * kMaxAngles * 32;
+    return c > fbytes ? c : fbytes;
+}
 // The same for matrices of up to 8 levels: two ROIs per wave (glcm_features_wave8), eight per workgroup.
-__global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs A)
+__global__ __launch_bounds__(kBlock, 6) void glcm_features_kernel8(const RoiArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2644,13 +2647,15 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs
     if (Ng[0] == 0 && Ng[1] == 0)
         return;                                       // degenerate / skipped ROIs: roi_features_kernel wrote the columns
     const int na = A.glcm_na, ngc = (int)A.L.ng_cap;
-    // per-wave carve-out: counts [2][na * ngc^2] u32 | per group (8): pcol [8] prow [8] pxpy [16] | features [8][32] | sums [8][32]  (doubles)
-    const size_t cnt_bytes = ((size_t)4 * kMaxAngles * ngc * ngc + 15) & ~(size_t)15;
-    const size_t per_wave = 2 * cnt_bytes + 8ull * (2 * kMaxAngles * 32 + 2 * 2 * kMaxAngles * 32);
+    // per-wave carve-out: count blocks [2] (an ROI's features are written over its dead counts: 4 angles x 32 doubles = the 1 KiB a block
+    // holds at 8 levels) | per group (8): pcol [8] prow [8] | sums [8][32]  (doubles) -- 5 KiB per wave (round 6; 8 KiB before: five
+    // workgroups per CU, now the register count's six waves per SIMD)
+    const size_t cnt_bytes = glcm8_cnt_bytes((uint32_t)ngc);
+    const size_t per_wave = 2 * cnt_bytes + 8ull * (2 * kMaxAngles * 16 + 2 * kMaxAngles * 32);
     unsigned char* base = lds_raw + (size_t)wave * per_wave;
     uint32_t* s_P[2] = {(uint32_t*)base, (uint32_t*)(base + cnt_bytes)};
     double* s_scr = (double*)(base + 2 * cnt_bytes);
-    double* s_f = s_scr + 2 * kMaxAngles * 32;
+    double* s_sum = s_scr + 2 * kMaxAngles * 16;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         if (Ng[q] == 0) continue;
@@ -2665,14 +2670,15 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs
         }
     }
     wav_sync<false>();
-    glcm_features_wave8(s_P[0], s_P[1], na, Ng[0], Ng[1], s_scr, 32, A.soft_nan, s_f, s_f + 2 * kMaxAngles * 32, lane);
+    // (group g = ROI g >> 2, angle g & 3 writes f = fslots + g * 32 doubles: the ROI's own count block)
+    glcm_features_wave8(s_P[0], s_P[1], na, Ng[0], Ng[1], s_scr, 16, A.soft_nan, (double*)base, (size_t)(cnt_bytes >> 3) - 4 * 32, s_sum, lane);
     wav_sync<false>();
     const int sh = na == 4 ? 2 : na == 2 ? 1 : na == 1 ? 0 : -1;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         if (Ng[q] == 0) continue;
         double* o = A.out + roi[q] * A.ld + A.col_glcm;
-        const double* fq = s_f + q * kMaxAngles * 32;
+        const double* fq = (const double*)(base + (size_t)q * cnt_bytes);
         for (int c = lane; c < kGlcmAngled * na; c += 64) {           // feature-major, angle-minor (output_2_buffer.cpp:336-346)
             const int k = sh >= 0 ? c >> sh : c / na, a = c - k * na;
             o[c] = fq[a * 32 + k];
@@ -2694,8 +2700,7 @@ __global__ __launch_bounds__(kBlock, 4) void glcm_features_kernel8(const RoiArgs
 
 size_t glcm_features8_lds(uint32_t ng_cap)
 {
-    const size_t cnt_bytes = ((size_t)4 * kMaxAngles * ng_cap * ng_cap + 15) & ~(size_t)15;
-    return (2 * cnt_bytes + 8ull * (2 * kMaxAngles * 32 + 2 * 2 * kMaxAngles * 32)) * kWaves;
+    return (2 * glcm8_cnt_bytes(ng_cap) + 8ull * (2 * kMaxAngles * 16 + 2 * kMaxAngles * 32)) * kWaves;
 }
 
 size_t glcm_features_lds(uint32_t ng_cap)
