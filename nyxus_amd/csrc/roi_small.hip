@@ -6,13 +6,16 @@
 // minus a third (7.4 against 12.4 ns): every phase has a fixed part (the 4096-entry counting table is scanned even for 49 values, every
 // exchange is a workgroup barrier) and a workgroup costs 1.1 ns of dispatch alone.  Here everything is proportional to the ROI:
 //   * four ROIs per workgroup, one per wave, no workgroup barrier anywhere (a wave's LDS block is its own);
-//   * the values (<= 4 per lane) are SORTED (bitonic network over the wave's LDS block) instead of counted into a table over [min, max]:
+//   * the values (<= 4 per lane) are SORTED (bitonic network in registers: one key per lane up to 64 pixels, four packed 16-bit keys per
+//     lane beyond) instead of counted into a table over [min, max]:
 //     the sorted array IS the cumulative table -- "pixels below offset d" is a lower bound, the median two reads, the mode the
 //     longest run;
 //   * the 100 + n histogram-bin lower bounds (histogram.h:55-78) are three binary searches per lane; percentiles, entropy, robust
 //     statistics follow intensity_table.h (intensity_from_table) line by line, wave sums instead of workgroup sums;
 //   * GLCM (matlab binning, <= 16 levels): the plane and the four Ng x Ng matrices in the wave's block, counts exported for
-//     glcm_features_kernel8 / glcm_features_kernel in the layout roi_features_kernel exports (angle-major, Ng^2 words per angle).
+//     glcm_features_kernel8 / glcm_features_kernel in the layout roi_features_kernel exports (angle-major, Ng^2 words per angle);
+//   * GLCM at 17..64 levels (the reference's default depth): the features themselves, from the <= 255 PAIRS of an angle -- marginal
+//     counts by atomics per pair, per-cell sums as sums over pairs, the rest through glcm_w64.h (the workgroup kernel's own tail).
 // Integer-exact columns follow the reference operation by operation (MIN, MAX, RANGE, MEAN, ENERGY, INTEGRATED_INTENSITY, RMS, MEDIAN,
 // MODE, percentiles, IQR, QCOD, ROBUST_MEAN, PIU); the floating-point sums run in a fixed order that is a function of the ROI.
 // Which ROIs come here is a function of the ROI alone: roi_class(...) == 0 (the launcher routes that class; anybody else returns or
