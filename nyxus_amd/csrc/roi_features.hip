@@ -745,6 +745,27 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
 // that caller and callee are always compiled for the same register budget.
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;     // a byte at an absolute LDS address
 
+// the kernel's RoiArgs (its only parameter: offset 0 of the kernarg segment) behind a pointer that is opaque to the optimiser at the point of
+// the call: loads through it stay scalar loads (constant address space) and stay BELOW the call
+typedef const __attribute__((address_space(4))) RoiArgs KArgs;
+__device__ __forceinline__ KArgs* late_kernarg()
+{
+    KArgs* p = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// B->field: through the late view (LATE) or the kernel's by-value argument itself (the generic builds: exactly the code they had)
+template <bool LATE>
+struct KView {
+    const RoiArgs& a;
+    KArgs* p;
+    __device__ __forceinline__ explicit KView(const RoiArgs& a_) : a(a_), p(LATE ? late_kernarg() : nullptr) {}
+    __device__ __forceinline__ auto operator->() const
+    {
+        if constexpr (LATE) return p;
+        else return &a;
+    }
+};
 template <bool GS, bool C16, bool SPLIT, bool D8, int FAM = 0, int TIER = 4, bool G16 = false, int WIN = 2, int NW = 4>
 __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64_t slot)
 {
@@ -1139,11 +1160,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     }
 
     STAMP(1);
+    // From here on the kernel arguments are read through a view of the kernarg segment whose loads the compiler cannot move above this
+    // point.  It had merged them into the wide scalar loads of the entry block (max_inten | slide_min | slide_max | out in one
+    // s_load_dwordx8, ...) and then SPILLED what the load pass had no scalar register for: 41 v_writelane_b32 and their v_readlane_b32
+    // reloads -- vector instructions in a kernel whose limit is vector issue (80 scalar registers per wave at eight waves per SIMD).
+    // (the compact and the 64-level builds only: the generic builds, 106 scalar registers at
+    //  four to six waves per SIMD, came out with MORE spills under the late view and keep the plain one -- KView)
+    const KView<FAM != 0 || G16> B(A);
+    double* const out_row_l = B->out + roi * B->ld;
     // =====================================================================================
     // first-order intensity
     // =====================================================================================
     if (do_int) {
-        double* o = out_row + A.col_intensity;
+        double* o = out_row_l + B->col_intensity;
         const double dn = (double)n;
         // integer sums are exact in any order (the reference's double accumulation is
         // exact too while partial sums stay below 2^53)
@@ -1171,12 +1200,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             const double mean = tot / dn;              // the one IEEE division; every other thread reads the mean after the barrier
             s_stat[S_MEAN] = mean;
             if (FAST)                                  // GLCM degenerate guard (glcm.cpp:27-95, on GLCM_GREYDEPTH): two binnings, once per ROI
-                s_stat[S_NG] = bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth) ? 1.0 : 0.0;
+                s_stat[S_NG] = bin_pixel(vmin, vmin, vmax, B->glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, B->glcm_grey_depth) ? 1.0 : 0.0;
             o[I_MIN] = (double)vmin;                   // intensity.cpp:67-69
             o[I_MAX] = (double)vmax;
             o[I_RANGE] = (double)vmax - (double)vmin;
-            if (A.slide_min && A.slide_max)            // intensity.cpp:72-77
-                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (A.slide_max[roi] - A.slide_min[roi]);
+            if (B->slide_min && B->slide_max)            // intensity.cpp:72-77
+                o[I_COVERED_IMAGE_INTENSITY_RANGE] = (double)(vmax - vmin) / (B->slide_max[roi] - B->slide_min[roi]);
             o[I_MEAN] = mean;                          // intensity.cpp:95-99
             o[I_ENERGY] = totsq;
             o[I_ROOT_MEAN_SQUARED] = sqrt(totsq / dn);
@@ -1189,7 +1218,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         STAMP(2);
 
         const double binW100 = (double)range / 100.;
-        const uint32_t nb = (uint32_t)A.n_hist;
+        const uint32_t nb = (uint32_t)B->n_hist;
         // count of values strictly below the first value whose bin index reaches b; `pred`
         // is the bin index of a value, monotone in the value (histogram.h:55-66, :69-78)
         auto idx100 = [=](uint32_t v) -> int {
@@ -1311,12 +1340,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             grp_sync<GS, NW>();
         } else if (radix) {
             // second key buffer [sort_cap] | digit counts [NW * 256 + NW]
-            if (k16) {                                               // (both key buffers in the value region, the counts in A.L.radix)
-                uint16_t* const kb = (uint16_t*)s_val + ((A.L.sort_cap + 7u) & ~7u);
-                s_val = (uint32_t*)radix_sort<GS, NW, uint16_t>((uint16_t*)s_val, kb, (uint32_t*)reg(A.L.radix), n, 0u, range, tid);
+            if (k16) {                                               // (both key buffers in the value region, the counts in B->L.radix)
+                uint16_t* const kb = (uint16_t*)s_val + ((B->L.sort_cap + 7u) & ~7u);
+                s_val = (uint32_t*)radix_sort<GS, NW, uint16_t>((uint16_t*)s_val, kb, (uint32_t*)reg(B->L.radix), n, 0u, range, tid);
             } else {
-                uint32_t* const s_rdx = (uint32_t*)reg(A.L.radix);
-                s_val = radix_sort<GS, NW, uint32_t>(s_val, s_rdx, s_rdx + A.L.sort_cap, n, vmin, range, tid);
+                uint32_t* const s_rdx = (uint32_t*)reg(B->L.radix);
+                s_val = radix_sort<GS, NW, uint32_t>(s_val, s_rdx, s_rdx + B->L.sort_cap, n, vmin, range, tid);
             }
         } else {
             bitonic_sort<GS, NW>(s_val, P2, tid);
@@ -1766,31 +1795,31 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         // form of the general block below (one pass over all angles, matrix order = grey depth, 8-bit plane at LDS address 0,
         // skip-column matrices).  Kept apart because the general block's loop structure and run-time cases cost this build
         // ~60 scalar-register spills per wave (each a vector instruction).
-        double* o = out_row + A.col_glcm;
-        const int na = A.glcm_na;
+        double* o = out_row_l + B->col_glcm;
+        const int na = B->glcm_na;
         const int Ng = greyInfo, NG1 = Ng + 1, NN = Ng * Ng, cells = NG1 * NG1;
         // (the guard of glcm.cpp:27-95 on GLCM_GREYDEPTH: taken beside the mean when the intensity block runs, here when it does not)
-        const bool degenerate = FAM == 3 ? bin_pixel(vmin, vmin, vmax, A.glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, A.glcm_grey_depth) : s_stat[S_NG] != 0.0;
+        const bool degenerate = FAM == 3 ? bin_pixel(vmin, vmin, vmax, B->glcm_grey_depth) == bin_pixel(vmax, vmin, vmax, B->glcm_grey_depth) : s_stat[S_NG] != 0.0;
         if (tid == 0)
-            A.glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
+            B->glcm_ng[roi] = degenerate ? 0u : (uint32_t)Ng;
         if (degenerate) {
             for (int c = tid; c < kGlcmAngled * na + kGlcmAve; c += BS)
-                o[c] = A.soft_nan;
+                o[c] = B->soft_nan;
             return;
         }
-        const bool symmetric = A.glcm_symmetric != 0;
+        const bool symmetric = B->glcm_symmetric != 0;
         int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
 #pragma unroll
         for (int q = 0; q < kMaxAngles; q++)
             if (q < na) {
-                const int ang = A.glcm_angles[q];
+                const int ang = B->glcm_angles[q];
                 if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
             }
         const bool usual = slot0 >= 0 && slot1 >= 0 && slot2 >= 0 && slot3 >= 0 && !symmetric;   // four angles, asymmetric counts
         // lane-per-column sweeps (skip-column matrices): boxes up to a wave wide, and -- for the usual request -- boxes up to
         // two waves wide with two columns per lane
-        const bool dpp2 = A.glcm_offset == 1 && w > 64 && w <= 128 && usual;
-        const bool dpp = (A.glcm_offset == 1 && w <= 64) || dpp2;
+        const bool dpp2 = B->glcm_offset == 1 && w > 64 && w <= 128 && usual;
+        const bool dpp = (B->glcm_offset == 1 && w <= 64) || dpp2;
         grp_sync<GS, NW>();
         for (int i = tid; i < na * (dpp ? cells : NN); i += BS)
             s_P[i] = 0;
@@ -1909,8 +1938,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     for (int q = 0; q < kMaxAngles; q++) {
                         if (q >= na)
                             break;
-                        const int ang = A.glcm_angles[q];                 // glcm.cpp:234-255
-                        const int dx = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset, dy = ang == 0 ? 0 : A.glcm_offset;
+                        const int ang = B->glcm_angles[q];                 // glcm.cpp:234-255
+                        const int dx = ang == 90 ? 0 : ang == 135 ? -B->glcm_offset : B->glcm_offset, dy = ang == 0 ? 0 : B->glcm_offset;
                         const int r2 = row + dy, c2 = col + dx;
                         if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
                             continue;
@@ -1926,7 +1955,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         grp_sync<GS, NW>();
         STAMP(11);
         {
-            uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
+            uint32_t* dst = B->glcm_ws + roi * B->glcm_ws_stride;
             if (dpp) {
                 // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
                 // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the error of the reciprocal.
@@ -1943,18 +1972,18 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         STAMP(12);
     } else
     if (do_glcm) {
-        double* o = out_row + A.col_glcm;
-        const int na = A.glcm_na;
+        double* o = out_row_l + B->col_glcm;
+        const int na = B->glcm_na;
         const int ncol_g = kGlcmAngled * na + kGlcmAve;
         // degenerate guard (glcm.cpp:27-95) uses GLCM_GREYDEPTH
         // (the extrema pass through readfirstlane so that their conversions to double are redone here instead of being kept
         // -- spilled -- since the load phase)
         const uint32_t vmin_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmin), vmax_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmax);
-        const bool degenerate = bin_pixel(vmin_g, vmin_g, vmax_g, A.glcm_grey_depth) == bin_pixel(vmax_g, vmin_g, vmax_g, A.glcm_grey_depth);
+        const bool degenerate = bin_pixel(vmin_g, vmin_g, vmax_g, B->glcm_grey_depth) == bin_pixel(vmax_g, vmin_g, vmax_g, B->glcm_grey_depth);
 
         // matrix order and level values (glcm.cpp:388-420)
         double* s_I = s_g;                       // [ng_cap] level values
-        double* s_f = s_g + A.L.ng_cap;          // [kMaxAngles][32] per-angle features
+        double* s_f = s_g + B->L.ng_cap;          // [kMaxAngles][32] per-angle features
         double* s_scr = s_f + kMaxAngles * 32;   // [kMaxAngles][6*ng_cap]
         if (FAST) {
             // matlab binning: the matrix order is the grey depth itself -- nothing to agree on, no barrier
@@ -1976,10 +2005,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 } else {
                     // unique sorted non-zero levels -> compact indices (glcm.cpp:391-397)
                     int k = 0;
-                    for (uint32_t l = 1; l <= A.L.lvl_cap; l++)
+                    for (uint32_t l = 1; l <= B->L.lvl_cap; l++)
                         if (s_lvlmap[l]) {
                             s_lvlmap[l] = (uint16_t)(k + 1);
-                            if ((uint32_t)k < A.L.ng_cap)
+                            if ((uint32_t)k < B->L.ng_cap)
                                 s_I[k] = (double)l;
                             k++;
                         }
@@ -1990,19 +2019,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
         }
         if (!FAST) grp_sync<GS, NW>();
         const int Ng = FAST ? greyInfo : (int)s_stat[S_NG];
-        const bool too_big = !FAST && (uint32_t)Ng > A.L.ng_cap;      // (FAST: make_layout reserved exactly this order)
+        const bool too_big = !FAST && (uint32_t)Ng > B->L.ng_cap;      // (FAST: make_layout reserved exactly this order)
         if (too_big && tid == 0)
-            atomicCAS(A.status, 0, NYXHIP_ERR_UNSUPPORTED);
+            atomicCAS(B->status, 0, NYXHIP_ERR_UNSUPPORTED);
         if (!SPLIT && !G16 && greyInfo >= 0 && !too_big)   // (G16: level values are i + 1 by construction, and its scratch lies over the live plane)
             for (int i = tid; i < Ng; i += BS)
                 s_I[i] = (double)(i + 1);
 
         const bool split = SPLIT && !degenerate && !too_big;
         if (SPLIT && tid == 0)
-            A.glcm_ng[roi] = split ? (uint32_t)Ng : 0u;
+            B->glcm_ng[roi] = split ? (uint32_t)Ng : 0u;
         if (degenerate) {
             for (int c = tid; c < ncol_g; c += BS)
-                o[c] = A.soft_nan;
+                o[c] = B->soft_nan;
         } else if (too_big) {
             for (int c = tid; c < ncol_g; c += BS)
                 o[c] = __longlong_as_double(0x7ff8000000000000LL);
@@ -2016,7 +2045,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             // Round 6 layout (glcm_features_wave64_v2): rows 0..Ng of an even pitch, cell (centre a, neighbour b) at a * pitch + b - 1:
             // data cells are word-aligned pairs, a skipped neighbour lands in the previous row's last column, column Ng stays zero.
             const int NG1 = (Ng + 3) & ~1, cellsw = ((Ng + 1) * NG1) >> 1;    // NG1: the pitch; words per matrix
-            const bool symmetric = A.glcm_symmetric != 0;
+            const bool symmetric = B->glcm_symmetric != 0;
             uint32_t* const s_blk = (uint32_t*)(s_f);                 // [kMaxAngles][256 words]: per-wave scratch of the feature pass; a wave's f = its first 32 doubles
             grp_sync<GS, NW>();
             {   // 16 bytes per store (word stores were 34 trips of four instructions: 1.1 ns of every ROI); the matrices' region is 16-byte aligned and 16 cellsw bytes long
@@ -2028,14 +2057,14 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             grp_sync<GS, NW>();
             STAMP(10);
             auto bump16 = [&](uint32_t* M, uint32_t idx) { idx -= 1u; atomicAdd(&M[idx >> 1], 1u << ((idx & 1u) << 4)); };
-            if (A.glcm_offset == 1 && w > 64 && w <= 128) {
+            if (B->glcm_offset == 1 && w > 64 && w <= 128) {
                 // boxes 65 .. 128 wide: lane = column and column + 64, the pairs across column 63 | 64 through v_readlane (see the
                 // <= 16-level block above); any angle subset, symmetric counts included
                 int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
 #pragma unroll
                 for (int q = 0; q < kMaxAngles; q++)
                     if (q < na) {
-                        const int ang = A.glcm_angles[q];
+                        const int ang = B->glcm_angles[q];
                         if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                     }
                 const int rows_per_wave = ((int)h + NW - 1) / NW;
@@ -2076,12 +2105,12 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     c0 = n0; c1 = n1;
                 }
             } else
-            if (A.glcm_offset == 1 && w <= 64) {
+            if (B->glcm_offset == 1 && w <= 64) {
                 int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
 #pragma unroll
                 for (int q = 0; q < kMaxAngles; q++)
                     if (q < na) {
-                        const int ang = A.glcm_angles[q];
+                        const int ang = B->glcm_angles[q];
                         if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                     }
                 const int rows_per_wave = ((int)h + NW - 1) / NW;
@@ -2142,13 +2171,13 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                     }
                     cur = nxt;
                 }
-            } else if (A.glcm_offset == 1) {
+            } else if (B->glcm_offset == 1) {
                 // boxes wider than two waves: column strips of 62 centre columns between two halo lanes (see the general block below)
                 int slot0 = -1, slot1 = -1, slot2 = -1, slot3 = -1;
 #pragma unroll
                 for (int q = 0; q < kMaxAngles; q++)
                     if (q < na) {
-                        const int ang = A.glcm_angles[q];
+                        const int ang = B->glcm_angles[q];
                         if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                     }
                 const int rows_per_wave = ((int)h + NW - 1) / NW;
@@ -2190,8 +2219,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                         for (int q = 0; q < kMaxAngles; q++) {
                             if (q >= na)
                                 break;
-                            const int ang = A.glcm_angles[q];                 // glcm.cpp:234-255
-                            const int dx = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset, dy = ang == 0 ? 0 : A.glcm_offset;
+                            const int ang = B->glcm_angles[q];                 // glcm.cpp:234-255
+                            const int dx = ang == 90 ? 0 : ang == 135 ? -B->glcm_offset : B->glcm_offset, dy = ang == 0 ? 0 : B->glcm_offset;
                             const int r2 = row + dy, c2 = col + dx;
                             if (r2 < 0 || r2 >= (int)h || c2 < 0 || c2 >= (int)w)
                                 continue;
@@ -2207,11 +2236,11 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             grp_sync<GS, NW>();
             STAMP(11);
             if (wave < na) {                             // (NW = 4 = kMaxAngles: a wave per angle)
-                if (Ng == 64) glcm_features_wave64_v2<64>((const uint16_t*)(s_P + (size_t)wave * cellsw), 64, s_blk + wave * 256, A.soft_nan, lane);
-                else glcm_features_wave64_v2<0>((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_blk + wave * 256, A.soft_nan, lane);
+                if (Ng == 64) glcm_features_wave64_v2<64>((const uint16_t*)(s_P + (size_t)wave * cellsw), 64, s_blk + wave * 256, B->soft_nan, lane);
+                else glcm_features_wave64_v2<0>((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_blk + wave * 256, B->soft_nan, lane);
             }
             grp_sync<GS, NW>();
-            if (tid < na) glcm_features_final(s_blk + tid * 256, A.soft_nan);
+            if (tid < na) glcm_features_final(s_blk + tid * 256, B->soft_nan);
             grp_sync<GS, NW>();
             STAMP(12);
             for (int c = tid; c < kGlcmAngled * na; c += BS) {
@@ -2233,8 +2262,8 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             }
         } else {
             const int NN = Ng * Ng;
-            const bool symmetric = A.glcm_symmetric || greyInfo <= 0; // glcm.cpp:475
-            const int app = FAST ? kMaxAngles : (int)A.L.app;         // (FAST launches hold every angle in one pass: build_args)
+            const bool symmetric = B->glcm_symmetric || greyInfo <= 0; // glcm.cpp:475
+            const int app = FAST ? kMaxAngles : (int)B->L.app;         // (FAST launches hold every angle in one pass: build_args)
             for (int a0 = 0; a0 < na; a0 += app) {
                 const int na_pass = (na - a0) < app ? (na - a0) : app;
                 // Split launches on the lane-per-column path count into matrices of order Ng + 1 indexed by the level itself:
@@ -2243,7 +2272,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 // centre instead of one per pair; the export below drops the extra row / column.  (Skipped CENTRES are masked
                 // out: sent to a cell of their own, a third of the box's lanes would pile on it and the LDS serialises same-
                 // address adds -- measured: 2.3 -> 3.4 ms per 196 k ROIs.)
-                const bool dpp = A.glcm_offset == 1 && w <= 64;
+                const bool dpp = B->glcm_offset == 1 && w <= 64;
                 const bool trash = SPLIT && dpp;
                 const int NG1 = Ng + 1, cells = trash ? NG1 * NG1 : NN;
                 grp_sync<GS, NW>();
@@ -2256,9 +2285,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 int ddx[kMaxAngles], ddy[kMaxAngles];
 #pragma unroll
                 for (int q = 0; q < kMaxAngles; q++) {
-                    int ang = A.glcm_angles[(a0 + q) < na ? (a0 + q) : 0]; // glcm.cpp:234-255
-                    ddx[q] = ang == 90 ? 0 : ang == 135 ? -A.glcm_offset : A.glcm_offset;
-                    ddy[q] = ang == 0 ? 0 : A.glcm_offset;
+                    int ang = B->glcm_angles[(a0 + q) < na ? (a0 + q) : 0]; // glcm.cpp:234-255
+                    ddx[q] = ang == 90 ? 0 : ang == 135 ? -B->glcm_offset : B->glcm_offset;
+                    ddy[q] = ang == 0 ? 0 : B->glcm_offset;
                 }
                 if (dpp) {
                     // one lane per column: horizontal neighbours come from DPP lane shifts, the
@@ -2269,7 +2298,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
 #pragma unroll
                     for (int q = 0; q < kMaxAngles; q++)
                         if (q < na_pass) {
-                            int ang = A.glcm_angles[a0 + q];
+                            int ang = B->glcm_angles[a0 + q];
                             if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                         }
                     const int rows_per_wave = ((int)h + NW - 1) / NW;
@@ -2387,7 +2416,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                         cur4 = nxt4;
                     }
                     }
-                } else if (A.glcm_offset == 1) {
+                } else if (B->glcm_offset == 1) {
                     // ---- boxes wider than a wave: column strips.  Lane L of a strip holds column c0 - 1 + L; lanes 1 .. 62 are the
                     // centres, lanes 0 and 63 only lend their values as the west / east neighbours of the strip's edge columns (a
                     // strip advances by 62 columns), so every neighbour is a DPP lane shift away as in the narrow-box sweep -- where
@@ -2397,7 +2426,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
 #pragma unroll
                     for (int q = 0; q < kMaxAngles; q++)
                         if (q < na_pass) {
-                            int ang = A.glcm_angles[a0 + q];
+                            int ang = B->glcm_angles[a0 + q];
                             if (ang == 0) slot0 = q; else if (ang == 45) slot1 = q; else if (ang == 90) slot2 = q; else slot3 = q;
                         }
                     const int rows_per_wave = ((int)h + NW - 1) / NW;
@@ -2465,7 +2494,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 grp_sync<GS, NW>();
                 STAMP(11);
                 if (SPLIT) {                         // the host sets this up only when every angle fits one pass
-                    uint32_t* dst = A.glcm_ws + roi * A.glcm_ws_stride;
+                    uint32_t* dst = B->glcm_ws + roi * B->glcm_ws_stride;
                     if (trash) {
                         // dense cell i = (q, r, c) sits at q * (Ng+1)^2 + (r+1) * (Ng+1) + c + 1.  The two small divisions go through
                         // float: (i + 1/2) / d is never closer than 1/(2d) to an integer, far beyond the rounding of the product.
@@ -2481,10 +2510,10 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
                 } else if (SPLIT) {
                 } else if (Ng <= 16) {               // small matrices: the four angles share one wave's instruction stream
                     if (wave == 0)
-                        glcm_features_rows<GS, 16, kRowsTag>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)A.L.ng_cap, A.soft_nan, s_f + a0 * 32, lane);
+                        glcm_features_rows<GS, 16, kRowsTag>(s_P, na_pass, Ng, s_I, s_scr, 6 * (int)B->L.ng_cap, B->soft_nan, s_f + a0 * 32, lane);
                 } else if (wave < na_pass)           // large matrices: a wave per angle, 64 lanes over the cells (NW = 4 = kMaxAngles)
-                    glcm_features_rows<GS, 64, kRowsTag>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * A.L.ng_cap, 6 * (int)A.L.ng_cap,
-                                               A.soft_nan, s_f + (a0 + wave) * 32, lane);
+                    glcm_features_rows<GS, 64, kRowsTag>(s_P + (size_t)wave * Ng * Ng, 1, Ng, s_I, s_scr + (size_t)wave * 6 * B->L.ng_cap, 6 * (int)B->L.ng_cap,
+                                               B->soft_nan, s_f + (a0 + wave) * 32, lane);
             }
             grp_sync<GS, NW>();
             STAMP(12);
