@@ -439,43 +439,56 @@ __device__ __forceinline__ void glcm_features_wave8(const uint32_t* P_a, const u
         o = dpp_perm<0x141>(cmax); cmax = o > cmax ? o : cmax;
     }
 
-    // ---- one term per lane: features of the marginal distributions
-    double t16[16];
+    // ---- one term per lane: features of the marginal distributions, in two halves of eight slots (sixteen doubles live at once cost the
+    // kernel its eighth wave per SIMD)
+    {
+        double t8[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) t16[k] = 0.0;
-    if (l < Ng) {
-        const double dr = (double)l1 - mr, dcl = (double)l1 - mc, dr2 = dr * dr;
-        t16[0] = prow * dr2;                                         // f_corr :617
-        t16[1] = pcol * (dcl * dcl);                                 // :626
-        t16[2] = (double)rc * dr2;                                   // f_var :672
-        t16[3] = pcol * dr2;                                         // f_GLCM_JVAR :1196-1199
-        const double q = pxmy, kd = (double)l, Ngd = (double)Ng;
-        t16[4] = fdiv(q, (double)(1 + l * l));                       // f_idm :685-687
-        t16[5] = q != 0 ? plogp(q, q) : 0.0;                         // f_dentropy :778-781
-        t16[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));            // :1083-1084
-        t16[7] = fdiv(q, 1.0 + kd);                                  // :1096-1097
-        t16[8] = fdiv(q, 1.0 + fdiv(kd, Ngd));                       // :1110-1111
-        t16[9] = l >= 1 ? q / (kd * kd) : 0.0;                       // :1123-1128
-        t16[10] = kd * q;                                            // f_difference_avg :791-792
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int k = l + 8 * u;
-        if (k < 2 * Ng - 1) {
-            const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
-            t16[11] += ks * q;                                       // f_savg :700-701
-            t16[12] += plogp(q, q);                                  // f_sentropy :712-716
-            const double m = ks - mc - mc, m2 = m * m;               // CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
-            t16[13] += m2 * m2 * q;
-            t16[14] += m2 * m * q;
-            t16[15] += m2 * q;
+        for (int k = 0; k < 8; k++) t8[k] = 0.0;
+        if (l < Ng) {
+            const double dr = (double)l1 - mr, dcl = (double)l1 - mc, dr2 = dr * dr;
+            t8[0] = prow * dr2;                                          // f_corr :617
+            t8[1] = pcol * (dcl * dcl);                                  // :626
+            t8[2] = (double)rc * dr2;                                    // f_var :672
+            t8[3] = pcol * dr2;                                          // f_GLCM_JVAR :1196-1199
+            const double q = pxmy, kd = (double)l, Ngd = (double)Ng;
+            t8[4] = fdiv(q, (double)(1 + l * l));                        // f_idm :685-687
+            t8[5] = q != 0 ? plogp(q, q) : 0.0;                          // f_dentropy :778-781
+            t8[6] = fdiv(q, 1.0 + fdiv(kd * kd, Ngd * Ngd));             // :1083-1084
+            t8[7] = fdiv(q, 1.0 + kd);                                   // :1096-1097
         }
+        transpose_sum_step<0x141, 4>(t8, (l & 4) != 0);                  // lane l of the group ends with the group total of slot l
+        transpose_sum_step<0x4E, 2>(t8, (l & 2) != 0);
+        transpose_sum_step<0xB1, 1>(t8, (l & 1) != 0);
+        if (live) sm[8 + l] = t8[0];
     }
     {
-        transpose_sum_step<0x141, 8>(t16, (l & 4) != 0);             // lane l of the group ends with the totals of slots 2 l and 2 l + 1
-        transpose_sum_step<0x4E, 4>(t16, (l & 2) != 0);
-        transpose_sum_step<0xB1, 2>(t16, (l & 1) != 0);
-        if (live) { sm[8 + 2 * l] = t16[0]; sm[8 + 2 * l + 1] = t16[1]; }
+        double t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t8[k] = 0.0;
+        if (l < Ng) {
+            const double q = pxmy, kd = (double)l, Ngd = (double)Ng;
+            t8[0] = fdiv(q, 1.0 + fdiv(kd, Ngd));                        // :1110-1111
+            t8[1] = l >= 1 ? q / (kd * kd) : 0.0;                        // :1123-1128
+            t8[2] = kd * q;                                              // f_difference_avg :791-792
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = l + 8 * u;
+            if (k < 2 * Ng - 1) {
+                const double q = pxpy[u], ks = (double)(k + 2);          // I[x] + I[k - x] = k + 2
+                t8[3] += ks * q;                                         // f_savg :700-701
+                t8[4] += plogp(q, q);                                    // f_sentropy :712-716
+                const double m = ks - mc - mc, m2 = m * m;               // CLUPROM :985, CLUSHADE :1007, CLUTEND :1034
+                t8[5] += m2 * m2 * q;
+                t8[6] += m2 * m * q;
+                t8[7] += m2 * q;
+            }
+        }
+        transpose_sum_step<0x141, 4>(t8, (l & 4) != 0);
+        transpose_sum_step<0x4E, 2>(t8, (l & 2) != 0);
+        transpose_sum_step<0xB1, 1>(t8, (l & 1) != 0);
+        if (live) sm[16 + l] = t8[0];
     }
     wav_sync<false>();
 #if defined(NYX_G8_EXIT) && NYX_G8_EXIT == 3
@@ -2663,7 +2676,7 @@ __host__ __device__ inline size_t glcm8_cnt_bytes(uint32_t ngc)   // a count blo
     return c > fbytes ? c : fbytes;
 }
 // The same for matrices of up to 8 levels: two ROIs per wave (glcm_features_wave8), eight per workgroup.
-__global__ __launch_bounds__(kBlock, 6) void glcm_features_kernel8(const RoiArgs A)
+__global__ __launch_bounds__(kBlock, 8) void glcm_features_kernel8(const RoiArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
