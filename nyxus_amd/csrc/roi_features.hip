@@ -788,7 +788,9 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     // 49-pixel ROIs 8.4 -> 7.3 ns, 253-pixel ROIs 8.7 -> 8.9 ns per ROI.  A two-wave build of the metric configuration
     // (round 4: what a wave pays once per phase whatever its share of the pixels is paid twice per ROI instead of four times, but
     // the same eight workgroups per CU are four waves per SIMD instead of eight) took 2.39 ms per 196 k ROIs against 2.16.
-    static_assert(NW == 4 && NW == kMaxAngles, "one workgroup of four waves per ROI (and a wave per GLCM angle)");
+    // (round 6: EIGHT waves for the GLCM-only launch at 17..64 levels -- FAM 4, G16 -- whose 39.8 KB of matrices allow four workgroups per CU:
+    //  the load, zeroing and co-occurrence sweep run on twice the waves; the feature pass keeps a wave per angle, the other four wait)
+    static_assert((NW == 4 && NW == kMaxAngles) || (NW == 8 && G16 && FAM == 4), "one workgroup of four waves per ROI (and a wave per GLCM angle)");
     constexpr int BS = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* const lds = GS ? A.sp.scratch + (size_t)blockIdx.x * A.sp.stride : lds_raw;
@@ -822,7 +824,7 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
     constexpr bool FAST = FAM == 1 || FAM == 3;       // (3: GLCM alone under the same conditions -- BASELINE configs[2], and the GLCM columns of the 16-bit path)
     constexpr int kRowsTag = 16 + TIER * 4 + (C16 ? 2 : 0) + (D8 ? 1 : 0);
     const bool do_int = FAM == 1 || FAM == 2 || (FAM == 0 && (A.mask & NYXHIP_FAM_INTENSITY) != 0);
-    const bool do_glcm = FAM == 1 || FAM == 3 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);
+    const bool do_glcm = FAM == 1 || FAM == 3 || FAM == 4 || (FAM == 0 && (A.mask & NYXHIP_FAM_GLCM) != 0);   // (4: GLCM alone, any binning the generic code serves)
     double* const out_row = A.out + roi * A.ld;
 #ifdef NYX_STAMP
     unsigned long long t_prev__ = __builtin_readcyclecounter();
@@ -2606,6 +2608,13 @@ __global__ __launch_bounds__(kBlock, 4) void roi_features_kernel_g16(const RoiAr
     roi_features_body<false, true, false, true, 0, 9, true, WIN>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
 }
 
+// ... and its GLCM-only form on eight waves (512 threads) per ROI
+template <int WIN>
+__global__ __launch_bounds__(512, 8) void roi_features_kernel_g16w8(const RoiArgs A)
+{
+    roi_features_body<false, true, false, true, 4, 9, true, WIN, 8>(A, (WIN == 1 && A.win.xcd_swz) ? xcd_slot(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x);
+}
+
 // A launch that serves some classes only (SpillArgs::class_mask, whole-batch launches): is this ROI one of them?  (The feature kernels
 // derive the class from what they load anyway; the two kernels below would otherwise redo the other launch group's ROIs.)
 __device__ __forceinline__ bool glcm_roi_in_launch(const RoiArgs& A, uint64_t roi)
@@ -2857,7 +2866,8 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
         if (a.small_class && !no_small && roi_small_supported(a)) return launch_roi_small(a, st, grid, a.small_class == 2);
         static DeviceOnce optin;
         if (int orc = optin.run([]() -> int {
-                for (const void* f : {(const void*)roi_features_kernel_g16<0>, (const void*)roi_features_kernel_g16<1>}) {
+                for (const void* f : {(const void*)roi_features_kernel_g16<0>, (const void*)roi_features_kernel_g16<1>,
+                                      (const void*)roi_features_kernel_g16w8<0>, (const void*)roi_features_kernel_g16w8<1>}) {
                     if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)roi_features_max_lds()); e != hipSuccess)
                         return (int)e;
                     if (int src = no_static_lds(f))
@@ -2866,6 +2876,11 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
                 return 0;
             }))
             return orc;
+        static const bool w4 = [] { const char* e = getenv("NYXHIP_G16_W4"); return e && *e && *e != '0'; }();   // A/B knob: four waves per ROI
+        if (!(a.mask & NYXHIP_FAM_INTENSITY) && !w4) {
+            if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16w8<1>, dim3(a.win.xcd_swz ? (grid + 7u) & ~7u : grid), dim3(512), a.L.total, st, a);
+            else hipLaunchKernelGGL(roi_features_kernel_g16w8<0>, dim3(grid), dim3(512), a.L.total, st, a);
+        } else
         if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16<1>, dim3(a.win.xcd_swz ? (grid + 7u) & ~7u : grid), dim3(kBlock), a.L.total, st, a);
         else hipLaunchKernelGGL(roi_features_kernel_g16<0>, dim3(grid), dim3(kBlock), a.L.total, st, a);
         return (int)hipGetLastError();
