@@ -575,7 +575,12 @@ typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 #else
 #define G16_EXIT(k, keep) do { } while (0)
 #endif
-template <int NG>
+// ROLE (the eight-wave launch, roi_features_kernel_g16w8): 0 = an angle's whole pass on one wave.  1 / 2 = the pass on TWO waves: wave 2 forms
+// the row and column sums it needs itself and runs the HXY1 / HXY2 row groups -- half of the pass's instructions -- while wave 1 does
+// everything else; wave 2's per-lane sums cross over through the angle's block (T2 | f, sm: dead between the two workgroup barriers) and
+// wave 1 closes with them: the same per-lane values in the same reductions as ROLE 0, bit for bit.  Waves without an angle take the two
+// barriers and nothing else.
+template <int NG, int ROLE = 0>
 __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int Ng_rt, uint32_t* blk, double soft_nan, int lane)
 {
     const int Ng = NG ? NG : Ng_rt;                    // (NG = 64: the reference's default grey depth as a compile-time fact -- row offsets become immediates)
@@ -600,6 +605,44 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
         rc = act ? (uint32_t)a2.x + (uint32_t)a2.y : 0u;
     }
     G16_EXIT(1, rc);
+    if constexpr (ROLE == 2) {
+        // ---- the partner wave: column sums (a plain walk down the column), the two marginal probabilities, the row groups ------------
+        const int cj = lane < Ng ? lane : Ng;
+        lds_cu16_t* pc = (lds_cu16_t*)(uintptr_t)(Pd + cj);
+        uint32_t cc2 = 0;
+#pragma unroll 8
+        for (int i = 0; i < Ng; i++) cc2 += pc[i * pitch];
+        if (!act) cc2 = 0;
+        const uint32_t csum2 = wave_sum_t<uint32_t>(rc);
+        const double sum_p2 = csum2 == 0 ? 1.0 : (double)csum2;
+        const double pcol = fdiv((double)cc2, sum_p2), prow = fdiv((double)rc, sum_p2);
+        double hxy1c = 0, hxy2 = 0;
+        unsigned long long rem = __ballot(act && rc != 0u);
+        while (rem) {
+            const int r0 = (int)__builtin_ctzll(rem);
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)rc, r0);
+            const unsigned long long pbits = (unsigned long long)__double_as_longlong(prow);
+            const double pr = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), r0) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, r0)));
+            unsigned long long grp = __ballot(act && rc == v);
+            rem &= ~grp;
+            const double pp = pcol * pr;                                 // px[i]*py[j], i = column, j = row (:869, :909)
+            const double lg = (double)fast_log2f(pp + 0.000000001);
+            hxy2 = __builtin_fma(pp * (double)(uint32_t)__popcll(grp), lg, hxy2);
+            uint32_t gsum = 0;
+            while (grp) {
+                const int r = (int)__builtin_ctzll(grp);
+                grp &= grp - 1ull;
+                gsum += pc[r * pitch];
+            }
+            hxy1c = __builtin_fma((double)gsum, lg, hxy1c);
+        }
+        blk_sync<false>();                             // wave 1 is through with the block's table
+        T2[lane] = hxy1c;
+        f[lane] = hxy2;                                // (f | sm: 64 doubles)
+        blk_sync<false>();
+        return;
+    }
     // ---- column sums and the two families of diagonals in one pass over the rows (lane = column; see the header) --------------
     uint32_t cc = 0, dc = 0;
     uint32_t pxpy_c[2] = {0u, 0u};
@@ -684,7 +727,7 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
     G16_EXIT(4, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1] + ent) + asm_i + cmax);
     // ---- HXY1 / HXY2: lane = column, rows visited in groups of equal row marginal (see the header) ---------------------------
     double hxy1c = 0, hxy2 = 0;
-    {
+    if constexpr (ROLE == 0) {
         const int cj = lane < Ng ? lane : Ng;
         lds_cu16_t* pc = (lds_cu16_t*)(uintptr_t)(Pd + cj);
         unsigned long long rem = __ballot(act && rc != 0u);
@@ -718,6 +761,13 @@ __device__ __forceinline__ void glcm_features_wave64_v2(const uint16_t* P, int N
             const uint32_t cnt = pc[r * pitch];
             if (cnt >= 7u) { const double p = (double)cnt * inv_sum_p; ent += p * (double)fast_log2f(p + 0.000000001); }
         }
+    }
+    if constexpr (ROLE == 1) {
+        blk_sync<false>();                             // (the partner wave writes its per-lane sums between the two barriers)
+        blk_sync<false>();
+        hxy1c = T2[lane];
+        hxy2 = f[lane];
+        wav_sync<false>();                             // (the tail writes sm)
     }
     G16_EXIT(5, (uint32_t)(pcol + prow + pxmy + pxpy[0] + pxpy[1] + ent + hxy1c + hxy2) + asm_i + cmax);
     glcm_w64_tail<NG>(Ng, lane, rc, cc, dc, pxpy_c, csum, sum_p, inv_sum_p, pcol, prow, pxmy, pxpy, ent, hxy1c, hxy2, asm_i, cmax, f);
@@ -2250,6 +2300,19 @@ __device__ __forceinline__ void roi_features_body(const RoiArgs& A, const uint64
             }
             grp_sync<GS, NW>();
             STAMP(11);
+            if constexpr (NW == 8) {                     // two waves per angle: wave a and wave a + 4 (glcm_features_wave64_v2, ROLE)
+                const int ang = wave & 3;
+                if (ang < na) {
+                    const uint16_t* const Pa = (const uint16_t*)(s_P + (size_t)ang * cellsw);
+                    if (wave < 4) {
+                        if (Ng == 64) glcm_features_wave64_v2<64, 1>(Pa, 64, s_blk + ang * 256, B->soft_nan, lane);
+                        else glcm_features_wave64_v2<0, 1>(Pa, Ng, s_blk + ang * 256, B->soft_nan, lane);
+                    } else {
+                        if (Ng == 64) glcm_features_wave64_v2<64, 2>(Pa, 64, s_blk + ang * 256, B->soft_nan, lane);
+                        else glcm_features_wave64_v2<0, 2>(Pa, Ng, s_blk + ang * 256, B->soft_nan, lane);
+                    }
+                } else { grp_sync<GS, NW>(); grp_sync<GS, NW>(); }
+            } else
             if (wave < na) {                             // (NW = 4 = kMaxAngles: a wave per angle)
                 if (Ng == 64) glcm_features_wave64_v2<64>((const uint16_t*)(s_P + (size_t)wave * cellsw), 64, s_blk + wave * 256, B->soft_nan, lane);
                 else glcm_features_wave64_v2<0>((const uint16_t*)(s_P + (size_t)wave * cellsw), Ng, s_blk + wave * 256, B->soft_nan, lane);
