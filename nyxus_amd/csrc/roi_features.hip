@@ -2940,8 +2940,9 @@ int launch_roi_features(const RoiArgs& a, void* stream, uint32_t grid)
             }))
             return orc;
         static const bool w4 = [] { const char* e = getenv("NYXHIP_G16_W4"); return e && *e && *e != '0'; }();   // A/B knob: four waves per ROI
+        static const uint32_t g16_w8_min = [] { const char* e = getenv("NYXHIP_G16_W8_MIN"); return e && *e ? (uint32_t)atoi(e) : 48u * 48u; }();   // tuning knob: smallest class box for eight waves
         // (eight waves pay where the load and the sweep are long: 2821-px ROIs 23.0 -> 22.1 ns, 1009-px ROIs 18.5 -> 18.8: by the class's largest box)
-        if (!(a.mask & NYXHIP_FAM_INTENSITY) && !w4 && a.L.dense_cap >= 48u * 48u) {
+        if (!(a.mask & NYXHIP_FAM_INTENSITY) && !w4 && a.L.dense_cap >= g16_w8_min) {
             if (a.win.inten != nullptr) hipLaunchKernelGGL(roi_features_kernel_g16w8<1>, dim3(a.win.xcd_swz ? (grid + 7u) & ~7u : grid), dim3(512), a.L.total, st, a);
             else hipLaunchKernelGGL(roi_features_kernel_g16w8<0>, dim3(grid), dim3(512), a.L.total, st, a);
         } else
