@@ -811,7 +811,7 @@ class Bench:
                             "rois": int(nroi.value), "ms_per_call": 1e3 * dt, "parity_check": par_t, "max_rel_err": getattr(tile_gate, "margin", None),
                             "algorithmic_GBps": tile_bytes / dt / 1e9, "hbm_frac": tile_bytes / dt / 1e9 / HBM_PEAK_GBS,
                             "traffic_bytes_per_tile": tp_traffic, "traffic_ratio": (tp_traffic / (tile_bytes / nt)) if tp_traffic else None,
-                            "traffic_source": "replayed from profiles/hbm_traffic.json (profiles/r06e_tilepath_traffic.txt)" if tp_traffic else None,
+                            "traffic_source": "replayed from profiles/hbm_traffic.json (profiles/r06f_tilepath_traffic.txt)" if tp_traffic else None,
                             "what": "nyxhip_featurize_tiles on uint32 intensity+label tiles resident in HBM: device label scan, "
                                     "compaction, label ranking, then the reduce kernels reading each ROI's bounding-box window of its tile "
                                     "(no materialised clouds; one host sync inside for the ROI count)"}
