@@ -851,3 +851,14 @@ def test_contour_wide_boxes_take_the_position_wise_pass(hip_ctx):
     small = synth.random_rois(6, seed=23)
     mask = _abi.FAM_SMOMS | _abi.FAM_IMOMS
     _check(hip_ctx, _abi.batch_from_rois([roi] + small), mask, _abi.default_settings(8), against_ref=False)
+
+
+@pytest.mark.gpu
+def test_eight_wave_64_level_launch_gives_the_bits_of_the_four_wave_one():
+    """Grey depths 17..64: classes whose largest box has >= 48 x 48 cells run the GLCM launch on eight waves per ROI with the feature pass on
+    two waves per angle (roi_features_kernel_g16w8); which launch a ROI meets depends on its companions' boxes, so both must give the same
+    bits.  Two child processes (the A/B knob NYXHIP_G16_W4 is read once per process) over mixed batches, three depths, both symmetries."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "g16_w8_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
