@@ -786,7 +786,7 @@ class Bench:
             if any(wrong.values()):
                 return f"all {n_} rows vs exact device reductions: MISMATCHES " + json.dumps({c: k for c, k in wrong.items() if k})
             return f"ok (rows of the last tile vs oracle; all {n_} rows, MIN/MAX/RANGE/MEAN/INTEGRATED_INTENSITY vs exact device reductions of the tiles)"
-        reps = 3
+        reps = 6
 
         def time_stack(label_stack):
             tile_step(label_stack)
